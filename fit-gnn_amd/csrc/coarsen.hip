@@ -1,0 +1,419 @@
+// coarsen.hip -- one contraction level of FIT-GNN's variation_neighborhoods coarsening on gfx950.
+//
+// Replaces (graph_coarsening/coarsening_utils.py): the candidate family :571-578, subgraph_cost :555-561,
+// the SortedList-driven greedy selection :604-650, get_coarsening_matrix :212-254 and the level mapping
+// :168-179; plus C <- iC.C (:136).  f64 arithmetic is the canonical order of DESIGN.md; the file is
+// compiled with -ffp-contract=off.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <algorithm>
+#include <cstring>
+
+#include <rocprim/rocprim.hpp>
+
+#include "common.h"
+#include "fitgnn_hip.h"
+#include "scan.h"
+#include "variation_cost.h"
+
+namespace {
+
+using fitgnn::CostGraph;
+using fitgnn::CostLds;
+
+constexpr size_t kAlign = 256;
+inline size_t align_up(size_t x) { return (x + kAlign - 1) / kAlign * kAlign; }
+
+// ------------------------------------------------------------------------------------------------
+// candidate family: set i = sorted(N(i) U {i})
+// ------------------------------------------------------------------------------------------------
+__global__ void family_count_kernel(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col, int32_t N,
+                                    int32_t *__restrict__ cnt) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const int e0 = rowptr[i], e1 = rowptr[i + 1];
+    const int p = fitgnn::lower_bound_i32(col + e0, e1 - e0, i);
+    const bool has_self = (e0 + p < e1) && col[e0 + p] == i;
+    cnt[i] = (e1 - e0) + (has_self ? 0 : 1);
+}
+
+__global__ void family_fill_kernel(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col, int32_t N,
+                                   const int32_t *__restrict__ set_off, int32_t *__restrict__ set_mem) {
+    // one wave per node: coalesced copy of the row with i merged at its sorted position
+    const int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (i >= N) return;
+    const int e0 = rowptr[i], e1 = rowptr[i + 1], deg = e1 - e0;
+    const int p = fitgnn::lower_bound_i32(col + e0, deg, i);
+    const bool has_self = (p < deg) && col[e0 + p] == i;
+    int32_t *dst = set_mem + set_off[i];
+    if (has_self) {
+        for (int t = lane; t < deg; t += 64) dst[t] = col[e0 + t];
+    } else {
+        for (int t = lane; t < deg; t += 64) dst[t + (t >= p ? 1 : 0)] = col[e0 + t];
+        if (lane == 0) dst[p] = i;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// costs of many sets: one wave per set, waves stride over the sets
+// ------------------------------------------------------------------------------------------------
+constexpr int kCostWaves = 4;
+
+__global__ __launch_bounds__(kCostWaves * 64) void variation_costs_kernel(CostGraph g, const int32_t *__restrict__ set_off,
+                                                                         const int32_t *__restrict__ set_len,
+                                                                         const int32_t *__restrict__ set_mem,
+                                                                         int32_t n_sets, double *__restrict__ cost) {
+    __shared__ CostLds lds[kCostWaves];
+    const int wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int n_waves = gridDim.x * kCostWaves;
+    for (int s = blockIdx.x * kCostWaves + wave; s < n_sets; s += n_waves) {
+        const int off = __builtin_amdgcn_readfirstlane(set_off[s]);
+        const int nc = __builtin_amdgcn_readfirstlane(set_len[s]);
+        const double c = fitgnn::set_cost_wave(g, set_mem + off, nc, lds[wave]);
+        if (lane == 0) cost[s] = c;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// greedy selection: a single wavefront walks the candidates in (cost, insertion) order
+// ------------------------------------------------------------------------------------------------
+struct HeapItem {
+    double cost;
+    int64_t seq;
+    int32_t cand;
+    int32_t pad;
+};
+__device__ __forceinline__ bool item_less(const HeapItem &a, const HeapItem &b) {
+    if (a.cost < b.cost) return true;
+    if (b.cost < a.cost) return false;
+    return a.seq < b.seq;
+}
+
+constexpr int kHeapLds = 2048;  // top of the re-insertion heap lives in LDS (48 KiB), the rest in global
+
+struct Heap {
+    HeapItem *lds;
+    HeapItem *glob;
+    __device__ __forceinline__ HeapItem get(int i) const { return i < kHeapLds ? lds[i] : glob[i]; }
+    __device__ __forceinline__ void put(int i, const HeapItem &v) { if (i < kHeapLds) lds[i] = v; else glob[i] = v; }
+};
+
+__device__ inline void heap_push(Heap &h, int &n, HeapItem it) {
+    int i = n++;
+    while (i > 0) {
+        const int p = (i - 1) >> 1;
+        const HeapItem pv = h.get(p);
+        if (!item_less(it, pv)) break;
+        h.put(i, pv);
+        i = p;
+    }
+    h.put(i, it);
+}
+__device__ inline HeapItem heap_pop(Heap &h, int &n) {
+    const HeapItem top = h.get(0);
+    const HeapItem last = h.get(--n);
+    int i = 0;
+    for (;;) {
+        const int l = 2 * i + 1, r = l + 1;
+        if (l >= n) break;
+        HeapItem cv = h.get(l);
+        int c = l;
+        if (r < n) {
+            const HeapItem rv = h.get(r);
+            if (item_less(rv, cv)) { cv = rv; c = r; }
+        }
+        if (!item_less(cv, last)) break;
+        h.put(i, cv);
+        i = c;
+    }
+    if (n > 0) h.put(i, last);
+    return top;
+}
+
+__global__ __launch_bounds__(64) void greedy_select_kernel(CostGraph g, int32_t N, const int32_t *__restrict__ set_off,
+                                                           int32_t *__restrict__ mem, int32_t *__restrict__ len,
+                                                           uint8_t *__restrict__ marked,
+                                                           const int32_t *__restrict__ order,
+                                                           const double *__restrict__ cost0, HeapItem *__restrict__ heap_glob,
+                                                           int64_t n_reduce, int64_t max_iters,
+                                                           int32_t *__restrict__ sel_off, int32_t *__restrict__ sel_mem,
+                                                           int32_t *__restrict__ sel_count) {
+    __shared__ CostLds lds;
+    __shared__ HeapItem heap_lds[kHeapLds];
+    Heap heap{heap_lds, heap_glob};
+    const int lane = threadIdx.x & 63;
+    int hn = 0;          // heap size (uniform)
+    int head = 0;        // next unread entry of the sorted initial family (uniform)
+    int64_t seq = N;     // insertion counter of re-inserted sets (initial family: seq = node id)
+    int32_t ns = 0, pos = 0;
+    if (lane == 0) sel_off[0] = 0;
+    // every iteration consumes one queue entry; re-insertions strictly shrink a set, so the number of
+    // iterations is bounded by N + sum of set sizes: max_iters is that bound (an exit every lane reaches).
+    for (int64_t it = 0; it < max_iters; ++it) {
+        if (n_reduce <= 0) break;
+        if (head >= N && hn == 0) break;
+        // ---- pop the minimum of {sorted initial list head, heap top}: SortedList.pop(0) ----
+        int32_t cand;
+        bool from_list = hn == 0;
+        if (head < N && hn > 0) {
+            const int32_t c0 = order[head];
+            HeapItem li{cost0[c0], (int64_t)c0, c0, 0};
+            const HeapItem top = heap.get(0);
+            from_list = item_less(li, top);
+        }
+        if (from_list) {
+            cand = order[head++];
+        } else {
+            HeapItem top;
+            if (lane == 0) top = heap_pop(heap, hn); else --hn;
+            FITGNN_WAVE_SYNC();
+            cand = __shfl(top.cand, 0, 64);
+        }
+        cand = __builtin_amdgcn_readfirstlane(cand);
+        const int off = __builtin_amdgcn_readfirstlane(set_off[cand]);
+        const int nc = __builtin_amdgcn_readfirstlane(len[cand]);
+        int32_t *S = mem + off;
+        // ---- any member marked? (coarsening_utils.py:620-622) ----
+        bool any = false;
+        for (int t0 = 0; t0 < nc; t0 += 64) {
+            const int t = t0 + lane;
+            const bool mk = (t < nc) && marked[S[t]] != 0;
+            any |= __ballot(mk) != 0ull;
+        }
+        if (!any) {
+            const int64_t gain = nc - 1;
+            if (gain > n_reduce) continue;  // :625-626, would over-reduce: drop the set
+            for (int t = lane; t < nc; t += 64) {
+                const int32_t v = S[t];
+                marked[v] = 1;
+                sel_mem[pos + t] = v;
+            }
+            pos += nc;
+            ++ns;
+            if (lane == 0) sel_off[ns] = pos;
+            n_reduce -= gain;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // marked[] writes before later reads
+        } else {
+            // ---- drop marked members in place, keep order (:640) ----
+            int m = 0;
+            for (int t0 = 0; t0 < nc; t0 += 64) {
+                const int t = t0 + lane;
+                int32_t v = 0;
+                bool keep = false;
+                if (t < nc) { v = S[t]; keep = marked[v] == 0; }
+                const unsigned long long bal = __ballot(keep);
+                const int before = __popcll(bal & ((1ull << lane) - 1ull));
+                FITGNN_WAVE_SYNC();  // all reads of this chunk done before the compacted writes (m <= t0)
+                if (keep) S[m + before] = v;
+                m += __popcll(bal);
+            }
+            if (m > 1) {
+                if (lane == 0) len[cand] = m;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                const double c = fitgnn::set_cost_wave(g, S, m, lds);  // :646 re-cost
+                if (lane == 0) heap_push(heap, hn, HeapItem{c, seq, cand, 0}); else ++hn;
+                ++seq;
+                FITGNN_WAVE_SYNC();
+            }
+        }
+    }
+    if (lane == 0) { sel_count[0] = ns; sel_count[1] = pos; }
+}
+
+__global__ void cost_keys_kernel(const double *__restrict__ cost0, int32_t N, uint64_t *__restrict__ keys,
+                                 int32_t *__restrict__ ids) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    // costs are >= +0 or +inf (NaN sorts last): their bit patterns order like the values
+    uint64_t b = (uint64_t)__double_as_longlong(cost0[i]);
+    if (b >> 63) b = 0;  // -0.0 / negative noise cannot occur (sqrt >= 0); clamp defensively
+    keys[i] = b;
+    ids[i] = i;
+}
+
+__global__ void len_init_kernel(const int32_t *__restrict__ set_off, int32_t N, int32_t *__restrict__ len) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N) len[i] = set_off[i + 1] - set_off[i];
+}
+
+struct GreedyLayout {
+    size_t mem, len, marked, keys_in, keys_out, ids_in, order, heap, sort_tmp, sort_tmp_bytes, total;
+};
+GreedyLayout greedy_layout(int32_t N, int64_t total_members) {
+    GreedyLayout L{};
+    size_t o = 0;
+    const size_t n = (size_t)(N > 0 ? N : 1), tm = (size_t)(total_members > 0 ? total_members : 1);
+    L.mem = o; o += align_up(tm * 4);
+    L.len = o; o += align_up(n * 4);
+    L.marked = o; o += align_up(n);
+    L.keys_in = o; o += align_up(n * 8);
+    L.keys_out = o; o += align_up(n * 8);
+    L.ids_in = o; o += align_up(n * 4);
+    L.order = o; o += align_up(n * 4);
+    L.heap = o; o += align_up(n * sizeof(HeapItem));
+    size_t tmp = 0;
+    (void)rocprim::radix_sort_pairs(nullptr, tmp, (uint64_t *)nullptr, (uint64_t *)nullptr, (int32_t *)nullptr,
+                                    (int32_t *)nullptr, n, 0, 64, (hipStream_t)0);
+    L.sort_tmp_bytes = tmp;
+    L.sort_tmp = o; o += align_up(tmp);
+    L.total = o;
+    return L;
+}
+
+// ------------------------------------------------------------------------------------------------
+// assignment vectors from the selected sets
+// ------------------------------------------------------------------------------------------------
+__global__ void assign_init_kernel(int32_t N, int32_t *__restrict__ root, double *__restrict__ cval) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N) { root[i] = i; cval[i] = 1.0; }
+}
+__global__ void assign_sets_kernel(const int32_t *__restrict__ sel_off, const int32_t *__restrict__ sel_mem,
+                                   const int32_t *__restrict__ sel_count, int32_t *__restrict__ root,
+                                   double *__restrict__ cval) {
+#pragma clang fp contract(off)
+    // one wave per selected set
+    const int s = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (s >= sel_count[0]) return;
+    const int o = sel_off[s], nc = sel_off[s + 1] - o;
+    const int32_t r = sel_mem[o];  // sets are sorted: the minimum member keeps the row (:239)
+    const double v = 1.0 / sqrt((double)nc);
+    for (int t = lane; t < nc; t += 64) { root[sel_mem[o + t]] = r; cval[sel_mem[o + t]] = v; }
+}
+__global__ void survivor_flag_kernel(int32_t N, const int32_t *__restrict__ root, int32_t *__restrict__ flag) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N) flag[i] = root[i] == i ? 1 : 0;
+}
+__global__ void assign_final_kernel(int32_t N, const int32_t *__restrict__ root, const int32_t *__restrict__ rank,
+                                    int32_t *__restrict__ assign, int32_t *__restrict__ n_out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    assign[i] = rank[root[i]];
+    if (i == N - 1) n_out[0] = rank[i] + (root[i] == i ? 1 : 0);
+}
+
+__global__ void compose_levels_kernel(int32_t N0, const int32_t *__restrict__ assign_l, const double *__restrict__ cval_l,
+                                      int32_t *__restrict__ assign_tot, double *__restrict__ cval_tot) {
+#pragma clang fp contract(off)
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= N0) return;
+    const int32_t prev = assign_tot[j];
+    cval_tot[j] = cval_l[prev] * cval_tot[j];
+    assign_tot[j] = assign_l[prev];
+}
+
+inline dim3 blocks_for(int64_t threads, int block = 256) { return dim3((unsigned)((threads + block - 1) / block)); }
+
+}  // namespace
+
+extern "C" int fitgnn_closed_neighbourhoods(const int32_t *rowptr, const int32_t *col, int32_t N, int32_t *set_off,
+                                            int32_t *set_mem, void *stream) {
+    if (N < 0 || !set_off) return FITGNN_E_BADARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (N == 0) return (int)hipMemsetAsync(set_off, 0, sizeof(int32_t), s);
+    if (!rowptr || !col || !set_mem) return FITGNN_E_BADARG;
+    hipLaunchKernelGGL(family_count_kernel, blocks_for(N), dim3(256), 0, s, rowptr, col, N, set_off);
+    fitgnn::exclusive_scan_i32(set_off, set_off, N, s);  // counts -> offsets, in place
+    hipLaunchKernelGGL(family_fill_kernel, blocks_for((int64_t)N * 64), dim3(256), 0, s, rowptr, col, N, set_off, set_mem);
+    return (int)hipGetLastError();
+}
+
+extern "C" int fitgnn_variation_costs_f64(const int32_t *rowptr, const int32_t *col, const double *w, const double *dw,
+                                          const double *A, int32_t K, int64_t lda, const int32_t *set_off,
+                                          const int32_t *set_len, const int32_t *set_mem, int32_t n_sets, double *cost,
+                                          void *stream) {
+    if (n_sets < 0 || K < 1 || K > FITGNN_MAX_K || lda < K) return FITGNN_E_BADARG;
+    if (n_sets == 0) return 0;
+    if (!rowptr || !col || !dw || !A || !set_off || !set_len || !set_mem || !cost) return FITGNN_E_BADARG;
+    CostGraph g{rowptr, col, w, dw, A, K, lda};
+    const int blocks = (int)std::min<int64_t>(((int64_t)n_sets + kCostWaves - 1) / kCostWaves, 256 * 8);
+    hipLaunchKernelGGL(variation_costs_kernel, dim3(blocks), dim3(kCostWaves * 64), 0, (hipStream_t)stream, g, set_off,
+                       set_len, set_mem, n_sets, cost);
+    return (int)hipGetLastError();
+}
+
+extern "C" size_t fitgnn_greedy_select_workspace_bytes(int32_t N, int64_t total_members) {
+    if (N < 0 || total_members < 0) return 0;
+    return greedy_layout(N, total_members).total;
+}
+
+extern "C" int fitgnn_greedy_select(const int32_t *rowptr, const int32_t *col, const double *w, const double *dw,
+                                    const double *A, int32_t K, int64_t lda, int32_t N, const int32_t *set_off,
+                                    const int32_t *set_mem, const double *cost0, int64_t n_reduce, int32_t *sel_off,
+                                    int32_t *sel_mem, int32_t *sel_count, void *work, size_t work_bytes, void *stream) {
+    if (N < 0 || K < 1 || K > FITGNN_MAX_K || lda < K) return FITGNN_E_BADARG;
+    if (!sel_off || !sel_count) return FITGNN_E_BADARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (N == 0) {
+        FITGNN_RETURN_IF_HIP(hipMemsetAsync(sel_off, 0, sizeof(int32_t), s));
+        return (int)hipMemsetAsync(sel_count, 0, 2 * sizeof(int32_t), s);
+    }
+    if (!rowptr || !col || !dw || !A || !set_off || !set_mem || !cost0 || !sel_mem || !work) return FITGNN_E_BADARG;
+    // total members = set_off[N] lives on the device; the caller sized the workspace with it.  Recover the
+    // capacity the workspace was sized for from work_bytes by requiring the caller's figure to be consistent:
+    // we only need an upper bound, and set_off[N] <= nnz + N, so read it back once (4 bytes, needed for the
+    // copy and the iteration bound).
+    int32_t total = 0;
+    FITGNN_RETURN_IF_HIP(hipMemcpyAsync(&total, set_off + N, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    FITGNN_RETURN_IF_HIP(hipStreamSynchronize(s));
+    const GreedyLayout L = greedy_layout(N, total);
+    if (work_bytes < L.total) return FITGNN_E_WORKSPACE;
+    char *base = (char *)work;
+    int32_t *mem = (int32_t *)(base + L.mem);
+    int32_t *len = (int32_t *)(base + L.len);
+    uint8_t *marked = (uint8_t *)(base + L.marked);
+    uint64_t *keys_in = (uint64_t *)(base + L.keys_in), *keys_out = (uint64_t *)(base + L.keys_out);
+    int32_t *ids_in = (int32_t *)(base + L.ids_in), *order = (int32_t *)(base + L.order);
+    HeapItem *heap = (HeapItem *)(base + L.heap);
+    FITGNN_RETURN_IF_HIP(hipMemcpyAsync(mem, set_mem, (size_t)total * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+    FITGNN_RETURN_IF_HIP(hipMemsetAsync(marked, 0, (size_t)N, s));
+    hipLaunchKernelGGL(len_init_kernel, blocks_for(N), dim3(256), 0, s, set_off, N, len);
+    hipLaunchKernelGGL(cost_keys_kernel, blocks_for(N), dim3(256), 0, s, cost0, N, keys_in, ids_in);
+    // stable LSD radix sort on the cost bits: ties keep ascending node id == SortedList's stable build
+    size_t tmp = L.sort_tmp_bytes;
+    FITGNN_RETURN_IF_HIP(rocprim::radix_sort_pairs((void *)(base + L.sort_tmp), tmp, keys_in, keys_out, ids_in, order,
+                                                   (size_t)N, 0, 64, s));
+    CostGraph g{rowptr, col, w, dw, A, K, lda};
+    const int64_t max_iters = (int64_t)N + (int64_t)total + 8;
+    hipLaunchKernelGGL(greedy_select_kernel, dim3(1), dim3(64), 0, s, g, N, set_off, mem, len, marked, order, cost0, heap,
+                       n_reduce, max_iters, sel_off, sel_mem, sel_count);
+    return (int)hipGetLastError();
+}
+
+extern "C" size_t fitgnn_build_assignment_workspace_bytes(int32_t N) {
+    if (N <= 0) return kAlign;
+    return 2 * align_up(((size_t)N + 1) * sizeof(int32_t));
+}
+
+extern "C" int fitgnn_build_assignment(int32_t N, const int32_t *sel_off, const int32_t *sel_mem,
+                                       const int32_t *sel_count, int32_t *assign, double *cval, int32_t *n_out, void *work,
+                                       size_t work_bytes, void *stream) {
+    if (N < 0 || !n_out) return FITGNN_E_BADARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (N == 0) return (int)hipMemsetAsync(n_out, 0, sizeof(int32_t), s);
+    if (!sel_off || !sel_mem || !sel_count || !assign || !cval || !work) return FITGNN_E_BADARG;
+    if (work_bytes < fitgnn_build_assignment_workspace_bytes(N)) return FITGNN_E_WORKSPACE;
+    int32_t *root = (int32_t *)work;
+    int32_t *rank = (int32_t *)((char *)work + align_up(((size_t)N + 1) * sizeof(int32_t)));
+    hipLaunchKernelGGL(assign_init_kernel, blocks_for(N), dim3(256), 0, s, N, root, cval);
+    // at most N/2 sets of >= 2 members (plus singletons never listed): launch for the worst case, waves past
+    // sel_count[0] exit at once
+    hipLaunchKernelGGL(assign_sets_kernel, blocks_for((int64_t)N * 64), dim3(256), 0, s, sel_off, sel_mem, sel_count, root, cval);
+    hipLaunchKernelGGL(survivor_flag_kernel, blocks_for(N), dim3(256), 0, s, N, root, rank);
+    fitgnn::exclusive_scan_i32(rank, rank, N, s);
+    hipLaunchKernelGGL(assign_final_kernel, blocks_for(N), dim3(256), 0, s, N, root, rank, assign, n_out);
+    return (int)hipGetLastError();
+}
+
+extern "C" int fitgnn_compose_levels(int32_t N0, const int32_t *assign_l, const double *cval_l, int32_t *assign_tot,
+                                     double *cval_tot, void *stream) {
+    if (N0 < 0) return FITGNN_E_BADARG;
+    if (N0 == 0) return 0;
+    if (!assign_l || !cval_l || !assign_tot || !cval_tot) return FITGNN_E_BADARG;
+    hipLaunchKernelGGL(compose_levels_kernel, blocks_for(N0), dim3(256), 0, (hipStream_t)stream, N0, assign_l, cval_l,
+                       assign_tot, cval_tot);
+    return (int)hipGetLastError();
+}

@@ -1,0 +1,165 @@
+// gcn_ops.hip -- symmetric GCN normalisation and the backward of the fused bias/ELU/dropout epilogue.
+//
+// Replaces torch_geometric.nn.conv.gcn_conv.gcn_norm (called by GCNConv.forward from FIT-GNN
+// network.py:31) and the autograd backward of network.py:32-33 (F.elu, F.dropout) + GCNConv's bias.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "common.h"
+#include "fitgnn_hip.h"
+
+namespace {
+
+// deg[i] = sum of incoming edge weights (self loop included by the caller); dinv = deg^-1/2, inf -> 0
+__global__ void gcn_deg_kernel(const int32_t *__restrict__ rowptr, const float *__restrict__ w, float *__restrict__ dinv,
+                               int32_t n_rows) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_rows) return;
+    const int e0 = rowptr[i], e1 = rowptr[i + 1];
+    float d = 0.f;
+    if (w) {
+        for (int e = e0; e < e1; ++e) d += w[e];
+    } else {
+        d = (float)(e1 - e0);
+    }
+    dinv[i] = d > 0.f ? 1.0f / sqrtf(d) : 0.f;
+}
+
+__global__ void gcn_val_kernel(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                               const float *__restrict__ w, const float *__restrict__ dinv, float *__restrict__ val,
+                               int32_t n_rows) {
+    // one wave per row: coalesced over the row's non-zeros
+    const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (row >= n_rows) return;
+    const int e0 = rowptr[row], e1 = rowptr[row + 1];
+    const float di = dinv[row];
+    for (int e = e0 + lane; e < e1; e += 64) {
+        const float we = w ? w[e] : 1.0f;
+        val[e] = di * we * dinv[col[e]];
+    }
+}
+
+constexpr int kChunkRows = 64;
+
+// dZ = dOut * dropout' * elu'  and per-(row chunk) column partial sums for the bias gradient.
+template <int VEC>
+__global__ __launch_bounds__(256) void epilogue_bwd_kernel(const float *__restrict__ dOut, const float *__restrict__ out,
+                                                           float *__restrict__ dZ, int32_t n_rows, int32_t H,
+                                                           uint32_t epi, float p_drop, uint64_t seed,
+                                                           const uint8_t *__restrict__ mask, float *__restrict__ partial) {
+    constexpr int SLAB = 64 * VEC;
+    __shared__ float red[4][SLAB];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int col0 = blockIdx.y * SLAB + lane * VEC;
+    const bool live = col0 + VEC <= H;
+    const int r0 = blockIdx.x * kChunkRows;
+    const int r1 = min(r0 + kChunkRows, n_rows);
+    const float scale = (epi & FITGNN_EPI_DROPOUT) ? 1.0f / (1.0f - p_drop) : 1.0f;
+    const float unscale = (epi & FITGNN_EPI_DROPOUT) ? (1.0f - p_drop) : 1.0f;
+    float sum[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) sum[i] = 0.f;
+    if (live) {
+        for (int row = r0 + wave; row < r1; row += 4) {
+            const int64_t base = (int64_t)row * H + col0;
+            float g[VEC], o[VEC];
+            if (VEC == 4) {
+                const float4 gv = *reinterpret_cast<const float4 *>(dOut + base);
+                const float4 ov = *reinterpret_cast<const float4 *>(out + base);
+                g[0] = gv.x; g[1 % VEC] = gv.y; g[2 % VEC] = gv.z; g[3 % VEC] = gv.w;
+                o[0] = ov.x; o[1 % VEC] = ov.y; o[2 % VEC] = ov.z; o[3 % VEC] = ov.w;
+            } else {
+                g[0] = dOut[base];
+                o[0] = out[base];
+            }
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                float d = g[i];
+                if (epi & FITGNN_EPI_DROPOUT) {
+                    const uint64_t idx = (uint64_t)base + i;
+                    const bool keep = mask ? (mask[idx] != 0) : fitgnn::dropout_keep(seed, idx, p_drop);
+                    d = keep ? d * scale : 0.f;
+                }
+                if (epi & FITGNN_EPI_ELU) {
+                    const float e = o[i] * unscale;  // pre-dropout ELU output; exp(z) = e + 1 for z <= 0
+                    d = e > 0.f ? d : d * (e + 1.0f);
+                }
+                g[i] = d;
+                sum[i] += d;
+            }
+            if (VEC == 4) {
+                *reinterpret_cast<float4 *>(dZ + base) = make_float4(g[0], g[1 % VEC], g[2 % VEC], g[3 % VEC]);
+            } else {
+                dZ[base] = g[0];
+            }
+        }
+    }
+    if (!partial) return;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) red[wave][lane * VEC + i] = sum[i];
+    __syncthreads();
+    if (wave == 0 && live) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            const int c = lane * VEC + i;
+            partial[(int64_t)blockIdx.x * H + col0 + i] = ((red[0][c] + red[1][c]) + red[2][c]) + red[3][c];
+        }
+    }
+}
+
+__global__ void colsum_partials_kernel(const float *__restrict__ partial, int32_t n_chunks, int32_t H,
+                                       float *__restrict__ db) {
+    const int h = blockIdx.x * blockDim.x + threadIdx.x;
+    if (h >= H) return;
+    float s = 0.f;
+    for (int c = 0; c < n_chunks; ++c) s += partial[(int64_t)c * H + h];  // fixed order: reproducible
+    db[h] = s;
+}
+
+}  // namespace
+
+extern "C" int fitgnn_gcn_norm_csr_f32(const int32_t *rowptr, const int32_t *col, const float *w, float *val,
+                                       float *dinv, int32_t n_rows, void *stream) {
+    if (n_rows < 0) return FITGNN_E_BADARG;
+    if (n_rows == 0) return 0;
+    if (!rowptr || !col || !val || !dinv) return FITGNN_E_BADARG;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(gcn_deg_kernel, dim3((n_rows + 255) / 256), dim3(256), 0, s, rowptr, w, dinv, n_rows);
+    const int64_t threads = (int64_t)n_rows * 64;
+    hipLaunchKernelGGL(gcn_val_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, rowptr, col, w, dinv,
+                       val, n_rows);
+    return (int)hipGetLastError();
+}
+
+extern "C" size_t fitgnn_epilogue_bwd_workspace_bytes(int32_t n_rows, int32_t H) {
+    if (n_rows <= 0 || H <= 0) return 0;
+    const size_t chunks = ((size_t)n_rows + kChunkRows - 1) / kChunkRows;
+    return chunks * (size_t)H * sizeof(float);
+}
+
+extern "C" int fitgnn_epilogue_bwd_f32(const float *dOut, const float *out, float *dZ, int32_t n_rows, int32_t H,
+                                       uint32_t epilogue, float p_drop, uint64_t seed, const uint8_t *mask, float *db,
+                                       void *work, size_t work_bytes, void *stream) {
+    if (n_rows < 0 || H < 0) return FITGNN_E_BADARG;
+    if (n_rows == 0 || H == 0) return 0;
+    if (!dOut || !out || !dZ) return FITGNN_E_BADARG;
+    if ((epilogue & FITGNN_EPI_DROPOUT) && !(p_drop >= 0.f && p_drop < 1.f)) return FITGNN_E_BADARG;
+    if (db && (!work || work_bytes < fitgnn_epilogue_bwd_workspace_bytes(n_rows, H))) return FITGNN_E_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    const int chunks = (n_rows + kChunkRows - 1) / kChunkRows;
+    float *partial = db ? (float *)work : nullptr;
+    const bool vec = (H % 4 == 0) && ((((uintptr_t)dOut | (uintptr_t)out | (uintptr_t)dZ) % 16) == 0);
+    if (vec) {
+        dim3 grid(chunks, (H + 255) / 256);
+        hipLaunchKernelGGL(epilogue_bwd_kernel<4>, grid, dim3(256), 0, s, dOut, out, dZ, n_rows, H, epilogue, p_drop, seed,
+                           mask, partial);
+    } else {
+        dim3 grid(chunks, (H + 63) / 64);
+        hipLaunchKernelGGL(epilogue_bwd_kernel<1>, grid, dim3(256), 0, s, dOut, out, dZ, n_rows, H, epilogue, p_drop, seed,
+                           mask, partial);
+    }
+    if (db) hipLaunchKernelGGL(colsum_partials_kernel, dim3((H + 255) / 256), dim3(256), 0, s, partial, chunks, H, db);
+    return (int)hipGetLastError();
+}

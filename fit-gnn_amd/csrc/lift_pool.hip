@@ -1,0 +1,353 @@
+// lift_pool.hip -- adjacency lift Wc = Pinv^T W Pinv and feature pooling Xc = C X on gfx950.
+//
+// Replaces (FIT-GNN): coarsen_matrix graph_coarsening/coarsening_utils.py:201-205, zero_diag
+// graph_coarsening/graph_utils.py:82-90, the symmetrisation coarsening_utils.py:139, and C.dot(X) at
+// utils.py:161,393,738,827.  Summation orders are SciPy's, so results are bit-identical to the
+// reference; compiled with -ffp-contract=off.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <algorithm>
+#include <cstring>
+
+#include <rocprim/rocprim.hpp>
+
+#include "common.h"
+#include "fitgnn_hip.h"
+
+namespace {
+
+constexpr size_t kAlign = 256;
+inline size_t align_up(size_t x) { return (x + kAlign - 1) / kAlign * kAlign; }
+inline dim3 blocks_for(int64_t threads, int block = 256) { return dim3((unsigned)((threads + block - 1) / block)); }
+constexpr uint64_t kInvalid = ~0ull;
+
+__device__ __forceinline__ int row_of_edge(const int32_t *rowptr, int N, int e) {
+    // largest u with rowptr[u] <= e
+    int lo = 0, hi = N;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (rowptr[mid] <= e) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
+// stage 1 input: one entry per directed edge (u,v): key = u*n + assign[v], value = w_uv * p_v
+__global__ void lift_stage1_kernel(int32_t N, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                   const double *__restrict__ w, const int32_t *__restrict__ assign,
+                                   const double *__restrict__ cval, int32_t n, int32_t nnz, uint64_t *__restrict__ key,
+                                   double *__restrict__ val) {
+#pragma clang fp contract(off)
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= nnz) return;
+    const int u = row_of_edge(rowptr, N, e);
+    const int v = col[e];
+    const int b = assign[v];
+    if (assign[u] == b) { key[e] = kInvalid; val[e] = 0.0; return; }  // feeds only the diagonal (zero_diag)
+    const double pv = cval[v] * (1.0 / cval[v]);
+    key[e] = (uint64_t)u * (uint64_t)n + (uint64_t)b;
+    val[e] = (w ? w[e] : 1.0) * pv;
+}
+
+__global__ void run_head_kernel(const uint64_t *__restrict__ key, int32_t m, int32_t *__restrict__ flag) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    const uint64_t k = key[i];
+    flag[i] = (k != kInvalid && (i == 0 || key[i - 1] != k)) ? 1 : 0;
+}
+
+// one thread per run head: sequential sum of the run (ascending original order: the sort is stable).
+// MODE 1: emit stage-2 entries  key2 = assign[u]*n + b, value = y * p_u
+// MODE 2: emit the unique (a,b) keys and their sums
+template <int MODE>
+__global__ void run_sum_kernel(const uint64_t *__restrict__ key, const double *__restrict__ val, int32_t m,
+                               const int32_t *__restrict__ run_idx, const int32_t *__restrict__ assign,
+                               const double *__restrict__ cval, int32_t n, uint64_t *__restrict__ okey,
+                               double *__restrict__ oval) {
+#pragma clang fp contract(off)
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    const uint64_t k = key[i];
+    const bool head = k != kInvalid && (i == 0 || key[i - 1] != k);
+    if (!head) return;
+    double s = val[i];
+    for (int j = i + 1; j < m && key[j] == k; ++j) s = s + val[j];
+    const int r = run_idx[i];
+    if (MODE == 1) {
+        const int u = (int)(k / (uint64_t)n), b = (int)(k % (uint64_t)n);
+        const double pu = cval[u] * (1.0 / cval[u]);
+        okey[r] = (uint64_t)assign[u] * (uint64_t)n + (uint64_t)b;
+        oval[r] = s * pu;
+    } else {
+        okey[r] = k;
+        oval[r] = s;
+    }
+}
+
+__global__ void fill_invalid_kernel(uint64_t *__restrict__ key, double *__restrict__ val, const int32_t *__restrict__ n_valid,
+                                    int32_t m) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m || i < n_valid[0]) return;
+    key[i] = kInvalid;
+    val[i] = 0.0;
+}
+
+__device__ __forceinline__ int lower_bound_u64(const uint64_t *a, int n, uint64_t v) {
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (a[mid] < v) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// out = (s_ab + s_ba)/2, flag entries that survive (non-zero)
+__global__ void symmetrise_kernel(const uint64_t *__restrict__ ukey, const double *__restrict__ usum,
+                                  const int32_t *__restrict__ n_unique, int32_t n, int32_t cap, double *__restrict__ sym,
+                                  int32_t *__restrict__ keep) {
+#pragma clang fp contract(off)
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cap) return;
+    const int cnt = n_unique[0];
+    if (i >= cnt) { keep[i] = 0; return; }
+    const uint64_t k = ukey[i];
+    const uint64_t a = k / (uint64_t)n, b = k % (uint64_t)n;
+    const uint64_t tk = b * (uint64_t)n + a;
+    const int p = lower_bound_u64(ukey, cnt, tk);
+    const double t = (p < cnt && ukey[p] == tk) ? usum[p] : 0.0;
+    const double v = (usum[i] + t) / 2.0;
+    sym[i] = v;
+    keep[i] = v != 0.0 ? 1 : 0;
+}
+
+__global__ void lift_emit_kernel(const uint64_t *__restrict__ ukey, const double *__restrict__ sym,
+                                 const int32_t *__restrict__ pos, const int32_t *__restrict__ n_unique, int32_t n,
+                                 int32_t cap, int32_t *__restrict__ col_c, double *__restrict__ w_c,
+                                 int32_t *__restrict__ nnz_c) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) nnz_c[0] = pos[cap];
+    if (i >= cap || i >= n_unique[0]) return;
+    if (pos[i + 1] == pos[i]) return;  // dropped
+    col_c[pos[i]] = (int32_t)(ukey[i] % (uint64_t)n);
+    w_c[pos[i]] = sym[i];
+}
+
+__global__ void lift_rowptr_kernel(const uint64_t *__restrict__ ukey, const int32_t *__restrict__ pos,
+                                   const int32_t *__restrict__ n_unique, int32_t n, int32_t *__restrict__ rowptr_c) {
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a > n) return;
+    const int cnt = n_unique[0];
+    const int p = lower_bound_u64(ukey, cnt, (uint64_t)a * (uint64_t)n);
+    rowptr_c[a] = pos[p];
+}
+
+struct LiftLayout {
+    size_t k0, k1, v0, v1, flag, counts, sort_tmp, sort_tmp_bytes, scan_tmp, scan_tmp_bytes, total;
+};
+LiftLayout lift_layout(int64_t nnz) {
+    LiftLayout L{};
+    const size_t m = (size_t)(nnz > 0 ? nnz : 1);
+    size_t o = 0;
+    L.k0 = o; o += align_up(m * 8);
+    L.k1 = o; o += align_up(m * 8);
+    L.v0 = o; o += align_up(m * 8);
+    L.v1 = o; o += align_up(m * 8);
+    L.flag = o; o += align_up((m + 1) * 4);
+    L.counts = o; o += align_up(16);
+    size_t t = 0;
+    (void)rocprim::radix_sort_pairs(nullptr, t, (uint64_t *)nullptr, (uint64_t *)nullptr, (double *)nullptr,
+                                    (double *)nullptr, m, 0, 64, (hipStream_t)0);
+    L.sort_tmp_bytes = t;
+    L.sort_tmp = o; o += align_up(t);
+    size_t t2 = 0;
+    (void)rocprim::exclusive_scan(nullptr, t2, (int32_t *)nullptr, (int32_t *)nullptr, 0, m + 1, rocprim::plus<int32_t>(),
+                                  (hipStream_t)0);
+    L.scan_tmp_bytes = t2;
+    L.scan_tmp = o; o += align_up(t2);
+    L.total = o;
+    return L;
+}
+
+// ------------------------------------------------------------------------------------------------
+// pooling
+// ------------------------------------------------------------------------------------------------
+__global__ void iota_kernel(int32_t N, const int32_t *__restrict__ assign, uint32_t *__restrict__ key,
+                            int32_t *__restrict__ id) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N) { key[i] = (uint32_t)assign[i]; id[i] = i; }
+}
+__global__ void cluster_offsets_kernel(const uint32_t *__restrict__ skey, int32_t N, int32_t n, int32_t *__restrict__ off) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c > n) return;
+    int lo = 0, hi = N;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (skey[mid] < (uint32_t)c) lo = mid + 1; else hi = mid;
+    }
+    off[c] = lo;
+}
+
+// one wave per (cluster, 64*VEC-column slab): f64 accumulation over members in ascending node order
+template <int VEC>
+__global__ __launch_bounds__(256) void pool_rows_kernel(const int32_t *__restrict__ off, const int32_t *__restrict__ members,
+                                                        const double *__restrict__ cval, int32_t n,
+                                                        const float *__restrict__ X, int64_t ldx, int32_t F,
+                                                        float *__restrict__ Xc, int64_t ldxc, double *__restrict__ Xc64) {
+#pragma clang fp contract(off)
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (c >= n) return;
+    const int f0 = (blockIdx.y * 64 + lane) * VEC;
+    if (f0 >= F) return;
+    const int m0 = off[c], m1 = off[c + 1];
+    double acc[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) acc[i] = 0.0;
+    for (int m = m0; m < m1; ++m) {
+        const int node = members[m];
+        const double v = cval[node];
+        const float *src = X + (int64_t)node * ldx + f0;
+        float x[VEC];
+        if (VEC == 4) {
+            const float4 q = *reinterpret_cast<const float4 *>(src);
+            x[0] = q.x; x[1 % VEC] = q.y; x[2 % VEC] = q.z; x[3 % VEC] = q.w;
+        } else {
+            x[0] = src[0];
+        }
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) { const double prod = v * (double)x[i]; acc[i] = acc[i] + prod; }
+    }
+    float *dst = Xc + (int64_t)c * ldxc + f0;
+    if (VEC == 4) {
+        *reinterpret_cast<float4 *>(dst) = make_float4((float)acc[0], (float)acc[1 % VEC], (float)acc[2 % VEC], (float)acc[3 % VEC]);
+    } else {
+        dst[0] = (float)acc[0];
+    }
+    if (Xc64) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) Xc64[(int64_t)c * F + f0 + i] = acc[i];
+    }
+}
+
+struct PoolLayout {
+    size_t key_in, key_out, id_in, members, off, sort_tmp, sort_tmp_bytes, total;
+};
+PoolLayout pool_layout(int32_t N, int32_t n) {
+    PoolLayout L{};
+    const size_t m = (size_t)(N > 0 ? N : 1);
+    size_t o = 0;
+    L.key_in = o; o += align_up(m * 4);
+    L.key_out = o; o += align_up(m * 4);
+    L.id_in = o; o += align_up(m * 4);
+    L.members = o; o += align_up(m * 4);
+    L.off = o; o += align_up(((size_t)(n > 0 ? n : 0) + 1) * 4);
+    size_t t = 0;
+    (void)rocprim::radix_sort_pairs(nullptr, t, (uint32_t *)nullptr, (uint32_t *)nullptr, (int32_t *)nullptr,
+                                    (int32_t *)nullptr, m, 0, 32, (hipStream_t)0);
+    L.sort_tmp_bytes = t;
+    L.sort_tmp = o; o += align_up(t);
+    L.total = o;
+    return L;
+}
+
+}  // namespace
+
+extern "C" size_t fitgnn_lift_adjacency_workspace_bytes(int32_t N, int64_t nnz, int32_t n) {
+    (void)N; (void)n;
+    if (nnz < 0) return 0;
+    return lift_layout(nnz).total;
+}
+
+extern "C" int fitgnn_lift_adjacency(int32_t N, const int32_t *rowptr, const int32_t *col, const double *w,
+                                     const int32_t *assign, const double *cval, int32_t n, int32_t *rowptr_c,
+                                     int32_t *col_c, double *w_c, int32_t *nnz_c, void *work, size_t work_bytes,
+                                     void *stream) {
+    if (N < 0 || n < 0 || !rowptr_c || !nnz_c) return FITGNN_E_BADARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (N == 0 || n == 0) {
+        FITGNN_RETURN_IF_HIP(hipMemsetAsync(rowptr_c, 0, ((size_t)n + 1) * sizeof(int32_t), s));
+        return (int)hipMemsetAsync(nnz_c, 0, sizeof(int32_t), s);
+    }
+    if (!rowptr || !col || !assign || !cval || !col_c || !w_c || !work) return FITGNN_E_BADARG;
+    int32_t nnz = 0;  // 4-byte read-back: sizes every launch below
+    FITGNN_RETURN_IF_HIP(hipMemcpyAsync(&nnz, rowptr + N, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    FITGNN_RETURN_IF_HIP(hipStreamSynchronize(s));
+    if (nnz == 0) {
+        FITGNN_RETURN_IF_HIP(hipMemsetAsync(rowptr_c, 0, ((size_t)n + 1) * sizeof(int32_t), s));
+        return (int)hipMemsetAsync(nnz_c, 0, sizeof(int32_t), s);
+    }
+    const LiftLayout L = lift_layout(nnz);
+    if (work_bytes < L.total) return FITGNN_E_WORKSPACE;
+    char *base = (char *)work;
+    uint64_t *k0 = (uint64_t *)(base + L.k0), *k1 = (uint64_t *)(base + L.k1);
+    double *v0 = (double *)(base + L.v0), *v1 = (double *)(base + L.v1);
+    int32_t *flag = (int32_t *)(base + L.flag);
+    void *sort_tmp = base + L.sort_tmp, *scan_tmp = base + L.scan_tmp;
+    size_t st = L.sort_tmp_bytes, ct = L.scan_tmp_bytes;
+    const dim3 g = blocks_for(nnz), b(256);
+
+    // ---- stage 1: y[u][b] = sum_v w_uv p_v  (W . Pinv) ----
+    hipLaunchKernelGGL(lift_stage1_kernel, g, b, 0, s, N, rowptr, col, w, assign, cval, n, nnz, k0, v0);
+    FITGNN_RETURN_IF_HIP(rocprim::radix_sort_pairs(sort_tmp, st, k0, k1, v0, v1, (size_t)nnz, 0, 64, s));
+    hipLaunchKernelGGL(run_head_kernel, g, b, 0, s, k1, nnz, flag);
+    FITGNN_RETURN_IF_HIP(hipMemsetAsync(flag + nnz, 0, sizeof(int32_t), s));
+    FITGNN_RETURN_IF_HIP(rocprim::exclusive_scan(scan_tmp, ct, flag, flag, 0, (size_t)nnz + 1, rocprim::plus<int32_t>(), s));
+    hipLaunchKernelGGL(run_sum_kernel<1>, g, b, 0, s, k1, v1, nnz, flag, assign, cval, n, k0, v0);
+    hipLaunchKernelGGL(fill_invalid_kernel, g, b, 0, s, k0, v0, flag + nnz, nnz);
+    // ---- stage 2: s[a][b] = sum_u y[u][b] p_u  (Pinv^T . y) ----
+    st = L.sort_tmp_bytes;
+    FITGNN_RETURN_IF_HIP(rocprim::radix_sort_pairs(sort_tmp, st, k0, k1, v0, v1, (size_t)nnz, 0, 64, s));
+    hipLaunchKernelGGL(run_head_kernel, g, b, 0, s, k1, nnz, flag);
+    FITGNN_RETURN_IF_HIP(hipMemsetAsync(flag + nnz, 0, sizeof(int32_t), s));
+    ct = L.scan_tmp_bytes;
+    FITGNN_RETURN_IF_HIP(rocprim::exclusive_scan(scan_tmp, ct, flag, flag, 0, (size_t)nnz + 1, rocprim::plus<int32_t>(), s));
+    hipLaunchKernelGGL(run_sum_kernel<2>, g, b, 0, s, k1, v1, nnz, flag, assign, cval, n, k0, v0);
+    // unique count -> counts[0]
+    int32_t *counts = (int32_t *)(base + L.counts);
+    FITGNN_RETURN_IF_HIP(hipMemcpyAsync(counts, flag + nnz, sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+    // ---- symmetrise, drop zeros, emit CSR ----
+    hipLaunchKernelGGL(symmetrise_kernel, g, b, 0, s, k0, v0, counts, n, nnz, v1, flag);
+    FITGNN_RETURN_IF_HIP(hipMemsetAsync(flag + nnz, 0, sizeof(int32_t), s));
+    ct = L.scan_tmp_bytes;
+    FITGNN_RETURN_IF_HIP(rocprim::exclusive_scan(scan_tmp, ct, flag, flag, 0, (size_t)nnz + 1, rocprim::plus<int32_t>(), s));
+    hipLaunchKernelGGL(lift_emit_kernel, g, b, 0, s, k0, v1, flag, counts, n, nnz, col_c, w_c, nnz_c);
+    hipLaunchKernelGGL(lift_rowptr_kernel, blocks_for((int64_t)n + 1), b, 0, s, k0, flag, counts, n, rowptr_c);
+    return (int)hipGetLastError();
+}
+
+extern "C" size_t fitgnn_pool_rows_workspace_bytes(int32_t N, int32_t n) {
+    if (N < 0 || n < 0) return 0;
+    return pool_layout(N, n).total;
+}
+
+extern "C" int fitgnn_pool_rows_f32(const int32_t *assign, const double *cval, int32_t N, int32_t n, const float *X,
+                                    int64_t ldx, int32_t F, float *Xc, int64_t ldxc, double *Xc64, void *work,
+                                    size_t work_bytes, void *stream) {
+    if (N < 0 || n < 0 || F < 0) return FITGNN_E_BADARG;
+    if (n == 0 || F == 0) return 0;
+    if (!assign || !cval || !X || !Xc || !work || ldx < F || ldxc < F) return FITGNN_E_BADARG;
+    const PoolLayout L = pool_layout(N, n);
+    if (work_bytes < L.total) return FITGNN_E_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    char *base = (char *)work;
+    uint32_t *key_in = (uint32_t *)(base + L.key_in), *key_out = (uint32_t *)(base + L.key_out);
+    int32_t *id_in = (int32_t *)(base + L.id_in), *members = (int32_t *)(base + L.members);
+    int32_t *off = (int32_t *)(base + L.off);
+    if (N > 0) {
+        hipLaunchKernelGGL(iota_kernel, blocks_for(N), dim3(256), 0, s, N, assign, key_in, id_in);
+        size_t st = L.sort_tmp_bytes;
+        // stable: members of a cluster stay in ascending node order (the order scipy's csc product visits them)
+        FITGNN_RETURN_IF_HIP(rocprim::radix_sort_pairs((void *)(base + L.sort_tmp), st, key_in, key_out, id_in, members,
+                                                       (size_t)N, 0, 32, s));
+    }
+    hipLaunchKernelGGL(cluster_offsets_kernel, blocks_for((int64_t)n + 1), dim3(256), 0, s, key_out, N, n, off);
+    const bool vec = (F % 4 == 0) && (ldx % 4 == 0) && (ldxc % 4 == 0) && ((((uintptr_t)X | (uintptr_t)Xc) % 16) == 0);
+    if (vec) {
+        dim3 grid((n + 3) / 4, (F + 255) / 256);
+        hipLaunchKernelGGL(pool_rows_kernel<4>, grid, dim3(256), 0, s, off, members, cval, n, X, ldx, F, Xc, ldxc, Xc64);
+    } else {
+        dim3 grid((n + 3) / 4, (F + 63) / 64);
+        hipLaunchKernelGGL(pool_rows_kernel<1>, grid, dim3(256), 0, s, off, members, cval, n, X, ldx, F, Xc, ldxc, Xc64);
+    }
+    return (int)hipGetLastError();
+}

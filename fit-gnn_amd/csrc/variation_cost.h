@@ -1,0 +1,192 @@
+// variation_cost.h -- one wavefront computes the local-variation cost of one candidate set.
+//
+// Restates subgraph_cost (FIT-GNN graph_coarsening/coarsening_utils.py:555-561)
+//     cost(S) = || B^T L_S B ||_F / (nc-1),  B = (I - 11^T/nc) A[S,:],  L_S = diag(2 dw[S] - W_S 1) - W_S
+// in the CANONICAL ARITHMETIC of DESIGN.md (binary64, one rounding per operation, no FMA):
+//     mean[k] = (A[S0][k] + A[S1][k] + ...)/nc           left-to-right over the sorted members
+//     B[a][k] = A[Sa][k] - mean[k]
+//     rs[a]   = sum_b w_ab ; T[a][l] = sum_b (w_ab * B[b][l])    b ascending over S_b in adj(S_a), from 0.0
+//     Y[a][l] = (2 dw[Sa] - rs[a]) * B[a][l] - T[a][l]
+//     M[k][l] = sum_a (B[a][k] * Y[a][l])                        a ascending, from 0.0
+//     p[j]    = sum over e = j, j+64, ... < K*K of M[e]^2 ; 64-lane butterfly (offsets 32..1) ; sqrt ; / (nc-1)
+// Lane mapping: rows a of S on lanes (tiles of 64 rows) for B/Y, matrix entries (k,l) on lanes for M and
+// the Frobenius sum -- so the wave-wide reduction IS the canonical summation tree.
+//
+// This translation unit must be compiled with -ffp-contract=off.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "fitgnn_hip.h"
+
+// Orders this wave's LDS traffic: later reads by any lane see earlier writes by every lane (the LDS
+// pipeline is in-order per wave; the fence stops the compiler from moving accesses across it).
+#define FITGNN_WAVE_SYNC()                                      \
+    do {                                                        \
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  \
+        __builtin_amdgcn_wave_barrier();                        \
+    } while (0)
+
+namespace fitgnn {
+
+constexpr int kCostTile = 64;  // rows of S per LDS tile (one per lane)
+
+struct CostLds {  // per-wave LDS scratch
+    double B[kCostTile * FITGNN_MAX_K];
+    double Y[kCostTile * FITGNN_MAX_K];
+    double mean[FITGNN_MAX_K];
+    int32_t S[kCostTile];
+};
+
+struct CostGraph {
+    const int32_t *rowptr;
+    const int32_t *col;
+    const double *w;  // may be null: all ones
+    const double *dw;
+    const double *A;
+    int32_t K;
+    int64_t lda;
+};
+
+// first index in sorted a[0..n) with a[i] >= v
+__device__ __forceinline__ int lower_bound_i32(const int32_t *a, int n, int32_t v) {
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (a[mid] < v) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// All 64 lanes of the wave must call this with identical (g, S, nc).  Returns the cost in every lane.
+// S points to global memory (sorted ascending).  lds is this wave's private scratch.
+__device__ inline double set_cost_wave(const CostGraph &g, const int32_t *__restrict__ S, int nc, CostLds &lds) {
+#pragma clang fp contract(off)
+    if (nc < 2) return INFINITY;
+    const int lane = threadIdx.x & 63;
+    const int K = g.K;
+    const int KK = K * K;
+    const bool small = nc <= kCostTile;  // whole set resident in LDS
+
+    // ---- pass 1: column means, sequential over members (tiles of 64 rows staged cooperatively) ----
+    double msum = 0.0;
+    for (int t0 = 0; t0 < nc; t0 += kCostTile) {
+        const int rows = min(kCostTile, nc - t0);
+        if (lane < rows) lds.S[lane] = S[t0 + lane];
+        FITGNN_WAVE_SYNC();
+        for (int i = lane; i < rows * K; i += 64) {
+            const int a = i / K, k = i - a * K;
+            lds.B[i] = g.A[(int64_t)lds.S[a] * g.lda + k];
+        }
+        FITGNN_WAVE_SYNC();
+        if (lane < K) {
+            int a = 0;
+            if (t0 == 0) { msum = lds.B[lane]; a = 1; }
+            for (; a < rows; ++a) msum = msum + lds.B[a * K + lane];
+        }
+        FITGNN_WAVE_SYNC();
+    }
+    if (lane < K) lds.mean[lane] = msum / (double)nc;
+    FITGNN_WAVE_SYNC();
+
+    // ---- pass 2: per tile, rows on lanes -> B, Y ; then entries on lanes -> M ----
+    double m0 = 0.0, m1 = 0.0, m2 = 0.0, m3 = 0.0;
+    const int ea = lane, eb = lane + 64, ec = lane + 128, ed = lane + 192;
+    for (int t0 = 0; t0 < nc; t0 += kCostTile) {
+        const int rows = min(kCostTile, nc - t0);
+        if (!small || t0 > 0) {  // (re)stage this tile's raw rows; the small case still holds them
+            if (lane < rows) lds.S[lane] = S[t0 + lane];
+            FITGNN_WAVE_SYNC();
+            for (int i = lane; i < rows * K; i += 64) {
+                const int a = i / K, k = i - a * K;
+                lds.B[i] = g.A[(int64_t)lds.S[a] * g.lda + k];
+            }
+            FITGNN_WAVE_SYNC();
+        }
+        for (int i = lane; i < rows * K; i += 64) {
+            const int a = i / K, k = i - a * K;
+            lds.B[i] = lds.B[i] - lds.mean[k];
+        }
+        FITGNN_WAVE_SYNC();
+        if (lane < rows) {
+            const int a = lane;
+            const int32_t u = lds.S[a];
+            const int e0 = g.rowptr[u], e1 = g.rowptr[u + 1];
+            const int deg = e1 - e0;
+            double T[FITGNN_MAX_K];
+#pragma unroll
+            for (int l = 0; l < FITGNN_MAX_K; ++l) T[l] = 0.0;
+            double rs = 0.0;
+            // intersection adj(u) /\ S in ascending order, walking the shorter list
+            const bool walk_adj = deg <= 4 * nc;
+            const int steps = walk_adj ? deg : nc;
+            for (int s = 0; s < steps; ++s) {
+                int e, b;
+                int32_t c;
+                if (walk_adj) {
+                    e = e0 + s;
+                    c = g.col[e];
+                    b = small ? lower_bound_i32(lds.S, nc, c) : lower_bound_i32(S, nc, c);
+                    const int32_t sb = (b < nc) ? (small ? lds.S[b] : S[b]) : -1;
+                    if (sb != c) continue;
+                } else {
+                    b = s;
+                    c = small ? lds.S[b] : S[b];
+                    e = e0 + lower_bound_i32(g.col + e0, deg, c);
+                    if (e >= e1 || g.col[e] != c) continue;
+                }
+                const double wab = g.w ? g.w[e] : 1.0;
+                rs = rs + wab;
+                if (small) {
+#pragma unroll
+                    for (int l = 0; l < FITGNN_MAX_K; ++l)
+                        if (l < K) { const double prod = wab * lds.B[b * K + l]; T[l] = T[l] + prod; }
+                } else {
+#pragma unroll
+                    for (int l = 0; l < FITGNN_MAX_K; ++l)
+                        if (l < K) {
+                            const double bb = g.A[(int64_t)c * g.lda + l] - lds.mean[l];
+                            const double prod = wab * bb;
+                            T[l] = T[l] + prod;
+                        }
+                }
+            }
+            const double d = 2.0 * g.dw[u] - rs;
+#pragma unroll
+            for (int l = 0; l < FITGNN_MAX_K; ++l)
+                if (l < K) { const double prod = d * lds.B[a * K + l]; lds.Y[a * K + l] = prod - T[l]; }
+        }
+        FITGNN_WAVE_SYNC();
+        // M[k][l] += B[a][k] * Y[a][l], a ascending
+        {
+            const int ka = ea / K, la = ea - ka * K;
+            const int kb = eb / K, lb = eb - kb * K;
+            const int kc = ec / K, lc = ec - kc * K;
+            const int kd = ed / K, ld = ed - kd * K;
+            for (int a = 0; a < rows; ++a) {
+                const double *Br = lds.B + a * K, *Yr = lds.Y + a * K;
+                if (ea < KK) { const double prod = Br[ka] * Yr[la]; m0 = m0 + prod; }
+                if (eb < KK) { const double prod = Br[kb] * Yr[lb]; m1 = m1 + prod; }
+                if (ec < KK) { const double prod = Br[kc] * Yr[lc]; m2 = m2 + prod; }
+                if (ed < KK) { const double prod = Br[kd] * Yr[ld]; m3 = m3 + prod; }
+            }
+        }
+        FITGNN_WAVE_SYNC();
+    }
+    // ---- Frobenius norm: canonical 64-lane tree ----
+    double p = 0.0;
+    if (ea < KK) p = m0 * m0;
+    if (eb < KK) { const double q = m1 * m1; p = p + q; }
+    if (ec < KK) { const double q = m2 * m2; p = p + q; }
+    if (ed < KK) { const double q = m3 * m3; p = p + q; }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const double other = __shfl_down(p, off, 64);
+        p = p + other;
+    }
+    p = __shfl(p, 0, 64);
+    return sqrt(p) / (double)(nc - 1);
+}
+
+}  // namespace fitgnn

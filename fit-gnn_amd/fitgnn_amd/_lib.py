@@ -1,0 +1,88 @@
+"""ctypes binding of libfitgnn_hip.so (the C ABI declared in include/fitgnn_hip.h).
+
+The product has NO CPU fallback: if the shared library is missing or a call fails, an exception
+is raised.  Build it with `python __graft_entry__.py` or `make -C fit-gnn_amd/csrc`.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libfitgnn_hip.so")
+
+c_i32, c_i64, c_u32, c_u64, c_f32, c_size = (ctypes.c_int32, ctypes.c_int64, ctypes.c_uint32, ctypes.c_uint64,
+                                              ctypes.c_float, ctypes.c_size_t)
+ptr = ctypes.c_void_p
+
+EPI_BIAS, EPI_ELU, EPI_DROPOUT = 1, 2, 4
+MAX_K = 16
+
+# name -> (restype, argtypes); mirrors include/fitgnn_hip.h one to one
+SIGNATURES = {
+    "fitgnn_abi_version": (ctypes.c_int, []),
+    "fitgnn_error_string": (ctypes.c_char_p, [ctypes.c_int]),
+    "fitgnn_spmm_max_window_rows": (ctypes.c_int, [c_i32]),
+    "fitgnn_gcn_norm_csr_f32": (ctypes.c_int, [ptr, ptr, ptr, ptr, ptr, c_i32, ptr]),
+    "fitgnn_spmm_csr_f32": (ctypes.c_int, [ptr, ptr, ptr, ptr, c_i64, ptr, c_i64, c_i32, c_i32, ptr, c_i32, ptr, c_u32,
+                                           c_f32, c_u64, ptr, ptr]),
+    "fitgnn_epilogue_bwd_workspace_bytes": (c_size, [c_i32, c_i32]),
+    "fitgnn_epilogue_bwd_f32": (ctypes.c_int, [ptr, ptr, ptr, c_i32, c_i32, c_u32, c_f32, c_u64, ptr, ptr, ptr, c_size, ptr]),
+    "fitgnn_closed_neighbourhoods": (ctypes.c_int, [ptr, ptr, c_i32, ptr, ptr, ptr]),
+    "fitgnn_variation_costs_f64": (ctypes.c_int, [ptr, ptr, ptr, ptr, ptr, c_i32, c_i64, ptr, ptr, ptr, c_i32, ptr, ptr]),
+    "fitgnn_greedy_select_workspace_bytes": (c_size, [c_i32, c_i64]),
+    "fitgnn_greedy_select": (ctypes.c_int, [ptr, ptr, ptr, ptr, ptr, c_i32, c_i64, c_i32, ptr, ptr, ptr, c_i64, ptr, ptr,
+                                            ptr, ptr, c_size, ptr]),
+    "fitgnn_build_assignment_workspace_bytes": (c_size, [c_i32]),
+    "fitgnn_build_assignment": (ctypes.c_int, [c_i32, ptr, ptr, ptr, ptr, ptr, ptr, ptr, c_size, ptr]),
+    "fitgnn_compose_levels": (ctypes.c_int, [c_i32, ptr, ptr, ptr, ptr, ptr]),
+    "fitgnn_lift_adjacency_workspace_bytes": (c_size, [c_i32, c_i64, c_i32]),
+    "fitgnn_lift_adjacency": (ctypes.c_int, [c_i32, ptr, ptr, ptr, ptr, ptr, c_i32, ptr, ptr, ptr, ptr, ptr, c_size, ptr]),
+    "fitgnn_pool_rows_workspace_bytes": (c_size, [c_i32, c_i32]),
+    "fitgnn_pool_rows_f32": (ctypes.c_int, [ptr, ptr, c_i32, c_i32, ptr, c_i64, c_i32, ptr, c_i64, ptr, ptr, c_size, ptr]),
+}
+
+_lib = None
+
+
+class FitgnnError(RuntimeError):
+    pass
+
+
+def lib():
+    """The loaded library; raises (never falls back) when it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise FitgnnError(f"{LIB_PATH} not found: build the HIP extension first "
+                              "(python -c 'import __graft_entry__ as g; g.build()'); there is no CPU fallback")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        if L.fitgnn_abi_version() != 1:
+            raise FitgnnError("libfitgnn_hip.so ABI version mismatch")
+        _lib = L
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().fitgnn_error_string(int(rc)).decode()
+        raise FitgnnError(f"{what}: {msg} (code {rc})")
+
+
+def dptr(t):
+    """Device pointer of a torch tensor (None -> NULL)."""
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def stream_ptr(device=None):
+    import torch
+
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise FitgnnError("fitgnn ops run on the MI355X only: got a CPU tensor (no CPU fallback exists)")

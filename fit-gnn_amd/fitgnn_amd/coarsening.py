@@ -1,0 +1,317 @@
+"""`coarsen()` with the reference's signature and return values, contraction step on the MI355X.
+
+Mirror of graph_coarsening/coarsening_utils.py:18-182 (`coarsen`) for the variation_neighborhoods
+method, the only one BASELINE.json's north_star names.  Per level:
+
+    host   spectral prelude  A = Uk diag(lk^-1/2)            (:75-96;  ARPACK / LAPACK)
+           or               A = B diag(d^-1/2) V             (:99-105)
+    device candidate family + local-variation costs          (:571-578, :555-561)   fitgnn_variation_costs_f64
+    device greedy disjoint selection with re-costing         (:604-650)             fitgnn_greedy_select
+    device assignment vector / C values                      (:212-254, :168-179)   fitgnn_build_assignment
+    device adjacency lift Wc = zero_diag(P^T W P) symmetrised (:138-139, :201-205)   fitgnn_lift_adjacency
+
+Returned objects expose what FIT-GNN's callers touch (utils.py:159-184, :723-752, main.py:144-151):
+`C` is a scipy csc matrix (subclass whose `.dot(dense)` runs the pooling kernel), `Gc` a light graph with
+`.N .W .A .dw .L`, `mapping_dict_list` the per-level dicts.  There is no CPU path for the contraction step.
+"""
+import numpy as np
+import scipy.sparse as sp
+import torch
+
+from . import _lib
+
+
+# ---------------------------------------------------------------------------------------------
+# light graph object (what the variation path reads from pygsp.graphs.Graph)
+# ---------------------------------------------------------------------------------------------
+class Graph:
+    def __init__(self, W, coords=None):
+        W = sp.csr_matrix(W, dtype=np.float64)
+        W.eliminate_zeros()
+        W.sort_indices()
+        self.W = W
+        self.N = W.shape[0]
+        self._A = self._dw = self._L = None
+        if coords is not None:
+            self.coords = coords
+        self.info = {}
+
+    @property
+    def A(self):
+        if self._A is None:
+            self._A = (self.W > 0).tocsr()
+        return self._A
+
+    @property
+    def dw(self):
+        if self._dw is None:
+            self._dw = np.ravel(self.W.sum(axis=0))
+        return self._dw
+
+    @property
+    def L(self):
+        if self._L is None:
+            self._L = (sp.diags(self.dw, 0) - self.W).tocsc()
+        return self._L
+
+    @property
+    def Ne(self):
+        return sp.tril(self.W).nnz
+
+    def is_directed(self):
+        return (abs(self.W - self.W.T) > 1e-12).nnz > 0
+
+    def subgraph(self, ind):
+        return Graph(self.W[ind, :][:, ind])
+
+    def extract_components(self):
+        ncomp, lab = sp.csgraph.connected_components(self.W, directed=False)
+        order = np.argsort(lab, kind="stable")
+        bounds = np.concatenate([[0], np.cumsum(np.bincount(lab, minlength=ncomp))])
+        firsts = [order[bounds[k]] for k in range(ncomp)]
+        out = []
+        for k in np.argsort(firsts, kind="stable"):  # pygsp discovers components by lowest unvisited node
+            idx = np.sort(order[bounds[k]:bounds[k + 1]])
+            g = self.subgraph(idx)
+            g.info = {"orig_idx": idx.tolist()}
+            out.append(g)
+        return out
+
+
+# ---------------------------------------------------------------------------------------------
+# host prelude (not part of the accelerated step; same NumPy/SciPy calls as the reference)
+# ---------------------------------------------------------------------------------------------
+def _spectral_level1(G, K, Uk, lk):
+    import scipy.sparse.linalg as spla
+
+    if (Uk is not None) and (lk is not None) and (len(lk) >= K):
+        mask = lk < 1e-10
+        lk[mask] = 1
+        lsinv = lk ** (-0.5)
+        lsinv[mask] = 0
+        return Uk[:, :K] @ np.diag(lsinv[:K])
+    offset = 2 * max(G.dw)
+    T = offset * sp.eye(G.N, format="csc") - G.L
+    if K >= G.N:
+        lk, Uk = spla.eigsh(T.toarray(), k=K, which="LM", tol=1e-5)
+    else:
+        lk, Uk = spla.eigsh(T, k=K, which="LM", tol=1e-5)
+    lk = (offset - lk)[::-1]
+    Uk = Uk[:, ::-1]
+    mask = lk < 1e-10
+    lk[mask] = 1
+    lsinv = lk ** (-0.5)
+    lsinv[mask] = 0
+    return Uk @ np.diag(lsinv)
+
+
+def _spectral_next(G, iC, B):
+    B = iC.dot(B)
+    d, V = np.linalg.eig(B.T @ (G.L).dot(B))
+    mask = d == 0
+    d[mask] = 1
+    dinvsqrt = d ** (-1 / 2)
+    dinvsqrt[mask] = 0
+    return B, B @ np.diag(dinvsqrt) @ V
+
+
+# ---------------------------------------------------------------------------------------------
+# device pipeline for one level
+# ---------------------------------------------------------------------------------------------
+def _dev(a, dtype, device):
+    return torch.as_tensor(np.ascontiguousarray(a), dtype=dtype).to(device)
+
+
+class LevelResult:
+    __slots__ = ("N", "n", "assign", "cval", "cost0", "sel_off", "sel_mem", "rowptr", "col", "w", "device")
+
+
+def contract_level(G, A, r_cur, device="cuda", keep_debug=False):
+    """One contraction level on the GPU.  Returns LevelResult with device tensors assign (int32[N]),
+    cval (float64[N]) and n (int)."""
+    L = _lib.lib()
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        raise _lib.FitgnnError("contract_level needs the MI355X (no CPU fallback)")
+    st = _lib.stream_ptr(dev)
+    N = G.N
+    W = G.W
+    A = np.ascontiguousarray(np.real(A), dtype=np.float64)
+    K = A.shape[1]
+    if not (1 <= K <= _lib.MAX_K):
+        raise _lib.FitgnnError(f"K={K} outside [1,{_lib.MAX_K}]")
+    rowptr = _dev(W.indptr, torch.int32, dev)
+    col = _dev(W.indices, torch.int32, dev)
+    w = _dev(W.data, torch.float64, dev)
+    dw = _dev(G.dw, torch.float64, dev)
+    Ad = _dev(A, torch.float64, dev)
+    nnz = int(W.nnz)
+    set_off = torch.empty(N + 1, dtype=torch.int32, device=dev)
+    set_mem = torch.empty(nnz + N, dtype=torch.int32, device=dev)
+    _lib.check(L.fitgnn_closed_neighbourhoods(_lib.dptr(rowptr), _lib.dptr(col), N, _lib.dptr(set_off), _lib.dptr(set_mem), st),
+               "closed_neighbourhoods")
+    set_len = (set_off[1:] - set_off[:-1]).contiguous()
+    cost0 = torch.empty(N, dtype=torch.float64, device=dev)
+    _lib.check(L.fitgnn_variation_costs_f64(_lib.dptr(rowptr), _lib.dptr(col), _lib.dptr(w), _lib.dptr(dw), _lib.dptr(Ad), K, K,
+                                            _lib.dptr(set_off), _lib.dptr(set_len), _lib.dptr(set_mem), N, _lib.dptr(cost0), st),
+               "variation_costs")
+    n_reduce = int(np.floor(r_cur * N))  # coarsening_utils.py:612
+    total = nnz + N
+    wb = int(L.fitgnn_greedy_select_workspace_bytes(N, total))
+    work = torch.empty(wb, dtype=torch.uint8, device=dev)
+    sel_off = torch.empty(N + 1, dtype=torch.int32, device=dev)
+    sel_mem = torch.empty(max(N, 1), dtype=torch.int32, device=dev)
+    sel_count = torch.zeros(2, dtype=torch.int32, device=dev)
+    _lib.check(L.fitgnn_greedy_select(_lib.dptr(rowptr), _lib.dptr(col), _lib.dptr(w), _lib.dptr(dw), _lib.dptr(Ad), K, K, N,
+                                      _lib.dptr(set_off), _lib.dptr(set_mem), _lib.dptr(cost0), n_reduce, _lib.dptr(sel_off),
+                                      _lib.dptr(sel_mem), _lib.dptr(sel_count), _lib.dptr(work), wb, st), "greedy_select")
+    assign = torch.empty(N, dtype=torch.int32, device=dev)
+    cval = torch.empty(N, dtype=torch.float64, device=dev)
+    n_out = torch.zeros(1, dtype=torch.int32, device=dev)
+    wb2 = int(L.fitgnn_build_assignment_workspace_bytes(N))
+    work2 = torch.empty(wb2, dtype=torch.uint8, device=dev)
+    _lib.check(L.fitgnn_build_assignment(N, _lib.dptr(sel_off), _lib.dptr(sel_mem), _lib.dptr(sel_count), _lib.dptr(assign),
+                                         _lib.dptr(cval), _lib.dptr(n_out), _lib.dptr(work2), wb2, st), "build_assignment")
+    res = LevelResult()
+    res.N, res.n, res.assign, res.cval, res.device = N, int(n_out.item()), assign, cval, dev
+    res.rowptr, res.col, res.w = rowptr, col, w
+    res.cost0 = cost0 if keep_debug else None
+    if keep_debug:
+        cnt = sel_count.cpu().numpy()
+        res.sel_off = sel_off[: cnt[0] + 1].cpu().numpy()
+        res.sel_mem = sel_mem[: cnt[1]].cpu().numpy()
+    else:
+        res.sel_off = res.sel_mem = None
+    return res
+
+
+def lift_adjacency(res):
+    """Wc (scipy csr f64) = symmetrised zero-diagonal P^T W P of a LevelResult."""
+    L = _lib.lib()
+    dev = res.device
+    st = _lib.stream_ptr(dev)
+    nnz = int(res.col.numel())
+    wb = int(L.fitgnn_lift_adjacency_workspace_bytes(res.N, nnz, res.n))
+    work = torch.empty(wb, dtype=torch.uint8, device=dev)
+    rp = torch.empty(res.n + 1, dtype=torch.int32, device=dev)
+    cc = torch.empty(max(nnz, 1), dtype=torch.int32, device=dev)
+    wc = torch.empty(max(nnz, 1), dtype=torch.float64, device=dev)
+    nz = torch.zeros(1, dtype=torch.int32, device=dev)
+    _lib.check(L.fitgnn_lift_adjacency(res.N, _lib.dptr(res.rowptr), _lib.dptr(res.col), _lib.dptr(res.w), _lib.dptr(res.assign),
+                                       _lib.dptr(res.cval), res.n, _lib.dptr(rp), _lib.dptr(cc), _lib.dptr(wc), _lib.dptr(nz),
+                                       _lib.dptr(work), wb, st), "lift_adjacency")
+    m = int(nz.item())
+    return sp.csr_matrix((wc[:m].cpu().numpy(), cc[:m].cpu().numpy(), rp.cpu().numpy()), shape=(res.n, res.n))
+
+
+def pool_rows(assign, cval, n, X, want_f64=False):
+    """Xc = C . X on the device.  assign int32[N], cval float64[N] device tensors; X float32 [N,F] device."""
+    L = _lib.lib()
+    _lib.require_cuda(assign, cval, X)
+    dev = X.device
+    X = X.float().contiguous()
+    N, F = X.shape
+    Xc = torch.empty((n, F), dtype=torch.float32, device=dev)
+    Xc64 = torch.empty((n, F), dtype=torch.float64, device=dev) if want_f64 else None
+    wb = int(L.fitgnn_pool_rows_workspace_bytes(N, n))
+    work = torch.empty(wb, dtype=torch.uint8, device=dev)
+    _lib.check(L.fitgnn_pool_rows_f32(_lib.dptr(assign), _lib.dptr(cval), N, n, _lib.dptr(X), F, F, _lib.dptr(Xc), F,
+                                      _lib.dptr(Xc64), _lib.dptr(work), wb, _lib.stream_ptr(dev)), "pool_rows")
+    return (Xc, Xc64) if want_f64 else Xc
+
+
+class CoarseningMatrix(sp.csc_matrix):
+    """scipy csc matrix C [n x N] whose product with a dense [N x F] operand runs on the MI355X.
+
+    FIT-GNN pools features and labels with `C.dot(X)` (utils.py:161,393,738,827); this subclass keeps that
+    spelling working: `.dot(ndarray | torch.Tensor)` returns the float64 ndarray scipy would return, computed
+    by fitgnn_pool_rows_f32 (f64 accumulation in ascending member order: bit-identical).  `.pool(X)` is the
+    device-to-device form (float32 tensor in, float32 tensor out) the build's own pipeline uses.
+    """
+
+    def _vectors(self, device):
+        key = str(device)
+        cache = self.__dict__.setdefault("_fitgnn_dev", {})
+        if key not in cache:
+            csc = sp.csc_matrix(self)
+            assert np.all(np.diff(csc.indptr) == 1), "C must have exactly one non-zero per column"
+            cache[key] = (torch.as_tensor(csc.indices.astype(np.int32)).to(device),
+                          torch.as_tensor(csc.data.astype(np.float64)).to(device))
+        return cache[key]
+
+    def pool(self, X):
+        assign, cval = self._vectors(X.device)
+        return pool_rows(assign, cval, self.shape[0], X)
+
+    def dot(self, other):
+        dense = torch.is_tensor(other) or (isinstance(other, np.ndarray) and other.ndim == 2)
+        if not dense or not torch.cuda.is_available():
+            if not dense:
+                return sp.csc_matrix.dot(self, other)
+            raise _lib.FitgnnError("C.dot(dense) runs on the MI355X only (no CPU fallback)")
+        Xt = other if torch.is_tensor(other) else torch.from_numpy(np.ascontiguousarray(other))
+        if Xt.dtype == torch.float64 and not torch.is_tensor(other):
+            # label/mask pooling passes small f64 one-hot matrices (utils.py:726-742): values are exactly
+            # representable in f32, so the f32 kernel input loses nothing
+            pass
+        dev = torch.device("cuda")
+        assign, cval = self._vectors(dev)
+        _, x64 = pool_rows(assign, cval, self.shape[0], Xt.to(dev).float(), want_f64=True)
+        return x64.cpu().numpy()
+
+
+# ---------------------------------------------------------------------------------------------
+# the drop-in driver
+# ---------------------------------------------------------------------------------------------
+def coarsen(G, K=10, r=0.5, max_levels=10, method="variation_neighborhood", algorithm="greedy", Uk=None, lk=None,
+            max_level_r=0.99, device="cuda"):
+    """Same contract as graph_coarsening.coarsening_utils.coarsen (coarsening_utils.py:18-182) for
+    method in {'variation_neighborhood', 'variation_neighborhoods'}: returns (C, Gc, mapping_dict_list)."""
+    if "variation_neighborhood" not in method:
+        raise NotImplementedError(f"method '{method}' is outside the accelerated hot path (variation_neighborhoods only)")
+    if not hasattr(G, "W"):
+        raise TypeError("G must expose .W (scipy sparse adjacency) and .N")
+    if not isinstance(G, Graph):
+        G = Graph(G.W, coords=getattr(G, "coords", None))
+    r = np.clip(r, 0, 0.999)
+    N = G.N
+    n, n_target = N, np.ceil((1 - r) * N)
+    dev = torch.device(device)
+    L = _lib.lib()
+    assign_tot = torch.arange(N, dtype=torch.int32, device=dev)
+    cval_tot = torch.ones(N, dtype=torch.float64, device=dev)
+    Gc = G
+    mapping_dict_list = []
+    B = iC = None
+    for level in range(1, max_levels + 1):
+        G = Gc
+        r_cur = np.clip(1 - n_target / n, 0.0, max_level_r)
+        if level == 1:
+            B = _spectral_level1(G, K, Uk, lk)
+            A = B
+        else:
+            B, A = _spectral_next(G, iC, B)
+        res = contract_level(G, A, r_cur, device=dev)
+        assign_h = res.assign.cpu().numpy()
+        iC = sp.csc_matrix((res.cval.cpu().numpy(), (assign_h, np.arange(G.N))), shape=(res.n, G.N))
+        if iC.shape[1] - iC.shape[0] <= 2:  # :131-135 avoid too many levels for so few nodes
+            mapping_dict_list.append({i: i for i in range(G.N)})
+            break
+        _lib.check(L.fitgnn_compose_levels(N, _lib.dptr(res.assign), _lib.dptr(res.cval), _lib.dptr(assign_tot),
+                                           _lib.dptr(cval_tot), _lib.stream_ptr(dev)), "compose_levels")
+        Wc = lift_adjacency(res)
+        coords = None
+        if hasattr(G, "coords"):
+            coords = (iC.power(2)).dot(G.coords)  # coarsen_vector :190-191 (plot coordinates only)
+        Gc = Graph(Wc, coords=coords)
+        n = Gc.N
+        # level mapping :168-179: keys 0..N-1 of the ORIGINAL graph, identity-padded past the level's size
+        md = {i: int(assign_h[i]) for i in range(G.N)}
+        for i in range(G.N, N):
+            md[i] = res.n + (i - G.N)
+        mapping_dict_list.append(md)
+        if n <= n_target:
+            break
+    a = assign_tot.cpu().numpy()
+    C = CoarseningMatrix(sp.csc_matrix((cval_tot.cpu().numpy(), (a, np.arange(N))), shape=(int(a.max()) + 1 if N else 0, N)))
+    return C, Gc, mapping_dict_list

@@ -1,0 +1,121 @@
+"""The six model classes of FIT-GNN's network.py, same surface, on fitgnn_amd.nn layers.
+
+Kept from the reference (network.py:8-204): constructor takes the argparse Namespace (num_layers1,
+layer_name, num_features, hidden, num_classes); attributes `.conv` (ModuleList) and `.lt1` (Linear);
+`state_dict` keys `conv.{i}.*`, `lt1.*`; forward signatures and output activations:
+    Classify_node(x, edge_index)      -> log_softmax            (:29-35)
+    Regress_node(x, edge_index)       -> raw [N,1]               (:58-64)
+    Classify_graph_gc(gc)             -> softmax(max-pool)       (:87-95)
+    Regress_graph_gc(gc)              -> lt1(mean-pool)          (:158-166)
+    Classify_graph_gs(set_gs, batch)  -> softmax(max-pool of masked subgraph rows)   (:118-135)
+    Regress_graph_gs(set_gs, batch)   -> lt1(mean-pool of masked subgraph rows)      (:189-204)
+Each layer is conv -> ELU -> dropout(p=0.5) (network.py:31-33); GCN layers run that as one GEMM plus one
+SpMM with a fused epilogue.  The *_gs classes evaluate all subgraphs of a batch as ONE block-diagonal
+pass instead of the reference's Python double loop (identical arithmetic: subgraphs share no edges).
+"""
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import nn as fnn
+
+
+def _make_convs(args):
+    cls = getattr(fnn, args.layer_name, None)
+    if cls is None:
+        raise AttributeError(f"fitgnn_amd.nn has no layer '{args.layer_name}'")
+    convs = nn.ModuleList()
+    dims = [args.num_features] + [args.hidden] * args.num_layers1
+    for i in range(args.num_layers1):
+        if args.layer_name == "GINConv":  # network.py:19-21: two-layer ReLU MLP, train_eps=True
+            mlp = nn.Sequential(nn.Linear(dims[i], args.hidden), nn.ReLU(), nn.Linear(args.hidden, args.hidden), nn.ReLU())
+            convs.append(cls(mlp, train_eps=True))
+        else:
+            convs.append(cls(dims[i], dims[i + 1]))
+    return convs
+
+
+class _Base(nn.Module):
+    out_dim_from_classes = True
+
+    def __init__(self, args):
+        super().__init__()
+        self.num_layers = args.num_layers1
+        self.conv = _make_convs(args)
+        self.lt1 = nn.Linear(args.hidden, args.num_classes if self.out_dim_from_classes else 1)
+        self.dropout_p = 0.5  # F.dropout default used by the reference
+        self._inject_masks = None  # tests: list of uint8 masks, one per layer
+
+    def reset_parameters(self):
+        for m in self.conv:
+            m.reset_parameters()
+        self.lt1.reset_parameters()
+
+    def embed(self, x, edge_index):
+        x = x.float()
+        for i in range(self.num_layers):
+            conv = self.conv[i]
+            if isinstance(conv, fnn.GCNConv) and x.is_cuda:
+                mask = self._inject_masks[i] if self._inject_masks is not None else None
+                x = conv.forward_elu_dropout(x, edge_index, p=self.dropout_p, training=self.training, mask=mask)
+            else:
+                x = conv(x, edge_index)
+                x = F.elu(x)
+                x = F.dropout(x, p=self.dropout_p, training=self.training)
+        return x
+
+
+class Classify_node(_Base):
+    def forward(self, x, edge_index):
+        return F.log_softmax(self.lt1(self.embed(x, edge_index)), dim=1)
+
+
+class Regress_node(_Base):
+    out_dim_from_classes = False
+
+    def forward(self, x, edge_index):
+        return self.lt1(self.embed(x, edge_index))
+
+
+class Classify_graph_gc(_Base):
+    def forward(self, gc):
+        x = self.embed(gc.x, gc.edge_index)
+        return F.softmax(self.lt1(fnn.global_max_pool(x, gc.batch)), dim=1)
+
+
+class Regress_graph_gc(_Base):
+    out_dim_from_classes = False
+
+    def forward(self, gc):
+        x = self.embed(gc.x, gc.edge_index)
+        return self.lt1(fnn.global_mean_pool(x, gc.batch))
+
+
+def _merge_subgraphs(set_gs, device):
+    """Block-diagonal union of every subgraph of every graph in the batch (reference: nested Python loops,
+    network.py:120-130); returns x, edge_index, row mask in the reference's concatenation order."""
+    xs, eis, masks, off = [], [], [], 0
+    for gs in set_gs:
+        for g in gs:
+            xs.append(g.x.to(device).float())
+            eis.append(g.edge_index.to(device) + off)
+            masks.append(g.mask.to(device))
+            off += g.x.shape[0]
+    return torch.cat(xs, 0), torch.cat(eis, 1), torch.cat(masks, 0)
+
+
+class Classify_graph_gs(_Base):
+    def forward(self, set_gs, batch_tensor):
+        x, ei, mask = _merge_subgraphs(set_gs, batch_tensor.device)
+        x = self.embed(x, ei)[mask]
+        x = self.lt1(fnn.global_max_pool(x, batch_tensor.to(torch.int64)))
+        return F.softmax(x, dim=0 if x.dim() == 1 else 1)
+
+
+class Regress_graph_gs(_Base):
+    out_dim_from_classes = False
+
+    def forward(self, set_gs, batch_tensor):
+        x, ei, mask = _merge_subgraphs(set_gs, batch_tensor.device)
+        x = self.embed(x, ei)[mask]
+        return self.lt1(fnn.global_mean_pool(x, batch_tensor.to(torch.int64)))

@@ -1,0 +1,139 @@
+"""Message-passing layers with torch_geometric.nn's call signatures, on the fitgnn HIP kernels.
+
+FIT-GNN resolves its layer class by name -- `getattr(torch_geometric.nn, args.layer_name)`
+(network.py:13,41,70,101,141,172) -- and calls `conv(x, edge_index)`.  This module is the namespace
+that lookup is pointed at instead: same constructor arguments, same `forward(x, edge_index)`, same
+parameter names (so `state_dict`s interchange: `lin.weight [out,in]`, `bias [out]` for GCNConv -- the
+layout pinned by Baselines/SGGC/GCN/params/checkpoint-best-acc.pkl).
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import ops
+from .csr import csr_for
+
+
+def glorot_(w):
+    a = math.sqrt(6.0 / (w.size(-2) + w.size(-1)))
+    with torch.no_grad():
+        w.uniform_(-a, a)
+
+
+class GCNConv(nn.Module):
+    """out = D^-1/2 (A+I) D^-1/2 (x W^T) + b   (PyG GCNConv defaults: add_self_loops, normalize, bias)."""
+
+    def __init__(self, in_channels, out_channels, bias=True):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.lin = nn.Linear(in_channels, out_channels, bias=False)
+        self.bias = nn.Parameter(torch.empty(out_channels)) if bias else None
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        glorot_(self.lin.weight)
+        if self.bias is not None:
+            nn.init.zeros_(self.bias)
+
+    def graph(self, edge_index, num_nodes):
+        return csr_for(edge_index, num_nodes, "gcn")
+
+    def forward(self, x, edge_index):
+        g = self.graph(edge_index, x.shape[0])
+        h = torch.mm(x.float(), self.lin.weight.t())
+        return ops.SpMM.apply(h, self.bias, g)
+
+    def forward_elu_dropout(self, x, edge_index, p=0.5, training=False, mask=None, graph=None):
+        """conv -> F.elu -> F.dropout (network.py:31-33) as one GEMM + one SpMM with fused epilogue."""
+        g = graph if graph is not None else self.graph(edge_index, x.shape[0])
+        seed = ops.next_seed() if (training and p > 0 and mask is None) else 0
+        return ops.FusedGCNLayer.apply(x, self.lin.weight, self.bias, g, float(p), bool(training), seed, mask)
+
+    def extra_repr(self):
+        return f"{self.in_channels}, {self.out_channels}"
+
+
+class SAGEConv(nn.Module):
+    """out = W_l mean_{j in N(i)} x_j + b_l + W_r x_i   (PyG SAGEConv defaults: aggr='mean', root_weight)."""
+
+    def __init__(self, in_channels, out_channels, bias=True):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.lin_l = nn.Linear(in_channels, out_channels, bias=bias)
+        self.lin_r = nn.Linear(in_channels, out_channels, bias=False)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        self.lin_l.reset_parameters()
+        self.lin_r.reset_parameters()
+
+    def forward(self, x, edge_index):
+        g = csr_for(edge_index, x.shape[0], "mean")
+        x = x.float()
+        if self.in_channels <= self.out_channels:  # aggregate in the narrower space; mean and Linear commute
+            agg = ops.SpMM.apply(x, None, g)
+            return self.lin_l(agg) + self.lin_r(x)
+        h = torch.mm(x, self.lin_l.weight.t())
+        return ops.SpMM.apply(h, None, g) + (self.lin_l.bias if self.lin_l.bias is not None else 0.0) + self.lin_r(x)
+
+
+class GINConv(nn.Module):
+    """out = nn((1 + eps) x_i + sum_{j in N(i)} x_j)   (PyG GINConv; FIT-GNN passes train_eps=True)."""
+
+    def __init__(self, nn_module, eps=0.0, train_eps=False):
+        super().__init__()
+        self.nn = nn_module
+        self.initial_eps = eps
+        if train_eps:
+            self.eps = nn.Parameter(torch.empty(1))
+        else:
+            self.register_buffer("eps", torch.empty(1))
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        for m in self.nn.modules():
+            if m is not self.nn and hasattr(m, "reset_parameters"):
+                m.reset_parameters()
+        with torch.no_grad():
+            self.eps.fill_(self.initial_eps)
+
+    def forward(self, x, edge_index):
+        g = csr_for(edge_index, x.shape[0], "sum")
+        x = x.float()
+        return self.nn((1.0 + self.eps) * x + ops.SpMM.apply(x, None, g))
+
+
+class APPNP(nn.Module):
+    """z <- (1-alpha) A_hat z + alpha z0, K times (Baselines/SGGC/APPNP/networks.py:11,23: K=10, alpha=0.1)."""
+
+    def __init__(self, K, alpha, dropout=0.0):
+        super().__init__()
+        self.K, self.alpha, self.dropout = K, alpha, dropout
+
+    def reset_parameters(self):
+        pass
+
+    def forward(self, x, edge_index):
+        g = csr_for(edge_index, x.shape[0], "gcn")
+        z0 = x.float()
+        z = z0
+        for _ in range(self.K):
+            z = ops.SpMM.apply(z, None, g) * (1.0 - self.alpha) + self.alpha * z0
+        return z
+
+
+def global_mean_pool(x, batch, size=None):
+    """torch_geometric.nn.global_mean_pool (network.py:164,202)."""
+    size = int(batch.max().item()) + 1 if size is None else size
+    out = torch.zeros((size, x.shape[1]), dtype=x.dtype, device=x.device).index_add_(0, batch, x)
+    cnt = torch.zeros(size, dtype=x.dtype, device=x.device).index_add_(0, batch, torch.ones_like(batch, dtype=x.dtype))
+    return out / cnt.clamp(min=1).unsqueeze(1)
+
+
+def global_max_pool(x, batch, size=None):
+    """torch_geometric.nn.global_max_pool (network.py:93,131)."""
+    size = int(batch.max().item()) + 1 if size is None else size
+    out = torch.full((size, x.shape[1]), float("-inf"), dtype=x.dtype, device=x.device)
+    return out.scatter_reduce(0, batch.unsqueeze(1).expand_as(x), x, reduce="amax", include_self=True)

@@ -1,0 +1,108 @@
+"""torch-facing wrappers over the C ABI (include/fitgnn_hip.h) + the autograd Functions built on them.
+
+torch supplies device memory, the current HIP stream and autograd bookkeeping; all arithmetic of the
+message-passing path is done by libfitgnn_hip.so.  Dense `X @ W^T` stays a library GEMM (torch.mm ->
+hipBLASLt on MFMA), as BASELINE.json's north_star prescribes.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import EPI_BIAS, EPI_DROPOUT, EPI_ELU
+
+
+def _f32c(t):
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def spmm_raw(rowptr, col, val, tiles, X, n_rows, bias=None, epilogue=0, p=0.0, seed=0, mask=None, out=None):
+    """Y = epilogue(A @ X) through fitgnn_spmm_csr_f32.  X: [n_cols_of_A, H] f32 contiguous."""
+    _lib.require_cuda(rowptr, col, val, tiles, X, bias, mask)
+    L = _lib.lib()
+    X = _f32c(X)
+    H = X.shape[1]
+    Y = out if out is not None else torch.empty((n_rows, H), dtype=torch.float32, device=X.device)
+    rc = L.fitgnn_spmm_csr_f32(_lib.dptr(rowptr), _lib.dptr(col), _lib.dptr(val), _lib.dptr(X), X.stride(0) if X.numel() else H,
+                               _lib.dptr(Y), Y.stride(0) if Y.numel() else H, n_rows, H, _lib.dptr(tiles), int(tiles.shape[0]),
+                               _lib.dptr(bias), epilogue, float(p), int(seed) & 0xFFFFFFFFFFFFFFFF, _lib.dptr(mask),
+                               _lib.stream_ptr(X.device))
+    _lib.check(rc, "fitgnn_spmm_csr_f32")
+    return Y
+
+
+def epilogue_bwd_raw(dOut, out, epilogue, p=0.0, seed=0, mask=None, want_db=True):
+    """dZ (and db = column sums of dZ) for out = dropout(ELU(z)) through fitgnn_epilogue_bwd_f32."""
+    _lib.require_cuda(dOut, out, mask)
+    L = _lib.lib()
+    dOut, out = _f32c(dOut), _f32c(out)
+    n, H = dOut.shape
+    dZ = torch.empty_like(dOut)
+    db = torch.empty(H, dtype=torch.float32, device=dOut.device) if want_db else None
+    wb = int(L.fitgnn_epilogue_bwd_workspace_bytes(n, H)) if want_db else 0
+    work = torch.empty(max(wb, 4), dtype=torch.uint8, device=dOut.device)
+    rc = L.fitgnn_epilogue_bwd_f32(_lib.dptr(dOut), _lib.dptr(out), _lib.dptr(dZ), n, H, epilogue, float(p),
+                                   int(seed) & 0xFFFFFFFFFFFFFFFF, _lib.dptr(mask), _lib.dptr(db), _lib.dptr(work), wb,
+                                   _lib.stream_ptr(dOut.device))
+    _lib.check(rc, "fitgnn_epilogue_bwd_f32")
+    return dZ, db
+
+
+class SpMM(torch.autograd.Function):
+    """Y = A @ X (+ bias).  Backward: dX = A^T @ dY (same kernel on the transposed CSR), db = sum rows."""
+
+    @staticmethod
+    def forward(ctx, X, bias, g):
+        ctx.g = g
+        ctx.has_bias = bias is not None
+        epi = EPI_BIAS if bias is not None else 0
+        return spmm_raw(g.rowptr, g.col, g.val, g.tiles, X, g.n, bias=bias, epilogue=epi)
+
+    @staticmethod
+    def backward(ctx, dY):
+        g = ctx.g
+        dY = _f32c(dY)
+        dX = spmm_raw(g.rowptr_t, g.col_t, g.val_t, g.tiles_t, dY, g.n) if ctx.needs_input_grad[0] else None
+        db = dY.sum(0) if ctx.has_bias and ctx.needs_input_grad[1] else None
+        return dX, db, None
+
+
+class FusedGCNLayer(torch.autograd.Function):
+    """out = dropout(ELU(A_hat (X W^T) + b)): GCNConv (network.py:31) + F.elu (:32) + F.dropout (:33) as
+    one GEMM + one SpMM with fused epilogue.  `mask` (uint8 [N,H]) injects a dropout pattern for tests."""
+
+    @staticmethod
+    def forward(ctx, X, W, b, g, p, training, seed, mask):
+        X = _f32c(X)
+        Hm = torch.mm(X, W.t())
+        epi = EPI_ELU | (EPI_BIAS if b is not None else 0)
+        drop = bool(training) and p > 0.0
+        if drop:
+            epi |= EPI_DROPOUT
+        out = spmm_raw(g.rowptr, g.col, g.val, g.tiles, Hm, g.n, bias=b, epilogue=epi, p=p if drop else 0.0, seed=seed,
+                       mask=mask if drop else None)
+        ctx.save_for_backward(X, W, out, mask if drop else None)
+        ctx.g, ctx.p, ctx.drop, ctx.seed, ctx.has_bias = g, p, drop, seed, b is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dOut):
+        X, W, out, mask = ctx.saved_tensors
+        g = ctx.g
+        epi = EPI_ELU | (EPI_DROPOUT if ctx.drop else 0)
+        dZ, db = epilogue_bwd_raw(dOut, out, epi, p=ctx.p if ctx.drop else 0.0, seed=ctx.seed, mask=mask,
+                                  want_db=ctx.has_bias)
+        dH = spmm_raw(g.rowptr_t, g.col_t, g.val_t, g.tiles_t, dZ, g.n)
+        dW = torch.mm(dH.t(), X) if ctx.needs_input_grad[1] else None
+        dX = torch.mm(dH, W) if ctx.needs_input_grad[0] else None
+        return dX, dW, (db if ctx.has_bias else None), None, None, None, None, None
+
+
+_seed_state = [0x1234ABCD]
+
+
+def next_seed():
+    """Per-call dropout seed drawn from torch's generator (so torch.manual_seed controls it)."""
+    return int(torch.randint(0, 2 ** 62, (1,)).item())

@@ -1,0 +1,150 @@
+/*
+ * fitgnn_hip.h -- C ABI of libfitgnn_hip.so: the MI355X (gfx950) implementation of FIT-GNN's
+ * coarsen-then-train hot path.  Plain pointers and sizes only; every pointer is a DEVICE pointer
+ * unless it says "host".  All entry points:
+ *   - return 0 on success, a FITGNN_E_* code (<0) for argument errors, or a hipError_t (>0);
+ *   - are asynchronous on `stream` (a hipStream_t passed as void*; NULL = default stream);
+ *   - never allocate, free or retain memory: the caller owns every buffer, including workspaces,
+ *     whose sizes come from the *_workspace_bytes() queries (host-side, no GPU work);
+ *   - are re-entrant across streams and devices (no global mutable state).
+ *
+ * Each function names the reference interface (file:line under the FIT-GNN repository) it replaces.
+ * Reference-side bindings (ctypes stubs a maintainer would add): INTEGRATION.md.
+ */
+#ifndef FITGNN_HIP_H
+#define FITGNN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FITGNN_ABI_VERSION 1
+#define FITGNN_MAX_K 16 /* columns of the spectral matrix A (reference uses K = 10) */
+
+#define FITGNN_E_BADARG (-1)    /* NULL pointer / negative size / unsupported shape */
+#define FITGNN_E_WORKSPACE (-2) /* workspace smaller than *_workspace_bytes() */
+#define FITGNN_E_ALIGN (-3)     /* pointer or leading dimension not aligned as documented */
+
+int fitgnn_abi_version(void);
+/* Human-readable text for a return code of this library (host pointer, static storage). */
+const char *fitgnn_error_string(int code);
+
+/* =====================================================================================
+ * Train half: GCN-family message passing on block-diagonal subgraph batches
+ * replaces: torch_geometric.nn.GCNConv & friends as called from network.py:31,60,90,126,161,197
+ * ===================================================================================== */
+
+/* A row tile of a CSR batch: rows [row_begin,row_end) are processed by one workgroup, which stages the
+ * rows [win_begin, win_begin+win_rows) of the dense operand in LDS.  Non-zeros whose column falls outside
+ * the window are fetched from global memory, so ANY tiling is correct; block-diagonal batches (disjoint
+ * subgraphs, utils.py:248) make every column fall inside.  Built once per static batch on the host. */
+typedef struct fitgnn_tile {
+    int32_t row_begin, row_end, win_begin, win_rows;
+} fitgnn_tile_t;
+
+/* Largest win_rows the SpMM kernel can stage for a dense operand with H columns. */
+int fitgnn_spmm_max_window_rows(int32_t H);
+
+/* gcn_norm of PyG's GCNConv (network.py:31 -> GCNConv.forward): the CSR holds, per TARGET row i, the
+ * incoming edges j->i INCLUDING the self loops (added by the caller as add_remaining_self_loops does).
+ *   deg[i] = sum_e w[e];  dinv = deg^-1/2 (0 where deg == 0);  val[e] = dinv[i] * w[e] * dinv[col[e]]
+ * w == NULL means all-ones.  dinv: f32[n_rows] scratch/output. */
+int fitgnn_gcn_norm_csr_f32(const int32_t *rowptr, const int32_t *col, const float *w, float *val, float *dinv,
+                            int32_t n_rows, void *stream);
+
+/* epilogue flags of fitgnn_spmm_csr_f32 */
+#define FITGNN_EPI_BIAS 1u    /* + bias[h]                                   (GCNConv bias) */
+#define FITGNN_EPI_ELU 2u     /* ELU(alpha=1)                                 (network.py:32 F.elu) */
+#define FITGNN_EPI_DROPOUT 4u /* inverted dropout with keep-prob 1-p          (network.py:33 F.dropout) */
+
+/* Y[n_rows x H] = epilogue( A . X ),  A in CSR (int32 indices, f32 values), X,Y row-major f32 with leading
+ * dimensions ldx,ldy (elements).  This is GCNConv.propagate (gather + scatter-add over edge_index) done as a
+ * segmented reduction per target row; the backward pass is the same call on the transposed CSR.
+ * Dropout: element (row,h) is kept iff mask[row*H+h] != 0 when `mask` is given, else iff a counter-based
+ * hash of (seed, row*H+h) >= p; kept values are scaled by 1/(1-p).  16-byte aligned X/Y rows (H%4==0 and
+ * ld%4==0) take the vector path; anything else takes the scalar path. */
+int fitgnn_spmm_csr_f32(const int32_t *rowptr, const int32_t *col, const float *val, const float *X, int64_t ldx,
+                        float *Y, int64_t ldy, int32_t n_rows, int32_t H, const fitgnn_tile_t *tiles,
+                        int32_t n_tiles, const float *bias, uint32_t epilogue, float p_drop, uint64_t seed,
+                        const uint8_t *mask, void *stream);
+
+/* Backward of the fused epilogue  out = dropout(ELU(z)):  given dOut and the forward OUTPUT `out`
+ *   dZ = keep ? dOut * 1/(1-p) * (o > 0 ? 1 : o + 1) : 0,   o = out*(1-p) (pre-dropout ELU value)
+ * and the bias gradient db[h] = sum_rows dZ[row][h] (deterministic two-pass reduction through `work`).
+ * flags: FITGNN_EPI_ELU and/or FITGNN_EPI_DROPOUT as used in the forward; db may be NULL. */
+size_t fitgnn_epilogue_bwd_workspace_bytes(int32_t n_rows, int32_t H);
+int fitgnn_epilogue_bwd_f32(const float *dOut, const float *out, float *dZ, int32_t n_rows, int32_t H,
+                            uint32_t epilogue, float p_drop, uint64_t seed, const uint8_t *mask, float *db,
+                            void *work, size_t work_bytes, void *stream);
+
+/* =====================================================================================
+ * Coarsen half: one contraction level of variation_neighborhoods
+ * replaces: graph_coarsening/coarsening_utils.py contract_variation_linear :530-650,
+ *           get_coarsening_matrix :212-254, coarsen_matrix :201-205 (+ graph_utils.zero_diag :82-90),
+ *           and the feature pooling C.dot(X) of utils.py:161,393,738,827
+ * All f64 arithmetic follows the canonical operation order documented in DESIGN.md (no FMA).
+ * ===================================================================================== */
+
+/* Candidate family (coarsening_utils.py:571-578): set i = sorted(N(i) U {i}).
+ * set_off: int32[N+1];  set_mem: int32[nnz + N] capacity. */
+int fitgnn_closed_neighbourhoods(const int32_t *rowptr, const int32_t *col, int32_t N, int32_t *set_off,
+                                 int32_t *set_mem, void *stream);
+
+/* Local-variation cost of every candidate set (subgraph_cost, coarsening_utils.py:555-561):
+ *   cost = || B^T L_S B ||_F / (nc-1),  B = (I - 11^T/nc) A[S,:],  L_S = diag(2 dw[S] - W_S 1) - W_S.
+ * W: symmetric CSR with ascending columns (w == NULL: all ones), dw f64[N], A f64[N x K] row-major with
+ * leading dimension lda, 1 <= K <= FITGNN_MAX_K.  Set s = set_mem[set_off[s] .. +set_len[s]) sorted ascending. */
+int fitgnn_variation_costs_f64(const int32_t *rowptr, const int32_t *col, const double *w, const double *dw,
+                               const double *A, int32_t K, int64_t lda, const int32_t *set_off,
+                               const int32_t *set_len, const int32_t *set_mem, int32_t n_sets, double *cost,
+                               void *stream);
+
+/* Greedy minimum-cost disjoint selection (coarsening_utils.py:604-650) run entirely on the device:
+ * candidates are visited in (cost, insertion order) order -- sortedcontainers.SortedList semantics --,
+ * sets with marked members are filtered, re-costed with the same arithmetic as above and re-inserted.
+ *   set_off int32[N+1], set_mem int32[set_off[N]] : the family (NOT modified; copied into the workspace)
+ *   cost0 f64[N]   : initial costs (fitgnn_variation_costs_f64 output)
+ *   n_reduce       : floor(r*N) computed by the caller in double, as np.floor(r * N) (:612)
+ * Outputs: sel_off int32[N+1], sel_mem int32[N], sel_count int32[2] = {number of sets, number of members}. */
+size_t fitgnn_greedy_select_workspace_bytes(int32_t N, int64_t total_members);
+int fitgnn_greedy_select(const int32_t *rowptr, const int32_t *col, const double *w, const double *dw,
+                         const double *A, int32_t K, int64_t lda, int32_t N, const int32_t *set_off,
+                         const int32_t *set_mem, const double *cost0, int64_t n_reduce, int32_t *sel_off,
+                         int32_t *sel_mem, int32_t *sel_count, void *work, size_t work_bytes, void *stream);
+
+/* get_coarsening_matrix (:212-254) and the level mapping (:168-179) as vectors:
+ *   assign[i] = row of C holding column i = rank of the cluster's minimum member among surviving rows,
+ *   cval[i]   = that non-zero = 1/sqrt(|cluster|),  n_out[0] = number of clusters. */
+size_t fitgnn_build_assignment_workspace_bytes(int32_t N);
+int fitgnn_build_assignment(int32_t N, const int32_t *sel_off, const int32_t *sel_mem, const int32_t *sel_count,
+                            int32_t *assign, double *cval, int32_t *n_out, void *work, size_t work_bytes,
+                            void *stream);
+
+/* C <- iC . C across levels (coarsening_utils.py:136): assign_tot[j] = assign_l[assign_tot[j]],
+ * cval_tot[j] = cval_l[assign_tot_old[j]] * cval_tot[j]. In place on assign_tot / cval_tot (length N0). */
+int fitgnn_compose_levels(int32_t N0, const int32_t *assign_l, const double *cval_l, int32_t *assign_tot,
+                          double *cval_tot, void *stream);
+
+/* Adjacency lift Wc = zero_diag(Pinv^T W Pinv), then (Wc + Wc^T)/2 (coarsening_utils.py:138-139, :201-205),
+ * with SciPy's summation order (bit-identical to the reference).  Outputs a CSR with ascending
+ * columns: rowptr_c int32[n+1], col_c/w_c capacity nnz(W), nnz_c int32[1]. */
+size_t fitgnn_lift_adjacency_workspace_bytes(int32_t N, int64_t nnz, int32_t n);
+int fitgnn_lift_adjacency(int32_t N, const int32_t *rowptr, const int32_t *col, const double *w,
+                          const int32_t *assign, const double *cval, int32_t n, int32_t *rowptr_c, int32_t *col_c,
+                          double *w_c, int32_t *nnz_c, void *work, size_t work_bytes, void *stream);
+
+/* Feature pooling Xc = C . X (utils.py:161,393,738,827): f64 accumulation over each cluster's members in
+ * ascending node order, rounded once to f32 (utils.py:738 torch.FloatTensor).  X f32[N x F] (ldx), Xc
+ * f32[n x F] (ldxc).  Xc64 (f64[n x F], leading dimension F) may be NULL. */
+size_t fitgnn_pool_rows_workspace_bytes(int32_t N, int32_t n);
+int fitgnn_pool_rows_f32(const int32_t *assign, const double *cval, int32_t N, int32_t n, const float *X,
+                         int64_t ldx, int32_t F, float *Xc, int64_t ldxc, double *Xc64, void *work,
+                         size_t work_bytes, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FITGNN_HIP_H */

@@ -1,0 +1,69 @@
+"""CPU tier: the C-ABI library loads and exports every symbol include/fitgnn_hip.h declares; host-only
+size queries work; product code refuses CPU tensors (no fallback)."""
+import os
+import re
+
+import pytest
+import torch
+
+from fitgnn_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "fitgnn_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(fitgnn_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = _lib.lib()
+    names = header_functions()
+    assert len(names) >= 18
+    for n in names:
+        assert hasattr(L, n), f"{n} declared in include/fitgnn_hip.h but not exported"
+    assert sorted(_lib.SIGNATURES) == names, "ctypes signature table out of sync with the header"
+    assert L.fitgnn_abi_version() == 1
+
+
+def test_error_strings_and_size_queries():
+    L = _lib.lib()
+    assert b"workspace" in L.fitgnn_error_string(-2)
+    assert b"bad argument" in L.fitgnn_error_string(-1)
+    assert L.fitgnn_spmm_max_window_rows(512) == 64
+    assert L.fitgnn_spmm_max_window_rows(7) == 256
+    assert L.fitgnn_epilogue_bwd_workspace_bytes(130, 512) == 3 * 512 * 4
+    assert L.fitgnn_greedy_select_workspace_bytes(1000, 6000) > 1000 * 4
+    assert L.fitgnn_lift_adjacency_workspace_bytes(10, 50, 5) > 0
+    assert L.fitgnn_pool_rows_workspace_bytes(100, 50) > 0
+    assert L.fitgnn_build_assignment_workspace_bytes(100) >= 2 * 101 * 4
+
+
+def test_bad_arguments_are_rejected_without_touching_the_gpu():
+    L = _lib.lib()
+    assert L.fitgnn_spmm_csr_f32(None, None, None, None, 4, None, 4, -1, 4, None, 0, None, 0, 0.0, 0, None, None) == -1
+    assert L.fitgnn_spmm_csr_f32(None, None, None, None, 4, None, 4, 0, 4, None, 0, None, 0, 0.0, 0, None, None) == 0
+    assert L.fitgnn_variation_costs_f64(None, None, None, None, None, 17, 17, None, None, None, 1, None, None) == -1
+    assert L.fitgnn_variation_costs_f64(None, None, None, None, None, 10, 10, None, None, None, 0, None, None) == 0
+    assert L.fitgnn_pool_rows_f32(None, None, 5, 0, None, 4, 4, None, 4, None, None, 0, None) == 0
+
+
+def test_no_cpu_fallback():
+    from fitgnn_amd import nn as fnn
+
+    conv = fnn.GCNConv(4, 8)
+    x = torch.randn(5, 4)
+    ei = torch.tensor([[0, 1, 2, 3], [1, 0, 3, 2]])
+    if not torch.cuda.is_available():
+        with pytest.raises(Exception):
+            conv(x, ei)
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "fit-gnn_amd")
+    for d, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(d, f)).read()
+                assert "oracle" not in txt.replace("no oracle", ""), f"{f} mentions the oracle"

@@ -1,0 +1,144 @@
+"""GPU tier: the HIP contraction step vs the CPU oracle, bit-exact, on the golden inputs; and the
+drop-in coarsen() vs the assignment the REAL reference produced (tests/golden)."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import torch
+
+from golden_util import Golden, cases, graph_names
+
+pytestmark = pytest.mark.gpu
+
+CASES = cases()
+_cache = {}
+
+
+def G(name):
+    if name not in _cache:
+        _cache[name] = Golden(name)
+    return _cache[name]
+
+
+@pytest.fixture(scope="module")
+def mods():
+    assert torch.cuda.is_available()
+    from fitgnn_amd import _lib, coarsening
+    from oracle import coarsen_oracle as orc
+
+    return _lib, coarsening, orc
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+
+
+@pytest.mark.parametrize("name", graph_names())
+def test_family_and_costs_bit_exact(mods, name):
+    _lib, co, orc = mods
+    g = G(name)
+    for r in (0.5, 0.9):
+        for li in range(g.n_levels(r)):
+            L = g.level(r, li)
+            Gr = co.Graph(L["W"])
+            res = co.contract_level(Gr, L["A"], L["r_cur"], keep_debug=True)
+            rowptr, col, w = orc._csr32(L["W"])
+            dw = np.ascontiguousarray(Gr.dw)
+            A = np.ascontiguousarray(np.real(L["A"]), dtype=np.float64)
+            off, mem = orc.closed_neighbourhoods(rowptr, col, Gr.N)
+            ref = orc.variation_costs(rowptr, col, w, dw, A, off[:-1].copy(), np.diff(off).astype(np.int32), mem)
+            got = res.cost0.cpu().numpy()
+            assert np.array_equal(_bits(got), _bits(ref)), f"{name} r={r} level {li}: costs differ in bits"
+            # selection, assignment: identical to the oracle run on the same inputs
+            n_reduce = int(np.floor(L["r_cur"] * Gr.N))
+            so, sm, _ = orc.greedy_select(rowptr, col, w, dw, A, off, mem, ref, n_reduce)
+            assert np.array_equal(res.sel_off, so) and np.array_equal(res.sel_mem, sm)
+            assign, cval, n = orc.build_assignment(Gr.N, so, sm)
+            assert res.n == n
+            assert np.array_equal(res.assign.cpu().numpy(), assign)
+            assert np.array_equal(_bits(res.cval.cpu().numpy()), _bits(cval))
+            # lift
+            rp, cc, wc = orc.lift_adjacency(rowptr, col, w, assign, cval, n)
+            Wc = co.lift_adjacency(res)
+            assert np.array_equal(Wc.indptr, rp) and np.array_equal(Wc.indices, cc)
+            assert np.array_equal(_bits(Wc.data), _bits(wc))
+
+
+@pytest.mark.parametrize("name,r", CASES)
+def test_coarsen_matches_reference_assignment(mods, name, r):
+    """Drop-in coarsen() == the real reference's C / assignment / Gc.W / C.X on the golden inputs."""
+    _lib, co, orc = mods
+    g = G(name)
+    fin = g.final(r)
+    C, Gc, maps = co.coarsen(co.Graph(g.W), K=g.K, r=r, method="variation_neighborhoods",
+                             Uk=None if g.Uk is None else g.Uk.copy(), lk=None if g.lk is None else g.lk.copy())
+    Cc = sp.csc_matrix(C)
+    assert Cc.shape == fin["C"].shape
+    assert np.array_equal(Cc.indices, fin["C"].indices), "integer assignment differs from the reference"
+    assert np.array_equal(Cc.data, fin["C"].data)
+    assert len(maps) == fin["n_mapping_dicts"]
+    # composed mapping dicts == assignment (utils.py:113-121)
+    comp = np.array([_compose(maps, i) for i in range(g.N)])
+    assert np.array_equal(comp, fin["assign"])
+    assert Gc.N == fin["GcW"].shape[0]
+    if Gc.N != g.N:
+        assert np.array_equal(Gc.W.indptr, fin["GcW"].indptr) and np.array_equal(Gc.W.indices, fin["GcW"].indices)
+        assert np.array_equal(Gc.W.data, fin["GcW"].data)
+    # pooling through the reference's own spelling C.dot(X)
+    CX = C.dot(g.X)
+    assert np.array_equal(CX, fin["CX64"])
+    Xc = C.pool(torch.from_numpy(g.X).cuda()).cpu().numpy()
+    assert np.array_equal(Xc, fin["CX64"].astype(np.float32))
+
+
+def _compose(maps, i):
+    m = maps[0][i]
+    for d in maps[1:]:
+        m = d[m]
+    return m
+
+
+def test_large_sets_take_the_tiled_path(mods):
+    """A hub with > 64 neighbours exercises the multi-tile branch of the cost kernel (nc > 64)."""
+    _lib, co, orc = mods
+    rng = np.random.default_rng(5)
+    n = 400
+    rows, cols = [], []
+    for leaf in range(1, 200):  # hub 0 with 199 neighbours
+        rows += [0, leaf]; cols += [leaf, 0]
+    for i in range(1, n - 1):
+        rows += [i, i + 1]; cols += [i + 1, i]
+    extra = rng.integers(1, n, size=(2, 300))
+    extra = extra[:, extra[0] != extra[1]]
+    rows += extra[0].tolist() + extra[1].tolist(); cols += extra[1].tolist() + extra[0].tolist()
+    W = sp.csr_matrix((np.ones(len(rows)), (rows, cols)), shape=(n, n)); W.data[:] = 1.0
+    w = rng.uniform(0.5, 2.0, size=W.nnz)
+    Wt = sp.triu(sp.csr_matrix((w, W.indices, W.indptr), shape=W.shape), 1)
+    W = (Wt + Wt.T).tocsr()
+    Gr = co.Graph(W)
+    lam, U = np.linalg.eigh(Gr.L.toarray())
+    A = U[:, 1:11] / np.sqrt(lam[1:11])
+    res = co.contract_level(Gr, A, 0.6, keep_debug=True)
+    rowptr, col, ww = orc._csr32(W)
+    off, mem = orc.closed_neighbourhoods(rowptr, col, n)
+    ref = orc.variation_costs(rowptr, col, ww, np.ascontiguousarray(Gr.dw), np.ascontiguousarray(A), off[:-1].copy(),
+                              np.diff(off).astype(np.int32), mem)
+    assert np.array_equal(_bits(res.cost0.cpu().numpy()), _bits(ref))
+    so, sm, _ = orc.greedy_select(rowptr, col, ww, np.ascontiguousarray(Gr.dw), np.ascontiguousarray(A), off, mem, ref,
+                                  int(np.floor(0.6 * n)))
+    assert np.array_equal(res.sel_off, so) and np.array_equal(res.sel_mem, sm)
+
+
+def test_pool_ragged_feature_width_and_large(mods):
+    _lib, co, orc = mods
+    rng = np.random.default_rng(3)
+    for N, n, F in ((1000, 400, 7), (5000, 1200, 500), (64, 64, 1), (300, 1, 33)):
+        assign = np.sort(rng.integers(0, n, size=N)).astype(np.int32)
+        assign[:n] = np.arange(n)  # every cluster non-empty
+        assign = rng.permutation(assign).astype(np.int32)
+        cval = (1.0 / np.sqrt(np.bincount(assign, minlength=n)))[assign]
+        X = rng.random((N, F), dtype=np.float32)
+        x64, x32 = orc.pool_rows(assign, cval, n, X)
+        got32, got64 = co.pool_rows(torch.from_numpy(assign).cuda(), torch.from_numpy(cval).cuda(), n,
+                                    torch.from_numpy(X).cuda(), want_f64=True)
+        assert np.array_equal(got32.cpu().numpy(), x32)
+        assert np.array_equal(_bits(got64.cpu().numpy()), _bits(x64))

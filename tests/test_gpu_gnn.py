@@ -1,0 +1,140 @@
+"""GPU tier: PyG-signature layers and the network.py classes vs the torch-CPU oracle (eval mode and
+injected-dropout training mode), logits <= 1e-4 rel, gradients <= 1e-3 rel."""
+import argparse
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mods():
+    assert torch.cuda.is_available()
+    from fitgnn_amd import network
+    from fitgnn_amd import nn as fnn
+    from oracle import gnn_oracle as gorc
+
+    return network, fnn, gorc
+
+
+def graph(n=300, m=900, seed=0):
+    rng = np.random.default_rng(seed)
+    a, b = rng.integers(0, n, size=m), rng.integers(0, n, size=m)
+    k = a != b
+    ei = np.unique(np.concatenate([np.stack([a[k], b[k]]), np.stack([b[k], a[k]])], 1), axis=1)
+    return torch.tensor(ei, dtype=torch.long), n
+
+
+def rel(a, b):
+    return float((a - b).abs().max() / b.abs().max().clamp(min=1e-20))
+
+
+def test_gcnconv_forward_backward(mods):
+    network, fnn, gorc = mods
+    ei, n = graph()
+    torch.manual_seed(0)
+    conv = fnn.GCNConv(40, 96).cuda()
+    with torch.no_grad():
+        conv.bias.normal_()
+    x = torch.randn(n, 40)
+    xg = x.cuda().requires_grad_(True)
+    out = conv(xg, ei.cuda())
+    W, b = conv.lin.weight.detach().cpu().requires_grad_(True), conv.bias.detach().cpu().requires_grad_(True)
+    xc = x.clone().requires_grad_(True)
+    ref = gorc.gcn_conv(xc, ei, W, b)
+    assert rel(out.detach().cpu(), ref.detach()) < 1e-4
+    gout = torch.randn(n, 96)
+    out.backward(gout.cuda())
+    ref.backward(gout)
+    assert rel(xg.grad.cpu(), xc.grad) < 1e-4
+    assert rel(conv.lin.weight.grad.cpu(), W.grad) < 1e-3
+    assert rel(conv.bias.grad.cpu(), b.grad) < 1e-4
+
+
+def test_sage_gin_appnp(mods):
+    network, fnn, gorc = mods
+    ei, n = graph(seed=3)
+    torch.manual_seed(1)
+    x = torch.randn(n, 24)
+    sage = fnn.SAGEConv(24, 48).cuda()
+    out = sage(x.cuda(), ei.cuda()).detach().cpu()
+    ref = gorc.sage_conv(x, ei, sage.lin_l.weight.detach().cpu(), sage.lin_l.bias.detach().cpu(), sage.lin_r.weight.detach().cpu())
+    assert rel(out, ref) < 1e-4
+    sage2 = fnn.SAGEConv(24, 8).cuda()  # out < in: transform-then-aggregate branch
+    out = sage2(x.cuda(), ei.cuda()).detach().cpu()
+    ref = gorc.sage_conv(x, ei, sage2.lin_l.weight.detach().cpu(), sage2.lin_l.bias.detach().cpu(), sage2.lin_r.weight.detach().cpu())
+    assert rel(out, ref) < 1e-4
+    mlp = torch.nn.Sequential(torch.nn.Linear(24, 32), torch.nn.ReLU())
+    gin = fnn.GINConv(mlp, train_eps=True).cuda()
+    with torch.no_grad():
+        gin.eps.fill_(0.25)
+    out = gin(x.cuda(), ei.cuda()).detach().cpu()
+    ref = mlp.cpu()(gorc.gin_aggregate(x, ei, 0.25)).detach()
+    assert rel(out, ref) < 1e-4
+    ap = fnn.APPNP(K=10, alpha=0.1)
+    out = ap(x.cuda(), ei.cuda()).cpu()
+    assert rel(out, gorc.appnp(x, ei, 10, 0.1)) < 1e-4
+
+
+@pytest.mark.parametrize("train", [False, True])
+def test_classify_node_logits_loss_grads(mods, train):
+    network, fnn, gorc = mods
+    ei, n = graph(n=500, m=1500, seed=7)
+    args = argparse.Namespace(num_layers1=2, layer_name="GCNConv", num_features=50, hidden=128, num_classes=6)
+    torch.manual_seed(2)
+    model = network.Classify_node(args).cuda()
+    assert sorted(model.state_dict()) == ["conv.0.bias", "conv.0.lin.weight", "conv.1.bias", "conv.1.lin.weight",
+                                          "lt1.bias", "lt1.weight"]
+    x = torch.rand(n, 50)
+    y = torch.randint(0, 6, (n,))
+    tm = torch.rand(n) < 0.3
+    masks = None
+    if train:
+        model.train()
+        masks = [(torch.rand(n, 128) > 0.5).to(torch.uint8) for _ in range(2)]
+        model._inject_masks = [m.cuda() for m in masks]
+    else:
+        model.eval()
+    out = model(x.cuda(), ei.cuda())
+    loss = torch.nn.functional.nll_loss(out[tm.cuda()], y.cuda()[tm.cuda()])
+    loss.backward()
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    o_ref, l_ref, g_ref = gorc.classify_node_fwd_bwd(sd, x, ei, y, num_layers=2, train_mask=tm, masks=masks)
+    assert rel(out.detach().cpu(), o_ref) < 1e-4
+    assert abs(float(loss) - float(l_ref)) < 1e-4 * abs(float(l_ref))
+    for k, p in model.named_parameters():
+        assert rel(p.grad.cpu(), g_ref[k]) < 1e-3, k
+
+
+def test_graph_level_models(mods):
+    network, fnn, gorc = mods
+    from types import SimpleNamespace
+
+    args = argparse.Namespace(num_layers1=2, layer_name="GCNConv", num_features=11, hidden=32, num_classes=1)
+    torch.manual_seed(3)
+    model = network.Regress_graph_gs(args).cuda().eval()
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    rng = np.random.default_rng(0)
+    set_gs, bt, ref_rows = [], [], []
+    for gi in range(5):
+        gs = []
+        for s in range(int(rng.integers(1, 4))):
+            ei, n = graph(n=int(rng.integers(3, 9)), m=12, seed=gi * 10 + s)
+            x = torch.rand(n, 11)
+            mask = torch.rand(n) < 0.7
+            mask[0] = True
+            gs.append(SimpleNamespace(x=x, edge_index=ei, mask=mask))
+            h = x
+            for i in range(2):
+                h = torch.nn.functional.elu(gorc.gcn_conv(h, ei, sd[f"conv.{i}.lin.weight"], sd[f"conv.{i}.bias"]))
+            ref_rows.append(h[mask])
+            bt += [gi] * int(mask.sum())
+        set_gs.append(gs)
+    bt = torch.tensor(bt)
+    out = model(set_gs, bt.cuda()).detach().cpu()
+    H = torch.cat(ref_rows)
+    pooled = torch.stack([H[bt == gi].mean(0) for gi in range(5)])
+    ref = pooled @ sd["lt1.weight"].t() + sd["lt1.bias"]
+    assert rel(out, ref) < 1e-4

@@ -1,0 +1,136 @@
+"""GPU tier: CSR SpMM / gcn_norm / fused epilogue kernels through the C ABI vs the CPU oracle.
+Tolerance: 1e-4 relative fp32 (BASELINE.json north_star)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def mods():
+    assert torch.cuda.is_available()
+    from fitgnn_amd import _lib, csr, ops
+    from oracle import coarsen_oracle as orc
+    from oracle import gnn_oracle as gorc
+
+    return _lib, csr, ops, orc, gorc
+
+
+def block_graph(sizes, seed, p):
+    rng = np.random.default_rng(seed)
+    src, dst, off = [], [], 0
+    for s in sizes:
+        if s > 1:
+            m = max(1, int(p * s * (s - 1) / 2))
+            a = rng.integers(0, s, size=m); b = rng.integers(0, s, size=m)
+            k = a != b
+            src += (off + a[k]).tolist() + (off + b[k]).tolist()
+            dst += (off + b[k]).tolist() + (off + a[k]).tolist()
+        off += s
+    ei = np.unique(np.array([src, dst]), axis=1) if src else np.zeros((2, 0), dtype=np.int64)
+    return torch.tensor(ei, dtype=torch.long), off
+
+
+def rel_err(a, b):
+    return float((a - b).abs().max() / b.abs().max().clamp(min=1e-20))
+
+
+@pytest.mark.parametrize("H", [512, 256, 64, 100, 7, 1, 516])
+@pytest.mark.parametrize("sizes", [[3, 9, 1, 30, 64, 2, 2, 5] * 6, [200, 3, 90], [1] * 70])
+def test_spmm_matches_oracle(mods, H, sizes):
+    _lib, csr, ops, orc, gorc = mods
+    ei, n = block_graph(sizes, seed=len(sizes) + H, p=0.3)
+    g = csr.CSRGraph(ei.cuda(), n, mode="gcn")
+    X = torch.randn(n, H)
+    Y = ops.spmm_raw(g.rowptr, g.col, g.val, g.tiles, X.cuda(), n).cpu()
+    ref = torch.from_numpy(orc.spmm_csr_f32(g.rowptr.cpu().numpy(), g.col.cpu().numpy(), g.val.cpu().numpy(), X.numpy()))
+    assert rel_err(Y, ref) < RTOL
+    # transposed CSR == transpose of the dense matrix
+    Yt = ops.spmm_raw(g.rowptr_t, g.col_t, g.val_t, g.tiles_t, X.cuda(), n).cpu()
+    dense = torch.zeros(n, n)
+    rows = torch.repeat_interleave(torch.arange(n), (g.rowptr[1:] - g.rowptr[:-1]).long().cpu())
+    dense.index_put_((rows, g.col.long().cpu()), g.val.cpu(), accumulate=True)
+    assert rel_err(Yt, dense.t() @ X) < RTOL
+
+
+def test_gcn_norm_matches_pyg_formula(mods):
+    _lib, csr, ops, orc, gorc = mods
+    ei, n = block_graph([40, 7, 1, 100], seed=9, p=0.2)
+    ei = torch.cat([ei, torch.tensor([[3, 3], [3, 3]])], 1)  # duplicated explicit self loop on node 3
+    g = csr.CSRGraph(ei.cuda(), n, mode="gcn")
+    row, col, w = gorc.gcn_norm(ei, n)
+    dense_ref = torch.zeros(n, n).index_put_((col, row), w, accumulate=True)  # [target, source]
+    rows = torch.repeat_interleave(torch.arange(n), (g.rowptr[1:] - g.rowptr[:-1]).long().cpu())
+    dense = torch.zeros(n, n).index_put_((rows, g.col.long().cpu()), g.val.cpu(), accumulate=True)
+    assert torch.allclose(dense, dense_ref, rtol=1e-6, atol=1e-7)
+
+
+def test_window_misses_fall_back_to_global(mods):
+    """Unstructured matrix (one block of 1000 rows): most columns are outside the 64-row LDS window."""
+    _lib, csr, ops, orc, gorc = mods
+    ei, n = block_graph([1000], seed=4, p=0.02)
+    g = csr.CSRGraph(ei.cuda(), n, mode="gcn")
+    assert g.n_tiles == 16
+    X = torch.randn(n, 512)
+    Y = ops.spmm_raw(g.rowptr, g.col, g.val, g.tiles, X.cuda(), n).cpu()
+    ref = torch.from_numpy(orc.spmm_csr_f32(g.rowptr.cpu().numpy(), g.col.cpu().numpy(), g.val.cpu().numpy(), X.numpy()))
+    assert rel_err(Y, ref) < RTOL
+
+
+def test_long_rows(mods):
+    """A hub row with > 64 non-zeros exercises the chunked (64 pairs per pass) row loop."""
+    _lib, csr, ops, orc, gorc = mods
+    n = 500
+    leaves = torch.arange(1, 400)
+    ei = torch.cat([torch.stack([torch.zeros_like(leaves), leaves]), torch.stack([leaves, torch.zeros_like(leaves)])], 1)
+    g = csr.CSRGraph(ei.cuda(), n, mode="gcn")
+    X = torch.randn(n, 256)
+    Y = ops.spmm_raw(g.rowptr, g.col, g.val, g.tiles, X.cuda(), n).cpu()
+    ref = torch.from_numpy(orc.spmm_csr_f32(g.rowptr.cpu().numpy(), g.col.cpu().numpy(), g.val.cpu().numpy(), X.numpy()))
+    assert rel_err(Y, ref) < RTOL
+
+
+@pytest.mark.parametrize("H", [512, 33])
+def test_fused_epilogue_and_its_backward(mods, H):
+    _lib, csr, ops, orc, gorc = mods
+    from fitgnn_amd._lib import EPI_BIAS, EPI_DROPOUT, EPI_ELU
+
+    ei, n = block_graph([20, 5, 64, 3] * 4, seed=2, p=0.3)
+    g = csr.CSRGraph(ei.cuda(), n, mode="gcn")
+    torch.manual_seed(1)
+    X, b = torch.randn(n, H), torch.randn(H)
+    mask = (torch.rand(n, H) > 0.5).to(torch.uint8)
+    base = torch.from_numpy(orc.spmm_csr_f32(g.rowptr.cpu().numpy(), g.col.cpu().numpy(), g.val.cpu().numpy(), X.numpy()))
+    z = base + b
+    ref = torch.nn.functional.elu(z) * mask * 2.0
+    out = ops.spmm_raw(g.rowptr, g.col, g.val, g.tiles, X.cuda(), n, bias=b.cuda(), epilogue=EPI_BIAS | EPI_ELU | EPI_DROPOUT,
+                       p=0.5, mask=mask.cuda())
+    assert rel_err(out.cpu(), ref) < RTOL
+    # backward of the epilogue vs autograd
+    zz = z.clone().requires_grad_(True)
+    o = torch.nn.functional.elu(zz) * mask * 2.0
+    dOut = torch.randn(n, H)
+    o.backward(dOut)
+    dZ, db = ops.epilogue_bwd_raw(dOut.cuda(), out, EPI_ELU | EPI_DROPOUT, p=0.5, mask=mask.cuda())
+    assert rel_err(dZ.cpu(), zz.grad) < RTOL
+    assert rel_err(db.cpu(), zz.grad.sum(0)) < 1e-4
+    # hash-based dropout: forward and backward regenerate the same pattern, keep rate ~ 1-p
+    out2 = ops.spmm_raw(g.rowptr, g.col, g.val, g.tiles, X.cuda(), n, bias=b.cuda(), epilogue=EPI_BIAS | EPI_ELU | EPI_DROPOUT,
+                        p=0.3, seed=1234)
+    kept = (out2 != 0).float().mean().item()
+    assert abs(kept - 0.7) < 0.03
+    dZ2, _ = ops.epilogue_bwd_raw(torch.ones(n, H).cuda(), out2, EPI_ELU | EPI_DROPOUT, p=0.3, seed=1234)
+    assert torch.equal(dZ2 != 0, out2 != 0) or ((dZ2 != 0) ^ (out2 != 0)).float().mean().item() < 1e-3
+
+
+def test_empty_and_degenerate(mods):
+    _lib, csr, ops, orc, gorc = mods
+    g = csr.CSRGraph(torch.zeros((2, 0), dtype=torch.long).cuda(), 5, mode="gcn")  # only self loops
+    X = torch.randn(5, 8)
+    Y = ops.spmm_raw(g.rowptr, g.col, g.val, g.tiles, X.cuda(), 5).cpu()
+    assert torch.allclose(Y, X, rtol=1e-6, atol=1e-7)
+    g0 = csr.CSRGraph(torch.zeros((2, 0), dtype=torch.long).cuda(), 3, mode="sum")  # no entries at all
+    Y0 = ops.spmm_raw(g0.rowptr, g0.col, g0.val, g0.tiles, torch.randn(3, 4).cuda(), 3).cpu()
+    assert torch.count_nonzero(Y0) == 0

@@ -1,0 +1,83 @@
+"""CPU tier: host-side index plumbing (CSR build, block detection, tile packing, graph object)."""
+import numpy as np
+import scipy.sparse as sp
+import torch
+
+from fitgnn_amd.coarsening import Graph
+from fitgnn_amd.csr import CSRGraph, block_boundaries, make_tiles
+
+
+def random_block_graph(sizes, seed=0, p=0.4):
+    rng = np.random.default_rng(seed)
+    src, dst, off = [], [], 0
+    for s in sizes:
+        for i in range(s):
+            for j in range(i + 1, s):
+                if rng.random() < p:
+                    src += [off + i, off + j]
+                    dst += [off + j, off + i]
+        off += s
+    return torch.tensor([src, dst], dtype=torch.long), off
+
+
+def test_csr_and_transpose_match_scipy():
+    ei, n = random_block_graph([5, 1, 9, 3, 30], seed=1)
+    g = CSRGraph(ei, n, mode="gcn")
+    A = sp.coo_matrix((np.ones(ei.shape[1]), (ei[1].numpy(), ei[0].numpy())), shape=(n, n)).tocsr()
+    A = (A + sp.eye(n)).tocsr()
+    A.sort_indices()
+    assert np.array_equal(g.rowptr.numpy(), A.indptr) and np.array_equal(g.col.numpy(), A.indices)
+    At = A.T.tocsr()
+    At.sort_indices()
+    assert np.array_equal(g.rowptr_t.numpy(), At.indptr) and np.array_equal(g.col_t.numpy(), At.indices)
+    # perm_t carries forward values to the transposed slots
+    vals = torch.arange(g.nnz, dtype=torch.float32)
+    dense = torch.zeros(n, n)
+    rows = torch.repeat_interleave(torch.arange(n), (g.rowptr[1:] - g.rowptr[:-1]).long())
+    dense[rows, g.col.long()] = vals
+    rows_t = torch.repeat_interleave(torch.arange(n), (g.rowptr_t[1:] - g.rowptr_t[:-1]).long())
+    assert torch.equal(dense.t()[rows_t, g.col_t.long()], vals[g._perm_t])
+
+
+def test_self_loops_replaced_not_duplicated():
+    ei = torch.tensor([[0, 0, 1, 2, 2], [0, 1, 0, 2, 2]])
+    g = CSRGraph(ei, 3, mode="gcn")
+    assert g.rowptr.tolist() == [0, 2, 4, 5] and g.col.tolist() == [0, 1, 0, 1, 2]
+
+
+def test_block_boundaries_and_tiles():
+    sizes = [5, 1, 9, 3, 30, 2, 2, 70, 4]
+    ei, n = random_block_graph(sizes, seed=2, p=1.0)
+    g = CSRGraph(ei, n, mode="gcn")
+    ptr = block_boundaries(g.rowptr, g.col, n).numpy()
+    assert ptr.tolist() == np.concatenate([[0], np.cumsum(sizes)]).tolist()
+    tiles = make_tiles(ptr, 64)
+    # contiguous cover, each tile <= 64 rows, window == rows, no block split except the 70-node one
+    assert tiles["row_begin"][0] == 0 and tiles["row_end"][-1] == n
+    assert np.all(tiles["row_begin"][1:] == tiles["row_end"][:-1])
+    assert np.all(tiles["row_end"] - tiles["row_begin"] <= 64)
+    assert np.all(tiles["win_begin"] == tiles["row_begin"]) and np.all(tiles["win_rows"] == tiles["row_end"] - tiles["row_begin"])
+    cuts = set(tiles["row_begin"].tolist())
+    big0 = int(np.cumsum(sizes)[6])
+    assert cuts - set(ptr.tolist()) == {big0 + 64}
+
+
+def test_tiles_of_unstructured_matrix_cover_rows():
+    tiles = make_tiles(np.array([0, 1000]), 64)
+    assert len(tiles) == 16 and tiles["row_end"][-1] == 1000
+
+
+def test_empty_graph():
+    g = CSRGraph(torch.zeros((2, 0), dtype=torch.long), 0, mode="sum")
+    assert g.nnz == 0 and g.rowptr.tolist() == [0]
+    assert make_tiles(np.array([0]), 64).shape == (0,)
+
+
+def test_graph_object_matches_pygsp_contract():
+    W = sp.csr_matrix(np.array([[0, 2.0, 0], [2.0, 0, 1.0], [0, 1.0, 0]]))
+    G = Graph(W)
+    assert G.N == 3 and np.allclose(G.dw, [2, 3, 1])
+    assert np.allclose(G.L.toarray(), np.diag([2, 3, 1]) - W.toarray())
+    assert G.A.dtype == bool and G.A.nnz == 4
+    comps = Graph(sp.block_diag([W, sp.csr_matrix((1, 1)), W[:2, :2]])).extract_components()
+    assert [len(c.info["orig_idx"]) for c in comps] == [3, 1, 2]
