@@ -1,0 +1,183 @@
+#!/usr/bin/env python3
+"""bench.py -- edges aggregated/sec (GCN fwd+bwd) on coarsened subgraphs (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+
+Workload (config.workload): S-pubmed = BASELINE.json configs[1] "PubMed node_cls FIT-GNN,
+variation_neighborhoods r=0.5" on synthetic data of PubMed's shape: preferential-
+attachment graph N=19717, E=44324 (graph seed = rank), features U[0,1) row-L1-normalised F=500, 3 classes,
+coarsened by the HIP contraction step (r=0.5), one 1-hop "extra node" subgraph per cluster, all
+subgraph batches merged into one device-resident block-diagonal CSR.  A step = one GD training epoch of
+run.py:177-215: forward over every subgraph (2-layer GCN, hidden 512), one NLL loss, backward, Adam step
+(4 SpMM launches; edges aggregated = 4 * nnz').  N>1 = data parallel over subgraph shards: every rank
+holds its own S-pubmed-sized shard (weak scaling), one flat RCCL gradient all-reduce per step.
+
+Prints ONE JSON line (rank 0) with `roofline` for the SpMM kernel (HIP-event timed inside the timed
+region) and `cpu_baseline` (the torch-CPU oracle of the same step, timed on this host's cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "fit-gnn_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import scipy.sparse as sp  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy ceiling is ~6300
+
+WORKLOADS = {
+    # name: (N, E, F, classes, Loukas r)
+    "S-pubmed": (19717, 44324, 500, 3, 0.5),
+    "S-cora": (2708, 5278, 1433, 7, 0.5),
+}
+
+
+def build_workload(name, seed, device, hidden=512):
+    from fitgnn_amd import coarsening, data
+
+    N, E, F, C, r = WORKLOADS[name]
+    t0 = time.time()
+    ei = data.synthetic_graph(N, E, seed=seed)
+    W = sp.csr_matrix((np.ones(ei.shape[1]), (ei[0], ei[1])), shape=(N, N))
+    G = coarsening.Graph(W)
+    # spectral input of the contraction step (host prelude, coarsening_utils.py:83-90), deterministic start vector
+    import scipy.sparse.linalg as spla
+    offset = 2 * max(G.dw)
+    T = offset * sp.eye(N, format="csc") - G.L
+    lk, Uk = spla.eigsh(T, k=10, which="LM", tol=1e-5, v0=np.random.default_rng(seed).standard_normal(N))
+    lk, Uk = (offset - lk)[::-1], Uk[:, ::-1]
+    t1 = time.time()
+    torch.cuda.synchronize()
+    Cmat, Gc, _ = coarsening.coarsen(G, r=r, method="variation_neighborhoods", Uk=np.ascontiguousarray(Uk), lk=lk.copy(),
+                                     device=device)
+    torch.cuda.synchronize()
+    t2 = time.time()
+    assign = sp.csc_matrix(Cmat).indices
+    sub = data.assemble_subgraphs(ei, N, assign, Cmat.shape[0], extra_node=True)
+    rng = np.random.default_rng(seed + 1)
+    X = rng.random((N, F), dtype=np.float32)
+    X /= X.sum(1, keepdims=True)  # --normalize_features (main.py:48)
+    y = rng.integers(0, C, size=N)
+    train_mask = np.ones(N, dtype=bool)  # every cluster node labelled: every subgraph takes part in the GD step
+    batch = data.SubgraphBatch(sub, X, y, train_mask, device=device)
+    info = dict(nodes=N, undirected_edges=E, features=F, classes=C, clusters=int(Cmat.shape[0]),
+                union_rows=batch.n_rows, nnz_prime=batch.nnz, t_graph_eig_s=round(t1 - t0, 2),
+                t_coarsen_hip_s=round(t2 - t1, 3), t_assemble_s=round(time.time() - t2, 2))
+    return batch, (F, C), info
+
+
+def cpu_baseline(batch, sd, num_layers, budget_s=20.0):
+    """The torch-CPU oracle of the same step (fwd + loss + bwd), timed on this host.  Sample = as many of the
+    reference's 128-subgraph loader batches (run.py:336) as fit the time budget, at least 8."""
+    from oracle import gnn_oracle as gorc
+
+    x, ei, y = batch.x.cpu(), batch.edge_index.cpu(), batch.y.cpu()
+    tm = batch.train_mask.cpu()
+    spans = batch.slice_batches(128)
+
+    def run(k):
+        r1 = spans[k - 1][1]
+        keep = ei[0] < r1
+        e = ei[:, keep]
+        t0 = time.time()
+        gorc.classify_node_fwd_bwd(sd, x[:r1], e, y[:r1], num_layers=num_layers, train_mask=tm[:r1])
+        return time.time() - t0, 4 * (int(e.shape[1]) + r1)
+
+    run(min(2, len(spans)))  # warm-up (thread pools, allocator)
+    k = min(8, len(spans))
+    dt, edges = run(k)
+    if dt < budget_s / 4 and k < len(spans):
+        k = min(len(spans), max(k + 1, int(k * (budget_s / 2) / max(dt, 1e-3))))
+        dt, edges = run(k)
+    return dict(value=edges / dt, unit="edges/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"first {k} of {len(spans)} loader batches (128 subgraphs each), 1 fwd+bwd step, {dt:.2f} s")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="S-pubmed")
+    ap.add_argument("--hidden", type=int, default=512)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group("nccl", device_id=device)
+    assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    from fitgnn_amd import network, ops, train
+
+    batch, (F, C), info = build_workload(args.workload, seed=rank, device=device, hidden=args.hidden)
+    margs = argparse.Namespace(num_layers1=2, layer_name="GCNConv", num_features=F, hidden=args.hidden, num_classes=C)
+    torch.manual_seed(2)  # weight seed; identical on every rank
+    model = network.Classify_node(margs).to(device)
+    sd0 = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    trainer = train.GDTrainer(model, batch, lr=0.01, weight_decay=5e-4)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        trainer.step()
+    barrier()
+    ops.PROFILE = []  # HIP-event pairs around every SpMM launch of the timed region
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = trainer.step()
+    barrier()
+    dt = time.perf_counter() - t0
+    events, ops.PROFILE = ops.PROFILE, None
+    tmax = torch.tensor([dt], device=device, dtype=torch.float64)
+    edges = torch.tensor([4.0 * batch.nnz * args.steps], device=device, dtype=torch.float64)
+    if world > 1:
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        torch.distributed.all_reduce(edges)
+    dt, total_edges = float(tmax.item()), float(edges.item())
+
+    # SpMM roofline: algorithmic bytes of one launch / mean HIP-event duration of the launches in the timed region
+    H, R = args.hidden, batch.n_rows
+    bytes_spmm = 4 * H * R + 4 * H * R + 8 * batch.nnz + 4 * (R + 1)
+    durs_ms = [a.elapsed_time(b) for a, b in events]
+    spmm_ms = float(np.mean(durs_ms)) if durs_ms else float("nan")
+    achieved = bytes_spmm / (spmm_ms * 1e-3) / 1e9
+    out = {
+        "metric": "edges aggregated/sec (GCN fwd+bwd) on coarsened subgraphs",
+        "value": total_edges / dt, "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{args.workload}: variation_neighborhoods r=0.5, extra-node subgraphs, one block-diagonal "
+                               f"union per GPU, 2-layer GCN hidden {H}, GD step + Adam", "parallelism": f"dp{world}", **info},
+        "roofline": {"kernel": "spmm_tile_kernel<4> (CSR SpMM, H=%d, f32)" % H, "bound": "hbm", "achieved": achieved,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "algorithmic_bytes_per_launch": bytes_spmm, "avg_launch_us": spmm_ms * 1e3,
+                     "launches_timed": len(durs_ms), "spmm_edges_per_s": batch.nnz / (spmm_ms * 1e-3)},
+        "loss": float(loss),
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(batch, sd0, 2)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -184,7 +184,8 @@ extern "C" int fitgnn_spmm_csr_f32(const int32_t *rowptr, const int32_t *col, co
                                    float p_drop, uint64_t seed, const uint8_t *mask, void *stream) {
     if (n_rows < 0 || H < 0 || n_tiles < 0) return FITGNN_E_BADARG;
     if (n_rows == 0 || H == 0 || n_tiles == 0) return 0;
-    if (!rowptr || !col || !val || !X || !Y || !tiles) return FITGNN_E_BADARG;
+    // col/val may be NULL only for a matrix without non-zeros (they are then never dereferenced)
+    if (!rowptr || !X || !Y || !tiles) return FITGNN_E_BADARG;
     if ((epilogue & FITGNN_EPI_BIAS) && !bias) return FITGNN_E_BADARG;
     if ((epilogue & FITGNN_EPI_DROPOUT) && !(p_drop >= 0.f && p_drop < 1.f)) return FITGNN_E_BADARG;
     if (ldx < H || ldy < H) return FITGNN_E_BADARG;

@@ -169,3 +169,11 @@ def csr_for(edge_index, num_nodes, mode="gcn"):
         _CACHE.clear()
     _CACHE[key] = (weakref.ref(edge_index), g)
     return g
+
+
+def register(edge_index, graph, mode="gcn"):
+    """Pre-seed the cache with a CSRGraph built with known block boundaries (SubgraphBatch does this)."""
+    key = (edge_index.data_ptr(), int(edge_index._version), tuple(edge_index.shape), int(graph.n), mode,
+           str(edge_index.device))
+    _CACHE[key] = (weakref.ref(edge_index), graph)
+    return graph

@@ -1,0 +1,139 @@
+"""Coarsened-subgraph batches: assembly of the per-cluster subgraphs Gs and their static block-diagonal
+union, device resident.
+
+Reference behaviour restated (utils.py, node-level tasks):
+  * one subgraph per cluster (utils.py:184-267): node set `value` = the cluster's nodes, plus
+      --extra_node   : every 1-hop neighbour outside the cluster           (:235-239, nodes_2_neighbours :58-62)
+      (neither flag) : nothing
+    sorted ascending (:243); M = data.subgraph(value) = the induced subgraph, nodes relabelled by rank (:248);
+  * per-subgraph train/val/test masks = the dataset masks on the cluster's own nodes, False on extra
+    nodes (load_data_classification, utils.py:683-703);
+  * batches: G_DataLoader(batch_size=128, shuffle=False) (run.py:336) -> block-diagonal union, static order.
+The reference builds this with Python loops that rescan all E edges per node (utils.neighbour :52-56);
+here it is a handful of vectorised sorts/searches (host numpy; SURVEY §8 f1 lists a device version as next).
+"""
+import numpy as np
+import torch
+
+from . import csr as _csr
+from .csr import CSRGraph
+
+
+def synthetic_graph(N, E, seed=0):
+    """Connected preferential-attachment graph with exactly N nodes and E undirected edges (E >= 2N-3 uses
+    m=2 attachments per node, the remainder are uniformly random extra edges).  Returns directed
+    edge_index [2, 2E] (both directions, int64 numpy), sorted by (src, dst)."""
+    rng = np.random.default_rng(seed)
+    m = 2 if E >= 2 * N - 3 else 1
+    targets = list(range(m))
+    repeated = []
+    src, dst = [], []
+    for v in range(m, N):
+        for t in set(targets):
+            src.append(v)
+            dst.append(t)
+        repeated.extend(set(targets))
+        repeated.extend([v] * m)
+        idx = rng.integers(0, len(repeated), size=m)
+        targets = [repeated[i] for i in idx]
+    und = {(min(a, b), max(a, b)) for a, b in zip(src, dst)}
+    while len(und) < E:
+        need = E - len(und)
+        a = rng.integers(0, N, size=2 * need + 16)
+        b = rng.integers(0, N, size=2 * need + 16)
+        for x, y in zip(a, b):
+            if x != y:
+                und.add((min(x, y), max(x, y)))
+                if len(und) >= E:
+                    break
+    und = np.array(sorted(und), dtype=np.int64)[:E]
+    ei = np.concatenate([und.T, und.T[::-1]], axis=1)
+    order = np.lexsort((ei[1], ei[0]))
+    return ei[:, order]
+
+
+def assemble_subgraphs(edge_index, num_nodes, assign, n_clusters, extra_node=True):
+    """All cluster subgraphs at once.
+
+    edge_index: int64 [2, E] directed (both directions present), assign: int [N] cluster id per node.
+    Returns dict with (everything numpy):
+      ptr        int64 [n_clusters+1]  rows of subgraph c are ptr[c]:ptr[c+1] of the union
+      node_id    int64 [R]             original node of each union row (sorted ascending inside a subgraph)
+      core       bool  [R]             True for the cluster's own nodes, False for extra nodes
+      edge_index int64 [2, E']         union-row indices, block diagonal
+    """
+    src, dst = np.asarray(edge_index[0], dtype=np.int64), np.asarray(edge_index[1], dtype=np.int64)
+    assign = np.asarray(assign, dtype=np.int64)
+    N = int(num_nodes)
+    # membership pairs (cluster, node): core pairs, plus for --extra_node the outside end of every cut edge
+    pc = [assign, ]
+    pn = [np.arange(N, dtype=np.int64), ]
+    if extra_node:
+        cut = assign[src] != assign[dst]
+        pc.append(assign[src[cut]])
+        pn.append(dst[cut])
+    key = np.unique(np.concatenate(pc) * N + np.concatenate(pn))  # sorted by (cluster, node)
+    mem_c, mem_n = key // N, key % N
+    ptr = np.zeros(n_clusters + 1, dtype=np.int64)
+    np.cumsum(np.bincount(mem_c, minlength=n_clusters), out=ptr[1:])
+    core = assign[mem_n] == mem_c
+    # induced edges: for every member row (c, x) and every neighbour y of x, keep it when (c, y) is a member
+    order = np.lexsort((dst, src))
+    s_src, s_dst = src[order], dst[order]
+    adj_ptr = np.zeros(N + 1, dtype=np.int64)
+    np.cumsum(np.bincount(s_src, minlength=N), out=adj_ptr[1:])
+    deg = adj_ptr[mem_n + 1] - adj_ptr[mem_n]
+    rows = np.repeat(np.arange(len(mem_n), dtype=np.int64), deg)          # union row of x
+    starts = np.repeat(adj_ptr[mem_n], deg)
+    within = np.arange(len(rows), dtype=np.int64) - np.repeat(np.cumsum(deg) - deg, deg)
+    nbr = s_dst[starts + within]                                            # y
+    want = mem_c[rows] * N + nbr
+    pos = np.searchsorted(key, want)
+    pos[pos >= len(key)] = len(key) - 1
+    hit = key[pos] == want
+    e_src, e_dst = rows[hit], pos[hit]                                      # x -> y inside the union
+    return dict(ptr=ptr, node_id=mem_n, core=core, edge_index=np.stack([e_src, e_dst]))
+
+
+class SubgraphBatch:
+    """Device-resident block-diagonal union of cluster subgraphs (one static 'batch of batches').
+
+    The reference trains in GD mode by forwarding every 128-subgraph batch and summing ONE loss over all of
+    them (run.py:184-204); subgraphs share no edges, so one union pass is the same arithmetic."""
+
+    def __init__(self, sub, X, y, train_mask, device="cuda", lds_rows=None):
+        dev = torch.device(device)
+        self.ptr = sub["ptr"]
+        self.n_rows = int(sub["ptr"][-1])
+        self.node_id = torch.from_numpy(sub["node_id"]).to(dev)
+        self.core = torch.from_numpy(sub["core"]).to(dev)
+        self.edge_index = torch.from_numpy(sub["edge_index"]).to(dev)
+        X = X if torch.is_tensor(X) else torch.from_numpy(np.asarray(X))
+        self.x = X.to(dev).float()[self.node_id].contiguous()
+        y = y if torch.is_tensor(y) else torch.from_numpy(np.asarray(y))
+        self.y = y.to(dev)[self.node_id].long()
+        tm = train_mask if torch.is_tensor(train_mask) else torch.from_numpy(np.asarray(train_mask))
+        self.train_mask = tm.to(dev)[self.node_id] & self.core          # utils.py:695-698
+        self.train_idx = torch.nonzero(self.train_mask).flatten()
+        self.graph = None
+        if dev.type == "cuda":
+            self.graph = CSRGraph(self.edge_index, self.n_rows, mode="gcn", ptr=self.ptr, lds_rows=lds_rows)
+            _csr.register(self.edge_index, self.graph, "gcn")  # model(x, edge_index) finds it by identity
+        self.nnz = int(self.edge_index.shape[1]) + self.n_rows           # nnz' = directed edges + self loops
+
+    def slice_batches(self, batch_size=128):
+        """(row_begin, row_end) of the reference's loader batches (run.py:336: 128 subgraphs each)."""
+        c = len(self.ptr) - 1
+        return [(int(self.ptr[b]), int(self.ptr[min(b + batch_size, c)])) for b in range(0, c, batch_size)]
+
+
+def shard_clusters(ptr, nnz_per_cluster, world_size):
+    """Static longest-processing-time assignment of whole subgraphs to ranks, balancing nnz' (SURVEY §8e)."""
+    order = np.argsort(-np.asarray(nnz_per_cluster), kind="stable")
+    load = np.zeros(world_size, dtype=np.int64)
+    owner = np.zeros(len(order), dtype=np.int64)
+    for c in order:
+        r = int(np.argmin(load))
+        owner[c] = r
+        load[r] += int(nnz_per_cluster[c])
+    return owner

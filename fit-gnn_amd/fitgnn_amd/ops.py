@@ -12,6 +12,11 @@ from . import _lib
 from ._lib import EPI_BIAS, EPI_DROPOUT, EPI_ELU
 
 
+# bench.py sets this to a list to collect a (start, end) HIP-event pair around every SpMM launch; the events are
+# recorded on the stream the kernel is launched on (torch's current stream).
+PROFILE = None
+
+
 def _f32c(t):
     if t.dtype != torch.float32:
         t = t.float()
@@ -25,10 +30,17 @@ def spmm_raw(rowptr, col, val, tiles, X, n_rows, bias=None, epilogue=0, p=0.0, s
     X = _f32c(X)
     H = X.shape[1]
     Y = out if out is not None else torch.empty((n_rows, H), dtype=torch.float32, device=X.device)
+    ev = None
+    if PROFILE is not None:
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
     rc = L.fitgnn_spmm_csr_f32(_lib.dptr(rowptr), _lib.dptr(col), _lib.dptr(val), _lib.dptr(X), X.stride(0) if X.numel() else H,
                                _lib.dptr(Y), Y.stride(0) if Y.numel() else H, n_rows, H, _lib.dptr(tiles), int(tiles.shape[0]),
                                _lib.dptr(bias), epilogue, float(p), int(seed) & 0xFFFFFFFFFFFFFFFF, _lib.dptr(mask),
                                _lib.stream_ptr(X.device))
+    if ev is not None:
+        ev[1].record()
+        PROFILE.append(ev)
     _lib.check(rc, "fitgnn_spmm_csr_f32")
     return Y
 

@@ -1,0 +1,67 @@
+"""Training-step functions of FIT-GNN's node-level path, on device-resident static batches.
+
+Restates run.py:177-215 (`node_train_Gs_GD`): forward every batch that holds a train node, concatenate
+the masked outputs, ONE loss over all of them, one backward, one optimiser step per epoch -- executed as
+a single pass over the block-diagonal union (fitgnn_amd.data.SubgraphBatch).  Loss / optimiser as
+run.py:341-344: NLLLoss(reduction=args.loss_reduction), Adam(lr, weight_decay=5e-4).
+Data parallel (new functionality): subgraphs are sharded over ranks, every rank computes
+sum-loss gradients scaled by 1/global_train_count, one flat all-reduce (RCCL) per step, replicated Adam.
+"""
+import torch
+import torch.nn.functional as F
+
+
+class FlatGrads:
+    """All parameter gradients as views into one contiguous buffer -> one all-reduce per step."""
+
+    def __init__(self, params):
+        self.params = [p for p in params if p.requires_grad]
+        n = sum(p.numel() for p in self.params)
+        self.buf = torch.zeros(n, dtype=torch.float32, device=self.params[0].device)
+        off = 0
+        for p in self.params:
+            p.grad = self.buf[off:off + p.numel()].view_as(p)
+            off += p.numel()
+
+    def zero(self):
+        self.buf.zero_()
+
+
+class GDTrainer:
+    def __init__(self, model, batch, lr=0.01, weight_decay=5e-4, reduction="mean", process_group=None):
+        self.model, self.batch = model, batch
+        self.opt = torch.optim.Adam(model.parameters(), lr=lr, weight_decay=weight_decay)
+        self.flat = FlatGrads(model.parameters())
+        self.reduction = reduction
+        self.pg = process_group
+        self.dist = process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()
+                                                  and torch.distributed.get_world_size() > 1)
+        count = torch.tensor([float(batch.train_idx.numel())], device=self.flat.buf.device)
+        if self.dist:
+            torch.distributed.all_reduce(count, group=self.pg)
+        self.global_count = float(count.item())
+
+    def step(self):
+        """One GD epoch (run.py:177-215).  Returns the (global) loss as a 0-dim device tensor."""
+        m, b = self.model, self.batch
+        m.train()
+        self.flat.zero()  # optimizer.zero_grad(); grads live in the flat buffer
+        out = m(b.x, b.edge_index)
+        sel = out.index_select(0, b.train_idx)
+        loss_sum = F.nll_loss(sel, b.y.index_select(0, b.train_idx), reduction="sum")
+        scale = 1.0 / self.global_count if self.reduction == "mean" else 1.0
+        loss = loss_sum * scale
+        loss.backward()
+        if self.dist:
+            torch.distributed.all_reduce(self.flat.buf, group=self.pg)  # one RCCL all-reduce per step
+        self.opt.step()
+        return loss.detach()
+
+    @torch.no_grad()
+    def evaluate(self, mask_idx):
+        self.model.eval()
+        b = self.batch
+        out = self.model(b.x, b.edge_index)
+        sel = out.index_select(0, mask_idx)
+        y = b.y.index_select(0, mask_idx)
+        return F.nll_loss(sel, y), (sel.argmax(1) == y).float().mean()

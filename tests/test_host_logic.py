@@ -81,3 +81,39 @@ def test_graph_object_matches_pygsp_contract():
     assert G.A.dtype == bool and G.A.nnz == 4
     comps = Graph(sp.block_diag([W, sp.csr_matrix((1, 1)), W[:2, :2]])).extract_components()
     assert [len(c.info["orig_idx"]) for c in comps] == [3, 1, 2]
+
+
+def test_subgraph_assembly_matches_bruteforce():
+    """assemble_subgraphs == the per-cluster construction of utils.py:186-267 (--extra_node) done naively."""
+    from fitgnn_amd.data import assemble_subgraphs, synthetic_graph
+
+    ei = synthetic_graph(300, 700, seed=3)
+    assert ei.shape == (2, 1400)
+    rng = np.random.default_rng(0)
+    n_c = 90
+    assign = rng.integers(0, n_c, size=300)
+    assign[:n_c] = np.arange(n_c)
+    for extra in (True, False):
+        sub = assemble_subgraphs(ei, 300, assign, n_c, extra_node=extra)
+        E = set(zip(ei[0].tolist(), ei[1].tolist()))
+        adj = {}
+        for a, b in E:
+            adj.setdefault(a, set()).add(b)
+        got_edges = set(zip(sub["edge_index"][0].tolist(), sub["edge_index"][1].tolist()))
+        want_edges = set()
+        for c in range(n_c):
+            core = set(np.nonzero(assign == c)[0].tolist())
+            value = set(core)
+            if extra:
+                for u in core:
+                    value |= adj.get(u, set())
+            value = sorted(value)
+            r0, r1 = int(sub["ptr"][c]), int(sub["ptr"][c + 1])
+            assert sub["node_id"][r0:r1].tolist() == value
+            assert sub["core"][r0:r1].tolist() == [v in core for v in value]
+            loc = {v: r0 + i for i, v in enumerate(value)}
+            for u in value:
+                for v in adj.get(u, ()):
+                    if v in loc:
+                        want_edges.add((loc[u], loc[v]))
+        assert got_edges == want_edges
