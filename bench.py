@@ -165,7 +165,7 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.workload}: variation_neighborhoods r=0.5, extra-node subgraphs, one block-diagonal "
                                f"union per GPU, 2-layer GCN hidden {H}, GD step + Adam", "parallelism": f"dp{world}", **info},
-        "roofline": {"kernel": "spmm_tile_kernel<4> (CSR SpMM, H=%d, f32)" % H, "bound": "hbm", "achieved": achieved,
+        "roofline": {"kernel": "spmm_tile_kernel<VEC=4,B=4,MPR=16> (CSR SpMM, LDS row windows, H=%d, f32)" % H, "bound": "hbm", "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                      "algorithmic_bytes_per_launch": bytes_spmm, "avg_launch_us": spmm_ms * 1e3,
                      "launches_timed": len(durs_ms), "spmm_edges_per_s": batch.nnz / (spmm_ms * 1e-3)},

@@ -5,6 +5,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
+
 #include "common.h"
 #include "fitgnn_hip.h"
 
@@ -40,13 +42,18 @@ __global__ void gcn_val_kernel(const int32_t *__restrict__ rowptr, const int32_t
     }
 }
 
-constexpr int kChunkRows = 64;
+constexpr int kMaxChunks = 256;  // row chunks of the bias-gradient reduction (one partial row of H floats each)
+
+inline int chunk_rows_for(int n_rows) {
+    const int per = (n_rows + kMaxChunks - 1) / kMaxChunks;
+    return std::max(4, (per + 3) / 4 * 4);
+}
 
 // dZ = dOut * dropout' * elu'  and per-(row chunk) column partial sums for the bias gradient.
 template <int VEC>
 __global__ __launch_bounds__(256) void epilogue_bwd_kernel(const float *__restrict__ dOut, const float *__restrict__ out,
                                                            float *__restrict__ dZ, int32_t n_rows, int32_t H,
-                                                           uint32_t epi, float p_drop, uint64_t seed,
+                                                           int32_t chunk_rows, uint32_t epi, float p_drop, uint64_t seed,
                                                            const uint8_t *__restrict__ mask, float *__restrict__ partial) {
     constexpr int SLAB = 64 * VEC;
     __shared__ float red[4][SLAB];
@@ -54,10 +61,11 @@ __global__ __launch_bounds__(256) void epilogue_bwd_kernel(const float *__restri
     const int wave = threadIdx.x >> 6;
     const int col0 = blockIdx.y * SLAB + lane * VEC;
     const bool live = col0 + VEC <= H;
-    const int r0 = blockIdx.x * kChunkRows;
-    const int r1 = min(r0 + kChunkRows, n_rows);
+    const int r0 = blockIdx.x * chunk_rows;
+    const int r1 = min(r0 + chunk_rows, n_rows);
     const float scale = (epi & FITGNN_EPI_DROPOUT) ? 1.0f / (1.0f - p_drop) : 1.0f;
     const float unscale = (epi & FITGNN_EPI_DROPOUT) ? (1.0f - p_drop) : 1.0f;
+    const uint32_t thresh = fitgnn::dropout_threshold(p_drop);
     float sum[VEC];
 #pragma unroll
     for (int i = 0; i < VEC; ++i) sum[i] = 0.f;
@@ -74,12 +82,14 @@ __global__ __launch_bounds__(256) void epilogue_bwd_kernel(const float *__restri
                 g[0] = dOut[base];
                 o[0] = out[base];
             }
+            uint64_t bits = 0;
+            if ((epi & FITGNN_EPI_DROPOUT) && !mask) bits = fitgnn::dropout_bits(seed, (uint64_t)base >> 2);
 #pragma unroll
             for (int i = 0; i < VEC; ++i) {
                 float d = g[i];
                 if (epi & FITGNN_EPI_DROPOUT) {
                     const uint64_t idx = (uint64_t)base + i;
-                    const bool keep = mask ? (mask[idx] != 0) : fitgnn::dropout_keep(seed, idx, p_drop);
+                    const bool keep = mask ? (mask[idx] != 0) : fitgnn::dropout_keep(bits, (int)(idx & 3), thresh);
                     d = keep ? d * scale : 0.f;
                 }
                 if (epi & FITGNN_EPI_ELU) {
@@ -109,13 +119,18 @@ __global__ __launch_bounds__(256) void epilogue_bwd_kernel(const float *__restri
     }
 }
 
-__global__ void colsum_partials_kernel(const float *__restrict__ partial, int32_t n_chunks, int32_t H,
-                                       float *__restrict__ db) {
-    const int h = blockIdx.x * blockDim.x + threadIdx.x;
-    if (h >= H) return;
+// db[h] = sum over chunks (fixed order: reproducible).  64 columns x 4 chunk-phases per block.
+__global__ __launch_bounds__(256) void colsum_partials_kernel(const float *__restrict__ partial, int32_t n_chunks, int32_t H,
+                                                              float *__restrict__ db) {
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, ph = threadIdx.x >> 6;
+    const int h = blockIdx.x * 64 + lane;
     float s = 0.f;
-    for (int c = 0; c < n_chunks; ++c) s += partial[(int64_t)c * H + h];  // fixed order: reproducible
-    db[h] = s;
+    if (h < H)
+        for (int c = ph; c < n_chunks; c += 4) s += partial[(int64_t)c * H + h];
+    red[ph][lane] = s;
+    __syncthreads();
+    if (ph == 0 && h < H) db[h] = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
 }
 
 }  // namespace
@@ -135,7 +150,8 @@ extern "C" int fitgnn_gcn_norm_csr_f32(const int32_t *rowptr, const int32_t *col
 
 extern "C" size_t fitgnn_epilogue_bwd_workspace_bytes(int32_t n_rows, int32_t H) {
     if (n_rows <= 0 || H <= 0) return 0;
-    const size_t chunks = ((size_t)n_rows + kChunkRows - 1) / kChunkRows;
+    const int cr = chunk_rows_for(n_rows);
+    const size_t chunks = ((size_t)n_rows + cr - 1) / cr;
     return chunks * (size_t)H * sizeof(float);
 }
 
@@ -148,18 +164,19 @@ extern "C" int fitgnn_epilogue_bwd_f32(const float *dOut, const float *out, floa
     if ((epilogue & FITGNN_EPI_DROPOUT) && !(p_drop >= 0.f && p_drop < 1.f)) return FITGNN_E_BADARG;
     if (db && (!work || work_bytes < fitgnn_epilogue_bwd_workspace_bytes(n_rows, H))) return FITGNN_E_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
-    const int chunks = (n_rows + kChunkRows - 1) / kChunkRows;
+    const int cr = chunk_rows_for(n_rows);
+    const int chunks = (n_rows + cr - 1) / cr;
     float *partial = db ? (float *)work : nullptr;
     const bool vec = (H % 4 == 0) && ((((uintptr_t)dOut | (uintptr_t)out | (uintptr_t)dZ) % 16) == 0);
     if (vec) {
         dim3 grid(chunks, (H + 255) / 256);
-        hipLaunchKernelGGL(epilogue_bwd_kernel<4>, grid, dim3(256), 0, s, dOut, out, dZ, n_rows, H, epilogue, p_drop, seed,
+        hipLaunchKernelGGL(epilogue_bwd_kernel<4>, grid, dim3(256), 0, s, dOut, out, dZ, n_rows, H, cr, epilogue, p_drop, seed,
                            mask, partial);
     } else {
         dim3 grid(chunks, (H + 63) / 64);
-        hipLaunchKernelGGL(epilogue_bwd_kernel<1>, grid, dim3(256), 0, s, dOut, out, dZ, n_rows, H, epilogue, p_drop, seed,
+        hipLaunchKernelGGL(epilogue_bwd_kernel<1>, grid, dim3(256), 0, s, dOut, out, dZ, n_rows, H, cr, epilogue, p_drop, seed,
                            mask, partial);
     }
-    if (db) hipLaunchKernelGGL(colsum_partials_kernel, dim3((H + 255) / 256), dim3(256), 0, s, partial, chunks, H, db);
+    if (db) hipLaunchKernelGGL(colsum_partials_kernel, dim3((H + 63) / 64), dim3(256), 0, s, partial, chunks, H, db);
     return (int)hipGetLastError();
 }

@@ -6,8 +6,10 @@
 //
 // Mapping (MI355X): one 256-thread workgroup (4 waves) per (row tile, 64*VEC-column slab).
 //   1. the tile's column window -- rows [win_begin, win_begin+win_rows) of X, slab columns only -- is
-//      streamed HBM -> registers -> LDS with 16-byte coalesced loads (1 KiB per wave instruction);
-//   2. each wave owns rows of the tile round-robin; the row's (col,val) pairs are read 64 at a time,
+//      streamed HBM -> registers -> LDS with 16-byte coalesced loads (1 KiB per wave instruction), up to
+//      8 loads in flight per lane; the tile's slice of the CSR (row pointers, column indices, values) is
+//      staged in LDS next to it, so the row loop never waits on a dependent global load;
+//   2. each wave owns rows of the tile round-robin; the row's (col,val) pairs are taken 64 at a time,
 //      one pair per lane, and broadcast with v_readlane; the lane accumulates its VEC columns from
 //      LDS (window hit, wave-uniform test) or straight from global/L2 (miss);
 //   3. bias / ELU / dropout are applied in registers and the row is stored with one coalesced write.
@@ -16,6 +18,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
+
 #include "common.h"
 #include "fitgnn_hip.h"
 
@@ -23,7 +27,9 @@ namespace {
 
 constexpr int kWaves = 4;
 constexpr int kThreads = kWaves * 64;
-constexpr int kLdsBytes = 64 * 1024;
+constexpr int kDefaultWindowRows = 16;  // LDS rows of the dense operand per workgroup (VEC=4: 1 KiB each)
+constexpr int kMaxWindowRows = 96;
+constexpr int kSmallWindowRows = 16;    // windows up to this size run the high-occupancy instantiation
 
 template <int VEC> struct Pack;
 template <> struct Pack<4> {
@@ -44,73 +50,155 @@ template <> struct Pack<1> {
 };
 
 template <int VEC>
-__global__ __launch_bounds__(kThreads) void spmm_tile_kernel(
+__device__ __forceinline__ void finish_row(typename Pack<VEC>::T acc, int row, int col0, int H, float *__restrict__ Y,
+                                           int64_t ldy, const float (&bv)[VEC], uint32_t epi, float keep_scale,
+                                           uint32_t thresh, uint64_t seed, const uint8_t *__restrict__ mask) {
+    using P = Pack<VEC>;
+    using T = typename P::T;
+    uint64_t bits = 0;
+    const uint64_t idx0 = (uint64_t)row * (uint64_t)H + (uint64_t)col0;
+    if ((epi & FITGNN_EPI_DROPOUT) && !mask) bits = fitgnn::dropout_bits(seed, idx0 >> 2);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+        float z = P::get(acc, i) + bv[i];
+        if (epi & FITGNN_EPI_ELU) z = z > 0.f ? z : __expf(z) - 1.0f;
+        if (epi & FITGNN_EPI_DROPOUT) {
+            const bool keep = mask ? (mask[idx0 + i] != 0) : fitgnn::dropout_keep(bits, (int)((idx0 + i) & 3), thresh);
+            z = keep ? z * keep_scale : 0.f;
+        }
+        P::set(acc, i, z);
+    }
+    *reinterpret_cast<T *>(Y + (int64_t)row * ldy + col0) = acc;
+}
+
+// B = window rows each wave keeps in flight per pass; MPR = staged CSR entries per window row (8 B each).
+// <B=4, MPR=16> needs <= 64 VGPRs and ~18 KiB of LDS for a 16-row window: 8 workgroups (32 waves) per CU, which is
+// what hides the fetch -> compute -> store-acknowledge latency chain of a tile (~8 us under load) at HBM rate.
+template <int VEC, int B, int MPR>
+__global__ __launch_bounds__(kThreads, (B <= 4 ? 8 : 4)) void spmm_tile_kernel(
     const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col, const float *__restrict__ val,
     const float *__restrict__ X, int64_t ldx, float *__restrict__ Y, int64_t ldy, int32_t H,
-    const fitgnn_tile_t *__restrict__ tiles, int32_t n_tiles, int32_t tiles_per_xcd, int32_t lds_rows,
+    const fitgnn_tile_t *__restrict__ tiles, int32_t n_tiles, int32_t tiles_per_xcd, int32_t n_slabs, int32_t lds_rows,
+    const int32_t *__restrict__ lcol, const int32_t *__restrict__ win_cols,
     const float *__restrict__ bias, uint32_t epi, float p_drop, uint64_t seed, const uint8_t *__restrict__ mask) {
     using P = Pack<VEC>;
     using T = typename P::T;
     constexpr int SLAB = 64 * VEC;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    // LDS carve: [window: lds_rows x 64 T][row pointers: lds_rows+1][col: meta_cap][val: meta_cap]
     T *lds = reinterpret_cast<T *>(lds_raw);
+    const int meta_cap = lds_rows * MPR;
+    int32_t *s_rp = reinterpret_cast<int32_t *>(lds_raw + (size_t)lds_rows * 64 * sizeof(T));
+    int32_t *s_col = s_rp + (lds_rows + 1 + 3) / 4 * 4;
+    float *s_val = reinterpret_cast<float *>(s_col + meta_cap);
 
-    // XCD-aware tile mapping: consecutive block ids are dealt round-robin over the 8 XCDs, so give
-    // each XCD a contiguous range of tiles (neighbouring tiles share L2 lines on the miss path).
+    // 1-D grid; block -> (tile, slab).  Blocks are dispatched in id order, round-robin over the 8 XCDs, so the
+    // tile at array position p runs on XCD p % 8: the host lays the tile array out so that every XCD gets a
+    // contiguous, equally heavy range of the batch (csr.arrange_tiles_for_xcds).  The slab is the FASTEST index
+    // inside an XCD's sequence, so both halves of every operand/output row are in flight at the same time (a
+    // slab-major order would stream bytes [0,1K) of every 2 KiB row first and [1K,2K) later).
     const int bid = blockIdx.x;
-    const int t = (bid & 7) * tiles_per_xcd + (bid >> 3);
+    const int seq = bid >> 3;
+    const int slab = seq % n_slabs;
+    const int t = (seq / n_slabs) * 8 + (bid & 7);  // tile array position p runs on XCD p % 8 (host balances it)
     if (t >= n_tiles) return;
     const fitgnn_tile_t tile = tiles[t];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int col0 = blockIdx.y * SLAB + lane * VEC;
+    const int col0 = slab * SLAB + lane * VEC;
     const bool live = col0 + VEC <= H;
+    const float *Xs = X + (live ? col0 : max(H - VEC, 0));  // dead lanes load a valid column group (never stored)
+    const bool planned = lcol != nullptr;                 // columns are LDS slots (>= 0) or -(global col + 1)
+    const bool listed = tile.reserved[0] != 0;            // window rows come from win_cols[]
     const int win_begin = tile.win_begin;
     const int win_rows = min(tile.win_rows, lds_rows);
+    const int tile_rows = tile.row_end - tile.row_begin;
+    const int rp_rows = min(tile_rows, lds_rows);  // rows whose pointers are staged
+    const int32_t *cidx = planned ? lcol : col;
 
-    // ---- stage the window: HBM -> LDS, 4 independent 16-byte loads in flight per lane ----
+    // ---- stage: HBM -> LDS in ONE round trip: the window rows (8 x 16 B per lane in flight), the tile's row
+    // ---- pointers and its (col, val) slice are all addressed from the tile descriptor alone.
+    const int E0 = tile.nnz_begin;
+    const int n_meta = min(tile.nnz_end - E0, meta_cap);
     {
-        int r = wave;
-        for (; r + 3 * kWaves < win_rows; r += 4 * kWaves) {
-            T v0 = P::zero(), v1 = P::zero(), v2 = P::zero(), v3 = P::zero();
-            if (live) {
-                v0 = *reinterpret_cast<const T *>(X + (int64_t)(win_begin + r) * ldx + col0);
-                v1 = *reinterpret_cast<const T *>(X + (int64_t)(win_begin + r + kWaves) * ldx + col0);
-                v2 = *reinterpret_cast<const T *>(X + (int64_t)(win_begin + r + 2 * kWaves) * ldx + col0);
-                v3 = *reinterpret_cast<const T *>(X + (int64_t)(win_begin + r + 3 * kWaves) * ldx + col0);
+        constexpr int MB = B <= 4 ? 1 : 4;  // CSR entries per thread in the first pass
+        int mc[MB];
+        float mv[MB];
+        int rpv = 0;
+        // this wave stages window rows wave, wave+4, ...; for a listed window fetch their operand-row ids first
+        int wcv = 0;
+        if (listed && wave + lane * kWaves < win_rows) wcv = win_cols[win_begin + wave + lane * kWaves];
+        for (int p0 = 0; p0 == 0 || wave + p0 * kWaves < win_rows; p0 += B) {
+            T v[B];
+#pragma unroll
+            for (int j = 0; j < B; ++j) {
+                const int r = wave + (p0 + j) * kWaves;
+                const int rr = min(r, max(win_rows - 1, 0));
+                const int src = listed ? __builtin_amdgcn_readlane(wcv, min(p0 + j, 63)) : win_begin + rr;
+                v[j] = P::zero();
+                if (r < win_rows) v[j] = *reinterpret_cast<const T *>(Xs + (int64_t)src * ldx);
             }
-            lds[(r)*64 + lane] = v0;
-            lds[(r + kWaves) * 64 + lane] = v1;
-            lds[(r + 2 * kWaves) * 64 + lane] = v2;
-            lds[(r + 3 * kWaves) * 64 + lane] = v3;
+            if (p0 == 0) {  // first pass: put the CSR slice in flight behind the window loads
+                if ((int)threadIdx.x <= rp_rows) rpv = rowptr[tile.row_begin + threadIdx.x];
+#pragma unroll
+                for (int j = 0; j < MB; ++j) {
+                    const int i = threadIdx.x + j * kThreads;
+                    mc[j] = 0; mv[j] = 0.f;
+                    if (i < n_meta) { mc[j] = cidx[E0 + i]; mv[j] = val[E0 + i]; }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < B; ++j) {
+                const int r = wave + (p0 + j) * kWaves;
+                if (r < win_rows) lds[r * 64 + lane] = v[j];
+            }
+            if (p0 == 0) {
+                if ((int)threadIdx.x <= rp_rows) s_rp[threadIdx.x] = rpv;
+#pragma unroll
+                for (int j = 0; j < MB; ++j) {
+                    const int i = threadIdx.x + j * kThreads;
+                    if (i < n_meta) { s_col[i] = mc[j]; s_val[i] = mv[j]; }
+                }
+            }
         }
-        for (; r < win_rows; r += kWaves) {
-            T v0 = P::zero();
-            if (live) v0 = *reinterpret_cast<const T *>(X + (int64_t)(win_begin + r) * ldx + col0);
-            lds[r * 64 + lane] = v0;
-        }
+        for (int i = threadIdx.x + kThreads; i <= rp_rows; i += kThreads) s_rp[i] = rowptr[tile.row_begin + i];
+        for (int i = threadIdx.x + MB * kThreads; i < n_meta; i += kThreads) { s_col[i] = cidx[E0 + i]; s_val[i] = val[E0 + i]; }
     }
     __syncthreads();
 
     const float keep_scale = (epi & FITGNN_EPI_DROPOUT) ? 1.0f / (1.0f - p_drop) : 1.0f;
+    const uint32_t thresh = fitgnn::dropout_threshold(p_drop);
+    float bv[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) bv[i] = ((epi & FITGNN_EPI_BIAS) && live) ? bias[col0 + i] : 0.f;
+    // entry value c -> LDS slot (c - slot_off) or, on a miss, the global operand row
+    const int slot_off = planned ? 0 : win_begin;
+    auto gcol = [&](int c) -> int {  // c is already slot-relative
+        if (!planned) return c + slot_off;
+        if (c < 0) return -(c + 1);                                   // planner: operand row not staged
+        return listed ? win_cols[win_begin + c] : win_begin + c;      // staged slot beyond a clamped LDS window
+    };
     for (int row = tile.row_begin + wave; row < tile.row_end; row += kWaves) {
-        const int e0 = __builtin_amdgcn_readfirstlane(rowptr[row]);
-        const int e1 = __builtin_amdgcn_readfirstlane(rowptr[row + 1]);
+        const int lr = row - tile.row_begin;
+        int e0, e1;
+        if (lr < rp_rows) { e0 = s_rp[lr]; e1 = s_rp[lr + 1]; } else { e0 = rowptr[row]; e1 = rowptr[row + 1]; }
+        e0 = __builtin_amdgcn_readfirstlane(e0);
+        e1 = __builtin_amdgcn_readfirstlane(e1);
         T acc = P::zero();
         for (int base = e0; base < e1; base += 64) {
             const int cnt = min(64, e1 - base);
             int my_c = 0;
             float my_v = 0.f;
             if (lane < cnt) {
-                my_c = col[base + lane];
-                my_v = val[base + lane];
+                const int i = base + lane - E0;
+                if (i < n_meta) { my_c = s_col[i]; my_v = s_val[i]; } else { my_c = cidx[base + lane]; my_v = val[base + lane]; }
             }
             int k = 0;
             for (; k + 4 <= cnt; k += 4) {
-                const int c0 = __builtin_amdgcn_readlane(my_c, k) - win_begin;
-                const int c1 = __builtin_amdgcn_readlane(my_c, k + 1) - win_begin;
-                const int c2 = __builtin_amdgcn_readlane(my_c, k + 2) - win_begin;
-                const int c3 = __builtin_amdgcn_readlane(my_c, k + 3) - win_begin;
+                const int c0 = __builtin_amdgcn_readlane(my_c, k) - slot_off;
+                const int c1 = __builtin_amdgcn_readlane(my_c, k + 1) - slot_off;
+                const int c2 = __builtin_amdgcn_readlane(my_c, k + 2) - slot_off;
+                const int c3 = __builtin_amdgcn_readlane(my_c, k + 3) - slot_off;
                 const float w0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_v), k));
                 const float w1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_v), k + 1));
                 const float w2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_v), k + 2));
@@ -122,75 +210,254 @@ __global__ __launch_bounds__(kThreads) void spmm_tile_kernel(
                     x0 = lds[c0 * 64 + lane]; x1 = lds[c1 * 64 + lane];
                     x2 = lds[c2 * 64 + lane]; x3 = lds[c3 * 64 + lane];
                 } else {
-                    x0 = x1 = x2 = x3 = P::zero();
-                    if (in0) x0 = lds[c0 * 64 + lane]; else if (live) x0 = *reinterpret_cast<const T *>(X + (int64_t)(c0 + win_begin) * ldx + col0);
-                    if (in1) x1 = lds[c1 * 64 + lane]; else if (live) x1 = *reinterpret_cast<const T *>(X + (int64_t)(c1 + win_begin) * ldx + col0);
-                    if (in2) x2 = lds[c2 * 64 + lane]; else if (live) x2 = *reinterpret_cast<const T *>(X + (int64_t)(c2 + win_begin) * ldx + col0);
-                    if (in3) x3 = lds[c3 * 64 + lane]; else if (live) x3 = *reinterpret_cast<const T *>(X + (int64_t)(c3 + win_begin) * ldx + col0);
+                    const int g0 = gcol(c0), g1 = gcol(c1), g2 = gcol(c2), g3 = gcol(c3);
+                    if (in0) x0 = lds[c0 * 64 + lane]; else x0 = *reinterpret_cast<const T *>(Xs + (int64_t)g0 * ldx);
+                    if (in1) x1 = lds[c1 * 64 + lane]; else x1 = *reinterpret_cast<const T *>(Xs + (int64_t)g1 * ldx);
+                    if (in2) x2 = lds[c2 * 64 + lane]; else x2 = *reinterpret_cast<const T *>(Xs + (int64_t)g2 * ldx);
+                    if (in3) x3 = lds[c3 * 64 + lane]; else x3 = *reinterpret_cast<const T *>(Xs + (int64_t)g3 * ldx);
                 }
                 P::fma(acc, w0, x0); P::fma(acc, w1, x1); P::fma(acc, w2, x2); P::fma(acc, w3, x3);
             }
             for (; k < cnt; ++k) {
-                const int c = __builtin_amdgcn_readlane(my_c, k) - win_begin;
+                const int c = __builtin_amdgcn_readlane(my_c, k) - slot_off;
                 const float w = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_v), k));
-                T x = P::zero();
+                T x;
                 if ((unsigned)c < (unsigned)win_rows) x = lds[c * 64 + lane];
-                else if (live) x = *reinterpret_cast<const T *>(X + (int64_t)(c + win_begin) * ldx + col0);
+                else x = *reinterpret_cast<const T *>(Xs + (int64_t)gcol(c) * ldx);
                 P::fma(acc, w, x);
             }
         }
-        if (!live) continue;
-        // ---- fused epilogue (GCNConv bias, network.py:32 F.elu, :33 F.dropout) ----
+        if (live) finish_row<VEC>(acc, row, col0, H, Y, ldy, bv, epi, keep_scale, thresh, seed, mask);
+    }
+}
+
+// Direct-gather variant for very sparse batches (few non-zeros per row, e.g. PubMed-like subgraphs with
+// ~3 entries per row): no LDS phase, no barrier.  Each wave owns a CONTIGUOUS run of the tile's rows, so its
+// slice of the CSR is contiguous too: one vector load brings the run's row pointers, one more its (col, val)
+// pairs (<= 64 of them on the fast path), and from then on every index comes out of registers via
+// v_readlane -- the only dependent memory chain is paid once per wave, not once per row.  Operand rows are
+// gathered straight from L2/HBM (a row's ~nnz/N consumers run on the same CU at about the same time), with
+// the gathers of row i+1 issued before the FMAs of row i.
+template <int VEC>
+struct RowQuad {
+    typename Pack<VEC>::T x[4];
+    float w[4];
+    int lo, hi;  // the row's entry range, relative to the wave's slice
+};
+
+// Always issues exactly four operand-row loads (missing entries re-read the row's first operand with weight 0:
+// an L1 hit), so the compiler can count outstanding loads statically and emit vmcnt(N) instead of draining
+// with vmcnt(0) -- which is what lets the next row's gathers stay in flight under this row's FMAs.
+template <int VEC>
+__device__ __forceinline__ void issue_row(RowQuad<VEC> &q, int i, int rp_v, int E0, int my_c, float my_v, const float *Xs,
+                                          int64_t ldx, bool live) {
+    using P = Pack<VEC>;
+    using T = typename P::T;
+    q.lo = __builtin_amdgcn_readlane(rp_v, i) - E0;
+    q.hi = __builtin_amdgcn_readlane(rp_v, i + 1) - E0;
+    const int c_first = __builtin_amdgcn_readlane(my_c, min(q.lo, 63));
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) {
-            float z = P::get(acc, i);
-            if (epi & FITGNN_EPI_BIAS) z += bias[col0 + i];
-            if (epi & FITGNN_EPI_ELU) z = z > 0.f ? z : expm1f(z);
-            if (epi & FITGNN_EPI_DROPOUT) {
-                const uint64_t idx = (uint64_t)row * (uint64_t)H + (uint64_t)(col0 + i);
-                const bool keep = mask ? (mask[idx] != 0) : fitgnn::dropout_keep(seed, idx, p_drop);
-                z = keep ? z * keep_scale : 0.f;
-            }
-            P::set(acc, i, z);
-        }
-        *reinterpret_cast<T *>(Y + (int64_t)row * ldy + col0) = acc;
+    for (int j = 0; j < 4; ++j) {
+        const bool has = q.lo + j < q.hi;
+        const int idx = has ? q.lo + j : min(q.lo, 63);
+        const int c = has ? __builtin_amdgcn_readlane(my_c, idx) : c_first;
+        const float w = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_v), idx));
+        q.w[j] = has ? w : 0.f;
+        q.x[j] = *reinterpret_cast<const T *>(Xs + (int64_t)c * ldx);  // unconditional: Xs is clamped for dead lanes
     }
 }
 
 template <int VEC>
+__device__ __forceinline__ typename Pack<VEC>::T consume_row(const RowQuad<VEC> &q, int my_c, float my_v, const float *Xs,
+                                                            int64_t ldx, bool live) {
+    using P = Pack<VEC>;
+    using T = typename P::T;
+    T acc = P::zero();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) P::fma(acc, q.w[j], q.x[j]);
+    for (int k = q.lo + 4; k < q.hi; ++k) {  // rows with more than four entries
+        const int c = __builtin_amdgcn_readlane(my_c, k);
+        const float w = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_v), k));
+        const T x = *reinterpret_cast<const T *>(Xs + (int64_t)c * ldx);
+        P::fma(acc, w, x);
+    }
+    return acc;
+}
+
+template <int VEC>
+__global__ __launch_bounds__(kThreads) void spmm_gather_kernel(
+    const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col, const float *__restrict__ val,
+    const float *__restrict__ X, int64_t ldx, float *__restrict__ Y, int64_t ldy, int32_t H,
+    const fitgnn_tile_t *__restrict__ tiles, int32_t n_tiles, int32_t tiles_per_xcd, int32_t n_slabs,
+    const float *__restrict__ bias, uint32_t epi, float p_drop, uint64_t seed, const uint8_t *__restrict__ mask) {
+    using P = Pack<VEC>;
+    using T = typename P::T;
+    constexpr int SLAB = 64 * VEC;
+    // 1-D grid; block -> (tile, slab).  Blocks are dispatched in id order, round-robin over the 8 XCDs: give each
+    // XCD a contiguous range of tiles, and make the slab the FASTEST index inside it, so that both halves of
+    // every operand/output row are in flight at the same time (a slab-major order streams bytes [0,1K) of
+    // every 2 KiB row first and [1K,2K) later, i.e. keeps only half of the HBM channels busy).
+    const int bid = blockIdx.x;
+    const int seq = bid >> 3;
+    const int slab = seq % n_slabs;
+    const int t = (seq / n_slabs) * 8 + (bid & 7);  // tile array position p runs on XCD p % 8 (host balances it)
+    if (t >= n_tiles) return;
+    const fitgnn_tile_t tile = tiles[t];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int col0 = slab * SLAB + lane * VEC;
+    const bool live = col0 + VEC <= H;
+    const float keep_scale = (epi & FITGNN_EPI_DROPOUT) ? 1.0f / (1.0f - p_drop) : 1.0f;
+    const uint32_t thresh = fitgnn::dropout_threshold(p_drop);
+    // lanes past the last column (only when H is not a multiple of the slab) load from the last valid
+    // column group instead of being branched around: keeps every load unconditional (static vmcnt counts)
+    const float *Xs = X + (live ? col0 : max(H - VEC, 0));
+    float bv[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) bv[i] = ((epi & FITGNN_EPI_BIAS) && live) ? bias[col0 + i] : 0.f;
+
+    // contiguous run of rows for this wave
+    const int tile_rows = tile.row_end - tile.row_begin;
+    const int per = (tile_rows + kWaves - 1) / kWaves;
+    const int r_lo = tile.row_begin + wave * per;
+    const int r_hi = min(r_lo + per, tile.row_end);
+    const int nrows = r_hi - r_lo;
+    if (nrows <= 0) return;
+    int E0 = 0, E1 = 0, rp_v = 0;
+    if (nrows <= 63) {
+        rp_v = lane <= nrows ? rowptr[r_lo + lane] : 0;
+        E0 = __builtin_amdgcn_readlane(rp_v, 0);
+        E1 = __builtin_amdgcn_readlane(rp_v, nrows);
+    }
+    if (nrows <= 63 && E1 - E0 <= 64) {
+        // ---- fast path: the wave's whole CSR slice sits in two registers ----
+        int my_c = 0;
+        float my_v = 0.f;
+        if (lane < E1 - E0) { my_c = col[E0 + lane]; my_v = val[E0 + lane]; }
+        RowQuad<VEC> qa, qb;
+        issue_row<VEC>(qa, 0, rp_v, E0, my_c, my_v, Xs, ldx, live);
+        int i = 0;
+        for (; i + 1 < nrows; i += 2) {
+            issue_row<VEC>(qb, i + 1, rp_v, E0, my_c, my_v, Xs, ldx, live);
+            const T a0 = consume_row<VEC>(qa, my_c, my_v, Xs, ldx, live);
+            if (live) finish_row<VEC>(a0, r_lo + i, col0, H, Y, ldy, bv, epi, keep_scale, thresh, seed, mask);
+            issue_row<VEC>(qa, min(i + 2, nrows - 1), rp_v, E0, my_c, my_v, Xs, ldx, live);
+            const T a1 = consume_row<VEC>(qb, my_c, my_v, Xs, ldx, live);
+            if (live) finish_row<VEC>(a1, r_lo + i + 1, col0, H, Y, ldy, bv, epi, keep_scale, thresh, seed, mask);
+        }
+        if (i < nrows) {
+            const T a0 = consume_row<VEC>(qa, my_c, my_v, Xs, ldx, live);
+            if (live) finish_row<VEC>(a0, r_lo + i, col0, H, Y, ldy, bv, epi, keep_scale, thresh, seed, mask);
+        }
+        return;
+    }
+    // ---- general path: any row length ----
+    for (int row = r_lo; row < r_hi; ++row) {
+        const int e0 = __builtin_amdgcn_readfirstlane(rowptr[row]);
+        const int e1 = __builtin_amdgcn_readfirstlane(rowptr[row + 1]);
+        T acc = P::zero();
+        for (int base = e0; base < e1; base += 64) {
+            const int cnt = min(64, e1 - base);
+            int my_c = 0;
+            float my_v = 0.f;
+            if (lane < cnt) { my_c = col[base + lane]; my_v = val[base + lane]; }
+            int k = 0;
+            for (; k + 4 <= cnt; k += 4) {
+                const int c0 = __builtin_amdgcn_readlane(my_c, k), c1 = __builtin_amdgcn_readlane(my_c, k + 1);
+                const int c2 = __builtin_amdgcn_readlane(my_c, k + 2), c3 = __builtin_amdgcn_readlane(my_c, k + 3);
+                const float w0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_v), k));
+                const float w1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_v), k + 1));
+                const float w2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_v), k + 2));
+                const float w3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_v), k + 3));
+                T x0 = P::zero(), x1 = P::zero(), x2 = P::zero(), x3 = P::zero();
+                if (live) {
+                    x0 = *reinterpret_cast<const T *>(Xs + (int64_t)c0 * ldx);
+                    x1 = *reinterpret_cast<const T *>(Xs + (int64_t)c1 * ldx);
+                    x2 = *reinterpret_cast<const T *>(Xs + (int64_t)c2 * ldx);
+                    x3 = *reinterpret_cast<const T *>(Xs + (int64_t)c3 * ldx);
+                }
+                P::fma(acc, w0, x0); P::fma(acc, w1, x1); P::fma(acc, w2, x2); P::fma(acc, w3, x3);
+            }
+            for (; k < cnt; ++k) {
+                const int c = __builtin_amdgcn_readlane(my_c, k);
+                const float w = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_v), k));
+                T x = P::zero();
+                if (live) x = *reinterpret_cast<const T *>(Xs + (int64_t)c * ldx);
+                P::fma(acc, w, x);
+            }
+        }
+        if (live) finish_row<VEC>(acc, row, col0, H, Y, ldy, bv, epi, keep_scale, thresh, seed, mask);
+    }
+}
+
+inline size_t lds_bytes_for(int lds_rows, int slab_floats, int mpr) {
+    return (size_t)lds_rows * slab_floats * 4 + (size_t)((lds_rows + 1 + 3) / 4 * 4) * 4 + (size_t)lds_rows * mpr * 8;
+}
+
+template <int VEC, int B, int MPR>
+int launch_tile(const int32_t *rowptr, const int32_t *col, const float *val, const float *X, int64_t ldx, float *Y,
+                int64_t ldy, int32_t H, const fitgnn_tile_t *tiles, int32_t n_tiles, const int32_t *lcol,
+                const int32_t *win_cols, int32_t lds_rows, int n_slabs, int tiles_per_xcd, const float *bias, uint32_t epi,
+                float p_drop, uint64_t seed, const uint8_t *mask, hipStream_t s) {
+    constexpr int SLAB = 64 * VEC;
+    const size_t lds_bytes = lds_bytes_for(lds_rows, SLAB, MPR);
+    if (lds_bytes > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)spmm_tile_kernel<VEC, B, MPR>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return (int)e;
+    }
+    dim3 grid(tiles_per_xcd * 8 * n_slabs);
+    hipLaunchKernelGGL((spmm_tile_kernel<VEC, B, MPR>), grid, dim3(kThreads), lds_bytes, s, rowptr, col, val, X, ldx, Y, ldy,
+                       H, tiles, n_tiles, tiles_per_xcd, n_slabs, lds_rows, lcol, win_cols, bias, epi, p_drop, seed, mask);
+    return (int)hipGetLastError();
+}
+
+template <int VEC>
 int launch(const int32_t *rowptr, const int32_t *col, const float *val, const float *X, int64_t ldx, float *Y,
-           int64_t ldy, int32_t H, const fitgnn_tile_t *tiles, int32_t n_tiles, const float *bias, uint32_t epi,
-           float p_drop, uint64_t seed, const uint8_t *mask, hipStream_t s) {
+           int64_t ldy, int32_t H, const fitgnn_tile_t *tiles, int32_t n_tiles, const int32_t *lcol, const int32_t *win_cols,
+           int32_t window_rows, const float *bias, uint32_t epi, float p_drop, uint64_t seed, const uint8_t *mask,
+           hipStream_t s) {
     constexpr int SLAB = 64 * VEC;
     const int n_slabs = (H + SLAB - 1) / SLAB;
     const int tiles_per_xcd = (n_tiles + 7) / 8;
-    const int lds_rows = kLdsBytes / (SLAB * 4);
-    dim3 grid(tiles_per_xcd * 8, n_slabs);
-    hipLaunchKernelGGL(spmm_tile_kernel<VEC>, grid, dim3(kThreads), kLdsBytes, s, rowptr, col, val, X, ldx, Y, ldy, H,
-                       tiles, n_tiles, tiles_per_xcd, lds_rows, bias, epi, p_drop, seed, mask);
-    return (int)hipGetLastError();
+    if (epi & FITGNN_SPMM_GATHER) {
+        dim3 grid(tiles_per_xcd * 8 * n_slabs);
+        hipLaunchKernelGGL(spmm_gather_kernel<VEC>, grid, dim3(kThreads), 0, s, rowptr, col, val, X, ldx, Y, ldy, H, tiles,
+                           n_tiles, tiles_per_xcd, n_slabs, bias, epi, p_drop, seed, mask);
+        return (int)hipGetLastError();
+    }
+    const int lds_rows = window_rows > 0 ? std::min(window_rows, kMaxWindowRows) : kDefaultWindowRows;
+    if (lds_rows <= kSmallWindowRows)
+        return launch_tile<VEC, 4, 16>(rowptr, col, val, X, ldx, Y, ldy, H, tiles, n_tiles, lcol, win_cols, lds_rows, n_slabs,
+                                       tiles_per_xcd, bias, epi, p_drop, seed, mask, s);
+    return launch_tile<VEC, 8, 32>(rowptr, col, val, X, ldx, Y, ldy, H, tiles, n_tiles, lcol, win_cols, lds_rows, n_slabs,
+                                   tiles_per_xcd, bias, epi, p_drop, seed, mask, s);
 }
 
 }  // namespace
 
+extern "C" int fitgnn_spmm_default_window_rows(void) { return kDefaultWindowRows; }
+
 extern "C" int fitgnn_spmm_max_window_rows(int32_t H) {
-    const bool vec = (H % 4) == 0;
-    return kLdsBytes / ((vec ? 256 : 64) * 4);
+    (void)H;
+    return kMaxWindowRows;
 }
 
 extern "C" int fitgnn_spmm_csr_f32(const int32_t *rowptr, const int32_t *col, const float *val, const float *X,
                                    int64_t ldx, float *Y, int64_t ldy, int32_t n_rows, int32_t H,
-                                   const fitgnn_tile_t *tiles, int32_t n_tiles, const float *bias, uint32_t epilogue,
+                                   const fitgnn_tile_t *tiles, int32_t n_tiles, const int32_t *lcol,
+                                   const int32_t *win_cols, int32_t window_rows, const float *bias, uint32_t epilogue,
                                    float p_drop, uint64_t seed, const uint8_t *mask, void *stream) {
-    if (n_rows < 0 || H < 0 || n_tiles < 0) return FITGNN_E_BADARG;
+    if (n_rows < 0 || H < 0 || n_tiles < 0 || window_rows < 0) return FITGNN_E_BADARG;
     if (n_rows == 0 || H == 0 || n_tiles == 0) return 0;
     // col/val may be NULL only for a matrix without non-zeros (they are then never dereferenced)
     if (!rowptr || !X || !Y || !tiles) return FITGNN_E_BADARG;
     if ((epilogue & FITGNN_EPI_BIAS) && !bias) return FITGNN_E_BADARG;
     if ((epilogue & FITGNN_EPI_DROPOUT) && !(p_drop >= 0.f && p_drop < 1.f)) return FITGNN_E_BADARG;
     if (ldx < H || ldy < H) return FITGNN_E_BADARG;
+    if ((lcol == nullptr) != (win_cols == nullptr) && lcol == nullptr) return FITGNN_E_BADARG;  // win_cols needs lcol
     hipStream_t s = (hipStream_t)stream;
     const bool vec = (H % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) && (((uintptr_t)X | (uintptr_t)Y) % 16 == 0);
-    if (vec) return launch<4>(rowptr, col, val, X, ldx, Y, ldy, H, tiles, n_tiles, bias, epilogue, p_drop, seed, mask, s);
-    return launch<1>(rowptr, col, val, X, ldx, Y, ldy, H, tiles, n_tiles, bias, epilogue, p_drop, seed, mask, s);
+    if (vec) return launch<4>(rowptr, col, val, X, ldx, Y, ldy, H, tiles, n_tiles, lcol, win_cols, window_rows, bias, epilogue, p_drop, seed, mask, s);
+    return launch<1>(rowptr, col, val, X, ldx, Y, ldy, H, tiles, n_tiles, lcol, win_cols, window_rows, bias, epilogue, p_drop, seed, mask, s);
 }

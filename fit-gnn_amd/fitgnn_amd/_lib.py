@@ -14,16 +14,19 @@ c_i32, c_i64, c_u32, c_u64, c_f32, c_size = (ctypes.c_int32, ctypes.c_int64, cty
 ptr = ctypes.c_void_p
 
 EPI_BIAS, EPI_ELU, EPI_DROPOUT = 1, 2, 4
+SPMM_GATHER = 0x100
 MAX_K = 16
 
 # name -> (restype, argtypes); mirrors include/fitgnn_hip.h one to one
 SIGNATURES = {
     "fitgnn_abi_version": (ctypes.c_int, []),
     "fitgnn_error_string": (ctypes.c_char_p, [ctypes.c_int]),
+    "fitgnn_spmm_default_window_rows": (ctypes.c_int, []),
     "fitgnn_spmm_max_window_rows": (ctypes.c_int, [c_i32]),
     "fitgnn_gcn_norm_csr_f32": (ctypes.c_int, [ptr, ptr, ptr, ptr, ptr, c_i32, ptr]),
-    "fitgnn_spmm_csr_f32": (ctypes.c_int, [ptr, ptr, ptr, ptr, c_i64, ptr, c_i64, c_i32, c_i32, ptr, c_i32, ptr, c_u32,
-                                           c_f32, c_u64, ptr, ptr]),
+    "fitgnn_spmm_csr_f32": (ctypes.c_int, [ptr, ptr, ptr, ptr, c_i64, ptr, c_i64, c_i32, c_i32, ptr, c_i32, ptr, ptr,
+                                           c_i32, ptr, c_u32, c_f32, c_u64, ptr, ptr]),
+    "fitgnn_plan_tiles_host": (ctypes.c_int, [ptr, ptr, c_i32, c_i32, ptr, c_i32, c_i32, c_i32, ptr, ptr, ptr, ptr, ptr]),
     "fitgnn_epilogue_bwd_workspace_bytes": (c_size, [c_i32, c_i32]),
     "fitgnn_epilogue_bwd_f32": (ctypes.c_int, [ptr, ptr, ptr, c_i32, c_i32, c_u32, c_f32, c_u64, ptr, ptr, ptr, c_size, ptr]),
     "fitgnn_closed_neighbourhoods": (ctypes.c_int, [ptr, ptr, c_i32, ptr, ptr, ptr]),

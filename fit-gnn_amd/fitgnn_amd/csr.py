@@ -16,6 +16,42 @@ import torch
 from . import _lib
 
 TILE_DTYPE = np.dtype([("row_begin", np.int32), ("row_end", np.int32), ("win_begin", np.int32), ("win_rows", np.int32)])
+TILE_INTS = 8  # sizeof(fitgnn_tile_t) / 4: the four fields above + nnz_begin, nnz_end, reserved[2]
+
+
+def arrange_tiles_for_xcds(tiles8, n_xcd=8):
+    """Lay the tile table out for the kernel's block -> tile mapping (array position p runs on XCD p % 8):
+    every XCD gets a CONTIGUOUS range of the batch (neighbouring tiles share L2 lines) holding an equal share of
+    the work (rows written + operand rows staged), interleaved as out[j*8 + k] = range_k[j]; shorter ranges are
+    padded with empty tiles (row_begin == row_end), which the kernel skips."""
+    t = np.ascontiguousarray(tiles8, dtype=np.int32).reshape(-1, TILE_INTS)
+    T = t.shape[0]
+    if T == 0:
+        return t
+    work = (t[:, 1] - t[:, 0]).astype(np.int64) + t[:, 3].astype(np.int64)
+    cum = np.concatenate([[0], np.cumsum(work)])
+    bounds = np.searchsorted(cum, np.linspace(0, cum[-1], n_xcd + 1), side="left")
+    bounds[0], bounds[-1] = 0, T
+    bounds = np.maximum.accumulate(bounds)
+    L = int(np.max(np.diff(bounds)))
+    out = np.zeros((L * n_xcd, TILE_INTS), dtype=np.int32)
+    for k in range(n_xcd):
+        seg = t[bounds[k]:bounds[k + 1]]
+        out[k:k + len(seg) * n_xcd:n_xcd] = seg
+    return out
+
+
+def tiles_to_device(tiles, rowptr):
+    """Host tile table (TILE_DTYPE) -> device int32 [T, 8] fitgnn_tile_t array with nnz_begin/nnz_end filled
+    from the (device) row pointers."""
+    dev = rowptr.device
+    t4 = torch.from_numpy(np.ascontiguousarray(tiles).view(np.int32).reshape(-1, 4)).to(dev)
+    out = torch.zeros((t4.shape[0], TILE_INTS), dtype=torch.int32, device=dev)
+    out[:, :4] = t4
+    if t4.shape[0]:
+        out[:, 4] = rowptr[t4[:, 0].long()]
+        out[:, 5] = rowptr[t4[:, 1].long()]
+    return torch.from_numpy(arrange_tiles_for_xcds(out.cpu().numpy())).to(dev)
 
 
 def block_boundaries(rowptr, col, n_rows):
@@ -88,67 +124,124 @@ def _csr_from_coo(row, col, n_rows):
     return rowptr.to(torch.int32), col[perm].to(torch.int32).contiguous(), perm
 
 
+class _Side:
+    """One orientation of the pattern (forward or transposed) with its planned tiles."""
+    __slots__ = ("rowptr", "col", "val", "tiles", "lcol", "win_cols", "n_tiles")
+
+    def __init__(self, rowptr, col):
+        self.rowptr, self.col = rowptr, col
+        self.val = self.tiles = self.lcol = self.win_cols = None
+        self.n_tiles = 0
+
+
+def plan_tiles(rowptr, col, n_rows, max_rows, max_window, block_ptr=None):
+    """fitgnn_plan_tiles_host on host copies of the pattern -> (tiles int32 [T,8], win_cols, lcol) numpy."""
+    L = _lib.lib()
+    rp = np.ascontiguousarray(rowptr.detach().cpu().numpy(), dtype=np.int32)
+    cc = np.ascontiguousarray(col.detach().cpu().numpy(), dtype=np.int32)
+    nnz = int(rp[-1]) if n_rows else 0
+    tiles = np.zeros((max(n_rows, 1), TILE_INTS), dtype=np.int32)
+    win = np.zeros(max(nnz, 1), dtype=np.int32)
+    lcol = np.zeros(max(nnz, 1), dtype=np.int32)
+    nt, nw = ctypes.c_int32(0), ctypes.c_int32(0)
+    vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    bp, nb = None, 0
+    if block_ptr is not None:
+        bp = np.ascontiguousarray(block_ptr.detach().cpu().numpy() if torch.is_tensor(block_ptr) else block_ptr, dtype=np.int64)
+        nb = len(bp) - 1
+    _lib.check(L.fitgnn_plan_tiles_host(vp(rp), vp(cc), n_rows, n_rows, None if bp is None else vp(bp), nb, int(max_rows),
+                                        int(max_window), vp(tiles), ctypes.byref(nt), vp(win), ctypes.byref(nw), vp(lcol)),
+               "plan_tiles")
+    return tiles[: nt.value].copy(), win[: max(nw.value, 1)].copy(), lcol[: max(nnz, 1)].copy()
+
+
 class CSRGraph:
     """Device CSR of one static batch: rows = target nodes, columns = source nodes.
 
-    Attributes (torch tensors on `device`): rowptr, col (int32), val (float32, per-mode), and the
-    transposed CSR rowptr_t, col_t, val_t used by the backward pass; tiles / tiles_t (int32 [T,4]).
+    `f` / `t`: the forward and the transposed orientation (the backward pass multiplies by A^T), each with
+    rowptr, col (int32), val (float32) and its planned tiles (tiles, lcol, win_cols).  Legacy aliases:
+    rowptr/col/val/tiles and rowptr_t/col_t/val_t/tiles_t.
     """
 
-    def __init__(self, edge_index, num_nodes, mode="gcn", ptr=None, lds_rows=None):
+    def __init__(self, edge_index, num_nodes, mode="gcn", ptr=None, lds_rows=None, planned=False, gather=False):
         """mode: 'gcn'  -> add_remaining_self_loops + D^-1/2 (A+I) D^-1/2      (GCNConv, APPNP)
                  'sum'  -> plain adjacency, value 1 per edge                  (GINConv aggregation)
                  'mean' -> plain adjacency, value 1/in_degree(target)         (SAGEConv aggregation)
+        planned: tiles from fitgnn_plan_tiles_host (column-set windows for blocks larger than the window);
+        False (default; measured faster on PubMed-like batches, profiles/): contiguous windows packed from the
+        diagonal-block boundaries `ptr` (detected when not given).  gather: use the direct-gather kernel.
         """
         assert edge_index.dim() == 2 and edge_index.shape[0] == 2
         device = edge_index.device
         self.device, self.n, self.mode = device, int(num_nodes), mode
+        self.planned, self.gather = planned, gather
         src, dst = edge_index[0].to(torch.int64), edge_index[1].to(torch.int64)
         if mode == "gcn":
             keep = src != dst
             loop = torch.arange(self.n, device=device, dtype=torch.int64)
             src, dst = torch.cat([src[keep], loop]), torch.cat([dst[keep], loop])
-        self.rowptr, self.col, _ = _csr_from_coo(dst, src, self.n)
-        self.nnz = int(self.col.numel())
+        rowptr, col, _ = _csr_from_coo(dst, src, self.n)
+        self.nnz = int(col.numel())
         # transpose: re-sort the forward entries by (col, row); perm_t carries values across
-        counts = (self.rowptr[1:] - self.rowptr[:-1]).to(torch.int64)
+        counts = (rowptr[1:] - rowptr[:-1]).to(torch.int64)
         rows_f = torch.repeat_interleave(torch.arange(self.n, device=device), counts)
-        self.rowptr_t, self.col_t, self._perm_t = _csr_from_coo(self.col.to(torch.int64), rows_f, self.n)
-        self.val = self.val_t = self.dinv = None
+        rowptr_t, col_t, self._perm_t = _csr_from_coo(col.to(torch.int64), rows_f, self.n)
+        self.f, self.t = _Side(rowptr, col), _Side(rowptr_t, col_t)
+        self.dinv = None
         self._ptr, self._lds_rows = ptr, lds_rows
-        self.tiles = self.tiles_t = None
-        self.n_tiles = 0
+        self.window_rows = 0
         if device.type == "cuda":
             self.finalize()
 
+    # legacy aliases
+    rowptr = property(lambda s: s.f.rowptr)
+    col = property(lambda s: s.f.col)
+    val = property(lambda s: s.f.val)
+    tiles = property(lambda s: s.f.tiles)
+    n_tiles = property(lambda s: s.f.n_tiles)
+    rowptr_t = property(lambda s: s.t.rowptr)
+    col_t = property(lambda s: s.t.col)
+    val_t = property(lambda s: s.t.val)
+    tiles_t = property(lambda s: s.t.tiles)
+
     # -- device-only part: values through the HIP library, tiles sized by the kernel's LDS window --
-    def finalize(self, H_hint=512):
+    def finalize(self):
         L = _lib.lib()
         dev = self.device
-        _lib.require_cuda(self.rowptr)
+        f, t = self.f, self.t
+        _lib.require_cuda(f.rowptr)
         st = _lib.stream_ptr(dev)
         if self.mode == "gcn":
-            self.val = torch.empty(self.nnz, dtype=torch.float32, device=dev)
+            f.val = torch.empty(self.nnz, dtype=torch.float32, device=dev)
             self.dinv = torch.empty(self.n, dtype=torch.float32, device=dev)
-            _lib.check(L.fitgnn_gcn_norm_csr_f32(_lib.dptr(self.rowptr), _lib.dptr(self.col), None, _lib.dptr(self.val),
+            _lib.check(L.fitgnn_gcn_norm_csr_f32(_lib.dptr(f.rowptr), _lib.dptr(f.col), None, _lib.dptr(f.val),
                                                  _lib.dptr(self.dinv), self.n, st), "gcn_norm")
         elif self.mode == "sum":
-            self.val = torch.ones(self.nnz, dtype=torch.float32, device=dev)
+            f.val = torch.ones(self.nnz, dtype=torch.float32, device=dev)
         elif self.mode == "mean":
-            deg = (self.rowptr[1:] - self.rowptr[:-1]).to(torch.float32).clamp(min=1.0)
-            rows = torch.repeat_interleave(torch.arange(self.n, device=dev), (self.rowptr[1:] - self.rowptr[:-1]).to(torch.int64))
-            self.val = (1.0 / deg)[rows].contiguous()
+            deg = (f.rowptr[1:] - f.rowptr[:-1]).to(torch.float32).clamp(min=1.0)
+            rows = torch.repeat_interleave(torch.arange(self.n, device=dev), (f.rowptr[1:] - f.rowptr[:-1]).to(torch.int64))
+            f.val = (1.0 / deg)[rows].contiguous()
         else:
             raise ValueError(self.mode)
-        self.val_t = self.val[self._perm_t].contiguous()
-        cap = self._lds_rows or int(L.fitgnn_spmm_max_window_rows(H_hint))
-        ptr = self._ptr if self._ptr is not None else block_boundaries(self.rowptr, self.col, self.n)
+        t.val = f.val[self._perm_t].contiguous()
+        cap = self._lds_rows or int(L.fitgnn_spmm_default_window_rows())
+        self.window_rows = cap
+        ptr = self._ptr if self._ptr is not None else block_boundaries(f.rowptr, f.col, self.n)
         ptr_np = ptr.detach().cpu().numpy() if torch.is_tensor(ptr) else np.asarray(ptr)
-        tiles = make_tiles(ptr_np, cap)
         self.ptr = ptr_np
-        self.tiles = torch.from_numpy(tiles.view(np.int32).reshape(-1, 4)).to(dev)
-        self.tiles_t = self.tiles  # the transposed pattern has the same diagonal blocks
-        self.n_tiles = int(self.tiles.shape[0])
+        if self.planned:
+            for side in (f, t):  # the transposed pattern has the same diagonal blocks
+                tiles, win, lcol = plan_tiles(side.rowptr, side.col, self.n, cap, cap, block_ptr=ptr_np if len(ptr_np) > 2 else None)
+                side.tiles = torch.from_numpy(arrange_tiles_for_xcds(tiles)).to(dev)
+                side.win_cols = torch.from_numpy(win).to(dev)
+                side.lcol = torch.from_numpy(lcol).to(dev)
+                side.n_tiles = int(tiles.shape[0])
+        else:
+            tiles = make_tiles(ptr_np, cap)
+            for side in (f, t):  # same diagonal blocks, each side its own CSR offsets
+                side.tiles = tiles_to_device(tiles, side.rowptr)
+                side.n_tiles = int(tiles.shape[0])
         return self
 
 

@@ -23,7 +23,8 @@ def _f32c(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
-def spmm_raw(rowptr, col, val, tiles, X, n_rows, bias=None, epilogue=0, p=0.0, seed=0, mask=None, out=None):
+def spmm_raw(rowptr, col, val, tiles, X, n_rows, bias=None, epilogue=0, p=0.0, seed=0, mask=None, out=None, window_rows=0,
+             lcol=None, win_cols=None):
     """Y = epilogue(A @ X) through fitgnn_spmm_csr_f32.  X: [n_cols_of_A, H] f32 contiguous."""
     _lib.require_cuda(rowptr, col, val, tiles, X, bias, mask)
     L = _lib.lib()
@@ -36,7 +37,7 @@ def spmm_raw(rowptr, col, val, tiles, X, n_rows, bias=None, epilogue=0, p=0.0, s
         ev[0].record()
     rc = L.fitgnn_spmm_csr_f32(_lib.dptr(rowptr), _lib.dptr(col), _lib.dptr(val), _lib.dptr(X), X.stride(0) if X.numel() else H,
                                _lib.dptr(Y), Y.stride(0) if Y.numel() else H, n_rows, H, _lib.dptr(tiles), int(tiles.shape[0]),
-                               _lib.dptr(bias), epilogue, float(p), int(seed) & 0xFFFFFFFFFFFFFFFF, _lib.dptr(mask),
+                               _lib.dptr(lcol), _lib.dptr(win_cols), int(window_rows), _lib.dptr(bias), epilogue, float(p), int(seed) & 0xFFFFFFFFFFFFFFFF, _lib.dptr(mask),
                                _lib.stream_ptr(X.device))
     if ev is not None:
         ev[1].record()
@@ -62,6 +63,14 @@ def epilogue_bwd_raw(dOut, out, epilogue, p=0.0, seed=0, mask=None, want_db=True
     return dZ, db
 
 
+def spmm_graph(g, X, transposed=False, **kw):
+    """SpMM with a CSRGraph (forward or transposed pattern), using its planned tiles and kernel variant."""
+    side = g.t if transposed else g.f
+    epi = kw.pop("epilogue", 0) | (_lib.SPMM_GATHER if g.gather else 0)
+    return spmm_raw(side.rowptr, side.col, side.val, side.tiles, X, g.n, epilogue=epi, window_rows=g.window_rows,
+                    lcol=side.lcol, win_cols=side.win_cols, **kw)
+
+
 class SpMM(torch.autograd.Function):
     """Y = A @ X (+ bias).  Backward: dX = A^T @ dY (same kernel on the transposed CSR), db = sum rows."""
 
@@ -70,13 +79,13 @@ class SpMM(torch.autograd.Function):
         ctx.g = g
         ctx.has_bias = bias is not None
         epi = EPI_BIAS if bias is not None else 0
-        return spmm_raw(g.rowptr, g.col, g.val, g.tiles, X, g.n, bias=bias, epilogue=epi)
+        return spmm_graph(g, X, bias=bias, epilogue=epi)
 
     @staticmethod
     def backward(ctx, dY):
         g = ctx.g
         dY = _f32c(dY)
-        dX = spmm_raw(g.rowptr_t, g.col_t, g.val_t, g.tiles_t, dY, g.n) if ctx.needs_input_grad[0] else None
+        dX = spmm_graph(g, dY, transposed=True) if ctx.needs_input_grad[0] else None
         db = dY.sum(0) if ctx.has_bias and ctx.needs_input_grad[1] else None
         return dX, db, None
 
@@ -93,8 +102,7 @@ class FusedGCNLayer(torch.autograd.Function):
         drop = bool(training) and p > 0.0
         if drop:
             epi |= EPI_DROPOUT
-        out = spmm_raw(g.rowptr, g.col, g.val, g.tiles, Hm, g.n, bias=b, epilogue=epi, p=p if drop else 0.0, seed=seed,
-                       mask=mask if drop else None)
+        out = spmm_graph(g, Hm, bias=b, epilogue=epi, p=p if drop else 0.0, seed=seed, mask=mask if drop else None)
         ctx.save_for_backward(X, W, out, mask if drop else None)
         ctx.g, ctx.p, ctx.drop, ctx.seed, ctx.has_bias = g, p, drop, seed, b is not None
         return out
@@ -106,7 +114,7 @@ class FusedGCNLayer(torch.autograd.Function):
         epi = EPI_ELU | (EPI_DROPOUT if ctx.drop else 0)
         dZ, db = epilogue_bwd_raw(dOut, out, epi, p=ctx.p if ctx.drop else 0.0, seed=ctx.seed, mask=mask,
                                   want_db=ctx.has_bias)
-        dH = spmm_raw(g.rowptr_t, g.col_t, g.val_t, g.tiles_t, dZ, g.n)
+        dH = spmm_graph(g, dZ, transposed=True)
         dW = torch.mm(dH.t(), X) if ctx.needs_input_grad[1] else None
         dX = torch.mm(dH, W) if ctx.needs_input_grad[0] else None
         return dX, dW, (db if ctx.has_bias else None), None, None, None, None, None

@@ -42,10 +42,36 @@ const char *fitgnn_error_string(int code);
  * the window are fetched from global memory, so ANY tiling is correct; block-diagonal batches (disjoint
  * subgraphs, utils.py:248) make every column fall inside.  Built once per static batch on the host. */
 typedef struct fitgnn_tile {
-    int32_t row_begin, row_end, win_begin, win_rows;
+    int32_t row_begin, row_end; /* output rows of the tile */
+    int32_t win_begin;          /* reserved[0]==0: first operand row of a contiguous window;
+                                   reserved[0]==1: offset into win_cols[] listing the window's operand rows */
+    int32_t win_rows;           /* operand rows staged in LDS */
+    int32_t nnz_begin, nnz_end; /* = rowptr[row_begin], rowptr[row_end]: lets the kernel fetch the tile's CSR
+                                   slice without first waiting on a row-pointer load */
+    int32_t reserved[2];        /* [0]: window kind (above); [1]: must be 0 */
 } fitgnn_tile_t;
 
-/* Largest win_rows the SpMM kernel can stage for a dense operand with H columns. */
+/* Tile order: the kernel runs the tile at array position p on XCD p % 8 (blocks are dealt round-robin over the
+ * 8 XCDs).  Any order is correct; for speed give each XCD a contiguous, equally heavy range of the batch,
+ * interleaved as tiles[j*8 + k] = range_k[j], padding short ranges with empty tiles (row_begin == row_end).
+ *
+ * HOST function (host pointers, no GPU work): plan the tiles of a square CSR pattern.  block_ptr[0..n_blocks]
+ * (may be NULL) are the row offsets of its diagonal blocks (disjoint subgraphs): whole blocks are packed into
+ * tiles with contiguous windows while they fit min(max_rows, max_window) rows; a larger block -- or the whole
+ * pattern when block_ptr is NULL -- is cut into runs of consecutive rows that have <= max_rows rows and
+ * reference <= max_window distinct operand rows (their window is that set of rows).  Outputs:
+ *   tiles    [capacity n_rows], *n_tiles
+ *   win_cols [capacity nnz], *n_win      operand rows of the non-contiguous windows
+ *   lcol     [nnz]   per non-zero: LDS slot of its operand row inside its tile's window (>= 0), or
+ *                    -(col+1) when the operand row is not staged (read from global memory instead) */
+int fitgnn_plan_tiles_host(const int32_t *rowptr, const int32_t *col, int32_t n_rows, int32_t n_cols,
+                           const int64_t *block_ptr, int32_t n_blocks, int32_t max_rows, int32_t max_window,
+                           fitgnn_tile_t *tiles, int32_t *n_tiles, int32_t *win_cols, int32_t *n_win, int32_t *lcol);
+
+/* LDS window sizes of the SpMM kernel (rows of the dense operand staged per workgroup): the default used
+ * when window_rows == 0, and the largest accepted value.  Tiles should be built with win_rows <= the
+ * window_rows later passed to fitgnn_spmm_csr_f32 (larger windows are clamped: still correct, slower). */
+int fitgnn_spmm_default_window_rows(void);
 int fitgnn_spmm_max_window_rows(int32_t H);
 
 /* gcn_norm of PyG's GCNConv (network.py:31 -> GCNConv.forward): the CSR holds, per TARGET row i, the
@@ -59,17 +85,24 @@ int fitgnn_gcn_norm_csr_f32(const int32_t *rowptr, const int32_t *col, const flo
 #define FITGNN_EPI_BIAS 1u    /* + bias[h]                                   (GCNConv bias) */
 #define FITGNN_EPI_ELU 2u     /* ELU(alpha=1)                                 (network.py:32 F.elu) */
 #define FITGNN_EPI_DROPOUT 4u /* inverted dropout with keep-prob 1-p          (network.py:33 F.dropout) */
+/* kernel-variant hint carried in the same word: skip the LDS window, gather operand rows straight from
+ * L2/HBM -- faster when rows hold only a few non-zeros (identical results) */
+#define FITGNN_SPMM_GATHER 0x100u
 
 /* Y[n_rows x H] = epilogue( A . X ),  A in CSR (int32 indices, f32 values), X,Y row-major f32 with leading
  * dimensions ldx,ldy (elements).  This is GCNConv.propagate (gather + scatter-add over edge_index) done as a
  * segmented reduction per target row; the backward pass is the same call on the transposed CSR.
- * Dropout: element (row,h) is kept iff mask[row*H+h] != 0 when `mask` is given, else iff a counter-based
- * hash of (seed, row*H+h) >= p; kept values are scaled by 1/(1-p).  16-byte aligned X/Y rows (H%4==0 and
+ * lcol / win_cols: outputs of fitgnn_plan_tiles_host (device copies).  Both NULL = every tile has a contiguous
+ * window and `col` is used as is.
+ * window_rows: LDS rows per workgroup (0 = default); see fitgnn_spmm_default_window_rows().
+ * Dropout: element (row,h) is kept iff mask[row*H+h] != 0 when `mask` is given, else iff 16 bits of a
+ * counter-based hash of (seed, (row*H+h)/4) are >= floor(p*65536); kept values are scaled by 1/(1-p).  16-byte aligned X/Y rows (H%4==0 and
  * ld%4==0) take the vector path; anything else takes the scalar path. */
 int fitgnn_spmm_csr_f32(const int32_t *rowptr, const int32_t *col, const float *val, const float *X, int64_t ldx,
                         float *Y, int64_t ldy, int32_t n_rows, int32_t H, const fitgnn_tile_t *tiles,
-                        int32_t n_tiles, const float *bias, uint32_t epilogue, float p_drop, uint64_t seed,
-                        const uint8_t *mask, void *stream);
+                        int32_t n_tiles, const int32_t *lcol, const int32_t *win_cols, int32_t window_rows,
+                        const float *bias, uint32_t epilogue, float p_drop, uint64_t seed, const uint8_t *mask,
+                        void *stream);
 
 /* Backward of the fused epilogue  out = dropout(ELU(z)):  given dOut and the forward OUTPUT `out`
  *   dZ = keep ? dOut * 1/(1-p) * (o > 0 ? 1 : o + 1) : 0,   o = out*(1-p) (pre-dropout ELU value)

@@ -20,7 +20,7 @@ def header_functions():
 def test_library_exports_every_declared_symbol():
     L = _lib.lib()
     names = header_functions()
-    assert len(names) >= 18
+    assert len(names) >= 20
     for n in names:
         assert hasattr(L, n), f"{n} declared in include/fitgnn_hip.h but not exported"
     assert sorted(_lib.SIGNATURES) == names, "ctypes signature table out of sync with the header"
@@ -31,9 +31,9 @@ def test_error_strings_and_size_queries():
     L = _lib.lib()
     assert b"workspace" in L.fitgnn_error_string(-2)
     assert b"bad argument" in L.fitgnn_error_string(-1)
-    assert L.fitgnn_spmm_max_window_rows(512) == 64
-    assert L.fitgnn_spmm_max_window_rows(7) == 256
-    assert L.fitgnn_epilogue_bwd_workspace_bytes(130, 512) == 3 * 512 * 4
+    assert 8 <= L.fitgnn_spmm_default_window_rows() <= L.fitgnn_spmm_max_window_rows(512)
+    assert L.fitgnn_epilogue_bwd_workspace_bytes(130, 512) == 33 * 512 * 4  # 4-row chunks, 33 of them
+    assert L.fitgnn_epilogue_bwd_workspace_bytes(100000, 512) <= 256 * 512 * 4
     assert L.fitgnn_greedy_select_workspace_bytes(1000, 6000) > 1000 * 4
     assert L.fitgnn_lift_adjacency_workspace_bytes(10, 50, 5) > 0
     assert L.fitgnn_pool_rows_workspace_bytes(100, 50) > 0
@@ -42,8 +42,8 @@ def test_error_strings_and_size_queries():
 
 def test_bad_arguments_are_rejected_without_touching_the_gpu():
     L = _lib.lib()
-    assert L.fitgnn_spmm_csr_f32(None, None, None, None, 4, None, 4, -1, 4, None, 0, None, 0, 0.0, 0, None, None) == -1
-    assert L.fitgnn_spmm_csr_f32(None, None, None, None, 4, None, 4, 0, 4, None, 0, None, 0, 0.0, 0, None, None) == 0
+    assert L.fitgnn_spmm_csr_f32(None, None, None, None, 4, None, 4, -1, 4, None, 0, None, None, 0, None, 0, 0.0, 0, None, None) == -1
+    assert L.fitgnn_spmm_csr_f32(None, None, None, None, 4, None, 4, 0, 4, None, 0, None, None, 0, None, 0, 0.0, 0, None, None) == 0
     assert L.fitgnn_variation_costs_f64(None, None, None, None, None, 17, 17, None, None, None, 1, None, None) == -1
     assert L.fitgnn_variation_costs_f64(None, None, None, None, None, 10, 10, None, None, None, 0, None, None) == 0
     assert L.fitgnn_pool_rows_f32(None, None, 5, 0, None, 4, 4, None, 4, None, None, 0, None) == 0

@@ -39,16 +39,23 @@ def rel_err(a, b):
 
 @pytest.mark.parametrize("H", [512, 256, 64, 100, 7, 1, 516])
 @pytest.mark.parametrize("sizes", [[3, 9, 1, 30, 64, 2, 2, 5] * 6, [200, 3, 90], [1] * 70])
-def test_spmm_matches_oracle(mods, H, sizes):
+@pytest.mark.parametrize("window", [None, 8, 64, 96])
+@pytest.mark.parametrize("planned", [True, False])
+def test_spmm_matches_oracle(mods, H, sizes, window, planned):
     _lib, csr, ops, orc, gorc = mods
+    if window is not None and H not in (512, 7):
+        pytest.skip("window sweep on two widths only")
     ei, n = block_graph(sizes, seed=len(sizes) + H, p=0.3)
-    g = csr.CSRGraph(ei.cuda(), n, mode="gcn")
+    g = csr.CSRGraph(ei.cuda(), n, mode="gcn", lds_rows=window, planned=planned)
     X = torch.randn(n, H)
-    Y = ops.spmm_raw(g.rowptr, g.col, g.val, g.tiles, X.cuda(), n).cpu()
+    Y = ops.spmm_graph(g, X.cuda()).cpu()
     ref = torch.from_numpy(orc.spmm_csr_f32(g.rowptr.cpu().numpy(), g.col.cpu().numpy(), g.val.cpu().numpy(), X.numpy()))
     assert rel_err(Y, ref) < RTOL
+    # the direct-gather variant computes the same thing
+    Yg = ops.spmm_graph(g, X.cuda(), epilogue=_lib.SPMM_GATHER).cpu()
+    assert rel_err(Yg, ref) < RTOL
     # transposed CSR == transpose of the dense matrix
-    Yt = ops.spmm_raw(g.rowptr_t, g.col_t, g.val_t, g.tiles_t, X.cuda(), n).cpu()
+    Yt = ops.spmm_graph(g, X.cuda(), transposed=True).cpu()
     dense = torch.zeros(n, n)
     rows = torch.repeat_interleave(torch.arange(n), (g.rowptr[1:] - g.rowptr[:-1]).long().cpu())
     dense.index_put_((rows, g.col.long().cpu()), g.val.cpu(), accumulate=True)
@@ -71,10 +78,61 @@ def test_window_misses_fall_back_to_global(mods):
     """Unstructured matrix (one block of 1000 rows): most columns are outside the 64-row LDS window."""
     _lib, csr, ops, orc, gorc = mods
     ei, n = block_graph([1000], seed=4, p=0.02)
-    g = csr.CSRGraph(ei.cuda(), n, mode="gcn")
-    assert g.n_tiles == 16
+    g = csr.CSRGraph(ei.cuda(), n, mode="gcn", planned=False)
+    tl = g.tiles.cpu().numpy()
+    assert int((tl[:, 1] > tl[:, 0]).sum()) == -(-1000 // g.window_rows)
     X = torch.randn(n, 512)
-    Y = ops.spmm_raw(g.rowptr, g.col, g.val, g.tiles, X.cuda(), n).cpu()
+    Y = ops.spmm_graph(g, X.cuda()).cpu()
+    ref = torch.from_numpy(orc.spmm_csr_f32(g.rowptr.cpu().numpy(), g.col.cpu().numpy(), g.val.cpu().numpy(), X.numpy()))
+    assert rel_err(Y, ref) < RTOL
+
+
+def test_window_smaller_than_tile_is_clamped(mods):
+    """Tiles built for 64-row windows but launched with a 16-row LDS window: misses go to global memory."""
+    _lib, csr, ops, orc, gorc = mods
+    ei, n = block_graph([40, 50, 64, 7] * 3, seed=8, p=0.3)
+    g = csr.CSRGraph(ei.cuda(), n, mode="gcn", lds_rows=64, planned=False)
+    X = torch.randn(n, 512)
+    Y = ops.spmm_raw(g.rowptr, g.col, g.val, g.tiles, X.cuda(), n, window_rows=16).cpu()
+    gp = csr.CSRGraph(ei.cuda(), n, mode="gcn", lds_rows=64, planned=True)   # planned for 64, launched with 16
+    Yp = ops.spmm_raw(gp.rowptr, gp.col, gp.val, gp.tiles, X.cuda(), n, window_rows=16, lcol=gp.f.lcol,
+                      win_cols=gp.f.win_cols).cpu()
+    ref = torch.from_numpy(orc.spmm_csr_f32(g.rowptr.cpu().numpy(), g.col.cpu().numpy(), g.val.cpu().numpy(), X.numpy()))
+    assert rel_err(Y, ref) < RTOL
+    assert rel_err(Yp, ref) < RTOL
+
+
+def test_hub_subgraph_larger_than_window_is_planned_into_lds(mods):
+    """Star subgraphs bigger than the window: the planner's column-set windows keep the hub row in LDS."""
+    _lib, csr, ops, orc, gorc = mods
+    src, dst, off = [], [], 0
+    for leaves in (150, 40, 7, 90):
+        for l in range(1, leaves + 1):
+            src += [off, off + l]; dst += [off + l, off]
+        off += leaves + 1
+    ei = torch.tensor([src, dst], dtype=torch.long)
+    g = csr.CSRGraph(ei.cuda(), off, mode="gcn", lds_rows=24)
+    lc = g.f.lcol.cpu().numpy()
+    # every leaf row finds hub + itself in LDS; only the hub rows (wider than the window) go to global memory
+    assert (lc < 0).mean() < 0.3
+    X = torch.randn(off, 512)
+    Y = ops.spmm_graph(g, X.cuda()).cpu()
+    ref = torch.from_numpy(orc.spmm_csr_f32(g.rowptr.cpu().numpy(), g.col.cpu().numpy(), g.val.cpu().numpy(), X.numpy()))
+    assert rel_err(Y, ref) < RTOL
+    Yt = ops.spmm_graph(g, X.cuda(), transposed=True).cpu()
+    assert rel_err(Yt, ref) < RTOL  # symmetric matrix
+
+
+def test_dense_tile_overflows_the_staged_csr_slice(mods):
+    """A complete graph on 60 nodes has 3600 entries per tile > the staged CSR slice (32 per window row)."""
+    _lib, csr, ops, orc, gorc = mods
+    a, b = np.meshgrid(np.arange(60), np.arange(60))
+    k = a != b
+    ei = torch.tensor(np.stack([a[k], b[k]]), dtype=torch.long)
+    ei = torch.cat([ei, ei + 60], 1)
+    g = csr.CSRGraph(ei.cuda(), 120, mode="gcn", lds_rows=64)
+    X = torch.randn(120, 256)
+    Y = ops.spmm_graph(g, X.cuda()).cpu()
     ref = torch.from_numpy(orc.spmm_csr_f32(g.rowptr.cpu().numpy(), g.col.cpu().numpy(), g.val.cpu().numpy(), X.numpy()))
     assert rel_err(Y, ref) < RTOL
 
@@ -87,7 +145,7 @@ def test_long_rows(mods):
     ei = torch.cat([torch.stack([torch.zeros_like(leaves), leaves]), torch.stack([leaves, torch.zeros_like(leaves)])], 1)
     g = csr.CSRGraph(ei.cuda(), n, mode="gcn")
     X = torch.randn(n, 256)
-    Y = ops.spmm_raw(g.rowptr, g.col, g.val, g.tiles, X.cuda(), n).cpu()
+    Y = ops.spmm_graph(g, X.cuda()).cpu()
     ref = torch.from_numpy(orc.spmm_csr_f32(g.rowptr.cpu().numpy(), g.col.cpu().numpy(), g.val.cpu().numpy(), X.numpy()))
     assert rel_err(Y, ref) < RTOL
 
@@ -105,9 +163,11 @@ def test_fused_epilogue_and_its_backward(mods, H):
     base = torch.from_numpy(orc.spmm_csr_f32(g.rowptr.cpu().numpy(), g.col.cpu().numpy(), g.val.cpu().numpy(), X.numpy()))
     z = base + b
     ref = torch.nn.functional.elu(z) * mask * 2.0
-    out = ops.spmm_raw(g.rowptr, g.col, g.val, g.tiles, X.cuda(), n, bias=b.cuda(), epilogue=EPI_BIAS | EPI_ELU | EPI_DROPOUT,
-                       p=0.5, mask=mask.cuda())
+    out = ops.spmm_graph(g, X.cuda(), bias=b.cuda(), epilogue=EPI_BIAS | EPI_ELU | EPI_DROPOUT, p=0.5, mask=mask.cuda())
     assert rel_err(out.cpu(), ref) < RTOL
+    outg = ops.spmm_graph(g, X.cuda(), bias=b.cuda(), epilogue=EPI_BIAS | EPI_ELU | EPI_DROPOUT | _lib.SPMM_GATHER, p=0.5,
+                          mask=mask.cuda())
+    assert rel_err(outg.cpu(), ref) < RTOL
     # backward of the epilogue vs autograd
     zz = z.clone().requires_grad_(True)
     o = torch.nn.functional.elu(zz) * mask * 2.0
@@ -117,8 +177,9 @@ def test_fused_epilogue_and_its_backward(mods, H):
     assert rel_err(dZ.cpu(), zz.grad) < RTOL
     assert rel_err(db.cpu(), zz.grad.sum(0)) < 1e-4
     # hash-based dropout: forward and backward regenerate the same pattern, keep rate ~ 1-p
-    out2 = ops.spmm_raw(g.rowptr, g.col, g.val, g.tiles, X.cuda(), n, bias=b.cuda(), epilogue=EPI_BIAS | EPI_ELU | EPI_DROPOUT,
-                        p=0.3, seed=1234)
+    out2 = ops.spmm_graph(g, X.cuda(), bias=b.cuda(), epilogue=EPI_BIAS | EPI_ELU | EPI_DROPOUT, p=0.3, seed=1234)
+    out2g = ops.spmm_graph(g, X.cuda(), bias=b.cuda(), epilogue=EPI_BIAS | EPI_ELU | EPI_DROPOUT | _lib.SPMM_GATHER, p=0.3, seed=1234)
+    assert torch.equal(out2g != 0, out2 != 0)  # both variants draw the same dropout pattern
     kept = (out2 != 0).float().mean().item()
     assert abs(kept - 0.7) < 0.03
     dZ2, _ = ops.epilogue_bwd_raw(torch.ones(n, H).cuda(), out2, EPI_ELU | EPI_DROPOUT, p=0.3, seed=1234)
@@ -129,8 +190,8 @@ def test_empty_and_degenerate(mods):
     _lib, csr, ops, orc, gorc = mods
     g = csr.CSRGraph(torch.zeros((2, 0), dtype=torch.long).cuda(), 5, mode="gcn")  # only self loops
     X = torch.randn(5, 8)
-    Y = ops.spmm_raw(g.rowptr, g.col, g.val, g.tiles, X.cuda(), 5).cpu()
+    Y = ops.spmm_graph(g, X.cuda()).cpu()
     assert torch.allclose(Y, X, rtol=1e-6, atol=1e-7)
     g0 = csr.CSRGraph(torch.zeros((2, 0), dtype=torch.long).cuda(), 3, mode="sum")  # no entries at all
-    Y0 = ops.spmm_raw(g0.rowptr, g0.col, g0.val, g0.tiles, torch.randn(3, 4).cuda(), 3).cpu()
+    Y0 = ops.spmm_graph(g0, torch.randn(3, 4).cuda()).cpu()
     assert torch.count_nonzero(Y0) == 0

@@ -117,3 +117,68 @@ def test_subgraph_assembly_matches_bruteforce():
                     if v in loc:
                         want_edges.add((loc[u], loc[v]))
         assert got_edges == want_edges
+
+
+def test_tile_planner_invariants():
+    """fitgnn_plan_tiles_host: contiguous row cover, row/window caps, lcol consistent with the windows."""
+    from fitgnn_amd.csr import plan_tiles
+
+    rng = np.random.default_rng(1)
+    sizes = [3, 40, 1, 150, 9, 9, 2, 70, 5] * 3
+    ei, n = random_block_graph(sizes, seed=5, p=0.15)
+    # add hubs: node 0 of each big block linked to everyone in the block
+    off, src, dst = 0, [], []
+    for s_ in sizes:
+        if s_ > 30:
+            for j in range(1, s_):
+                src += [off, off + j]; dst += [off + j, off]
+        off += s_
+    ei = torch.cat([ei, torch.tensor([src, dst], dtype=torch.long)], 1)
+    g = CSRGraph(ei, n, mode="gcn")
+    bptr = np.concatenate([[0], np.cumsum(sizes)])
+    for max_rows, max_win, bp in ((16, 16, None), (8, 24, None), (32, 32, None), (4, 4, None), (16, 16, bptr), (24, 24, bptr)):
+        tiles, win, lcol = plan_tiles(g.rowptr, g.col, n, max_rows, max_win, block_ptr=bp)
+        if bp is not None:  # blocks that fit are never split
+            cuts = set(tiles[:, 0].tolist())
+            for b0, b1 in zip(bp[:-1], bp[1:]):
+                if b1 - b0 <= min(max_rows, max_win):
+                    assert not any(b0 < c < b1 for c in cuts)
+        rp, col = g.rowptr.numpy(), g.col.numpy()
+        assert tiles[0, 0] == 0 and tiles[-1, 1] == n and np.all(tiles[1:, 0] == tiles[:-1, 1])
+        assert np.all(tiles[:, 1] - tiles[:, 0] <= max_rows) and np.all(tiles[:, 1] > tiles[:, 0])
+        assert np.all(tiles[:, 3] <= max_win)
+        assert np.all(tiles[:, 4] == rp[tiles[:, 0]]) and np.all(tiles[:, 5] == rp[tiles[:, 1]])
+        hits = 0
+        for t in tiles:
+            wcols = win[t[2]: t[2] + t[3]] if t[6] else np.arange(t[2], t[2] + t[3])
+            assert np.all(np.diff(wcols) > 0)
+            for e in range(t[4], t[5]):
+                if lcol[e] >= 0:
+                    assert wcols[lcol[e]] == col[e]
+                    hits += 1
+                else:
+                    assert -(lcol[e] + 1) == col[e]
+        if max_win >= 16:
+            assert hits / len(col) > 0.6  # dense random blocks cannot fit; star-shaped ones do (GPU test)
+
+
+def test_xcd_tile_layout_is_balanced_and_complete():
+    from fitgnn_amd.csr import TILE_INTS, arrange_tiles_for_xcds
+
+    rng = np.random.default_rng(0)
+    T = 1003
+    rows = rng.integers(1, 17, size=T)
+    rows[:100] = 16  # heavy head, light tail
+    rb = np.concatenate([[0], np.cumsum(rows)])
+    t = np.zeros((T, TILE_INTS), dtype=np.int32)
+    t[:, 0], t[:, 1], t[:, 2], t[:, 3] = rb[:-1], rb[1:], rb[:-1], rows
+    out = arrange_tiles_for_xcds(t)
+    assert out.shape[0] % 8 == 0
+    live = out[out[:, 1] > out[:, 0]]
+    assert len(live) == T and sorted(live[:, 0].tolist()) == t[:, 0].tolist()
+    per_xcd = [int((out[k::8, 1] - out[k::8, 0]).sum()) for k in range(8)]
+    assert max(per_xcd) - min(per_xcd) <= 2 * 16 + 16
+    for k in range(8):  # each XCD walks a contiguous ascending range
+        seg = out[k::8]
+        seg = seg[seg[:, 1] > seg[:, 0]]
+        assert np.all(seg[1:, 0] == seg[:-1, 1])
