@@ -108,6 +108,9 @@ def main():
     ap.add_argument("--workload", default="S-pubmed")
     ap.add_argument("--hidden", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gemm-precision", default="high", choices=["high", "highest"],
+                    help="dense GEMM policy (fitgnn_amd.ops.GEMM_PRECISION): high = fp32 via 3xbf16 split on the forward/dX "
+                         "products (rel err ~5e-6), highest = plain fp32 MFMA everywhere")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -122,6 +125,8 @@ def main():
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from fitgnn_amd import network, ops, train
+
+    ops.GEMM_PRECISION = args.gemm_precision
 
     batch, (F, C), info = build_workload(args.workload, seed=rank, device=device, hidden=args.hidden)
     margs = argparse.Namespace(num_layers1=2, layer_name="GCNConv", num_features=F, hidden=args.hidden, num_classes=C)
@@ -164,7 +169,10 @@ def main():
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.workload}: variation_neighborhoods r=0.5, extra-node subgraphs, one block-diagonal "
-                               f"union per GPU, 2-layer GCN hidden {H}, GD step + Adam", "parallelism": f"dp{world}", **info},
+                               f"union per GPU, 2-layer GCN hidden {H}, GD step + Adam", "parallelism": f"dp{world}",
+                   "dense_gemm": ("hipBLASLt fp32 operands, 3xbf16-split MFMA for X@W^T and dH@W (rel err ~5e-6 vs fp64), "
+                                  "fp32 MFMA for dH^T@X") if args.gemm_precision == "high" else "hipBLASLt fp32 MFMA",
+                   **info},
         "roofline": {"kernel": "spmm_tile_kernel<VEC=4,B=4,MPR=16> (CSR SpMM, LDS row windows, H=%d, f32)" % H, "bound": "hbm", "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                      "algorithmic_bytes_per_launch": bytes_spmm, "avg_launch_us": spmm_ms * 1e3,

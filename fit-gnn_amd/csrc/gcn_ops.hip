@@ -50,13 +50,22 @@ inline int chunk_rows_for(int n_rows) {
 }
 
 // dZ = dOut * dropout' * elu'  and per-(row chunk) column partial sums for the bias gradient.
-template <int VEC>
+constexpr int kMaxHeadC = 16;  // widest head (classes) whose backward is folded into this kernel
+
+// dOut is either read (HEAD == false) or formed on the fly as dy @ Wl (HEAD == true: the backward of the output
+// head lt1, network.py:34, whose K = num_classes GEMM would otherwise write and re-read a full [rows x H] matrix).
+// CW > 0 (HEAD only): also accumulate the head's weight gradient dWl[c][h] = sum_rows dy[row][c] * out[row][h] for
+// c < C <= CW in registers (out is being read anyway), reduced through partialW like the bias gradient.
+template <int VEC, bool HEAD, int CW>
 __global__ __launch_bounds__(256) void epilogue_bwd_kernel(const float *__restrict__ dOut, const float *__restrict__ out,
                                                            float *__restrict__ dZ, int32_t n_rows, int32_t H,
                                                            int32_t chunk_rows, uint32_t epi, float p_drop, uint64_t seed,
-                                                           const uint8_t *__restrict__ mask, float *__restrict__ partial) {
+                                                           const uint8_t *__restrict__ mask, float *__restrict__ partial,
+                                                           const float *__restrict__ dy, const float *__restrict__ Wl,
+                                                           int32_t C, float *__restrict__ partialW) {
     constexpr int SLAB = 64 * VEC;
     __shared__ float red[4][SLAB];
+    __shared__ float s_w[HEAD ? kMaxHeadC * SLAB : 1];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int col0 = blockIdx.y * SLAB + lane * VEC;
@@ -69,11 +78,47 @@ __global__ __launch_bounds__(256) void epilogue_bwd_kernel(const float *__restri
     float sum[VEC];
 #pragma unroll
     for (int i = 0; i < VEC; ++i) sum[i] = 0.f;
+    float wacc[CW > 0 ? CW : 1][VEC];
+#pragma unroll
+    for (int c = 0; c < (CW > 0 ? CW : 1); ++c)
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) wacc[c][i] = 0.f;
+    if (HEAD) {  // this slab's columns of the head weight, [C x SLAB]
+        for (int i = threadIdx.x; i < C * SLAB; i += 256) {
+            const int c = i / SLAB, j = i - c * SLAB;
+            const int h = blockIdx.y * SLAB + j;
+            s_w[i] = h < H ? Wl[(int64_t)c * H + h] : 0.f;
+        }
+        __syncthreads();
+    }
     if (live) {
         for (int row = r0 + wave; row < r1; row += 4) {
             const int64_t base = (int64_t)row * H + col0;
             float g[VEC], o[VEC];
-            if (VEC == 4) {
+            if (HEAD) {
+                const float dyl = lane < C ? dy[(int64_t)row * C + lane] : 0.f;
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) g[i] = 0.f;
+                for (int c = 0; c < C; ++c) {
+                    const float d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dyl), c));
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) g[i] = fmaf(d, s_w[c * SLAB + lane * VEC + i], g[i]);
+                }
+                if (VEC == 4) {
+                    const float4 ov = *reinterpret_cast<const float4 *>(out + base);
+                    o[0] = ov.x; o[1 % VEC] = ov.y; o[2 % VEC] = ov.z; o[3 % VEC] = ov.w;
+                } else {
+                    o[0] = out[base];
+                }
+                if (CW > 0) {
+#pragma unroll
+                    for (int c = 0; c < (CW > 0 ? CW : 1); ++c) {
+                        const float d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dyl), c));  // 0 for c >= C
+#pragma unroll
+                        for (int i = 0; i < VEC; ++i) wacc[c][i] = fmaf(d, o[i], wacc[c][i]);
+                    }
+                }
+            } else if (VEC == 4) {
                 const float4 gv = *reinterpret_cast<const float4 *>(dOut + base);
                 const float4 ov = *reinterpret_cast<const float4 *>(out + base);
                 g[0] = gv.x; g[1 % VEC] = gv.y; g[2 % VEC] = gv.z; g[3 % VEC] = gv.w;
@@ -106,15 +151,35 @@ __global__ __launch_bounds__(256) void epilogue_bwd_kernel(const float *__restri
             }
         }
     }
-    if (!partial) return;
+    if (partial) {
 #pragma unroll
-    for (int i = 0; i < VEC; ++i) red[wave][lane * VEC + i] = sum[i];
-    __syncthreads();
-    if (wave == 0 && live) {
+        for (int i = 0; i < VEC; ++i) red[wave][lane * VEC + i] = sum[i];
+        __syncthreads();
+        if (wave == 0 && live) {
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) {
-            const int c = lane * VEC + i;
-            partial[(int64_t)blockIdx.x * H + col0 + i] = ((red[0][c] + red[1][c]) + red[2][c]) + red[3][c];
+            for (int i = 0; i < VEC; ++i) {
+                const int c = lane * VEC + i;
+                partial[(int64_t)blockIdx.x * H + col0 + i] = ((red[0][c] + red[1][c]) + red[2][c]) + red[3][c];
+            }
+        }
+    }
+    if (CW > 0 && partialW) {
+        for (int cc = 0; cc < C; ++cc) {
+            __syncthreads();
+#pragma unroll
+            for (int c = 0; c < (CW > 0 ? CW : 1); ++c)
+                if (c == cc) {
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) red[wave][lane * VEC + i] = wacc[c][i];
+                }
+            __syncthreads();
+            if (wave == 0 && live) {
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) {
+                    const int j = lane * VEC + i;
+                    partialW[((int64_t)blockIdx.x * C + cc) * H + col0 + i] = ((red[0][j] + red[1][j]) + red[2][j]) + red[3][j];
+                }
+            }
         }
     }
 }
@@ -155,28 +220,65 @@ extern "C" size_t fitgnn_epilogue_bwd_workspace_bytes(int32_t n_rows, int32_t H)
     return chunks * (size_t)H * sizeof(float);
 }
 
-extern "C" int fitgnn_epilogue_bwd_f32(const float *dOut, const float *out, float *dZ, int32_t n_rows, int32_t H,
-                                       uint32_t epilogue, float p_drop, uint64_t seed, const uint8_t *mask, float *db,
-                                       void *work, size_t work_bytes, void *stream) {
+namespace {
+int epilogue_bwd_launch(const float *dOut, const float *dy, const float *Wl, int32_t C, const float *out, float *dZ,
+                        int32_t n_rows, int32_t H, uint32_t epilogue, float p_drop, uint64_t seed, const uint8_t *mask,
+                        float *db, float *dWl, void *work, size_t work_bytes, void *stream) {
     if (n_rows < 0 || H < 0) return FITGNN_E_BADARG;
     if (n_rows == 0 || H == 0) return 0;
-    if (!dOut || !out || !dZ) return FITGNN_E_BADARG;
+    const bool head = dOut == nullptr;
+    if (!out || !dZ) return FITGNN_E_BADARG;
+    if (head && (!dy || !Wl || C < 1 || C > kMaxHeadC)) return FITGNN_E_BADARG;
+    if (!head && dWl) return FITGNN_E_BADARG;
     if ((epilogue & FITGNN_EPI_DROPOUT) && !(p_drop >= 0.f && p_drop < 1.f)) return FITGNN_E_BADARG;
-    if (db && (!work || work_bytes < fitgnn_epilogue_bwd_workspace_bytes(n_rows, H))) return FITGNN_E_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     const int cr = chunk_rows_for(n_rows);
     const int chunks = (n_rows + cr - 1) / cr;
+    const size_t need = ((db ? 1 : 0) + (dWl ? (size_t)C : 0)) * (size_t)chunks * (size_t)H * sizeof(float);
+    if (need && (!work || work_bytes < need)) return FITGNN_E_WORKSPACE;
     float *partial = db ? (float *)work : nullptr;
+    float *partialW = dWl ? (float *)work + (db ? (size_t)chunks * H : 0) : nullptr;
     const bool vec = (H % 4 == 0) && ((((uintptr_t)dOut | (uintptr_t)out | (uintptr_t)dZ) % 16) == 0);
-    if (vec) {
-        dim3 grid(chunks, (H + 255) / 256);
-        hipLaunchKernelGGL(epilogue_bwd_kernel<4>, grid, dim3(256), 0, s, dOut, out, dZ, n_rows, H, cr, epilogue, p_drop, seed,
-                           mask, partial);
+    const dim3 grid(chunks, vec ? (H + 255) / 256 : (H + 63) / 64);
+#define FITGNN_LAUNCH_EB(V, HD, CWV)                                                                                     \
+    hipLaunchKernelGGL((epilogue_bwd_kernel<V, HD, CWV>), grid, dim3(256), 0, s, dOut, out, dZ, n_rows, H, cr, epilogue,   \
+                       p_drop, seed, mask, partial, dy, Wl, C, partialW)
+    if (!head) {
+        if (vec) FITGNN_LAUNCH_EB(4, false, 0); else FITGNN_LAUNCH_EB(1, false, 0);
+    } else if (!dWl) {
+        if (vec) FITGNN_LAUNCH_EB(4, true, 0); else FITGNN_LAUNCH_EB(1, true, 0);
+    } else if (C <= 4) {
+        if (vec) FITGNN_LAUNCH_EB(4, true, 4); else FITGNN_LAUNCH_EB(1, true, 4);
     } else {
-        dim3 grid(chunks, (H + 63) / 64);
-        hipLaunchKernelGGL(epilogue_bwd_kernel<1>, grid, dim3(256), 0, s, dOut, out, dZ, n_rows, H, cr, epilogue, p_drop, seed,
-                           mask, partial);
+        if (vec) FITGNN_LAUNCH_EB(4, true, kMaxHeadC); else FITGNN_LAUNCH_EB(1, true, kMaxHeadC);
     }
+#undef FITGNN_LAUNCH_EB
     if (db) hipLaunchKernelGGL(colsum_partials_kernel, dim3((H + 63) / 64), dim3(256), 0, s, partial, chunks, H, db);
+    if (dWl)  // partialW rows are [C x H] per chunk: the same reduction over C*H "columns"
+        hipLaunchKernelGGL(colsum_partials_kernel, dim3((C * H + 63) / 64), dim3(256), 0, s, partialW, chunks, C * H, dWl);
     return (int)hipGetLastError();
+}
+}  // namespace
+
+extern "C" int fitgnn_epilogue_bwd_f32(const float *dOut, const float *out, float *dZ, int32_t n_rows, int32_t H,
+                                       uint32_t epilogue, float p_drop, uint64_t seed, const uint8_t *mask, float *db,
+                                       void *work, size_t work_bytes, void *stream) {
+    if (n_rows > 0 && H > 0 && !dOut) return FITGNN_E_BADARG;
+    return epilogue_bwd_launch(dOut, nullptr, nullptr, 0, out, dZ, n_rows, H, epilogue, p_drop, seed, mask, db, nullptr, work,
+                               work_bytes, stream);
+}
+
+extern "C" int fitgnn_head_max_classes(void) { return kMaxHeadC; }
+
+extern "C" size_t fitgnn_epilogue_bwd_head_workspace_bytes(int32_t n_rows, int32_t H, int32_t C) {
+    if (n_rows <= 0 || H <= 0 || C < 0) return 0;
+    return fitgnn_epilogue_bwd_workspace_bytes(n_rows, H) * (size_t)(1 + C);
+}
+
+extern "C" int fitgnn_epilogue_bwd_head_f32(const float *dy, const float *Wl, int32_t C, const float *out, float *dZ,
+                                            int32_t n_rows, int32_t H, uint32_t epilogue, float p_drop, uint64_t seed,
+                                            const uint8_t *mask, float *db, float *dWl, void *work, size_t work_bytes,
+                                            void *stream) {
+    return epilogue_bwd_launch(nullptr, dy, Wl, C, out, dZ, n_rows, H, epilogue, p_drop, seed, mask, db, dWl, work, work_bytes,
+                               stream);
 }

@@ -29,6 +29,10 @@ SIGNATURES = {
     "fitgnn_plan_tiles_host": (ctypes.c_int, [ptr, ptr, c_i32, c_i32, ptr, c_i32, c_i32, c_i32, ptr, ptr, ptr, ptr, ptr]),
     "fitgnn_epilogue_bwd_workspace_bytes": (c_size, [c_i32, c_i32]),
     "fitgnn_epilogue_bwd_f32": (ctypes.c_int, [ptr, ptr, ptr, c_i32, c_i32, c_u32, c_f32, c_u64, ptr, ptr, ptr, c_size, ptr]),
+    "fitgnn_head_max_classes": (ctypes.c_int, []),
+    "fitgnn_epilogue_bwd_head_workspace_bytes": (c_size, [c_i32, c_i32, c_i32]),
+    "fitgnn_epilogue_bwd_head_f32": (ctypes.c_int, [ptr, ptr, c_i32, ptr, ptr, c_i32, c_i32, c_u32, c_f32, c_u64, ptr, ptr, ptr,
+                                                   ptr, c_size, ptr]),
     "fitgnn_closed_neighbourhoods": (ctypes.c_int, [ptr, ptr, c_i32, ptr, ptr, ptr]),
     "fitgnn_variation_costs_f64": (ctypes.c_int, [ptr, ptr, ptr, ptr, ptr, c_i32, c_i64, ptr, ptr, ptr, c_i32, ptr, ptr]),
     "fitgnn_greedy_select_workspace_bytes": (c_size, [c_i32, c_i64]),

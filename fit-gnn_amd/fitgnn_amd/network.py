@@ -18,6 +18,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from . import nn as fnn
+from . import ops
 
 
 def _make_convs(args):
@@ -64,23 +65,49 @@ class _Base(nn.Module):
                 x = F.dropout(x, p=self.dropout_p, training=self.training)
         return x
 
+    def embed_and_head(self, x, edge_index):
+        """embed() followed by lt1; on the GPU the last GCN layer and the head form one autograd node."""
+        L = self.num_layers
+        last = self.conv[L - 1] if L > 0 else None
+        if not (L > 0 and x.is_cuda and isinstance(last, fnn.GCNConv) and self.lt1.out_features <= ops.head_max_classes()):
+            return self.head(self.embed(x, edge_index))
+        x = x.float()
+        for i in range(L - 1):
+            conv = self.conv[i]
+            if isinstance(conv, fnn.GCNConv):
+                mask = self._inject_masks[i] if self._inject_masks is not None else None
+                x = conv.forward_elu_dropout(x, edge_index, p=self.dropout_p, training=self.training, mask=mask)
+            else:
+                x = F.dropout(F.elu(conv(x, edge_index)), p=self.dropout_p, training=self.training)
+        mask = self._inject_masks[L - 1] if self._inject_masks is not None else None
+        g = last.graph(edge_index, x.shape[0])
+        seed = ops.next_seed() if (self.training and self.dropout_p > 0 and mask is None) else 0
+        return ops.FusedGCNLayerHead.apply(x, last.lin.weight, last.bias, self.lt1.weight, self.lt1.bias, g,
+                                           float(self.dropout_p), bool(self.training), seed, mask)
+
+    def head(self, x):
+        """lt1 (network.py:34): same parameters as nn.Linear, evaluated as mm + broadcast add."""
+        if x.is_cuda:
+            return ops.SmallLinear.apply(x, self.lt1.weight, self.lt1.bias)
+        return self.lt1(x)
+
 
 class Classify_node(_Base):
     def forward(self, x, edge_index):
-        return F.log_softmax(self.lt1(self.embed(x, edge_index)), dim=1)
+        return F.log_softmax(self.embed_and_head(x, edge_index), dim=1)
 
 
 class Regress_node(_Base):
     out_dim_from_classes = False
 
     def forward(self, x, edge_index):
-        return self.lt1(self.embed(x, edge_index))
+        return self.embed_and_head(x, edge_index)
 
 
 class Classify_graph_gc(_Base):
     def forward(self, gc):
         x = self.embed(gc.x, gc.edge_index)
-        return F.softmax(self.lt1(fnn.global_max_pool(x, gc.batch)), dim=1)
+        return F.softmax(self.head(fnn.global_max_pool(x, gc.batch)), dim=1)
 
 
 class Regress_graph_gc(_Base):
@@ -88,7 +115,7 @@ class Regress_graph_gc(_Base):
 
     def forward(self, gc):
         x = self.embed(gc.x, gc.edge_index)
-        return self.lt1(fnn.global_mean_pool(x, gc.batch))
+        return self.head(fnn.global_mean_pool(x, gc.batch))
 
 
 def _merge_subgraphs(set_gs, device):
@@ -108,7 +135,7 @@ class Classify_graph_gs(_Base):
     def forward(self, set_gs, batch_tensor):
         x, ei, mask = _merge_subgraphs(set_gs, batch_tensor.device)
         x = self.embed(x, ei)[mask]
-        x = self.lt1(fnn.global_max_pool(x, batch_tensor.to(torch.int64)))
+        x = self.head(fnn.global_max_pool(x, batch_tensor.to(torch.int64)))
         return F.softmax(x, dim=0 if x.dim() == 1 else 1)
 
 
@@ -118,4 +145,4 @@ class Regress_graph_gs(_Base):
     def forward(self, set_gs, batch_tensor):
         x, ei, mask = _merge_subgraphs(set_gs, batch_tensor.device)
         x = self.embed(x, ei)[mask]
-        return self.lt1(fnn.global_mean_pool(x, batch_tensor.to(torch.int64)))
+        return self.head(fnn.global_mean_pool(x, batch_tensor.to(torch.int64)))

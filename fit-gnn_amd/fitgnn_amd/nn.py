@@ -42,7 +42,7 @@ class GCNConv(nn.Module):
 
     def forward(self, x, edge_index):
         g = self.graph(edge_index, x.shape[0])
-        h = torch.mm(x.float(), self.lin.weight.t())
+        h = ops.Linear.apply(x.float(), self.lin.weight)
         return ops.SpMM.apply(h, self.bias, g)
 
     def forward_elu_dropout(self, x, edge_index, p=0.5, training=False, mask=None, graph=None):

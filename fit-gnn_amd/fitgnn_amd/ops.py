@@ -17,6 +17,60 @@ from ._lib import EPI_BIAS, EPI_DROPOUT, EPI_ELU
 PROFILE = None
 
 
+# Dense GEMM policy (BASELINE.json north_star: MFMA only for the dense weight GEMMs, library GEMM allowed).
+# "high": hipBLASLt computes the [rows x in] @ [in x out] products (forward, dX) with the 3 x bf16 split of each
+# fp32 operand on the bf16 MFMA pipe (fp32 accumulate; measured 4-5e-6 relative error vs fp64, 2.2x faster than the
+# fp32 MFMA path on gfx950).  The weight-gradient products dH^T @ X (reduction over all rows) stay "highest": the
+# split kernels are slower for that shape.  "highest" everywhere = plain fp32 MFMA.
+GEMM_PRECISION = "high"
+
+
+def mm(a, b, allow_split=True):
+    if GEMM_PRECISION == "high" and allow_split:
+        prev = torch.get_float32_matmul_precision()
+        torch.set_float32_matmul_precision("high")
+        try:
+            return torch.mm(a, b)
+        finally:
+            torch.set_float32_matmul_precision(prev)
+    return torch.mm(a, b)
+
+
+class Linear(torch.autograd.Function):
+    """h = x W^T (GCNConv's bias-free Linear) under the GEMM policy above."""
+
+    @staticmethod
+    def forward(ctx, x, W):
+        ctx.save_for_backward(x, W)
+        return mm(x, W.t())
+
+    @staticmethod
+    def backward(ctx, dh):
+        x, W = ctx.saved_tensors
+        dx = mm(dh, W) if ctx.needs_input_grad[0] else None
+        dW = mm(dh.t(), x, allow_split=False) if ctx.needs_input_grad[1] else None
+        return dx, dW
+
+
+class SmallLinear(torch.autograd.Function):
+    """y = x W^T + b for a narrow output (lt1: hidden -> classes, network.py:34).  nn.Linear's addmm picks a 340 us
+    kernel for [90k x 512] @ [512 x 3]; mm + a broadcast add is 10x faster.  Same arithmetic."""
+
+    @staticmethod
+    def forward(ctx, x, W, b):
+        ctx.save_for_backward(x, W)
+        y = torch.mm(x, W.t())
+        return y if b is None else y + b
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, W = ctx.saved_tensors
+        dx = torch.mm(dy, W) if ctx.needs_input_grad[0] else None
+        dW = torch.mm(dy.t(), x) if ctx.needs_input_grad[1] else None
+        db = dy.sum(0) if ctx.needs_input_grad[2] else None
+        return dx, dW, db
+
+
 def _f32c(t):
     if t.dtype != torch.float32:
         t = t.float()
@@ -71,6 +125,26 @@ def spmm_graph(g, X, transposed=False, **kw):
                     lcol=side.lcol, win_cols=side.win_cols, **kw)
 
 
+def epilogue_bwd_head_raw(dy, Wl, out, epilogue, p=0.0, seed=0, mask=None, want_db=True, want_dWl=True):
+    """dZ / db as epilogue_bwd_raw, with dOut = dy @ Wl formed inside the kernel (fitgnn_epilogue_bwd_head_f32);
+    also returns dWl = dy^T @ out when asked."""
+    _lib.require_cuda(dy, Wl, out, mask)
+    L = _lib.lib()
+    dy, Wl, out = _f32c(dy), _f32c(Wl), _f32c(out)
+    n, H = out.shape
+    C = Wl.shape[0]
+    dZ = torch.empty_like(out)
+    db = torch.empty(H, dtype=torch.float32, device=out.device) if want_db else None
+    dWl = torch.empty((C, H), dtype=torch.float32, device=out.device) if want_dWl else None
+    wb = int(L.fitgnn_epilogue_bwd_head_workspace_bytes(n, H, C))
+    work = torch.empty(max(wb, 4), dtype=torch.uint8, device=out.device)
+    rc = L.fitgnn_epilogue_bwd_head_f32(_lib.dptr(dy), _lib.dptr(Wl), C, _lib.dptr(out), _lib.dptr(dZ), n, H, epilogue, float(p),
+                                        int(seed) & 0xFFFFFFFFFFFFFFFF, _lib.dptr(mask), _lib.dptr(db), _lib.dptr(dWl),
+                                        _lib.dptr(work), wb, _lib.stream_ptr(out.device))
+    _lib.check(rc, "fitgnn_epilogue_bwd_head_f32")
+    return dZ, db, dWl
+
+
 class SpMM(torch.autograd.Function):
     """Y = A @ X (+ bias).  Backward: dX = A^T @ dY (same kernel on the transposed CSR), db = sum rows."""
 
@@ -97,7 +171,7 @@ class FusedGCNLayer(torch.autograd.Function):
     @staticmethod
     def forward(ctx, X, W, b, g, p, training, seed, mask):
         X = _f32c(X)
-        Hm = torch.mm(X, W.t())
+        Hm = mm(X, W.t())
         epi = EPI_ELU | (EPI_BIAS if b is not None else 0)
         drop = bool(training) and p > 0.0
         if drop:
@@ -115,12 +189,60 @@ class FusedGCNLayer(torch.autograd.Function):
         dZ, db = epilogue_bwd_raw(dOut, out, epi, p=ctx.p if ctx.drop else 0.0, seed=ctx.seed, mask=mask,
                                   want_db=ctx.has_bias)
         dH = spmm_graph(g, dZ, transposed=True)
-        dW = torch.mm(dH.t(), X) if ctx.needs_input_grad[1] else None
-        dX = torch.mm(dH, W) if ctx.needs_input_grad[0] else None
+        dW = mm(dH.t(), X, allow_split=False) if ctx.needs_input_grad[1] else None
+        dX = mm(dH, W) if ctx.needs_input_grad[0] else None
         return dX, dW, (db if ctx.has_bias else None), None, None, None, None, None
 
 
+class FusedGCNLayerHead(torch.autograd.Function):
+    """Last GCN layer + output head in one autograd node:
+        out = dropout(ELU(A_hat (X W^T) + b))       (network.py:31-33)
+        y   = out Wl^T + bl                          (network.py:34, lt1)
+    so that the backward never materialises d(out) = dy @ Wl (a K = num_classes GEMM writing [rows x hidden]):
+    the epilogue-backward kernel forms it on the fly.  Requires num_classes <= fitgnn_head_max_classes()."""
+
+    @staticmethod
+    def forward(ctx, X, W, b, Wl, bl, g, p, training, seed, mask):
+        X = _f32c(X)
+        Hm = mm(X, W.t())
+        epi = EPI_ELU | (EPI_BIAS if b is not None else 0)
+        drop = bool(training) and p > 0.0
+        if drop:
+            epi |= EPI_DROPOUT
+        out = spmm_graph(g, Hm, bias=b, epilogue=epi, p=p if drop else 0.0, seed=seed, mask=mask if drop else None)
+        y = torch.mm(out, Wl.t())
+        if bl is not None:
+            y = y + bl
+        ctx.save_for_backward(X, W, Wl, out, mask if drop else None)
+        ctx.g, ctx.p, ctx.drop, ctx.seed, ctx.has_bias, ctx.has_bl = g, p, drop, seed, b is not None, bl is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        X, W, Wl, out, mask = ctx.saved_tensors
+        g = ctx.g
+        dy = _f32c(dy)
+        epi = EPI_ELU | (EPI_DROPOUT if ctx.drop else 0)
+        dZ, db, dWl = epilogue_bwd_head_raw(dy, Wl, out, epi, p=ctx.p if ctx.drop else 0.0, seed=ctx.seed, mask=mask,
+                                            want_db=ctx.has_bias, want_dWl=ctx.needs_input_grad[3])
+        dbl = dy.sum(0) if ctx.has_bl and ctx.needs_input_grad[4] else None
+        dH = spmm_graph(g, dZ, transposed=True)
+        dW = mm(dH.t(), X, allow_split=False) if ctx.needs_input_grad[1] else None
+        dX = mm(dH, W) if ctx.needs_input_grad[0] else None
+        return dX, dW, (db if ctx.has_bias else None), dWl, dbl, None, None, None, None, None
+
+
 _seed_state = [0x1234ABCD]
+
+
+_HEAD_MAX = None
+
+
+def head_max_classes():
+    global _HEAD_MAX
+    if _HEAD_MAX is None:
+        _HEAD_MAX = int(_lib.lib().fitgnn_head_max_classes())
+    return _HEAD_MAX
 
 
 def next_seed():

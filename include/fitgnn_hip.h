@@ -113,6 +113,17 @@ int fitgnn_epilogue_bwd_f32(const float *dOut, const float *out, float *dZ, int3
                             uint32_t epilogue, float p_drop, uint64_t seed, const uint8_t *mask, float *db,
                             void *work, size_t work_bytes, void *stream);
 
+/* The same, with the backward of the output head lt1 (network.py:34, y = out Wl^T + bl) folded in: dOut is not
+ * read but formed on the fly as dy[n_rows x C] @ Wl[C x H], 1 <= C <= fitgnn_head_max_classes().  Replaces the
+ * K = num_classes GEMM dy @ Wl and the [n_rows x H] matrix it would write and this kernel would re-read.
+ * dWl (f32[C x H], may be NULL) receives the head's weight gradient dy^T @ out, accumulated while `out` streams by
+ * (the library GEMM for this [C x rows] @ [rows x H] shape takes 220-340 us on its own). */
+int fitgnn_head_max_classes(void);
+size_t fitgnn_epilogue_bwd_head_workspace_bytes(int32_t n_rows, int32_t H, int32_t C);
+int fitgnn_epilogue_bwd_head_f32(const float *dy, const float *Wl, int32_t C, const float *out, float *dZ,
+                                 int32_t n_rows, int32_t H, uint32_t epilogue, float p_drop, uint64_t seed,
+                                 const uint8_t *mask, float *db, float *dWl, void *work, size_t work_bytes, void *stream);
+
 /* =====================================================================================
  * Coarsen half: one contraction level of variation_neighborhoods
  * replaces: graph_coarsening/coarsening_utils.py contract_variation_linear :530-650,

@@ -111,7 +111,7 @@ def test_hub_subgraph_larger_than_window_is_planned_into_lds(mods):
             src += [off, off + l]; dst += [off + l, off]
         off += leaves + 1
     ei = torch.tensor([src, dst], dtype=torch.long)
-    g = csr.CSRGraph(ei.cuda(), off, mode="gcn", lds_rows=24)
+    g = csr.CSRGraph(ei.cuda(), off, mode="gcn", lds_rows=24, planned=True)
     lc = g.f.lcol.cpu().numpy()
     # every leaf row finds hub + itself in LDS; only the hub rows (wider than the window) go to global memory
     assert (lc < 0).mean() < 0.3
@@ -195,3 +195,22 @@ def test_empty_and_degenerate(mods):
     g0 = csr.CSRGraph(torch.zeros((2, 0), dtype=torch.long).cuda(), 3, mode="sum")  # no entries at all
     Y0 = ops.spmm_graph(g0, torch.randn(3, 4).cuda()).cpu()
     assert torch.count_nonzero(Y0) == 0
+
+
+@pytest.mark.parametrize("H,C", [(512, 3), (512, 16), (100, 1), (33, 7)])
+def test_head_backward_folded_into_epilogue_kernel(mods, H, C):
+    """fitgnn_epilogue_bwd_head_f32 == epilogue backward applied to dOut = dy @ Wl."""
+    _lib, csr, ops, orc, gorc = mods
+    from fitgnn_amd._lib import EPI_DROPOUT, EPI_ELU
+
+    torch.manual_seed(5)
+    n = 777
+    out = torch.nn.functional.elu(torch.randn(n, H))
+    mask = (torch.rand(n, H) > 0.5).to(torch.uint8)
+    out = out * mask * 2.0
+    dy, Wl = torch.randn(n, C), torch.randn(C, H)
+    dZ_ref, db_ref = ops.epilogue_bwd_raw((dy @ Wl).cuda(), out.cuda(), EPI_ELU | EPI_DROPOUT, p=0.5, mask=mask.cuda())
+    dZ, db, dWl = ops.epilogue_bwd_head_raw(dy.cuda(), Wl.cuda(), out.cuda(), EPI_ELU | EPI_DROPOUT, p=0.5, mask=mask.cuda())
+    assert rel_err(dZ.cpu(), dZ_ref.cpu()) < 1e-5
+    assert rel_err(db.cpu(), db_ref.cpu()) < 1e-4
+    assert rel_err(dWl.cpu(), (dy.double().t() @ out.double()).float()) < 1e-5
