@@ -163,6 +163,14 @@ def main():
     durs_ms = [a.elapsed_time(b) for a, b in events]
     spmm_ms = float(np.mean(durs_ms)) if durs_ms else float("nan")
     achieved = bytes_spmm / (spmm_ms * 1e-3) / 1e9
+    # HBM traffic of one SpMM launch from the committed PMC profile of this same command (rocprofv3 --pmc, separate
+    # passes; gfx950 correction: FETCH_SIZE counts half of a wide coalesced read; both counters in KiB)
+    traffic = None
+    pmc_file = os.path.join(ROOT, "profiles", "r01_pmc_spmm_tile_kernel.json")
+    if args.workload == "S-pubmed" and H == 512 and os.path.exists(pmc_file):
+        with open(pmc_file) as f:
+            pmc = json.load(f)
+        traffic = (2.0 * pmc["FETCH_SIZE"]["mean"] + pmc["WRITE_SIZE"]["mean"]) * 1024.0
     out = {
         "metric": "edges aggregated/sec (GCN fwd+bwd) on coarsened subgraphs",
         "value": total_edges / dt, "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -174,7 +182,7 @@ def main():
                                   "fp32 MFMA for dH^T@X") if args.gemm_precision == "high" else "hipBLASLt fp32 MFMA",
                    **info},
         "roofline": {"kernel": "spmm_tile_kernel<VEC=4,B=4,MPR=16> (CSR SpMM, LDS row windows, H=%d, f32)" % H, "bound": "hbm", "achieved": achieved,
-                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "algorithmic_bytes_per_launch": bytes_spmm, "avg_launch_us": spmm_ms * 1e3,
                      "launches_timed": len(durs_ms), "spmm_edges_per_s": batch.nnz / (spmm_ms * 1e-3)},
         "loss": float(loss),
