@@ -1,0 +1,227 @@
+// gat.hip -- graph-attention kernels on the CSR batch (PyG GATConv with FIT-GNN's defaults: heads = 1,
+// negative_slope = 0.2, add_self_loops, no attention dropout; network.py:13 with --layer_name GATConv).
+//
+//   h = x W^T;  s_ij = a_src.h_j + a_dst.h_i;  e_ij = LeakyReLU(s_ij);  alpha_ij = softmax_j(e_ij) over the
+//   incoming edges of i (CSR row i);  out_i = sum_j alpha_ij h_j + bias.
+// The aggregation itself is fitgnn_spmm_csr_f32 with val = alpha.  This file adds the per-node score dots, the
+// per-row edge softmax, the per-edge gradient d(alpha_ij) = dOut_i . h_j (SDDMM) and the softmax/LeakyReLU
+// backward.  Rows of h / dOut are read with 16-byte lane loads; per-row reductions are 64-lane butterflies.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "common.h"
+#include "fitgnn_hip.h"
+
+namespace {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
+// a_src[i] = h_i . att_src,  a_dst[i] = h_i . att_dst          (one wave per row)
+__global__ __launch_bounds__(256) void gat_scores_kernel(const float *__restrict__ h, int64_t ldh, int32_t n, int32_t C,
+                                                         const float *__restrict__ att_src, const float *__restrict__ att_dst,
+                                                         float *__restrict__ a_src, float *__restrict__ a_dst) {
+    const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (row >= n) return;
+    const float *hr = h + (int64_t)row * ldh;
+    float s = 0.f, d = 0.f;
+    if ((C & 3) == 0 && (ldh & 3) == 0) {
+        for (int c = lane * 4; c < C; c += 256) {
+            const float4 v = *reinterpret_cast<const float4 *>(hr + c);
+            const float4 as = *reinterpret_cast<const float4 *>(att_src + c);
+            const float4 ad = *reinterpret_cast<const float4 *>(att_dst + c);
+            s += v.x * as.x + v.y * as.y + v.z * as.z + v.w * as.w;
+            d += v.x * ad.x + v.y * ad.y + v.z * ad.z + v.w * ad.w;
+        }
+    } else {
+        for (int c = lane; c < C; c += 64) { s += hr[c] * att_src[c]; d += hr[c] * att_dst[c]; }
+    }
+    s = wave_sum(s);
+    d = wave_sum(d);
+    if (lane == 0) { a_src[row] = s; a_dst[row] = d; }
+}
+
+// alpha over each CSR row: softmax_j LeakyReLU(a_src[col] + a_dst[row])      (one wave per row)
+__global__ __launch_bounds__(256) void gat_edge_softmax_kernel(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                                               const float *__restrict__ a_src, const float *__restrict__ a_dst,
+                                                               float slope, int32_t n, float *__restrict__ alpha) {
+    const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (row >= n) return;
+    const int e0 = rowptr[row], e1 = rowptr[row + 1];
+    const float ad = a_dst[row];
+    float m = -INFINITY;
+    for (int e = e0 + lane; e < e1; e += 64) {
+        float s = a_src[col[e]] + ad;
+        s = s > 0.f ? s : slope * s;
+        m = fmaxf(m, s);
+    }
+    m = wave_max(m);
+    float z = 0.f;
+    for (int e = e0 + lane; e < e1; e += 64) {
+        float s = a_src[col[e]] + ad;
+        s = s > 0.f ? s : slope * s;
+        const float p = __expf(s - m);
+        alpha[e] = p;
+        z += p;
+    }
+    z = wave_sum(z);
+    const float inv = z > 0.f ? 1.0f / z : 0.f;
+    for (int e = e0 + lane; e < e1; e += 64) alpha[e] *= inv;
+}
+
+// d_alpha[e] = dOut[row] . h[col[e]]        (SDDMM; one wave per row keeps dOut[row] in registers)
+template <int MAXV>  // MAXV float4 per lane: C <= 256 * MAXV
+__global__ __launch_bounds__(256) void gat_sddmm_kernel(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                                        const float *__restrict__ dOut, int64_t ldo,
+                                                        const float *__restrict__ h, int64_t ldh, int32_t n, int32_t C,
+                                                        float *__restrict__ dalpha) {
+    const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (row >= n) return;
+    float4 g[MAXV];
+#pragma unroll
+    for (int v = 0; v < MAXV; ++v) {
+        const int c = (v * 64 + lane) * 4;
+        g[v] = c < C ? *reinterpret_cast<const float4 *>(dOut + (int64_t)row * ldo + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const int e0 = rowptr[row], e1 = rowptr[row + 1];
+    for (int e = e0; e < e1; ++e) {
+        const float *hr = h + (int64_t)col[e] * ldh;
+        float s = 0.f;
+#pragma unroll
+        for (int v = 0; v < MAXV; ++v) {
+            const int c = (v * 64 + lane) * 4;
+            if (c < C) {
+                const float4 x = *reinterpret_cast<const float4 *>(hr + c);
+                s += g[v].x * x.x + g[v].y * x.y + g[v].z * x.z + g[v].w * x.w;
+            }
+        }
+        s = wave_sum(s);
+        if (lane == 0) dalpha[e] = s;
+    }
+}
+__global__ __launch_bounds__(256) void gat_sddmm_scalar_kernel(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                                               const float *__restrict__ dOut, int64_t ldo,
+                                                               const float *__restrict__ h, int64_t ldh, int32_t n, int32_t C,
+                                                               float *__restrict__ dalpha) {
+    const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (row >= n) return;
+    const int e0 = rowptr[row], e1 = rowptr[row + 1];
+    for (int e = e0; e < e1; ++e) {
+        const float *hr = h + (int64_t)col[e] * ldh;
+        float s = 0.f;
+        for (int c = lane; c < C; c += 64) s += dOut[(int64_t)row * ldo + c] * hr[c];
+        s = wave_sum(s);
+        if (lane == 0) dalpha[e] = s;
+    }
+}
+
+// softmax + LeakyReLU backward per row:  ds_e = alpha_e (dalpha_e - sum_k alpha_k dalpha_k) * lrelu'(s_e);
+// da_dst[row] = sum_e ds_e.  ds is left per edge for the column-side sum (done on the transposed order).
+__global__ __launch_bounds__(256) void gat_softmax_bwd_kernel(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                                              const float *__restrict__ a_src, const float *__restrict__ a_dst,
+                                                              const float *__restrict__ alpha, const float *__restrict__ dalpha,
+                                                              float slope, int32_t n, float *__restrict__ ds,
+                                                              float *__restrict__ da_dst) {
+    const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (row >= n) return;
+    const int e0 = rowptr[row], e1 = rowptr[row + 1];
+    float dot = 0.f;
+    for (int e = e0 + lane; e < e1; e += 64) dot += alpha[e] * dalpha[e];
+    dot = wave_sum(dot);
+    const float ad = a_dst[row];
+    float acc = 0.f;
+    for (int e = e0 + lane; e < e1; e += 64) {
+        const float s = a_src[col[e]] + ad;
+        const float d = alpha[e] * (dalpha[e] - dot) * (s > 0.f ? 1.0f : slope);
+        ds[e] = d;
+        acc += d;
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) da_dst[row] = acc;
+}
+
+// y[row] = sum of v over the CSR row (used for da_src on the transposed order)
+__global__ __launch_bounds__(256) void csr_row_sum_kernel(const int32_t *__restrict__ rowptr, const float *__restrict__ v, int32_t n,
+                                                          float *__restrict__ y) {
+    const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (row >= n) return;
+    float acc = 0.f;
+    for (int e = rowptr[row] + lane; e < rowptr[row + 1]; e += 64) acc += v[e];
+    acc = wave_sum(acc);
+    if (lane == 0) y[row] = acc;
+}
+
+inline dim3 wave_grid(int32_t n) { return dim3((unsigned)(((int64_t)n * 64 + 255) / 256)); }
+
+}  // namespace
+
+extern "C" int fitgnn_gat_scores_f32(const float *h, int64_t ldh, int32_t n, int32_t C, const float *att_src,
+                                     const float *att_dst, float *a_src, float *a_dst, void *stream) {
+    if (n < 0 || C < 0 || ldh < C) return FITGNN_E_BADARG;
+    if (n == 0) return 0;
+    if (!h || !att_src || !att_dst || !a_src || !a_dst) return FITGNN_E_BADARG;
+    hipLaunchKernelGGL(gat_scores_kernel, wave_grid(n), dim3(256), 0, (hipStream_t)stream, h, ldh, n, C, att_src, att_dst, a_src,
+                       a_dst);
+    return (int)hipGetLastError();
+}
+
+extern "C" int fitgnn_gat_edge_softmax_f32(const int32_t *rowptr, const int32_t *col, const float *a_src, const float *a_dst,
+                                           float negative_slope, int32_t n, float *alpha, void *stream) {
+    if (n < 0) return FITGNN_E_BADARG;
+    if (n == 0) return 0;
+    if (!rowptr || !a_src || !a_dst) return FITGNN_E_BADARG;
+    hipLaunchKernelGGL(gat_edge_softmax_kernel, wave_grid(n), dim3(256), 0, (hipStream_t)stream, rowptr, col, a_src, a_dst,
+                       negative_slope, n, alpha);
+    return (int)hipGetLastError();
+}
+
+extern "C" int fitgnn_sddmm_csr_f32(const int32_t *rowptr, const int32_t *col, const float *dOut, int64_t ldo, const float *h,
+                                    int64_t ldh, int32_t n, int32_t C, float *dalpha, void *stream) {
+    if (n < 0 || C < 0 || ldo < C || ldh < C) return FITGNN_E_BADARG;
+    if (n == 0) return 0;
+    if (!rowptr || !dOut || !h) return FITGNN_E_BADARG;
+    hipStream_t s = (hipStream_t)stream;
+    const bool vec = (C % 4 == 0) && (ldo % 4 == 0) && (ldh % 4 == 0) && ((((uintptr_t)dOut | (uintptr_t)h) % 16) == 0);
+    if (vec && C <= 256)
+        hipLaunchKernelGGL(gat_sddmm_kernel<1>, wave_grid(n), dim3(256), 0, s, rowptr, col, dOut, ldo, h, ldh, n, C, dalpha);
+    else if (vec && C <= 512)
+        hipLaunchKernelGGL(gat_sddmm_kernel<2>, wave_grid(n), dim3(256), 0, s, rowptr, col, dOut, ldo, h, ldh, n, C, dalpha);
+    else if (vec && C <= 1024)
+        hipLaunchKernelGGL(gat_sddmm_kernel<4>, wave_grid(n), dim3(256), 0, s, rowptr, col, dOut, ldo, h, ldh, n, C, dalpha);
+    else
+        hipLaunchKernelGGL(gat_sddmm_scalar_kernel, wave_grid(n), dim3(256), 0, s, rowptr, col, dOut, ldo, h, ldh, n, C, dalpha);
+    return (int)hipGetLastError();
+}
+
+extern "C" int fitgnn_gat_softmax_bwd_f32(const int32_t *rowptr, const int32_t *col, const float *a_src, const float *a_dst,
+                                          const float *alpha, const float *dalpha, float negative_slope, int32_t n, float *ds,
+                                          float *da_dst, void *stream) {
+    if (n < 0) return FITGNN_E_BADARG;
+    if (n == 0) return 0;
+    if (!rowptr || !a_src || !a_dst || !da_dst) return FITGNN_E_BADARG;
+    hipLaunchKernelGGL(gat_softmax_bwd_kernel, wave_grid(n), dim3(256), 0, (hipStream_t)stream, rowptr, col, a_src, a_dst, alpha,
+                       dalpha, negative_slope, n, ds, da_dst);
+    return (int)hipGetLastError();
+}
+
+extern "C" int fitgnn_csr_row_sum_f32(const int32_t *rowptr, const float *v, int32_t n, float *y, void *stream) {
+    if (n < 0) return FITGNN_E_BADARG;
+    if (n == 0) return 0;
+    if (!rowptr || !y) return FITGNN_E_BADARG;
+    hipLaunchKernelGGL(csr_row_sum_kernel, wave_grid(n), dim3(256), 0, (hipStream_t)stream, rowptr, v, n, y);
+    return (int)hipGetLastError();
+}

@@ -167,6 +167,7 @@ class CSRGraph:
         """mode: 'gcn'  -> add_remaining_self_loops + D^-1/2 (A+I) D^-1/2      (GCNConv, APPNP)
                  'sum'  -> plain adjacency, value 1 per edge                  (GINConv aggregation)
                  'mean' -> plain adjacency, value 1/in_degree(target)         (SAGEConv aggregation)
+                 'gat'  -> add_remaining_self_loops, values = attention        (GATConv)
         planned: tiles from fitgnn_plan_tiles_host (column-set windows for blocks larger than the window);
         False (default; measured faster on PubMed-like batches, profiles/): contiguous windows packed from the
         diagonal-block boundaries `ptr` (detected when not given).  gather: use the direct-gather kernel.
@@ -176,7 +177,7 @@ class CSRGraph:
         self.device, self.n, self.mode = device, int(num_nodes), mode
         self.planned, self.gather = planned, gather
         src, dst = edge_index[0].to(torch.int64), edge_index[1].to(torch.int64)
-        if mode == "gcn":
+        if mode in ("gcn", "gat"):  # add_remaining_self_loops: exactly one self loop per node
             keep = src != dst
             loop = torch.arange(self.n, device=device, dtype=torch.int64)
             src, dst = torch.cat([src[keep], loop]), torch.cat([dst[keep], loop])
@@ -216,7 +217,7 @@ class CSRGraph:
             self.dinv = torch.empty(self.n, dtype=torch.float32, device=dev)
             _lib.check(L.fitgnn_gcn_norm_csr_f32(_lib.dptr(f.rowptr), _lib.dptr(f.col), None, _lib.dptr(f.val),
                                                  _lib.dptr(self.dinv), self.n, st), "gcn_norm")
-        elif self.mode == "sum":
+        elif self.mode in ("sum", "gat"):  # gat: values are replaced by attention weights per forward
             f.val = torch.ones(self.nnz, dtype=torch.float32, device=dev)
         elif self.mode == "mean":
             deg = (f.rowptr[1:] - f.rowptr[:-1]).to(torch.float32).clamp(min=1.0)

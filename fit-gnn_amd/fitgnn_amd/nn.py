@@ -105,6 +105,35 @@ class GINConv(nn.Module):
         return self.nn((1.0 + self.eps) * x + ops.SpMM.apply(x, None, g))
 
 
+class GATConv(nn.Module):
+    """PyG GATConv with the arguments FIT-GNN passes (network.py:13-17: `GATConv(in, out)` -> heads=1, concat,
+    negative_slope=0.2, dropout=0, add_self_loops, bias).  Parameters: lin.weight [out,in], att_src [1,1,out],
+    att_dst [1,1,out], bias [out] (PyG >= 2.4 naming)."""
+
+    def __init__(self, in_channels, out_channels, heads=1, negative_slope=0.2, bias=True):
+        super().__init__()
+        if heads != 1:
+            raise NotImplementedError("FIT-GNN constructs GATConv with the default single head")
+        self.in_channels, self.out_channels, self.negative_slope = in_channels, out_channels, negative_slope
+        self.lin = nn.Linear(in_channels, out_channels, bias=False)
+        self.att_src = nn.Parameter(torch.empty(1, 1, out_channels))
+        self.att_dst = nn.Parameter(torch.empty(1, 1, out_channels))
+        self.bias = nn.Parameter(torch.empty(out_channels)) if bias else None
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        glorot_(self.lin.weight)
+        glorot_(self.att_src)
+        glorot_(self.att_dst)
+        if self.bias is not None:
+            nn.init.zeros_(self.bias)
+
+    def forward(self, x, edge_index):
+        g = csr_for(edge_index, x.shape[0], "gat")
+        h = ops.Linear.apply(x.float(), self.lin.weight)
+        return ops.GATAggregate.apply(h, self.att_src.view(-1), self.att_dst.view(-1), self.bias, g, self.negative_slope)
+
+
 class APPNP(nn.Module):
     """z <- (1-alpha) A_hat z + alpha z0, K times (Baselines/SGGC/APPNP/networks.py:11,23: K=10, alpha=0.1)."""
 

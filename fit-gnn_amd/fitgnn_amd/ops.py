@@ -235,6 +235,62 @@ class FusedGCNLayerHead(torch.autograd.Function):
 _seed_state = [0x1234ABCD]
 
 
+class GATAggregate(torch.autograd.Function):
+    """out = softmax-attention aggregation of h over the CSR graph g (GATConv.propagate, heads = 1) + bias.
+    Inputs h [N,C], att_src [C], att_dst [C], bias [C] | None.  g must be a 'sum'-valued pattern with self loops
+    (CSRGraph(mode='gat')); attention weights replace its values."""
+
+    @staticmethod
+    def forward(ctx, h, att_src, att_dst, bias, g, slope):
+        L = _lib.lib()
+        h = _f32c(h)
+        n, C = h.shape
+        dev = h.device
+        st = _lib.stream_ptr(dev)
+        a_src = torch.empty(n, dtype=torch.float32, device=dev)
+        a_dst = torch.empty(n, dtype=torch.float32, device=dev)
+        att_src, att_dst = _f32c(att_src.reshape(-1)), _f32c(att_dst.reshape(-1))
+        _lib.check(L.fitgnn_gat_scores_f32(_lib.dptr(h), C, n, C, _lib.dptr(att_src), _lib.dptr(att_dst), _lib.dptr(a_src),
+                                           _lib.dptr(a_dst), st), "gat_scores")
+        alpha = torch.empty(g.nnz, dtype=torch.float32, device=dev)
+        _lib.check(L.fitgnn_gat_edge_softmax_f32(_lib.dptr(g.f.rowptr), _lib.dptr(g.f.col), _lib.dptr(a_src), _lib.dptr(a_dst),
+                                                 float(slope), n, _lib.dptr(alpha), st), "gat_edge_softmax")
+        out = spmm_raw(g.f.rowptr, g.f.col, alpha, g.f.tiles, h, n, bias=bias, epilogue=EPI_BIAS if bias is not None else 0,
+                       window_rows=g.window_rows, lcol=g.f.lcol, win_cols=g.f.win_cols)
+        ctx.save_for_backward(h, att_src, att_dst, a_src, a_dst, alpha)
+        ctx.g, ctx.slope, ctx.has_bias = g, slope, bias is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dOut):
+        h, att_src, att_dst, a_src, a_dst, alpha = ctx.saved_tensors
+        g, L = ctx.g, _lib.lib()
+        dOut = _f32c(dOut)
+        n, C = h.shape
+        dev = h.device
+        st = _lib.stream_ptr(dev)
+        dalpha = torch.empty_like(alpha)
+        _lib.check(L.fitgnn_sddmm_csr_f32(_lib.dptr(g.f.rowptr), _lib.dptr(g.f.col), _lib.dptr(dOut), C, _lib.dptr(h), C, n, C,
+                                          _lib.dptr(dalpha), st), "sddmm")
+        ds = torch.empty_like(alpha)
+        da_dst = torch.empty(n, dtype=torch.float32, device=dev)
+        _lib.check(L.fitgnn_gat_softmax_bwd_f32(_lib.dptr(g.f.rowptr), _lib.dptr(g.f.col), _lib.dptr(a_src), _lib.dptr(a_dst),
+                                                _lib.dptr(alpha), _lib.dptr(dalpha), float(ctx.slope), n, _lib.dptr(ds),
+                                                _lib.dptr(da_dst), st), "gat_softmax_bwd")
+        ds_t = ds[g._perm_t].contiguous()
+        da_src = torch.empty(n, dtype=torch.float32, device=dev)
+        _lib.check(L.fitgnn_csr_row_sum_f32(_lib.dptr(g.t.rowptr), _lib.dptr(ds_t), n, _lib.dptr(da_src), st), "csr_row_sum")
+        # dh = A_alpha^T dOut + da_src (x) att_src + da_dst (x) att_dst
+        alpha_t = alpha[g._perm_t].contiguous()
+        dh = spmm_raw(g.t.rowptr, g.t.col, alpha_t, g.t.tiles, dOut, n, window_rows=g.window_rows, lcol=g.t.lcol,
+                      win_cols=g.t.win_cols)
+        dh.addcmul_(da_src.unsqueeze(1), att_src.unsqueeze(0)).addcmul_(da_dst.unsqueeze(1), att_dst.unsqueeze(0))
+        datt_src = torch.mv(h.t(), da_src) if ctx.needs_input_grad[1] else None
+        datt_dst = torch.mv(h.t(), da_dst) if ctx.needs_input_grad[2] else None
+        db = dOut.sum(0) if ctx.has_bias and ctx.needs_input_grad[3] else None
+        return dh, datt_src, datt_dst, db, None, None
+
+
 _HEAD_MAX = None
 
 

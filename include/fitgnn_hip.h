@@ -124,6 +124,24 @@ int fitgnn_epilogue_bwd_head_f32(const float *dy, const float *Wl, int32_t C, co
                                  int32_t n_rows, int32_t H, uint32_t epilogue, float p_drop, uint64_t seed,
                                  const uint8_t *mask, float *db, float *dWl, void *work, size_t work_bytes, void *stream);
 
+/* ---- graph attention (torch_geometric.nn.GATConv as network.py:13 constructs it: heads = 1, negative_slope 0.2,
+ * add_self_loops, bias; no attention dropout).  CSR rows = target nodes, self loops included by the caller.
+ *   a_src[j] = h_j . att_src,  a_dst[i] = h_i . att_dst
+ *   alpha_e  = softmax over CSR row i of LeakyReLU(a_src[col[e]] + a_dst[i])
+ *   out      = fitgnn_spmm_csr_f32 with val = alpha (+ bias)
+ * backward:  dalpha_e = dOut_i . h_col[e] (SDDMM);  ds_e = alpha_e (dalpha_e - sum_k alpha_k dalpha_k) LeakyReLU'(s_e);
+ *            da_dst[i] = sum over row i of ds;  da_src = row sums of ds on the transposed order. */
+int fitgnn_gat_scores_f32(const float *h, int64_t ldh, int32_t n, int32_t C, const float *att_src, const float *att_dst,
+                          float *a_src, float *a_dst, void *stream);
+int fitgnn_gat_edge_softmax_f32(const int32_t *rowptr, const int32_t *col, const float *a_src, const float *a_dst,
+                                float negative_slope, int32_t n, float *alpha, void *stream);
+int fitgnn_sddmm_csr_f32(const int32_t *rowptr, const int32_t *col, const float *dOut, int64_t ldo, const float *h,
+                         int64_t ldh, int32_t n, int32_t C, float *dalpha, void *stream);
+int fitgnn_gat_softmax_bwd_f32(const int32_t *rowptr, const int32_t *col, const float *a_src, const float *a_dst,
+                               const float *alpha, const float *dalpha, float negative_slope, int32_t n, float *ds,
+                               float *da_dst, void *stream);
+int fitgnn_csr_row_sum_f32(const int32_t *rowptr, const float *v, int32_t n, float *y, void *stream);
+
 /* =====================================================================================
  * Coarsen half: one contraction level of variation_neighborhoods
  * replaces: graph_coarsening/coarsening_utils.py contract_variation_linear :530-650,

@@ -61,6 +61,25 @@ def gin_aggregate(x, edge_index, eps):
     return (1.0 + eps) * x + torch.zeros_like(x).index_add_(0, col, x[row])
 
 
+def gat_conv(x, edge_index, weight, att_src, att_dst, bias, negative_slope=0.2):
+    """GATConv.forward, heads=1: h = x W^T; e = leaky_relu(a_src.h_j + a_dst.h_i); softmax over the incoming
+    edges of i (self loops: existing ones removed, one added per node); out_i = sum alpha_ij h_j + bias."""
+    n = x.shape[0]
+    row, col = edge_index[0], edge_index[1]
+    keep = row != col
+    loop = torch.arange(n, dtype=row.dtype)
+    row, col = torch.cat([row[keep], loop]), torch.cat([col[keep], loop])
+    h = x @ weight.t()
+    a_s, a_d = (h * att_src.view(1, -1)).sum(1), (h * att_dst.view(1, -1)).sum(1)
+    e = F.leaky_relu(a_s[row] + a_d[col], negative_slope)
+    m = torch.full((n,), float("-inf"), dtype=x.dtype).scatter_reduce(0, col, e, reduce="amax", include_self=True)
+    p = torch.exp(e - m[col])
+    z = torch.zeros(n, dtype=x.dtype).index_add_(0, col, p)
+    alpha = p / z[col]
+    out = torch.zeros((n, h.shape[1]), dtype=x.dtype).index_add_(0, col, h[row] * alpha.unsqueeze(1))
+    return out if bias is None else out + bias
+
+
 def appnp(x, edge_index, K, alpha):
     """APPNP.forward (Baselines/SGGC/APPNP/networks.py:11,23): z <- (1-alpha) A_hat z + alpha z0."""
     n = x.shape[0]

@@ -138,3 +138,45 @@ def test_graph_level_models(mods):
     pooled = torch.stack([H[bt == gi].mean(0) for gi in range(5)])
     ref = pooled @ sd["lt1.weight"].t() + sd["lt1.bias"]
     assert rel(out, ref) < 1e-4
+
+
+@pytest.mark.parametrize("C", [512, 96, 7])
+def test_gatconv_forward_backward(mods, C):
+    network, fnn, gorc = mods
+    ei, n = graph(n=400, m=1600, seed=11)
+    ei = torch.cat([ei, torch.tensor([[5, 9], [5, 9]])], 1)  # explicit self loops are replaced, not doubled
+    torch.manual_seed(3)
+    conv = fnn.GATConv(40, C).cuda()
+    with torch.no_grad():
+        conv.bias.normal_()
+    assert sorted(conv.state_dict()) == ["att_dst", "att_src", "bias", "lin.weight"]
+    x = torch.randn(n, 40)
+    xg = x.cuda().requires_grad_(True)
+    out = conv(xg, ei.cuda())
+    P = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in conv.state_dict().items()}
+    xc = x.clone().requires_grad_(True)
+    ref = gorc.gat_conv(xc, ei, P["lin.weight"], P["att_src"], P["att_dst"], P["bias"])
+    assert rel(out.detach().cpu(), ref.detach()) < 1e-4
+    gout = torch.randn(n, C)
+    out.backward(gout.cuda())
+    ref.backward(gout)
+    assert rel(xg.grad.cpu(), xc.grad) < 1e-3
+    for k, p in conv.named_parameters():
+        assert rel(p.grad.cpu().reshape(-1), P[k].grad.reshape(-1)) < 1e-3, k
+
+
+def test_classify_node_with_gat_layers(mods):
+    network, fnn, gorc = mods
+    ei, n = graph(n=300, m=900, seed=13)
+    args = argparse.Namespace(num_layers1=2, layer_name="GATConv", num_features=20, hidden=64, num_classes=4)
+    torch.manual_seed(4)
+    model = network.Classify_node(args).cuda().eval()
+    x = torch.rand(n, 20)
+    out = model(x.cuda(), ei.cuda()).detach().cpu()
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    h = x
+    for i in range(2):
+        h = torch.nn.functional.elu(gorc.gat_conv(h, ei, sd[f"conv.{i}.lin.weight"], sd[f"conv.{i}.att_src"],
+                                                  sd[f"conv.{i}.att_dst"], sd[f"conv.{i}.bias"]))
+    ref = torch.log_softmax(h @ sd["lt1.weight"].t() + sd["lt1.bias"], dim=1)
+    assert rel(out, ref) < 1e-4
