@@ -1,0 +1,358 @@
+"""Node-level FIT-GNN pipeline behind main.py: dataset -> components -> coarsen -> Gc / Gs -> train -> infer.
+
+Restates, on device-resident structures, what the reference does for `--task node_cls`:
+    utils.coarsening_classification   utils.py:143-374   components, coarsen(), cluster map, subgraphs Gs
+    utils.splits_classification       utils.py:612-643   fixed / random / few / ogbn_split masks
+    utils.load_data_classification    utils.py:661-778   Gc features C.X, pooled labels and masks, Gc edges, Gs masks
+    run.node_classification           run.py:329-506     exp_setup loops, best-val checkpoint, results CSV
+    run.node_classification_baseline  run.py:832-902     full-graph baseline
+The contraction step, pooling and all message passing run through libfitgnn_hip.so; index bookkeeping is
+vectorised NumPy/torch instead of the reference's per-node Python loops.
+"""
+import os
+import pickle
+import time
+
+import numpy as np
+import scipy.sparse as sp
+import torch
+import torch.nn.functional as F
+
+from . import coarsening, data as fdata, network
+from .train import GDTrainer
+
+SYNTHETIC_SHAPES = {  # name: (N, E, F, classes)   dataset_info.csv:4-7
+    "synthetic-cora": (2708, 5278, 1433, 7),
+    "synthetic-citeseer": (3327, 4552, 3703, 6),
+    "synthetic-pubmed": (19717, 44324, 500, 3),
+    "synthetic-physics": (34493, 247962, 8415, 5),
+}
+
+
+class NodeData:
+    """The fields of a PyG `Data` object the node-level path reads."""
+
+    def __init__(self, x, edge_index, y, train_mask=None, val_mask=None, test_mask=None):
+        self.x, self.edge_index, self.y = x, edge_index, y
+        self.num_nodes = x.shape[0]
+        z = torch.zeros(self.num_nodes, dtype=torch.bool)
+        self.train_mask = z.clone() if train_mask is None else train_mask
+        self.val_mask = z.clone() if val_mask is None else val_mask
+        self.test_mask = z.clone() if test_mask is None else test_mask
+
+
+def load_planetoid(root, name):
+    """Planetoid raw files ind.<name>.{x,tx,allx,y,ty,ally,graph,test.index} (the format torch_geometric's Planetoid
+    downloads; the reference ships Cora/CiteSeer copies under Baselines/SGGC/APPNP/dataset/<name>/raw)."""
+    def rd(suffix):
+        with open(os.path.join(root, f"ind.{name}.{suffix}"), "rb") as f:
+            return pickle.load(f, encoding="latin1")
+
+    x, tx, allx, y, ty, ally, graph = (rd(s) for s in ("x", "tx", "allx", "y", "ty", "ally", "graph"))
+    test_idx = np.loadtxt(os.path.join(root, f"ind.{name}.test.index"), dtype=np.int64)
+    test_sorted = np.sort(test_idx)
+    if name == "citeseer":  # isolated test nodes are missing from tx/ty: pad with zeros (PyG does the same)
+        full = np.arange(test_sorted[0], test_sorted[-1] + 1)
+        tx_ext = sp.lil_matrix((len(full), tx.shape[1]))
+        tx_ext[test_sorted - test_sorted[0], :] = tx
+        ty_ext = np.zeros((len(full), ty.shape[1]))
+        ty_ext[test_sorted - test_sorted[0], :] = ty
+        tx, ty = tx_ext, ty_ext
+    feats = sp.vstack([allx, tx]).tolil()
+    feats[test_idx, :] = feats[test_sorted, :]
+    labels = np.vstack([ally, ty])
+    labels[test_idx, :] = labels[test_sorted, :]
+    N = feats.shape[0]
+    src, dst = [], []
+    for u, nbrs in graph.items():
+        for v in nbrs:
+            if u != v:
+                src += [u, v]
+                dst += [v, u]
+    ei = np.unique(np.array([src, dst], dtype=np.int64), axis=1)
+    ei = ei[:, (ei[0] < N) & (ei[1] < N)]
+    yv = torch.from_numpy(labels.argmax(1).astype(np.int64))
+    train = torch.zeros(N, dtype=torch.bool); val = train.clone(); test = train.clone()
+    train[: y.shape[0]] = True
+    val[y.shape[0]: y.shape[0] + 500] = True
+    test[torch.from_numpy(test_idx)] = True
+    return NodeData(torch.from_numpy(np.asarray(feats.todense(), dtype=np.float32)), ei, yv, train, val, test), int(labels.shape[1])
+
+
+def synthetic_dataset(name, seed=0):
+    """Seeded stand-in of a dataset's shape (no network access for the real files): preferential-attachment graph,
+    labels = a noisy function of graph position so that the task is learnable, features = class centroid + noise."""
+    N, E, Fdim, C = SYNTHETIC_SHAPES[name]
+    rng = np.random.default_rng(seed)
+    ei = fdata.synthetic_graph(N, E, seed=seed)
+    W = sp.csr_matrix((np.ones(ei.shape[1]), (ei[0], ei[1])), shape=(N, N))
+    lab = rng.integers(0, C, size=N)
+    for _ in range(3):  # smooth labels over the graph so neighbours agree (homophily)
+        onehot = np.eye(C)[lab]
+        lab = np.asarray((W @ onehot) + 0.5 * onehot + 1e-3 * rng.random((N, C))).argmax(1)
+    # bag-of-words features: 12 words per node, 70 % drawn from the class's own block of the vocabulary
+    words = 12
+    own = rng.random((N, words)) < 0.7
+    blk = Fdim // C
+    w_own = lab[:, None] * blk + rng.integers(0, blk, size=(N, words))
+    w_any = rng.integers(0, Fdim, size=(N, words))
+    w = np.where(own, w_own, w_any)
+    X = np.zeros((N, Fdim), dtype=np.float32)
+    X[np.repeat(np.arange(N), words), w.ravel()] = 1.0
+    d = NodeData(torch.from_numpy(X), ei, torch.from_numpy(lab.astype(np.int64)))
+    perm = rng.permutation(N)
+    d.train_mask[perm[: 20 * C]] = True
+    d.val_mask[perm[20 * C: 20 * C + 500]] = True
+    d.test_mask[perm[20 * C + 500: 20 * C + 1500]] = True
+    return d, C
+
+
+def splits_classification(data, num_classes, exp, rng=None):
+    """utils.py:612-643."""
+    if exp == "fixed":
+        return data
+    g = torch.Generator().manual_seed(int(rng.integers(0, 2 ** 31))) if rng is not None else None
+    idxs = []
+    for c in range(num_classes):
+        idx = (data.y.flatten() == c).nonzero().view(-1)
+        idxs.append(idx[torch.randperm(idx.numel(), generator=g)])
+    N = data.num_nodes
+    if exp == "random":
+        tr, va, te = (torch.cat([i[:20] for i in idxs]), torch.cat([i[20:50] for i in idxs]), torch.cat([i[50:] for i in idxs]))
+    elif exp == "few":
+        tr, va, te = (torch.cat([i[:5] for i in idxs]), torch.cat([i[5:10] for i in idxs]), torch.cat([i[10:] for i in idxs]))
+    elif exp == "ogbn_split":
+        p = torch.randperm(N, generator=g)
+        tr, va, te = p[: int(0.08 * N)], p[int(0.08 * N): int(0.1 * N)], p[int(0.1 * N):]
+    else:
+        raise ValueError(exp)
+    for name, idx in (("train_mask", tr), ("val_mask", va), ("test_mask", te)):
+        m = torch.zeros(N, dtype=torch.bool)
+        m[idx] = True
+        setattr(data, name, m)
+    return data
+
+
+class Coarsened:
+    """Result of coarsening_classification: per-component C / Gc and the global node -> cluster map."""
+    pass
+
+
+def coarsening_classification(args, data, coarsening_ratio, coarsening_method, device="cuda"):
+    """utils.py:143-184: components sorted by size (descending, stable), coarsen() on every component with more
+    than one node (Loukas r = 1 - --coarsening_ratio is passed by main.py:278), node -> cluster map from the
+    level mapping dicts; single nodes are their own cluster."""
+    N = data.num_nodes
+    ei = np.asarray(data.edge_index)
+    W = sp.csr_matrix((np.ones(ei.shape[1]), (ei[0], ei[1])), shape=(N, N))
+    W.data[:] = 1.0
+    comps = coarsening.Graph(W).extract_components()
+    comps = sorted(comps, key=lambda g: len(g.info["orig_idx"]), reverse=True)  # utils.py:146 (stable)
+    out = Coarsened()
+    out.components, out.C_list, out.Gc_list = comps, [], []   # *_list: components with > 10 nodes only (:164-166)
+    out.all_C, out.all_Gc = [], []
+    assign = np.zeros(N, dtype=np.int64)
+    off = 0
+    out.comp_cluster_off = []
+    for H in comps:
+        idx = np.asarray(H.info["orig_idx"], dtype=np.int64)
+        out.comp_cluster_off.append(off)
+        if len(idx) > 1:
+            C, Gc, maps = coarsening.coarsen(H, r=coarsening_ratio, method=coarsening_method, device=device)
+            a = sp.csc_matrix(C).indices.astype(np.int64)  # composed mapping dicts == row of C's single entry
+            assign[idx] = off + a
+            off += C.shape[0]
+            out.all_C.append(C); out.all_Gc.append(Gc)
+            if len(idx) > 10:
+                out.C_list.append(C); out.Gc_list.append(Gc)
+        else:
+            assign[idx] = off
+            off += 1
+            out.all_C.append(None); out.all_Gc.append(None)
+    out.assign, out.n_clusters = assign, off
+    return out
+
+
+def build_gs(args, data, co, device="cuda"):
+    """Subgraphs Gs (utils.py:186-267) + their masks (utils.py:683-703) as one block-diagonal SubgraphBatch."""
+    if getattr(args, "cluster_node", False):
+        raise NotImplementedError("--cluster_node subgraphs are not built yet; use --extra_node or neither")
+    sub = fdata.assemble_subgraphs(data.edge_index, data.num_nodes, co.assign, co.n_clusters,
+                                   extra_node=bool(getattr(args, "extra_node", False)))
+    batch = fdata.SubgraphBatch(sub, data.x, data.y.flatten(), data.train_mask, device=device)
+    core = batch.core
+    batch.val_idx = torch.nonzero(data.val_mask.to(device)[batch.node_id] & core).flatten()
+    batch.test_idx = torch.nonzero(data.test_mask.to(device)[batch.node_id] & core).flatten()
+    return batch
+
+
+def build_gc(args, data, co, device="cuda"):
+    """The coarsened graph Gc of load_data_classification (utils.py:705-775): per component with > 10 nodes that holds
+    train/val nodes: features C.X, label = argmax of pooled one-hot train (val) labels, mask = cluster holds labelled
+    nodes of exactly one class, edges of Gc.W; smaller such components pass through uncoarsened."""
+    n_classes = args.num_classes
+    xs, tr_lab, tr_mask, va_lab, va_mask, rows, cols = [], [], [], [], [], [], []
+    off, k_big = 0, 0
+    y = data.y.flatten()
+    onehot = torch.eye(n_classes)
+    for H in co.components:
+        idx = torch.as_tensor(np.asarray(H.info["orig_idx"], dtype=np.int64))
+        big = len(idx) > 10
+        C = Gc = None
+        if big:
+            C, Gc = co.C_list[k_big], co.Gc_list[k_big]  # utils.py:723-724: indexed by rank among big components
+            k_big += 1
+        tm, vm = data.train_mask[idx], data.val_mask[idx]
+        if int(tm.sum()) + int(vm.sum()) == 0:
+            continue
+        if big:
+            Xc = C.pool(data.x[idx].to(device)).cpu()
+            tl = onehot[y[idx]].clone(); tl[~tm] = 0
+            vl = onehot[y[idx]].clone(); vl[~vm] = 0
+            ptl, pvl = torch.from_numpy(C.dot(tl.numpy())), torch.from_numpy(C.dot(vl.numpy()))
+            for pooled, labs, masks in ((ptl, tr_lab, tr_mask), (pvl, va_lab, va_mask)):
+                m = pooled.sum(1) > 0
+                m &= ~((pooled > 0).sum(1) > 1)  # clusters mixing classes are not train (val) nodes (:728-730)
+                labs.append(pooled.argmax(1))
+                masks.append(m)
+            coo = Gc.W.tocoo()
+            n_c = Gc.N
+        else:
+            if not rows:
+                raise Exception("The graph does not need coarsening.")  # utils.py:763
+            Xc = data.x[idx]
+            tr_lab.append(y[idx]); va_lab.append(y[idx]); tr_mask.append(tm); va_mask.append(vm)
+            coo = H.W.tocoo()
+            n_c = len(idx)
+        xs.append(Xc.float())
+        rows.append(coo.row.astype(np.int64) + off); cols.append(coo.col.astype(np.int64) + off)
+        off += n_c
+    gc = type("Gc", (), {})()
+    gc.x = torch.cat(xs).to(device)
+    if getattr(args, "normalize_features", False):
+        gc.x = F.normalize(gc.x, p=1)  # run.py:334-335
+    gc.edge_index = torch.from_numpy(np.stack([np.concatenate(rows), np.concatenate(cols)])).to(device)
+    gc.train_labels, gc.val_labels = torch.cat(tr_lab).long().to(device), torch.cat(va_lab).long().to(device)
+    gc.train_idx = torch.nonzero(torch.cat(tr_mask)).flatten().to(device)
+    gc.val_idx = torch.nonzero(torch.cat(va_mask)).flatten().to(device)
+    return gc
+
+
+def _nll(model, x, ei, idx, labels, reduction):
+    out = model(x, ei)
+    return F.nll_loss(out.index_select(0, idx), labels.index_select(0, idx) if labels.numel() != idx.numel() else labels,
+                      reduction=reduction), out
+
+
+@torch.no_grad()
+def infer_gs(model, batch, idx, reduction="mean"):
+    """node_infer_Gs_GD (run.py:49-115): loss, accuracy and forward wall time over the subgraphs."""
+    model.eval()
+    torch.cuda.synchronize()
+    t0 = time.time()
+    out = model(batch.x, batch.edge_index)
+    torch.cuda.synchronize()
+    dt = time.time() - t0
+    sel, y = out.index_select(0, idx), batch.y.index_select(0, idx)
+    loss = float(F.nll_loss(sel, y, reduction="mean"))
+    return loss, float((sel.argmax(1) == y).float().mean()), dt
+
+
+def node_classification(args, path, data, co, device="cuda", log=print):
+    """run.node_classification (run.py:329-506) for exp_setup in {Gc_train_2_Gs_infer, Gs_train_2_Gs_infer,
+    Gc_train_2_Gs_train}, gradient_method GD."""
+    if args.gradient_method != "GD":
+        raise NotImplementedError("MB mode (sequential step per batch, run.py:217-252) is not built; use GD")
+    rng = np.random.default_rng(args.seed)
+    data = splits_classification(data, args.num_classes, args.experiment, rng)
+    batch = build_gs(args, data, co, device)
+    gc = build_gc(args, data, co, device) if args.exp_setup != "Gs_train_2_Gs_infer" else None
+    all_loss, all_acc, all_time = [], [], []
+    ckpt = os.path.join(path, "model.pt")
+    for run in range(args.runs):
+        if args.seed is not None:
+            torch.manual_seed(args.seed + run)
+        model = network.Classify_node(args).to(device)
+        model.reset_parameters()
+        opt = torch.optim.Adam(model.parameters(), lr=args.lr, weight_decay=args.weight_decay)
+        if args.exp_setup in ("Gc_train_2_Gs_infer", "Gc_train_2_Gs_train"):
+            best = float("inf")
+            for epoch in range(args.epochs1):  # node_train_Gc / node_val_Gc (run.py:26-47)
+                model.train()
+                opt.zero_grad()
+                out = model(gc.x, gc.edge_index)
+                loss = F.nll_loss(out.index_select(0, gc.train_idx), gc.train_labels.index_select(0, gc.train_idx),
+                                  reduction=args.loss_reduction)
+                loss.backward()
+                opt.step()
+                model.eval()
+                with torch.no_grad():
+                    out = model(gc.x, gc.edge_index)
+                    vloss = float(F.nll_loss(out.index_select(0, gc.val_idx), gc.val_labels.index_select(0, gc.val_idx),
+                                             reduction=args.loss_reduction))
+                if vloss < best or epoch == 0:
+                    best = vloss
+                    torch.save(model.state_dict(), ckpt)
+            model.load_state_dict(torch.load(ckpt))
+        if args.exp_setup in ("Gs_train_2_Gs_infer", "Gc_train_2_Gs_train"):
+            trainer = GDTrainer(model, batch, lr=args.lr, weight_decay=args.weight_decay, reduction=args.loss_reduction)
+            if args.exp_setup == "Gc_train_2_Gs_train":
+                trainer.opt.load_state_dict(opt.state_dict())  # the reference keeps ONE optimizer across both phases
+            best = float("inf")
+            for epoch in range(args.epochs2):
+                trainer.step()
+                vloss, vacc, _ = infer_gs(model, batch, batch.val_idx)
+                if vloss < best or epoch == 0:
+                    best = vloss
+                    torch.save(model.state_dict(), ckpt)
+            model.load_state_dict(torch.load(ckpt))
+        tloss, tacc, ttime = infer_gs(model, batch, batch.test_idx)
+        log(f"run {run + 1}: test_loss {tloss:.4f} test_acc {tacc:.4f} infer_time {ttime * 1e3:.2f} ms")
+        all_loss.append(tloss); all_acc.append(tacc); all_time.append(ttime)
+    return all_loss, all_acc, all_time
+
+
+def node_classification_baseline(args, path, data, device="cuda", log=print):
+    """run.node_classification_baseline (run.py:832-902): the 2-layer model on the full graph."""
+    rng = np.random.default_rng(args.seed)
+    data = splits_classification(data, args.num_classes, args.experiment, rng)
+    x = data.x.to(device).float()
+    ei = torch.as_tensor(np.asarray(data.edge_index)).to(device)
+    y = data.y.flatten().to(device)
+    tr, va, te = (torch.nonzero(m.to(device)).flatten() for m in (data.train_mask, data.val_mask, data.test_mask))
+    all_loss, all_acc, all_time = [], [], []
+    ckpt = os.path.join(path, "model.pt")
+    for run in range(args.runs):
+        if args.seed is not None:
+            torch.manual_seed(args.seed + run)
+        model = network.Classify_node(args).to(device)
+        model.reset_parameters()
+        opt = torch.optim.Adam(model.parameters(), lr=args.lr, weight_decay=args.weight_decay)
+        best = float("inf")
+        for epoch in range(args.epochs1):
+            model.train()
+            opt.zero_grad()
+            out = model(x, ei)
+            F.nll_loss(out.index_select(0, tr), y.index_select(0, tr), reduction=args.loss_reduction).backward()
+            opt.step()
+            model.eval()
+            with torch.no_grad():
+                out = model(x, ei)
+                vloss = float(F.nll_loss(out.index_select(0, va), y.index_select(0, va), reduction=args.loss_reduction))
+            if vloss < best or epoch == 0:
+                best = vloss
+                torch.save(model.state_dict(), ckpt)
+        model.load_state_dict(torch.load(ckpt))
+        model.eval()
+        with torch.no_grad():
+            torch.cuda.synchronize()
+            t0 = time.time()
+            out = model(x, ei)
+            torch.cuda.synchronize()
+            dt = time.time() - t0
+            sel = out.index_select(0, te)
+            tloss = float(F.nll_loss(sel, y.index_select(0, te)))
+            tacc = float((sel.argmax(1) == y.index_select(0, te)).float().mean())
+        log(f"run {run + 1}: test_loss {tloss:.4f} test_acc {tacc:.4f} infer_time {dt * 1e3:.2f} ms")
+        all_loss.append(tloss); all_acc.append(tacc); all_time.append(dt)
+    return all_loss, all_acc, all_time

@@ -1,0 +1,166 @@
+#!/usr/bin/env python3
+"""main.py -- FIT-GNN's training command line on the MI355X implementation.
+
+Same flags, defaults and `store_true` semantics as the reference's main.py:176-208, same post-parse corrections
+(arg_correction, main.py:117-129), same outputs: best-val `model.pt` under save/<task>/[baseline/]<output_dir>/ and a
+row appended to results/<dataset>.csv (results/baseline/<dataset>.csv) with the reference's columns
+(run.py:480-485, :883-887).  Node-classification tasks only in this round (the hot path BASELINE.json names).
+
+Datasets: the reference downloads through torch_geometric / ogb, which are not available here.  Accepted:
+  cora | citeseer | pubmed   Planetoid raw files `ind.<name>.*` under --data_root/<name>/raw (PyG's own layout)
+  synthetic-{cora,citeseer,pubmed,physics}   seeded stand-ins of the same shape (dataset_info.csv)
+Extra flags (not in the reference): --data_root, --device.
+"""
+import argparse
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+if HERE not in sys.path:
+    sys.path.insert(0, HERE)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+
+def build_parser():
+    p = argparse.ArgumentParser()
+    p.add_argument('--dataset', type=str, default='cora')
+    p.add_argument('--experiment', type=str, default='fixed')
+    p.add_argument('--runs', type=int, default=20)
+    p.add_argument('--exp_setup', type=str, default='Gc_train_2_Gs_infer')
+    p.add_argument('--hidden', type=int, default=512)
+    p.add_argument('--layer_name', type=str, default='GCNConv')  # GCNConv, GATConv, SAGEConv, GINConv
+    p.add_argument('--epochs1', type=int, default=100)
+    p.add_argument('--epochs2', type=int, default=300)
+    p.add_argument('--num_layers1', type=int, default=2)
+    p.add_argument('--num_layers2', type=int, default=2)
+    p.add_argument('--batch_size', type=int, default=128)
+    p.add_argument('--train_ratio', type=float, default=0.3)
+    p.add_argument('--val_ratio', type=float, default=0.2)
+    p.add_argument('--early_stopping', type=int, default=10)
+    p.add_argument('--extra_node', action='store_true')
+    p.add_argument('--cluster_node', action='store_true')
+    p.add_argument('--lr', type=float, default=0.01)
+    p.add_argument('--weight_decay', type=float, default=0.0005)
+    p.add_argument('--gradient_method', type=str, default='GD')
+    p.add_argument('--use_community_detection', action='store_true')
+    p.add_argument('--normalize_features', action='store_true')
+    p.add_argument('--coarsening_ratio', type=float, default=0.5)
+    p.add_argument('--coarsening_method', type=str, default='variation_neighborhoods')
+    p.add_argument('--output_dir', type=str, required=True)
+    p.add_argument('--task', type=str, default='node_cls')
+    p.add_argument('--seed', type=int, default=None)
+    p.add_argument('--multi_prop', action='store_true')
+    p.add_argument('--loss_reduction', type=str, default='mean')
+    p.add_argument('--property', type=int, default=0)
+    p.add_argument('--train_fitgnn', action='store_true')
+    p.add_argument('--run_intermediate_inference', action='store_true')
+    p.add_argument('--intermediate_inference_freq', type=int, default=10)
+    p.add_argument('--baseline', action='store_true')
+    # not in the reference
+    p.add_argument('--data_root', type=str, default='./dataset')
+    p.add_argument('--device', type=str, default='cuda')
+    return p
+
+
+def arg_correction(args):
+    """main.py:117-129."""
+    if args.cluster_node:
+        args.extra_node = False
+    elif args.extra_node:
+        args.cluster_node = False
+    if args.experiment == 'fixed' and args.dataset in ('ogbn-products', 'dblp', 'Physics', 'WikiCS', 'Flickr'):
+        args.experiment = 'random'
+    if args.train_fitgnn:
+        args.baseline = False
+    if args.train_fitgnn is False:
+        args.baseline = True
+    return args
+
+
+def process_dataset(args):
+    from fitgnn_amd import pipeline
+
+    name = args.dataset
+    if name in pipeline.SYNTHETIC_SHAPES:
+        data, n_classes = pipeline.synthetic_dataset(name, seed=0 if args.seed is None else args.seed)
+        if args.experiment == 'fixed':
+            pass  # the generator already provides a 20-per-class / 500 / 1000 split
+    elif name in ('cora', 'citeseer', 'pubmed'):
+        root = os.path.join(args.data_root, name, 'raw')
+        if not os.path.exists(os.path.join(root, f'ind.{name}.x')):
+            raise FileNotFoundError(f"{root}/ind.{name}.* not found (no network access to download; point --data_root at a "
+                                    f"directory holding <name>/raw, or use --dataset synthetic-{name})")
+        data, n_classes = pipeline.load_planetoid(root, name)
+    else:
+        raise NotImplementedError(f"dataset '{name}' needs torch_geometric/ogb downloads, which this build does not have; "
+                                  f"available: cora citeseer pubmed {' '.join(pipeline.SYNTHETIC_SHAPES)}")
+    if args.normalize_features:
+        data.x = torch.nn.functional.normalize(data.x, p=1)
+    args.task = 'node_cls'
+    args.num_features, args.num_classes = data.x.shape[1], n_classes
+    return data, args
+
+
+def write_results(args, all_loss, all_acc, all_time, baseline):
+    top_acc = sorted(all_acc, reverse=True)[:10]
+    top_loss = sorted(all_loss)[:10]
+    os.makedirs('results/baseline', exist_ok=True)
+    if baseline:
+        fn = f"results/baseline/{args.dataset}.csv"
+        header = 'dataset,experiment,layer_name,hidden,runs,num_layers,lr,ave_acc,ave_time,top_10_acc,best_acc,top_10_loss,best_loss\n'
+        row = (f"{args.dataset},{args.experiment},{args.layer_name},{args.hidden},{args.runs},{args.num_layers1},{args.lr},"
+               f"{np.mean(all_acc)} +/- {np.std(all_acc)},{np.mean(all_time)},{np.mean(top_acc)} +/- {np.std(top_acc)}, {top_acc[0]}, "
+               f"{np.mean(top_loss)} +/- {np.std(top_loss)}, {top_loss[0]}\n")
+    else:
+        fn = f"results/{args.dataset}.csv"
+        header = ('dataset,coarsening_method,coarsening_ratio,experiment,exp_setup,layer_name,extra_nodes,cluster_node,community_used,'
+                  'hidden,runs,num_layers,batch_size,lr,ave_acc,ave_time,top_10_acc,best_acc,top_10_loss,best_loss\n')
+        row = (f"{args.dataset},{args.coarsening_method},{args.coarsening_ratio},{args.experiment},{args.exp_setup},{args.layer_name},"
+               f"{args.extra_node},{args.cluster_node},{args.use_community_detection},{args.hidden},{args.runs},{args.num_layers1},"
+               f"{args.batch_size},{args.lr},{np.mean(all_acc)} +/- {np.std(all_acc)},{np.mean(all_time)},"
+               f"{np.mean(top_acc)} +/- {np.std(top_acc)}, {top_acc[0]}, {np.mean(top_loss)} +/- {np.std(top_loss)}, {top_loss[0]}\n")
+    if not os.path.exists(fn):
+        with open(fn, 'w') as f:
+            f.write(header)
+    with open(fn, 'a') as f:
+        f.write(row)
+    tag = "BASELINE MODEL" if baseline else "FIT-GNN MODEL"
+    print(f"############################### {tag} ###############################")
+    for k in ("dataset", "experiment", "exp_setup", "layer_name", "hidden", "runs", "lr", "coarsening_ratio", "coarsening_method"):
+        print(f"{k}: {getattr(args, k)}")
+    print(f"ave_acc: {np.mean(all_acc)} +/- {np.std(all_acc)}")
+    print(f"ave_time: {np.mean(all_time)}")
+    print(f"best_acc: {top_acc[0]}")
+    print(f"best_loss: {top_loss[0]}")
+    print("#############################################################################")
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    args = arg_correction(args)
+    if args.seed is not None:
+        np.random.seed(args.seed)
+        torch.manual_seed(args.seed)
+    data, args = process_dataset(args)
+    from fitgnn_amd import pipeline
+
+    path = f"save/{args.task}/" + (f"baseline/{args.output_dir}/" if args.baseline else f"{args.output_dir}/")
+    os.makedirs(path, exist_ok=True)
+    if args.use_community_detection:
+        raise NotImplementedError("--use_community_detection needs igraph/leidenalg (main.py:247-267), not available here")
+    if args.baseline:
+        res = pipeline.node_classification_baseline(args, path, data, device=args.device)
+        write_results(args, *res, baseline=True)
+    else:
+        co = pipeline.coarsening_classification(args, data, 1 - args.coarsening_ratio, args.coarsening_method,
+                                                device=args.device)  # main.py:278 passes 1 - rho as Loukas' r
+        print(f"coarsened {data.num_nodes} nodes in {len(co.components)} components into {co.n_clusters} clusters")
+        res = pipeline.node_classification(args, path, data, co, device=args.device)
+        write_results(args, *res, baseline=False)
+    return res
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,87 @@
+"""CLI surface of fit-gnn_amd/main.py vs the reference's main.py (flags, defaults, arg_correction), the Planetoid
+raw-file loader (CPU tier; reference files are read only when /root/reference is present), and an end-to-end
+GPU run of both the baseline and the FIT-GNN path on a synthetic Cora-shaped dataset."""
+import ast
+import os
+import re
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "fit-gnn_amd"))
+import main as cli  # noqa: E402
+
+REF_MAIN = "/root/reference/main.py"
+REF_CORA = "/root/reference/Baselines/SGGC/APPNP/dataset/cora/raw"
+
+
+def test_arg_correction_rules():
+    p = cli.build_parser()
+    a = cli.arg_correction(p.parse_args(["--output_dir", "x"]))
+    assert a.baseline is True and a.train_fitgnn is False          # main.py:125-128
+    a = cli.arg_correction(p.parse_args(["--output_dir", "x", "--train_fitgnn", "--baseline"]))
+    assert a.baseline is False
+    a = cli.arg_correction(p.parse_args(["--output_dir", "x", "--cluster_node", "--extra_node"]))
+    assert a.cluster_node and not a.extra_node                     # main.py:118-119
+    a = cli.arg_correction(p.parse_args(["--output_dir", "x", "--dataset", "Physics"]))
+    assert a.experiment == "random"                                # main.py:122-124
+
+
+@pytest.mark.skipif(not os.path.exists(REF_MAIN), reason="reference not mounted")
+def test_flags_and_defaults_match_reference_main_py():
+    src = open(REF_MAIN).read()
+    ref = {}
+    for m in re.finditer(r"parser\.add_argument\((.*)\)", src):
+        call = ast.parse("f(" + m.group(1).split("#")[0].rstrip().rstrip(")") + ")").body[0].value
+        name = call.args[0].value
+        kw = {k.arg: k.value for k in call.keywords}
+        default = ast.literal_eval(kw["default"]) if "default" in kw else (False if "action" in kw else None)
+        ref[name] = (default, "action" in kw, "required" in kw)
+    assert len(ref) == 33
+    mine = {a.option_strings[0]: a for a in cli.build_parser()._actions if a.option_strings and a.option_strings[0] != "-h"}
+    for name, (default, is_flag, required) in ref.items():
+        assert name in mine, name
+        assert mine[name].default == default, name
+        assert (mine[name].nargs == 0) == is_flag, name
+        assert mine[name].required == required, name
+
+
+@pytest.mark.skipif(not os.path.exists(REF_CORA), reason="reference not mounted")
+def test_planetoid_loader_on_reference_cora_files():
+    from fitgnn_amd import pipeline
+
+    data, C = pipeline.load_planetoid(REF_CORA, "cora")
+    assert (data.num_nodes, data.x.shape[1], C) == (2708, 1433, 7)          # dataset_info.csv:5
+    assert data.edge_index.shape[1] == 2 * 5278
+    assert int(data.train_mask.sum()) == 140 and int(data.val_mask.sum()) == 500 and int(data.test_mask.sum()) == 1000
+
+
+def test_splits():
+    from fitgnn_amd import pipeline
+
+    d, C = pipeline.synthetic_dataset("synthetic-cora", seed=1)
+    assert d.x.shape == (2708, 1433) and d.edge_index.shape == (2, 2 * 5278)
+    d = pipeline.splits_classification(d, C, "random", np.random.default_rng(0))
+    assert int(d.train_mask.sum()) == 20 * C and int(d.val_mask.sum()) == 30 * C
+    assert not bool((d.train_mask & d.val_mask).any()) and not bool((d.train_mask & d.test_mask).any())
+    assert int(d.train_mask.sum() + d.val_mask.sum() + d.test_mask.sum()) == 2708
+
+
+@pytest.mark.gpu
+def test_cli_end_to_end_on_synthetic_cora(tmp_path, monkeypatch):
+    monkeypatch.chdir(tmp_path)
+    common = ["--dataset", "synthetic-cora", "--runs", "1", "--hidden", "64", "--seed", "0", "--normalize_features"]
+    _, acc, _ = cli.main(common + ["--output_dir", "b", "--baseline", "--epochs1", "40"])
+    assert acc[0] > 0.5, acc  # 7 classes, homophilous synthetic labels: far above 1/7
+    assert os.path.exists("save/node_cls/baseline/b/model.pt") and os.path.exists("results/baseline/synthetic-cora.csv")
+    for setup, extra in (("Gs_train_2_Gs_infer", ["--extra_node"]), ("Gc_train_2_Gs_infer", []), ("Gc_train_2_Gs_train", ["--extra_node"])):
+        _, acc, _ = cli.main(common + ["--output_dir", "f", "--train_fitgnn", "--exp_setup", setup, "--coarsening_ratio", "0.5",
+                                       "--epochs1", "40", "--epochs2", "40"] + extra)
+        assert acc[0] > 0.4, (setup, acc)
+    rows = open("results/synthetic-cora.csv").read().strip().split("\n")
+    assert rows[0].startswith("dataset,coarsening_method,coarsening_ratio") and len(rows) == 4
+    sd = torch.load("save/node_cls/f/model.pt")
+    assert sorted(sd) == ["conv.0.bias", "conv.0.lin.weight", "conv.1.bias", "conv.1.lin.weight", "lt1.bias", "lt1.weight"]
