@@ -108,6 +108,9 @@ def main():
     ap.add_argument("--workload", default="S-pubmed")
     ap.add_argument("--hidden", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-dedup", action="store_true",
+                    help="run layer 0's X@W^T on the materialised union rows (one copy per subgraph membership) instead of "
+                         "the de-duplicated feature table")
     ap.add_argument("--gemm-precision", default="high", choices=["high", "highest"],
                     help="dense GEMM policy (fitgnn_amd.ops.GEMM_PRECISION): high = fp32 via 3xbf16 split on the forward/dX "
                          "products (rel err ~5e-6), highest = plain fp32 MFMA everywhere")
@@ -133,7 +136,7 @@ def main():
     torch.manual_seed(2)  # weight seed; identical on every rank
     model = network.Classify_node(margs).to(device)
     sd0 = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
-    trainer = train.GDTrainer(model, batch, lr=0.01, weight_decay=5e-4)
+    trainer = train.GDTrainer(model, batch, lr=0.01, weight_decay=5e-4, dedup=not args.no_dedup)
 
     def barrier():
         if world > 1:
@@ -180,6 +183,8 @@ def main():
                                f"union per GPU, 2-layer GCN hidden {H}, GD step + Adam", "parallelism": f"dp{world}",
                    "dense_gemm": ("hipBLASLt fp32 operands, 3xbf16-split MFMA for X@W^T and dH@W (rel err ~5e-6 vs fp64), "
                                   "fp32 MFMA for dH^T@X") if args.gemm_precision == "high" else "hipBLASLt fp32 MFMA",
+                   "layer0_features": "de-duplicated table (19717 rows) + row indirection in the SpMM" if trainer.dedup
+                   else "materialised union rows",
                    **info},
         "roofline": {"kernel": "spmm_tile_kernel<VEC=4,B=4,MPR=16> (CSR SpMM, LDS row windows, H=%d, f32)" % H, "bound": "hbm", "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

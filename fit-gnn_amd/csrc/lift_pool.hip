@@ -229,6 +229,34 @@ __global__ __launch_bounds__(256) void pool_rows_kernel(const int32_t *__restric
     }
 }
 
+// f32 segment sum (one wave per (segment, 64*VEC-column slab)), members in the given order
+template <int VEC>
+__global__ __launch_bounds__(256) void segment_sum_kernel(const int32_t *__restrict__ off, const int32_t *__restrict__ members,
+                                                          int32_t n_seg, const float *__restrict__ X, int64_t ldx, int32_t F,
+                                                          float *__restrict__ out, int64_t ldo) {
+    const int sgm = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (sgm >= n_seg) return;
+    const int f0 = (blockIdx.y * 64 + lane) * VEC;
+    if (f0 >= F) return;
+    const int m0 = off[sgm], m1 = off[sgm + 1];
+    float acc[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+    for (int m = m0; m < m1; ++m) {
+        const float *src = X + (int64_t)members[m] * ldx + f0;
+        if (VEC == 4) {
+            const float4 q = *reinterpret_cast<const float4 *>(src);
+            acc[0] += q.x; acc[1 % VEC] += q.y; acc[2 % VEC] += q.z; acc[3 % VEC] += q.w;
+        } else {
+            acc[0] += src[0];
+        }
+    }
+    float *dst = out + (int64_t)sgm * ldo + f0;
+    if (VEC == 4) *reinterpret_cast<float4 *>(dst) = make_float4(acc[0], acc[1 % VEC], acc[2 % VEC], acc[3 % VEC]);
+    else dst[0] = acc[0];
+}
+
 struct PoolLayout {
     size_t key_in, key_out, id_in, members, off, sort_tmp, sort_tmp_bytes, total;
 };
@@ -348,6 +376,23 @@ extern "C" int fitgnn_pool_rows_f32(const int32_t *assign, const double *cval, i
     } else {
         dim3 grid((n + 3) / 4, (F + 63) / 64);
         hipLaunchKernelGGL(pool_rows_kernel<1>, grid, dim3(256), 0, s, off, members, cval, n, X, ldx, F, Xc, ldxc, Xc64);
+    }
+    return (int)hipGetLastError();
+}
+
+extern "C" int fitgnn_segment_sum_f32(const int32_t *seg_off, const int32_t *members, int32_t n_seg, const float *X,
+                                      int64_t ldx, int32_t F, float *out, int64_t ldo, void *stream) {
+    if (n_seg < 0 || F < 0 || ldx < F || ldo < F) return FITGNN_E_BADARG;
+    if (n_seg == 0 || F == 0) return 0;
+    if (!seg_off || !X || !out) return FITGNN_E_BADARG;
+    hipStream_t s = (hipStream_t)stream;
+    const bool vec = (F % 4 == 0) && (ldx % 4 == 0) && (ldo % 4 == 0) && ((((uintptr_t)X | (uintptr_t)out) % 16) == 0);
+    if (vec) {
+        dim3 grid((n_seg + 3) / 4, (F + 255) / 256);
+        hipLaunchKernelGGL(segment_sum_kernel<4>, grid, dim3(256), 0, s, seg_off, members, n_seg, X, ldx, F, out, ldo);
+    } else {
+        dim3 grid((n_seg + 3) / 4, (F + 63) / 64);
+        hipLaunchKernelGGL(segment_sum_kernel<1>, grid, dim3(256), 0, s, seg_off, members, n_seg, X, ldx, F, out, ldo);
     }
     return (int)hipGetLastError();
 }

@@ -79,7 +79,7 @@ __global__ __launch_bounds__(kThreads, (B <= 4 ? 8 : 4)) void spmm_tile_kernel(
     const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col, const float *__restrict__ val,
     const float *__restrict__ X, int64_t ldx, float *__restrict__ Y, int64_t ldy, int32_t H,
     const fitgnn_tile_t *__restrict__ tiles, int32_t n_tiles, int32_t tiles_per_xcd, int32_t n_slabs, int32_t lds_rows,
-    const int32_t *__restrict__ lcol, const int32_t *__restrict__ win_cols,
+    const int32_t *__restrict__ lcol, const int32_t *__restrict__ win_cols, const int32_t *__restrict__ xrow,
     const float *__restrict__ bias, uint32_t epi, float p_drop, uint64_t seed, const uint8_t *__restrict__ mask) {
     using P = Pack<VEC>;
     using T = typename P::T;
@@ -126,15 +126,22 @@ __global__ __launch_bounds__(kThreads, (B <= 4 ? 8 : 4)) void spmm_tile_kernel(
         float mv[MB];
         int rpv = 0;
         // this wave stages window rows wave, wave+4, ...; for a listed window fetch their operand-row ids first
+        // xrow (optional): operand row r of the pattern lives at X[xrow[r]] -- union rows that are copies of the
+        // same original node share one row of a de-duplicated operand table
         int wcv = 0;
-        if (listed && wave + lane * kWaves < win_rows) wcv = win_cols[win_begin + wave + lane * kWaves];
+        if (wave + lane * kWaves < win_rows) {
+            if (listed) wcv = win_cols[win_begin + wave + lane * kWaves];
+            else if (xrow) wcv = win_begin + wave + lane * kWaves;
+            if (xrow) wcv = xrow[wcv];
+        }
+        const bool indirect = listed || xrow != nullptr;
         for (int p0 = 0; p0 == 0 || wave + p0 * kWaves < win_rows; p0 += B) {
             T v[B];
 #pragma unroll
             for (int j = 0; j < B; ++j) {
                 const int r = wave + (p0 + j) * kWaves;
                 const int rr = min(r, max(win_rows - 1, 0));
-                const int src = listed ? __builtin_amdgcn_readlane(wcv, min(p0 + j, 63)) : win_begin + rr;
+                const int src = indirect ? __builtin_amdgcn_readlane(wcv, min(p0 + j, 63)) : win_begin + rr;
                 v[j] = P::zero();
                 if (r < win_rows) v[j] = *reinterpret_cast<const T *>(Xs + (int64_t)src * ldx);
             }
@@ -178,6 +185,7 @@ __global__ __launch_bounds__(kThreads, (B <= 4 ? 8 : 4)) void spmm_tile_kernel(
         if (c < 0) return -(c + 1);                                   // planner: operand row not staged
         return listed ? win_cols[win_begin + c] : win_begin + c;      // staged slot beyond a clamped LDS window
     };
+    auto xsrc = [&](int g) -> int64_t { return xrow ? xrow[g] : g; };
     for (int row = tile.row_begin + wave; row < tile.row_end; row += kWaves) {
         const int lr = row - tile.row_begin;
         int e0, e1;
@@ -211,10 +219,10 @@ __global__ __launch_bounds__(kThreads, (B <= 4 ? 8 : 4)) void spmm_tile_kernel(
                     x2 = lds[c2 * 64 + lane]; x3 = lds[c3 * 64 + lane];
                 } else {
                     const int g0 = gcol(c0), g1 = gcol(c1), g2 = gcol(c2), g3 = gcol(c3);
-                    if (in0) x0 = lds[c0 * 64 + lane]; else x0 = *reinterpret_cast<const T *>(Xs + (int64_t)g0 * ldx);
-                    if (in1) x1 = lds[c1 * 64 + lane]; else x1 = *reinterpret_cast<const T *>(Xs + (int64_t)g1 * ldx);
-                    if (in2) x2 = lds[c2 * 64 + lane]; else x2 = *reinterpret_cast<const T *>(Xs + (int64_t)g2 * ldx);
-                    if (in3) x3 = lds[c3 * 64 + lane]; else x3 = *reinterpret_cast<const T *>(Xs + (int64_t)g3 * ldx);
+                    if (in0) x0 = lds[c0 * 64 + lane]; else x0 = *reinterpret_cast<const T *>(Xs + xsrc(g0) * ldx);
+                    if (in1) x1 = lds[c1 * 64 + lane]; else x1 = *reinterpret_cast<const T *>(Xs + xsrc(g1) * ldx);
+                    if (in2) x2 = lds[c2 * 64 + lane]; else x2 = *reinterpret_cast<const T *>(Xs + xsrc(g2) * ldx);
+                    if (in3) x3 = lds[c3 * 64 + lane]; else x3 = *reinterpret_cast<const T *>(Xs + xsrc(g3) * ldx);
                 }
                 P::fma(acc, w0, x0); P::fma(acc, w1, x1); P::fma(acc, w2, x2); P::fma(acc, w3, x3);
             }
@@ -223,7 +231,7 @@ __global__ __launch_bounds__(kThreads, (B <= 4 ? 8 : 4)) void spmm_tile_kernel(
                 const float w = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_v), k));
                 T x;
                 if ((unsigned)c < (unsigned)win_rows) x = lds[c * 64 + lane];
-                else x = *reinterpret_cast<const T *>(Xs + (int64_t)gcol(c) * ldx);
+                else x = *reinterpret_cast<const T *>(Xs + xsrc(gcol(c)) * ldx);
                 P::fma(acc, w, x);
             }
         }
@@ -397,8 +405,8 @@ inline size_t lds_bytes_for(int lds_rows, int slab_floats, int mpr) {
 template <int VEC, int B, int MPR>
 int launch_tile(const int32_t *rowptr, const int32_t *col, const float *val, const float *X, int64_t ldx, float *Y,
                 int64_t ldy, int32_t H, const fitgnn_tile_t *tiles, int32_t n_tiles, const int32_t *lcol,
-                const int32_t *win_cols, int32_t lds_rows, int n_slabs, int tiles_per_xcd, const float *bias, uint32_t epi,
-                float p_drop, uint64_t seed, const uint8_t *mask, hipStream_t s) {
+                const int32_t *win_cols, const int32_t *xrow, int32_t lds_rows, int n_slabs, int tiles_per_xcd,
+                const float *bias, uint32_t epi, float p_drop, uint64_t seed, const uint8_t *mask, hipStream_t s) {
     constexpr int SLAB = 64 * VEC;
     const size_t lds_bytes = lds_bytes_for(lds_rows, SLAB, MPR);
     if (lds_bytes > 64 * 1024) {
@@ -408,18 +416,19 @@ int launch_tile(const int32_t *rowptr, const int32_t *col, const float *val, con
     }
     dim3 grid(tiles_per_xcd * 8 * n_slabs);
     hipLaunchKernelGGL((spmm_tile_kernel<VEC, B, MPR>), grid, dim3(kThreads), lds_bytes, s, rowptr, col, val, X, ldx, Y, ldy,
-                       H, tiles, n_tiles, tiles_per_xcd, n_slabs, lds_rows, lcol, win_cols, bias, epi, p_drop, seed, mask);
+                       H, tiles, n_tiles, tiles_per_xcd, n_slabs, lds_rows, lcol, win_cols, xrow, bias, epi, p_drop, seed, mask);
     return (int)hipGetLastError();
 }
 
 template <int VEC>
 int launch(const int32_t *rowptr, const int32_t *col, const float *val, const float *X, int64_t ldx, float *Y,
            int64_t ldy, int32_t H, const fitgnn_tile_t *tiles, int32_t n_tiles, const int32_t *lcol, const int32_t *win_cols,
-           int32_t window_rows, const float *bias, uint32_t epi, float p_drop, uint64_t seed, const uint8_t *mask,
+           const int32_t *xrow, int32_t window_rows, const float *bias, uint32_t epi, float p_drop, uint64_t seed, const uint8_t *mask,
            hipStream_t s) {
     constexpr int SLAB = 64 * VEC;
     const int n_slabs = (H + SLAB - 1) / SLAB;
     const int tiles_per_xcd = (n_tiles + 7) / 8;
+    if ((epi & FITGNN_SPMM_GATHER) && xrow) return FITGNN_E_BADARG;  // the gather variant has no row indirection
     if (epi & FITGNN_SPMM_GATHER) {
         dim3 grid(tiles_per_xcd * 8 * n_slabs);
         hipLaunchKernelGGL(spmm_gather_kernel<VEC>, grid, dim3(kThreads), 0, s, rowptr, col, val, X, ldx, Y, ldy, H, tiles,
@@ -428,9 +437,9 @@ int launch(const int32_t *rowptr, const int32_t *col, const float *val, const fl
     }
     const int lds_rows = window_rows > 0 ? std::min(window_rows, kMaxWindowRows) : kDefaultWindowRows;
     if (lds_rows <= kSmallWindowRows)
-        return launch_tile<VEC, 4, 16>(rowptr, col, val, X, ldx, Y, ldy, H, tiles, n_tiles, lcol, win_cols, lds_rows, n_slabs,
+        return launch_tile<VEC, 4, 16>(rowptr, col, val, X, ldx, Y, ldy, H, tiles, n_tiles, lcol, win_cols, xrow, lds_rows, n_slabs,
                                        tiles_per_xcd, bias, epi, p_drop, seed, mask, s);
-    return launch_tile<VEC, 8, 32>(rowptr, col, val, X, ldx, Y, ldy, H, tiles, n_tiles, lcol, win_cols, lds_rows, n_slabs,
+    return launch_tile<VEC, 8, 32>(rowptr, col, val, X, ldx, Y, ldy, H, tiles, n_tiles, lcol, win_cols, xrow, lds_rows, n_slabs,
                                    tiles_per_xcd, bias, epi, p_drop, seed, mask, s);
 }
 
@@ -446,8 +455,8 @@ extern "C" int fitgnn_spmm_max_window_rows(int32_t H) {
 extern "C" int fitgnn_spmm_csr_f32(const int32_t *rowptr, const int32_t *col, const float *val, const float *X,
                                    int64_t ldx, float *Y, int64_t ldy, int32_t n_rows, int32_t H,
                                    const fitgnn_tile_t *tiles, int32_t n_tiles, const int32_t *lcol,
-                                   const int32_t *win_cols, int32_t window_rows, const float *bias, uint32_t epilogue,
-                                   float p_drop, uint64_t seed, const uint8_t *mask, void *stream) {
+                                   const int32_t *win_cols, const int32_t *xrow, int32_t window_rows, const float *bias,
+                                   uint32_t epilogue, float p_drop, uint64_t seed, const uint8_t *mask, void *stream) {
     if (n_rows < 0 || H < 0 || n_tiles < 0 || window_rows < 0) return FITGNN_E_BADARG;
     if (n_rows == 0 || H == 0 || n_tiles == 0) return 0;
     // col/val may be NULL only for a matrix without non-zeros (they are then never dereferenced)
@@ -458,6 +467,6 @@ extern "C" int fitgnn_spmm_csr_f32(const int32_t *rowptr, const int32_t *col, co
     if ((lcol == nullptr) != (win_cols == nullptr) && lcol == nullptr) return FITGNN_E_BADARG;  // win_cols needs lcol
     hipStream_t s = (hipStream_t)stream;
     const bool vec = (H % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) && (((uintptr_t)X | (uintptr_t)Y) % 16 == 0);
-    if (vec) return launch<4>(rowptr, col, val, X, ldx, Y, ldy, H, tiles, n_tiles, lcol, win_cols, window_rows, bias, epilogue, p_drop, seed, mask, s);
-    return launch<1>(rowptr, col, val, X, ldx, Y, ldy, H, tiles, n_tiles, lcol, win_cols, window_rows, bias, epilogue, p_drop, seed, mask, s);
+    if (vec) return launch<4>(rowptr, col, val, X, ldx, Y, ldy, H, tiles, n_tiles, lcol, win_cols, xrow, window_rows, bias, epilogue, p_drop, seed, mask, s);
+    return launch<1>(rowptr, col, val, X, ldx, Y, ldy, H, tiles, n_tiles, lcol, win_cols, xrow, window_rows, bias, epilogue, p_drop, seed, mask, s);
 }

@@ -101,7 +101,9 @@ class SubgraphBatch:
     The reference trains in GD mode by forwarding every 128-subgraph batch and summing ONE loss over all of
     them (run.py:184-204); subgraphs share no edges, so one union pass is the same arithmetic."""
 
-    def __init__(self, sub, X, y, train_mask, device="cuda", lds_rows=None):
+    def __init__(self, sub, X, y, train_mask, device="cuda", lds_rows=None, dedup=True):
+        """dedup: keep ONE copy of every original node's features on the device (`x_table`, `row_index`) next to the
+        materialised union rows `x`; models that accept `x_index` then run their first layer on the table."""
         dev = torch.device(device)
         self.ptr = sub["ptr"]
         self.n_rows = int(sub["ptr"][-1])
@@ -109,7 +111,13 @@ class SubgraphBatch:
         self.core = torch.from_numpy(sub["core"]).to(dev)
         self.edge_index = torch.from_numpy(sub["edge_index"]).to(dev)
         X = X if torch.is_tensor(X) else torch.from_numpy(np.asarray(X))
-        self.x = X.to(dev).float()[self.node_id].contiguous()
+        Xd = X.to(dev).float()
+        self.x = Xd[self.node_id].contiguous()
+        self.x_table, self.row_index = None, None
+        if dedup and dev.type == "cuda":
+            from .ops import RowIndex
+            self.x_table = Xd.contiguous()
+            self.row_index = RowIndex(self.node_id, Xd.shape[0])
         y = y if torch.is_tensor(y) else torch.from_numpy(np.asarray(y))
         self.y = y.to(dev)[self.node_id].long()
         tm = train_mask if torch.is_tensor(train_mask) else torch.from_numpy(np.asarray(train_mask))

@@ -52,9 +52,20 @@ class _Base(nn.Module):
             m.reset_parameters()
         self.lt1.reset_parameters()
 
-    def embed(self, x, edge_index):
+    def _first_layer_dedup(self, x_table, edge_index, x_index):
+        """Layer 0 on a de-duplicated feature table (x_index: ops.RowIndex mapping union rows to table rows)."""
+        conv = self.conv[0]
+        if not (isinstance(conv, fnn.GCNConv) and x_table.is_cuda):
+            return None
+        mask = self._inject_masks[0] if self._inject_masks is not None else None
+        g = conv.graph(edge_index, int(x_index.index.numel()))
+        seed = ops.next_seed() if (self.training and self.dropout_p > 0 and mask is None) else 0
+        return ops.FusedGCNLayerDedup.apply(x_table.float(), conv.lin.weight, conv.bias, g, x_index, float(self.dropout_p),
+                                            bool(self.training), seed, mask)
+
+    def embed(self, x, edge_index, x_index=None, first=0):
         x = x.float()
-        for i in range(self.num_layers):
+        for i in range(first, self.num_layers):
             conv = self.conv[i]
             if isinstance(conv, fnn.GCNConv) and x.is_cuda:
                 mask = self._inject_masks[i] if self._inject_masks is not None else None
@@ -65,14 +76,22 @@ class _Base(nn.Module):
                 x = F.dropout(x, p=self.dropout_p, training=self.training)
         return x
 
-    def embed_and_head(self, x, edge_index):
-        """embed() followed by lt1; on the GPU the last GCN layer and the head form one autograd node."""
+    def embed_and_head(self, x, edge_index, x_index=None):
+        """embed() followed by lt1; on the GPU the last GCN layer and the head form one autograd node.
+        x_index (ops.RowIndex, optional): x is a de-duplicated table and union row r is table row x_index.index[r]."""
         L = self.num_layers
+        first = 0
+        if x_index is not None:
+            h = self._first_layer_dedup(x, edge_index, x_index) if L > 1 else None
+            if h is None:
+                x = x.index_select(0, x_index.index.long())  # materialise the union rows
+            else:
+                x, first = h, 1
         last = self.conv[L - 1] if L > 0 else None
         if not (L > 0 and x.is_cuda and isinstance(last, fnn.GCNConv) and self.lt1.out_features <= ops.head_max_classes()):
-            return self.head(self.embed(x, edge_index))
+            return self.head(self.embed(x, edge_index, first=first))
         x = x.float()
-        for i in range(L - 1):
+        for i in range(first, L - 1):
             conv = self.conv[i]
             if isinstance(conv, fnn.GCNConv):
                 mask = self._inject_masks[i] if self._inject_masks is not None else None
@@ -93,15 +112,15 @@ class _Base(nn.Module):
 
 
 class Classify_node(_Base):
-    def forward(self, x, edge_index):
-        return F.log_softmax(self.embed_and_head(x, edge_index), dim=1)
+    def forward(self, x, edge_index, x_index=None):
+        return F.log_softmax(self.embed_and_head(x, edge_index, x_index), dim=1)
 
 
 class Regress_node(_Base):
     out_dim_from_classes = False
 
-    def forward(self, x, edge_index):
-        return self.embed_and_head(x, edge_index)
+    def forward(self, x, edge_index, x_index=None):
+        return self.embed_and_head(x, edge_index, x_index)
 
 
 class Classify_graph_gc(_Base):

@@ -78,7 +78,7 @@ def _f32c(t):
 
 
 def spmm_raw(rowptr, col, val, tiles, X, n_rows, bias=None, epilogue=0, p=0.0, seed=0, mask=None, out=None, window_rows=0,
-             lcol=None, win_cols=None):
+             lcol=None, win_cols=None, xrow=None):
     """Y = epilogue(A @ X) through fitgnn_spmm_csr_f32.  X: [n_cols_of_A, H] f32 contiguous."""
     _lib.require_cuda(rowptr, col, val, tiles, X, bias, mask)
     L = _lib.lib()
@@ -91,7 +91,7 @@ def spmm_raw(rowptr, col, val, tiles, X, n_rows, bias=None, epilogue=0, p=0.0, s
         ev[0].record()
     rc = L.fitgnn_spmm_csr_f32(_lib.dptr(rowptr), _lib.dptr(col), _lib.dptr(val), _lib.dptr(X), X.stride(0) if X.numel() else H,
                                _lib.dptr(Y), Y.stride(0) if Y.numel() else H, n_rows, H, _lib.dptr(tiles), int(tiles.shape[0]),
-                               _lib.dptr(lcol), _lib.dptr(win_cols), int(window_rows), _lib.dptr(bias), epilogue, float(p), int(seed) & 0xFFFFFFFFFFFFFFFF, _lib.dptr(mask),
+                               _lib.dptr(lcol), _lib.dptr(win_cols), _lib.dptr(xrow), int(window_rows), _lib.dptr(bias), epilogue, float(p), int(seed) & 0xFFFFFFFFFFFFFFFF, _lib.dptr(mask),
                                _lib.stream_ptr(X.device))
     if ev is not None:
         ev[1].record()
@@ -143,6 +143,32 @@ def epilogue_bwd_head_raw(dy, Wl, out, epilogue, p=0.0, seed=0, mask=None, want_
                                         _lib.dptr(work), wb, _lib.stream_ptr(out.device))
     _lib.check(rc, "fitgnn_epilogue_bwd_head_f32")
     return dZ, db, dWl
+
+
+def segment_sum(seg_off, members, X, n_seg):
+    """out[s] = sum of X[members[seg_off[s]:seg_off[s+1]]] (fitgnn_segment_sum_f32)."""
+    _lib.require_cuda(seg_off, members, X)
+    X = _f32c(X)
+    F_ = X.shape[1]
+    out = torch.empty((n_seg, F_), dtype=torch.float32, device=X.device)
+    _lib.check(_lib.lib().fitgnn_segment_sum_f32(_lib.dptr(seg_off), _lib.dptr(members), n_seg, _lib.dptr(X), F_, F_, _lib.dptr(out),
+                                                 F_, _lib.stream_ptr(X.device)), "fitgnn_segment_sum_f32")
+    return out
+
+
+class RowIndex:
+    """Row indirection of a de-duplicated operand table: union row r is a copy of table row `index[r]`.
+    Holds the int32 index and its inverse (segments of union rows per table row) for the adjoint."""
+
+    def __init__(self, index, n_table):
+        idx = index.to(torch.int64)
+        self.n_table = int(n_table)
+        self.index = idx.to(torch.int32).contiguous()
+        order = torch.argsort(idx, stable=True)
+        self.members = order.to(torch.int32).contiguous()
+        off = torch.zeros(self.n_table + 1, dtype=torch.int64, device=idx.device)
+        off[1:] = torch.cumsum(torch.bincount(idx, minlength=self.n_table), 0)
+        self.seg_off = off.to(torch.int32).contiguous()
 
 
 class SpMM(torch.autograd.Function):
@@ -230,6 +256,40 @@ class FusedGCNLayerHead(torch.autograd.Function):
         dW = mm(dH.t(), X, allow_split=False) if ctx.needs_input_grad[1] else None
         dX = mm(dH, W) if ctx.needs_input_grad[0] else None
         return dX, dW, (db if ctx.has_bias else None), dWl, dbl, None, None, None, None, None
+
+
+class FusedGCNLayerDedup(torch.autograd.Function):
+    """First GCN layer on a de-duplicated feature table: the union batch's rows are copies of N0 original nodes
+    (X_union = Xt[index]), so  X_union W^T = (Xt W^T)[index]: one GEMM on N0 rows, the copies are resolved by the
+    SpMM kernel's row indirection (never materialised); backward sums dH over each node's copies
+    (fitgnn_segment_sum_f32) before the weight-gradient GEMM.  Same arithmetic as FusedGCNLayer on X_union."""
+
+    @staticmethod
+    def forward(ctx, Xt, W, b, g, ridx, p, training, seed, mask):
+        Xt = _f32c(Xt)
+        Ht = mm(Xt, W.t())  # [N0, H]
+        epi = EPI_ELU | (EPI_BIAS if b is not None else 0)
+        drop = bool(training) and p > 0.0
+        if drop:
+            epi |= EPI_DROPOUT
+        out = spmm_graph(g, Ht, bias=b, epilogue=epi, p=p if drop else 0.0, seed=seed, mask=mask if drop else None,
+                         xrow=ridx.index)
+        ctx.save_for_backward(Xt, W, out, mask if drop else None)
+        ctx.g, ctx.ridx, ctx.p, ctx.drop, ctx.seed, ctx.has_bias = g, ridx, p, drop, seed, b is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dOut):
+        Xt, W, out, mask = ctx.saved_tensors
+        g, ridx = ctx.g, ctx.ridx
+        epi = EPI_ELU | (EPI_DROPOUT if ctx.drop else 0)
+        dZ, db = epilogue_bwd_raw(dOut, out, epi, p=ctx.p if ctx.drop else 0.0, seed=ctx.seed, mask=mask,
+                                  want_db=ctx.has_bias)
+        dH = spmm_graph(g, dZ, transposed=True)                      # [R, H] per union row
+        dHt = segment_sum(ridx.seg_off, ridx.members, dH, ridx.n_table)  # [N0, H] per original node
+        dW = mm(dHt.t(), Xt, allow_split=False) if ctx.needs_input_grad[1] else None
+        dXt = mm(dHt, W) if ctx.needs_input_grad[0] else None
+        return dXt, dW, (db if ctx.has_bias else None), None, None, None, None, None, None
 
 
 _seed_state = [0x1234ABCD]

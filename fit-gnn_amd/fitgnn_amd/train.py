@@ -28,8 +28,10 @@ class FlatGrads:
 
 
 class GDTrainer:
-    def __init__(self, model, batch, lr=0.01, weight_decay=5e-4, reduction="mean", process_group=None):
+    def __init__(self, model, batch, lr=0.01, weight_decay=5e-4, reduction="mean", process_group=None, dedup=True):
         self.model, self.batch = model, batch
+        # first layer on the de-duplicated feature table when the batch carries one (same arithmetic, fewer FLOPs)
+        self.dedup = dedup and getattr(batch, "row_index", None) is not None
         self.opt = torch.optim.Adam(model.parameters(), lr=lr, weight_decay=weight_decay)
         self.flat = FlatGrads(model.parameters())
         self.reduction = reduction
@@ -46,7 +48,7 @@ class GDTrainer:
         m, b = self.model, self.batch
         m.train()
         self.flat.zero()  # optimizer.zero_grad(); grads live in the flat buffer
-        out = m(b.x, b.edge_index)
+        out = m(b.x_table, b.edge_index, x_index=b.row_index) if self.dedup else m(b.x, b.edge_index)
         sel = out.index_select(0, b.train_idx)
         loss_sum = F.nll_loss(sel, b.y.index_select(0, b.train_idx), reduction="sum")
         scale = 1.0 / self.global_count if self.reduction == "mean" else 1.0

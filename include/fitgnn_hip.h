@@ -94,15 +94,23 @@ int fitgnn_gcn_norm_csr_f32(const int32_t *rowptr, const int32_t *col, const flo
  * segmented reduction per target row; the backward pass is the same call on the transposed CSR.
  * lcol / win_cols: outputs of fitgnn_plan_tiles_host (device copies).  Both NULL = every tile has a contiguous
  * window and `col` is used as is.
+ * xrow (may be NULL): operand row r of the pattern is read from X[xrow[r]] instead of X[r] -- lets the many union rows
+ * that are copies of one original node (extra nodes of the subgraphs, utils.py:235-239) share a single row of a
+ * de-duplicated operand table.
  * window_rows: LDS rows per workgroup (0 = default); see fitgnn_spmm_default_window_rows().
  * Dropout: element (row,h) is kept iff mask[row*H+h] != 0 when `mask` is given, else iff 16 bits of a
  * counter-based hash of (seed, (row*H+h)/4) are >= floor(p*65536); kept values are scaled by 1/(1-p).  16-byte aligned X/Y rows (H%4==0 and
  * ld%4==0) take the vector path; anything else takes the scalar path. */
 int fitgnn_spmm_csr_f32(const int32_t *rowptr, const int32_t *col, const float *val, const float *X, int64_t ldx,
                         float *Y, int64_t ldy, int32_t n_rows, int32_t H, const fitgnn_tile_t *tiles,
-                        int32_t n_tiles, const int32_t *lcol, const int32_t *win_cols, int32_t window_rows,
-                        const float *bias, uint32_t epilogue, float p_drop, uint64_t seed, const uint8_t *mask,
-                        void *stream);
+                        int32_t n_tiles, const int32_t *lcol, const int32_t *win_cols, const int32_t *xrow,
+                        int32_t window_rows, const float *bias, uint32_t epilogue, float p_drop, uint64_t seed,
+                        const uint8_t *mask, void *stream);
+
+/* out[s] = sum of X[members[m]] for m in [seg_off[s], seg_off[s+1]) in that order (f32, fixed order: reproducible).
+ * The adjoint of the row indirection above: gradients of duplicated union rows summed back per original node. */
+int fitgnn_segment_sum_f32(const int32_t *seg_off, const int32_t *members, int32_t n_seg, const float *X, int64_t ldx,
+                           int32_t F, float *out, int64_t ldo, void *stream);
 
 /* Backward of the fused epilogue  out = dropout(ELU(z)):  given dOut and the forward OUTPUT `out`
  *   dZ = keep ? dOut * 1/(1-p) * (o > 0 ? 1 : o + 1) : 0,   o = out*(1-p) (pre-dropout ELU value)

@@ -180,3 +180,31 @@ def test_classify_node_with_gat_layers(mods):
                                                   sd[f"conv.{i}.att_dst"], sd[f"conv.{i}.bias"]))
     ref = torch.log_softmax(h @ sd["lt1.weight"].t() + sd["lt1.bias"], dim=1)
     assert rel(out, ref) < 1e-4
+
+
+def test_dedup_first_layer_equals_materialised_rows(mods):
+    """Layer 0 on the de-duplicated table + SpMM row indirection == layer 0 on the gathered union rows."""
+    network, fnn, gorc = mods
+    from fitgnn_amd import ops
+
+    ei, n = graph(n=600, m=1800, seed=21)
+    torch.manual_seed(5)
+    N0 = 150
+    idx = torch.randint(0, N0, (n,))
+    idx[:N0] = torch.arange(N0)
+    Xt = torch.rand(N0, 40)
+    args = argparse.Namespace(num_layers1=2, layer_name="GCNConv", num_features=40, hidden=128, num_classes=5)
+    model = network.Classify_node(args).cuda().train()
+    masks = [(torch.rand(n, 128) > 0.5).to(torch.uint8).cuda() for _ in range(2)]
+    model._inject_masks = masks
+    y = torch.randint(0, 5, (n,)).cuda()
+    ridx = ops.RowIndex(idx.cuda(), N0)
+    out_d = model(Xt.cuda(), ei.cuda(), x_index=ridx)
+    torch.nn.functional.nll_loss(out_d, y).backward()
+    g_d = {k: p.grad.clone() for k, p in model.named_parameters()}
+    model.zero_grad()
+    out_m = model(Xt[idx].cuda(), ei.cuda())
+    torch.nn.functional.nll_loss(out_m, y).backward()
+    assert rel(out_d.detach().cpu(), out_m.detach().cpu()) < 1e-5
+    for k, p in model.named_parameters():
+        assert rel(g_d[k].cpu(), p.grad.cpu()) < 1e-4, k
