@@ -229,7 +229,10 @@ __global__ __launch_bounds__(256) void pool_rows_kernel(const int32_t *__restric
     }
 }
 
-// f32 segment sum (one wave per (segment, 64*VEC-column slab)), members in the given order
+// f32 segment sum (one wave per (segment, 64*VEC-column slab)), members in the given order.  The member ids of
+// a segment are fetched with one lane-parallel load and broadcast by v_readlane; rows are loaded four at a time
+// (always four loads: missing ones re-read the first row with weight 0) so that the loads overlap instead of
+// forming a dependent id -> row chain per member.
 template <int VEC>
 __global__ __launch_bounds__(256) void segment_sum_kernel(const int32_t *__restrict__ off, const int32_t *__restrict__ members,
                                                           int32_t n_seg, const float *__restrict__ X, int64_t ldx, int32_t F,
@@ -238,20 +241,40 @@ __global__ __launch_bounds__(256) void segment_sum_kernel(const int32_t *__restr
     const int lane = threadIdx.x & 63;
     if (sgm >= n_seg) return;
     const int f0 = (blockIdx.y * 64 + lane) * VEC;
-    if (f0 >= F) return;
-    const int m0 = off[sgm], m1 = off[sgm + 1];
+    const bool live = f0 + VEC <= F;
+    const float *Xs = X + (live ? f0 : (F >= VEC ? F - VEC : 0));
+    const int m0 = __builtin_amdgcn_readfirstlane(off[sgm]), m1 = __builtin_amdgcn_readfirstlane(off[sgm + 1]);
     float acc[VEC];
 #pragma unroll
     for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
-    for (int m = m0; m < m1; ++m) {
-        const float *src = X + (int64_t)members[m] * ldx + f0;
-        if (VEC == 4) {
-            const float4 q = *reinterpret_cast<const float4 *>(src);
-            acc[0] += q.x; acc[1 % VEC] += q.y; acc[2 % VEC] += q.z; acc[3 % VEC] += q.w;
-        } else {
-            acc[0] += src[0];
+    for (int base = m0; base < m1; base += 64) {
+        const int cnt = min(64, m1 - base);
+        const int my = lane < cnt ? members[base + lane] : 0;
+        for (int k = 0; k < cnt; k += 4) {
+            float v[4][VEC];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool has = k + j < cnt;
+                const int node = __builtin_amdgcn_readlane(my, has ? k + j : k);
+                const float *src = Xs + (int64_t)node * ldx;
+                if (VEC == 4) {
+                    const float4 q = *reinterpret_cast<const float4 *>(src);
+                    v[j][0] = q.x; v[j][1 % VEC] = q.y; v[j][2 % VEC] = q.z; v[j][3 % VEC] = q.w;
+                } else {
+                    v[j][0] = src[0];
+                }
+                if (!has) {
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) v[j][i] = 0.f;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) acc[i] += v[j][i];
         }
     }
+    if (!live) return;
     float *dst = out + (int64_t)sgm * ldo + f0;
     if (VEC == 4) *reinterpret_cast<float4 *>(dst) = make_float4(acc[0], acc[1 % VEC], acc[2 % VEC], acc[3 % VEC]);
     else dst[0] = acc[0];

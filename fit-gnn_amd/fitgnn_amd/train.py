@@ -32,7 +32,9 @@ class GDTrainer:
         self.model, self.batch = model, batch
         # first layer on the de-duplicated feature table when the batch carries one (same arithmetic, fewer FLOPs)
         self.dedup = dedup and getattr(batch, "row_index", None) is not None
-        self.opt = torch.optim.Adam(model.parameters(), lr=lr, weight_decay=weight_decay)
+        # fused=True: one multi-tensor kernel for the whole update (same arithmetic as the reference's torch.optim.Adam)
+        fused = next(model.parameters()).is_cuda
+        self.opt = torch.optim.Adam(model.parameters(), lr=lr, weight_decay=weight_decay, fused=fused)
         self.flat = FlatGrads(model.parameters())
         self.reduction = reduction
         self.pg = process_group

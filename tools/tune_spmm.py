@@ -44,7 +44,7 @@ def main():
     Y = torch.empty_like(X)
     b = torch.randn(H, device=dev)
     bytes_spmm = 8 * H * R + 8 * batch.nnz + 4 * (R + 1)
-    graphs = {w: CSRGraph(batch.edge_index, R, mode="gcn", ptr=batch.ptr, lds_rows=w) for w in windows}
+    graphs = {w: CSRGraph(batch.edge_index, R, mode="gcn", ptr=batch.ptr, lds_rows=w, planned=True) for w in windows}
     graphs_c = {w: CSRGraph(batch.edge_index, R, mode="gcn", ptr=batch.ptr, lds_rows=w, planned=False) for w in windows}
     res = {w: {"plain": [], "epi": [], "T": [], "gplain": [], "gepi": []} for w in windows}
     GA = 0x100
