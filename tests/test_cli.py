@@ -49,6 +49,23 @@ def test_flags_and_defaults_match_reference_main_py():
         assert mine[name].required == required, name
 
 
+@pytest.mark.skipif(not os.path.exists("/root/reference/inference.py"), reason="reference not mounted")
+def test_inference_flags_and_defaults_match_reference():
+    import inference as icli
+
+    src = open("/root/reference/inference.py").read()
+    ref = {}
+    for m in re.finditer(r"parser\.add_argument\((.*)\)", src):
+        call = ast.parse("f(" + m.group(1).split("#")[0].rstrip().rstrip(")") + ")").body[0].value
+        kw = {k.arg: k.value for k in call.keywords}
+        ref[call.args[0].value] = (ast.literal_eval(kw["default"]) if "default" in kw else (False if "action" in kw else None),
+                                   "action" in kw)
+    assert len(ref) == 33
+    mine = {a.option_strings[0]: a for a in icli.build_parser()._actions if a.option_strings and a.option_strings[0] != "-h"}
+    for name, (default, is_flag) in ref.items():
+        assert name in mine and mine[name].default == default and (mine[name].nargs == 0) == is_flag, name
+
+
 @pytest.mark.skipif(not os.path.exists(REF_CORA), reason="reference not mounted")
 def test_planetoid_loader_on_reference_cora_files():
     from fitgnn_amd import pipeline
@@ -83,5 +100,12 @@ def test_cli_end_to_end_on_synthetic_cora(tmp_path, monkeypatch):
         assert acc[0] > 0.4, (setup, acc)
     rows = open("results/synthetic-cora.csv").read().strip().split("\n")
     assert rows[0].startswith("dataset,coarsening_method,coarsening_ratio") and len(rows) == 4
+    import inference as icli
+    t_gs, acc_gs = icli.main(["--dataset", "synthetic-cora", "--hidden", "64", "--seed", "0", "--normalize_features", "--extra_node",
+                              "--num_test_samples", "30", "--path_gs", "save/node_cls/f/", "--baseline",
+                              "--path_b", "save/node_cls/baseline/b/", "--model_name_b", "model.pt"])
+    assert acc_gs > 0.4 and t_gs < 0.05
+    rows = open("inference_results/node_cls.csv").read().strip().split("\n")
+    assert rows[0].startswith("dataset,baseline,experiment,exp_setup") and len(rows) == 3
     sd = torch.load("save/node_cls/f/model.pt")
     assert sorted(sd) == ["conv.0.bias", "conv.0.lin.weight", "conv.1.bias", "conv.1.lin.weight", "lt1.bias", "lt1.weight"]
