@@ -108,6 +108,7 @@ def main():
     ap.add_argument("--workload", default="S-pubmed")
     ap.add_argument("--hidden", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fold", action="store_true", help="A/B: epilogue backward folded into the transposed SpMM (slower, see DESIGN.md)")
     ap.add_argument("--no-dedup", action="store_true",
                     help="run layer 0's X@W^T on the materialised union rows (one copy per subgraph membership) instead of "
                          "the de-duplicated feature table")
@@ -130,6 +131,7 @@ def main():
     from fitgnn_amd import network, ops, train
 
     ops.GEMM_PRECISION = args.gemm_precision
+    ops.FOLD_BACKWARD = args.fold
 
     batch, (F, C), info = build_workload(args.workload, seed=rank, device=device, hidden=args.hidden)
     margs = argparse.Namespace(num_layers1=2, layer_name="GCNConv", num_features=F, hidden=args.hidden, num_classes=C)

@@ -34,6 +34,10 @@ SIGNATURES = {
     "fitgnn_epilogue_bwd_head_workspace_bytes": (c_size, [c_i32, c_i32, c_i32]),
     "fitgnn_epilogue_bwd_head_f32": (ctypes.c_int, [ptr, ptr, c_i32, ptr, ptr, c_i32, c_i32, c_u32, c_f32, c_u64, ptr, ptr, ptr,
                                                    ptr, c_size, ptr]),
+    "fitgnn_spmm_epilogue_bwd_supported": (ctypes.c_int, [c_i32, c_i32, c_i32]),
+    "fitgnn_spmm_epilogue_bwd_workspace_bytes": (c_size, [c_i32, c_i32, c_i32]),
+    "fitgnn_spmm_epilogue_bwd_f32": (ctypes.c_int, [ptr, ptr, ptr, ptr, c_i32, c_i32, ptr, ptr, ptr, c_i32, ptr, ptr, c_i32, c_i32,
+                                                   c_u32, c_f32, c_u64, ptr, ptr, ptr, ptr, c_size, ptr]),
     "fitgnn_gat_scores_f32": (ctypes.c_int, [ptr, c_i64, c_i32, c_i32, ptr, ptr, ptr, ptr, ptr]),
     "fitgnn_gat_edge_softmax_f32": (ctypes.c_int, [ptr, ptr, ptr, ptr, c_f32, c_i32, ptr, ptr]),
     "fitgnn_sddmm_csr_f32": (ctypes.c_int, [ptr, ptr, ptr, c_i64, ptr, c_i64, c_i32, c_i32, ptr, ptr]),

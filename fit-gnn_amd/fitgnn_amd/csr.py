@@ -176,6 +176,8 @@ class CSRGraph:
         device = edge_index.device
         self.device, self.n, self.mode = device, int(num_nodes), mode
         self.planned, self.gather = planned, gather
+        # tiles from make_tiles: contiguous windows covering their own rows -> the folded backward kernel applies
+        self.fold_ok = (not planned) and (not gather)
         src, dst = edge_index[0].to(torch.int64), edge_index[1].to(torch.int64)
         if mode in ("gcn", "gat"):  # add_remaining_self_loops: exactly one self loop per node
             keep = src != dst

@@ -194,6 +194,58 @@ class RowIndex:
         self.seg_off = off.to(torch.int32).contiguous()
 
 
+# Use fitgnn_spmm_epilogue_bwd_f32 (dZ kept in LDS) when the graph / shape allow it.  Off by default: measured on the
+# S-pubmed union it is no faster than the two kernels (254 vs 223 us per hidden layer, 262 vs 263 us with the head; see
+# DESIGN.md "folded backward"), because the extra operand stream and the transform sit on the tile's critical path
+# (descriptor -> window loads -> barrier -> row loop) while the separate elementwise kernel streams at HBM rate.
+FOLD_BACKWARD = False
+
+
+def layer_backward(g, out, epi, p, seed, mask, want_db, dOut=None, dy=None, Wl=None, want_dWl=False):
+    """(dH, db, dWl) of one fused layer: dZ = epilogue'(dOut or dy @ Wl), db = colsum dZ, dH = A^T dZ.
+    One kernel (dZ stays in LDS) when supported, else epilogue-backward kernel + SpMM."""
+    L = _lib.lib()
+    out = _f32c(out)
+    n, H = out.shape
+    head = dOut is None
+    C = int(Wl.shape[0]) if head else 0
+    if FOLD_BACKWARD and getattr(g, "fold_ok", False) and L.fitgnn_spmm_epilogue_bwd_supported(H, C, g.window_rows):
+        side = g.t
+        dev = out.device
+        dH = torch.empty_like(out)
+        db = torch.empty(H, dtype=torch.float32, device=dev) if want_db else None
+        dWl = torch.empty((C, H), dtype=torch.float32, device=dev) if (head and want_dWl) else None
+        nt = int(side.tiles.shape[0])
+        wb = int(L.fitgnn_spmm_epilogue_bwd_workspace_bytes(nt, H, C if dWl is not None else 0)) if (want_db or dWl is not None) else 0
+        work = torch.empty(max(wb, 4), dtype=torch.uint8, device=dev)
+        if head:
+            dy, Wl = _f32c(dy), _f32c(Wl)
+        else:
+            dOut = _f32c(dOut)
+        ev = None
+        if PROFILE is not None:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+        rc = L.fitgnn_spmm_epilogue_bwd_f32(_lib.dptr(side.rowptr), _lib.dptr(side.col), _lib.dptr(side.val), _lib.dptr(side.tiles), nt,
+                                            g.window_rows, _lib.dptr(dOut), _lib.dptr(dy), _lib.dptr(Wl), C, _lib.dptr(out),
+                                            _lib.dptr(dH), n, H, epi, float(p), int(seed) & 0xFFFFFFFFFFFFFFFF, _lib.dptr(mask),
+                                            _lib.dptr(db), _lib.dptr(dWl), _lib.dptr(work), wb, _lib.stream_ptr(dev))
+        if ev is not None:
+            ev[1].record()
+            PROFILE_FUSED.append(ev)
+        _lib.check(rc, "fitgnn_spmm_epilogue_bwd_f32")
+        return dH, db, dWl
+    if head:
+        dZ, db, dWl = epilogue_bwd_head_raw(dy, Wl, out, epi, p=p, seed=seed, mask=mask, want_db=want_db, want_dWl=want_dWl)
+    else:
+        dZ, db = epilogue_bwd_raw(dOut, out, epi, p=p, seed=seed, mask=mask, want_db=want_db)
+        dWl = None
+    return spmm_graph(g, dZ, transposed=True), db, dWl
+
+
+PROFILE_FUSED = []
+
+
 class SpMM(torch.autograd.Function):
     """Y = A @ X (+ bias).  Backward: dX = A^T @ dY (same kernel on the transposed CSR), db = sum rows."""
 
@@ -235,9 +287,7 @@ class FusedGCNLayer(torch.autograd.Function):
         X, W, out, mask = ctx.saved_tensors
         g = ctx.g
         epi = EPI_ELU | (EPI_DROPOUT if ctx.drop else 0)
-        dZ, db = epilogue_bwd_raw(dOut, out, epi, p=ctx.p if ctx.drop else 0.0, seed=ctx.seed, mask=mask,
-                                  want_db=ctx.has_bias)
-        dH = spmm_graph(g, dZ, transposed=True)
+        dH, db, _ = layer_backward(g, out, epi, ctx.p if ctx.drop else 0.0, ctx.seed, mask, ctx.has_bias, dOut=dOut)
         dW = mm_at_b(dH, X) if ctx.needs_input_grad[1] else None
         dX = mm(dH, W) if ctx.needs_input_grad[0] else None
         return dX, dW, (db if ctx.has_bias else None), None, None, None, None, None
@@ -272,10 +322,9 @@ class FusedGCNLayerHead(torch.autograd.Function):
         g = ctx.g
         dy = _f32c(dy)
         epi = EPI_ELU | (EPI_DROPOUT if ctx.drop else 0)
-        dZ, db, dWl = epilogue_bwd_head_raw(dy, Wl, out, epi, p=ctx.p if ctx.drop else 0.0, seed=ctx.seed, mask=mask,
-                                            want_db=ctx.has_bias, want_dWl=ctx.needs_input_grad[3])
+        dH, db, dWl = layer_backward(g, out, epi, ctx.p if ctx.drop else 0.0, ctx.seed, mask, ctx.has_bias, dy=dy, Wl=Wl,
+                                     want_dWl=ctx.needs_input_grad[3])
         dbl = dy.sum(0) if ctx.has_bl and ctx.needs_input_grad[4] else None
-        dH = spmm_graph(g, dZ, transposed=True)
         dW = mm_at_b(dH, X) if ctx.needs_input_grad[1] else None
         dX = mm(dH, W) if ctx.needs_input_grad[0] else None
         return dX, dW, (db if ctx.has_bias else None), dWl, dbl, None, None, None, None, None
@@ -306,9 +355,7 @@ class FusedGCNLayerDedup(torch.autograd.Function):
         Xt, W, out, mask = ctx.saved_tensors
         g, ridx = ctx.g, ctx.ridx
         epi = EPI_ELU | (EPI_DROPOUT if ctx.drop else 0)
-        dZ, db = epilogue_bwd_raw(dOut, out, epi, p=ctx.p if ctx.drop else 0.0, seed=ctx.seed, mask=mask,
-                                  want_db=ctx.has_bias)
-        dH = spmm_graph(g, dZ, transposed=True)                      # [R, H] per union row
+        dH, db, _ = layer_backward(g, out, epi, ctx.p if ctx.drop else 0.0, ctx.seed, mask, ctx.has_bias, dOut=dOut)  # [R, H]
         dHt = segment_sum(ridx.seg_off, ridx.members, dH, ridx.n_table)  # [N0, H] per original node
         dW = mm_at_b(dHt, Xt) if ctx.needs_input_grad[1] else None
         dXt = mm(dHt, W) if ctx.needs_input_grad[0] else None

@@ -132,6 +132,19 @@ int fitgnn_epilogue_bwd_head_f32(const float *dy, const float *Wl, int32_t C, co
                                  int32_t n_rows, int32_t H, uint32_t epilogue, float p_drop, uint64_t seed,
                                  const uint8_t *mask, float *db, float *dWl, void *work, size_t work_bytes, void *stream);
 
+/* Backward SpMM with the epilogue backward folded in: dH = A^T dZ with dZ (above) formed while the operand rows are
+ * staged, never written to memory; db / dWl reduced over tiles in a fixed order.  (rowptr, col, val, tiles) describe
+ * the TRANSPOSED pattern; tiles must have contiguous windows that cover their own rows (fitgnn_amd.csr.make_tiles) and
+ * window_rows <= 16.  dOut == NULL selects the head form (dy, Wl, C as in fitgnn_epilogue_bwd_head_f32, C <= 4).
+ * fitgnn_spmm_epilogue_bwd_supported() tells whether a shape is covered; otherwise use the two separate calls. */
+int fitgnn_spmm_epilogue_bwd_supported(int32_t H, int32_t C, int32_t window_rows);
+size_t fitgnn_spmm_epilogue_bwd_workspace_bytes(int32_t n_tiles, int32_t H, int32_t C);
+int fitgnn_spmm_epilogue_bwd_f32(const int32_t *rowptr, const int32_t *col, const float *val, const fitgnn_tile_t *tiles,
+                                 int32_t n_tiles, int32_t window_rows, const float *dOut, const float *dy, const float *Wl,
+                                 int32_t C, const float *out, float *dH, int32_t n_rows, int32_t H, uint32_t epilogue,
+                                 float p_drop, uint64_t seed, const uint8_t *mask, float *db, float *dWl, void *work,
+                                 size_t work_bytes, void *stream);
+
 /* ---- graph attention (torch_geometric.nn.GATConv as network.py:13 constructs it: heads = 1, negative_slope 0.2,
  * add_self_loops, bias; no attention dropout).  CSR rows = target nodes, self loops included by the caller.
  *   a_src[j] = h_j . att_src,  a_dst[i] = h_i . att_dst

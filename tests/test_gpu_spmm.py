@@ -214,3 +214,37 @@ def test_head_backward_folded_into_epilogue_kernel(mods, H, C):
     assert rel_err(dZ.cpu(), dZ_ref.cpu()) < 1e-5
     assert rel_err(db.cpu(), db_ref.cpu()) < 1e-4
     assert rel_err(dWl.cpu(), (dy.double().t() @ out.double()).float()) < 1e-5
+
+
+@pytest.mark.parametrize("head", [False, True])
+@pytest.mark.parametrize("use_mask", [False, True])
+def test_folded_backward_equals_two_kernels(mods, head, use_mask):
+    """fitgnn_spmm_epilogue_bwd_f32 (dZ kept in LDS) == epilogue backward kernel followed by the transposed SpMM."""
+    _lib, csr, ops, orc, gorc = mods
+    from fitgnn_amd._lib import EPI_DROPOUT, EPI_ELU
+
+    ei, n = block_graph([3, 9, 1, 30, 64, 2, 2, 5, 150, 7] * 5, seed=12, p=0.2)
+    g = csr.CSRGraph(ei.cuda(), n, mode="gcn")
+    assert g.fold_ok and g.window_rows <= 16
+    H, C = 512, 3
+    torch.manual_seed(9)
+    out = torch.nn.functional.elu(torch.randn(n, H))
+    mask = (torch.rand(n, H) > 0.5).to(torch.uint8).cuda() if use_mask else None
+    if use_mask:
+        out = out * mask.cpu() * 2.0
+    else:  # production path: zeros where the hash dropped the element
+        keep = ops.spmm_graph(g, torch.ones(n, H).cuda(), epilogue=EPI_DROPOUT, p=0.5, seed=77) != 0
+        out = out * keep.cpu() * 2.0
+    out = out.cuda()
+    dOut, dy, Wl = torch.randn(n, H).cuda(), torch.randn(n, C).cuda(), torch.randn(C, H).cuda()
+    epi = EPI_ELU | EPI_DROPOUT
+    ops.FOLD_BACKWARD = False
+    ref = ops.layer_backward(g, out, epi, 0.5, 77, mask, True, dOut=None if head else dOut, dy=dy if head else None,
+                             Wl=Wl if head else None, want_dWl=head)
+    ops.FOLD_BACKWARD = True
+    got = ops.layer_backward(g, out, epi, 0.5, 77, mask, True, dOut=None if head else dOut, dy=dy if head else None,
+                             Wl=Wl if head else None, want_dWl=head)
+    assert rel_err(got[0].cpu(), ref[0].cpu()) < 1e-5
+    assert rel_err(got[1].cpu(), ref[1].cpu()) < 1e-4
+    if head:
+        assert rel_err(got[2].cpu(), ref[2].cpu()) < 1e-4
