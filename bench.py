@@ -176,6 +176,18 @@ def main():
         with open(pmc_file) as f:
             pmc = json.load(f)
         traffic = (2.0 * pmc["FETCH_SIZE"]["mean"] + pmc["WRITE_SIZE"]["mean"]) * 1024.0
+    # device-to-device copy ceiling of this GPU, same process, after the timed region (read + write bytes / time)
+    src = torch.empty(256 << 20, dtype=torch.float32, device=device)
+    dst = torch.empty_like(src)
+    dst.copy_(src)
+    c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    c0.record()
+    for _ in range(10):
+        dst.copy_(src)
+    c1.record()
+    torch.cuda.synchronize()
+    copy_gbs = 10 * 2 * src.numel() * 4 / (c0.elapsed_time(c1) * 1e-3) / 1e9
+    del src, dst
     out = {
         "metric": "edges aggregated/sec (GCN fwd+bwd) on coarsened subgraphs",
         "value": total_edges / dt, "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -184,14 +196,15 @@ def main():
         "config": {"workload": f"{args.workload}: variation_neighborhoods r=0.5, extra-node subgraphs, one block-diagonal "
                                f"union per GPU, 2-layer GCN hidden {H}, GD step + Adam", "parallelism": f"dp{world}",
                    "dense_gemm": ("hipBLASLt fp32 operands, 3xbf16-split MFMA for X@W^T and dH@W (rel err ~5e-6 vs fp64), "
-                                  "fp32 MFMA for dH^T@X") if args.gemm_precision == "high" else "hipBLASLt fp32 MFMA",
+                                  "dH^T@X as a split-K batched GEMM of the same precision + fixed-order sum") if args.gemm_precision == "high" else "hipBLASLt fp32 MFMA",
                    "layer0_features": "de-duplicated table (19717 rows) + row indirection in the SpMM" if trainer.dedup
                    else "materialised union rows",
                    **info},
         "roofline": {"kernel": "spmm_tile_kernel<VEC=4,B=4,MPR=16> (CSR SpMM, LDS row windows, H=%d, f32)" % H, "bound": "hbm", "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "algorithmic_bytes_per_launch": bytes_spmm, "avg_launch_us": spmm_ms * 1e3,
-                     "launches_timed": len(durs_ms), "spmm_edges_per_s": batch.nnz / (spmm_ms * 1e-3)},
+                     "launches_timed": len(durs_ms), "spmm_edges_per_s": batch.nnz / (spmm_ms * 1e-3),
+                     "copy_ceiling_GBps": copy_gbs, "frac_of_copy_ceiling": achieved / copy_gbs},
         "loss": float(loss),
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
