@@ -208,3 +208,26 @@ def test_dedup_first_layer_equals_materialised_rows(mods):
     assert rel(out_d.detach().cpu(), out_m.detach().cpu()) < 1e-5
     for k, p in model.named_parameters():
         assert rel(g_d[k].cpu(), p.grad.cpu()) < 1e-4, k
+
+
+def test_real_cora_trained_checkpoint(mods):
+    """The reference's own trained Cora GCN (SGGC checkpoint, tests/golden/gcn_cora_sggc.npz) through the HIP GCNConv:
+    log-probabilities within 1e-4 of the frozen oracle output, identical test accuracy."""
+    import os
+
+    import scipy.sparse as sp
+
+    network, fnn, gorc = mods
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "gcn_cora_sggc.npz"))
+    X = sp.coo_matrix((d["x_val"], (d["x_row"], d["x_col"])), shape=tuple(d["x_shape"])).toarray()
+    x = torch.nn.functional.normalize(torch.from_numpy(X), p=1).cuda()
+    ei = torch.from_numpy(d["edge_index"].astype(np.int64)).cuda()
+    c1, c2 = fnn.GCNConv(1433, 64).cuda(), fnn.GCNConv(64, 7).cuda()
+    c1.load_state_dict({"lin.weight": torch.from_numpy(d["w:conv1.lin.weight"]), "bias": torch.from_numpy(d["w:conv1.bias"])})
+    c2.load_state_dict({"lin.weight": torch.from_numpy(d["w:conv2.lin.weight"]), "bias": torch.from_numpy(d["w:conv2.bias"])})
+    with torch.no_grad():
+        logits = torch.log_softmax(c2(torch.relu(c1(x, ei)), ei), dim=1).cpu()
+    ref = torch.from_numpy(d["logits"])
+    assert float((logits - ref).abs().max()) < 1e-4 * float(ref.abs().max())
+    pred = logits.argmax(1).numpy()
+    assert float((pred[d["test_idx"]] == d["y"][d["test_idx"]]).mean()) == pytest.approx(float(d["test_acc"]), abs=1e-3)
