@@ -95,6 +95,79 @@ def assemble_subgraphs(edge_index, num_nodes, assign, n_clusters, extra_node=Tru
     return dict(ptr=ptr, node_id=mem_n, core=core, edge_index=np.stack([e_src, e_dst]))
 
 
+def assemble_subgraphs_cluster(edge_index, num_nodes, assign, n_clusters, coarse_adj):
+    """--cluster_node subgraphs (utils.py:190-232, :252-259), all clusters at once.
+
+    Cluster c's subgraph = its own nodes (ascending) followed by one NEW node per neighbouring cluster d, in the
+    reference's order of first appearance (members ascending, and per member its connected clusters ascending);
+    a new node carries the pooled features (C.X)[d], label 0, mask False.  Edges: the induced edges of the own nodes,
+    member <-> new node for every (member, neighbouring cluster) pair, and new(d1) <-> new(d2) when the coarse graph
+    links d1 and d2 (`adj[d1, d2] or adj[d2, d1]`).
+    coarse_adj: scipy sparse [n_clusters x n_clusters], non-zero = coarse edge (Gc.A of every component, global ids).
+    Returns the dict of assemble_subgraphs; node_id >= num_nodes encodes the new node of cluster node_id - num_nodes
+    (rows of a feature table [X ; C.X])."""
+    import scipy.sparse as sp
+
+    src, dst = np.asarray(edge_index[0], dtype=np.int64), np.asarray(edge_index[1], dtype=np.int64)
+    assign = np.asarray(assign, dtype=np.int64)
+    N, n = int(num_nodes), int(n_clusters)
+    cut = assign[src] != assign[dst]
+    cx, cd = src[cut], assign[dst[cut]]                     # member x (in cluster assign[x]) sees cluster d
+    cc = assign[cx]
+    # distinct (c, d) pairs = new nodes; order inside c by (first member that sees d, d)
+    pair_key, inv = np.unique(cc * n + cd, return_inverse=True)
+    first_x = np.full(len(pair_key), N, dtype=np.int64)
+    np.minimum.at(first_x, inv, cx)
+    pc, pd = pair_key // n, pair_key % n
+    order = np.lexsort((pd, first_x, pc))
+    pc, pd, pair_sorted = pc[order], pd[order], pair_key[order]
+    n_new = np.bincount(pc, minlength=n)
+    n_core = np.bincount(assign, minlength=n)
+    ptr = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(n_core + n_new, out=ptr[1:])
+    # union rows: own nodes first (ascending id), then the new nodes in the order above
+    core_order = np.lexsort((np.arange(N), assign))
+    core_start = np.cumsum(n_core) - n_core
+    row_of_node = np.empty(N, dtype=np.int64)
+    row_of_node[core_order] = ptr[assign[core_order]] + (np.arange(N) - core_start[assign[core_order]])
+    new_start = np.cumsum(n_new) - n_new
+    new_row = ptr[pc] + n_core[pc] + (np.arange(len(pc)) - new_start[pc])
+    R = int(ptr[-1])
+    node_id = np.empty(R, dtype=np.int64)
+    node_id[row_of_node] = np.arange(N)
+    node_id[new_row] = N + pd
+    core = np.zeros(R, dtype=bool)
+    core[row_of_node] = True
+    # lookup (c, d) -> new row
+    look = np.argsort(pair_sorted, kind="stable")
+    keys_sorted, rows_sorted = pair_sorted[look], new_row[look]
+    def new_row_of(c, d):
+        pos = np.searchsorted(keys_sorted, c * n + d)
+        pos = np.minimum(pos, len(keys_sorted) - 1) if len(keys_sorted) else pos
+        ok = (keys_sorted[pos] == c * n + d) if len(keys_sorted) else np.zeros(len(c), dtype=bool)
+        return rows_sorted[pos] if len(keys_sorted) else pos, ok
+    es, ed = [], []
+    inn = ~cut
+    es.append(row_of_node[src[inn]]); ed.append(row_of_node[dst[inn]])                 # induced edges of the own nodes
+    xd = np.unique(cx * n + cd)                                                        # (member, neighbouring cluster)
+    mx, md = xd // n, xd % n
+    r_new, ok = new_row_of(assign[mx], md)
+    assert bool(np.all(ok))
+    es += [row_of_node[mx], r_new]; ed += [r_new, row_of_node[mx]]
+    S = sp.csr_matrix(coarse_adj)
+    S = ((S + S.T) != 0).tocsr()
+    S.setdiag(False); S.eliminate_zeros()
+    if len(pc):                                                                        # new(d1) - new(d2), d2 a coarse neighbour of d1
+        deg = np.diff(S.indptr)[pd]
+        rep = np.repeat(np.arange(len(pc)), deg)
+        within = np.arange(len(rep)) - np.repeat(np.cumsum(deg) - deg, deg)
+        d2 = S.indices[S.indptr[pd][rep] + within].astype(np.int64)
+        r2, ok2 = new_row_of(pc[rep], d2)
+        es.append(new_row[rep][ok2]); ed.append(r2[ok2])
+    return dict(ptr=ptr, node_id=node_id, core=core,
+                edge_index=np.stack([np.concatenate(es), np.concatenate(ed)]).astype(np.int64))
+
+
 class SubgraphBatch:
     """Device-resident block-diagonal union of cluster subgraphs (one static 'batch of batches').
 

@@ -19,7 +19,7 @@ import torch
 import torch.nn.functional as F
 
 from . import coarsening, data as fdata, network
-from .train import GDTrainer
+from .train import GDTrainer, MBTrainer
 
 SYNTHETIC_SHAPES = {  # name: (N, E, F, classes)   dataset_info.csv:4-7
     "synthetic-cora": (2708, 5278, 1433, 7),
@@ -175,14 +175,33 @@ def coarsening_classification(args, data, coarsening_ratio, coarsening_method, d
 
 def build_gs(args, data, co, device="cuda"):
     """Subgraphs Gs (utils.py:186-267) + their masks (utils.py:683-703) as one block-diagonal SubgraphBatch."""
+    N, n = data.num_nodes, co.n_clusters
+    x, y = data.x, data.y.flatten()
+    masks = [data.train_mask, data.val_mask, data.test_mask]
     if getattr(args, "cluster_node", False):
-        raise NotImplementedError("--cluster_node subgraphs are not built yet; use --extra_node or neither")
-    sub = fdata.assemble_subgraphs(data.edge_index, data.num_nodes, co.assign, co.n_clusters,
-                                   extra_node=bool(getattr(args, "extra_node", False)))
-    batch = fdata.SubgraphBatch(sub, data.x, data.y.flatten(), data.train_mask, device=device)
+        # new nodes carry the pooled features C.X of the neighbouring cluster (utils.py:160-161, :209), label 0, no mask
+        Xc = torch.zeros((n, x.shape[1]), dtype=torch.float32)
+        rows, cols = [], []
+        for H, C, Gc, off in zip(co.components, co.all_C, co.all_Gc, co.comp_cluster_off):
+            if C is None:
+                continue
+            idx = torch.as_tensor(np.asarray(H.info["orig_idx"], dtype=np.int64))
+            Xc[off:off + C.shape[0]] = C.pool(x[idx].to(device)).cpu()
+            coo = Gc.W.tocoo()
+            rows.append(coo.row.astype(np.int64) + off); cols.append(coo.col.astype(np.int64) + off)
+        r = np.concatenate(rows) if rows else np.zeros(0, dtype=np.int64)
+        c = np.concatenate(cols) if cols else np.zeros(0, dtype=np.int64)
+        adj = sp.csr_matrix((np.ones(len(r)), (r, c)), shape=(n, n))
+        sub = fdata.assemble_subgraphs_cluster(data.edge_index, N, co.assign, n, adj)
+        x = torch.cat([x.float(), Xc])
+        y = torch.cat([y, torch.zeros(n, dtype=y.dtype)])
+        masks = [torch.cat([m, torch.zeros(n, dtype=torch.bool)]) for m in masks]
+    else:
+        sub = fdata.assemble_subgraphs(data.edge_index, N, co.assign, n, extra_node=bool(getattr(args, "extra_node", False)))
+    batch = fdata.SubgraphBatch(sub, x, y, masks[0], device=device)
     core = batch.core
-    batch.val_idx = torch.nonzero(data.val_mask.to(device)[batch.node_id] & core).flatten()
-    batch.test_idx = torch.nonzero(data.test_mask.to(device)[batch.node_id] & core).flatten()
+    batch.val_idx = torch.nonzero(masks[1].to(device)[batch.node_id] & core).flatten()
+    batch.test_idx = torch.nonzero(masks[2].to(device)[batch.node_id] & core).flatten()
     return batch
 
 
@@ -260,9 +279,9 @@ def infer_gs(model, batch, idx, reduction="mean"):
 
 def node_classification(args, path, data, co, device="cuda", log=print):
     """run.node_classification (run.py:329-506) for exp_setup in {Gc_train_2_Gs_infer, Gs_train_2_Gs_infer,
-    Gc_train_2_Gs_train}, gradient_method GD."""
-    if args.gradient_method != "GD":
-        raise NotImplementedError("MB mode (sequential step per batch, run.py:217-252) is not built; use GD")
+    Gc_train_2_Gs_train}, gradient_method GD (one step per epoch over the union) or MB (one step per loader batch)."""
+    if args.gradient_method not in ("GD", "MB"):
+        raise ValueError(f"--gradient_method {args.gradient_method}: GD or MB")
     rng = np.random.default_rng(args.seed)
     data = splits_classification(data, args.num_classes, args.experiment, rng)
     batch = build_gs(args, data, co, device)
@@ -295,7 +314,11 @@ def node_classification(args, path, data, co, device="cuda", log=print):
                     torch.save(model.state_dict(), ckpt)
             model.load_state_dict(torch.load(ckpt))
         if args.exp_setup in ("Gs_train_2_Gs_infer", "Gc_train_2_Gs_train"):
-            trainer = GDTrainer(model, batch, lr=args.lr, weight_decay=args.weight_decay, reduction=args.loss_reduction)
+            if args.gradient_method == "GD":
+                trainer = GDTrainer(model, batch, lr=args.lr, weight_decay=args.weight_decay, reduction=args.loss_reduction)
+            else:
+                trainer = MBTrainer(model, batch, batch_size=args.batch_size, lr=args.lr, weight_decay=args.weight_decay,
+                                    reduction=args.loss_reduction)
             if args.exp_setup == "Gc_train_2_Gs_train":
                 trainer.opt.load_state_dict(opt.state_dict())  # the reference keeps ONE optimizer across both phases
             best = float("inf")

@@ -69,3 +69,49 @@ class GDTrainer:
         sel = out.index_select(0, mask_idx)
         y = b.y.index_select(0, mask_idx)
         return F.nll_loss(sel, y), (sel.argmax(1) == y).float().mean()
+
+
+class MBTrainer:
+    """node_train_Gs_MB (run.py:217-252): per epoch ONE zero_grad, then for every loader batch (128 subgraphs,
+    run.py:336) that holds a train node: forward, loss over the batch's train nodes, backward, optimiser step.
+    The reference never clears the gradients between batches, so batch k steps with the SUM of the gradients of
+    batches 0..k of this epoch; reproduced here because it changes the trained weights.
+    Sequential by construction: single GPU only."""
+
+    def __init__(self, model, batch, batch_size=128, lr=0.01, weight_decay=5e-4, reduction="mean"):
+        from .csr import CSRGraph, register
+
+        self.model, self.reduction = model, reduction
+        fused = next(model.parameters()).is_cuda
+        self.opt = torch.optim.Adam(model.parameters(), lr=lr, weight_decay=weight_decay, fused=fused)
+        self.flat = FlatGrads(model.parameters())
+        ei = batch.edge_index
+        order = torch.argsort(ei[0], stable=True)
+        src_sorted = ei[0][order].contiguous()
+        self.parts = []
+        self.n_loader_batches = 0
+        for r0, r1 in batch.slice_batches(batch_size):
+            self.n_loader_batches += 1
+            tm = batch.train_mask[r0:r1]
+            if not bool(tm.any()):
+                continue  # run.py:225 `if True in train_mask`
+            lo, hi = (int(v) for v in torch.searchsorted(src_sorted, torch.tensor([r0, r1], device=ei.device)))
+            e = (ei[:, order[lo:hi]] - r0).contiguous()
+            if e.is_cuda:
+                register(e, CSRGraph(e, r1 - r0, mode="gcn", ptr=batch.ptr[(batch.ptr >= r0) & (batch.ptr <= r1)] - r0), "gcn")
+            self.parts.append((batch.x[r0:r1], e, batch.y[r0:r1].index_select(0, torch.nonzero(tm).flatten()),
+                               torch.nonzero(tm).flatten()))
+        self.n_train = sum(int(p[3].numel()) for p in self.parts)
+
+    def step(self):
+        m = self.model
+        m.train()
+        self.flat.zero()
+        total = torch.zeros((), device=self.flat.buf.device)
+        for x, e, y, idx in self.parts:
+            out = m(x, e)
+            loss = F.nll_loss(out.index_select(0, idx), y, reduction=self.reduction)
+            loss.backward()       # accumulates into the flat buffer: no zero_grad between batches (run.py:222)
+            self.opt.step()
+            total += loss.detach()
+        return total / (self.n_loader_batches if self.reduction == "mean" else max(self.n_train, 1))

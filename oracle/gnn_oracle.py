@@ -133,3 +133,26 @@ def gd_train_step(sd, batches, num_layers=2, lr=0.01, weight_decay=5e-4, adam_st
         opt.load_state_dict(adam_state)
     opt.step()
     return loss.detach(), {k: v.detach() for k, v in params.items()}, opt.state_dict()
+
+
+def mb_train_epoch(sd, batches, num_layers=2, lr=0.01, weight_decay=5e-4, adam_state=None, reduction="mean"):
+    """One epoch of node_train_Gs_MB (run.py:217-252): zero_grad ONCE (:222), then per batch with a train node:
+    forward, loss, backward, optimizer.step() -- gradients accumulate across the epoch's batches.  Dropout off
+    (the caller compares in p=0 mode).  Returns (reported loss, new_state_dict, adam_state)."""
+    params = {k: v.detach().clone().requires_grad_(True) for k, v in sd.items()}
+    opt = torch.optim.Adam(list(params.values()), lr=lr, weight_decay=weight_decay)
+    if adam_state is not None:
+        opt.load_state_dict(adam_state)
+    opt.zero_grad()
+    total, n_out = 0.0, 0
+    for b in batches:
+        if not bool(b["train_mask"].any()):
+            continue
+        out = classify_node_forward(params, b["x"], b["edge_index"], num_layers, masks=None, p=0.0)
+        loss = F.nll_loss(out[b["train_mask"]], b["y"][b["train_mask"]].long(), reduction=reduction)
+        loss.backward()
+        opt.step()
+        total += float(loss)
+        n_out += int(b["train_mask"].sum())
+    rep = total / len(batches) if reduction == "mean" else total / max(n_out, 1)
+    return rep, {k: v.detach() for k, v in params.items()}, opt.state_dict()

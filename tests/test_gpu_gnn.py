@@ -231,3 +231,52 @@ def test_real_cora_trained_checkpoint(mods):
     assert float((logits - ref).abs().max()) < 1e-4 * float(ref.abs().max())
     pred = logits.argmax(1).numpy()
     assert float((pred[d["test_idx"]] == d["y"][d["test_idx"]]).mean()) == pytest.approx(float(d["test_acc"]), abs=1e-3)
+
+
+def _subgraph_batches(seed=0):
+    """A small Gs: 40 clusters over a 400-node graph with extra nodes, as loader batches of 8 subgraphs."""
+    from fitgnn_amd import data as fdata
+
+    ei = fdata.synthetic_graph(400, 900, seed=seed)
+    rng = np.random.default_rng(seed)
+    assign = rng.integers(0, 40, size=400); assign[:40] = np.arange(40)
+    sub = fdata.assemble_subgraphs(ei, 400, assign, 40, extra_node=True)
+    X = torch.from_numpy(rng.standard_normal((400, 24)).astype(np.float32))
+    y = torch.from_numpy(rng.integers(0, 4, size=400))
+    tm = torch.from_numpy(rng.random(400) < 0.3)
+    batch = fdata.SubgraphBatch(sub, X, y, tm, device="cuda")
+    cpu = []
+    for r0, r1 in batch.slice_batches(8):
+        e = batch.edge_index.cpu()
+        k = (e[0] >= r0) & (e[0] < r1)
+        cpu.append(dict(x=batch.x[r0:r1].cpu(), edge_index=e[:, k] - r0, y=batch.y[r0:r1].cpu(), train_mask=batch.train_mask[r0:r1].cpu()))
+    return batch, cpu
+
+
+@pytest.mark.parametrize("method", ["GD", "MB"])
+def test_trainers_follow_the_reference_step_functions(mods, method):
+    """GDTrainer / MBTrainer vs the oracle's restatement of run.py:177-215 / :217-252 over three epochs (dropout off):
+    same reported loss and the same weights (MB: including the gradient accumulation across batches)."""
+    from fitgnn_amd import train
+
+    network, fnn, gorc = mods
+    batch, cpu = _subgraph_batches()
+    args = argparse.Namespace(num_layers1=2, layer_name="GCNConv", num_features=24, hidden=32, num_classes=4)
+    torch.manual_seed(5)
+    model = network.Classify_node(args).cuda()
+    model.dropout_p = 0.0
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    if method == "GD":
+        tr = train.GDTrainer(model, batch, lr=0.01, weight_decay=5e-4)
+    else:
+        tr = train.MBTrainer(model, batch, batch_size=8, lr=0.01, weight_decay=5e-4)
+    state = None
+    for epoch in range(3):
+        got = float(tr.step())
+        if method == "GD":
+            want, sd, state = gorc.gd_train_step(sd, cpu, adam_state=state, masks=None)
+        else:
+            want, sd, state = gorc.mb_train_epoch(sd, cpu, adam_state=state)
+        assert got == pytest.approx(float(want), rel=2e-4), (epoch, got, float(want))
+    for k, v in model.state_dict().items():
+        assert rel(v.detach().cpu(), sd[k]) < 2e-3, k

@@ -182,3 +182,56 @@ def test_xcd_tile_layout_is_balanced_and_complete():
         seg = out[k::8]
         seg = seg[seg[:, 1] > seg[:, 0]]
         assert np.all(seg[1:, 0] == seg[:-1, 1])
+
+
+def test_cluster_node_assembly_matches_reference_construction():
+    """assemble_subgraphs_cluster == the loop of utils.py:190-232 restated literally (new-node order, edges)."""
+    import scipy.sparse as sp
+
+    from fitgnn_amd.data import assemble_subgraphs_cluster, synthetic_graph
+
+    N, n_c = 240, 60
+    ei = synthetic_graph(N, 520, seed=5)
+    rng = np.random.default_rng(2)
+    assign = rng.integers(0, n_c, size=N)
+    assign[:n_c] = np.arange(n_c)
+    # coarse adjacency = lift of the edges (what Gc.A holds), upper triangle only to exercise the `or adj[j, i]` branch
+    cu, cv = assign[ei[0]], assign[ei[1]]
+    k = cu < cv
+    adj = sp.csr_matrix((np.ones(int(k.sum())), (cu[k], cv[k])), shape=(n_c, n_c))
+    adj.data[:] = 1
+    sub = assemble_subgraphs_cluster(ei, N, assign, n_c, adj)
+    nbrs = {}
+    for a, b in zip(ei[0].tolist(), ei[1].tolist()):
+        nbrs.setdefault(a, []).append(b)
+    A = adj.toarray() > 0
+    got = set(zip(sub["edge_index"][0].tolist(), sub["edge_index"][1].tolist()))
+    assert len(got) == sub["edge_index"].shape[1]  # no duplicate edges
+    want = set()
+    for c in range(n_c):
+        value = np.sort(np.nonzero(assign == c)[0])
+        r0 = int(sub["ptr"][c])
+        loc = {int(v): r0 + i for i, v in enumerate(value)}
+        num_nodes = len(value)
+        new_of = {}                                   # meta_node_2_new_node, insertion ordered
+        for node in value.tolist():
+            outside = [v for v in nbrs.get(node, []) if v not in loc]
+            for cl in np.unique(assign[outside]).tolist() if outside else []:
+                if cl not in new_of:
+                    new_of[cl] = r0 + num_nodes
+                    num_nodes += 1
+                want.add((loc[node], new_of[cl])); want.add((new_of[cl], loc[node]))
+        keys = list(new_of)
+        for i in range(len(keys) - 1):
+            for j in range(i + 1, len(keys)):
+                if A[keys[i], keys[j]] or A[keys[j], keys[i]]:
+                    want.add((new_of[keys[i]], new_of[keys[j]])); want.add((new_of[keys[j]], new_of[keys[i]]))
+        for u in value.tolist():
+            for v in nbrs.get(u, []):
+                if v in loc:
+                    want.add((loc[u], loc[v]))
+        assert int(sub["ptr"][c + 1]) - r0 == num_nodes
+        assert sub["node_id"][r0:r0 + len(value)].tolist() == value.tolist()
+        assert sub["node_id"][r0 + len(value):r0 + num_nodes].tolist() == [N + k for k in keys]
+        assert sub["core"][r0:r0 + num_nodes].tolist() == [True] * len(value) + [False] * len(keys)
+    assert got == want
