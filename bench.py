@@ -36,6 +36,8 @@ WORKLOADS = {
     # name: (N, E, F, classes, Loukas r)
     "S-pubmed": (19717, 44324, 500, 3, 0.5),
     "S-cora": (2708, 5278, 1433, 7, 0.5),
+    "S-physics": (34493, 247962, 8415, 5, 0.7),     # CLI --coarsening_ratio 0.3 (main.py:278 passes 1 - ratio)
+    "S-products": (165000, 4125000, 100, 47, 0.5),  # one ogbn-products community (<= 165 000 nodes, main.py:264), mean degree 50 assumed
 }
 
 
@@ -60,7 +62,9 @@ def build_workload(name, seed, device, hidden=512):
     torch.cuda.synchronize()
     t2 = time.time()
     assign = sp.csc_matrix(Cmat).indices
-    sub = data.assemble_subgraphs(ei, N, assign, Cmat.shape[0], extra_node=True)
+    sub = data.assemble_subgraphs_torch(torch.from_numpy(ei).to(device), N, assign, Cmat.shape[0], extra_node=True)
+    torch.cuda.synchronize()
+    t3 = time.time()
     rng = np.random.default_rng(seed + 1)
     X = rng.random((N, F), dtype=np.float32)
     X /= X.sum(1, keepdims=True)  # --normalize_features (main.py:48)
@@ -69,7 +73,7 @@ def build_workload(name, seed, device, hidden=512):
     batch = data.SubgraphBatch(sub, X, y, train_mask, device=device)
     info = dict(nodes=N, undirected_edges=E, features=F, classes=C, clusters=int(Cmat.shape[0]),
                 union_rows=batch.n_rows, nnz_prime=batch.nnz, t_graph_eig_s=round(t1 - t0, 2),
-                t_coarsen_hip_s=round(t2 - t1, 3), t_assemble_s=round(time.time() - t2, 2))
+                t_coarsen_hip_s=round(t2 - t1, 3), t_assemble_s=round(t3 - t2, 2), t_batch_csr_s=round(time.time() - t3, 2))
     return batch, (F, C), info
 
 
@@ -193,11 +197,11 @@ def main():
         "value": total_edges / dt, "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{args.workload}: variation_neighborhoods r=0.5, extra-node subgraphs, one block-diagonal "
+        "config": {"workload": f"{args.workload}: variation_neighborhoods r={WORKLOADS[args.workload][4]}, extra-node subgraphs, one block-diagonal "
                                f"union per GPU, 2-layer GCN hidden {H}, GD step + Adam", "parallelism": f"dp{world}",
                    "dense_gemm": ("hipBLASLt fp32 operands, 3xbf16-split MFMA for X@W^T and dH@W (rel err ~5e-6 vs fp64), "
                                   "dH^T@X as a split-K batched GEMM of the same precision + fixed-order sum") if args.gemm_precision == "high" else "hipBLASLt fp32 MFMA",
-                   "layer0_features": "de-duplicated table (19717 rows) + row indirection in the SpMM" if trainer.dedup
+                   "layer0_features": f"de-duplicated table ({info['nodes']} rows) + row indirection in the SpMM" if trainer.dedup
                    else "materialised union rows",
                    **info},
         "roofline": {"kernel": "spmm_tile_kernel<VEC=4,B=4,MPR=16> (CSR SpMM, LDS row windows, H=%d, f32)" % H, "bound": "hbm", "achieved": achieved,

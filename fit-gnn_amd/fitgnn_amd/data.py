@@ -36,6 +36,21 @@ def synthetic_graph(N, E, seed=0):
         repeated.extend([v] * m)
         idx = rng.integers(0, len(repeated), size=m)
         targets = [repeated[i] for i in idx]
+    if E > 1_000_000:  # large stand-ins (S-products): the uniformly random remainder drawn and de-duplicated in bulk
+        base = np.array([(min(a, b), max(a, b)) for a, b in zip(src, dst)], dtype=np.int64)
+        keys = np.unique(base[:, 0] * N + base[:, 1])
+        while len(keys) < E:
+            need = E - len(keys)
+            a = rng.integers(0, N, size=need + need // 8 + 16)
+            b = rng.integers(0, N, size=len(a))
+            ok = a != b
+            lo, hi = np.minimum(a[ok], b[ok]), np.maximum(a[ok], b[ok])
+            fresh = np.setdiff1d(np.unique(lo * N + hi), keys)
+            keys = np.union1d(keys, rng.permutation(fresh)[:need])
+        und = np.stack([keys // N, keys % N], axis=1)
+        ei = np.concatenate([und.T, und.T[::-1]], axis=1)
+        order = np.lexsort((ei[1], ei[0]))
+        return ei[:, order]
     und = {(min(a, b), max(a, b)) for a, b in zip(src, dst)}
     while len(und) < E:
         need = E - len(und)
@@ -93,6 +108,46 @@ def assemble_subgraphs(edge_index, num_nodes, assign, n_clusters, extra_node=Tru
     hit = key[pos] == want
     e_src, e_dst = rows[hit], pos[hit]                                      # x -> y inside the union
     return dict(ptr=ptr, node_id=mem_n, core=core, edge_index=np.stack([e_src, e_dst]))
+
+
+def assemble_subgraphs_torch(edge_index, num_nodes, assign, n_clusters, extra_node=True, chunk_rows=1 << 20):
+    """assemble_subgraphs with torch tensor ops on the device of `edge_index` (the reference's
+    neighbour() scans all E edges per node, utils.py:52-56; here: one sort of the membership keys, one CSR gather and a
+    binary search per (member, neighbour) pair, in chunks of `chunk_rows` members to bound memory).
+    Same dict as assemble_subgraphs, values are int64 / bool tensors on that device (ptr too)."""
+    dev = edge_index.device
+    src, dst = edge_index[0].long(), edge_index[1].long()
+    assign = torch.as_tensor(assign, device=dev).long()
+    N, n = int(num_nodes), int(n_clusters)
+    pc, pn = [assign], [torch.arange(N, device=dev)]
+    if extra_node:
+        cut = assign[src] != assign[dst]
+        pc.append(assign[src[cut]])
+        pn.append(dst[cut])
+    key = torch.unique(torch.cat(pc) * N + torch.cat(pn))            # sorted by (cluster, node)
+    mem_c, mem_n = key // N, key % N
+    ptr = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    ptr[1:] = torch.cumsum(torch.bincount(mem_c, minlength=n), 0)
+    core = assign[mem_n] == mem_c
+    order = torch.argsort(src * N + dst)
+    s_dst = dst[order]
+    adj_ptr = torch.zeros(N + 1, dtype=torch.int64, device=dev)
+    adj_ptr[1:] = torch.cumsum(torch.bincount(src, minlength=N), 0)
+    deg = adj_ptr[mem_n + 1] - adj_ptr[mem_n]
+    es, ed = [], []
+    R = int(key.numel())
+    for r0 in range(0, R, chunk_rows):
+        r1 = min(R, r0 + chunk_rows)
+        d = deg[r0:r1]
+        rows = torch.repeat_interleave(torch.arange(r0, r1, device=dev), d)
+        first = torch.cumsum(d, 0) - d
+        within = torch.arange(int(rows.numel()), device=dev) - torch.repeat_interleave(first, d)
+        nbr = s_dst[torch.repeat_interleave(adj_ptr[mem_n[r0:r1]], d) + within]
+        want = mem_c[rows] * N + nbr
+        pos = torch.searchsorted(key, want).clamp_(max=R - 1)
+        hit = key[pos] == want
+        es.append(rows[hit]); ed.append(pos[hit])
+    return dict(ptr=ptr, node_id=mem_n, core=core, edge_index=torch.stack([torch.cat(es), torch.cat(ed)]))
 
 
 def assemble_subgraphs_cluster(edge_index, num_nodes, assign, n_clusters, coarse_adj):
@@ -178,11 +233,12 @@ class SubgraphBatch:
         """dedup: keep ONE copy of every original node's features on the device (`x_table`, `row_index`) next to the
         materialised union rows `x`; models that accept `x_index` then run their first layer on the table."""
         dev = torch.device(device)
-        self.ptr = sub["ptr"]
-        self.n_rows = int(sub["ptr"][-1])
-        self.node_id = torch.from_numpy(sub["node_id"]).to(dev)
-        self.core = torch.from_numpy(sub["core"]).to(dev)
-        self.edge_index = torch.from_numpy(sub["edge_index"]).to(dev)
+        as_t = lambda a: (a if torch.is_tensor(a) else torch.from_numpy(a)).to(dev)  # noqa: E731
+        self.ptr = sub["ptr"].cpu().numpy() if torch.is_tensor(sub["ptr"]) else sub["ptr"]
+        self.n_rows = int(self.ptr[-1])
+        self.node_id = as_t(sub["node_id"])
+        self.core = as_t(sub["core"])
+        self.edge_index = as_t(sub["edge_index"])
         X = X if torch.is_tensor(X) else torch.from_numpy(np.asarray(X))
         Xd = X.to(dev).float()
         self.x = Xd[self.node_id].contiguous()

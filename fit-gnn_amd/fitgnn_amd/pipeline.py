@@ -197,7 +197,8 @@ def build_gs(args, data, co, device="cuda"):
         y = torch.cat([y, torch.zeros(n, dtype=y.dtype)])
         masks = [torch.cat([m, torch.zeros(n, dtype=torch.bool)]) for m in masks]
     else:
-        sub = fdata.assemble_subgraphs(data.edge_index, N, co.assign, n, extra_node=bool(getattr(args, "extra_node", False)))
+        ei_dev = torch.as_tensor(np.asarray(data.edge_index)).to(device)
+        sub = fdata.assemble_subgraphs_torch(ei_dev, N, co.assign, n, extra_node=bool(getattr(args, "extra_node", False)))
     batch = fdata.SubgraphBatch(sub, x, y, masks[0], device=device)
     core = batch.core
     batch.val_idx = torch.nonzero(masks[1].to(device)[batch.node_id] & core).flatten()

@@ -235,3 +235,22 @@ def test_cluster_node_assembly_matches_reference_construction():
         assert sub["node_id"][r0 + len(value):r0 + num_nodes].tolist() == [N + k for k in keys]
         assert sub["core"][r0:r0 + num_nodes].tolist() == [True] * len(value) + [False] * len(keys)
     assert got == want
+
+
+def test_torch_assembly_equals_numpy_assembly():
+    """assemble_subgraphs_torch (device tensor ops, chunked) == assemble_subgraphs (NumPy), edge set and row layout."""
+    import torch
+
+    from fitgnn_amd.data import assemble_subgraphs, assemble_subgraphs_torch, synthetic_graph
+
+    ei = synthetic_graph(500, 1300, seed=7)
+    rng = np.random.default_rng(1)
+    assign = rng.integers(0, 120, size=500); assign[:120] = np.arange(120)
+    for extra in (True, False):
+        a = assemble_subgraphs(ei, 500, assign, 120, extra_node=extra)
+        b = assemble_subgraphs_torch(torch.from_numpy(ei), 500, assign, 120, extra_node=extra, chunk_rows=97)
+        assert np.array_equal(a["ptr"], b["ptr"].numpy()) and np.array_equal(a["node_id"], b["node_id"].numpy())
+        assert np.array_equal(a["core"], b["core"].numpy())
+        ea = set(zip(a["edge_index"][0].tolist(), a["edge_index"][1].tolist()))
+        eb = set(zip(b["edge_index"][0].tolist(), b["edge_index"][1].tolist()))
+        assert ea == eb and len(eb) == b["edge_index"].shape[1]
