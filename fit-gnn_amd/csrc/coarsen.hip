@@ -92,16 +92,19 @@ __device__ __forceinline__ bool item_less(const HeapItem &a, const HeapItem &b) 
     return a.seq < b.seq;
 }
 
-constexpr int kHeapLds = 2048;  // top of the re-insertion heap lives in LDS (48 KiB), the rest in global
+constexpr int kHeapLds = 2048;      // single graph: top of the re-insertion heap lives in LDS (48 KiB), the rest in global
+constexpr int kHeapLdsBatch = 128;  // batched small components: 3 KiB per wave, 8 waves per CU
 
+template <int HEAP_LDS>
 struct Heap {
     HeapItem *lds;
     HeapItem *glob;
-    __device__ __forceinline__ HeapItem get(int i) const { return i < kHeapLds ? lds[i] : glob[i]; }
-    __device__ __forceinline__ void put(int i, const HeapItem &v) { if (i < kHeapLds) lds[i] = v; else glob[i] = v; }
+    __device__ __forceinline__ HeapItem get(int i) const { return i < HEAP_LDS ? lds[i] : glob[i]; }
+    __device__ __forceinline__ void put(int i, const HeapItem &v) { if (i < HEAP_LDS) lds[i] = v; else glob[i] = v; }
 };
 
-__device__ inline void heap_push(Heap &h, int &n, HeapItem it) {
+template <class H>
+__device__ inline void heap_push(H &h, int &n, HeapItem it) {
     int i = n++;
     while (i > 0) {
         const int p = (i - 1) >> 1;
@@ -112,7 +115,8 @@ __device__ inline void heap_push(Heap &h, int &n, HeapItem it) {
     }
     h.put(i, it);
 }
-__device__ inline HeapItem heap_pop(Heap &h, int &n) {
+template <class H>
+__device__ inline HeapItem heap_pop(H &h, int &n) {
     const HeapItem top = h.get(0);
     const HeapItem last = h.get(--n);
     int i = 0;
@@ -133,32 +137,30 @@ __device__ inline HeapItem heap_pop(Heap &h, int &n) {
     return top;
 }
 
-__global__ __launch_bounds__(64) void greedy_select_kernel(CostGraph g, int32_t N, const int32_t *__restrict__ set_off,
-                                                           int32_t *__restrict__ mem, int32_t *__restrict__ len,
-                                                           uint8_t *__restrict__ marked,
-                                                           const int32_t *__restrict__ order,
-                                                           const double *__restrict__ cost0, HeapItem *__restrict__ heap_glob,
-                                                           int64_t n_reduce, int64_t max_iters,
-                                                           int32_t *__restrict__ sel_off, int32_t *__restrict__ sel_mem,
-                                                           int32_t *__restrict__ sel_count) {
-    __shared__ CostLds lds;
-    __shared__ HeapItem heap_lds[kHeapLds];
-    Heap heap{heap_lds, heap_glob};
+// The greedy selection of contract_variation_linear (:604-650) over ONE connected component, run by one wavefront.
+// The component's candidates are order[head0 .. head1) (ascending (cost, node id)); node ids, set_off/mem/len/marked
+// are those of the whole (possibly block-diagonal) graph.  Selected sets go to sel_mem[0 .. ) and their END
+// positions to sel_end[0 .. ) (both relative to the pointers passed in).  Returns through ns / pos / the residual
+// n_reduce.  Every iteration consumes one queue entry and re-insertions strictly shrink a set, so the loop is
+// bounded by max_iters = candidates + members + slack (an exit every lane reaches).
+template <int HEAP_LDS>
+__device__ inline void greedy_component(const CostGraph &g, CostLds &lds, Heap<HEAP_LDS> heap, int32_t head0, int32_t head1,
+                                        int64_t seq, const int32_t *__restrict__ set_off, int32_t *__restrict__ mem,
+                                        int32_t *__restrict__ len, uint8_t *__restrict__ marked,
+                                        const int32_t *__restrict__ order, const double *__restrict__ cost0,
+                                        int64_t &n_reduce, int64_t max_iters, int32_t *__restrict__ sel_end,
+                                        int32_t *__restrict__ sel_mem, int32_t &ns, int32_t &pos) {
     const int lane = threadIdx.x & 63;
     int hn = 0;          // heap size (uniform)
-    int head = 0;        // next unread entry of the sorted initial family (uniform)
-    int64_t seq = N;     // insertion counter of re-inserted sets (initial family: seq = node id)
-    int32_t ns = 0, pos = 0;
-    if (lane == 0) sel_off[0] = 0;
-    // every iteration consumes one queue entry; re-insertions strictly shrink a set, so the number of
-    // iterations is bounded by N + sum of set sizes: max_iters is that bound (an exit every lane reaches).
+    int head = head0;    // next unread entry of the sorted initial family (uniform)
+    ns = 0; pos = 0;
     for (int64_t it = 0; it < max_iters; ++it) {
         if (n_reduce <= 0) break;
-        if (head >= N && hn == 0) break;
+        if (head >= head1 && hn == 0) break;
         // ---- pop the minimum of {sorted initial list head, heap top}: SortedList.pop(0) ----
         int32_t cand;
         bool from_list = hn == 0;
-        if (head < N && hn > 0) {
+        if (head < head1 && hn > 0) {
             const int32_t c0 = order[head];
             HeapItem li{cost0[c0], (int64_t)c0, c0, 0};
             const HeapItem top = heap.get(0);
@@ -192,8 +194,8 @@ __global__ __launch_bounds__(64) void greedy_select_kernel(CostGraph g, int32_t 
                 sel_mem[pos + t] = v;
             }
             pos += nc;
+            if (lane == 0) sel_end[ns] = pos;
             ++ns;
-            if (lane == 0) sel_off[ns] = pos;
             n_reduce -= gain;
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // marked[] writes before later reads
         } else {
@@ -220,7 +222,90 @@ __global__ __launch_bounds__(64) void greedy_select_kernel(CostGraph g, int32_t 
             }
         }
     }
-    if (lane == 0) { sel_count[0] = ns; sel_count[1] = pos; }
+}
+
+__global__ __launch_bounds__(64) void greedy_select_kernel(CostGraph g, int32_t N, const int32_t *__restrict__ set_off,
+                                                           int32_t *__restrict__ mem, int32_t *__restrict__ len,
+                                                           uint8_t *__restrict__ marked,
+                                                           const int32_t *__restrict__ order,
+                                                           const double *__restrict__ cost0, HeapItem *__restrict__ heap_glob,
+                                                           int64_t n_reduce, int64_t max_iters,
+                                                           int32_t *__restrict__ sel_off, int32_t *__restrict__ sel_mem,
+                                                           int32_t *__restrict__ sel_count) {
+    __shared__ CostLds lds;
+    __shared__ HeapItem heap_lds[kHeapLds];
+    if ((threadIdx.x & 63) == 0) sel_off[0] = 0;
+    int32_t ns, pos;
+    // re-inserted sets get seq = N, N+1, ... (initial family: seq = node id)
+    greedy_component<kHeapLds>(g, lds, Heap<kHeapLds>{heap_lds, heap_glob}, 0, N, (int64_t)N, set_off, mem, len, marked, order,
+                               cost0, n_reduce, max_iters, sel_off + 1, sel_mem, ns, pos);
+    if ((threadIdx.x & 63) == 0) { sel_count[0] = ns; sel_count[1] = pos; }
+}
+
+// One wavefront (= one 64-thread workgroup) per connected component of a block-diagonal graph whose components are
+// contiguous node ranges [comp_off[c], comp_off[c+1]).  Stages each component's sets in its own node range of
+// stage_mem / stage_end; comp_stat[c] = {number of sets, number of members}; gain[c] = sum of (|set| - 1).
+__global__ __launch_bounds__(64) void greedy_select_batch_kernel(CostGraph g, int32_t N, int32_t n_comp,
+                                                                 const int32_t *__restrict__ comp_off,
+                                                                 const int32_t *__restrict__ set_off, int32_t *__restrict__ mem,
+                                                                 int32_t *__restrict__ len, uint8_t *__restrict__ marked,
+                                                                 const int32_t *__restrict__ order,
+                                                                 const double *__restrict__ cost0,
+                                                                 HeapItem *__restrict__ heap_glob,
+                                                                 const int64_t *__restrict__ n_reduce_in,
+                                                                 int32_t *__restrict__ stage_end, int32_t *__restrict__ stage_mem,
+                                                                 int32_t *__restrict__ cnt_sets, int32_t *__restrict__ cnt_mem,
+                                                                 int64_t *__restrict__ gain) {
+    __shared__ CostLds lds;
+    __shared__ HeapItem heap_lds[kHeapLdsBatch];
+    const int c = blockIdx.x;
+    if (c >= n_comp) return;
+    const int32_t b = comp_off[c], e = comp_off[c + 1];
+    int64_t n_reduce = n_reduce_in[c];
+    const int64_t budget = n_reduce;
+    const int64_t max_iters = (int64_t)(e - b) + (int64_t)(set_off[e] - set_off[b]) + 8;
+    int32_t ns = 0, pos = 0;
+    if (e > b && n_reduce > 0)
+        greedy_component<kHeapLdsBatch>(g, lds, Heap<kHeapLdsBatch>{heap_lds, heap_glob + b}, b, e, (int64_t)N, set_off, mem, len,
+                                        marked, order, cost0, n_reduce, max_iters, stage_end + b, stage_mem + b, ns, pos);
+    if ((threadIdx.x & 63) == 0) { cnt_sets[c] = ns; cnt_mem[c] = pos; gain[c] = budget - n_reduce; }
+}
+
+// keep[c] = gain[c] > min_gain: components whose whole level would remove <= min_gain nodes are left untouched
+// (coarsening_utils.py:131-135 breaks before applying such a level)
+__global__ void batch_keep_kernel(int32_t n_comp, const int64_t *__restrict__ gain, int64_t min_gain,
+                                  int32_t *__restrict__ cnt_sets, int32_t *__restrict__ cnt_mem) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_comp) return;
+    if (gain[c] <= min_gain) { cnt_sets[c] = 0; cnt_mem[c] = 0; }
+}
+// scatter the staged per-component lists into one (sel_off, sel_mem) list; set_base / mem_base = exclusive scans
+__global__ __launch_bounds__(64) void batch_compact_kernel(int32_t n_comp, const int32_t *__restrict__ comp_off,
+                                                           const int32_t *__restrict__ cnt_sets, const int32_t *__restrict__ cnt_mem,
+                                                           const int32_t *__restrict__ set_base, const int32_t *__restrict__ mem_base,
+                                                           const int32_t *__restrict__ stage_end, const int32_t *__restrict__ stage_mem,
+                                                           int32_t *__restrict__ sel_off, int32_t *__restrict__ sel_mem,
+                                                           int32_t *__restrict__ sel_count) {
+    const int c = blockIdx.x;
+    if (c >= n_comp) return;
+    const int b = comp_off[c], ns = cnt_sets[c], nm = cnt_mem[c], sb = set_base[c], mb = mem_base[c];
+    for (int k = threadIdx.x; k < ns; k += 64) sel_off[sb + k + 1] = mb + stage_end[b + k];
+    for (int t = threadIdx.x; t < nm; t += 64) sel_mem[mb + t] = stage_mem[b + t];
+    if (c == 0 && threadIdx.x == 0) {
+        sel_off[0] = 0;
+        sel_count[0] = set_base[n_comp];
+        sel_count[1] = mem_base[n_comp];
+    }
+}
+__global__ void comp_of_kernel(int32_t n_comp, const int32_t *__restrict__ comp_off, uint32_t *__restrict__ comp_of) {
+    const int c = blockIdx.x;
+    if (c >= n_comp) return;
+    for (int i = comp_off[c] + threadIdx.x; i < comp_off[c + 1]; i += blockDim.x) comp_of[i] = (uint32_t)c;
+}
+__global__ void gather_u32_kernel(const uint32_t *__restrict__ src, const int32_t *__restrict__ idx, int32_t n,
+                                  uint32_t *__restrict__ dst) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[idx[i]];
 }
 
 __global__ void cost_keys_kernel(const double *__restrict__ cost0, int32_t N, uint64_t *__restrict__ keys,
@@ -328,7 +413,21 @@ extern "C" int fitgnn_variation_costs_f64(const int32_t *rowptr, const int32_t *
     if (n_sets < 0 || K < 1 || K > FITGNN_MAX_K || lda < K) return FITGNN_E_BADARG;
     if (n_sets == 0) return 0;
     if (!rowptr || !col || !dw || !A || !set_off || !set_len || !set_mem || !cost) return FITGNN_E_BADARG;
-    CostGraph g{rowptr, col, w, dw, A, K, lda};
+    CostGraph g{rowptr, col, w, dw, A, K, lda, nullptr};
+    const int blocks = (int)std::min<int64_t>(((int64_t)n_sets + kCostWaves - 1) / kCostWaves, 256 * 8);
+    hipLaunchKernelGGL(variation_costs_kernel, dim3(blocks), dim3(kCostWaves * 64), 0, (hipStream_t)stream, g, set_off,
+                       set_len, set_mem, n_sets, cost);
+    return (int)hipGetLastError();
+}
+
+extern "C" int fitgnn_variation_costs_batch_f64(const int32_t *rowptr, const int32_t *col, const double *w, const double *dw,
+                                                const double *A, int32_t K, int64_t lda, const int32_t *node_K,
+                                                const int32_t *set_off, const int32_t *set_len, const int32_t *set_mem,
+                                                int32_t n_sets, double *cost, void *stream) {
+    if (n_sets < 0 || K < 1 || K > FITGNN_MAX_K || lda < K) return FITGNN_E_BADARG;
+    if (n_sets == 0) return 0;
+    if (!rowptr || !col || !dw || !A || !set_off || !set_len || !set_mem || !cost) return FITGNN_E_BADARG;
+    CostGraph g{rowptr, col, w, dw, A, K, lda, node_K};
     const int blocks = (int)std::min<int64_t>(((int64_t)n_sets + kCostWaves - 1) / kCostWaves, 256 * 8);
     hipLaunchKernelGGL(variation_costs_kernel, dim3(blocks), dim3(kCostWaves * 64), 0, (hipStream_t)stream, g, set_off,
                        set_len, set_mem, n_sets, cost);
@@ -376,10 +475,101 @@ extern "C" int fitgnn_greedy_select(const int32_t *rowptr, const int32_t *col, c
     size_t tmp = L.sort_tmp_bytes;
     FITGNN_RETURN_IF_HIP(rocprim::radix_sort_pairs((void *)(base + L.sort_tmp), tmp, keys_in, keys_out, ids_in, order,
                                                    (size_t)N, 0, 64, s));
-    CostGraph g{rowptr, col, w, dw, A, K, lda};
+    CostGraph g{rowptr, col, w, dw, A, K, lda, nullptr};
     const int64_t max_iters = (int64_t)N + (int64_t)total + 8;
     hipLaunchKernelGGL(greedy_select_kernel, dim3(1), dim3(64), 0, s, g, N, set_off, mem, len, marked, order, cost0, heap,
                        n_reduce, max_iters, sel_off, sel_mem, sel_count);
+    return (int)hipGetLastError();
+}
+
+struct BatchLayout {
+    GreedyLayout G;
+    size_t comp_of, ckey_in, ckey_out, order1, stage_end, stage_mem, cnt_sets, cnt_mem, set_base, mem_base, total;
+};
+BatchLayout batch_layout(int32_t N, int64_t total_members, int32_t n_comp) {
+    BatchLayout L{};
+    L.G = greedy_layout(N, total_members);
+    size_t o = L.G.total;
+    const size_t n = (size_t)(N > 0 ? N : 1), c = (size_t)(n_comp > 0 ? n_comp : 1);
+    L.comp_of = o; o += align_up(n * 4);
+    L.ckey_in = o; o += align_up(n * 4);
+    L.ckey_out = o; o += align_up(n * 4);
+    L.order1 = o; o += align_up(n * 4);
+    L.stage_end = o; o += align_up(n * 4);
+    L.stage_mem = o; o += align_up(n * 4);
+    L.cnt_sets = o; o += align_up((c + 1) * 4);
+    L.cnt_mem = o; o += align_up((c + 1) * 4);
+    L.set_base = o; o += align_up((c + 1) * 4);
+    L.mem_base = o; o += align_up((c + 1) * 4);
+    L.total = o;
+    return L;
+}
+
+extern "C" size_t fitgnn_greedy_select_batch_workspace_bytes(int32_t N, int64_t total_members, int32_t n_comp) {
+    if (N < 0 || total_members < 0 || n_comp < 0) return 0;
+    return batch_layout(N, total_members, n_comp).total;
+}
+
+extern "C" int fitgnn_greedy_select_batch(const int32_t *rowptr, const int32_t *col, const double *w, const double *dw,
+                                          const double *A, int32_t K, int64_t lda, int32_t N, const int32_t *set_off,
+                                          const int32_t *set_mem, const double *cost0, int32_t n_comp,
+                                          const int32_t *comp_off, const int64_t *n_reduce, int64_t min_gain,
+                                          const int32_t *node_K, int32_t *sel_off, int32_t *sel_mem, int32_t *sel_count,
+                                          int64_t *comp_gain, void *work, size_t work_bytes, void *stream) {
+    if (N < 0 || n_comp < 0 || K < 1 || K > FITGNN_MAX_K || lda < K) return FITGNN_E_BADARG;
+    if (!sel_off || !sel_count) return FITGNN_E_BADARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (N == 0 || n_comp == 0) {
+        FITGNN_RETURN_IF_HIP(hipMemsetAsync(sel_off, 0, sizeof(int32_t), s));
+        return (int)hipMemsetAsync(sel_count, 0, 2 * sizeof(int32_t), s);
+    }
+    if (!rowptr || !col || !dw || !A || !set_off || !set_mem || !cost0 || !sel_mem || !work || !comp_off || !n_reduce ||
+        !comp_gain)
+        return FITGNN_E_BADARG;
+    int32_t total = 0;
+    FITGNN_RETURN_IF_HIP(hipMemcpyAsync(&total, set_off + N, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    FITGNN_RETURN_IF_HIP(hipStreamSynchronize(s));
+    const BatchLayout L = batch_layout(N, total, n_comp);
+    if (work_bytes < L.total) return FITGNN_E_WORKSPACE;
+    char *base = (char *)work;
+    int32_t *mem = (int32_t *)(base + L.G.mem);
+    int32_t *len = (int32_t *)(base + L.G.len);
+    uint8_t *marked = (uint8_t *)(base + L.G.marked);
+    uint64_t *keys_in = (uint64_t *)(base + L.G.keys_in), *keys_out = (uint64_t *)(base + L.G.keys_out);
+    int32_t *ids_in = (int32_t *)(base + L.G.ids_in), *order = (int32_t *)(base + L.G.order);
+    HeapItem *heap = (HeapItem *)(base + L.G.heap);
+    uint32_t *comp_of = (uint32_t *)(base + L.comp_of), *ckey_in = (uint32_t *)(base + L.ckey_in),
+             *ckey_out = (uint32_t *)(base + L.ckey_out);
+    int32_t *order1 = (int32_t *)(base + L.order1), *stage_end = (int32_t *)(base + L.stage_end),
+            *stage_mem = (int32_t *)(base + L.stage_mem), *cnt_sets = (int32_t *)(base + L.cnt_sets),
+            *cnt_mem = (int32_t *)(base + L.cnt_mem), *set_base = (int32_t *)(base + L.set_base),
+            *mem_base = (int32_t *)(base + L.mem_base);
+    FITGNN_RETURN_IF_HIP(hipMemcpyAsync(mem, set_mem, (size_t)total * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+    FITGNN_RETURN_IF_HIP(hipMemsetAsync(marked, 0, (size_t)N, s));
+    hipLaunchKernelGGL(len_init_kernel, blocks_for(N), dim3(256), 0, s, set_off, N, len);
+    hipLaunchKernelGGL(cost_keys_kernel, blocks_for(N), dim3(256), 0, s, cost0, N, keys_in, ids_in);
+    // candidates in (component, cost, node id) order: stable sort on the cost bits, then a stable sort on the
+    // component id (the 64-bit sort's temporary storage is large enough for the 32-bit one)
+    size_t tmp = L.G.sort_tmp_bytes;
+    FITGNN_RETURN_IF_HIP(rocprim::radix_sort_pairs((void *)(base + L.G.sort_tmp), tmp, keys_in, keys_out, ids_in, order1,
+                                                   (size_t)N, 0, 64, s));
+    hipLaunchKernelGGL(comp_of_kernel, dim3(n_comp), dim3(64), 0, s, n_comp, comp_off, comp_of);
+    hipLaunchKernelGGL(gather_u32_kernel, blocks_for(N), dim3(256), 0, s, comp_of, order1, N, ckey_in);
+    int bits = 1;
+    while ((1ll << bits) < (long long)n_comp) ++bits;
+    size_t tmp2 = 0;
+    (void)rocprim::radix_sort_pairs(nullptr, tmp2, ckey_in, ckey_out, order1, order, (size_t)N, 0, bits, s);
+    if (tmp2 > L.G.sort_tmp_bytes) return FITGNN_E_WORKSPACE;
+    FITGNN_RETURN_IF_HIP(rocprim::radix_sort_pairs((void *)(base + L.G.sort_tmp), tmp2, ckey_in, ckey_out, order1, order, (size_t)N,
+                                                   0, bits, s));
+    CostGraph g{rowptr, col, w, dw, A, K, lda, node_K};
+    hipLaunchKernelGGL(greedy_select_batch_kernel, dim3(n_comp), dim3(64), 0, s, g, N, n_comp, comp_off, set_off, mem, len, marked,
+                       order, cost0, heap, n_reduce, stage_end, stage_mem, cnt_sets, cnt_mem, comp_gain);
+    hipLaunchKernelGGL(batch_keep_kernel, blocks_for(n_comp), dim3(256), 0, s, n_comp, comp_gain, min_gain, cnt_sets, cnt_mem);
+    fitgnn::exclusive_scan_i32(cnt_sets, set_base, n_comp, s);
+    fitgnn::exclusive_scan_i32(cnt_mem, mem_base, n_comp, s);
+    hipLaunchKernelGGL(batch_compact_kernel, dim3(n_comp), dim3(64), 0, s, n_comp, comp_off, cnt_sets, cnt_mem, set_base, mem_base,
+                       stage_end, stage_mem, sel_off, sel_mem, sel_count);
     return (int)hipGetLastError();
 }
 

@@ -47,6 +47,8 @@ struct CostGraph {
     const double *A;
     int32_t K;
     int64_t lda;
+    const int32_t *node_K;  // optional: per-node column count (block-diagonal batches whose components have
+                            // fewer than K spectral columns: a component of N <= K nodes has N, coarsening_utils.py:85-86)
 };
 
 // first index in sorted a[0..n) with a[i] >= v
@@ -65,7 +67,7 @@ __device__ inline double set_cost_wave(const CostGraph &g, const int32_t *__rest
 #pragma clang fp contract(off)
     if (nc < 2) return INFINITY;
     const int lane = threadIdx.x & 63;
-    const int K = g.K;
+    const int K = g.node_K ? __builtin_amdgcn_readfirstlane(g.node_K[S[0]]) : g.K;
     const int KK = K * K;
     const bool small = nc <= kCostTile;  // whole set resident in LDS
 

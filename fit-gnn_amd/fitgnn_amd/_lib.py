@@ -45,9 +45,13 @@ SIGNATURES = {
     "fitgnn_csr_row_sum_f32": (ctypes.c_int, [ptr, ptr, c_i32, ptr, ptr]),
     "fitgnn_closed_neighbourhoods": (ctypes.c_int, [ptr, ptr, c_i32, ptr, ptr, ptr]),
     "fitgnn_variation_costs_f64": (ctypes.c_int, [ptr, ptr, ptr, ptr, ptr, c_i32, c_i64, ptr, ptr, ptr, c_i32, ptr, ptr]),
+    "fitgnn_variation_costs_batch_f64": (ctypes.c_int, [ptr, ptr, ptr, ptr, ptr, c_i32, c_i64, ptr, ptr, ptr, ptr, c_i32, ptr, ptr]),
     "fitgnn_greedy_select_workspace_bytes": (c_size, [c_i32, c_i64]),
     "fitgnn_greedy_select": (ctypes.c_int, [ptr, ptr, ptr, ptr, ptr, c_i32, c_i64, c_i32, ptr, ptr, ptr, c_i64, ptr, ptr,
                                             ptr, ptr, c_size, ptr]),
+    "fitgnn_greedy_select_batch_workspace_bytes": (c_size, [c_i32, c_i64, c_i32]),
+    "fitgnn_greedy_select_batch": (ctypes.c_int, [ptr, ptr, ptr, ptr, ptr, c_i32, c_i64, c_i32, ptr, ptr, ptr, c_i32, ptr, ptr,
+                                                  c_i64, ptr, ptr, ptr, ptr, ptr, ptr, c_size, ptr]),
     "fitgnn_build_assignment_workspace_bytes": (c_size, [c_i32]),
     "fitgnn_build_assignment": (ctypes.c_int, [c_i32, ptr, ptr, ptr, ptr, ptr, ptr, ptr, c_size, ptr]),
     "fitgnn_compose_levels": (ctypes.c_int, [c_i32, ptr, ptr, ptr, ptr, ptr]),

@@ -315,3 +315,171 @@ def coarsen(G, K=10, r=0.5, max_levels=10, method="variation_neighborhood", algo
     a = assign_tot.cpu().numpy()
     C = CoarseningMatrix(sp.csc_matrix((cval_tot.cpu().numpy(), (a, np.arange(N))), shape=(int(a.max()) + 1 if N else 0, N)))
     return C, Gc, mapping_dict_list
+
+
+# ---------------------------------------------------------------------------------------------
+# many graphs at once: the reference's per-component / per-dataset-graph Python loop as one batch
+# ---------------------------------------------------------------------------------------------
+class BatchCoarsening:
+    """Result of coarsen_batch: `assign` int64[N] (global cluster id of every node; a component's clusters are a
+    contiguous id range in ascending order of their minimum member, i.e. per-component id = assign - cluster_off[c]),
+    `cval` float64[N] (the non-zero of C in that node's column), `comp_off` / `cluster_off` int64[n_comp+1],
+    `Wc` scipy csr (block-diagonal coarse adjacency, global cluster ids), `levels` per-component level count."""
+    __slots__ = ("assign", "cval", "comp_off", "cluster_off", "Wc", "levels", "n_clusters", "_dev")
+
+    def C(self):
+        N = len(self.assign)
+        return CoarseningMatrix(sp.csc_matrix((self.cval, (self.assign, np.arange(N))), shape=(self.n_clusters, N)))
+
+    def pool(self, X):
+        """C . X for every component at once (device tensor in / out)."""
+        a, c = self._dev
+        return pool_rows(a.to(X.device), c.to(X.device), self.n_clusters, X)
+
+
+def _dense_prelude(W, b, e, K):
+    """Level-1 spectral input of one small component from a dense symmetric eigendecomposition (all eigenpairs,
+    smallest K kept) -- same formula as coarsening_utils.py:89-96, exact eigenvectors instead of ARPACK's tol=1e-5."""
+    Wd = W[b:e, b:e].toarray()
+    Ld = np.diag(Wd.sum(0)) - Wd
+    lk, Uk = np.linalg.eigh(Ld)
+    k = min(K, e - b)
+    lk, Uk = lk[:k].copy(), Uk[:, :k]
+    mask = lk < 1e-10
+    lk[mask] = 1
+    lsinv = lk ** (-0.5)
+    lsinv[mask] = 0
+    return Uk @ np.diag(lsinv)
+
+
+def coarsen_batch(W, comp_off, r=0.5, K=10, max_levels=10, A0=None, max_level_r=0.99, device="cuda", spectral="arpack"):
+    """coarsen() (coarsening_utils.py:18-182, method variation_neighborhoods) applied independently to every connected
+    component of the block-diagonal adjacency W (scipy sparse [N x N]); component c = node range
+    comp_off[c]:comp_off[c+1] and must be connected.  Per level ONE launch each of the family, cost, selection (one
+    wavefront per component), assignment and lift kernels covers all components; a component leaves the loop exactly
+    when the reference's driver would (target reached :180, or a level that removes <= 2 nodes :131-135, which is not
+    applied).  The spectral prelude stays on the host per component (level 1: ARPACK as the reference, or
+    spectral='dense'; later levels: the K x K eigenproblem of :98-104).  A0: optional list of per-component level-1
+    matrices A (n_c x K_c), e.g. from injected (Uk, lk).  Returns BatchCoarsening."""
+    L = _lib.lib()
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        raise _lib.FitgnnError("coarsen_batch needs the MI355X (no CPU fallback)")
+    st = _lib.stream_ptr(dev)
+    W = sp.csr_matrix(W).astype(np.float64)
+    W.sort_indices()
+    comp_off = np.asarray(comp_off, dtype=np.int64)
+    n_comp, N0 = len(comp_off) - 1, int(comp_off[-1])
+    assert W.shape == (N0, N0)
+    r = float(np.clip(r, 0, 0.999))
+    size0 = np.diff(comp_off)
+    n_cur = size0.copy()
+    n_target = np.ceil((1 - r) * size0)
+    active = size0 > 1
+    levels = np.zeros(n_comp, dtype=np.int64)
+    assign_tot = torch.arange(N0, dtype=torch.int32, device=dev)
+    cval_tot = torch.ones(N0, dtype=torch.float64, device=dev)
+    B = None            # pooled spectral basis [N_level x Kmax], rows of inactive components are not used
+    node_K = None
+    iC = None
+    off = comp_off.copy()
+    G = Graph(W)
+    for level in range(1, max_levels + 1):
+        if not active.any():
+            break
+        N = G.N
+        r_cur = np.clip(1 - n_target / np.maximum(n_cur, 1), 0.0, max_level_r)
+        n_reduce = np.where(active, np.floor(r_cur * n_cur), 0).astype(np.int64)  # :612 per component
+        if level == 1:
+            Kc = np.where(size0 <= K, size0, K).astype(np.int32)  # eigsh(dense, k=K >= N) returns N pairs (:85-86)
+            Kmax = int(max(K, Kc.max()))
+            A = np.zeros((N, Kmax))
+            for c in np.nonzero(active)[0]:
+                b, e = int(off[c]), int(off[c + 1])
+                if A0 is not None and A0[c] is not None:
+                    Ac = np.asarray(A0[c], dtype=np.float64)
+                elif spectral == "dense":
+                    Ac = _dense_prelude(W, b, e, K)
+                else:
+                    Ac = _spectral_level1(Graph(W[b:e, b:e]), K, None, None)
+                Kc[c] = Ac.shape[1]
+                A[b:e, :Ac.shape[1]] = np.real(Ac)
+            node_K_comp = Kc
+            B = A
+        else:
+            B = iC.dot(B)                      # :97, all components at once (rows are independent)
+            LB = G.L.dot(B)
+            A = np.zeros_like(B)
+            for c in np.nonzero(active)[0]:    # :98-104, K x K per component
+                b, e, k = int(off[c]), int(off[c + 1]), int(node_K_comp[c])
+                Bc = B[b:e, :k]
+                d, V = np.linalg.eig(Bc.T @ LB[b:e, :k])
+                mask = d == 0
+                d[mask] = 1
+                dinvsqrt = d ** (-1 / 2)
+                dinvsqrt[mask] = 0
+                A[b:e, :k] = np.real(Bc @ np.diag(dinvsqrt) @ V)
+        node_K = np.repeat(node_K_comp, np.diff(off)).astype(np.int32)
+        # ---- device: family, costs, per-component selection, assignment ----
+        Wl = G.W
+        rowptr, col = _dev(Wl.indptr, torch.int32, dev), _dev(Wl.indices, torch.int32, dev)
+        w, dw = _dev(Wl.data, torch.float64, dev), _dev(G.dw, torch.float64, dev)
+        Ad, nK = _dev(A, torch.float64, dev), _dev(node_K, torch.int32, dev)
+        lda = int(A.shape[1])
+        nnz = int(Wl.nnz)
+        set_off = torch.empty(N + 1, dtype=torch.int32, device=dev)
+        set_mem = torch.empty(nnz + N, dtype=torch.int32, device=dev)
+        _lib.check(L.fitgnn_closed_neighbourhoods(_lib.dptr(rowptr), _lib.dptr(col), N, _lib.dptr(set_off), _lib.dptr(set_mem), st),
+                   "closed_neighbourhoods")
+        set_len = (set_off[1:] - set_off[:-1]).contiguous()
+        cost0 = torch.empty(N, dtype=torch.float64, device=dev)
+        _lib.check(L.fitgnn_variation_costs_batch_f64(_lib.dptr(rowptr), _lib.dptr(col), _lib.dptr(w), _lib.dptr(dw), _lib.dptr(Ad),
+                                                      lda, lda, _lib.dptr(nK), _lib.dptr(set_off), _lib.dptr(set_len),
+                                                      _lib.dptr(set_mem), N, _lib.dptr(cost0), st), "variation_costs_batch")
+        wb = int(L.fitgnn_greedy_select_batch_workspace_bytes(N, nnz + N, n_comp))
+        work = torch.empty(wb, dtype=torch.uint8, device=dev)
+        sel_off = torch.empty(N + 1, dtype=torch.int32, device=dev)
+        sel_mem = torch.empty(max(N, 1), dtype=torch.int32, device=dev)
+        sel_count = torch.zeros(2, dtype=torch.int32, device=dev)
+        gain_d = torch.zeros(n_comp, dtype=torch.int64, device=dev)
+        off_d, n_reduce_d = _dev(off, torch.int32, dev), _dev(n_reduce, torch.int64, dev)  # named: they must outlive the call
+        _lib.check(L.fitgnn_greedy_select_batch(_lib.dptr(rowptr), _lib.dptr(col), _lib.dptr(w), _lib.dptr(dw), _lib.dptr(Ad), lda,
+                                                lda, N, _lib.dptr(set_off), _lib.dptr(set_mem), _lib.dptr(cost0), n_comp,
+                                                _lib.dptr(off_d), _lib.dptr(n_reduce_d),
+                                                2, _lib.dptr(nK), _lib.dptr(sel_off), _lib.dptr(sel_mem), _lib.dptr(sel_count),
+                                                _lib.dptr(gain_d), _lib.dptr(work), wb, st), "greedy_select_batch")
+        assign = torch.empty(N, dtype=torch.int32, device=dev)
+        cval = torch.empty(N, dtype=torch.float64, device=dev)
+        n_out = torch.zeros(1, dtype=torch.int32, device=dev)
+        wb2 = int(L.fitgnn_build_assignment_workspace_bytes(N))
+        work2 = torch.empty(wb2, dtype=torch.uint8, device=dev)
+        _lib.check(L.fitgnn_build_assignment(N, _lib.dptr(sel_off), _lib.dptr(sel_mem), _lib.dptr(sel_count), _lib.dptr(assign),
+                                             _lib.dptr(cval), _lib.dptr(n_out), _lib.dptr(work2), wb2, st), "build_assignment")
+        gain = gain_d.cpu().numpy()
+        applied = active & (gain > 2)          # :131-135: a level removing <= 2 nodes is not applied and ends the loop
+        levels[applied] += 1
+        active = applied.copy()
+        if not applied.any():
+            break
+        _lib.check(L.fitgnn_compose_levels(N0, _lib.dptr(assign), _lib.dptr(cval), _lib.dptr(assign_tot), _lib.dptr(cval_tot), st),
+                   "compose_levels")
+        res = LevelResult()
+        res.N, res.n, res.assign, res.cval, res.device = N, int(n_out.item()), assign, cval, dev
+        res.rowptr, res.col, res.w = rowptr, col, w
+        Wc = lift_adjacency(res)
+        assign_h = assign.cpu().numpy()
+        iC = sp.csc_matrix((cval.cpu().numpy(), (assign_h, np.arange(N))), shape=(res.n, N))
+        n_cur = np.where(applied, n_cur - gain, n_cur)
+        new_off = np.zeros(n_comp + 1, dtype=np.int64)
+        np.cumsum(n_cur, out=new_off[1:])
+        assert int(new_off[-1]) == res.n, (level, int(new_off[-1]), res.n, gain.tolist(), n_reduce.tolist(), sel_count.cpu().tolist())
+        off = new_off
+        G = Graph(Wc)
+        active &= n_cur > n_target             # :180
+    out = BatchCoarsening()
+    out.assign = assign_tot.cpu().numpy().astype(np.int64)
+    out.cval = cval_tot.cpu().numpy()
+    out.comp_off, out.cluster_off, out.Wc, out.levels = comp_off, off, G.W, levels
+    out.n_clusters = int(off[-1])
+    out._dev = (assign_tot, cval_tot)
+    return out

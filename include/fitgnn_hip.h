@@ -185,6 +185,14 @@ int fitgnn_variation_costs_f64(const int32_t *rowptr, const int32_t *col, const 
                                const int32_t *set_len, const int32_t *set_mem, int32_t n_sets, double *cost,
                                void *stream);
 
+/* The same over a block-diagonal batch whose components carry different numbers of spectral columns: node_K
+ * int32[N] gives, per node, the K of its component (a component of N_c <= K nodes has N_c columns,
+ * coarsening_utils.py:85-86); A is stored with the common leading dimension lda >= max K.  node_K == NULL: uniform K. */
+int fitgnn_variation_costs_batch_f64(const int32_t *rowptr, const int32_t *col, const double *w, const double *dw,
+                                     const double *A, int32_t K, int64_t lda, const int32_t *node_K,
+                                     const int32_t *set_off, const int32_t *set_len, const int32_t *set_mem,
+                                     int32_t n_sets, double *cost, void *stream);
+
 /* Greedy minimum-cost disjoint selection (coarsening_utils.py:604-650) run entirely on the device:
  * candidates are visited in (cost, insertion order) order -- sortedcontainers.SortedList semantics --,
  * sets with marked members are filtered, re-costed with the same arithmetic as above and re-inserted.
@@ -197,6 +205,23 @@ int fitgnn_greedy_select(const int32_t *rowptr, const int32_t *col, const double
                          const double *A, int32_t K, int64_t lda, int32_t N, const int32_t *set_off,
                          const int32_t *set_mem, const double *cost0, int64_t n_reduce, int32_t *sel_off,
                          int32_t *sel_mem, int32_t *sel_count, void *work, size_t work_bytes, void *stream);
+
+/* The same selection run independently on every connected component of a block-diagonal graph (one wavefront per
+ * component; components are the contiguous node ranges [comp_off[c], comp_off[c+1]), n_comp of them).  This is the
+ * reference's per-component / per-dataset-graph loop (utils.py:154-159, utils.py:386-391, main.py:370) as ONE launch:
+ * 130 831 QM9 molecules, or the components of a node-level dataset.  n_reduce[c] = floor(r_cur_c * N_c) per component
+ * (0 = leave the component alone).  Components whose selection would remove <= min_gain nodes are dropped from the
+ * output (coarsening_utils.py:131-135 breaks before applying a level that removes <= 2 nodes: pass min_gain = 2);
+ * comp_gain[c] reports the nodes removed BEFORE that filter.  Output: one combined list of sets in the format of
+ * fitgnn_greedy_select (node ids are those of the whole graph), ready for fitgnn_build_assignment.  node_K as in
+ * fitgnn_variation_costs_batch_f64 (may be NULL). */
+size_t fitgnn_greedy_select_batch_workspace_bytes(int32_t N, int64_t total_members, int32_t n_comp);
+int fitgnn_greedy_select_batch(const int32_t *rowptr, const int32_t *col, const double *w, const double *dw,
+                               const double *A, int32_t K, int64_t lda, int32_t N, const int32_t *set_off,
+                               const int32_t *set_mem, const double *cost0, int32_t n_comp, const int32_t *comp_off,
+                               const int64_t *n_reduce, int64_t min_gain, const int32_t *node_K, int32_t *sel_off,
+                               int32_t *sel_mem, int32_t *sel_count, int64_t *comp_gain, void *work, size_t work_bytes,
+                               void *stream);
 
 /* get_coarsening_matrix (:212-254) and the level mapping (:168-179) as vectors:
  *   assign[i] = row of C holding column i = rank of the cluster's minimum member among surviving rows,

@@ -142,3 +142,33 @@ def test_pool_ragged_feature_width_and_large(mods):
                                     torch.from_numpy(X).cuda(), want_f64=True)
         assert np.array_equal(got32.cpu().numpy(), x32)
         assert np.array_equal(_bits(got64.cpu().numpy()), _bits(x64))
+
+
+@pytest.mark.parametrize("r", [0.3, 0.5, 0.7, 0.9])
+def test_batched_coarsening_equals_the_reference_per_component(mods, r):
+    """coarsen_batch on the block-diagonal union of ALL golden graphs (one wavefront per component, components
+    leaving the level loop at different levels) == the real reference's per-graph C, Gc.W and C.X."""
+    _lib, co, orc = mods
+    names = [n for n in graph_names() if (n, r) in CASES]
+    gs = [G(n) for n in names]
+    W = sp.block_diag([g.W for g in gs], format="csr")
+    comp_off = np.concatenate([[0], np.cumsum([g.N for g in gs])])
+    out = co.coarsen_batch(W, comp_off, r=r, K=10, A0=[g.A0() for g in gs])
+    Cb = sp.csc_matrix(out.C())
+    X = np.concatenate([g.X for g in gs])
+    Xc = out.pool(torch.from_numpy(X).cuda()).cpu().numpy()
+    for c, (g, name) in enumerate(zip(gs, names)):
+        fin = g.final(r)
+        b, e = int(comp_off[c]), int(comp_off[c + 1])
+        cb, ce = int(out.cluster_off[c]), int(out.cluster_off[c + 1])
+        assert ce - cb == fin["C"].shape[0], (name, ce - cb, fin["C"].shape)
+        assert np.array_equal(out.assign[b:e] - cb, fin["assign"]), name
+        assert np.array_equal(out.cval[b:e], fin["C"].data), name
+        Wc = out.Wc[cb:ce, cb:ce].tocsr()
+        if fin["GcW"].shape[0] != g.N:
+            assert np.array_equal(Wc.indptr, fin["GcW"].indptr) and np.array_equal(Wc.indices, fin["GcW"].indices), name
+            assert np.array_equal(Wc.data, fin["GcW"].data), name
+        assert np.array_equal(Xc[cb:ce], fin["CX64"].astype(np.float32)), name
+    assert out.Wc[:, :].nnz == sum(out.Wc[int(out.cluster_off[c]):int(out.cluster_off[c + 1]),
+                                          int(out.cluster_off[c]):int(out.cluster_off[c + 1])].nnz for c in range(len(gs)))
+    assert Cb.shape == (out.n_clusters, W.shape[0])
