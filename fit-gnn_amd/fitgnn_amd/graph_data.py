@@ -1,0 +1,118 @@
+"""Graph-level datasets (QM9-shaped: many small graphs) as flat device-resident arrays.
+
+The reference walks the dataset graph by graph in Python (main.py:370): coarsening_regression (utils.py:376-534: components,
+coarsen, per-cluster subgraphs) then load_graph_data (utils.py:811-852: Gc = pooled features + coarse edges), and its
+graph-level models loop over every subgraph of every graph of a batch (network.py:120-130, :189-204).  Here the whole
+dataset is ONE block-diagonal graph: one batched contraction (coarsening.coarsen_batch), one subgraph assembly
+(data.assemble_subgraphs_torch) and one pooling launch build, for all graphs at once,
+    Gs : the union of all cluster subgraphs, rows ordered by (graph, cluster, node id), with the reference's row mask
+    Gc : pooled features C.X, coarse edges, cluster -> graph vector
+and a training batch is a contiguous range of graphs of a fixed (seeded) order.
+"""
+import numpy as np
+import scipy.sparse as sp
+import torch
+
+from . import coarsening
+from . import data as fdata
+from .csr import CSRGraph, register
+
+
+def synthetic_molecules(n_graphs, seed=0, n_features=11, n_targets=19):
+    """QM9-shaped stand-in: node count ~ round(N(18, 3^2)) clipped to [3, 29]; a ring plus random
+    chords up to ~18.7 undirected edges on average (connected); F = 11 features, 19 float targets that are smooth
+    functions of the graph (size, chord count, mean feature) so that regression is learnable."""
+    rng = np.random.default_rng(seed)
+    n = np.clip(np.rint(rng.normal(18, 3, size=n_graphs)), 3, 29).astype(np.int64)
+    node_ptr = np.zeros(n_graphs + 1, dtype=np.int64)
+    np.cumsum(n, out=node_ptr[1:])
+    src, dst = [], []
+    chords = np.zeros(n_graphs)
+    for g in range(n_graphs):
+        k, o = int(n[g]), int(node_ptr[g])
+        ring = np.arange(k)
+        und = {(min(a, b), max(a, b)) for a, b in zip(ring, np.roll(ring, -1)) if a != b}
+        want = max(len(und), int(round(k * 18.7 / 18)))
+        tries = 0
+        while len(und) < want and tries < 8 * want:
+            a, b = rng.integers(0, k, size=2)
+            tries += 1
+            if a != b:
+                und.add((min(a, b), max(a, b)))
+        chords[g] = len(und) - k
+        u = np.array(sorted(und), dtype=np.int64) + o
+        src += [u[:, 0], u[:, 1]]
+        dst += [u[:, 1], u[:, 0]]
+    ei = np.stack([np.concatenate(src), np.concatenate(dst)])
+    ei = ei[:, np.lexsort((ei[1], ei[0]))]
+    N = int(node_ptr[-1])
+    x = rng.random((N, n_features), dtype=np.float32)
+    gid = np.repeat(np.arange(n_graphs), n)
+    mean_x = np.zeros((n_graphs, n_features)); np.add.at(mean_x, gid, x); mean_x /= n[:, None]
+    base = np.stack([n / 18.0, chords / 3.0, mean_x[:, 0], mean_x[:, 1]], 1)
+    mix = rng.standard_normal((4, n_targets))
+    # QM9-like magnitudes (units to tens): the reference casts targets to long (run.py:260,:294), so sub-unit targets
+    # would all truncate to 0
+    y = (8.0 * (base @ mix) + 0.2 * rng.standard_normal((n_graphs, n_targets))).astype(np.float32)
+    return dict(node_ptr=node_ptr, edge_index=ei, x=x, y=y)
+
+
+class GraphSet:
+    """All graphs of a graph-level dataset, coarsened and assembled once, resident on the device.
+
+    Rows of a graph are contiguous everywhere: original nodes node_ptr, clusters cluster_ptr (Gc rows), Gs union
+    rows gs_ptr.  `gs_mask` is the reference's row mask M.mask (utils.py:498-503): with --extra_node it marks the
+    FIRST k rows of each sorted subgraph, k = number of own nodes -- not the own nodes themselves (SURVEY §8 a12
+    quirk iii); `gs_core` marks the true own nodes.  network.*_graph_gs pools x[mask] per graph."""
+
+    def __init__(self, mol, ratio=0.5, extra_node=False, device="cuda", spectral="dense", reference_mask=True):
+        dev = torch.device(device)
+        node_ptr, ei = np.asarray(mol["node_ptr"]), np.asarray(mol["edge_index"])
+        N, G = int(node_ptr[-1]), len(node_ptr) - 1
+        self.n_graphs, self.node_ptr = G, node_ptr
+        W = sp.csr_matrix((np.ones(ei.shape[1]), (ei[0], ei[1])), shape=(N, N))
+        # main.py:370-377 passes Loukas r = 1 - coarsening_ratio; every graph is one connected component here
+        self.co = coarsening.coarsen_batch(W, node_ptr, r=1 - ratio, device=dev, spectral=spectral)
+        co = self.co
+        self.cluster_ptr = np.asarray(co.cluster_off)
+        n = co.n_clusters
+        self.x = torch.as_tensor(mol["x"]).to(dev).float()
+        self.y = torch.as_tensor(mol["y"]).to(dev).float()
+        # ---- Gc (load_graph_data, utils.py:811-852) ----
+        self.gc_x = co.pool(self.x)
+        coo = co.Wc.tocoo()
+        self.gc_edge_index = torch.from_numpy(np.stack([coo.row, coo.col]).astype(np.int64)).to(dev)
+        self.gc_graph = torch.from_numpy(np.repeat(np.arange(G), np.diff(self.cluster_ptr))).to(dev)
+        # ---- Gs (utils.py:417-534), all clusters of all graphs at once ----
+        sub = fdata.assemble_subgraphs_torch(torch.from_numpy(ei).to(dev), N, co.assign, n, extra_node=extra_node)
+        self.sub_ptr = sub["ptr"].cpu().numpy()                       # union rows of every cluster subgraph
+        self.gs_node = sub["node_id"]
+        self.gs_core = sub["core"]
+        self.gs_edge_index = sub["edge_index"]
+        self.gs_x = self.x[self.gs_node].contiguous()
+        R = int(self.sub_ptr[-1])
+        sub_of_row = torch.repeat_interleave(torch.arange(n, device=dev), torch.from_numpy(np.diff(self.sub_ptr)).to(dev))
+        n_core = torch.zeros(n, dtype=torch.int64, device=dev).index_add_(0, sub_of_row, self.gs_core.long())
+        pos_in_sub = torch.arange(R, device=dev) - torch.from_numpy(self.sub_ptr[:-1]).to(dev)[sub_of_row]
+        self.gs_mask = (pos_in_sub < n_core[sub_of_row]) if reference_mask else self.gs_core.clone()
+        self.gs_graph = self.gc_graph[sub_of_row]                     # graph of every union row
+        self.gs_ptr = self.sub_ptr[self.cluster_ptr]                  # union rows of every graph
+
+    # ---- batches: contiguous graph ranges ------------------------------------------------------------------
+    def batch(self, g0, g1, kind):
+        """Graphs g0:g1 as one block-diagonal piece: dict(x, edge_index, graph (0-based), mask, y, n_graphs) for
+        kind 'gs' (subgraph union) or 'gc' (coarse graphs).  The piece's CSR is built and registered once."""
+        dev = self.x.device
+        if kind == "gs":
+            r0, r1 = int(self.gs_ptr[g0]), int(self.gs_ptr[g1])
+            x, graph, mask, ei, ptr = self.gs_x[r0:r1], self.gs_graph[r0:r1] - g0, self.gs_mask[r0:r1], self.gs_edge_index, self.sub_ptr
+            blocks = ptr[(ptr >= r0) & (ptr <= r1)] - r0
+        else:
+            r0, r1 = int(self.cluster_ptr[g0]), int(self.cluster_ptr[g1])
+            x, graph, mask, ei = self.gc_x[r0:r1], self.gc_graph[r0:r1] - g0, None, self.gc_edge_index
+            blocks = self.cluster_ptr[g0:g1 + 1] - r0
+        sel = (ei[0] >= r0) & (ei[0] < r1)
+        e = (ei[:, sel] - r0).contiguous()
+        if dev.type == "cuda" and r1 > r0:
+            register(e, CSRGraph(e, r1 - r0, mode="gcn", ptr=blocks), "gcn")
+        return dict(x=x, edge_index=e, graph=graph, mask=mask, y=self.y[g0:g1], n_graphs=g1 - g0)

@@ -150,9 +150,17 @@ def _merge_subgraphs(set_gs, device):
     return torch.cat(xs, 0), torch.cat(eis, 1), torch.cat(masks, 0)
 
 
+def _gs_inputs(set_gs, batch_tensor):
+    """Reference form (list of per-graph lists of subgraph Data, network.py:120-130) or the pre-merged union a
+    fitgnn_amd.graph_data.GraphSet batch carries (dict with x, edge_index, mask)."""
+    if isinstance(set_gs, dict):
+        return set_gs["x"], set_gs["edge_index"], set_gs["mask"]
+    return _merge_subgraphs(set_gs, batch_tensor.device)
+
+
 class Classify_graph_gs(_Base):
     def forward(self, set_gs, batch_tensor):
-        x, ei, mask = _merge_subgraphs(set_gs, batch_tensor.device)
+        x, ei, mask = _gs_inputs(set_gs, batch_tensor)
         x = self.embed(x, ei)[mask]
         x = self.head(fnn.global_max_pool(x, batch_tensor.to(torch.int64)))
         return F.softmax(x, dim=0 if x.dim() == 1 else 1)
@@ -162,6 +170,6 @@ class Regress_graph_gs(_Base):
     out_dim_from_classes = False
 
     def forward(self, set_gs, batch_tensor):
-        x, ei, mask = _merge_subgraphs(set_gs, batch_tensor.device)
+        x, ei, mask = _gs_inputs(set_gs, batch_tensor)
         x = self.embed(x, ei)[mask]
         return self.head(fnn.global_mean_pool(x, batch_tensor.to(torch.int64)))

@@ -380,3 +380,68 @@ def node_classification_baseline(args, path, data, device="cuda", log=print):
         log(f"run {run + 1}: test_loss {tloss:.4f} test_acc {tacc:.4f} infer_time {dt * 1e3:.2f} ms")
         all_loss.append(tloss); all_acc.append(tacc); all_time.append(dt)
     return all_loss, all_acc, all_time
+
+
+def graph_regression(args, path, mol, device="cuda", log=print):
+    """run.graph_regression (run.py:707-830) on a graph_data.GraphSet: 50/25/25 split of a random permutation
+    (utils.py:23-39), Regress_graph_gc / Regress_graph_gs, L1 loss, the four exp_setups, best-val checkpoint, and the
+    reference's results row.  Returns best_test_loss."""
+    from . import graph_data
+    from .train import GraphTrainer
+
+    if args.cluster_node:
+        raise NotImplementedError("--cluster_node subgraphs for graph-level tasks are not built (node-level only)")
+    gset = graph_data.GraphSet(mol, ratio=args.coarsening_ratio, extra_node=bool(args.extra_node), device=device)
+    G = gset.n_graphs
+    gen = torch.Generator().manual_seed(0 if args.seed is None else args.seed)
+    idx = torch.randperm(G, generator=gen).tolist()
+    split = {"train": idx[: G // 2], "val": idx[G // 2: 3 * G // 4], "test": idx[3 * G // 4:]}
+    args.num_classes = 1
+    model_gc, model_gs = network.Regress_graph_gc(args).to(device), network.Regress_graph_gs(args).to(device)
+    kw = dict(batch_size=args.batch_size, lr=args.lr, weight_decay=args.weight_decay, multi_prop=bool(args.multi_prop),
+              prop=args.property)
+    T = {(m, s): GraphTrainer(model_gc if m == "gc" else model_gs, gset, split[s], kind=m, **kw)
+         for m in ("gc", "gs") for s in ("train", "val", "test")}
+    # one optimiser per model across all phases (run.py:718-719)
+    for m in ("gc", "gs"):
+        for s in ("val", "test"):
+            T[(m, s)].opt, T[(m, s)].flat = T[(m, "train")].opt, T[(m, "train")].flat
+    ckpt = os.path.join(path, "model.pt")
+    best_val, best_test = float("inf"), float("inf")
+    setup = args.exp_setup
+
+    def consider(epoch, val, test, model):
+        nonlocal best_val, best_test
+        if val < best_val or epoch == 0:
+            best_val, best_test = val, test
+            torch.save(model.state_dict(), ckpt)
+
+    if setup in ("Gc_train_2_Gs_train", "Gc_train_2_Gc_infer", "Gc_train_2_Gs_infer"):
+        for epoch in range(args.epochs1):
+            T[("gc", "train")].step()
+            v = float(T[("gc", "val")].evaluate())
+            if setup == "Gc_train_2_Gc_infer":
+                consider(epoch, v, float(T[("gc", "test")].evaluate()), model_gc)
+            elif setup == "Gc_train_2_Gs_infer":   # the Gs model is never loaded with the Gc weights here (run.py:769-784)
+                consider(epoch, v, float(T[("gs", "test")].evaluate()), model_gc)
+            else:
+                consider(epoch, v, float("inf"), model_gc)
+    if setup == "Gc_train_2_Gs_train":
+        model_gs.load_state_dict(torch.load(ckpt))
+        best_val = float("inf")
+    if setup in ("Gc_train_2_Gs_train", "Gs_train_2_Gs_infer"):
+        for epoch in range(args.epochs2):
+            T[("gs", "train")].step()
+            consider(epoch, float(T[("gs", "val")].evaluate()), float(T[("gs", "test")].evaluate()), model_gs)
+    os.makedirs("results", exist_ok=True)
+    fn = f"results/{args.dataset}.csv"
+    if not os.path.exists(fn):
+        with open(fn, "w") as f:
+            f.write("dataset,coarsening_method,coarsening_ratio,exp_setup,layer_name,extra_nodes,cluster_node,community_used,hidden,"
+                    "num_layers1,num_layers2,epochs1,epochs2,batch_size,lr,best_test_loss" + (",property_idx}" if args.multi_prop else "") + "\n")
+    with open(fn, "a") as f:
+        f.write(f"{args.dataset},{args.coarsening_method},{args.coarsening_ratio},{args.exp_setup},{args.layer_name},{args.extra_node},"
+                f"{args.cluster_node},{args.use_community_detection},{args.hidden},{args.num_layers1},{args.num_layers2},{args.epochs1},"
+                f"{args.epochs2},{args.batch_size},{args.lr},{best_test}" + (f",{args.property}" if args.multi_prop else "") + "\n")
+    log(f"best_test_loss: {best_test}")
+    return best_test

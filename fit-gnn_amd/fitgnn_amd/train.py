@@ -115,3 +115,106 @@ class MBTrainer:
             self.opt.step()
             total += loss.detach()
         return total / (self.n_loader_batches if self.reduction == "mean" else max(self.n_train, 1))
+
+
+class GraphTrainer:
+    """graph_train_Gs / graph_train_Gc (run.py:254-269, :288-304) on a fitgnn_amd.graph_data.GraphSet.
+
+    Per epoch ONE zero_grad, then per batch of `batch_size` graphs: forward, loss, backward, optimiser step -- the
+    gradients are never cleared between batches (quirk i), and regression targets go through `.type(torch.long)`
+    (run.py:260,:294: values are truncated toward zero; quirk ii) -- both reproduced.  Batches are contiguous ranges
+    of `order` (a fixed permutation of the split's graphs; the reference reshuffles its loader every epoch, here the
+    order is drawn once so that every batch's CSR is built once and stays resident).
+    kind 'gs': model(set_gs, batch_tensor) pools the masked rows of the subgraph union; kind 'gc': model(gc)."""
+
+    def __init__(self, model, gset, graphs, kind="gs", batch_size=128, lr=0.01, weight_decay=5e-4, task="graph_reg",
+                 multi_prop=True, prop=0, truncate_targets=True):
+        import types
+
+        self.model, self.kind, self.task, self.multi_prop, self.prop = model, kind, task, multi_prop, prop
+        self.truncate = truncate_targets
+        fused = next(model.parameters()).is_cuda
+        self.opt = torch.optim.Adam(model.parameters(), lr=lr, weight_decay=weight_decay, fused=fused)
+        self.flat = FlatGrads(model.parameters())
+        graphs = [int(g) for g in graphs]
+        self.batches = []
+        # contiguous runs of graph ids inside `graphs` are merged into ranges; a batch = list of ranges
+        for b0 in range(0, len(graphs), batch_size):
+            ids = graphs[b0:b0 + batch_size]
+            pieces = [gset.batch(g, g + 1, kind) for g in ids] if not _is_range(ids) else [gset.batch(ids[0], ids[-1] + 1, kind)]
+            self.batches.append(_cat_pieces(pieces, kind, types))
+
+    def _loss(self, out, y):
+        if self.truncate:
+            y = y.long()
+        if self.task == "graph_reg":
+            tgt = (y[:, self.prop].view(-1, 1) if self.multi_prop else y).to(out.dtype)
+            return F.l1_loss(out, tgt)
+        return F.cross_entropy(out, y.long().flatten())
+
+    def _forward(self, b):
+        if self.kind == "gs":
+            return self.model(b, b["graph_of_masked"])
+        return self.model(b["gc"])
+
+    def step(self):
+        self.model.train()
+        self.flat.zero()
+        total = torch.zeros((), device=self.flat.buf.device)
+        for b in self.batches:
+            loss = self._loss(self._forward(b), b["y"])
+            loss.backward()
+            self.opt.step()
+            total += loss.detach()
+        return total / max(len(self.batches), 1)
+
+    @torch.no_grad()
+    def evaluate(self):
+        """graph_infer_Gs / graph_val_Gc: mean batch loss; regression losses of the Gs path are divided by the std of
+        the (truncated) labels (run.py:323-325)."""
+        self.model.eval()
+        total, labels = torch.zeros((), device=self.flat.buf.device), []
+        for b in self.batches:
+            total += self._loss(self._forward(b), b["y"])
+            y = b["y"].long() if self.truncate else b["y"]
+            labels.append(y[:, self.prop] if self.multi_prop else y.flatten())
+        if self.task == "graph_reg" and self.kind == "gs":
+            total = total / torch.cat(labels).float().std()
+        return total / max(len(self.batches), 1)
+
+
+def _is_range(ids):
+    return all(b == a + 1 for a, b in zip(ids, ids[1:]))
+
+
+def _cat_pieces(pieces, kind, types):
+    """One batch from per-range pieces (block-diagonal concatenation; a single range needs no copy)."""
+    if len(pieces) == 1:
+        p = pieces[0]
+        x, e, graph, mask, y = p["x"], p["edge_index"], p["graph"], p["mask"], p["y"]
+    else:
+        from .csr import CSRGraph, register
+
+        offs = np_cumsum([int(p["x"].shape[0]) for p in pieces])
+        goff = np_cumsum([p["n_graphs"] for p in pieces])
+        x = torch.cat([p["x"] for p in pieces])
+        e = torch.cat([p["edge_index"] + o for p, o in zip(pieces, offs)], 1).contiguous()
+        graph = torch.cat([p["graph"] + o for p, o in zip(pieces, goff)])
+        mask = torch.cat([p["mask"] for p in pieces]) if kind == "gs" else None
+        y = torch.cat([p["y"] for p in pieces])
+        if x.is_cuda:
+            register(e, CSRGraph(e, int(x.shape[0]), mode="gcn"), "gcn")
+    b = dict(x=x, edge_index=e, mask=mask, y=y)
+    if kind == "gs":
+        b["graph_of_masked"] = graph[mask]
+    else:
+        b["gc"] = types.SimpleNamespace(x=x, edge_index=e, batch=graph)
+    return b
+
+
+def np_cumsum(v):
+    out, s = [], 0
+    for a in v:
+        out.append(s)
+        s += a
+    return out

@@ -7,6 +7,7 @@ row appended to results/<dataset>.csv (results/baseline/<dataset>.csv) with the 
 (run.py:480-485, :883-887).  Node-classification tasks only in this round (the hot path BASELINE.json names).
 
 Datasets: the reference downloads through torch_geometric / ogb, which are not available here.  Accepted:
+  synthetic-qm9              QM9-shaped graph regression stand-in (--n_graphs molecules of ~18 nodes, 19 targets)
   cora | citeseer | pubmed   Planetoid raw files `ind.<name>.*` under --data_root/<name>/raw (PyG's own layout)
   synthetic-{cora,citeseer,pubmed,physics}   seeded stand-ins of the same shape (dataset_info.csv)
 Extra flags (not in the reference): --data_root, --device.
@@ -61,6 +62,7 @@ def build_parser():
     # not in the reference
     p.add_argument('--data_root', type=str, default='./dataset')
     p.add_argument('--device', type=str, default='cuda')
+    p.add_argument('--n_graphs', type=int, default=2000)  # size of the synthetic-qm9 stand-in (QM9 itself: 130 831)
     return p
 
 
@@ -83,6 +85,12 @@ def process_dataset(args):
     from fitgnn_amd import pipeline
 
     name = args.dataset
+    if name == 'synthetic-qm9':  # QM9-shaped stand-in (main.py:105-108: task graph_reg, multi_prop forced on)
+        from fitgnn_amd import graph_data
+        mol = graph_data.synthetic_molecules(args.n_graphs, seed=0 if args.seed is None else args.seed)
+        args.task, args.multi_prop = 'graph_reg', True
+        args.num_features = mol["x"].shape[1]
+        return mol, args
     if name in pipeline.SYNTHETIC_SHAPES:
         data, n_classes = pipeline.synthetic_dataset(name, seed=0 if args.seed is None else args.seed)
         if args.experiment == 'fixed':
@@ -150,6 +158,10 @@ def main(argv=None):
     os.makedirs(path, exist_ok=True)
     if args.use_community_detection:
         raise NotImplementedError("--use_community_detection needs igraph/leidenalg (main.py:247-267), not available here")
+    if args.task == 'graph_reg':
+        if args.baseline:
+            raise NotImplementedError("graph-level baselines (run.py:904-) are outside the hot path")
+        return pipeline.graph_regression(args, path, data, device=args.device)
     if args.baseline:
         res = pipeline.node_classification_baseline(args, path, data, device=args.device)
         write_results(args, *res, baseline=True)

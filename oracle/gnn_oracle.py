@@ -156,3 +156,50 @@ def mb_train_epoch(sd, batches, num_layers=2, lr=0.01, weight_decay=5e-4, adam_s
         n_out += int(b["train_mask"].sum())
     rep = total / len(batches) if reduction == "mean" else total / max(n_out, 1)
     return rep, {k: v.detach() for k, v in params.items()}, opt.state_dict()
+
+
+def conv_stack(sd, x, edge_index, num_layers):
+    """for l < L: conv -> elu (-> dropout, off here): the body shared by every model of network.py."""
+    for i in range(num_layers):
+        x = F.elu(gcn_conv(x, edge_index, sd[f"conv.{i}.lin.weight"], sd.get(f"conv.{i}.bias")))
+    return x
+
+
+def mean_pool(x, batch, size):
+    out = torch.zeros((size, x.shape[1]), dtype=x.dtype).index_add_(0, batch, x)
+    cnt = torch.zeros(size, dtype=x.dtype).index_add_(0, batch, torch.ones(batch.numel(), dtype=x.dtype))
+    return out / cnt.clamp(min=1).unsqueeze(1)
+
+
+def regress_graph_gs_forward(sd, set_gs, batch_tensor, num_layers=2):
+    """Regress_graph_gs.forward (network.py:189-204), literally: every subgraph of every graph runs the conv stack on
+    its OWN (its own gcn_norm), x[mask] rows are concatenated in loop order, mean-pooled per graph, then lt1.
+    set_gs: list (graphs) of lists (subgraphs) of dicts x, edge_index, mask."""
+    rows = [conv_stack(sd, g["x"].float(), g["edge_index"], num_layers)[g["mask"]] for gs in set_gs for g in gs]
+    x = mean_pool(torch.cat(rows, 0), batch_tensor.long(), len(set_gs))
+    return x @ sd["lt1.weight"].t() + sd["lt1.bias"]
+
+
+def regress_graph_gc_forward(sd, gc_x, gc_edge_index, gc_batch, n_graphs, num_layers=2):
+    """Regress_graph_gc.forward (network.py:156-164)."""
+    x = mean_pool(conv_stack(sd, gc_x, gc_edge_index, num_layers), gc_batch.long(), n_graphs)
+    return x @ sd["lt1.weight"].t() + sd["lt1.bias"]
+
+
+def graph_train_epoch(sd, batches, forward, prop=0, lr=0.01, weight_decay=5e-4, adam_state=None):
+    """graph_train_Gs / graph_train_Gc (run.py:254-269, :288-304), multi_prop regression: zero_grad ONCE per epoch,
+    then per batch: y.type(torch.long) (truncation!), L1Loss(out, y[:, prop].view(-1, 1)), backward, step.
+    batches: list of (inputs..., y); forward(params, *inputs) -> [B, 1].  Returns (mean batch loss, sd, adam)."""
+    params = {k: v.detach().clone().requires_grad_(True) for k, v in sd.items()}
+    opt = torch.optim.Adam(list(params.values()), lr=lr, weight_decay=weight_decay)
+    if adam_state is not None:
+        opt.load_state_dict(adam_state)
+    opt.zero_grad()
+    total = 0.0
+    for *inputs, y in batches:
+        out = forward(params, *inputs)
+        loss = F.l1_loss(out, y.long()[:, prop].view(-1, 1).to(out.dtype))
+        loss.backward()
+        opt.step()
+        total += float(loss)
+    return total / len(batches), {k: v.detach() for k, v in params.items()}, opt.state_dict()

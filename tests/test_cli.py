@@ -110,3 +110,19 @@ def test_cli_end_to_end_on_synthetic_cora(tmp_path, monkeypatch):
     assert rows[0].startswith("dataset,baseline,experiment,exp_setup") and len(rows) == 3
     sd = torch.load("save/node_cls/f/model.pt")
     assert sorted(sd) == ["conv.0.bias", "conv.0.lin.weight", "conv.1.bias", "conv.1.lin.weight", "lt1.bias", "lt1.weight"]
+
+
+@pytest.mark.gpu
+def test_cli_graph_regression_on_synthetic_qm9(tmp_path, monkeypatch):
+    """main.py on the QM9-shaped stand-in (BASELINE.json config 5's plumbing): batched coarsening of every molecule,
+    Gs / Gc training loops, results row with the reference's columns; the model must beat predicting zero."""
+    monkeypatch.chdir(tmp_path)
+    common = ["--dataset", "synthetic-qm9", "--n_graphs", "600", "--hidden", "64", "--seed", "0", "--train_fitgnn", "--batch_size", "64",
+              "--lr", "0.002", "--property", "0", "--epochs1", "15", "--epochs2", "15", "--output_dir", "q"]
+    losses = {}
+    for setup, extra in (("Gs_train_2_Gs_infer", ["--extra_node"]), ("Gc_train_2_Gc_infer", []), ("Gc_train_2_Gs_train", [])):
+        losses[setup] = cli.main(common + ["--exp_setup", setup] + extra)
+        assert np.isfinite(losses[setup])
+    rows = open("results/synthetic-qm9.csv").read().strip().split("\n")
+    assert rows[0].startswith("dataset,coarsening_method,coarsening_ratio,exp_setup") and rows[0].endswith("property_idx}") and len(rows) == 4
+    assert os.path.exists("save/graph_reg/q/model.pt")

@@ -280,3 +280,51 @@ def test_trainers_follow_the_reference_step_functions(mods, method):
         assert got == pytest.approx(float(want), rel=2e-4), (epoch, got, float(want))
     for k, v in model.state_dict().items():
         assert rel(v.detach().cpu(), sd[k]) < 2e-3, k
+
+
+@pytest.mark.parametrize("kind,extra", [("gs", True), ("gs", False), ("gc", False)])
+def test_graph_level_training_follows_the_reference_loops(mods, kind, extra):
+    """GraphSet + GraphTrainer (one block-diagonal pass per batch) vs the oracle's literal restatement: per-subgraph
+    conv stacks with the reference's first-k row mask (network.py:189-204) and the graph_train_Gs / _Gc step loops
+    (run.py:254-304: one zero_grad per epoch, targets through .long())."""
+    from fitgnn_amd import graph_data, train
+
+    network, fnn, gorc = mods
+    mol = graph_data.synthetic_molecules(48, seed=3)
+    gset = graph_data.GraphSet(mol, ratio=0.5, extra_node=extra, device="cuda")
+    assert int(gset.gs_mask.sum()) == int(mol["node_ptr"][-1])   # sum of k over subgraphs = number of nodes
+    args = argparse.Namespace(num_layers1=2, layer_name="GCNConv", num_features=11, hidden=32, num_classes=1)
+    torch.manual_seed(11)
+    model = (network.Regress_graph_gs if kind == "gs" else network.Regress_graph_gc)(args).cuda()
+    model.dropout_p = 0.0
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    tr = train.GraphTrainer(model, gset, list(range(48)), kind=kind, batch_size=16, prop=2)
+    # the same three batches for the oracle, in the reference's data layout
+    cpu_batches = []
+    y = torch.from_numpy(mol["y"])
+    for g0 in range(0, 48, 16):
+        if kind == "gs":
+            set_gs = []
+            for g in range(g0, g0 + 16):
+                subs = []
+                for c in range(int(gset.cluster_ptr[g]), int(gset.cluster_ptr[g + 1])):
+                    r0, r1 = int(gset.sub_ptr[c]), int(gset.sub_ptr[c + 1])
+                    e = gset.gs_edge_index.cpu()
+                    k = (e[0] >= r0) & (e[0] < r1)
+                    subs.append(dict(x=gset.gs_x[r0:r1].cpu(), edge_index=e[:, k] - r0, mask=gset.gs_mask[r0:r1].cpu()))
+                set_gs.append(subs)
+            bt = torch.repeat_interleave(torch.arange(16), torch.from_numpy(np.diff(mol["node_ptr"][g0:g0 + 17])))
+            cpu_batches.append((set_gs, bt, y[g0:g0 + 16]))
+        else:
+            r0, r1 = int(gset.cluster_ptr[g0]), int(gset.cluster_ptr[g0 + 16])
+            e = gset.gc_edge_index.cpu()
+            k = (e[0] >= r0) & (e[0] < r1)
+            cpu_batches.append((gset.gc_x[r0:r1].cpu(), e[:, k] - r0, gset.gc_graph[r0:r1].cpu() - g0, 16, y[g0:g0 + 16]))
+    fwd = gorc.regress_graph_gs_forward if kind == "gs" else gorc.regress_graph_gc_forward
+    state = None
+    for epoch in range(2):
+        got = float(tr.step())
+        want, sd, state = gorc.graph_train_epoch(sd, cpu_batches, fwd, prop=2, adam_state=state)
+        assert got == pytest.approx(want, rel=5e-4), (epoch, got, want)
+    for k, v in model.state_dict().items():
+        assert rel(v.detach().cpu(), sd[k]) < 3e-3, k
