@@ -198,7 +198,42 @@ __global__ __launch_bounds__(256) void colsum_partials_kernel(const float *__res
     if (ph == 0 && h < H) db[h] = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
 }
 
+// out[w] = sum_b part[b][w], partials combined in a fixed tree: four interleaved running sums, then (s0+s1)+(s2+s3)
+__global__ __launch_bounds__(256) void sum_leading_kernel(const float4 *__restrict__ part, int32_t B, int64_t W4,
+                                                          float4 *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= W4) return;
+    float4 s[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    int b = 0;
+    for (; b + 4 <= B; b += 4) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float4 v = part[(int64_t)(b + k) * W4 + i];
+            s[k].x += v.x; s[k].y += v.y; s[k].z += v.z; s[k].w += v.w;
+        }
+    }
+    for (; b < B; ++b) {
+        const float4 v = part[(int64_t)b * W4 + i];
+        s[0].x += v.x; s[0].y += v.y; s[0].z += v.z; s[0].w += v.w;
+    }
+    out[i] = make_float4((s[0].x + s[1].x) + (s[2].x + s[3].x), (s[0].y + s[1].y) + (s[2].y + s[3].y),
+                         (s[0].z + s[1].z) + (s[2].z + s[3].z), (s[0].w + s[1].w) + (s[2].w + s[3].w));
+}
+
 }  // namespace
+
+extern "C" int fitgnn_sum_leading_f32(const float *part, int32_t B, int64_t W, float *out, void *stream) {
+    if (B < 1 || W < 0 || (W % 4) != 0) return FITGNN_E_BADARG;
+    if (W == 0) return 0;
+    if (!part || !out) return FITGNN_E_BADARG;
+    if ((((uintptr_t)part | (uintptr_t)out) % 16) != 0) return FITGNN_E_ALIGN;
+    const int64_t W4 = W / 4;
+    hipLaunchKernelGGL(sum_leading_kernel, dim3((unsigned)((W4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const float4 *)part, B, W4, (float4 *)out);
+    return (int)hipGetLastError();
+}
 
 extern "C" int fitgnn_gcn_norm_csr_f32(const int32_t *rowptr, const int32_t *col, const float *w, float *val,
                                        float *dinv, int32_t n_rows, void *stream) {

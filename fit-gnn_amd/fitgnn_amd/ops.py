@@ -24,7 +24,6 @@ PROFILE = None
 # split kernels are slower for that shape.  "highest" everywhere = plain fp32 MFMA.
 GEMM_PRECISION = "high"
 
-
 def mm(a, b, allow_split=True):
     if GEMM_PRECISION == "high" and allow_split:
         prev = torch.get_float32_matmul_precision()
@@ -51,7 +50,14 @@ def mm_at_b(a, b):
     if GEMM_PRECISION == "high":
         torch.set_float32_matmul_precision("high")
     try:
-        out = torch.bmm(a[:main].view(B, Kc, a.shape[1]).transpose(1, 2), b[:main].view(B, Kc, b.shape[1])).sum(0)
+        part = torch.bmm(a[:main].view(B, Kc, a.shape[1]).transpose(1, 2), b[:main].view(B, Kc, b.shape[1]))
+        W = part.shape[1] * part.shape[2]
+        if part.is_cuda and W % 4 == 0:
+            out = torch.empty(part.shape[1:], dtype=torch.float32, device=part.device)
+            _lib.check(_lib.lib().fitgnn_sum_leading_f32(_lib.dptr(part), B, W, _lib.dptr(out), _lib.stream_ptr(part.device)),
+                       "fitgnn_sum_leading_f32")
+        else:
+            out = part.sum(0)
         if main < R:
             out = out + torch.mm(a[main:].t(), b[main:])
     finally:
@@ -90,7 +96,7 @@ class SmallLinear(torch.autograd.Function):
         x, W = ctx.saved_tensors
         dx = torch.mm(dy, W) if ctx.needs_input_grad[0] else None
         dW = torch.mm(dy.t(), x) if ctx.needs_input_grad[1] else None
-        db = dy.sum(0) if ctx.needs_input_grad[2] else None
+        db = dy.t().contiguous().sum(1) if ctx.needs_input_grad[2] else None
         return dx, dW, db
 
 
@@ -324,7 +330,9 @@ class FusedGCNLayerHead(torch.autograd.Function):
         epi = EPI_ELU | (EPI_DROPOUT if ctx.drop else 0)
         dH, db, dWl = layer_backward(g, out, epi, ctx.p if ctx.drop else 0.0, ctx.seed, mask, ctx.has_bias, dy=dy, Wl=Wl,
                                      want_dWl=ctx.needs_input_grad[3])
-        dbl = dy.sum(0) if ctx.has_bl and ctx.needs_input_grad[4] else None
+        # [R, C] column sums: reduce over the contiguous axis of the transposed copy (torch's dim-0 reduction of a
+        # tall 3-column matrix takes 50 us, this 10)
+        dbl = dy.t().contiguous().sum(1) if ctx.has_bl and ctx.needs_input_grad[4] else None
         dW = mm_at_b(dH, X) if ctx.needs_input_grad[1] else None
         dX = mm(dH, W) if ctx.needs_input_grad[0] else None
         return dX, dW, (db if ctx.has_bias else None), dWl, dbl, None, None, None, None, None

@@ -112,6 +112,10 @@ int fitgnn_spmm_csr_f32(const int32_t *rowptr, const int32_t *col, const float *
 int fitgnn_segment_sum_f32(const int32_t *seg_off, const int32_t *members, int32_t n_seg, const float *X, int64_t ldx,
                            int32_t F, float *out, int64_t ldo, void *stream);
 
+/* out[W] = sum over b < B of part[b][W] in a fixed order (W % 4 == 0, 16-byte aligned): combines the partial products
+ * of the split-K weight-gradient GEMM dH^T @ X (the library has no deterministic split-K for K = number of rows). */
+int fitgnn_sum_leading_f32(const float *part, int32_t B, int64_t W, float *out, void *stream);
+
 /* Backward of the fused epilogue  out = dropout(ELU(z)):  given dOut and the forward OUTPUT `out`
  *   dZ = keep ? dOut * 1/(1-p) * (o > 0 ? 1 : o + 1) : 0,   o = out*(1-p) (pre-dropout ELU value)
  * and the bias gradient db[h] = sum_rows dZ[row][h] (deterministic two-pass reduction through `work`).
