@@ -143,6 +143,15 @@ __device__ inline HeapItem heap_pop(H &h, int &n) {
 // positions to sel_end[0 .. ) (both relative to the pointers passed in).  Returns through ns / pos / the residual
 // n_reduce.  Every iteration consumes one queue entry and re-insertions strictly shrink a set, so the loop is
 // bounded by max_iters = candidates + members + slack (an exit every lane reaches).
+#ifdef FITGNN_GREEDY_STAMPS
+__device__ unsigned long long g_greedy_dbg[8];  // cycles: pop, mark check, select, prune, recost, heap push; counts: pops, recosts
+#define FITGNN_STAMP(var) const unsigned long long var = __builtin_readcyclecounter()
+#define FITGNN_ACC(i, a, b) if ((threadIdx.x & 63) == 0) g_greedy_dbg[i] += (b) - (a)
+#else
+#define FITGNN_STAMP(var)
+#define FITGNN_ACC(i, a, b)
+#endif
+
 template <int HEAP_LDS>
 __device__ inline void greedy_component(const CostGraph &g, CostLds &lds, Heap<HEAP_LDS> heap, int32_t head0, int32_t head1,
                                         int64_t seq, const int32_t *__restrict__ set_off, int32_t *__restrict__ mem,
@@ -154,30 +163,43 @@ __device__ inline void greedy_component(const CostGraph &g, CostLds &lds, Heap<H
     int hn = 0;          // heap size (uniform)
     int head = head0;    // next unread entry of the sorted initial family (uniform)
     ns = 0; pos = 0;
+    // the head of the sorted list is fetched one pop ahead (candidate, cost, set extent): the loads of the NEXT list
+    // entry are in flight while the current candidate is processed.  len[] of an unprocessed list entry is its initial
+    // length (only the candidate being processed is ever shrunk).
+    int32_t nx_cand = 0, nx_off = 0, nx_len = 0;
+    double nx_cost = 0.0;
+    if (head < head1) { nx_cand = order[head]; nx_cost = cost0[nx_cand]; nx_off = set_off[nx_cand]; nx_len = len[nx_cand]; }
     for (int64_t it = 0; it < max_iters; ++it) {
         if (n_reduce <= 0) break;
         if (head >= head1 && hn == 0) break;
         // ---- pop the minimum of {sorted initial list head, heap top}: SortedList.pop(0) ----
+        FITGNN_STAMP(t_a);
         int32_t cand;
+        int off, nc;
         bool from_list = hn == 0;
         if (head < head1 && hn > 0) {
-            const int32_t c0 = order[head];
-            HeapItem li{cost0[c0], (int64_t)c0, c0, 0};
+            HeapItem li{nx_cost, (int64_t)nx_cand, nx_cand, 0};
             const HeapItem top = heap.get(0);
             from_list = item_less(li, top);
         }
         if (from_list) {
-            cand = order[head++];
+            cand = __builtin_amdgcn_readfirstlane(nx_cand);
+            off = __builtin_amdgcn_readfirstlane(nx_off);
+            nc = __builtin_amdgcn_readfirstlane(nx_len);
+            ++head;
+            if (head < head1) { nx_cand = order[head]; nx_cost = cost0[nx_cand]; nx_off = set_off[nx_cand]; nx_len = len[nx_cand]; }
         } else {
             HeapItem top;
             if (lane == 0) top = heap_pop(heap, hn); else --hn;
             FITGNN_WAVE_SYNC();
-            cand = __shfl(top.cand, 0, 64);
+            cand = __builtin_amdgcn_readfirstlane(__shfl(top.cand, 0, 64));
+            off = __builtin_amdgcn_readfirstlane(set_off[cand]);
+            nc = __builtin_amdgcn_readfirstlane(len[cand]);
         }
-        cand = __builtin_amdgcn_readfirstlane(cand);
-        const int off = __builtin_amdgcn_readfirstlane(set_off[cand]);
-        const int nc = __builtin_amdgcn_readfirstlane(len[cand]);
         int32_t *S = mem + off;
+        FITGNN_STAMP(t_b);
+        FITGNN_ACC(0, t_a, t_b);
+        FITGNN_ACC(6, 0ull, 1ull);
         // ---- any member marked? (coarsening_utils.py:620-622) ----
         bool any = false;
         for (int t0 = 0; t0 < nc; t0 += 64) {
@@ -185,6 +207,8 @@ __device__ inline void greedy_component(const CostGraph &g, CostLds &lds, Heap<H
             const bool mk = (t < nc) && marked[S[t]] != 0;
             any |= __ballot(mk) != 0ull;
         }
+        FITGNN_STAMP(t_c);
+        FITGNN_ACC(1, t_b, t_c);
         if (!any) {
             const int64_t gain = nc - 1;
             if (gain > n_reduce) continue;  // :625-626, would over-reduce: drop the set
@@ -198,6 +222,8 @@ __device__ inline void greedy_component(const CostGraph &g, CostLds &lds, Heap<H
             ++ns;
             n_reduce -= gain;
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // marked[] writes before later reads
+            FITGNN_STAMP(t_d);
+            FITGNN_ACC(2, t_c, t_d);
         } else {
             // ---- drop marked members in place, keep order (:640) ----
             int m = 0;
@@ -212,13 +238,20 @@ __device__ inline void greedy_component(const CostGraph &g, CostLds &lds, Heap<H
                 if (keep) S[m + before] = v;
                 m += __popcll(bal);
             }
+            FITGNN_STAMP(t_e);
+            FITGNN_ACC(3, t_c, t_e);
             if (m > 1) {
                 if (lane == 0) len[cand] = m;
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
                 const double c = fitgnn::set_cost_wave(g, S, m, lds);  // :646 re-cost
+                FITGNN_STAMP(t_f);
+                FITGNN_ACC(4, t_e, t_f);
+                FITGNN_ACC(7, 0ull, 1ull);
                 if (lane == 0) heap_push(heap, hn, HeapItem{c, seq, cand, 0}); else ++hn;
                 ++seq;
                 FITGNN_WAVE_SYNC();
+                FITGNN_STAMP(t_g);
+                FITGNN_ACC(5, t_f, t_g);
             }
         }
     }
@@ -433,6 +466,15 @@ extern "C" int fitgnn_variation_costs_batch_f64(const int32_t *rowptr, const int
                        set_len, set_mem, n_sets, cost);
     return (int)hipGetLastError();
 }
+
+#ifdef FITGNN_GREEDY_STAMPS
+extern "C" int fitgnn_debug_greedy_counters(unsigned long long *out, int reset) {
+    hipDeviceSynchronize();
+    int rc = (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_greedy_dbg), sizeof(unsigned long long) * 8);
+    if (reset) { unsigned long long z[8] = {0}; rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(g_greedy_dbg), z, sizeof(z)); }
+    return rc;
+}
+#endif
 
 extern "C" size_t fitgnn_greedy_select_workspace_bytes(int32_t N, int64_t total_members) {
     if (N < 0 || total_members < 0) return 0;

@@ -32,11 +32,18 @@ namespace fitgnn {
 
 constexpr int kCostTile = 64;  // rows of S per LDS tile (one per lane)
 
+constexpr int kHitCap = 512;   // matches (adjacency entries inside the set) listed in LDS per set; more -> serial path
+
 struct CostLds {  // per-wave LDS scratch
     double B[kCostTile * FITGNN_MAX_K];
     double Y[kCostTile * FITGNN_MAX_K];
     double mean[FITGNN_MAX_K];
+    double hit_w[kHitCap];        // weight of every match, in (row, column) order
     int32_t S[kCostTile];
+    int32_t rstart[kCostTile + 1];  // first flattened adjacency index of every member row
+    int32_t re0[kCostTile];         // rowptr of every member
+    int32_t cnt[kCostTile];         // matches per member row
+    uint8_t hit_b[kHitCap];         // position in S of every match
 };
 
 struct CostGraph {
@@ -73,9 +80,15 @@ __device__ inline double set_cost_wave(const CostGraph &g, const int32_t *__rest
 
     // ---- pass 1: column means, sequential over members (tiles of 64 rows staged cooperatively) ----
     double msum = 0.0;
+    int pre_e0 = 0, pre_deg = 0;   // small sets: the member's row extent and degree term ride along with the A gather
+    double pre_dw = 0.0;
     for (int t0 = 0; t0 < nc; t0 += kCostTile) {
         const int rows = min(kCostTile, nc - t0);
-        if (lane < rows) lds.S[lane] = S[t0 + lane];
+        if (lane < rows) {
+            const int32_t u = S[t0 + lane];
+            lds.S[lane] = u;
+            if (small) { pre_e0 = g.rowptr[u]; pre_deg = g.rowptr[u + 1] - pre_e0; pre_dw = g.dw[u]; }
+        }
         FITGNN_WAVE_SYNC();
         for (int i = lane; i < rows * K; i += 64) {
             const int a = i / K, k = i - a * K;
@@ -111,6 +124,89 @@ __device__ inline double set_cost_wave(const CostGraph &g, const int32_t *__rest
             lds.B[i] = lds.B[i] - lds.mean[k];
         }
         FITGNN_WAVE_SYNC();
+        // W_S rows: the matches adj(u) /\ S of every member u, each row in ascending column order.
+        // Fast path (whole set in one tile): all 64 lanes scan the members' adjacency lists TOGETHER -- one flattened
+        // index space, independent loads -- and list the matches (position in S, weight) in LDS in (row, column)
+        // order; each member's lane then folds ITS matches in that same order, so the arithmetic is the serial walk's.
+        bool listed = false;
+        if (small) {
+            const int e0 = pre_e0, deg = pre_deg;
+            int incl = deg;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) { const int y = __shfl_up(incl, off, 64); if (lane >= off) incl += y; }
+            const int total = __shfl(incl, 63, 64);
+            lds.rstart[lane] = incl - deg;
+            if (lane == 63) lds.rstart[64] = total;
+            lds.re0[lane] = e0;
+            lds.cnt[lane] = 0;
+            FITGNN_WAVE_SYNC();
+            int nh = 0;
+            listed = true;
+            // four 64-entry chunks per round: their column (and weight) loads are issued together, then folded in order
+            for (int base = 0; base < total && listed; base += 256) {
+                int a4[4], e4[4];
+                int32_t c4[4];
+                double w4[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    // clamped: every lane loads a valid entry (total >= 1 here), dead ones are masked below
+                    const int ii = min(base + q * 64 + lane, total - 1);
+                    int lo = 0, hi = rows;             // row a = last row whose first index is <= ii
+                    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (lds.rstart[mid] <= ii) lo = mid; else hi = mid; }
+                    a4[q] = lo;
+                    e4[q] = lds.re0[lo] + (ii - lds.rstart[lo]);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    c4[q] = g.col[e4[q]];
+                    w4[q] = g.w ? g.w[e4[q]] : 1.0;
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (base + q * 64 >= total) break;  // wave-uniform
+                    const bool valid = base + q * 64 + lane < total;
+                    const int b = lower_bound_i32(lds.S, nc, c4[q]);
+                    const bool hit = valid && b < nc && lds.S[b] == c4[q];
+                    const unsigned long long bal = __ballot(hit);
+                    const int nb = __popcll(bal);
+                    if (nh + nb > kHitCap) { listed = false; break; }  // wave-uniform
+                    if (hit) {
+                        const int at = nh + __popcll(bal & ((1ull << lane) - 1ull));
+                        lds.hit_b[at] = (uint8_t)b;
+                        lds.hit_w[at] = w4[q];
+                        atomicAdd(&lds.cnt[a4[q]], 1);
+                    }
+                    nh += nb;
+                }
+            }
+            FITGNN_WAVE_SYNC();
+            if (listed) {
+                const int cn = lane < rows ? lds.cnt[lane] : 0;
+                int hincl = cn;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) { const int y = __shfl_up(hincl, off, 64); if (lane >= off) hincl += y; }
+                if (lane < rows) {
+                    const int a = lane;
+                    double T[FITGNN_MAX_K];
+#pragma unroll
+                    for (int l = 0; l < FITGNN_MAX_K; ++l) T[l] = 0.0;
+                    double rs = 0.0;
+                    for (int h = hincl - cn; h < hincl; ++h) {
+                        const int b = lds.hit_b[h];
+                        const double wab = lds.hit_w[h];
+                        rs = rs + wab;
+#pragma unroll
+                        for (int l = 0; l < FITGNN_MAX_K; ++l)
+                            if (l < K) { const double prod = wab * lds.B[b * K + l]; T[l] = T[l] + prod; }
+                    }
+                    const double d = 2.0 * pre_dw - rs;
+#pragma unroll
+                    for (int l = 0; l < FITGNN_MAX_K; ++l)
+                        if (l < K) { const double prod = d * lds.B[a * K + l]; lds.Y[a * K + l] = prod - T[l]; }
+                }
+            }
+        }
+        if (!listed)
         if (lane < rows) {
             const int a = lane;
             const int32_t u = lds.S[a];
