@@ -37,14 +37,15 @@ def rel_err(a, b):
     return float((a - b).abs().max() / b.abs().max().clamp(min=1e-20))
 
 
-@pytest.mark.parametrize("H", [512, 256, 64, 100, 7, 1, 516])
+# every width with the default window; the window sweep on two widths only
+_HW = [(H, None) for H in (512, 256, 64, 100, 7, 1, 516)] + [(H, w) for H in (512, 7) for w in (8, 64, 96)]
+
+
+@pytest.mark.parametrize("H,window", _HW)
 @pytest.mark.parametrize("sizes", [[3, 9, 1, 30, 64, 2, 2, 5] * 6, [200, 3, 90], [1] * 70])
-@pytest.mark.parametrize("window", [None, 8, 64, 96])
 @pytest.mark.parametrize("planned", [True, False])
 def test_spmm_matches_oracle(mods, H, sizes, window, planned):
     _lib, csr, ops, orc, gorc = mods
-    if window is not None and H not in (512, 7):
-        pytest.skip("window sweep on two widths only")
     ei, n = block_graph(sizes, seed=len(sizes) + H, p=0.3)
     g = csr.CSRGraph(ei.cuda(), n, mode="gcn", lds_rows=window, planned=planned)
     X = torch.randn(n, H)
@@ -248,3 +249,36 @@ def test_folded_backward_equals_two_kernels(mods, head, use_mask):
     assert rel_err(got[1].cpu(), ref[1].cpu()) < 1e-4
     if head:
         assert rel_err(got[2].cpu(), ref[2].cpu()) < 1e-4
+
+
+def test_torch_ops_namespace(mods):
+    """torch.ops.fitgnn.* (schema-registered custom ops over the C ABI): forward == the ctypes path, spmm_csr_pair's
+    autograd == SpMM with the transposed pattern, opcheck-style fake kernels give the right shapes, CPU tensors are
+    refused by the dispatcher (no CPU kernel is registered)."""
+    _lib, csr, ops, orc, gorc = mods
+    from fitgnn_amd import torch_ops
+
+    ei, n = block_graph([3, 9, 1, 30, 64, 2, 2, 5] * 4, seed=4, p=0.3)
+    g = csr.CSRGraph(ei.cuda(), n, mode="gcn")
+    X = torch.randn(n, 96, device="cuda", requires_grad=True)
+    Y = torch_ops.spmm(g, X)
+    assert torch.equal(Y.detach(), ops.spmm_graph(g, X.detach()))
+    dY = torch.randn_like(Y)
+    Y.backward(dY)
+    assert torch.equal(X.grad, ops.spmm_graph(g, dY, transposed=True))
+    val, dinv = torch.ops.fitgnn.gcn_norm_csr(g.f.rowptr, g.f.col, None)
+    assert torch.equal(val, g.f.val)
+    Y2 = torch.ops.fitgnn.spmm_csr(g.f.rowptr, g.f.col, g.f.val, X.detach(), g.f.tiles, g.window_rows, None, 0, 0.0, 0, None)
+    assert torch.equal(Y2, Y.detach())
+    with torch.device("meta"):
+        m = torch.ops.fitgnn.spmm_csr(torch.empty(n + 1, dtype=torch.int32), torch.empty(5, dtype=torch.int32), torch.empty(5),
+                                      torch.empty(n, 96), torch.empty(3, 8, dtype=torch.int32), 16, None, 0, 0.0, 0, None)
+    assert m.shape == (n, 96)
+    with pytest.raises((NotImplementedError, RuntimeError)):
+        torch.ops.fitgnn.spmm_csr(g.f.rowptr.cpu(), g.f.col.cpu(), g.f.val.cpu(), X.detach().cpu(), g.f.tiles.cpu(), 16, None, 0, 0.0, 0, None)
+    assign = torch.tensor([0, 0, 1, 1, 1], dtype=torch.int32, device="cuda")
+    cval = torch.tensor([2 ** -0.5] * 2 + [3 ** -0.5] * 3, dtype=torch.float64, device="cuda")
+    Xs = torch.arange(10, dtype=torch.float32, device="cuda").view(5, 2)
+    Xc = torch.ops.fitgnn.pool_rows(assign, cval, 2, Xs)
+    ref = torch.stack([(Xs[:2].double() * 2 ** -0.5).sum(0), (Xs[2:].double() * 3 ** -0.5).sum(0)]).float()
+    assert torch.allclose(Xc, ref, rtol=1e-6)
