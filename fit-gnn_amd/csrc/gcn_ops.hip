@@ -59,10 +59,11 @@ constexpr int kMaxHeadC = 16;  // widest head (classes) whose backward is folded
 template <int VEC, bool HEAD, int CW>
 __global__ __launch_bounds__(256) void epilogue_bwd_kernel(const float *__restrict__ dOut, const float *__restrict__ out,
                                                            float *__restrict__ dZ, int32_t n_rows, int32_t H,
-                                                           int32_t chunk_rows, uint32_t epi, float p_drop, uint64_t seed,
+                                                           int32_t chunk_rows, uint32_t epi, float p_drop, uint64_t seed_arg,
                                                            const uint8_t *__restrict__ mask, float *__restrict__ partial,
                                                            const float *__restrict__ dy, const float *__restrict__ Wl,
                                                            int32_t C, float *__restrict__ partialW) {
+    const uint64_t seed = fitgnn::resolve_seed(seed_arg, epi);
     constexpr int SLAB = 64 * VEC;
     __shared__ float red[4][SLAB];
     __shared__ float s_w[HEAD ? kMaxHeadC * SLAB : 1];

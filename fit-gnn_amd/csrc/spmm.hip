@@ -80,7 +80,8 @@ __global__ __launch_bounds__(kThreads, (B <= 4 ? 8 : 4)) void spmm_tile_kernel(
     const float *__restrict__ X, int64_t ldx, float *__restrict__ Y, int64_t ldy, int32_t H,
     const fitgnn_tile_t *__restrict__ tiles, int32_t n_tiles, int32_t tiles_per_xcd, int32_t n_slabs, int32_t lds_rows,
     const int32_t *__restrict__ lcol, const int32_t *__restrict__ win_cols, const int32_t *__restrict__ xrow,
-    const float *__restrict__ bias, uint32_t epi, float p_drop, uint64_t seed, const uint8_t *__restrict__ mask) {
+    const float *__restrict__ bias, uint32_t epi, float p_drop, uint64_t seed_arg, const uint8_t *__restrict__ mask) {
+    const uint64_t seed = fitgnn::resolve_seed(seed_arg, epi);
     using P = Pack<VEC>;
     using T = typename P::T;
     constexpr int SLAB = 64 * VEC;
@@ -297,7 +298,8 @@ __global__ __launch_bounds__(kThreads) void spmm_gather_kernel(
     const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col, const float *__restrict__ val,
     const float *__restrict__ X, int64_t ldx, float *__restrict__ Y, int64_t ldy, int32_t H,
     const fitgnn_tile_t *__restrict__ tiles, int32_t n_tiles, int32_t tiles_per_xcd, int32_t n_slabs,
-    const float *__restrict__ bias, uint32_t epi, float p_drop, uint64_t seed, const uint8_t *__restrict__ mask) {
+    const float *__restrict__ bias, uint32_t epi, float p_drop, uint64_t seed_arg, const uint8_t *__restrict__ mask) {
+    const uint64_t seed = fitgnn::resolve_seed(seed_arg, epi);
     using P = Pack<VEC>;
     using T = typename P::T;
     constexpr int SLAB = 64 * VEC;

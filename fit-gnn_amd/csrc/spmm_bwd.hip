@@ -94,13 +94,14 @@ __global__ __launch_bounds__(kThreads, (EPI >= 0 ? (HEAD ? 5 : 7) : (HEAD ? 6 : 
     const float scale = (epi & FITGNN_EPI_DROPOUT) ? 1.0f / (1.0f - xa.p_drop) : 1.0f;
     const float unscale = (epi & FITGNN_EPI_DROPOUT) ? (1.0f - xa.p_drop) : 1.0f;
     const uint32_t thresh = fitgnn::dropout_threshold(xa.p_drop);
+    const uint64_t seed = fitgnn::resolve_seed(xa.seed, xa.epi);
     // dZ of operand row `grow` at columns [cbase, cbase+4), from g (dOut row; HEAD: dy row @ Wl) and o (out row)
     auto transform = [&](int64_t grow, int cbase, float4 g, float4 o) -> float4 {
         float gv[4] = {g.x, g.y, g.z, g.w};
         const float ov[4] = {o.x, o.y, o.z, o.w};
         const uint64_t idx0 = (uint64_t)grow * (uint64_t)H + (uint64_t)cbase;
         uint64_t bits = 0;
-        if ((epi & FITGNN_EPI_DROPOUT) && !mask) bits = fitgnn::dropout_bits(xa.seed, idx0 >> 2);
+        if ((epi & FITGNN_EPI_DROPOUT) && !mask) bits = fitgnn::dropout_bits(seed, idx0 >> 2);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             float d = gv[i];

@@ -13,7 +13,7 @@ c_i32, c_i64, c_u32, c_u64, c_f32, c_size = (ctypes.c_int32, ctypes.c_int64, cty
                                               ctypes.c_float, ctypes.c_size_t)
 ptr = ctypes.c_void_p
 
-EPI_BIAS, EPI_ELU, EPI_DROPOUT = 1, 2, 4
+EPI_BIAS, EPI_ELU, EPI_DROPOUT, EPI_SEED_DEVICE = 1, 2, 4, 8
 SPMM_GATHER = 0x100
 MAX_K = 16
 

@@ -126,7 +126,7 @@ class Regress_node(_Base):
 class Classify_graph_gc(_Base):
     def forward(self, gc):
         x = self.embed(gc.x, gc.edge_index)
-        return F.softmax(self.head(fnn.global_max_pool(x, gc.batch)), dim=1)
+        return F.softmax(self.head(fnn.global_max_pool(x, gc.batch, getattr(gc, "num_graphs", None))), dim=1)
 
 
 class Regress_graph_gc(_Base):
@@ -134,7 +134,7 @@ class Regress_graph_gc(_Base):
 
     def forward(self, gc):
         x = self.embed(gc.x, gc.edge_index)
-        return self.head(fnn.global_mean_pool(x, gc.batch))
+        return self.head(fnn.global_mean_pool(x, gc.batch, getattr(gc, "num_graphs", None)))
 
 
 def _merge_subgraphs(set_gs, device):
@@ -154,15 +154,20 @@ def _gs_inputs(set_gs, batch_tensor):
     """Reference form (list of per-graph lists of subgraph Data, network.py:120-130) or the pre-merged union a
     fitgnn_amd.graph_data.GraphSet batch carries (dict with x, edge_index, mask)."""
     if isinstance(set_gs, dict):
-        return set_gs["x"], set_gs["edge_index"], set_gs["mask"]
-    return _merge_subgraphs(set_gs, batch_tensor.device)
+        return set_gs["x"], set_gs["edge_index"], set_gs.get("mask_idx", set_gs["mask"]), set_gs.get("n_graphs")
+    return _merge_subgraphs(set_gs, batch_tensor.device) + (None,)
+
+
+def _take(x, mask):
+    """x[mask] for a bool mask, or index_select for a precomputed index (no host sync: usable under graph capture)."""
+    return x.index_select(0, mask) if mask.dtype == torch.int64 else x[mask]
 
 
 class Classify_graph_gs(_Base):
     def forward(self, set_gs, batch_tensor):
-        x, ei, mask = _gs_inputs(set_gs, batch_tensor)
-        x = self.embed(x, ei)[mask]
-        x = self.head(fnn.global_max_pool(x, batch_tensor.to(torch.int64)))
+        x, ei, mask, size = _gs_inputs(set_gs, batch_tensor)
+        x = _take(self.embed(x, ei), mask)
+        x = self.head(fnn.global_max_pool(x, batch_tensor.to(torch.int64), size))
         return F.softmax(x, dim=0 if x.dim() == 1 else 1)
 
 
@@ -170,6 +175,6 @@ class Regress_graph_gs(_Base):
     out_dim_from_classes = False
 
     def forward(self, set_gs, batch_tensor):
-        x, ei, mask = _gs_inputs(set_gs, batch_tensor)
-        x = self.embed(x, ei)[mask]
-        return self.head(fnn.global_mean_pool(x, batch_tensor.to(torch.int64)))
+        x, ei, mask, size = _gs_inputs(set_gs, batch_tensor)
+        x = _take(self.embed(x, ei), mask)
+        return self.head(fnn.global_mean_pool(x, batch_tensor.to(torch.int64), size))

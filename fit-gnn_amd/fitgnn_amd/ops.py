@@ -113,6 +113,7 @@ def spmm_raw(rowptr, col, val, tiles, X, n_rows, bias=None, epilogue=0, p=0.0, s
     L = _lib.lib()
     X = _f32c(X)
     H = X.shape[1]
+    seed, epilogue = _seed_arg(seed, epilogue)
     Y = out if out is not None else torch.empty((n_rows, H), dtype=torch.float32, device=X.device)
     ev = None
     if PROFILE is not None:
@@ -120,7 +121,7 @@ def spmm_raw(rowptr, col, val, tiles, X, n_rows, bias=None, epilogue=0, p=0.0, s
         ev[0].record()
     rc = L.fitgnn_spmm_csr_f32(_lib.dptr(rowptr), _lib.dptr(col), _lib.dptr(val), _lib.dptr(X), X.stride(0) if X.numel() else H,
                                _lib.dptr(Y), Y.stride(0) if Y.numel() else H, n_rows, H, _lib.dptr(tiles), int(tiles.shape[0]),
-                               _lib.dptr(lcol), _lib.dptr(win_cols), _lib.dptr(xrow), int(window_rows), _lib.dptr(bias), epilogue, float(p), int(seed) & 0xFFFFFFFFFFFFFFFF, _lib.dptr(mask),
+                               _lib.dptr(lcol), _lib.dptr(win_cols), _lib.dptr(xrow), int(window_rows), _lib.dptr(bias), epilogue, float(p), seed, _lib.dptr(mask),
                                _lib.stream_ptr(X.device))
     if ev is not None:
         ev[1].record()
@@ -135,12 +136,13 @@ def epilogue_bwd_raw(dOut, out, epilogue, p=0.0, seed=0, mask=None, want_db=True
     L = _lib.lib()
     dOut, out = _f32c(dOut), _f32c(out)
     n, H = dOut.shape
+    seed, epilogue = _seed_arg(seed, epilogue)
     dZ = torch.empty_like(dOut)
     db = torch.empty(H, dtype=torch.float32, device=dOut.device) if want_db else None
     wb = int(L.fitgnn_epilogue_bwd_workspace_bytes(n, H)) if want_db else 0
     work = torch.empty(max(wb, 4), dtype=torch.uint8, device=dOut.device)
     rc = L.fitgnn_epilogue_bwd_f32(_lib.dptr(dOut), _lib.dptr(out), _lib.dptr(dZ), n, H, epilogue, float(p),
-                                   int(seed) & 0xFFFFFFFFFFFFFFFF, _lib.dptr(mask), _lib.dptr(db), _lib.dptr(work), wb,
+                                   seed, _lib.dptr(mask), _lib.dptr(db), _lib.dptr(work), wb,
                                    _lib.stream_ptr(dOut.device))
     _lib.check(rc, "fitgnn_epilogue_bwd_f32")
     return dZ, db
@@ -162,13 +164,14 @@ def epilogue_bwd_head_raw(dy, Wl, out, epilogue, p=0.0, seed=0, mask=None, want_
     dy, Wl, out = _f32c(dy), _f32c(Wl), _f32c(out)
     n, H = out.shape
     C = Wl.shape[0]
+    seed, epilogue = _seed_arg(seed, epilogue)
     dZ = torch.empty_like(out)
     db = torch.empty(H, dtype=torch.float32, device=out.device) if want_db else None
     dWl = torch.empty((C, H), dtype=torch.float32, device=out.device) if want_dWl else None
     wb = int(L.fitgnn_epilogue_bwd_head_workspace_bytes(n, H, C))
     work = torch.empty(max(wb, 4), dtype=torch.uint8, device=out.device)
     rc = L.fitgnn_epilogue_bwd_head_f32(_lib.dptr(dy), _lib.dptr(Wl), C, _lib.dptr(out), _lib.dptr(dZ), n, H, epilogue, float(p),
-                                        int(seed) & 0xFFFFFFFFFFFFFFFF, _lib.dptr(mask), _lib.dptr(db), _lib.dptr(dWl),
+                                        seed, _lib.dptr(mask), _lib.dptr(db), _lib.dptr(dWl),
                                         _lib.dptr(work), wb, _lib.stream_ptr(out.device))
     _lib.check(rc, "fitgnn_epilogue_bwd_head_f32")
     return dZ, db, dWl
@@ -232,9 +235,10 @@ def layer_backward(g, out, epi, p, seed, mask, want_db, dOut=None, dy=None, Wl=N
         if PROFILE is not None:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
+        seed_v, epi_v = _seed_arg(seed, epi)
         rc = L.fitgnn_spmm_epilogue_bwd_f32(_lib.dptr(side.rowptr), _lib.dptr(side.col), _lib.dptr(side.val), _lib.dptr(side.tiles), nt,
                                             g.window_rows, _lib.dptr(dOut), _lib.dptr(dy), _lib.dptr(Wl), C, _lib.dptr(out),
-                                            _lib.dptr(dH), n, H, epi, float(p), int(seed) & 0xFFFFFFFFFFFFFFFF, _lib.dptr(mask),
+                                            _lib.dptr(dH), n, H, epi_v, float(p), seed_v, _lib.dptr(mask),
                                             _lib.dptr(db), _lib.dptr(dWl), _lib.dptr(work), wb, _lib.stream_ptr(dev))
         if ev is not None:
             ev[1].record()
@@ -439,6 +443,42 @@ def head_max_classes():
     return _HEAD_MAX
 
 
+class SeedBank:
+    """Device-resident dropout seeds for steps captured in a hipGraph: kernel arguments are frozen at capture, so the
+    kernels read their seed through a pointer (FITGNN_EPI_SEED_DEVICE) and `advance()` -- itself a kernel of the
+    captured step -- moves every seed on, giving each replay fresh dropout patterns."""
+
+    GOLD = -7046029254386353131  # 0x9E3779B97F4A7C15 as int64 (addition wraps modulo 2^64)
+
+    def __init__(self, n, device):
+        self.seeds = torch.randint(0, 2 ** 62, (n,), dtype=torch.int64).to(device)
+        self.cursor = 0
+
+    def advance(self):
+        self.seeds.add_(self.GOLD)
+        self.cursor = 0
+
+    def take(self):
+        s = self.seeds[self.cursor:self.cursor + 1]
+        self.cursor += 1
+        if self.cursor > self.seeds.numel():
+            raise RuntimeError("SeedBank exhausted: size it for every dropout site of the step")
+        return s
+
+
+SEED_BANK = None  # set to a SeedBank while building / replaying captured steps
+
+
 def next_seed():
-    """Per-call dropout seed drawn from torch's generator (so torch.manual_seed controls it)."""
+    """Per-call dropout seed: drawn from torch's generator (so torch.manual_seed controls it), or -- under a SeedBank --
+    a one-element device tensor the kernels dereference."""
+    if SEED_BANK is not None:
+        return SEED_BANK.take()
     return int(torch.randint(0, 2 ** 62, (1,)).item())
+
+
+def _seed_arg(seed, epilogue):
+    """(integer for the C ABI, epilogue flags): a tensor seed is passed by address with FITGNN_EPI_SEED_DEVICE."""
+    if torch.is_tensor(seed):
+        return int(seed.data_ptr()), int(epilogue) | _lib.EPI_SEED_DEVICE
+    return int(seed) & 0xFFFFFFFFFFFFFFFF, int(epilogue)

@@ -319,7 +319,7 @@ def node_classification(args, path, data, co, device="cuda", log=print):
                 trainer = GDTrainer(model, batch, lr=args.lr, weight_decay=args.weight_decay, reduction=args.loss_reduction)
             else:
                 trainer = MBTrainer(model, batch, batch_size=args.batch_size, lr=args.lr, weight_decay=args.weight_decay,
-                                    reduction=args.loss_reduction)
+                                    reduction=args.loss_reduction, capture=True)  # launch-bound: replayed from hipGraphs
             if args.exp_setup == "Gc_train_2_Gs_train":
                 trainer.opt.load_state_dict(opt.state_dict())  # the reference keeps ONE optimizer across both phases
             best = float("inf")
@@ -399,13 +399,13 @@ def graph_regression(args, path, mol, device="cuda", log=print):
     args.num_classes = 1
     model_gc, model_gs = network.Regress_graph_gc(args).to(device), network.Regress_graph_gs(args).to(device)
     kw = dict(batch_size=args.batch_size, lr=args.lr, weight_decay=args.weight_decay, multi_prop=bool(args.multi_prop),
-              prop=args.property)
-    T = {(m, s): GraphTrainer(model_gc if m == "gc" else model_gs, gset, split[s], kind=m, **kw)
-         for m in ("gc", "gs") for s in ("train", "val", "test")}
-    # one optimiser per model across all phases (run.py:718-719)
-    for m in ("gc", "gs"):
+              prop=args.property, capture=True)  # launch-bound batch steps: replayed from hipGraphs
+    T = {}
+    for m in ("gc", "gs"):   # one optimiser per model across all phases (run.py:718-719)
+        model = model_gc if m == "gc" else model_gs
+        T[(m, "train")] = GraphTrainer(model, gset, split["train"], kind=m, **kw)
         for s in ("val", "test"):
-            T[(m, s)].opt, T[(m, s)].flat = T[(m, "train")].opt, T[(m, "train")].flat
+            T[(m, s)] = GraphTrainer(model, gset, split[s], kind=m, share=T[(m, "train")], **kw)
     ckpt = os.path.join(path, "model.pt")
     best_val, best_test = float("inf"), float("inf")
     setup = args.exp_setup

@@ -71,19 +71,78 @@ class GDTrainer:
         return F.nll_loss(sel, y), (sel.argmax(1) == y).float().mean()
 
 
-class MBTrainer:
+class _CapturedSteps:
+    """Launch-bound step sequences (one optimiser step per small batch) replayed from hipGraphs: each batch's
+    forward + loss + backward + Adam is captured once; dropout seeds live on the device (ops.SeedBank) and are advanced by
+    a kernel inside every captured step.  Users provide self.model / self.opt (capturable Adam) / self.flat and
+    _steps() (the batches) and _one(batch) (one eager step returning the detached loss)."""
+
+    def _build_graphs(self):
+        """Capture one hipGraph per batch (shared memory pool: the graphs replay one after another, in order)."""
+        from . import ops
+
+        dev = self.flat.buf.device
+        self._bank = ops.SeedBank(max(len(self.model.conv), 1), dev)
+        self._losses = torch.zeros(len(self._steps()), device=dev)
+        # warm-up on a side stream (library workspaces, autograd buffers), then put the weights / Adam state back
+        saved_m = {k: v.detach().clone() for k, v in self.model.state_dict().items()}
+        # Adam's moment / step tensors must EXIST before capture (a lazily initialised state would be allocated and
+        # zeroed inside the first captured step, i.e. reset on every replay): warm up, then restore them in place
+        saved_o = {p: {k: (v.clone() if torch.is_tensor(v) else v) for k, v in st.items()} for p, st in self.opt.state.items()}
+        prev, ops.SEED_BANK = ops.SEED_BANK, self._bank
+        try:
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                for b in self._steps()[:2]:
+                    self._bank.advance()
+                    self._one(b)
+            torch.cuda.current_stream(dev).wait_stream(side)
+            torch.cuda.synchronize(dev)
+            self.model.load_state_dict(saved_m)
+            for p, st in self.opt.state.items():
+                for k, v in st.items():
+                    if torch.is_tensor(v):
+                        v.copy_(saved_o[p][k]) if p in saved_o and k in saved_o[p] else v.zero_()
+            self.flat.zero()
+            pool = torch.cuda.graph_pool_handle()
+            self._graphs = []
+            for k, b in enumerate(self._steps()):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, pool=pool):
+                    self._bank.advance()
+                    self._losses[k:k + 1].copy_(self._one(b).view(1))
+                self._graphs.append(g)
+            # capturing does not execute: the weights are untouched, but the gradient buffer was only zeroed eagerly
+            self.flat.zero()
+        finally:
+            ops.SEED_BANK = prev
+
+
+    def _replay(self):
+        if self._graphs is None:
+            self._build_graphs()
+        self.flat.zero()
+        for g in self._graphs:
+            g.replay()
+        return self._losses
+
+
+class MBTrainer(_CapturedSteps):
     """node_train_Gs_MB (run.py:217-252): per epoch ONE zero_grad, then for every loader batch (128 subgraphs,
     run.py:336) that holds a train node: forward, loss over the batch's train nodes, backward, optimiser step.
     The reference never clears the gradients between batches, so batch k steps with the SUM of the gradients of
     batches 0..k of this epoch; reproduced here because it changes the trained weights.
     Sequential by construction: single GPU only."""
 
-    def __init__(self, model, batch, batch_size=128, lr=0.01, weight_decay=5e-4, reduction="mean"):
+    def __init__(self, model, batch, batch_size=128, lr=0.01, weight_decay=5e-4, reduction="mean", capture=False):
         from .csr import CSRGraph, register
 
         self.model, self.reduction = model, reduction
+        self.capture, self._graphs = bool(capture), None
         fused = next(model.parameters()).is_cuda
-        self.opt = torch.optim.Adam(model.parameters(), lr=lr, weight_decay=weight_decay, fused=fused)
+        self.opt = torch.optim.Adam(model.parameters(), lr=lr, weight_decay=weight_decay, fused=fused,
+                                    capturable=bool(capture) and fused)
         self.flat = FlatGrads(model.parameters())
         ei = batch.edge_index
         order = torch.argsort(ei[0], stable=True)
@@ -103,21 +162,29 @@ class MBTrainer:
                                torch.nonzero(tm).flatten()))
         self.n_train = sum(int(p[3].numel()) for p in self.parts)
 
+    def _steps(self):
+        return self.parts
+
+    def _one(self, part):
+        x, e, y, idx = part
+        loss = F.nll_loss(self.model(x, e).index_select(0, idx), y, reduction=self.reduction)
+        loss.backward()           # accumulates into the flat buffer: no zero_grad between batches (run.py:222)
+        self.opt.step()
+        return loss.detach()
+
     def step(self):
-        m = self.model
-        m.train()
+        self.model.train()
+        denom = self.n_loader_batches if self.reduction == "mean" else max(self.n_train, 1)
+        if self.capture and self.flat.buf.is_cuda:
+            return self._replay().sum() / denom
         self.flat.zero()
         total = torch.zeros((), device=self.flat.buf.device)
-        for x, e, y, idx in self.parts:
-            out = m(x, e)
-            loss = F.nll_loss(out.index_select(0, idx), y, reduction=self.reduction)
-            loss.backward()       # accumulates into the flat buffer: no zero_grad between batches (run.py:222)
-            self.opt.step()
-            total += loss.detach()
-        return total / (self.n_loader_batches if self.reduction == "mean" else max(self.n_train, 1))
+        for part in self.parts:
+            total += self._one(part)
+        return total / denom
 
 
-class GraphTrainer:
+class GraphTrainer(_CapturedSteps):
     """graph_train_Gs / graph_train_Gc (run.py:254-269, :288-304) on a fitgnn_amd.graph_data.GraphSet.
 
     Per epoch ONE zero_grad, then per batch of `batch_size` graphs: forward, loss, backward, optimiser step -- the
@@ -128,14 +195,22 @@ class GraphTrainer:
     kind 'gs': model(set_gs, batch_tensor) pools the masked rows of the subgraph union; kind 'gc': model(gc)."""
 
     def __init__(self, model, gset, graphs, kind="gs", batch_size=128, lr=0.01, weight_decay=5e-4, task="graph_reg",
-                 multi_prop=True, prop=0, truncate_targets=True):
+                 multi_prop=True, prop=0, truncate_targets=True, capture=False, share=None):
+        """capture=True: every batch step (forward, loss, backward, Adam) is captured once in a hipGraph and replayed
+        -- the steps are launch-bound (small batches, ~40 kernels each).  Dropout seeds then live on the device
+        (ops.SeedBank) and are advanced by a kernel inside each captured step."""
         import types
 
         self.model, self.kind, self.task, self.multi_prop, self.prop = model, kind, task, multi_prop, prop
         self.truncate = truncate_targets
+        self.capture, self._graphs = bool(capture), None
         fused = next(model.parameters()).is_cuda
-        self.opt = torch.optim.Adam(model.parameters(), lr=lr, weight_decay=weight_decay, fused=fused)
-        self.flat = FlatGrads(model.parameters())
+        if share is not None:   # evaluation-only views of the same model: one optimiser / gradient buffer (run.py:718-719)
+            self.opt, self.flat = share.opt, share.flat
+        else:
+            self.opt = torch.optim.Adam(model.parameters(), lr=lr, weight_decay=weight_decay, fused=fused,
+                                        capturable=bool(capture) and fused)
+            self.flat = FlatGrads(model.parameters())
         graphs = [int(g) for g in graphs]
         self.batches = []
         # contiguous runs of graph ids inside `graphs` are merged into ranges; a batch = list of ranges
@@ -157,15 +232,23 @@ class GraphTrainer:
             return self.model(b, b["graph_of_masked"])
         return self.model(b["gc"])
 
+    def _steps(self):
+        return self.batches
+
+    def _one(self, b):
+        loss = self._loss(self._forward(b), b["y"])
+        loss.backward()
+        self.opt.step()
+        return loss.detach()
+
     def step(self):
         self.model.train()
+        if self.capture and self.flat.buf.is_cuda:
+            return self._replay().sum() / max(len(self.batches), 1)
         self.flat.zero()
         total = torch.zeros((), device=self.flat.buf.device)
         for b in self.batches:
-            loss = self._loss(self._forward(b), b["y"])
-            loss.backward()
-            self.opt.step()
-            total += loss.detach()
+            total += self._one(b)
         return total / max(len(self.batches), 1)
 
     @torch.no_grad()
@@ -204,11 +287,13 @@ def _cat_pieces(pieces, kind, types):
         y = torch.cat([p["y"] for p in pieces])
         if x.is_cuda:
             register(e, CSRGraph(e, int(x.shape[0]), mode="gcn"), "gcn")
-    b = dict(x=x, edge_index=e, mask=mask, y=y)
+    n_graphs = int(y.shape[0])
+    b = dict(x=x, edge_index=e, mask=mask, y=y, n_graphs=n_graphs)
     if kind == "gs":
+        b["mask_idx"] = torch.nonzero(mask).flatten()      # precomputed: x[mask] would synchronise with the host
         b["graph_of_masked"] = graph[mask]
     else:
-        b["gc"] = types.SimpleNamespace(x=x, edge_index=e, batch=graph)
+        b["gc"] = types.SimpleNamespace(x=x, edge_index=e, batch=graph, num_graphs=n_graphs)
     return b
 
 

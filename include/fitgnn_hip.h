@@ -85,6 +85,9 @@ int fitgnn_gcn_norm_csr_f32(const int32_t *rowptr, const int32_t *col, const flo
 #define FITGNN_EPI_BIAS 1u    /* + bias[h]                                   (GCNConv bias) */
 #define FITGNN_EPI_ELU 2u     /* ELU(alpha=1)                                 (network.py:32 F.elu) */
 #define FITGNN_EPI_DROPOUT 4u /* inverted dropout with keep-prob 1-p          (network.py:33 F.dropout) */
+/* the `seed` argument is a DEVICE pointer to the uint64 seed (read by the kernel), not the seed itself: a step
+ * captured in a hipGraph keeps drawing fresh dropout patterns, its seeds are advanced by a kernel of the graph */
+#define FITGNN_EPI_SEED_DEVICE 8u
 /* kernel-variant hint carried in the same word: skip the LDS window, gather operand rows straight from
  * L2/HBM -- faster when rows hold only a few non-zeros (identical results) */
 #define FITGNN_SPMM_GATHER 0x100u

@@ -253,7 +253,7 @@ def _subgraph_batches(seed=0):
     return batch, cpu
 
 
-@pytest.mark.parametrize("method", ["GD", "MB"])
+@pytest.mark.parametrize("method", ["GD", "MB", "MB-captured"])
 def test_trainers_follow_the_reference_step_functions(mods, method):
     """GDTrainer / MBTrainer vs the oracle's restatement of run.py:177-215 / :217-252 over three epochs (dropout off):
     same reported loss and the same weights (MB: including the gradient accumulation across batches)."""
@@ -269,7 +269,7 @@ def test_trainers_follow_the_reference_step_functions(mods, method):
     if method == "GD":
         tr = train.GDTrainer(model, batch, lr=0.01, weight_decay=5e-4)
     else:
-        tr = train.MBTrainer(model, batch, batch_size=8, lr=0.01, weight_decay=5e-4)
+        tr = train.MBTrainer(model, batch, batch_size=8, lr=0.01, weight_decay=5e-4, capture=method.endswith("captured"))
     state = None
     for epoch in range(3):
         got = float(tr.step())
@@ -328,3 +328,33 @@ def test_graph_level_training_follows_the_reference_loops(mods, kind, extra):
         assert got == pytest.approx(want, rel=5e-4), (epoch, got, want)
     for k, v in model.state_dict().items():
         assert rel(v.detach().cpu(), sd[k]) < 3e-3, k
+
+
+@pytest.mark.parametrize("kind", ["gs", "gc"])
+def test_captured_graph_steps_equal_eager_steps(mods, kind):
+    """GraphTrainer(capture=True): every batch step replayed from a hipGraph == the eager steps (dropout off: same
+    losses and weights); with dropout on, successive replays draw different patterns (device-resident seeds)."""
+    from fitgnn_amd import graph_data, train
+
+    network, fnn, gorc = mods
+    mol = graph_data.synthetic_molecules(64, seed=5)
+    gset = graph_data.GraphSet(mol, ratio=0.5, extra_node=True, device="cuda")
+    args = argparse.Namespace(num_layers1=2, layer_name="GCNConv", num_features=11, hidden=32, num_classes=1)
+    cls = network.Regress_graph_gs if kind == "gs" else network.Regress_graph_gc
+    torch.manual_seed(3)
+    m1 = cls(args).cuda()
+    m2 = cls(args).cuda()
+    m2.load_state_dict(m1.state_dict())
+    m1.dropout_p = m2.dropout_p = 0.0
+    t1 = train.GraphTrainer(m1, gset, list(range(64)), kind=kind, batch_size=16, prop=1)
+    t2 = train.GraphTrainer(m2, gset, list(range(64)), kind=kind, batch_size=16, prop=1, capture=True)
+    for epoch in range(3):
+        a, b = float(t1.step()), float(t2.step())
+        assert a == pytest.approx(b, rel=1e-5), (epoch, a, b)
+    for (k, v), (_, w) in zip(m1.state_dict().items(), m2.state_dict().items()):
+        assert rel(w, v) < 1e-4, k
+    # dropout on: two replays of the same captured step must not repeat the pattern
+    m2.dropout_p = 0.5
+    t3 = train.GraphTrainer(m2, gset, list(range(16)), kind=kind, batch_size=16, prop=1, capture=True, lr=0.0)
+    l1, l2 = float(t3.step()), float(t3.step())
+    assert l1 != l2

@@ -19,5 +19,11 @@ tr = train.GraphTrainer(model, gset, list(range(n // 2)), kind="gs", batch_size=
 print(f"trainer ({len(tr.batches)} batches of 128 graphs, CSR per batch): {t3 - t2:.1f} s", flush=True)
 tr.step(); torch.cuda.synchronize()
 t4 = time.time(); l = float(tr.step()); torch.cuda.synchronize(); t5 = time.time()
+model2 = network.Regress_graph_gs(args).cuda()
+tc = time.time(); tr2 = train.GraphTrainer(model2, gset, list(range(n // 2)), kind="gs", batch_size=128, lr=0.001, capture=True)
+tr2.step(); torch.cuda.synchronize(); tc1 = time.time()
+tr2.step(); torch.cuda.synchronize()
+tc2 = time.time(); l2 = float(tr2.step()); torch.cuda.synchronize(); tc3 = time.time()
+print(f"hipGraph-captured steps: build + capture {tc1 - tc:.1f} s; epoch {tc3 - tc2:.3f} s -> {(n // 2) / (tc3 - tc2):.0f} graphs/s, loss {l2:.4f}", flush=True)
 nnzp = int(gset.gs_edge_index.shape[1] * 0.5) + int(gset.sub_ptr[gset.cluster_ptr[n // 2]])
 print(f"epoch (Gs, {n // 2} graphs): {t5 - t4:.2f} s -> {(n // 2) / (t5 - t4):.0f} graphs/s, loss {l:.4f}", flush=True)
