@@ -105,6 +105,60 @@ def _spectral_level1(G, K, Uk, lk):
     return Uk @ np.diag(lsinv)
 
 
+def lanczos_smallest(L, K, device="cuda", tol=1e-5, m=None, max_restarts=300, seed=0):
+    """The K smallest eigenpairs of the graph Laplacian L on the device: thick-restart Lanczos with full (two-pass)
+    reorthogonalisation in float64 on T = 2 max(diag L) I - L, the shifted operator the reference hands to ARPACK
+    (coarsening_utils.py:83-90), same relative tolerance.  SURVEY §8 f4: 42 % of the reference's coarsening time is this
+    solve.  Returns (lk ascending, Uk) as NumPy arrays, the (lk, Uk) coarsen() accepts."""
+    dev = torch.device(device)
+    Lc = sp.csr_matrix(L).astype(np.float64)
+    N = Lc.shape[0]
+    offset = 2.0 * float(Lc.diagonal().max())
+    T = (offset * sp.eye(N, format="csr") - Lc).tocsr()
+    Td = torch.sparse_csr_tensor(torch.from_numpy(T.indptr.astype(np.int64)).to(dev), torch.from_numpy(T.indices.astype(np.int64)).to(dev),
+                                 torch.from_numpy(T.data).to(dev), size=(N, N))
+    m = int(m or min(N - 1, max(4 * K + 20, 60)))
+    K = min(K, m - 1)
+    gen = torch.Generator(device="cpu").manual_seed(seed)
+    V = torch.zeros(N, m + 1, dtype=torch.float64, device=dev)
+    v = torch.randn(N, generator=gen, dtype=torch.float64).to(dev)
+    V[:, 0] = v / v.norm()
+    H = torch.zeros(m + 1, m, dtype=torch.float64, device=dev)
+    j0 = 0
+    for _ in range(max_restarts):
+        for j in range(j0, m):
+            w = (Td @ V[:, j:j + 1]).squeeze(1)
+            Vj = V[:, :j + 1]
+            h = Vj.T @ w
+            w = w - Vj @ h
+            h2 = Vj.T @ w
+            w = w - Vj @ h2
+            H[:j + 1, j] = h + h2
+            beta = w.norm()
+            H[j + 1, j] = beta
+            V[:, j + 1] = w / beta.clamp(min=1e-300)
+        Hm = (H[:m, :m] + H[:m, :m].T) / 2
+        theta, S = torch.linalg.eigh(Hm)
+        order = torch.argsort(theta, descending=True)
+        idx = order[:K]
+        resid = (H[m, m - 1] * S[m - 1, idx]).abs()
+        if float(resid.max()) <= tol * float(theta.abs().max()):
+            break
+        keep = order[:min(K + 5, m - 2)]
+        nk = int(keep.numel())
+        Vn = torch.zeros_like(V)
+        Vn[:, :nk] = V[:, :m] @ S[:, keep]
+        Vn[:, nk] = V[:, m]
+        Hn = torch.zeros_like(H)
+        Hn[:nk, :nk] = torch.diag(theta[keep])
+        Hn[nk, :nk] = H[m, m - 1] * S[m - 1, keep]
+        V, H, j0 = Vn, Hn, nk
+    lk = (offset - theta[idx]).cpu().numpy()
+    Uk = (V[:, :m] @ S[:, idx]).cpu().numpy()
+    o = np.argsort(lk)
+    return lk[o], np.ascontiguousarray(Uk[:, o])
+
+
 def _spectral_next(G, iC, B):
     B = iC.dot(B)
     d, V = np.linalg.eig(B.T @ (G.L).dot(B))
@@ -264,7 +318,7 @@ class CoarseningMatrix(sp.csc_matrix):
 # the drop-in driver
 # ---------------------------------------------------------------------------------------------
 def coarsen(G, K=10, r=0.5, max_levels=10, method="variation_neighborhood", algorithm="greedy", Uk=None, lk=None,
-            max_level_r=0.99, device="cuda"):
+            max_level_r=0.99, device="cuda", spectral="arpack"):
     """Same contract as graph_coarsening.coarsening_utils.coarsen (coarsening_utils.py:18-182) for
     method in {'variation_neighborhood', 'variation_neighborhoods'}: returns (C, Gc, mapping_dict_list)."""
     if "variation_neighborhood" not in method:
@@ -287,6 +341,8 @@ def coarsen(G, K=10, r=0.5, max_levels=10, method="variation_neighborhood", algo
         G = Gc
         r_cur = np.clip(1 - n_target / n, 0.0, max_level_r)
         if level == 1:
+            if spectral == "device" and Uk is None and G.N > 4 * K:  # extension: the eigensolve on the MI355X
+                lk, Uk = lanczos_smallest(G.L, K, device=dev)
             B = _spectral_level1(G, K, Uk, lk)
             A = B
         else:

@@ -172,3 +172,24 @@ def test_batched_coarsening_equals_the_reference_per_component(mods, r):
     assert out.Wc[:, :].nnz == sum(out.Wc[int(out.cluster_off[c]):int(out.cluster_off[c + 1]),
                                           int(out.cluster_off[c]):int(out.cluster_off[c + 1])].nnz for c in range(len(gs)))
     assert Cb.shape == (out.n_clusters, W.shape[0])
+
+
+def test_device_eigensolver_feeds_the_contraction(mods):
+    """lanczos_smallest (thick-restart Lanczos on the device) == ARPACK's eigenvalues to the tolerance the
+    reference asks for; coarsen(spectral='device') returns a valid partition of the requested size."""
+    import scipy.sparse.linalg as spla
+
+    _lib, co, orc = mods
+    g = G("cora_giant")
+    Gr = co.Graph(g.W)
+    lk, Uk = co.lanczos_smallest(Gr.L, 10)
+    offset = 2 * max(Gr.dw)
+    ref = np.sort(offset - spla.eigsh((offset * sp.eye(g.N, format="csc") - Gr.L), k=10, which="LM", tol=1e-5,
+                                      v0=np.ones(g.N))[0])
+    assert np.abs(lk - ref).max() < 1e-4 * offset
+    R = Gr.L @ Uk - Uk * lk
+    assert np.abs(R).max() < 1e-3 * offset and np.abs(Uk.T @ Uk - np.eye(10)).max() < 1e-8
+    C, Gc, maps = co.coarsen(Gr, r=0.5, method="variation_neighborhoods", spectral="device")
+    Cc = sp.csc_matrix(C)
+    assert np.all(np.diff(Cc.indptr) == 1) and Cc.shape[0] == int(np.ceil(0.5 * g.N))
+    assert np.allclose(np.asarray(Cc.power(2).sum(1)).ravel(), 1.0)
