@@ -170,6 +170,11 @@ def main(argv=None):
                                                 device=args.device)  # main.py:278 passes 1 - rho as Loukas' r
         print(f"coarsened {data.num_nodes} nodes in {len(co.components)} components into {co.n_clusters} clusters")
         res = pipeline.node_classification(args, path, data, co, device=args.device)
+        # main.py:279 `save(...)`: the subgraph union as a flat, memory-mappable artefact (fitgnn_amd.store)
+        from fitgnn_amd import store
+        store.save_gs(store.artefact_dir(f"./dataset/{args.dataset}/saved/{args.coarsening_method}", args),
+                      pipeline.build_gs(args, pipeline.splits_classification(data, args.num_classes, args.experiment,
+                                                                             np.random.default_rng(args.seed)), co, args.device), co)
         write_results(args, *res, baseline=False)
     return res
 

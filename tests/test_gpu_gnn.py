@@ -358,3 +358,25 @@ def test_captured_graph_steps_equal_eager_steps(mods, kind):
     t3 = train.GraphTrainer(m2, gset, list(range(16)), kind=kind, batch_size=16, prop=1, capture=True, lr=0.0)
     l1, l2 = float(t3.step()), float(t3.step())
     assert l1 != l2
+
+
+def test_flat_artefact_round_trip(mods, tmp_path):
+    """store.save_gs / load_gs: the subgraph union written as flat .npy arrays and mapped back gives the same batch
+    (rows, edges, features, labels, masks) and the same model output."""
+    from fitgnn_amd import store
+
+    network, fnn, gorc = mods
+    batch, _ = _subgraph_batches(seed=4)
+    store.save_gs(str(tmp_path / "a"), batch, extra_meta={"dataset": "t"})
+    got, meta = store.load_gs(str(tmp_path / "a"))
+    assert meta["format"] == store.FORMAT and meta["n_rows"] == batch.n_rows and meta["dataset"] == "t"
+    assert np.array_equal(got.ptr, batch.ptr)
+    for k in ("node_id", "core", "y", "train_mask", "train_idx", "x"):
+        assert torch.equal(getattr(got, k), getattr(batch, k)), k
+    ea = set(map(tuple, batch.edge_index.t().tolist())); eb = set(map(tuple, got.edge_index.t().tolist()))
+    assert ea == eb
+    args = argparse.Namespace(num_layers1=2, layer_name="GCNConv", num_features=24, hidden=32, num_classes=4)
+    torch.manual_seed(0)
+    model = network.Classify_node(args).cuda().eval()
+    with torch.no_grad():
+        assert torch.allclose(model(batch.x, batch.edge_index), model(got.x, got.edge_index), rtol=1e-5, atol=1e-6)
