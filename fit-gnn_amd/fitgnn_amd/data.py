@@ -229,7 +229,7 @@ class SubgraphBatch:
     The reference trains in GD mode by forwarding every 128-subgraph batch and summing ONE loss over all of
     them (run.py:184-204); subgraphs share no edges, so one union pass is the same arithmetic."""
 
-    def __init__(self, sub, X, y, train_mask, device="cuda", lds_rows=None, dedup=True):
+    def __init__(self, sub, X, y, train_mask, device="cuda", lds_rows=None, dedup=True, float_targets=False):
         """dedup: keep ONE copy of every original node's features on the device (`x_table`, `row_index`) next to the
         materialised union rows `x`; models that accept `x_index` then run their first layer on the table."""
         dev = torch.device(device)
@@ -248,7 +248,7 @@ class SubgraphBatch:
             self.x_table = Xd.contiguous()
             self.row_index = RowIndex(self.node_id, Xd.shape[0])
         y = y if torch.is_tensor(y) else torch.from_numpy(np.asarray(y))
-        self.y = y.to(dev)[self.node_id].long()
+        self.y = y.to(dev)[self.node_id].float() if float_targets else y.to(dev)[self.node_id].long()
         tm = train_mask if torch.is_tensor(train_mask) else torch.from_numpy(np.asarray(train_mask))
         self.train_mask = tm.to(dev)[self.node_id] & self.core          # utils.py:695-698
         self.train_idx = torch.nonzero(self.train_mask).flatten()

@@ -445,3 +445,108 @@ def graph_regression(args, path, mol, device="cuda", log=print):
                 f"{args.epochs2},{args.batch_size},{args.lr},{best_test}" + (f",{args.property}" if args.multi_prop else "") + "\n")
     log(f"best_test_loss: {best_test}")
     return best_test
+
+
+# ---------------------------------------------------------------------------------------------
+# node regression (chameleon / squirrel / crocodile shaped): run.node_regression, run.py:508-573
+# ---------------------------------------------------------------------------------------------
+SYNTHETIC_REG_SHAPES = {  # name: (N, E, F)   dataset_info.csv:8-10
+    "synthetic-chameleon": (2277, 31396, 128),
+    "synthetic-squirrel": (5201, 198423, 128),
+    "synthetic-crocodile": (11631, 170845, 128),
+}
+
+
+def synthetic_regression_dataset(name, seed=0):
+    """Seeded stand-in of a WikipediaNetwork node-regression dataset's shape (geom_gcn_preprocess=False: the target is
+    the log of the page traffic, a float per node): target = a linear readout of the features averaged over the closed
+    neighbourhood (what one propagation step can represent) plus noise."""
+    N, E, Fdim = SYNTHETIC_REG_SHAPES[name]
+    rng = np.random.default_rng(seed)
+    ei = fdata.synthetic_graph(N, E, seed=seed)
+    W = sp.csr_matrix((np.ones(ei.shape[1]), (ei[0], ei[1])), shape=(N, N))
+    x = rng.standard_normal((N, Fdim)).astype(np.float32)
+    deg = np.asarray(W.sum(1)).ravel()
+    z = x[:, :16] @ rng.standard_normal(16)                            # a linear readout of the features ...
+    z = (z + np.asarray(W @ z).ravel()) / (deg + 1)                # ... averaged over the closed neighbourhood
+    y = (2.0 + 3.0 * (z - z.mean()) / z.std() + 0.1 * rng.standard_normal(N)).astype(np.float32)
+    return NodeData(torch.from_numpy(x), ei, torch.from_numpy(y), None, None, None)
+
+
+def splits_regression(data, train_ratio, val_ratio, rng):
+    """utils.py:645-659: random node permutation cut at train_ratio / train_ratio + val_ratio."""
+    if train_ratio + val_ratio >= 1:
+        raise ValueError("train_ratio + val_ratio should be less than 1")
+    N = data.x.shape[0]
+    perm = torch.from_numpy(rng.permutation(N))
+    n_tr, n_va = int(train_ratio * N), int(val_ratio * N)
+    masks = []
+    for idx in (perm[:n_tr], perm[n_tr:n_tr + n_va], perm[n_tr + n_va:]):
+        m = torch.zeros(N, dtype=torch.bool)
+        m[idx] = True
+        masks.append(m)
+    data.train_mask, data.val_mask, data.test_mask = masks
+    return data
+
+
+@torch.no_grad()
+def infer_gs_regression(model, batch, idx):
+    """node_infer_Gs_GD for node_reg (run.py:106-115): L1 over the selected nodes divided by the std of their labels."""
+    model.eval()
+    torch.cuda.synchronize()
+    t0 = time.time()
+    out = model(batch.x, batch.edge_index)
+    torch.cuda.synchronize()
+    dt = time.time() - t0
+    sel, y = out.index_select(0, idx).flatten(), batch.y.index_select(0, idx).flatten()
+    return float(F.l1_loss(sel, y) / y.std(unbiased=False)), 0.0, dt
+
+
+def node_regression(args, path, data, co, device="cuda", log=print):
+    """run.node_regression (run.py:508-573): Regress_node trained on Gs only (GD or MB), L1 loss, best-val checkpoint."""
+    rng = np.random.default_rng(args.seed)
+    data = splits_regression(data, args.train_ratio, args.val_ratio, rng)
+    N, n = data.num_nodes, co.n_clusters
+    if getattr(args, "cluster_node", False):
+        raise NotImplementedError("--cluster_node for node regression is not built; use --extra_node or neither")
+    ei_dev = torch.as_tensor(np.asarray(data.edge_index)).to(device)
+    sub = fdata.assemble_subgraphs_torch(ei_dev, N, co.assign, n, extra_node=bool(getattr(args, "extra_node", False)))
+    batch = fdata.SubgraphBatch(sub, data.x, data.y.flatten(), data.train_mask, device=device, float_targets=True)
+    batch.val_idx = torch.nonzero(data.val_mask.to(device)[batch.node_id] & batch.core).flatten()
+    batch.test_idx = torch.nonzero(data.test_mask.to(device)[batch.node_id] & batch.core).flatten()
+    all_loss, all_time = [], []
+    ckpt = os.path.join(path, "model.pt")
+    args.num_classes = 1
+    for run in range(args.runs):
+        if args.seed is not None:
+            torch.manual_seed(args.seed + run)
+        model = network.Regress_node(args).to(device)
+        model.reset_parameters()
+        if args.gradient_method == "GD":
+            trainer = GDTrainer(model, batch, lr=args.lr, weight_decay=args.weight_decay, reduction=args.loss_reduction, task="node_reg")
+        else:
+            raise NotImplementedError("node regression: --gradient_method GD only")
+        best = float("inf")
+        for epoch in range(args.epochs2):
+            trainer.step()
+            vloss, _, _ = infer_gs_regression(model, batch, batch.val_idx)
+            if vloss < best or epoch == 0:
+                best = vloss
+                torch.save(model.state_dict(), ckpt)
+        model.load_state_dict(torch.load(ckpt))
+        tloss, _, ttime = infer_gs_regression(model, batch, batch.test_idx)
+        log(f"run {run + 1}: test_loss {tloss:.4f} infer_time {ttime * 1e3:.2f} ms")
+        all_loss.append(tloss); all_time.append(ttime)
+    top = sorted(all_loss)[:10]
+    os.makedirs("results", exist_ok=True)
+    fn = f"results/{args.dataset}.csv"
+    if not os.path.exists(fn):
+        with open(fn, "w") as f:
+            f.write("dataset,coarsening_method,coarsening_ratio,layer_name,extra_nodes,cluster_node,community_used,hidden,runs,num_layers,"
+                    "batch_size,lr,ave_time,top_10_loss,best_loss\n")
+    with open(fn, "a") as f:
+        f.write(f"{args.dataset},{args.coarsening_method},{args.coarsening_ratio},{args.layer_name},{args.extra_node},{args.cluster_node},"
+                f"{args.use_community_detection},{args.hidden},{args.runs},{args.num_layers1},{args.batch_size},{args.lr},{np.mean(all_time)},"
+                f"{np.mean(top)} +/- {np.std(top)},{top[0]}\n")
+    log(f"top_10_loss: {np.mean(top)} +/- {np.std(top)}  best_loss: {top[0]}")
+    return all_loss, all_time

@@ -28,8 +28,10 @@ class FlatGrads:
 
 
 class GDTrainer:
-    def __init__(self, model, batch, lr=0.01, weight_decay=5e-4, reduction="mean", process_group=None, dedup=True):
-        self.model, self.batch = model, batch
+    def __init__(self, model, batch, lr=0.01, weight_decay=5e-4, reduction="mean", process_group=None, dedup=True,
+                 task="node_cls"):
+        """task 'node_cls': NLLLoss on log-probabilities (run.py:341); 'node_reg': L1Loss on the [n, 1] outputs (run.py:518)."""
+        self.model, self.batch, self.task = model, batch, task
         # first layer on the de-duplicated feature table when the batch carries one (same arithmetic, fewer FLOPs)
         self.dedup = dedup and getattr(batch, "row_index", None) is not None
         # fused=True: one multi-tensor kernel for the whole update (same arithmetic as the reference's torch.optim.Adam)
@@ -52,7 +54,10 @@ class GDTrainer:
         self.flat.zero()  # optimizer.zero_grad(); grads live in the flat buffer
         out = m(b.x_table, b.edge_index, x_index=b.row_index) if self.dedup else m(b.x, b.edge_index)
         sel = out.index_select(0, b.train_idx)
-        loss_sum = F.nll_loss(sel, b.y.index_select(0, b.train_idx), reduction="sum")
+        if self.task == "node_reg":
+            loss_sum = F.l1_loss(sel.view(-1, 1), b.y.index_select(0, b.train_idx).view(-1, 1), reduction="sum")
+        else:
+            loss_sum = F.nll_loss(sel, b.y.index_select(0, b.train_idx), reduction="sum")
         scale = 1.0 / self.global_count if self.reduction == "mean" else 1.0
         loss = loss_sum * scale
         loss.backward()

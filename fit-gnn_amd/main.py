@@ -7,6 +7,7 @@ row appended to results/<dataset>.csv (results/baseline/<dataset>.csv) with the 
 (run.py:480-485, :883-887).  Node-classification tasks only in this round (the hot path BASELINE.json names).
 
 Datasets: the reference downloads through torch_geometric / ogb, which are not available here.  Accepted:
+  synthetic-{chameleon,squirrel,crocodile}   node-regression stand-ins (dataset_info.csv:8-10)
   synthetic-qm9              QM9-shaped graph regression stand-in (--n_graphs molecules of ~18 nodes, 19 targets)
   cora | citeseer | pubmed   Planetoid raw files `ind.<name>.*` under --data_root/<name>/raw (PyG's own layout)
   synthetic-{cora,citeseer,pubmed,physics}   seeded stand-ins of the same shape (dataset_info.csv)
@@ -91,6 +92,12 @@ def process_dataset(args):
         args.task, args.multi_prop = 'graph_reg', True
         args.num_features = mol["x"].shape[1]
         return mol, args
+    if name in pipeline.SYNTHETIC_REG_SHAPES:  # main.py:71-85: WikipediaNetwork datasets are node regression
+        data = pipeline.synthetic_regression_dataset(name, seed=0 if args.seed is None else args.seed)
+        if args.normalize_features:
+            data.x = torch.nn.functional.normalize(data.x, p=1)
+        args.task, args.num_features, args.num_classes = 'node_reg', data.x.shape[1], 1
+        return data, args
     if name in pipeline.SYNTHETIC_SHAPES:
         data, n_classes = pipeline.synthetic_dataset(name, seed=0 if args.seed is None else args.seed)
         if args.experiment == 'fixed':
@@ -158,6 +165,11 @@ def main(argv=None):
     os.makedirs(path, exist_ok=True)
     if args.use_community_detection:
         raise NotImplementedError("--use_community_detection needs igraph/leidenalg (main.py:247-267), not available here")
+    if args.task == 'node_reg':
+        if args.baseline:
+            raise NotImplementedError("node-regression baseline (run.py:904-) is outside the hot path")
+        co = pipeline.coarsening_classification(args, data, 1 - args.coarsening_ratio, args.coarsening_method, device=args.device)
+        return pipeline.node_regression(args, path, data, co, device=args.device)
     if args.task == 'graph_reg':
         if args.baseline:
             raise NotImplementedError("graph-level baselines (run.py:904-) are outside the hot path")
