@@ -57,6 +57,38 @@ def synthetic_molecules(n_graphs, seed=0, n_features=11, n_targets=19):
     return dict(node_ptr=node_ptr, edge_index=ei, x=x, y=y)
 
 
+def synthetic_graph_classes(n_graphs, seed=0, n_features=3, n_classes=2, mean_nodes=19):
+    """TU-dataset-shaped stand-in (PROTEINS: 1113 graphs, ~19 nodes (csv shows halved counts), 3 node labels, 2
+    classes; dataset_info.csv:11): the class sets the chord density and the node-label distribution, so both structure and
+    features carry signal.  Same dict as synthetic_molecules with integer class labels in y [G, 1]."""
+    rng = np.random.default_rng(seed)
+    cls = rng.integers(0, n_classes, size=n_graphs)
+    n = np.clip(np.rint(rng.normal(mean_nodes, 4, size=n_graphs)), 4, 3 * mean_nodes).astype(np.int64)
+    node_ptr = np.zeros(n_graphs + 1, dtype=np.int64)
+    np.cumsum(n, out=node_ptr[1:])
+    src, dst, xs = [], [], []
+    for g in range(n_graphs):
+        k, o, c = int(n[g]), int(node_ptr[g]), int(cls[g])
+        ring = np.arange(k)
+        und = {(min(a, b), max(a, b)) for a, b in zip(ring, np.roll(ring, -1)) if a != b}
+        want = len(und) + int(round(k * (0.3 + 0.9 * c / max(n_classes - 1, 1))))
+        tries = 0
+        while len(und) < want and tries < 8 * want:
+            a, b = rng.integers(0, k, size=2)
+            tries += 1
+            if a != b:
+                und.add((min(a, b), max(a, b)))
+        u = np.array(sorted(und), dtype=np.int64) + o
+        src += [u[:, 0], u[:, 1]]
+        dst += [u[:, 1], u[:, 0]]
+        p = np.full(n_features, 1.0)
+        p[c % n_features] += 2.0
+        xs.append(np.eye(n_features, dtype=np.float32)[rng.choice(n_features, size=k, p=p / p.sum())])
+    ei = np.stack([np.concatenate(src), np.concatenate(dst)])
+    ei = ei[:, np.lexsort((ei[1], ei[0]))]
+    return dict(node_ptr=node_ptr, edge_index=ei, x=np.concatenate(xs), y=cls.reshape(-1, 1).astype(np.float32))
+
+
 class GraphSet:
     """All graphs of a graph-level dataset, coarsened and assembled once, resident on the device.
 

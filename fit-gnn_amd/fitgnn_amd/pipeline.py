@@ -383,9 +383,10 @@ def node_classification_baseline(args, path, data, device="cuda", log=print):
 
 
 def graph_regression(args, path, mol, device="cuda", log=print):
-    """run.graph_regression (run.py:707-830) on a graph_data.GraphSet: 50/25/25 split of a random permutation
-    (utils.py:23-39), Regress_graph_gc / Regress_graph_gs, L1 loss, the four exp_setups, best-val checkpoint, and the
-    reference's results row.  Returns best_test_loss."""
+    """run.graph_regression (run.py:707-830) / run.graph_classification (run.py:575-706) on a graph_data.GraphSet:
+    50/25/25 split of a random permutation (utils.py:23-39), {Regress,Classify}_graph_gc / _gs, L1 / cross-entropy
+    loss, the four exp_setups, best-val checkpoint, and the reference's results row.  Returns best_test_loss
+    (graph_cls: (best_test_loss, best_test_acc))."""
     from . import graph_data
     from .train import GraphTrainer
 
@@ -396,10 +397,15 @@ def graph_regression(args, path, mol, device="cuda", log=print):
     gen = torch.Generator().manual_seed(0 if args.seed is None else args.seed)
     idx = torch.randperm(G, generator=gen).tolist()
     split = {"train": idx[: G // 2], "val": idx[G // 2: 3 * G // 4], "test": idx[3 * G // 4:]}
-    args.num_classes = 1
-    model_gc, model_gs = network.Regress_graph_gc(args).to(device), network.Regress_graph_gs(args).to(device)
+    cls_task = args.task == "graph_cls"
+    if cls_task:
+        model_gc, model_gs = network.Classify_graph_gc(args).to(device), network.Classify_graph_gs(args).to(device)
+    else:
+        args.num_classes = 1
+        model_gc, model_gs = network.Regress_graph_gc(args).to(device), network.Regress_graph_gs(args).to(device)
     kw = dict(batch_size=args.batch_size, lr=args.lr, weight_decay=args.weight_decay, multi_prop=bool(args.multi_prop),
-              prop=args.property, capture=True)  # launch-bound batch steps: replayed from hipGraphs
+              prop=args.property, capture=True, task=args.task,   # launch-bound batch steps: replayed from hipGraphs
+              truncate_targets=True)
     T = {}
     for m in ("gc", "gs"):   # one optimiser per model across all phases (run.py:718-719)
         model = model_gc if m == "gc" else model_gs
@@ -407,13 +413,15 @@ def graph_regression(args, path, mol, device="cuda", log=print):
         for s in ("val", "test"):
             T[(m, s)] = GraphTrainer(model, gset, split[s], kind=m, share=T[(m, "train")], **kw)
     ckpt = os.path.join(path, "model.pt")
-    best_val, best_test = float("inf"), float("inf")
+    best_val, best_test, best_acc = float("inf"), float("inf"), 0.0
     setup = args.exp_setup
 
     def consider(epoch, val, test, model):
-        nonlocal best_val, best_test
+        nonlocal best_val, best_test, best_acc
         if val < best_val or epoch == 0:
             best_val, best_test = val, test
+            if cls_task and np.isfinite(test):
+                best_acc = T[("gc" if model is model_gc and setup == "Gc_train_2_Gc_infer" else "gs", "test")].accuracy()
             torch.save(model.state_dict(), ckpt)
 
     if setup in ("Gc_train_2_Gs_train", "Gc_train_2_Gc_infer", "Gc_train_2_Gs_infer"):
@@ -438,13 +446,15 @@ def graph_regression(args, path, mol, device="cuda", log=print):
     if not os.path.exists(fn):
         with open(fn, "w") as f:
             f.write("dataset,coarsening_method,coarsening_ratio,exp_setup,layer_name,extra_nodes,cluster_node,community_used,hidden,"
-                    "num_layers1,num_layers2,epochs1,epochs2,batch_size,lr,best_test_loss" + (",property_idx}" if args.multi_prop else "") + "\n")
+                    "num_layers1,num_layers2,epochs1,epochs2,batch_size,lr,best_test_loss"
+                    + (",best_test_acc" if cls_task else (",property_idx}" if args.multi_prop else "")) + "\n")
+    tail = f",{best_acc}" if cls_task else (f",{args.property}" if args.multi_prop else "")
     with open(fn, "a") as f:
         f.write(f"{args.dataset},{args.coarsening_method},{args.coarsening_ratio},{args.exp_setup},{args.layer_name},{args.extra_node},"
                 f"{args.cluster_node},{args.use_community_detection},{args.hidden},{args.num_layers1},{args.num_layers2},{args.epochs1},"
-                f"{args.epochs2},{args.batch_size},{args.lr},{best_test}" + (f",{args.property}" if args.multi_prop else "") + "\n")
-    log(f"best_test_loss: {best_test}")
-    return best_test
+                f"{args.epochs2},{args.batch_size},{args.lr},{best_test}" + tail + "\n")
+    log(f"best_test_loss: {best_test}" + (f"  best_test_acc: {best_acc}" if cls_task else ""))
+    return (best_test, best_acc) if cls_task else best_test
 
 
 # ---------------------------------------------------------------------------------------------

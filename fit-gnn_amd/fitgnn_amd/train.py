@@ -230,6 +230,7 @@ class GraphTrainer(_CapturedSteps):
         if self.task == "graph_reg":
             tgt = (y[:, self.prop].view(-1, 1) if self.multi_prop else y).to(out.dtype)
             return F.l1_loss(out, tgt)
+        # graph_cls: CrossEntropyLoss on the model's SOFTMAX output (run.py:583 on network.py:94,133: a double softmax, kept)
         return F.cross_entropy(out, y.long().flatten())
 
     def _forward(self, b):
@@ -269,6 +270,17 @@ class GraphTrainer(_CapturedSteps):
         if self.task == "graph_reg" and self.kind == "gs":
             total = total / torch.cat(labels).float().std()
         return total / max(len(self.batches), 1)
+
+    @torch.no_grad()
+    def accuracy(self):
+        """graph_cls accuracy over ALL graphs of the split (the reference reports the last batch's only, run.py:284,324)."""
+        self.model.eval()
+        hit = n = 0
+        for b in self.batches:
+            pred = self._forward(b).argmax(1)
+            hit += int((pred == b["y"].long().flatten()).sum())
+            n += int(pred.numel())
+        return hit / max(n, 1)
 
 
 def _is_range(ids):

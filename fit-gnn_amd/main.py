@@ -8,6 +8,7 @@ row appended to results/<dataset>.csv (results/baseline/<dataset>.csv) with the 
 
 Datasets: the reference downloads through torch_geometric / ogb, which are not available here.  Accepted:
   synthetic-{chameleon,squirrel,crocodile}   node-regression stand-ins (dataset_info.csv:8-10)
+  synthetic-proteins         PROTEINS-shaped graph classification stand-in (--n_graphs graphs, 2 classes)
   synthetic-qm9              QM9-shaped graph regression stand-in (--n_graphs molecules of ~18 nodes, 19 targets)
   cora | citeseer | pubmed   Planetoid raw files `ind.<name>.*` under --data_root/<name>/raw (PyG's own layout)
   synthetic-{cora,citeseer,pubmed,physics}   seeded stand-ins of the same shape (dataset_info.csv)
@@ -86,6 +87,12 @@ def process_dataset(args):
     from fitgnn_amd import pipeline
 
     name = args.dataset
+    if name == 'synthetic-proteins':  # main.py:86-99: TU datasets are graph classification
+        from fitgnn_amd import graph_data
+        mol = graph_data.synthetic_graph_classes(args.n_graphs, seed=0 if args.seed is None else args.seed)
+        args.task, args.multi_prop = 'graph_cls', False
+        args.num_features, args.num_classes = mol["x"].shape[1], 2
+        return mol, args
     if name == 'synthetic-qm9':  # QM9-shaped stand-in (main.py:105-108: task graph_reg, multi_prop forced on)
         from fitgnn_amd import graph_data
         mol = graph_data.synthetic_molecules(args.n_graphs, seed=0 if args.seed is None else args.seed)
@@ -170,7 +177,7 @@ def main(argv=None):
             raise NotImplementedError("node-regression baseline (run.py:904-) is outside the hot path")
         co = pipeline.coarsening_classification(args, data, 1 - args.coarsening_ratio, args.coarsening_method, device=args.device)
         return pipeline.node_regression(args, path, data, co, device=args.device)
-    if args.task == 'graph_reg':
+    if args.task in ('graph_reg', 'graph_cls'):
         if args.baseline:
             raise NotImplementedError("graph-level baselines (run.py:904-) are outside the hot path")
         return pipeline.graph_regression(args, path, data, device=args.device)

@@ -138,3 +138,18 @@ def test_cli_node_regression_on_synthetic_chameleon(tmp_path, monkeypatch):
     assert losses[0] < 0.76, losses  # constant predictor: ~0.80
     rows = open("results/synthetic-chameleon.csv").read().strip().split("\n")
     assert rows[0].startswith("dataset,coarsening_method,coarsening_ratio,layer_name") and len(rows) == 2
+
+
+@pytest.mark.gpu
+def test_cli_graph_classification_on_synthetic_proteins(tmp_path, monkeypatch):
+    """main.py graph classification (run.py:575-706) on a PROTEINS-shaped stand-in: Classify_graph_gc / _gs with the
+    reference's softmax + CrossEntropyLoss, results row with best_test_acc; both classes are separable by structure and
+    node labels, so accuracy must clear chance."""
+    monkeypatch.chdir(tmp_path)
+    common = ["--dataset", "synthetic-proteins", "--n_graphs", "400", "--hidden", "64", "--seed", "0", "--train_fitgnn", "--batch_size", "50",
+              "--lr", "0.005", "--epochs1", "30", "--epochs2", "30", "--output_dir", "p"]
+    for setup in ("Gs_train_2_Gs_infer", "Gc_train_2_Gc_infer"):
+        loss, acc = cli.main(common + ["--exp_setup", setup])
+        assert np.isfinite(loss) and acc > 0.6, (setup, loss, acc)
+    rows = open("results/synthetic-proteins.csv").read().strip().split("\n")
+    assert rows[0].endswith("best_test_loss,best_test_acc") and len(rows) == 3
