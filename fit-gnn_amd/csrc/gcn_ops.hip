@@ -185,18 +185,29 @@ __global__ __launch_bounds__(256) void epilogue_bwd_kernel(const float *__restri
     }
 }
 
-// db[h] = sum over chunks (fixed order: reproducible).  64 columns x 4 chunk-phases per block.
-__global__ __launch_bounds__(256) void colsum_partials_kernel(const float *__restrict__ partial, int32_t n_chunks, int32_t H,
-                                                              float *__restrict__ db) {
-    __shared__ float red[4][64];
+// db[h] = sum over chunks (fixed order: reproducible).  64 columns x 16 chunk-phases per block: every thread sums
+// n_chunks / 16 partials (the loads of a thread are a serial chain of L2 round trips), then a fixed tree over the phases.
+constexpr int kColsumPhases = 16;
+__global__ __launch_bounds__(64 * kColsumPhases) void colsum_partials_kernel(const float *__restrict__ partial, int32_t n_chunks,
+                                                                             int32_t H, float *__restrict__ db) {
+    __shared__ float red[kColsumPhases][64];
     const int lane = threadIdx.x & 63, ph = threadIdx.x >> 6;
     const int h = blockIdx.x * 64 + lane;
     float s = 0.f;
     if (h < H)
-        for (int c = ph; c < n_chunks; c += 4) s += partial[(int64_t)c * H + h];
+        for (int c = ph; c < n_chunks; c += kColsumPhases) s += partial[(int64_t)c * H + h];
     red[ph][lane] = s;
     __syncthreads();
-    if (ph == 0 && h < H) db[h] = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
+    if (ph == 0 && h < H) {
+        float t[kColsumPhases];
+#pragma unroll
+        for (int k = 0; k < kColsumPhases; ++k) t[k] = red[k][lane];
+#pragma unroll
+        for (int w = kColsumPhases / 2; w >= 1; w >>= 1)
+#pragma unroll
+            for (int k = 0; k < w; ++k) t[k] = t[k] + t[k + w];
+        db[h] = t[0];
+    }
 }
 
 // out[w] = sum_b part[b][w], partials combined in a fixed tree: four interleaved running sums, then (s0+s1)+(s2+s3)
@@ -223,7 +234,46 @@ __global__ __launch_bounds__(256) void sum_leading_kernel(const float4 *__restri
                          (s[0].z + s[1].z) + (s[2].z + s[3].z), (s[0].w + s[1].w) + (s[2].w + s[3].w));
 }
 
+// torch.optim.Adam (amsgrad=False, maximize=False) over one flat parameter buffer: g += wd * p (L2, as torch's
+// weight_decay), m = b1 m + (1-b1) g, v = b2 v + (1-b2) g^2, p -= (lr / (1-b1^t)) * m / (sqrt(v) / sqrt(1-b2^t) + eps).
+// `step` is a device counter (float, as torch keeps it) advanced by thread 0: the update can sit in a captured graph.
+__global__ __launch_bounds__(256) void adam_flat_kernel(float4 *__restrict__ p, const float4 *__restrict__ g, float4 *__restrict__ m,
+                                                        float4 *__restrict__ v, int64_t n4, float lr, float b1, float b2, float eps,
+                                                        float wd, float *__restrict__ step) {
+    const float t = *step + 1.0f;
+    const float bc1 = 1.0f - powf(b1, t), bc2s = sqrtf(1.0f - powf(b2, t));
+    const float step_size = lr / bc1;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n4) {
+        float4 pp = p[i], gg = g[i], mm = m[i], vv = v[i];
+        float *pa = &pp.x, *ga = &gg.x, *ma = &mm.x, *va = &vv.x;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float gk = ga[k] + wd * pa[k];
+            ma[k] = b1 * ma[k] + (1.0f - b1) * gk;
+            va[k] = b2 * va[k] + (1.0f - b2) * gk * gk;
+            pa[k] -= step_size * ma[k] / (sqrtf(va[k]) / bc2s + eps);
+        }
+        p[i] = pp; m[i] = mm; v[i] = vv;
+    }
+}
+__global__ void adam_step_advance_kernel(float *step) { *step += 1.0f; }
+
 }  // namespace
+
+extern "C" int fitgnn_adam_step_f32(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, float lr,
+                                    float beta1, float beta2, float eps, float weight_decay, float *step, void *stream) {
+    if (n < 0 || (n % 4) != 0) return FITGNN_E_BADARG;
+    if (n == 0) return 0;
+    if (!param || !grad || !exp_avg || !exp_avg_sq || !step) return FITGNN_E_BADARG;
+    if ((((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) % 16) != 0) return FITGNN_E_ALIGN;
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t n4 = n / 4;
+    hipLaunchKernelGGL(adam_flat_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, (float4 *)param, (const float4 *)grad,
+                       (float4 *)exp_avg, (float4 *)exp_avg_sq, n4, lr, beta1, beta2, eps, weight_decay, step);
+    hipLaunchKernelGGL(adam_step_advance_kernel, dim3(1), dim3(1), 0, s, step);
+    return (int)hipGetLastError();
+}
 
 extern "C" int fitgnn_sum_leading_f32(const float *part, int32_t B, int64_t W, float *out, void *stream) {
     if (B < 1 || W < 0 || (W % 4) != 0) return FITGNN_E_BADARG;
@@ -289,9 +339,9 @@ int epilogue_bwd_launch(const float *dOut, const float *dy, const float *Wl, int
         if (vec) FITGNN_LAUNCH_EB(4, true, kMaxHeadC); else FITGNN_LAUNCH_EB(1, true, kMaxHeadC);
     }
 #undef FITGNN_LAUNCH_EB
-    if (db) hipLaunchKernelGGL(colsum_partials_kernel, dim3((H + 63) / 64), dim3(256), 0, s, partial, chunks, H, db);
+    if (db) hipLaunchKernelGGL(colsum_partials_kernel, dim3((H + 63) / 64), dim3(64 * kColsumPhases), 0, s, partial, chunks, H, db);
     if (dWl)  // partialW rows are [C x H] per chunk: the same reduction over C*H "columns"
-        hipLaunchKernelGGL(colsum_partials_kernel, dim3((C * H + 63) / 64), dim3(256), 0, s, partialW, chunks, C * H, dWl);
+        hipLaunchKernelGGL(colsum_partials_kernel, dim3((C * H + 63) / 64), dim3(64 * kColsumPhases), 0, s, partialW, chunks, C * H, dWl);
     return (int)hipGetLastError();
 }
 }  // namespace

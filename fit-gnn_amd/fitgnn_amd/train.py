@@ -11,20 +11,78 @@ import torch
 import torch.nn.functional as F
 
 
+def _pad4(n):
+    return (n + 3) // 4 * 4
+
+
 class FlatGrads:
-    """All parameter gradients as views into one contiguous buffer -> one all-reduce per step."""
+    """All parameter gradients as views into one contiguous buffer -> one all-reduce per step.  Every parameter starts
+    on a 16-byte boundary (sizes padded to multiples of four floats; the padding stays zero)."""
 
     def __init__(self, params):
         self.params = [p for p in params if p.requires_grad]
-        n = sum(p.numel() for p in self.params)
-        self.buf = torch.zeros(n, dtype=torch.float32, device=self.params[0].device)
-        off = 0
+        self.offsets, n = [], 0
         for p in self.params:
+            self.offsets.append(n)
+            n += _pad4(p.numel())
+        self.buf = torch.zeros(n, dtype=torch.float32, device=self.params[0].device)
+        for p, off in zip(self.params, self.offsets):
             p.grad = self.buf[off:off + p.numel()].view_as(p)
-            off += p.numel()
 
     def zero(self):
         self.buf.zero_()
+
+
+class FlatAdam:
+    """torch.optim.Adam(lr, weight_decay) (run.py:344) as ONE kernel per step (fitgnn_adam_step_f32) over a flat parameter
+    buffer: the model's parameters are re-pointed to views of it, laid out like FlatGrads' gradient buffer.  torch's
+    multi-tensor Adam takes 44 us for this model's six tensors, this 6.  The step counter lives on the device.
+    state_dict() / load_state_dict() speak torch.optim.Adam's format (run.py keeps one optimiser across the Gc and Gs
+    phases of Gc_train_2_Gs_train)."""
+
+    def __init__(self, flat, lr=0.01, weight_decay=5e-4, betas=(0.9, 0.999), eps=1e-8):
+        self.flat, self.lr, self.wd, self.betas, self.eps = flat, float(lr), float(weight_decay), betas, float(eps)
+        dev = flat.buf.device
+        self.P = torch.zeros_like(flat.buf)
+        for p, off in zip(flat.params, flat.offsets):
+            view = self.P[off:off + p.numel()].view_as(p)
+            view.copy_(p.data)
+            p.data = view
+        self.m, self.v = torch.zeros_like(self.P), torch.zeros_like(self.P)
+        self.step_count = torch.zeros(1, dtype=torch.float32, device=dev)
+
+    def step(self):
+        from . import _lib
+
+        b = self.flat.buf
+        _lib.check(_lib.lib().fitgnn_adam_step_f32(_lib.dptr(self.P), _lib.dptr(b), _lib.dptr(self.m), _lib.dptr(self.v), int(b.numel()),
+                                                   self.lr, self.betas[0], self.betas[1], self.eps, self.wd, _lib.dptr(self.step_count),
+                                                   _lib.stream_ptr(b.device)), "fitgnn_adam_step_f32")
+
+    def zero_grad(self, set_to_none=False):
+        self.flat.zero()
+
+    def _views(self, buf):
+        return [buf[off:off + p.numel()].view_as(p) for p, off in zip(self.flat.params, self.flat.offsets)]
+
+    def state_dict(self):
+        st = {}
+        if float(self.step_count) > 0:
+            for i, (m, v) in enumerate(zip(self._views(self.m), self._views(self.v))):
+                st[i] = {"step": self.step_count[0].clone(), "exp_avg": m.clone(), "exp_avg_sq": v.clone()}
+        group = dict(lr=self.lr, betas=self.betas, eps=self.eps, weight_decay=self.wd, amsgrad=False, maximize=False,
+                     params=list(range(len(self.flat.params))))
+        return {"state": st, "param_groups": [group]}
+
+    def load_state_dict(self, sd):
+        g = sd["param_groups"][0]
+        self.lr, self.wd, self.eps, self.betas = float(g["lr"]), float(g["weight_decay"]), float(g["eps"]), tuple(g["betas"])
+        self.m.zero_(); self.v.zero_(); self.step_count.zero_()
+        for i, (m, v) in enumerate(zip(self._views(self.m), self._views(self.v))):
+            if i in sd["state"]:
+                e = sd["state"][i]
+                m.copy_(e["exp_avg"]); v.copy_(e["exp_avg_sq"])
+                self.step_count.fill_(float(e["step"]))
 
 
 class GDTrainer:
@@ -34,10 +92,11 @@ class GDTrainer:
         self.model, self.batch, self.task = model, batch, task
         # first layer on the de-duplicated feature table when the batch carries one (same arithmetic, fewer FLOPs)
         self.dedup = dedup and getattr(batch, "row_index", None) is not None
-        # fused=True: one multi-tensor kernel for the whole update (same arithmetic as the reference's torch.optim.Adam)
-        fused = next(model.parameters()).is_cuda
-        self.opt = torch.optim.Adam(model.parameters(), lr=lr, weight_decay=weight_decay, fused=fused)
         self.flat = FlatGrads(model.parameters())
+        if next(model.parameters()).is_cuda:   # one kernel over the flat buffers (same arithmetic as torch.optim.Adam)
+            self.opt = FlatAdam(self.flat, lr=lr, weight_decay=weight_decay)
+        else:                                  # host-side logic tests (gloo): the reference's optimiser itself
+            self.opt = torch.optim.Adam(model.parameters(), lr=lr, weight_decay=weight_decay)
         self.reduction = reduction
         self.pg = process_group
         self.dist = process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()

@@ -119,6 +119,12 @@ int fitgnn_segment_sum_f32(const int32_t *seg_off, const int32_t *members, int32
  * of the split-K weight-gradient GEMM dH^T @ X (the library has no deterministic split-K for K = number of rows). */
 int fitgnn_sum_leading_f32(const float *part, int32_t B, int64_t W, float *out, void *stream);
 
+/* One Adam update (torch.optim.Adam semantics: L2 weight decay folded into the gradient, bias-corrected moments;
+ * run.py:344 Adam(lr, weight_decay=5e-4)) over a FLAT parameter buffer of n floats (n % 4 == 0, 16-byte aligned) and its
+ * equally laid out gradient / moment buffers.  step: device counter of completed updates (read, then advanced). */
+int fitgnn_adam_step_f32(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, float lr,
+                         float beta1, float beta2, float eps, float weight_decay, float *step, void *stream);
+
 /* Backward of the fused epilogue  out = dropout(ELU(z)):  given dOut and the forward OUTPUT `out`
  *   dZ = keep ? dOut * 1/(1-p) * (o > 0 ? 1 : o + 1) : 0,   o = out*(1-p) (pre-dropout ELU value)
  * and the bias gradient db[h] = sum_rows dZ[row][h] (deterministic two-pass reduction through `work`).

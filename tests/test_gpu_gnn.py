@@ -380,3 +380,31 @@ def test_flat_artefact_round_trip(mods, tmp_path):
     model = network.Classify_node(args).cuda().eval()
     with torch.no_grad():
         assert torch.allclose(model(batch.x, batch.edge_index), model(got.x, got.edge_index), rtol=1e-5, atol=1e-6)
+
+
+def test_flat_adam_equals_torch_adam(mods):
+    """train.FlatAdam (one kernel over the flat parameter / gradient / moment buffers) == torch.optim.Adam with the
+    reference's settings (run.py:344), step by step, and speaks its state_dict format."""
+    from fitgnn_amd import train
+
+    torch.manual_seed(0)
+    shapes = [(64, 24), (64,), (64, 64), (64,), (5, 64), (5,)]
+    ps = [torch.nn.Parameter(torch.randn(s, device="cuda")) for s in shapes]
+    qs = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    ref = torch.optim.Adam(qs, lr=0.01, weight_decay=5e-4)
+    flat = train.FlatGrads(ps)
+    opt = train.FlatAdam(flat, lr=0.01, weight_decay=5e-4)
+    for it in range(5):
+        for p, q in zip(ps, qs):
+            g = torch.randn_like(q)
+            p.grad.copy_(g)
+            q.grad = g.clone()
+        opt.step(); ref.step()
+        for p, q in zip(ps, qs):
+            assert rel(p.detach(), q.detach()) < 1e-6, it
+    sd = opt.state_dict()
+    assert set(sd["state"]) == set(range(6)) and float(sd["state"][0]["step"]) == 5.0
+    ref2 = torch.optim.Adam(qs, lr=0.01, weight_decay=5e-4)
+    ref2.load_state_dict(sd)          # torch accepts it
+    opt.load_state_dict(ref.state_dict())
+    assert float(opt.step_count) == 5.0 and rel(opt._views(opt.m)[2], ref.state[qs[2]]["exp_avg"]) < 1e-6
