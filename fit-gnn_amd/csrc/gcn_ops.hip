@@ -42,7 +42,7 @@ __global__ void gcn_val_kernel(const int32_t *__restrict__ rowptr, const int32_t
     }
 }
 
-constexpr int kMaxChunks = 256;  // row chunks of the bias-gradient reduction (one partial row of H floats each)
+constexpr int kMaxChunks = 1024;  // row chunks of the bias-gradient reduction (one partial row of H floats each)
 
 inline int chunk_rows_for(int n_rows) {
     const int per = (n_rows + kMaxChunks - 1) / kMaxChunks;
@@ -93,62 +93,70 @@ __global__ __launch_bounds__(256) void epilogue_bwd_kernel(const float *__restri
         __syncthreads();
     }
     if (live) {
-        for (int row = r0 + wave; row < r1; row += 4) {
-            const int64_t base = (int64_t)row * H + col0;
-            float g[VEC], o[VEC];
-            if (HEAD) {
-                const float dyl = lane < C ? dy[(int64_t)row * C + lane] : 0.f;
+        constexpr int U = 4;  // rows per wave in flight: all loads of a step are issued before the first use
+        for (int row0 = r0 + wave; row0 < r1; row0 += 4 * U) {
+            float g[U][VEC], o[U][VEC], dyl[U];
 #pragma unroll
-                for (int i = 0; i < VEC; ++i) g[i] = 0.f;
-                for (int c = 0; c < C; ++c) {
-                    const float d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dyl), c));
-#pragma unroll
-                    for (int i = 0; i < VEC; ++i) g[i] = fmaf(d, s_w[c * SLAB + lane * VEC + i], g[i]);
-                }
+            for (int u = 0; u < U; ++u) {
+                const int row = min(row0 + 4 * u, r1 - 1);  // clamped: rows past the chunk are loaded again, never used
+                const int64_t base = (int64_t)row * H + col0;
+                if (HEAD) dyl[u] = lane < C ? dy[(int64_t)row * C + lane] : 0.f;
                 if (VEC == 4) {
                     const float4 ov = *reinterpret_cast<const float4 *>(out + base);
-                    o[0] = ov.x; o[1 % VEC] = ov.y; o[2 % VEC] = ov.z; o[3 % VEC] = ov.w;
+                    o[u][0] = ov.x; o[u][1 % VEC] = ov.y; o[u][2 % VEC] = ov.z; o[u][3 % VEC] = ov.w;
+                    if (!HEAD) {
+                        const float4 gv = *reinterpret_cast<const float4 *>(dOut + base);
+                        g[u][0] = gv.x; g[u][1 % VEC] = gv.y; g[u][2 % VEC] = gv.z; g[u][3 % VEC] = gv.w;
+                    }
                 } else {
-                    o[0] = out[base];
+                    o[u][0] = out[base];
+                    if (!HEAD) g[u][0] = dOut[base];
                 }
-                if (CW > 0) {
+            }
 #pragma unroll
-                    for (int c = 0; c < (CW > 0 ? CW : 1); ++c) {
-                        const float d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dyl), c));  // 0 for c >= C
+            for (int u = 0; u < U; ++u) {
+                const int row = row0 + 4 * u;
+                if (row >= r1) break;  // wave-uniform
+                const int64_t base = (int64_t)row * H + col0;
+                if (HEAD) {
 #pragma unroll
-                        for (int i = 0; i < VEC; ++i) wacc[c][i] = fmaf(d, o[i], wacc[c][i]);
+                    for (int i = 0; i < VEC; ++i) g[u][i] = 0.f;
+                    for (int c = 0; c < C; ++c) {
+                        const float d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dyl[u]), c));
+#pragma unroll
+                        for (int i = 0; i < VEC; ++i) g[u][i] = fmaf(d, s_w[c * SLAB + lane * VEC + i], g[u][i]);
+                    }
+                    if (CW > 0) {
+#pragma unroll
+                        for (int c = 0; c < (CW > 0 ? CW : 1); ++c) {
+                            const float d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dyl[u]), c));  // 0 for c >= C
+#pragma unroll
+                            for (int i = 0; i < VEC; ++i) wacc[c][i] = fmaf(d, o[u][i], wacc[c][i]);
+                        }
                     }
                 }
-            } else if (VEC == 4) {
-                const float4 gv = *reinterpret_cast<const float4 *>(dOut + base);
-                const float4 ov = *reinterpret_cast<const float4 *>(out + base);
-                g[0] = gv.x; g[1 % VEC] = gv.y; g[2 % VEC] = gv.z; g[3 % VEC] = gv.w;
-                o[0] = ov.x; o[1 % VEC] = ov.y; o[2 % VEC] = ov.z; o[3 % VEC] = ov.w;
-            } else {
-                g[0] = dOut[base];
-                o[0] = out[base];
-            }
-            uint64_t bits = 0;
-            if ((epi & FITGNN_EPI_DROPOUT) && !mask) bits = fitgnn::dropout_bits(seed, (uint64_t)base >> 2);
+                uint64_t bits = 0;
+                if ((epi & FITGNN_EPI_DROPOUT) && !mask) bits = fitgnn::dropout_bits(seed, (uint64_t)base >> 2);
 #pragma unroll
-            for (int i = 0; i < VEC; ++i) {
-                float d = g[i];
-                if (epi & FITGNN_EPI_DROPOUT) {
-                    const uint64_t idx = (uint64_t)base + i;
-                    const bool keep = mask ? (mask[idx] != 0) : fitgnn::dropout_keep(bits, (int)(idx & 3), thresh);
-                    d = keep ? d * scale : 0.f;
+                for (int i = 0; i < VEC; ++i) {
+                    float d = g[u][i];
+                    if (epi & FITGNN_EPI_DROPOUT) {
+                        const uint64_t idx = (uint64_t)base + i;
+                        const bool keep = mask ? (mask[idx] != 0) : fitgnn::dropout_keep(bits, (int)(idx & 3), thresh);
+                        d = keep ? d * scale : 0.f;
+                    }
+                    if (epi & FITGNN_EPI_ELU) {
+                        const float e = o[u][i] * unscale;  // pre-dropout ELU output; exp(z) = e + 1 for z <= 0
+                        d = e > 0.f ? d : d * (e + 1.0f);
+                    }
+                    g[u][i] = d;
+                    sum[i] += d;
                 }
-                if (epi & FITGNN_EPI_ELU) {
-                    const float e = o[i] * unscale;  // pre-dropout ELU output; exp(z) = e + 1 for z <= 0
-                    d = e > 0.f ? d : d * (e + 1.0f);
+                if (VEC == 4) {
+                    *reinterpret_cast<float4 *>(dZ + base) = make_float4(g[u][0], g[u][1 % VEC], g[u][2 % VEC], g[u][3 % VEC]);
+                } else {
+                    dZ[base] = g[u][0];
                 }
-                g[i] = d;
-                sum[i] += d;
-            }
-            if (VEC == 4) {
-                *reinterpret_cast<float4 *>(dZ + base) = make_float4(g[0], g[1 % VEC], g[2 % VEC], g[3 % VEC]);
-            } else {
-                dZ[base] = g[0];
             }
         }
     }
