@@ -69,9 +69,9 @@ __global__ __launch_bounds__(256) void epilogue_bwd_kernel(const float *__restri
     __shared__ float s_w[HEAD ? kMaxHeadC * SLAB : 1];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int col0 = blockIdx.y * SLAB + lane * VEC;
+    const int col0 = blockIdx.x * SLAB + lane * VEC;
     const bool live = col0 + VEC <= H;
-    const int r0 = blockIdx.x * chunk_rows;
+    const int r0 = blockIdx.y * chunk_rows;
     const int r1 = min(r0 + chunk_rows, n_rows);
     const float scale = (epi & FITGNN_EPI_DROPOUT) ? 1.0f / (1.0f - p_drop) : 1.0f;
     const float unscale = (epi & FITGNN_EPI_DROPOUT) ? (1.0f - p_drop) : 1.0f;
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void epilogue_bwd_kernel(const float *__restri
     if (HEAD) {  // this slab's columns of the head weight, [C x SLAB]
         for (int i = threadIdx.x; i < C * SLAB; i += 256) {
             const int c = i / SLAB, j = i - c * SLAB;
-            const int h = blockIdx.y * SLAB + j;
+            const int h = blockIdx.x * SLAB + j;
             s_w[i] = h < H ? Wl[(int64_t)c * H + h] : 0.f;
         }
         __syncthreads();
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256) void epilogue_bwd_kernel(const float *__restri
 #pragma unroll
             for (int i = 0; i < VEC; ++i) {
                 const int c = lane * VEC + i;
-                partial[(int64_t)blockIdx.x * H + col0 + i] = ((red[0][c] + red[1][c]) + red[2][c]) + red[3][c];
+                partial[(int64_t)blockIdx.y * H + col0 + i] = ((red[0][c] + red[1][c]) + red[2][c]) + red[3][c];
             }
         }
     }
@@ -186,7 +186,7 @@ __global__ __launch_bounds__(256) void epilogue_bwd_kernel(const float *__restri
 #pragma unroll
                 for (int i = 0; i < VEC; ++i) {
                     const int j = lane * VEC + i;
-                    partialW[((int64_t)blockIdx.x * C + cc) * H + col0 + i] = ((red[0][j] + red[1][j]) + red[2][j]) + red[3][j];
+                    partialW[((int64_t)blockIdx.y * C + cc) * H + col0 + i] = ((red[0][j] + red[1][j]) + red[2][j]) + red[3][j];
                 }
             }
         }
@@ -333,7 +333,8 @@ int epilogue_bwd_launch(const float *dOut, const float *dy, const float *Wl, int
     float *partial = db ? (float *)work : nullptr;
     float *partialW = dWl ? (float *)work + (db ? (size_t)chunks * H : 0) : nullptr;
     const bool vec = (H % 4 == 0) && ((((uintptr_t)dOut | (uintptr_t)out | (uintptr_t)dZ) % 16) == 0);
-    const dim3 grid(chunks, vec ? (H + 255) / 256 : (H + 63) / 64);
+    // x (fastest) = column slab: both halves of every row are in flight together; y = row chunk
+    const dim3 grid(vec ? (H + 255) / 256 : (H + 63) / 64, chunks);
 #define FITGNN_LAUNCH_EB(V, HD, CWV)                                                                                     \
     hipLaunchKernelGGL((epilogue_bwd_kernel<V, HD, CWV>), grid, dim3(256), 0, s, dOut, out, dZ, n_rows, H, cr, epilogue,   \
                        p_drop, seed, mask, partial, dy, Wl, C, partialW)

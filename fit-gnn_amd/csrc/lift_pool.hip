@@ -236,11 +236,14 @@ __global__ __launch_bounds__(256) void pool_rows_kernel(const int32_t *__restric
 template <int VEC>
 __global__ __launch_bounds__(256) void segment_sum_kernel(const int32_t *__restrict__ off, const int32_t *__restrict__ members,
                                                           int32_t n_seg, const float *__restrict__ X, int64_t ldx, int32_t F,
-                                                          float *__restrict__ out, int64_t ldo) {
-    const int sgm = blockIdx.x * 4 + (threadIdx.x >> 6);
+                                                          float *__restrict__ out, int64_t ldo, int32_t n_slabs) {
+    // 1-D grid, column slab fastest: both 1-KiB halves of every 2-KiB row are in flight together (a slab-major order
+    // streams the first half of every row, then the second: half the channels idle, as measured on the SpMM)
+    const int slab = blockIdx.x % n_slabs;
+    const int sgm = (blockIdx.x / n_slabs) * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (sgm >= n_seg) return;
-    const int f0 = (blockIdx.y * 64 + lane) * VEC;
+    const int f0 = (slab * 64 + lane) * VEC;
     const bool live = f0 + VEC <= F;
     const float *Xs = X + (live ? f0 : (F >= VEC ? F - VEC : 0));
     const int m0 = __builtin_amdgcn_readfirstlane(off[sgm]), m1 = __builtin_amdgcn_readfirstlane(off[sgm + 1]);
@@ -411,11 +414,13 @@ extern "C" int fitgnn_segment_sum_f32(const int32_t *seg_off, const int32_t *mem
     hipStream_t s = (hipStream_t)stream;
     const bool vec = (F % 4 == 0) && (ldx % 4 == 0) && (ldo % 4 == 0) && ((((uintptr_t)X | (uintptr_t)out) % 16) == 0);
     if (vec) {
-        dim3 grid((n_seg + 3) / 4, (F + 255) / 256);
-        hipLaunchKernelGGL(segment_sum_kernel<4>, grid, dim3(256), 0, s, seg_off, members, n_seg, X, ldx, F, out, ldo);
+        const int n_slabs = (F + 255) / 256;
+        dim3 grid((unsigned)((n_seg + 3) / 4) * n_slabs);
+        hipLaunchKernelGGL(segment_sum_kernel<4>, grid, dim3(256), 0, s, seg_off, members, n_seg, X, ldx, F, out, ldo, n_slabs);
     } else {
-        dim3 grid((n_seg + 3) / 4, (F + 63) / 64);
-        hipLaunchKernelGGL(segment_sum_kernel<1>, grid, dim3(256), 0, s, seg_off, members, n_seg, X, ldx, F, out, ldo);
+        const int n_slabs = (F + 63) / 64;
+        dim3 grid((unsigned)((n_seg + 3) / 4) * n_slabs);
+        hipLaunchKernelGGL(segment_sum_kernel<1>, grid, dim3(256), 0, s, seg_off, members, n_seg, X, ldx, F, out, ldo, n_slabs);
     }
     return (int)hipGetLastError();
 }
