@@ -33,7 +33,7 @@ def test_error_strings_and_size_queries():
     assert b"bad argument" in L.fitgnn_error_string(-1)
     assert 8 <= L.fitgnn_spmm_default_window_rows() <= L.fitgnn_spmm_max_window_rows(512)
     assert L.fitgnn_epilogue_bwd_workspace_bytes(130, 512) == 33 * 512 * 4  # 4-row chunks, 33 of them
-    assert L.fitgnn_epilogue_bwd_workspace_bytes(100000, 512) <= 256 * 512 * 4
+    assert L.fitgnn_epilogue_bwd_workspace_bytes(100000, 512) <= 1024 * 512 * 4  # at most 1024 row chunks
     assert L.fitgnn_greedy_select_workspace_bytes(1000, 6000) > 1000 * 4
     assert L.fitgnn_lift_adjacency_workspace_bytes(10, 50, 5) > 0
     assert L.fitgnn_pool_rows_workspace_bytes(100, 50) > 0
