@@ -74,6 +74,7 @@ def build_workload(name, seed, device, hidden=512):
     info = dict(nodes=N, undirected_edges=E, features=F, classes=C, clusters=int(Cmat.shape[0]),
                 union_rows=batch.n_rows, nnz_prime=batch.nnz, t_graph_eig_s=round(t1 - t0, 2),
                 t_coarsen_hip_s=round(t2 - t1, 3), t_assemble_s=round(t3 - t2, 2), t_batch_csr_s=round(time.time() - t3, 2))
+    info["_coarsen_inputs"] = (W, np.ascontiguousarray(Uk), lk.copy(), r)
     return batch, (F, C), info
 
 
@@ -138,6 +139,7 @@ def main():
     ops.FOLD_BACKWARD = args.fold
 
     batch, (F, C), info = build_workload(args.workload, seed=rank, device=device, hidden=args.hidden)
+    coarsen_inputs = info.pop("_coarsen_inputs")
     margs = argparse.Namespace(num_layers1=2, layer_name="GCNConv", num_features=F, hidden=args.hidden, num_classes=C)
     torch.manual_seed(2)  # weight seed; identical on every rank
     model = network.Classify_node(margs).to(device)
@@ -213,6 +215,14 @@ def main():
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(batch, sd0, 2)
+        # the contraction step of the same graph on the host: the C restatement (one core), next to the HIP time above
+        from oracle import coarsen_oracle as corc
+        Wc, Ukc, lkc, rc = coarsen_inputs
+        t0 = time.time()
+        corc.coarsen_oracle(Wc, K=10, r=rc, Uk=Ukc.copy(), lk=lkc.copy())
+        out["cpu_baseline"]["coarsen_port_s"] = round(time.time() - t0, 3)
+        out["cpu_baseline"]["coarsen_port_cores"] = 1
+        out["cpu_baseline"]["coarsen_reference_probe"] = "profiles/reference_probe_timings.json (reference Python, 8 cores: 17.97 s at this size)"
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
