@@ -259,11 +259,22 @@ class GraphTrainer(_CapturedSteps):
     kind 'gs': model(set_gs, batch_tensor) pools the masked rows of the subgraph union; kind 'gc': model(gc)."""
 
     def __init__(self, model, gset, graphs, kind="gs", batch_size=128, lr=0.01, weight_decay=5e-4, task="graph_reg",
-                 multi_prop=True, prop=0, truncate_targets=True, capture=False, share=None):
+                 multi_prop=True, prop=0, truncate_targets=True, capture=False, share=None, rank=None, world=None,
+                 process_group=None, batches=None, global_sizes=None):
         """capture=True: every batch step (forward, loss, backward, Adam) is captured once in a hipGraph and replayed
         -- the steps are launch-bound (small batches, ~40 kernels each).  Dropout seeds then live on the device
-        (ops.SeedBank) and are advanced by a kernel inside each captured step."""
+        (ops.SeedBank) and are advanced by a kernel inside each captured step.
+        Data parallel (graph level): under an initialised process group every rank takes graphs
+        ids[rank::world] of EVERY global batch (the unit is a whole graph: pooling is intra-graph, nothing is
+        exchanged in the forward pass), losses are sums scaled by 1 / global batch size, and the accumulated gradient
+        buffer is all-reduced once per step (see _dp_step for how the never-cleared gradients stay exact).
+        batches (+ global_sizes): pre-built batch dicts (tests / custom pipelines) instead of gset + graphs."""
         import types
+
+        dist_on = torch.distributed.is_available() and torch.distributed.is_initialized()
+        self.world = int(world if world is not None else (torch.distributed.get_world_size(process_group) if dist_on else 1))
+        self.rank = int(rank if rank is not None else (torch.distributed.get_rank(process_group) if dist_on else 0))
+        self.pg = process_group
 
         self.model, self.kind, self.task, self.multi_prop, self.prop = model, kind, task, multi_prop, prop
         self.truncate = truncate_targets
@@ -275,22 +286,49 @@ class GraphTrainer(_CapturedSteps):
             self.opt = torch.optim.Adam(model.parameters(), lr=lr, weight_decay=weight_decay, fused=fused,
                                         capturable=bool(capture) and fused)
             self.flat = FlatGrads(model.parameters())
-        graphs = [int(g) for g in graphs]
-        self.batches = []
-        # contiguous runs of graph ids inside `graphs` are merged into ranges; a batch = list of ranges
-        for b0 in range(0, len(graphs), batch_size):
-            ids = graphs[b0:b0 + batch_size]
-            pieces = [gset.batch(g, g + 1, kind) for g in ids] if not _is_range(ids) else [gset.batch(ids[0], ids[-1] + 1, kind)]
-            self.batches.append(_cat_pieces(pieces, kind, types))
+        if batches is not None:   # pre-built (entries may be None: this rank holds no graph of that batch)
+            self.batches = list(batches)
+            self.global_sizes = list(global_sizes) if global_sizes is not None else [int(b["y"].shape[0]) for b in self.batches]
+        else:
+            graphs = [int(g) for g in graphs]
+            self.batches, self.global_sizes = [], []
+            # contiguous runs of graph ids inside `graphs` are merged into ranges; a batch = list of ranges
+            for b0 in range(0, len(graphs), batch_size):
+                ids_all = graphs[b0:b0 + batch_size]
+                ids = ids_all[self.rank::self.world]
+                self.global_sizes.append(len(ids_all))
+                if not ids:
+                    self.batches.append(None)   # this rank holds no graph of a short last batch: it still joins the step
+                    continue
+                pieces = [gset.batch(g, g + 1, kind) for g in ids] if not _is_range(ids) else [gset.batch(ids[0], ids[-1] + 1, kind)]
+                self.batches.append(_cat_pieces(pieces, kind, types))
+        if self.world > 1:
+            self.capture = False   # the per-step collective is issued eagerly
 
-    def _loss(self, out, y):
+    def _loss(self, out, y, reduction="mean"):
         if self.truncate:
             y = y.long()
         if self.task == "graph_reg":
             tgt = (y[:, self.prop].view(-1, 1) if self.multi_prop else y).to(out.dtype)
-            return F.l1_loss(out, tgt)
+            return F.l1_loss(out, tgt, reduction=reduction)
         # graph_cls: CrossEntropyLoss on the model's SOFTMAX output (run.py:583 on network.py:94,133: a double softmax, kept)
-        return F.cross_entropy(out, y.long().flatten())
+        return F.cross_entropy(out, y.long().flatten(), reduction=reduction)
+
+    def _dp_step(self, k, b):
+        """One data-parallel batch step.  The reference never clears the gradients inside an epoch, so after step k the
+        buffer must hold G(k) = sum over steps <= k and over ranks of the local gradients.  The buffer enters step k
+        holding G(k-1) on every rank: scale it by 1 / world, add this rank's gradient of (local loss sum / global
+        batch size), all-reduce(sum): sum_r (G(k-1)/world + g_r(k)) = G(k-1) + sum_r g_r(k) = G(k)."""
+        buf = self.flat.buf
+        if k > 0:
+            buf.mul_(1.0 / self.world)
+        loss = torch.zeros((), device=buf.device)
+        if b is not None:
+            loss = self._loss(self._forward(b), b["y"], reduction="sum") / float(self.global_sizes[k])
+            loss.backward()
+        torch.distributed.all_reduce(buf, group=self.pg)
+        self.opt.step()
+        return loss.detach()
 
     def _forward(self, b):
         if self.kind == "gs":
@@ -312,6 +350,11 @@ class GraphTrainer(_CapturedSteps):
             return self._replay().sum() / max(len(self.batches), 1)
         self.flat.zero()
         total = torch.zeros((), device=self.flat.buf.device)
+        if self.world > 1:
+            for k, b in enumerate(self.batches):
+                total += self._dp_step(k, b)
+            torch.distributed.all_reduce(total, group=self.pg)   # sum of the ranks' shares of every batch mean
+            return total / max(len(self.batches), 1)
         for b in self.batches:
             total += self._one(b)
         return total / max(len(self.batches), 1)

@@ -95,3 +95,83 @@ def test_shard_clusters_balances_nnz():
     load = np.bincount(owner, weights=nnz, minlength=8)
     assert load.max() - load.min() <= nnz.max()
     assert set(owner.tolist()) == set(range(8))
+
+
+class TinyGraphModel(torch.nn.Module):
+    """Stand-in with the Regress_graph_gc call signature: mean-pool node features per graph, then an MLP."""
+
+    def __init__(self, F):
+        super().__init__()
+        self.a = torch.nn.Linear(F, 8)
+        self.b = torch.nn.Linear(8, 1)
+
+    def forward(self, gc):
+        n = gc.num_graphs
+        pooled = torch.zeros(n, gc.x.shape[1]).index_add_(0, gc.batch, gc.x)
+        cnt = torch.zeros(n).index_add_(0, gc.batch, torch.ones(gc.batch.numel())).clamp(min=1)
+        return self.b(torch.tanh(self.a(pooled / cnt.unsqueeze(1))))
+
+
+def _graph_batches(rank, world):
+    """Three global batches of 6, 6 and 3 graphs (4 nodes each); rank r holds graphs r::world of every batch."""
+    import types
+
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(15, 4, 5, generator=g)
+    y = 5.0 * torch.randn(15, 2, generator=g)
+    out = []
+    for lo, hi in ((0, 6), (6, 12), (12, 15)):
+        ids = list(range(lo, hi))[rank::world]
+        if not ids:
+            out.append(None)
+            continue
+        xb = x[ids].reshape(-1, 5)
+        bt = torch.repeat_interleave(torch.arange(len(ids)), 4)
+        out.append(dict(y=y[ids], n_graphs=len(ids),
+                        gc=types.SimpleNamespace(x=xb, edge_index=None, batch=bt, num_graphs=len(ids))))
+    return out
+
+
+def _graph_worker(rank, world, port, out_q):
+    sys.path.insert(0, os.path.join(ROOT, "fit-gnn_amd"))
+    from fitgnn_amd import train
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(2)
+    model = TinyGraphModel(5)
+    tr = train.GraphTrainer(model, None, None, kind="gc", lr=0.01, weight_decay=5e-4, prop=1,
+                            batches=_graph_batches(rank, world), global_sizes=[6, 6, 3])
+    losses = [float(tr.step()) for _ in range(3)]
+    out_q.put((rank, losses, {k: v.numpy().copy() for k, v in model.state_dict().items()}))
+    torch.distributed.destroy_process_group()
+
+
+def test_graph_level_two_rank_steps_equal_single_process():
+    """GraphTrainer data parallel over world_size 2 (gloo): per-batch steps with the reference's never-cleared gradients
+    == the single-process trainer on the whole batches (losses and weights); the last batch is short (3 graphs: 2 + 1)."""
+    sys.path.insert(0, os.path.join(ROOT, "fit-gnn_amd"))
+    from fitgnn_amd import train
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_graph_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    torch.manual_seed(2)
+    model = TinyGraphModel(5)
+    tr = train.GraphTrainer(model, None, None, kind="gc", lr=0.01, weight_decay=5e-4, prop=1, batches=_graph_batches(0, 1),
+                            global_sizes=[6, 6, 3], world=1, rank=0)
+    ref = [float(tr.step()) for _ in range(3)]
+    assert np.allclose(res[0][1], ref, rtol=1e-5), (res[0][1], ref)
+    assert np.allclose(res[1][1], ref, rtol=1e-5)
+    for k, v in model.state_dict().items():
+        assert np.allclose(res[0][2][k], v.numpy(), rtol=1e-5, atol=1e-6), k
+        assert np.array_equal(res[0][2][k], res[1][2][k]), f"ranks diverged on {k}"
