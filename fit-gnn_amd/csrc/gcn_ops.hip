@@ -193,29 +193,26 @@ __global__ __launch_bounds__(256) void epilogue_bwd_kernel(const float *__restri
     }
 }
 
-// db[h] = sum over chunks (fixed order: reproducible).  64 columns x 16 chunk-phases per block: every thread sums
-// n_chunks / 16 partials (the loads of a thread are a serial chain of L2 round trips), then a fixed tree over the phases.
-constexpr int kColsumPhases = 16;
-__global__ __launch_bounds__(64 * kColsumPhases) void colsum_partials_kernel(const float *__restrict__ partial, int32_t n_chunks,
-                                                                             int32_t H, float *__restrict__ db) {
-    __shared__ float red[kColsumPhases][64];
-    const int lane = threadIdx.x & 63, ph = threadIdx.x >> 6;
-    const int h = blockIdx.x * 64 + lane;
+// db[h] = sum over chunks (fixed order: reproducible).  16 columns x 64 chunk-phases per block: every thread sums
+// n_chunks / 64 partials (a thread's loads are a serial chain of L2 round trips: keep it short), then a fixed
+// binary tree over the 64 phases in LDS.
+constexpr int kColsumPhases = 64, kColsumCols = 16;
+__global__ __launch_bounds__(kColsumPhases * kColsumCols) void colsum_partials_kernel(const float *__restrict__ partial,
+                                                                                      int32_t n_chunks, int32_t H,
+                                                                                      float *__restrict__ db) {
+    __shared__ float red[kColsumPhases][kColsumCols];
+    const int cl = threadIdx.x % kColsumCols, ph = threadIdx.x / kColsumCols;
+    const int h = blockIdx.x * kColsumCols + cl;
     float s = 0.f;
     if (h < H)
         for (int c = ph; c < n_chunks; c += kColsumPhases) s += partial[(int64_t)c * H + h];
-    red[ph][lane] = s;
+    red[ph][cl] = s;
     __syncthreads();
-    if (ph == 0 && h < H) {
-        float t[kColsumPhases];
-#pragma unroll
-        for (int k = 0; k < kColsumPhases; ++k) t[k] = red[k][lane];
-#pragma unroll
-        for (int w = kColsumPhases / 2; w >= 1; w >>= 1)
-#pragma unroll
-            for (int k = 0; k < w; ++k) t[k] = t[k] + t[k + w];
-        db[h] = t[0];
+    for (int w = kColsumPhases / 2; w >= 1; w >>= 1) {
+        if (ph < w) red[ph][cl] = red[ph][cl] + red[ph + w][cl];
+        __syncthreads();
     }
+    if (ph == 0 && h < H) db[h] = red[0][cl];
 }
 
 // out[w] = sum_b part[b][w], partials combined in a fixed tree: four interleaved running sums, then (s0+s1)+(s2+s3)
@@ -348,9 +345,9 @@ int epilogue_bwd_launch(const float *dOut, const float *dy, const float *Wl, int
         if (vec) FITGNN_LAUNCH_EB(4, true, kMaxHeadC); else FITGNN_LAUNCH_EB(1, true, kMaxHeadC);
     }
 #undef FITGNN_LAUNCH_EB
-    if (db) hipLaunchKernelGGL(colsum_partials_kernel, dim3((H + 63) / 64), dim3(64 * kColsumPhases), 0, s, partial, chunks, H, db);
+    if (db) hipLaunchKernelGGL(colsum_partials_kernel, dim3((H + kColsumCols - 1) / kColsumCols), dim3(kColsumPhases * kColsumCols), 0, s, partial, chunks, H, db);
     if (dWl)  // partialW rows are [C x H] per chunk: the same reduction over C*H "columns"
-        hipLaunchKernelGGL(colsum_partials_kernel, dim3((C * H + 63) / 64), dim3(64 * kColsumPhases), 0, s, partialW, chunks, C * H, dWl);
+        hipLaunchKernelGGL(colsum_partials_kernel, dim3((C * H + kColsumCols - 1) / kColsumCols), dim3(kColsumPhases * kColsumCols), 0, s, partialW, chunks, C * H, dWl);
     return (int)hipGetLastError();
 }
 }  // namespace
