@@ -264,7 +264,69 @@ __global__ __launch_bounds__(256) void adam_flat_kernel(float4 *__restrict__ p, 
 }
 __global__ void adam_step_advance_kernel(float *step) { *step += 1.0f; }
 
+// NLLLoss(log_softmax(z)[idx], labels) (network.py:35 + run.py:341) and its gradient in one pass over the selected rows:
+//   part[block] = sum over the block's rows of (logsumexp(z_r) - z_r[label]) * scale,  dz[r] = (softmax(z_r) - onehot) * scale
+// dz is zero elsewhere (cleared by the launcher).  One thread per selected row; fixed-order block and grid reductions.
+__global__ __launch_bounds__(256) void softmax_nll_kernel(const float *__restrict__ z, int64_t ldz, int32_t C,
+                                                          const int64_t *__restrict__ idx, const int64_t *__restrict__ labels,
+                                                          int32_t n, float scale, float *__restrict__ dz,
+                                                          float *__restrict__ part) {
+    __shared__ float red[256];
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    float loss = 0.f;
+    if (t < n) {
+        const int64_t r = idx[t];
+        const float *zr = z + r * ldz;
+        float m = zr[0];
+        for (int c = 1; c < C; ++c) m = fmaxf(m, zr[c]);
+        float se = 0.f;
+        for (int c = 0; c < C; ++c) se += expf(zr[c] - m);
+        const float lse = m + logf(se);
+        const int lab = (int)labels[t];
+        loss = (lse - zr[lab]) * scale;
+        float *dr = dz + r * ldz;
+        for (int c = 0; c < C; ++c) dr[c] = (expf(zr[c] - lse) - (c == lab ? 1.f : 0.f)) * scale;
+    }
+    red[threadIdx.x] = loss;
+    __syncthreads();
+    for (int w = 128; w >= 1; w >>= 1) {
+        if ((int)threadIdx.x < w) red[threadIdx.x] = red[threadIdx.x] + red[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) part[blockIdx.x] = red[0];
+}
+__global__ __launch_bounds__(256) void sum_partials_kernel(const float *__restrict__ part, int32_t n, float *__restrict__ out) {
+    __shared__ float red[256];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) s += part[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w >= 1; w >>= 1) {
+        if ((int)threadIdx.x < w) red[threadIdx.x] = red[threadIdx.x] + red[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = red[0];
+}
+
 }  // namespace
+
+extern "C" size_t fitgnn_softmax_nll_workspace_bytes(int32_t n) { return (size_t)((n > 0 ? n : 0) + 255) / 256 * sizeof(float) + 16; }
+
+extern "C" int fitgnn_softmax_nll_f32(const float *z, int64_t ldz, int32_t n_rows, int32_t C, const int64_t *idx,
+                                      const int64_t *labels, int32_t n, float scale, float *loss, float *dz, void *work,
+                                      size_t work_bytes, void *stream) {
+    if (n_rows < 0 || C < 1 || n < 0 || ldz < C) return FITGNN_E_BADARG;
+    if (!loss) return FITGNN_E_BADARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (dz && n_rows > 0) FITGNN_RETURN_IF_HIP(hipMemsetAsync(dz, 0, (size_t)n_rows * (size_t)ldz * sizeof(float), s));
+    if (n == 0) return (int)hipMemsetAsync(loss, 0, sizeof(float), s);
+    if (!z || !idx || !labels || !dz || !work) return FITGNN_E_BADARG;
+    if (work_bytes < fitgnn_softmax_nll_workspace_bytes(n)) return FITGNN_E_WORKSPACE;
+    const int blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(softmax_nll_kernel, dim3(blocks), dim3(256), 0, s, z, ldz, C, idx, labels, n, scale, dz, (float *)work);
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, s, (const float *)work, blocks, loss);
+    return (int)hipGetLastError();
+}
 
 extern "C" int fitgnn_adam_step_f32(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, float lr,
                                     float beta1, float beta2, float eps, float weight_decay, float *step, void *stream) {

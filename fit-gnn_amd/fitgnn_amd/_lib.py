@@ -42,6 +42,8 @@ SIGNATURES = {
     "fitgnn_gat_edge_softmax_f32": (ctypes.c_int, [ptr, ptr, ptr, ptr, c_f32, c_i32, ptr, ptr]),
     "fitgnn_sddmm_csr_f32": (ctypes.c_int, [ptr, ptr, ptr, c_i64, ptr, c_i64, c_i32, c_i32, ptr, ptr]),
     "fitgnn_gat_softmax_bwd_f32": (ctypes.c_int, [ptr, ptr, ptr, ptr, ptr, ptr, c_f32, c_i32, ptr, ptr, ptr]),
+    "fitgnn_softmax_nll_workspace_bytes": (c_size, [c_i32]),
+    "fitgnn_softmax_nll_f32": (ctypes.c_int, [ptr, c_i64, c_i32, c_i32, ptr, ptr, c_i32, c_f32, ptr, ptr, ptr, c_size, ptr]),
     "fitgnn_adam_step_f32": (ctypes.c_int, [ptr, ptr, ptr, ptr, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, ptr, ptr]),
     "fitgnn_sum_leading_f32": (ctypes.c_int, [ptr, c_i32, c_i64, ptr, ptr]),
     "fitgnn_csr_row_sum_f32": (ctypes.c_int, [ptr, ptr, c_i32, ptr, ptr]),

@@ -100,6 +100,35 @@ class SmallLinear(torch.autograd.Function):
         return dx, dW, db
 
 
+class SoftmaxNLL(torch.autograd.Function):
+    """scale * sum_t NLL(log_softmax(z[idx[t]]), labels[t]): Classify_node's log_softmax (network.py:35) + NLLLoss
+    (run.py:341) over the train rows, with the gradient w.r.t. the logits produced by the same kernel
+    (fitgnn_softmax_nll_f32) -- one pass instead of seven small kernels.  Returns a 0-dim loss."""
+
+    @staticmethod
+    def forward(ctx, z, idx, labels, scale):
+        _lib.require_cuda(z, idx, labels)
+        L = _lib.lib()
+        z = _f32c(z)
+        n_rows, C = z.shape
+        n = int(idx.numel())
+        idx, labels = idx.long().contiguous(), labels.long().contiguous()
+        loss = torch.empty(1, dtype=torch.float32, device=z.device)
+        dz = torch.empty_like(z)
+        wb = int(L.fitgnn_softmax_nll_workspace_bytes(n))
+        work = torch.empty(wb, dtype=torch.uint8, device=z.device)
+        _lib.check(L.fitgnn_softmax_nll_f32(_lib.dptr(z), C, n_rows, C, _lib.dptr(idx), _lib.dptr(labels), n, float(scale),
+                                            _lib.dptr(loss), _lib.dptr(dz), _lib.dptr(work), wb, _lib.stream_ptr(z.device)),
+                   "fitgnn_softmax_nll_f32")
+        ctx.save_for_backward(dz)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (dz,) = ctx.saved_tensors
+        return dz * g, None, None, None
+
+
 def _f32c(t):
     if t.dtype != torch.float32:
         t = t.float()

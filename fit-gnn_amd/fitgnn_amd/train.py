@@ -101,6 +101,9 @@ class GDTrainer:
         self.pg = process_group
         self.dist = process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()
                                                   and torch.distributed.get_world_size() > 1)
+        from . import network as _net
+        self.fused_loss = (task == "node_cls" and isinstance(model, _net.Classify_node) and next(model.parameters()).is_cuda)
+        self._y_train = batch.y.index_select(0, batch.train_idx) if self.fused_loss else None
         count = torch.tensor([float(batch.train_idx.numel())], device=self.flat.buf.device)
         if self.dist:
             torch.distributed.all_reduce(count, group=self.pg)
@@ -111,6 +114,16 @@ class GDTrainer:
         m, b = self.model, self.batch
         m.train()
         self.flat.zero()  # optimizer.zero_grad(); grads live in the flat buffer
+        scale = 1.0 / self.global_count if self.reduction == "mean" else 1.0
+        if self.fused_loss:   # logits -> loss and d(loss)/d(logits) in one kernel (same arithmetic as log_softmax + NLLLoss)
+            from .ops import SoftmaxNLL
+            z = m.embed_and_head(b.x_table, b.edge_index, b.row_index) if self.dedup else m.embed_and_head(b.x, b.edge_index)
+            loss = SoftmaxNLL.apply(z, b.train_idx, self._y_train, scale)
+            loss.backward()
+            if self.dist:
+                torch.distributed.all_reduce(self.flat.buf, group=self.pg)
+            self.opt.step()
+            return loss.detach()
         out = m(b.x_table, b.edge_index, x_index=b.row_index) if self.dedup else m(b.x, b.edge_index)
         sel = out.index_select(0, b.train_idx)
         if self.task == "node_reg":

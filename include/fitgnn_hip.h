@@ -119,6 +119,15 @@ int fitgnn_segment_sum_f32(const int32_t *seg_off, const int32_t *members, int32
  * of the split-K weight-gradient GEMM dH^T @ X (the library has no deterministic split-K for K = number of rows). */
 int fitgnn_sum_leading_f32(const float *part, int32_t B, int64_t W, float *out, void *stream);
 
+/* loss[0] = scale * sum_t NLL(log_softmax(z[idx[t]]), labels[t]) over n selected rows (Classify_node's log_softmax,
+ * network.py:35, followed by NLLLoss, run.py:341; scale = 1/n for reduction='mean', 1/global count under data
+ * parallelism), and dz [n_rows x ldz] = its gradient w.r.t. the logits z (zero on rows that are not selected).
+ * One pass over the selected rows instead of log_softmax + gather + nll_loss and their three backward kernels. */
+size_t fitgnn_softmax_nll_workspace_bytes(int32_t n);
+int fitgnn_softmax_nll_f32(const float *z, int64_t ldz, int32_t n_rows, int32_t C, const int64_t *idx,
+                           const int64_t *labels, int32_t n, float scale, float *loss, float *dz, void *work,
+                           size_t work_bytes, void *stream);
+
 /* One Adam update (torch.optim.Adam semantics: L2 weight decay folded into the gradient, bias-corrected moments;
  * run.py:344 Adam(lr, weight_decay=5e-4)) over a FLAT parameter buffer of n floats (n % 4 == 0, 16-byte aligned) and its
  * equally laid out gradient / moment buffers.  step: device counter of completed updates (read, then advanced). */
