@@ -114,6 +114,9 @@ def main():
     ap.add_argument("--hidden", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fold", action="store_true", help="A/B: epilogue backward folded into the transposed SpMM (slower, see DESIGN.md)")
+    ap.add_argument("--prune-unused-rows", action="store_true",
+                    help="NOT the headline configuration: last layer only on the clusters' own nodes (the extra nodes' outputs "
+                         "never reach the loss); the edge count of the metric is then the number actually aggregated")
     ap.add_argument("--no-dedup", action="store_true",
                     help="run layer 0's X@W^T on the materialised union rows (one copy per subgraph membership) instead of "
                          "the de-duplicated feature table")
@@ -144,7 +147,7 @@ def main():
     torch.manual_seed(2)  # weight seed; identical on every rank
     model = network.Classify_node(margs).to(device)
     sd0 = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
-    trainer = train.GDTrainer(model, batch, lr=0.01, weight_decay=5e-4, dedup=not args.no_dedup)
+    trainer = train.GDTrainer(model, batch, lr=0.01, weight_decay=5e-4, dedup=not args.no_dedup, prune_unused_rows=args.prune_unused_rows)
 
     def barrier():
         if world > 1:
@@ -162,7 +165,10 @@ def main():
     dt = time.perf_counter() - t0
     events, ops.PROFILE = ops.PROFILE, None
     tmax = torch.tensor([dt], device=device, dtype=torch.float64)
-    edges = torch.tensor([4.0 * batch.nnz * args.steps], device=device, dtype=torch.float64)
+    edges_per_step = 4.0 * batch.nnz
+    if trainer.sub is not None:   # two full SpMMs (layer 0) + the own-node rows of A_hat twice (layer 1 forward / backward)
+        edges_per_step = 2.0 * batch.nnz + 2.0 * int(trainer.sub.f.col.numel())
+    edges = torch.tensor([edges_per_step * args.steps], device=device, dtype=torch.float64)
     if world > 1:
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         torch.distributed.all_reduce(edges)

@@ -273,3 +273,62 @@ def register(edge_index, graph, mode="gcn"):
            str(edge_index.device))
     _CACHE[key] = (weakref.ref(edge_index), graph)
     return graph
+
+
+# ---------------------------------------------------------------------------------------------
+# row subsets: the rows of A_hat whose outputs are consumed (the last layer only needs the clusters' own nodes)
+# ---------------------------------------------------------------------------------------------
+def make_tiles_pair(out_ptr, win_ptr, max_rows):
+    """Tiles for a rectangular block-diagonal pattern: block b owns output rows out_ptr[b]:out_ptr[b+1] and reads operand
+    rows win_ptr[b]:win_ptr[b+1].  Consecutive blocks are packed while both ranges stay within max_rows; a block that
+    exceeds it is cut along its output rows, its window clamped by the kernel (rows beyond it are fetched directly)."""
+    out_ptr, win_ptr = np.asarray(out_ptr, dtype=np.int64), np.asarray(win_ptr, dtype=np.int64)
+    nb = len(out_ptr) - 1
+    tiles, b = [], 0
+    while b < nb:
+        o0, w0 = int(out_ptr[b]), int(win_ptr[b])
+        if out_ptr[b + 1] - o0 > max_rows or win_ptr[b + 1] - w0 > max_rows:
+            for s in range(o0, int(out_ptr[b + 1]), max_rows):
+                tiles.append((s, min(s + max_rows, int(out_ptr[b + 1])), w0, int(win_ptr[b + 1]) - w0))
+            b += 1
+            continue
+        e = b + 1
+        while e < nb and out_ptr[e + 1] - o0 <= max_rows and win_ptr[e + 1] - w0 <= max_rows:
+            e += 1
+        if out_ptr[e] > o0:
+            tiles.append((o0, int(out_ptr[e]), w0, int(win_ptr[e]) - w0))
+        b = e
+    out = np.zeros(len(tiles), dtype=TILE_DTYPE)
+    if tiles:
+        arr = np.asarray(tiles, dtype=np.int32)
+        out["row_begin"], out["row_end"], out["win_begin"], out["win_rows"] = arr[:, 0], arr[:, 1], arr[:, 2], arr[:, 3]
+    return out
+
+
+class RowSubset:
+    """A_sub = A_hat[rows, :] of a CSRGraph (gcn mode) and its transpose, each with tiles, for a layer whose output is
+    only consumed on `rows` (sorted union-row ids; e.g. the clusters' own nodes: the outputs of the last GCN layer on
+    extra nodes never reach the loss, run.py:193-204 keeps out[mask] only).  `f`: [m x R] maps operand rows (all union
+    rows) to the m kept rows; `t`: [R x m] is its adjoint for the backward pass."""
+
+    def __init__(self, g, rows):
+        dev = g.device
+        rows = rows.to(dev).long()
+        self.rows, self.m, self.n, self.window_rows = rows, int(rows.numel()), g.n, g.window_rows
+        rp = g.f.rowptr.long()
+        cnt = rp[rows + 1] - rp[rows]
+        rowptr = torch.zeros(self.m + 1, dtype=torch.int64, device=dev)
+        rowptr[1:] = torch.cumsum(cnt, 0)
+        src = torch.repeat_interleave(rp[rows], cnt) + (torch.arange(int(rowptr[-1]), device=dev) - torch.repeat_interleave(rowptr[:-1], cnt))
+        col, val = g.f.col[src].contiguous(), g.f.val[src].contiguous()
+        self.f = _Side(rowptr.to(torch.int32), col)
+        self.f.val = val
+        kept_row = torch.repeat_interleave(torch.arange(self.m, device=dev), cnt)        # compact row of every entry
+        rowptr_t, col_t, perm = _csr_from_coo(col.long(), kept_row, g.n)
+        self.t = _Side(rowptr_t, col_t)
+        self.t.val = val[perm].contiguous()
+        ptr = np.asarray(g.ptr, dtype=np.int64)                                          # union-row block boundaries
+        kp = np.searchsorted(rows.cpu().numpy(), ptr, side="left")                       # kept-row block boundaries
+        self.f.tiles = tiles_to_device(make_tiles_pair(kp, ptr, g.window_rows), self.f.rowptr)
+        self.t.tiles = tiles_to_device(make_tiles_pair(ptr, kp, g.window_rows), self.t.rowptr)
+        self.f.n_tiles, self.t.n_tiles = int(self.f.tiles.shape[0]), int(self.t.tiles.shape[0])

@@ -76,10 +76,15 @@ class _Base(nn.Module):
                 x = F.dropout(x, p=self.dropout_p, training=self.training)
         return x
 
-    def embed_and_head(self, x, edge_index, x_index=None):
+    def embed_and_head(self, x, edge_index, x_index=None, out_rows=None):
         """embed() followed by lt1; on the GPU the last GCN layer and the head form one autograd node.
-        x_index (ops.RowIndex, optional): x is a de-duplicated table and union row r is table row x_index.index[r]."""
+        x_index (ops.RowIndex, optional): x is a de-duplicated table and union row r is table row x_index.index[r].
+        out_rows (csr.RowSubset, optional): return the head's output on those rows only.  The last layer is then
+        evaluated as (A_hat[rows] h) W^T -- aggregation first, on the kept rows, so that its GEMM, activation and the
+        head run on len(rows) rows instead of all of them (same values on those rows: A (h W^T) = (A h) W^T)."""
         L = self.num_layers
+        if out_rows is not None:
+            return self._embed_and_head_rows(x, edge_index, x_index, out_rows)
         first = 0
         if x_index is not None:
             h = self._first_layer_dedup(x, edge_index, x_index) if L > 1 else None
@@ -103,6 +108,36 @@ class _Base(nn.Module):
         seed = ops.next_seed() if (self.training and self.dropout_p > 0 and mask is None) else 0
         return ops.FusedGCNLayerHead.apply(x, last.lin.weight, last.bias, self.lt1.weight, self.lt1.bias, g,
                                            float(self.dropout_p), bool(self.training), seed, mask)
+
+    def _embed_and_head_rows(self, x, edge_index, x_index, sub):
+        L = self.num_layers
+        last = self.conv[L - 1]
+        if not (L > 0 and isinstance(last, fnn.GCNConv)):
+            raise NotImplementedError("out_rows needs a GCNConv last layer")
+        first = 0
+        if x_index is not None:
+            h = self._first_layer_dedup(x, edge_index, x_index) if L > 1 else None
+            if h is None:
+                x = x.index_select(0, x_index.index.long())
+            else:
+                x, first = h, 1
+        x = x.float()
+        for i in range(first, L - 1):
+            conv = self.conv[i]
+            mask = self._inject_masks[i] if self._inject_masks is not None else None
+            x = conv.forward_elu_dropout(x, edge_index, p=self.dropout_p, training=self.training, mask=mask) \
+                if isinstance(conv, fnn.GCNConv) else F.dropout(F.elu(conv(x, edge_index)), p=self.dropout_p, training=self.training)
+        agg = ops.SpMMRows.apply(x, sub)                                   # [m, H_in]
+        z = ops.Linear.apply(agg, last.lin.weight)
+        if last.bias is not None:
+            z = z + last.bias
+        mask = self._inject_masks[L - 1] if self._inject_masks is not None else None
+        z = F.elu(z)
+        if mask is not None and self.training:
+            z = z * mask.index_select(0, sub.rows).to(z.dtype) / (1.0 - self.dropout_p)
+        else:
+            z = F.dropout(z, p=self.dropout_p, training=self.training)
+        return self.head(z)
 
     def head(self, x):
         """lt1 (network.py:34): same parameters as nn.Linear, evaluated as mm + broadcast add."""

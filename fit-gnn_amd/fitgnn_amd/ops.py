@@ -304,6 +304,21 @@ class SpMM(torch.autograd.Function):
         return dX, db, None
 
 
+class SpMMRows(torch.autograd.Function):
+    """Y = A_hat[rows, :] X for a csr.RowSubset (only the rows whose outputs are consumed); backward = its adjoint."""
+
+    @staticmethod
+    def forward(ctx, X, sub):
+        ctx.sub = sub
+        f = sub.f
+        return spmm_raw(f.rowptr, f.col, f.val, f.tiles, X, sub.m, window_rows=sub.window_rows)
+
+    @staticmethod
+    def backward(ctx, dY):
+        t = ctx.sub.t
+        return spmm_raw(t.rowptr, t.col, t.val, t.tiles, _f32c(dY), ctx.sub.n, window_rows=ctx.sub.window_rows), None
+
+
 class FusedGCNLayer(torch.autograd.Function):
     """out = dropout(ELU(A_hat (X W^T) + b)): GCNConv (network.py:31) + F.elu (:32) + F.dropout (:33) as
     one GEMM + one SpMM with fused epilogue.  `mask` (uint8 [N,H]) injects a dropout pattern for tests."""

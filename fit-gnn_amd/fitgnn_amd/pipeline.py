@@ -316,7 +316,9 @@ def node_classification(args, path, data, co, device="cuda", log=print):
             model.load_state_dict(torch.load(ckpt))
         if args.exp_setup in ("Gs_train_2_Gs_infer", "Gc_train_2_Gs_train"):
             if args.gradient_method == "GD":
-                trainer = GDTrainer(model, batch, lr=args.lr, weight_decay=args.weight_decay, reduction=args.loss_reduction)
+                # the extra nodes' last-layer outputs never reach the loss: evaluate that layer on the own nodes only
+                trainer = GDTrainer(model, batch, lr=args.lr, weight_decay=args.weight_decay, reduction=args.loss_reduction,
+                                    prune_unused_rows=True)
             else:
                 trainer = MBTrainer(model, batch, batch_size=args.batch_size, lr=args.lr, weight_decay=args.weight_decay,
                                     reduction=args.loss_reduction, capture=True)  # launch-bound: replayed from hipGraphs

@@ -87,9 +87,14 @@ class FlatAdam:
 
 class GDTrainer:
     def __init__(self, model, batch, lr=0.01, weight_decay=5e-4, reduction="mean", process_group=None, dedup=True,
-                 task="node_cls"):
-        """task 'node_cls': NLLLoss on log-probabilities (run.py:341); 'node_reg': L1Loss on the [n, 1] outputs (run.py:518)."""
+                 task="node_cls", prune_unused_rows=False):
+        """task 'node_cls': NLLLoss on log-probabilities (run.py:341); 'node_reg': L1Loss on the [n, 1] outputs (run.py:518).
+        prune_unused_rows: evaluate the last layer only on the rows that can reach the loss (the clusters' own nodes: the
+        reference computes and then discards the extra nodes' outputs, run.py:193-204).  Same loss and gradients; the
+        last layer's GEMMs and both of its SpMMs shrink to the own-node rows.  Off by default: bench.py's metric counts
+        every non-zero of A_hat in all four SpMMs."""
         self.model, self.batch, self.task = model, batch, task
+        self.sub = None
         # first layer on the de-duplicated feature table when the batch carries one (same arithmetic, fewer FLOPs)
         self.dedup = dedup and getattr(batch, "row_index", None) is not None
         self.flat = FlatGrads(model.parameters())
@@ -104,6 +109,14 @@ class GDTrainer:
         from . import network as _net
         self.fused_loss = (task == "node_cls" and isinstance(model, _net.Classify_node) and next(model.parameters()).is_cuda)
         self._y_train = batch.y.index_select(0, batch.train_idx) if self.fused_loss else None
+        if prune_unused_rows and self.fused_loss and batch.graph is not None:
+            from .csr import RowSubset
+            core_rows = torch.nonzero(batch.core).flatten()
+            self.sub = RowSubset(batch.graph, core_rows)
+            pos = torch.full((batch.n_rows,), -1, dtype=torch.int64, device=core_rows.device)
+            pos[core_rows] = torch.arange(core_rows.numel(), device=core_rows.device)
+            self._train_pos = pos[batch.train_idx]          # train rows are own nodes (utils.py:695-698)
+            assert int(self._train_pos.min()) >= 0
         count = torch.tensor([float(batch.train_idx.numel())], device=self.flat.buf.device)
         if self.dist:
             torch.distributed.all_reduce(count, group=self.pg)
@@ -117,8 +130,13 @@ class GDTrainer:
         scale = 1.0 / self.global_count if self.reduction == "mean" else 1.0
         if self.fused_loss:   # logits -> loss and d(loss)/d(logits) in one kernel (same arithmetic as log_softmax + NLLLoss)
             from .ops import SoftmaxNLL
-            z = m.embed_and_head(b.x_table, b.edge_index, b.row_index) if self.dedup else m.embed_and_head(b.x, b.edge_index)
-            loss = SoftmaxNLL.apply(z, b.train_idx, self._y_train, scale)
+            if self.sub is not None:
+                z = (m.embed_and_head(b.x_table, b.edge_index, b.row_index, out_rows=self.sub) if self.dedup
+                     else m.embed_and_head(b.x, b.edge_index, out_rows=self.sub))
+                loss = SoftmaxNLL.apply(z, self._train_pos, self._y_train, scale)
+            else:
+                z = m.embed_and_head(b.x_table, b.edge_index, b.row_index) if self.dedup else m.embed_and_head(b.x, b.edge_index)
+                loss = SoftmaxNLL.apply(z, b.train_idx, self._y_train, scale)
             loss.backward()
             if self.dist:
                 torch.distributed.all_reduce(self.flat.buf, group=self.pg)

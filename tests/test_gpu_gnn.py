@@ -408,3 +408,35 @@ def test_flat_adam_equals_torch_adam(mods):
     ref2.load_state_dict(sd)          # torch accepts it
     opt.load_state_dict(ref.state_dict())
     assert float(opt.step_count) == 5.0 and rel(opt._views(opt.m)[2], ref.state[qs[2]]["exp_avg"]) < 1e-6
+
+
+def test_pruned_last_layer_equals_full_evaluation(mods):
+    """GDTrainer(prune_unused_rows=True) -- last layer as (A_hat[own rows] h) W^T on the clusters' own nodes only -- gives
+    the same loss and, after three epochs, the same weights as the full evaluation (dropout off); RowSubset's two
+    patterns are adjoint."""
+    from fitgnn_amd import ops, train
+    from fitgnn_amd.csr import RowSubset
+
+    network, fnn, gorc = mods
+    batch, _ = _subgraph_batches(seed=6)
+    args = argparse.Namespace(num_layers1=2, layer_name="GCNConv", num_features=24, hidden=32, num_classes=4)
+    torch.manual_seed(8)
+    m1 = network.Classify_node(args).cuda(); m1.dropout_p = 0.0
+    m2 = network.Classify_node(args).cuda(); m2.dropout_p = 0.0
+    m2.load_state_dict(m1.state_dict())
+    t1 = train.GDTrainer(m1, batch, lr=0.01, weight_decay=5e-4)
+    t2 = train.GDTrainer(m2, batch, lr=0.01, weight_decay=5e-4, prune_unused_rows=True)
+    assert t2.sub is not None and t2.sub.m == int(batch.core.sum())
+    for epoch in range(3):
+        a, b = float(t1.step()), float(t2.step())
+        assert a == pytest.approx(b, rel=2e-5), (epoch, a, b)
+    for (k, v), (_, w) in zip(m1.state_dict().items(), m2.state_dict().items()):
+        assert rel(w, v) < 2e-4, k
+    sub = t2.sub
+    X, Z = torch.randn(batch.n_rows, 32, device="cuda"), torch.randn(sub.m, 32, device="cuda")
+    Y = ops.SpMMRows.apply(X, sub)
+    full = ops.spmm_graph(batch.graph, X).index_select(0, sub.rows)
+    assert rel(Y, full) < 1e-6
+    XT = ops.spmm_raw(sub.t.rowptr, sub.t.col, sub.t.val, sub.t.tiles, Z, sub.n, window_rows=sub.window_rows)
+    lhs, rhs = float((Y.double() * Z.double()).sum()), float((X.double() * XT.double()).sum())
+    assert abs(lhs - rhs) < 1e-6 * (abs(lhs) + abs(rhs) + 1)
