@@ -129,11 +129,17 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    n_dev = torch.cuda.device_count()
+    local_rank %= max(n_dev, 1)   # rehearsal on a box with fewer GPUs than ranks (FITGNN_BENCH_BACKEND=gloo)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.distributed.init_process_group("nccl", device_id=device)
+        backend = os.environ.get("FITGNN_BENCH_BACKEND", "nccl")   # nccl = RCCL over xGMI; gloo only to rehearse the
+        if backend == "nccl":                                       # multi-process path on a single-GPU box
+            torch.distributed.init_process_group("nccl", device_id=device)
+        else:
+            torch.distributed.init_process_group(backend)
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from fitgnn_amd import network, ops, train
