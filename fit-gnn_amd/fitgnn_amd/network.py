@@ -29,7 +29,7 @@ def _make_convs(args):
     dims = [args.num_features] + [args.hidden] * args.num_layers1
     for i in range(args.num_layers1):
         if args.layer_name == "GINConv":  # network.py:19-21: two-layer ReLU MLP, train_eps=True
-            mlp = nn.Sequential(nn.Linear(dims[i], args.hidden), nn.ReLU(), nn.Linear(args.hidden, args.hidden), nn.ReLU())
+            mlp = nn.Sequential(fnn.Linear(dims[i], args.hidden), nn.ReLU(), fnn.Linear(args.hidden, args.hidden), nn.ReLU())
             convs.append(cls(mlp, train_eps=True))
         else:
             convs.append(cls(dims[i], dims[i + 1]))
