@@ -67,7 +67,7 @@ class _Base(nn.Module):
         x = x.float()
         for i in range(first, self.num_layers):
             conv = self.conv[i]
-            if isinstance(conv, fnn.GCNConv) and x.is_cuda:
+            if isinstance(conv, (fnn.GCNConv, fnn.GATConv)) and x.is_cuda:
                 mask = self._inject_masks[i] if self._inject_masks is not None else None
                 x = conv.forward_elu_dropout(x, edge_index, p=self.dropout_p, training=self.training, mask=mask)
             else:

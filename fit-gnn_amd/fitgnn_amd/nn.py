@@ -145,6 +145,14 @@ class GATConv(nn.Module):
         h = ops.Linear.apply(x.float(), self.lin.weight)
         return ops.GATAggregate.apply(h, self.att_src.view(-1), self.att_dst.view(-1), self.bias, g, self.negative_slope)
 
+    def forward_elu_dropout(self, x, edge_index, p=0.5, training=False, mask=None):
+        """conv -> F.elu -> F.dropout (network.py:31-33) with the activation in the aggregation kernel's epilogue."""
+        g = csr_for(edge_index, x.shape[0], "gat")
+        h = ops.Linear.apply(x.float(), self.lin.weight)
+        seed = ops.next_seed() if (training and p > 0 and mask is None) else 0
+        return ops.GATAggregate.apply(h, self.att_src.view(-1), self.att_dst.view(-1), self.bias, g, self.negative_slope,
+                                      True, float(p), bool(training), seed, mask)
+
 
 class APPNP(nn.Module):
     """z <- (1-alpha) A_hat z + alpha z0, K times (Baselines/SGGC/APPNP/networks.py:11,23: K=10, alpha=0.1)."""

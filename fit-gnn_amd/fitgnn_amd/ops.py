@@ -427,7 +427,8 @@ class GATAggregate(torch.autograd.Function):
     (CSRGraph(mode='gat')); attention weights replace its values."""
 
     @staticmethod
-    def forward(ctx, h, att_src, att_dst, bias, g, slope):
+    def forward(ctx, h, att_src, att_dst, bias, g, slope, act=False, p=0.0, training=False, seed=0, mask=None):
+        """act=True fuses F.elu and F.dropout(p) (network.py:32-33) into the aggregation's epilogue, as for GCNConv."""
         L = _lib.lib()
         h = _f32c(h)
         n, C = h.shape
@@ -441,17 +442,26 @@ class GATAggregate(torch.autograd.Function):
         alpha = torch.empty(g.nnz, dtype=torch.float32, device=dev)
         _lib.check(L.fitgnn_gat_edge_softmax_f32(_lib.dptr(g.f.rowptr), _lib.dptr(g.f.col), _lib.dptr(a_src), _lib.dptr(a_dst),
                                                  float(slope), n, _lib.dptr(alpha), st), "gat_edge_softmax")
-        out = spmm_raw(g.f.rowptr, g.f.col, alpha, g.f.tiles, h, n, bias=bias, epilogue=EPI_BIAS if bias is not None else 0,
-                       window_rows=g.window_rows, lcol=g.f.lcol, win_cols=g.f.win_cols)
-        ctx.save_for_backward(h, att_src, att_dst, a_src, a_dst, alpha)
+        epi = EPI_BIAS if bias is not None else 0
+        drop = bool(act) and bool(training) and p > 0.0
+        if act:
+            epi |= EPI_ELU | (EPI_DROPOUT if drop else 0)
+        out = spmm_raw(g.f.rowptr, g.f.col, alpha, g.f.tiles, h, n, bias=bias, epilogue=epi, p=p if drop else 0.0, seed=seed,
+                       mask=mask if drop else None, window_rows=g.window_rows, lcol=g.f.lcol, win_cols=g.f.win_cols)
+        ctx.save_for_backward(h, att_src, att_dst, a_src, a_dst, alpha, out if act else None, mask if drop else None)
         ctx.g, ctx.slope, ctx.has_bias = g, slope, bias is not None
+        ctx.act, ctx.drop, ctx.p, ctx.seed = bool(act), drop, p, seed
         return out
 
     @staticmethod
     def backward(ctx, dOut):
-        h, att_src, att_dst, a_src, a_dst, alpha = ctx.saved_tensors
+        h, att_src, att_dst, a_src, a_dst, alpha, out, mask = ctx.saved_tensors
         g, L = ctx.g, _lib.lib()
         dOut = _f32c(dOut)
+        db_fused = None
+        if ctx.act:   # through ELU / dropout first: dOut becomes the gradient of the pre-activation, db its column sums
+            dOut, db_fused = epilogue_bwd_raw(dOut, out, EPI_ELU | (EPI_DROPOUT if ctx.drop else 0), p=ctx.p if ctx.drop else 0.0,
+                                              seed=ctx.seed, mask=mask, want_db=ctx.has_bias)
         n, C = h.shape
         dev = h.device
         st = _lib.stream_ptr(dev)
@@ -476,8 +486,11 @@ class GATAggregate(torch.autograd.Function):
         datt = mm_at_b(torch.stack([da_src, da_dst], dim=1), h) if (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]) else None
         datt_src = datt[0] if ctx.needs_input_grad[1] else None
         datt_dst = datt[1] if ctx.needs_input_grad[2] else None
-        db = dOut.sum(0) if ctx.has_bias and ctx.needs_input_grad[3] else None
-        return dh, datt_src, datt_dst, db, None, None
+        if ctx.act:
+            db = db_fused if ctx.has_bias else None
+        else:
+            db = dOut.sum(0) if ctx.has_bias and ctx.needs_input_grad[3] else None
+        return dh, datt_src, datt_dst, db, None, None, None, None, None, None, None
 
 
 _HEAD_MAX = None
