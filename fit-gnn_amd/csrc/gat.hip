@@ -95,19 +95,37 @@ __global__ __launch_bounds__(256) void gat_sddmm_kernel(const int32_t *__restric
         g[v] = c < C ? *reinterpret_cast<const float4 *>(dOut + (int64_t)row * ldo + c) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     const int e0 = rowptr[row], e1 = rowptr[row + 1];
-    for (int e = e0; e < e1; ++e) {
-        const float *hr = h + (int64_t)col[e] * ldh;
-        float s = 0.f;
+    // the row's column ids sit on the lanes; four edges per step: their operand rows are all in flight before the first
+    // dot product (one edge at a time is a chain col -> row fetch -> reduction per edge)
+    for (int base = e0; base < e1; base += 64) {
+        const int cnt = min(64, e1 - base);
+        const int my_c = lane < cnt ? col[base + lane] : 0;
+        for (int k = 0; k < cnt; k += 4) {
+            const int n4 = min(4, cnt - k);  // wave-uniform
+            float4 x[4][MAXV];
 #pragma unroll
-        for (int v = 0; v < MAXV; ++v) {
-            const int c = (v * 64 + lane) * 4;
-            if (c < C) {
-                const float4 x = *reinterpret_cast<const float4 *>(hr + c);
-                s += g[v].x * x.x + g[v].y * x.y + g[v].z * x.z + g[v].w * x.w;
+            for (int j = 0; j < 4; ++j) {
+                const int cj = __builtin_amdgcn_readlane(my_c, k + min(j, n4 - 1));
+                const float *hr = h + (int64_t)cj * ldh;
+#pragma unroll
+                for (int v = 0; v < MAXV; ++v) {
+                    const int c = (v * 64 + lane) * 4;
+                    x[j][v] = c < C ? *reinterpret_cast<const float4 *>(hr + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
             }
+            float sj[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float s = 0.f;
+#pragma unroll
+                for (int v = 0; v < MAXV; ++v)
+                    s += g[v].x * x[j][v].x + g[v].y * x[j][v].y + g[v].z * x[j][v].z + g[v].w * x[j][v].w;
+                sj[j] = s;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sj[j] = wave_sum(sj[j]);
+            if (lane < n4) dalpha[base + k + lane] = lane == 0 ? sj[0] : lane == 1 ? sj[1] : lane == 2 ? sj[2] : sj[3];
         }
-        s = wave_sum(s);
-        if (lane == 0) dalpha[e] = s;
     }
 }
 __global__ __launch_bounds__(256) void gat_sddmm_scalar_kernel(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
