@@ -236,6 +236,39 @@ extern "C" int fitgnn_gat_softmax_bwd_f32(const int32_t *rowptr, const int32_t *
     return (int)hipGetLastError();
 }
 
+// Narrow SpMM for propagation on class-wide signals (APPNP: K = 10 steps on [rows x num_classes]):
+//   Y[r, c] = beta * sum_e val[e] X[col[e], c] + gamma * Z0[r, c];   optionally ACC[r, c] += delta * X[r, c].
+// One thread per (row, column): a row's H threads read the same (col, val) stream (served by the cache) and
+// neighbouring columns of X.  The tiled kernel gives H < 64 columns a 64-lane slab each, i.e. 3 live lanes for H = 3.
+__global__ __launch_bounds__(256) void spmm_narrow_kernel(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                                          const float *__restrict__ val, const float *__restrict__ X,
+                                                          float *__restrict__ Y, int32_t n, int32_t H, float beta,
+                                                          const float *__restrict__ Z0, float gamma, float *__restrict__ ACC,
+                                                          float delta) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (int64_t)n * H) return;
+    const int r = (int)(t / H), c = (int)(t - (int64_t)r * H);
+    float acc = 0.f;
+    const int e1 = rowptr[r + 1];
+    for (int e = rowptr[r]; e < e1; ++e) acc = fmaf(val[e], X[(int64_t)col[e] * H + c], acc);
+    float y = beta * acc;
+    if (Z0) y = fmaf(gamma, Z0[t], y);
+    Y[t] = y;
+    if (ACC) ACC[t] = fmaf(delta, X[t], ACC[t]);
+}
+
+extern "C" int fitgnn_spmm_narrow_f32(const int32_t *rowptr, const int32_t *col, const float *val, const float *X, float *Y,
+                                      int32_t n_rows, int32_t H, float beta, const float *Z0, float gamma, float *ACC,
+                                      float delta, void *stream) {
+    if (n_rows < 0 || H < 0) return FITGNN_E_BADARG;
+    if (n_rows == 0 || H == 0) return 0;
+    if (!rowptr || !X || !Y) return FITGNN_E_BADARG;
+    const int64_t threads = (int64_t)n_rows * H;
+    hipLaunchKernelGGL(spmm_narrow_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rowptr, col, val,
+                       X, Y, n_rows, H, beta, Z0, gamma, ACC, delta);
+    return (int)hipGetLastError();
+}
+
 extern "C" int fitgnn_csr_row_sum_f32(const int32_t *rowptr, const float *v, int32_t n, float *y, void *stream) {
     if (n < 0) return FITGNN_E_BADARG;
     if (n == 0) return 0;

@@ -495,6 +495,43 @@ class GATAggregate(torch.autograd.Function):
         return dh, datt_src, datt_dst, db, None, None, None, None, None, None, None
 
 
+class APPNPPropagate(torch.autograd.Function):
+    """z_K of  z_{k+1} = (1 - alpha) A_hat z_k + alpha z0,  z_0 = z0  (APPNP's K propagation steps) on a class-wide signal,
+    one narrow-SpMM launch per step with the teleport term in its epilogue; the backward pass propagates with A_hat^T and
+    accumulates d z0 = alpha * sum_k dz_{k+1} + dz_0 in the same launches."""
+
+    @staticmethod
+    def forward(ctx, z0, g, K, alpha):
+        L = _lib.lib()
+        z0 = _f32c(z0)
+        n, H = z0.shape
+        st = _lib.stream_ptr(z0.device)
+        f = g.f
+        z = z0
+        for _ in range(K):
+            nxt = torch.empty_like(z0)
+            _lib.check(L.fitgnn_spmm_narrow_f32(_lib.dptr(f.rowptr), _lib.dptr(f.col), _lib.dptr(f.val), _lib.dptr(z), _lib.dptr(nxt),
+                                                n, H, 1.0 - alpha, _lib.dptr(z0), float(alpha), None, 0.0, st), "spmm_narrow")
+            z = nxt
+        ctx.g, ctx.K, ctx.alpha = g, K, alpha
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        L = _lib.lib()
+        dz = _f32c(dz)
+        n, H = dz.shape
+        st = _lib.stream_ptr(dz.device)
+        t = ctx.g.t
+        acc = torch.zeros_like(dz)
+        for _ in range(ctx.K):   # dz_k = (1 - alpha) A^T dz_{k+1};  acc += alpha * dz_{k+1}
+            nxt = torch.empty_like(dz)
+            _lib.check(L.fitgnn_spmm_narrow_f32(_lib.dptr(t.rowptr), _lib.dptr(t.col), _lib.dptr(t.val), _lib.dptr(dz), _lib.dptr(nxt),
+                                                n, H, 1.0 - ctx.alpha, None, 0.0, _lib.dptr(acc), float(ctx.alpha), st), "spmm_narrow")
+            dz = nxt
+        return acc + dz, None, None, None
+
+
 _HEAD_MAX = None
 
 

@@ -185,6 +185,14 @@ int fitgnn_gat_softmax_bwd_f32(const int32_t *rowptr, const int32_t *col, const 
                                float *da_dst, void *stream);
 int fitgnn_csr_row_sum_f32(const int32_t *rowptr, const float *v, int32_t n, float *y, void *stream);
 
+/* Propagation on narrow signals (APPNP, Baselines/SGGC/APPNP/networks.py:11,23: z <- (1-alpha) A_hat z + alpha z0 on
+ * [rows x num_classes]): Y = beta * (A X) + gamma * Z0 (Z0 may be NULL), and optionally ACC += delta * X (the backward
+ * pass accumulates d z0 while it propagates).  X, Y, Z0, ACC: dense row-major [n_rows x H], leading dimension H; A is
+ * square.  Meant for H well below 64, where the tiled kernel would idle most of a wavefront. */
+int fitgnn_spmm_narrow_f32(const int32_t *rowptr, const int32_t *col, const float *val, const float *X, float *Y,
+                           int32_t n_rows, int32_t H, float beta, const float *Z0, float gamma, float *ACC, float delta,
+                           void *stream);
+
 /* =====================================================================================
  * Coarsen half: one contraction level of variation_neighborhoods
  * replaces: graph_coarsening/coarsening_utils.py contract_variation_linear :530-650,

@@ -76,6 +76,17 @@ def test_sage_gin_appnp(mods):
     ap = fnn.APPNP(K=10, alpha=0.1)
     out = ap(x.cuda(), ei.cuda()).cpu()
     assert rel(out, gorc.appnp(x, ei, 10, 0.1)) < 1e-4
+    # class-wide signal -> the narrow kernel with the teleport term fused; wide signal -> the tiled kernel: same values,
+    # and the propagation's gradient against the oracle's autograd
+    for width in (7, 96):
+        z = torch.randn(n, width)
+        zg = z.cuda().requires_grad_(True)
+        zc = z.clone().requires_grad_(True)
+        o, r = ap(zg, ei.cuda()), gorc.appnp(zc, ei, 10, 0.1)
+        assert rel(o.detach().cpu(), r.detach()) < 1e-4
+        w = torch.randn(n, width)
+        o.backward(w.cuda()); r.backward(w)
+        assert rel(zg.grad.cpu(), zc.grad) < 1e-4, width
 
 
 @pytest.mark.parametrize("train", [False, True])

@@ -30,7 +30,7 @@ for layer in ("GCNConv", "GATConv", "SAGEConv", "GINConv"):
 class APPNPNet(torch.nn.Module):   # Baselines/SGGC/APPNP/networks.py: lin1 -> relu -> dropout -> lin2 -> APPNP(K=10, alpha=0.1)
     def __init__(self):
         super().__init__()
-        self.l1, self.l2, self.prop = torch.nn.Linear(Fdim, 512), torch.nn.Linear(512, C), fnn.APPNP(10, 0.1)
+        self.l1, self.l2, self.prop = fnn.Linear(Fdim, 512), fnn.Linear(512, C), fnn.APPNP(10, 0.1)
     def forward(self, x, ei):
         h = F.dropout(F.relu(self.l1(F.dropout(x, 0.5, self.training))), 0.5, self.training)
         return F.log_softmax(self.prop(self.l2(h), ei), dim=1)
