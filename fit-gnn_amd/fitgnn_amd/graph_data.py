@@ -110,6 +110,8 @@ class GraphSet:
         n = co.n_clusters
         self.x = torch.as_tensor(mol["x"]).to(dev).float()
         self.y = torch.as_tensor(mol["y"]).to(dev).float()
+        self.edge_index = torch.from_numpy(ei).to(dev)                # the original graphs (baselines, run.py:967-1100)
+        self.node_graph = torch.from_numpy(np.repeat(np.arange(G), np.diff(node_ptr))).to(dev)
         # ---- Gc (load_graph_data, utils.py:811-852) ----
         self.gc_x = co.pool(self.x)
         coo = co.Wc.tocoo()
@@ -133,9 +135,14 @@ class GraphSet:
     # ---- batches: contiguous graph ranges ------------------------------------------------------------------
     def batch(self, g0, g1, kind):
         """Graphs g0:g1 as one block-diagonal piece: dict(x, edge_index, graph (0-based), mask, y, n_graphs) for
-        kind 'gs' (subgraph union) or 'gc' (coarse graphs).  The piece's CSR is built and registered once."""
+        kind 'gs' (subgraph union), 'gc' (coarse graphs) or 'orig' (the uncoarsened graphs: baselines).  The piece's CSR is
+        built and registered once."""
         dev = self.x.device
-        if kind == "gs":
+        if kind == "orig":
+            r0, r1 = int(self.node_ptr[g0]), int(self.node_ptr[g1])
+            x, graph, mask, ei = self.x[r0:r1], self.node_graph[r0:r1] - g0, None, self.edge_index
+            blocks = self.node_ptr[g0:g1 + 1] - r0
+        elif kind == "gs":
             r0, r1 = int(self.gs_ptr[g0]), int(self.gs_ptr[g1])
             x, graph, mask, ei, ptr = self.gs_x[r0:r1], self.gs_graph[r0:r1] - g0, self.gs_mask[r0:r1], self.gs_edge_index, self.sub_ptr
             blocks = ptr[(ptr >= r0) & (ptr <= r1)] - r0

@@ -562,3 +562,97 @@ def node_regression(args, path, data, co, device="cuda", log=print):
                 f"{np.mean(top)} +/- {np.std(top)},{top[0]}\n")
     log(f"top_10_loss: {np.mean(top)} +/- {np.std(top)}  best_loss: {top[0]}")
     return all_loss, all_time
+
+
+def graph_baseline(args, path, mol, device="cuda", log=print):
+    """run.graph_regression_baseline / graph_classification_baseline (run.py:967-1100): the *_graph_gc model on the
+    UNCOARSENED graphs, gradients cleared per batch, float targets, best-val checkpoint, results/baseline row."""
+    from . import graph_data
+    from .train import GraphTrainer
+
+    cls_task = args.task == "graph_cls"
+    gset = graph_data.GraphSet(mol, ratio=0.5, extra_node=False, device=device)   # the contraction is unused here
+    G = gset.n_graphs
+    gen = torch.Generator().manual_seed(0 if args.seed is None else args.seed)
+    idx = torch.randperm(G, generator=gen).tolist()
+    split = {"train": idx[: G // 2], "val": idx[G // 2: 3 * G // 4], "test": idx[3 * G // 4:]}
+    if not cls_task:
+        args.num_classes = 1
+    model = (network.Classify_graph_gc if cls_task else network.Regress_graph_gc)(args).to(device)
+    kw = dict(kind="orig", batch_size=args.batch_size, lr=args.lr, weight_decay=args.weight_decay, multi_prop=bool(args.multi_prop),
+              prop=args.property, task=args.task, truncate_targets=False, accumulate=False, capture=True)
+    tr = GraphTrainer(model, gset, split["train"], **kw)
+    va, te = (GraphTrainer(model, gset, split[s], share=tr, **kw) for s in ("val", "test"))
+    ckpt = os.path.join(path, "model.pt")
+    best_val, best_test, best_acc = float("inf"), float("inf"), 0.0
+    for epoch in range(args.epochs1):
+        tr.step()
+        v, t = float(va.evaluate()), float(te.evaluate())
+        if v < best_val or epoch == 0:
+            best_val, best_test = v, t
+            best_acc = te.accuracy() if cls_task else 0.0
+            torch.save(model.state_dict(), ckpt)
+    os.makedirs("results/baseline", exist_ok=True)
+    fn = f"results/baseline/{args.dataset}.csv"
+    if not os.path.exists(fn):
+        with open(fn, "w") as f:
+            f.write("dataset,layer_name,hidden,num_layers,epochs,batch_size,lr,best_test_loss" + (",best_test_acc" if cls_task else "") + "\n")
+    with open(fn, "a") as f:
+        f.write(f"{args.dataset},{args.layer_name},{args.hidden},{args.num_layers1},{args.epochs1},{args.batch_size},{args.lr},{best_test}"
+                + (f",{best_acc}" if cls_task else "") + "\n")
+    log(f"baseline best_test_loss: {best_test}" + (f"  best_test_acc: {best_acc}" if cls_task else ""))
+    return (best_test, best_acc) if cls_task else best_test
+
+
+def node_regression_baseline(args, path, data, device="cuda", log=print):
+    """run.node_regression_baseline (run.py:904-965): Regress_node on the full graph, L1 loss, test loss / std(labels)."""
+    rng = np.random.default_rng(args.seed)
+    data = splits_regression(data, args.train_ratio, args.val_ratio, rng)
+    x = data.x.to(device).float()
+    ei = torch.as_tensor(np.asarray(data.edge_index)).to(device)
+    y = data.y.flatten().to(device).float()
+    tr, va, te = (torch.nonzero(m.to(device)).flatten() for m in (data.train_mask, data.val_mask, data.test_mask))
+    args.num_classes = 1
+    all_loss, all_time = [], []
+    ckpt = os.path.join(path, "model.pt")
+    for run in range(args.runs):
+        if args.seed is not None:
+            torch.manual_seed(args.seed + run)
+        model = network.Regress_node(args).to(device)
+        model.reset_parameters()
+        opt = torch.optim.Adam(model.parameters(), lr=args.lr, weight_decay=args.weight_decay)
+        best = float("inf")
+        for epoch in range(args.epochs1):
+            model.train()
+            opt.zero_grad()
+            out = model(x, ei).flatten()
+            F.l1_loss(out.index_select(0, tr), y.index_select(0, tr), reduction=args.loss_reduction).backward()
+            opt.step()
+            model.eval()
+            with torch.no_grad():
+                vloss = float(F.l1_loss(model(x, ei).flatten().index_select(0, va), y.index_select(0, va), reduction=args.loss_reduction))
+            if vloss < best or epoch == 0:
+                best = vloss
+                torch.save(model.state_dict(), ckpt)
+        model.load_state_dict(torch.load(ckpt))
+        model.eval()
+        with torch.no_grad():
+            torch.cuda.synchronize()
+            t0 = time.time()
+            out = model(x, ei).flatten()
+            torch.cuda.synchronize()
+            dt = time.time() - t0
+            yt = y.index_select(0, te)
+            tloss = float(F.l1_loss(out.index_select(0, te), yt) / yt.std())
+        log(f"run {run + 1}: test_loss {tloss:.4f} infer_time {dt * 1e3:.2f} ms")
+        all_loss.append(tloss); all_time.append(dt)
+    top = sorted(all_loss)[:10]
+    os.makedirs("results/baseline", exist_ok=True)
+    fn = f"results/baseline/{args.dataset}.csv"
+    if not os.path.exists(fn):
+        with open(fn, "w") as f:
+            f.write("dataset,experiment,layer_name,runs,num_layers,batch_size,lr,ave_time,top_10_loss,best_loss\n")
+    with open(fn, "a") as f:
+        f.write(f"{args.dataset},{args.experiment},{args.layer_name},{args.runs},{args.num_layers1},{args.batch_size},{args.lr},"
+                f"{np.mean(all_time)},{np.mean(top)} +/- {np.std(top)},{top[0]}\n")
+    return all_loss, all_time

@@ -291,7 +291,7 @@ class GraphTrainer(_CapturedSteps):
 
     def __init__(self, model, gset, graphs, kind="gs", batch_size=128, lr=0.01, weight_decay=5e-4, task="graph_reg",
                  multi_prop=True, prop=0, truncate_targets=True, capture=False, share=None, rank=None, world=None,
-                 process_group=None, batches=None, global_sizes=None):
+                 process_group=None, batches=None, global_sizes=None, accumulate=True):
         """capture=True: every batch step (forward, loss, backward, Adam) is captured once in a hipGraph and replayed
         -- the steps are launch-bound (small batches, ~40 kernels each).  Dropout seeds then live on the device
         (ops.SeedBank) and are advanced by a kernel inside each captured step.
@@ -299,7 +299,8 @@ class GraphTrainer(_CapturedSteps):
         ids[rank::world] of EVERY global batch (the unit is a whole graph: pooling is intra-graph, nothing is
         exchanged in the forward pass), losses are sums scaled by 1 / global batch size, and the accumulated gradient
         buffer is all-reduced once per step (see _dp_step for how the never-cleared gradients stay exact).
-        batches (+ global_sizes): pre-built batch dicts (tests / custom pipelines) instead of gset + graphs."""
+        batches (+ global_sizes): pre-built batch dicts (tests / custom pipelines) instead of gset + graphs.
+        accumulate=False: clear the gradients before every batch (the baselines' loops, run.py:988-991, :1058-1060)."""
         import types
 
         dist_on = torch.distributed.is_available() and torch.distributed.is_initialized()
@@ -309,6 +310,7 @@ class GraphTrainer(_CapturedSteps):
 
         self.model, self.kind, self.task, self.multi_prop, self.prop = model, kind, task, multi_prop, prop
         self.truncate = truncate_targets
+        self.accumulate = bool(accumulate)
         self.capture, self._graphs = bool(capture), None
         fused = next(model.parameters()).is_cuda
         if share is not None:   # evaluation-only views of the same model: one optimiser / gradient buffer (run.py:718-719)
@@ -364,12 +366,14 @@ class GraphTrainer(_CapturedSteps):
     def _forward(self, b):
         if self.kind == "gs":
             return self.model(b, b["graph_of_masked"])
-        return self.model(b["gc"])
+        return self.model(b["gc"])   # 'gc' and 'orig': one block-diagonal graph batch
 
     def _steps(self):
         return self.batches
 
     def _one(self, b):
+        if not self.accumulate:
+            self.flat.zero()
         loss = self._loss(self._forward(b), b["y"])
         loss.backward()
         self.opt.step()

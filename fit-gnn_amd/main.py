@@ -174,12 +174,12 @@ def main(argv=None):
         raise NotImplementedError("--use_community_detection needs igraph/leidenalg (main.py:247-267), not available here")
     if args.task == 'node_reg':
         if args.baseline:
-            raise NotImplementedError("node-regression baseline (run.py:904-) is outside the hot path")
+            return pipeline.node_regression_baseline(args, path, data, device=args.device)
         co = pipeline.coarsening_classification(args, data, 1 - args.coarsening_ratio, args.coarsening_method, device=args.device)
         return pipeline.node_regression(args, path, data, co, device=args.device)
     if args.task in ('graph_reg', 'graph_cls'):
         if args.baseline:
-            raise NotImplementedError("graph-level baselines (run.py:904-) are outside the hot path")
+            return pipeline.graph_baseline(args, path, data, device=args.device)
         return pipeline.graph_regression(args, path, data, device=args.device)
     if args.baseline:
         res = pipeline.node_classification_baseline(args, path, data, device=args.device)

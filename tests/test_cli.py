@@ -153,3 +153,21 @@ def test_cli_graph_classification_on_synthetic_proteins(tmp_path, monkeypatch):
         assert np.isfinite(loss) and acc > 0.6, (setup, loss, acc)
     rows = open("results/synthetic-proteins.csv").read().strip().split("\n")
     assert rows[0].endswith("best_test_loss,best_test_acc") and len(rows) == 3
+
+
+@pytest.mark.gpu
+def test_cli_baselines_of_the_other_tasks(tmp_path, monkeypatch):
+    """--baseline for node regression and the graph-level tasks (run.py:904-1100): full-graph / uncoarsened-graph models,
+    results under results/baseline/."""
+    monkeypatch.chdir(tmp_path)
+    losses, _ = cli.main(["--dataset", "synthetic-chameleon", "--runs", "1", "--hidden", "64", "--seed", "0", "--baseline", "--epochs1", "200",
+                          "--output_dir", "b"])
+    assert losses[0] < 0.79, losses   # constant predictor ~0.80; 683 train nodes, dropout 0.5
+    loss = cli.main(["--dataset", "synthetic-qm9", "--n_graphs", "400", "--hidden", "64", "--seed", "0", "--baseline", "--batch_size", "50",
+                     "--lr", "0.002", "--epochs1", "15", "--output_dir", "b"])
+    assert np.isfinite(loss)
+    loss, acc = cli.main(["--dataset", "synthetic-proteins", "--n_graphs", "400", "--hidden", "64", "--seed", "0", "--baseline",
+                          "--batch_size", "50", "--lr", "0.005", "--epochs1", "30", "--output_dir", "b"])
+    assert np.isfinite(loss) and acc > 0.6
+    for name in ("synthetic-chameleon", "synthetic-qm9", "synthetic-proteins"):
+        assert os.path.exists(f"results/baseline/{name}.csv")
