@@ -97,7 +97,8 @@ class GraphSet:
     FIRST k rows of each sorted subgraph, k = number of own nodes -- not the own nodes themselves (SURVEY §8 a12
     quirk iii); `gs_core` marks the true own nodes.  network.*_graph_gs pools x[mask] per graph."""
 
-    def __init__(self, mol, ratio=0.5, extra_node=False, device="cuda", spectral="dense", reference_mask=True):
+    def __init__(self, mol, ratio=0.5, extra_node=False, device="cuda", spectral="dense", reference_mask=True,
+                 cluster_node=False):
         dev = torch.device(device)
         node_ptr, ei = np.asarray(mol["node_ptr"]), np.asarray(mol["edge_index"])
         N, G = int(node_ptr[-1]), len(node_ptr) - 1
@@ -118,12 +119,18 @@ class GraphSet:
         self.gc_edge_index = torch.from_numpy(np.stack([coo.row, coo.col]).astype(np.int64)).to(dev)
         self.gc_graph = torch.from_numpy(np.repeat(np.arange(G), np.diff(self.cluster_ptr))).to(dev)
         # ---- Gs (utils.py:417-534), all clusters of all graphs at once ----
-        sub = fdata.assemble_subgraphs_torch(torch.from_numpy(ei).to(dev), N, co.assign, n, extra_node=extra_node)
+        if cluster_node:   # utils.py:424-470: one new node per neighbouring cluster, carrying its pooled features
+            sub = fdata.assemble_subgraphs_cluster(ei, N, co.assign, n, co.Wc)
+            sub = {k: (torch.from_numpy(v).to(dev) if k != "ptr" else torch.from_numpy(v)) for k, v in sub.items()}
+            table = torch.cat([self.x, self.gc_x])
+        else:
+            sub = fdata.assemble_subgraphs_torch(torch.from_numpy(ei).to(dev), N, co.assign, n, extra_node=extra_node)
+            table = self.x
         self.sub_ptr = sub["ptr"].cpu().numpy()                       # union rows of every cluster subgraph
         self.gs_node = sub["node_id"]
         self.gs_core = sub["core"]
         self.gs_edge_index = sub["edge_index"]
-        self.gs_x = self.x[self.gs_node].contiguous()
+        self.gs_x = table[self.gs_node].contiguous()
         R = int(self.sub_ptr[-1])
         sub_of_row = torch.repeat_interleave(torch.arange(n, device=dev), torch.from_numpy(np.diff(self.sub_ptr)).to(dev))
         n_core = torch.zeros(n, dtype=torch.int64, device=dev).index_add_(0, sub_of_row, self.gs_core.long())

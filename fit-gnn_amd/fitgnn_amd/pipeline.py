@@ -173,7 +173,7 @@ def coarsening_classification(args, data, coarsening_ratio, coarsening_method, d
     return out
 
 
-def build_gs(args, data, co, device="cuda"):
+def build_gs(args, data, co, device="cuda", float_targets=False):
     """Subgraphs Gs (utils.py:186-267) + their masks (utils.py:683-703) as one block-diagonal SubgraphBatch."""
     N, n = data.num_nodes, co.n_clusters
     x, y = data.x, data.y.flatten()
@@ -199,7 +199,7 @@ def build_gs(args, data, co, device="cuda"):
     else:
         ei_dev = torch.as_tensor(np.asarray(data.edge_index)).to(device)
         sub = fdata.assemble_subgraphs_torch(ei_dev, N, co.assign, n, extra_node=bool(getattr(args, "extra_node", False)))
-    batch = fdata.SubgraphBatch(sub, x, y, masks[0], device=device)
+    batch = fdata.SubgraphBatch(sub, x, y, masks[0], device=device, float_targets=float_targets)
     core = batch.core
     batch.val_idx = torch.nonzero(masks[1].to(device)[batch.node_id] & core).flatten()
     batch.test_idx = torch.nonzero(masks[2].to(device)[batch.node_id] & core).flatten()
@@ -392,9 +392,8 @@ def graph_regression(args, path, mol, device="cuda", log=print):
     from . import graph_data
     from .train import GraphTrainer
 
-    if args.cluster_node:
-        raise NotImplementedError("--cluster_node subgraphs for graph-level tasks are not built (node-level only)")
-    gset = graph_data.GraphSet(mol, ratio=args.coarsening_ratio, extra_node=bool(args.extra_node), device=device)
+    gset = graph_data.GraphSet(mol, ratio=args.coarsening_ratio, extra_node=bool(args.extra_node), device=device,
+                               cluster_node=bool(args.cluster_node))
     G = gset.n_graphs
     gen = torch.Generator().manual_seed(0 if args.seed is None else args.seed)
     idx = torch.randperm(G, generator=gen).tolist()
@@ -518,14 +517,7 @@ def node_regression(args, path, data, co, device="cuda", log=print):
     """run.node_regression (run.py:508-573): Regress_node trained on Gs only (GD or MB), L1 loss, best-val checkpoint."""
     rng = np.random.default_rng(args.seed)
     data = splits_regression(data, args.train_ratio, args.val_ratio, rng)
-    N, n = data.num_nodes, co.n_clusters
-    if getattr(args, "cluster_node", False):
-        raise NotImplementedError("--cluster_node for node regression is not built; use --extra_node or neither")
-    ei_dev = torch.as_tensor(np.asarray(data.edge_index)).to(device)
-    sub = fdata.assemble_subgraphs_torch(ei_dev, N, co.assign, n, extra_node=bool(getattr(args, "extra_node", False)))
-    batch = fdata.SubgraphBatch(sub, data.x, data.y.flatten(), data.train_mask, device=device, float_targets=True)
-    batch.val_idx = torch.nonzero(data.val_mask.to(device)[batch.node_id] & batch.core).flatten()
-    batch.test_idx = torch.nonzero(data.test_mask.to(device)[batch.node_id] & batch.core).flatten()
+    batch = build_gs(args, data, co, device, float_targets=True)   # plain / --extra_node / --cluster_node subgraphs
     all_loss, all_time = [], []
     ckpt = os.path.join(path, "model.pt")
     args.num_classes = 1

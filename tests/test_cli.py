@@ -120,7 +120,7 @@ def test_cli_graph_regression_on_synthetic_qm9(tmp_path, monkeypatch):
     common = ["--dataset", "synthetic-qm9", "--n_graphs", "600", "--hidden", "64", "--seed", "0", "--train_fitgnn", "--batch_size", "64",
               "--lr", "0.002", "--property", "0", "--epochs1", "15", "--epochs2", "15", "--output_dir", "q"]
     losses = {}
-    for setup, extra in (("Gs_train_2_Gs_infer", ["--extra_node"]), ("Gc_train_2_Gc_infer", []), ("Gc_train_2_Gs_train", [])):
+    for setup, extra in (("Gs_train_2_Gs_infer", ["--extra_node"]), ("Gc_train_2_Gc_infer", []), ("Gc_train_2_Gs_train", ["--cluster_node"])):
         losses[setup] = cli.main(common + ["--exp_setup", setup] + extra)
         assert np.isfinite(losses[setup])
     rows = open("results/synthetic-qm9.csv").read().strip().split("\n")
