@@ -648,3 +648,59 @@ def node_regression_baseline(args, path, data, device="cuda", log=print):
         f.write(f"{args.dataset},{args.experiment},{args.layer_name},{args.runs},{args.num_layers1},{args.batch_size},{args.lr},"
                 f"{np.mean(all_time)},{np.mean(top)} +/- {np.std(top)},{top[0]}\n")
     return all_loss, all_time
+
+
+# ---------------------------------------------------------------------------------------------
+# --use_community_detection (main.py:247-267): keep the largest communities up to k nodes
+# ---------------------------------------------------------------------------------------------
+def detect_communities(edge_index, num_nodes, seed=0, iters=20):
+    """A node partition for --use_community_detection.  The reference calls leidenalg.find_partition(...,
+    ModularityVertexPartition) on an igraph Graph (main.py:257-258); neither package exists here, and only the partition
+    is consumed downstream, so this is a substitute: seeded label propagation (every node repeatedly adopts the most
+    frequent label among its neighbours, ties to the smallest label, half of the nodes per sweep), vectorised with
+    sort-based modes.  Returns int64 labels in 0..n_comm-1."""
+    ei = np.asarray(edge_index)
+    src, dst = ei[0].astype(np.int64), ei[1].astype(np.int64)
+    N = int(num_nodes)
+    rng = np.random.default_rng(seed)
+    label = np.arange(N, dtype=np.int64)
+    for it in range(iters):
+        lab_src = label[src]
+        order = np.lexsort((lab_src, dst))
+        d, l = dst[order], lab_src[order]
+        start = np.concatenate([[True], (d[1:] != d[:-1]) | (l[1:] != l[:-1])])
+        run_id = np.cumsum(start) - 1
+        cnt = np.bincount(run_id)
+        rd, rl = d[start], l[start]
+        best = np.lexsort((rl, -cnt, rd))              # per node: highest count, then smallest label
+        first = np.concatenate([[True], rd[best][1:] != rd[best][:-1]])
+        nodes, new = rd[best][first], rl[best][first]
+        move = rng.random(len(nodes)) < 0.5            # half of the nodes per sweep: damps the oscillation of synchronous updates
+        changed = int((label[nodes[move]] != new[move]).sum())
+        label[nodes[move]] = new[move]
+        if changed == 0 and it > 2:
+            break
+    _, label = np.unique(label, return_inverse=True)
+    return label.astype(np.int64)
+
+
+def merge_communities(data, labels, k):
+    """utils.merge_communities (utils.py:132-141): communities largest first, taken whole while the node total stays <= k;
+    the dataset becomes the subgraph induced by those nodes (renumbered in that order)."""
+    sizes = np.bincount(labels)
+    order = np.argsort(-sizes, kind="stable")
+    keep, total = [], 0
+    for c in order:
+        if total + sizes[c] <= k:
+            keep.append(np.nonzero(labels == c)[0])
+            total += int(sizes[c])
+            if total == k:
+                break
+    nodes = np.concatenate(keep) if keep else np.zeros(0, dtype=np.int64)
+    new_id = np.full(data.num_nodes, -1, dtype=np.int64)
+    new_id[nodes] = np.arange(len(nodes))
+    ei = np.asarray(data.edge_index)
+    m = (new_id[ei[0]] >= 0) & (new_id[ei[1]] >= 0)
+    t = torch.from_numpy(nodes)
+    return NodeData(data.x[t], np.stack([new_id[ei[0][m]], new_id[ei[1][m]]]), data.y[t], data.train_mask[t], data.val_mask[t],
+                    data.test_mask[t])

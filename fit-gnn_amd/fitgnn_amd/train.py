@@ -116,7 +116,7 @@ class GDTrainer:
             pos = torch.full((batch.n_rows,), -1, dtype=torch.int64, device=core_rows.device)
             pos[core_rows] = torch.arange(core_rows.numel(), device=core_rows.device)
             self._train_pos = pos[batch.train_idx]          # train rows are own nodes (utils.py:695-698)
-            assert int(self._train_pos.min()) >= 0
+            assert self._train_pos.numel() == 0 or int(self._train_pos.min()) >= 0
         count = torch.tensor([float(batch.train_idx.numel())], device=self.flat.buf.device)
         if self.dist:
             torch.distributed.all_reduce(count, group=self.pg)

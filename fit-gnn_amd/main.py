@@ -64,6 +64,7 @@ def build_parser():
     # not in the reference
     p.add_argument('--data_root', type=str, default='./dataset')
     p.add_argument('--device', type=str, default='cuda')
+    p.add_argument('--community_nodes', type=int, default=165000)  # main.py:264 hard-codes 165000
     p.add_argument('--n_graphs', type=int, default=2000)  # size of the synthetic-qm9 stand-in (QM9 itself: 130 831)
     return p
 
@@ -170,8 +171,10 @@ def main(argv=None):
 
     path = f"save/{args.task}/" + (f"baseline/{args.output_dir}/" if args.baseline else f"{args.output_dir}/")
     os.makedirs(path, exist_ok=True)
-    if args.use_community_detection:
-        raise NotImplementedError("--use_community_detection needs igraph/leidenalg (main.py:247-267), not available here")
+    if args.use_community_detection and args.task == 'node_cls':   # main.py:247-267
+        labels = pipeline.detect_communities(data.edge_index, data.num_nodes, seed=0 if args.seed is None else args.seed)
+        data = pipeline.merge_communities(data, labels, args.community_nodes)
+        print(f"community detection: {int(labels.max()) + 1} communities, kept {data.num_nodes} nodes (<= {args.community_nodes})")
     if args.task == 'node_reg':
         if args.baseline:
             return pipeline.node_regression_baseline(args, path, data, device=args.device)

@@ -95,12 +95,13 @@ def test_cli_end_to_end_on_synthetic_cora(tmp_path, monkeypatch):
     assert acc[0] > 0.5, acc  # 7 classes, homophilous synthetic labels: far above 1/7
     assert os.path.exists("save/node_cls/baseline/b/model.pt") and os.path.exists("results/baseline/synthetic-cora.csv")
     for setup, extra in (("Gs_train_2_Gs_infer", ["--cluster_node"]), ("Gs_train_2_Gs_infer", ["--extra_node", "--gradient_method", "MB", "--lr", "0.002"]),
+                         ("Gs_train_2_Gs_infer", ["--extra_node", "--use_community_detection"]),
                          ("Gs_train_2_Gs_infer", ["--extra_node"]), ("Gc_train_2_Gs_infer", []), ("Gc_train_2_Gs_train", ["--extra_node"])):
         _, acc, _ = cli.main(common + ["--output_dir", "f", "--train_fitgnn", "--exp_setup", setup, "--coarsening_ratio", "0.5",
                                        "--epochs1", "40", "--epochs2", "40"] + extra)
         assert acc[0] > 0.4, (setup, acc)
     rows = open("results/synthetic-cora.csv").read().strip().split("\n")
-    assert rows[0].startswith("dataset,coarsening_method,coarsening_ratio") and len(rows) == 6
+    assert rows[0].startswith("dataset,coarsening_method,coarsening_ratio") and len(rows) == 7
     import inference as icli
     t_gs, acc_gs = icli.main(["--dataset", "synthetic-cora", "--hidden", "64", "--seed", "0", "--normalize_features", "--extra_node",
                               "--num_test_samples", "30", "--path_gs", "save/node_cls/f/", "--baseline",

@@ -254,3 +254,30 @@ def test_torch_assembly_equals_numpy_assembly():
         ea = set(zip(a["edge_index"][0].tolist(), a["edge_index"][1].tolist()))
         eb = set(zip(b["edge_index"][0].tolist(), b["edge_index"][1].tolist()))
         assert ea == eb and len(eb) == b["edge_index"].shape[1]
+
+
+def test_community_detection_substitute_and_merge():
+    """detect_communities finds planted communities; merge_communities == utils.merge_communities (largest first, whole
+    communities while the total stays <= k, induced subgraph renumbered in that order)."""
+    import torch
+
+    from fitgnn_amd import pipeline
+
+    rng = np.random.default_rng(0)
+    sizes, edges, off = [60, 40, 25, 10], [], 0
+    for s in sizes:                                        # dense blocks ...
+        a = rng.integers(0, s, size=6 * s); b = rng.integers(0, s, size=6 * s)
+        k = a != b
+        edges.append(np.stack([a[k] + off, b[k] + off])); off += s
+    N = off
+    ei = np.concatenate(edges + [np.array([[0, 60, 100], [60, 100, 125]])], axis=1)   # ... joined by three single edges
+    ei = np.unique(np.concatenate([ei, ei[::-1]], axis=1), axis=1)
+    lab = pipeline.detect_communities(ei, N, seed=1)
+    truth = np.repeat(np.arange(4), sizes)
+    for c in range(4):                                      # every planted block is (almost) one community
+        blk = lab[truth == c]
+        assert np.bincount(blk).max() >= 0.9 * len(blk)
+    data = pipeline.NodeData(torch.arange(N).float().view(-1, 1), ei, torch.from_numpy(truth))
+    out = pipeline.merge_communities(data, truth, 75)       # 60 fits, 40 does not, 25 does not (85 > 75), 10 fits: 70 nodes
+    assert out.num_nodes == 70 and out.x.flatten().tolist() == list(range(60)) + list(range(125, 135))
+    assert int(out.edge_index.max()) < 70 and out.y.tolist() == [0] * 60 + [3] * 10
