@@ -291,7 +291,7 @@ class GraphTrainer(_CapturedSteps):
 
     def __init__(self, model, gset, graphs, kind="gs", batch_size=128, lr=0.01, weight_decay=5e-4, task="graph_reg",
                  multi_prop=True, prop=0, truncate_targets=True, capture=False, share=None, rank=None, world=None,
-                 process_group=None, batches=None, global_sizes=None, accumulate=True):
+                 process_group=None, batches=None, global_sizes=None, accumulate=True, reshuffle=False):
         """capture=True: every batch step (forward, loss, backward, Adam) is captured once in a hipGraph and replayed
         -- the steps are launch-bound (small batches, ~40 kernels each).  Dropout seeds then live on the device
         (ops.SeedBank) and are advanced by a kernel inside each captured step.
@@ -300,7 +300,10 @@ class GraphTrainer(_CapturedSteps):
         exchanged in the forward pass), losses are sums scaled by 1 / global batch size, and the accumulated gradient
         buffer is all-reduced once per step (see _dp_step for how the never-cleared gradients stay exact).
         batches (+ global_sizes): pre-built batch dicts (tests / custom pipelines) instead of gset + graphs.
-        accumulate=False: clear the gradients before every batch (the baselines' loops, run.py:988-991, :1058-1060)."""
+        accumulate=False: clear the gradients before every batch (the baselines' loops, run.py:988-991, :1058-1060).
+        reshuffle=True: re-draw the graph order before every epoch, as the reference's DataLoader(shuffle=True) does
+        (run.py:710); every batch's CSR is then rebuilt per epoch and the steps run eagerly (≈ 3 ms of set-up per batch: the
+        default draws the order once and replays captured steps)."""
         import types
 
         dist_on = torch.distributed.is_available() and torch.distributed.is_initialized()
@@ -319,6 +322,10 @@ class GraphTrainer(_CapturedSteps):
             self.opt = torch.optim.Adam(model.parameters(), lr=lr, weight_decay=weight_decay, fused=fused,
                                         capturable=bool(capture) and fused)
             self.flat = FlatGrads(model.parameters())
+        self._rebuild = None
+        if batches is None and reshuffle:
+            self.capture = False
+            self._rebuild = (gset, [int(g) for g in graphs], kind, batch_size, types)
         if batches is not None:   # pre-built (entries may be None: this rank holds no graph of that batch)
             self.batches = list(batches)
             self.global_sizes = list(global_sizes) if global_sizes is not None else [int(b["y"].shape[0]) for b in self.batches]
@@ -379,8 +386,21 @@ class GraphTrainer(_CapturedSteps):
         self.opt.step()
         return loss.detach()
 
+    def _reshuffle(self):
+        gset, graphs, kind, batch_size, types = self._rebuild
+        perm = torch.randperm(len(graphs)).tolist()   # torch's generator, as the DataLoader's sampler; same on every rank
+        graphs = [graphs[i] for i in perm]            # when the ranks share the seed
+        self.batches, self.global_sizes = [], []
+        for b0 in range(0, len(graphs), batch_size):
+            ids_all = graphs[b0:b0 + batch_size]
+            ids = ids_all[self.rank::self.world]
+            self.global_sizes.append(len(ids_all))
+            self.batches.append(_cat_pieces([gset.batch(g, g + 1, kind) for g in ids], kind, types) if ids else None)
+
     def step(self):
         self.model.train()
+        if self._rebuild is not None:
+            self._reshuffle()
         if self.capture and self.flat.buf.is_cuda:
             return self._replay().sum() / max(len(self.batches), 1)
         self.flat.zero()

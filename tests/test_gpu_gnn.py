@@ -451,3 +451,24 @@ def test_pruned_last_layer_equals_full_evaluation(mods):
     XT = ops.spmm_raw(sub.t.rowptr, sub.t.col, sub.t.val, sub.t.tiles, Z, sub.n, window_rows=sub.window_rows)
     lhs, rhs = float((Y.double() * Z.double()).sum()), float((X.double() * XT.double()).sum())
     assert abs(lhs - rhs) < 1e-6 * (abs(lhs) + abs(rhs) + 1)
+
+
+def test_graph_trainer_reshuffle_option(mods):
+    """GraphTrainer(reshuffle=True) re-draws the graph order every epoch (run.py:710 shuffle=True): batches change between
+    epochs, every graph is still visited exactly once per epoch, and the loss keeps decreasing."""
+    from fitgnn_amd import graph_data, train
+
+    network, fnn, gorc = mods
+    mol = graph_data.synthetic_molecules(96, seed=9)
+    gset = graph_data.GraphSet(mol, ratio=0.5, extra_node=True, device="cuda")
+    args = argparse.Namespace(num_layers1=2, layer_name="GCNConv", num_features=11, hidden=32, num_classes=1)
+    torch.manual_seed(1)
+    model = network.Regress_graph_gs(args).cuda()
+    tr = train.GraphTrainer(model, gset, list(range(96)), kind="gs", batch_size=32, prop=0, lr=0.005, reshuffle=True)
+    seen, losses = [], []
+    for epoch in range(6):
+        losses.append(float(tr.step()))
+        seen.append(torch.cat([b["y"][:, 0] for b in tr.batches]).cpu())
+    assert not torch.equal(seen[0], seen[1])                                    # a different order ...
+    assert torch.equal(seen[0].sort().values, seen[1].sort().values)            # ... of the same graphs
+    assert losses[-1] < losses[0]
