@@ -471,6 +471,8 @@ extern "C" int fitgnn_variation_costs_batch_f64(const int32_t *rowptr, const int
 extern "C" int fitgnn_debug_greedy_counters(unsigned long long *out, int reset) {
     hipDeviceSynchronize();
     int rc = (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_greedy_dbg), sizeof(unsigned long long) * 8);
+    rc |= (int)hipMemcpyFromSymbol(out + 8, HIP_SYMBOL(g_cost_dbg), sizeof(unsigned long long) * 8);
+    if (reset) { unsigned long long z2[8] = {0}; rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(g_cost_dbg), z2, sizeof(z2)); }
     if (reset) { unsigned long long z[8] = {0}; rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(g_greedy_dbg), z, sizeof(z)); }
     return rc;
 }

@@ -28,6 +28,15 @@
         __builtin_amdgcn_wave_barrier();                        \
     } while (0)
 
+#ifdef FITGNN_GREEDY_STAMPS
+static __device__ unsigned long long g_cost_dbg[8];
+#define CSTAMP(var) const unsigned long long var = __builtin_readcyclecounter()
+#define CACC(i, a, b) if ((threadIdx.x & 63) == 0) g_cost_dbg[i] += (b) - (a)
+#else
+#define CSTAMP(var)
+#define CACC(i, a, b)
+#endif
+
 namespace fitgnn {
 
 constexpr int kCostTile = 64;  // rows of S per LDS tile (one per lane)
@@ -78,6 +87,7 @@ __device__ inline double set_cost_wave(const CostGraph &g, const int32_t *__rest
     const int KK = K * K;
     const bool small = nc <= kCostTile;  // whole set resident in LDS
 
+    CSTAMP(c0);
     // ---- pass 1: column means, sequential over members (tiles of 64 rows staged cooperatively) ----
     double msum = 0.0;
     int pre_e0 = 0, pre_deg = 0;   // small sets: the member's row extent and degree term ride along with the A gather
@@ -104,6 +114,7 @@ __device__ inline double set_cost_wave(const CostGraph &g, const int32_t *__rest
     }
     if (lane < K) lds.mean[lane] = msum / (double)nc;
     FITGNN_WAVE_SYNC();
+    CSTAMP(c1); CACC(0, c0, c1);
 
     // ---- pass 2: per tile, rows on lanes -> B, Y ; then entries on lanes -> M ----
     double m0 = 0.0, m1 = 0.0, m2 = 0.0, m3 = 0.0;
@@ -128,6 +139,7 @@ __device__ inline double set_cost_wave(const CostGraph &g, const int32_t *__rest
         // Fast path (whole set in one tile): all 64 lanes scan the members' adjacency lists TOGETHER -- one flattened
         // index space, independent loads -- and list the matches (position in S, weight) in LDS in (row, column)
         // order; each member's lane then folds ITS matches in that same order, so the arithmetic is the serial walk's.
+        CSTAMP(c2);
         bool listed = false;
         if (small) {
             const int e0 = pre_e0, deg = pre_deg;
@@ -149,6 +161,8 @@ __device__ inline double set_cost_wave(const CostGraph &g, const int32_t *__rest
                 double w4[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
+                    a4[q] = 0; e4[q] = 0;
+                    if (q > 0 && base + q * 64 >= total) continue;  // wave-uniform: most re-costed sets fit one chunk
                     // clamped: every lane loads a valid entry (total >= 1 here), dead ones are masked below
                     const int ii = min(base + q * 64 + lane, total - 1);
                     int lo = 0, hi = rows;             // row a = last row whose first index is <= ii
@@ -158,8 +172,10 @@ __device__ inline double set_cost_wave(const CostGraph &g, const int32_t *__rest
                 }
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
+                    c4[q] = 0; w4[q] = 1.0;
+                    if (q > 0 && base + q * 64 >= total) continue;
                     c4[q] = g.col[e4[q]];
-                    w4[q] = g.w ? g.w[e4[q]] : 1.0;
+                    if (g.w) w4[q] = g.w[e4[q]];
                 }
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -256,6 +272,7 @@ __device__ inline double set_cost_wave(const CostGraph &g, const int32_t *__rest
                 if (l < K) { const double prod = d * lds.B[a * K + l]; lds.Y[a * K + l] = prod - T[l]; }
         }
         FITGNN_WAVE_SYNC();
+        CSTAMP(c3); CACC(1, c2, c3);
         // M[k][l] += B[a][k] * Y[a][l], a ascending
         {
             const int ka = ea / K, la = ea - ka * K;
@@ -272,6 +289,7 @@ __device__ inline double set_cost_wave(const CostGraph &g, const int32_t *__rest
         }
         FITGNN_WAVE_SYNC();
     }
+    CSTAMP(c4);
     // ---- Frobenius norm: canonical 64-lane tree ----
     double p = 0.0;
     if (ea < KK) p = m0 * m0;
@@ -284,7 +302,9 @@ __device__ inline double set_cost_wave(const CostGraph &g, const int32_t *__rest
         p = p + other;
     }
     p = __shfl(p, 0, 64);
-    return sqrt(p) / (double)(nc - 1);
+    const double res = sqrt(p) / (double)(nc - 1);
+    CSTAMP(c5); CACC(3, c4, c5); CACC(4, c0, c5);
+    return res;
 }
 
 }  // namespace fitgnn

@@ -21,7 +21,7 @@ lk, Uk = (offset - lk)[::-1], np.ascontiguousarray(Uk[:, ::-1])
 A = coarsening._spectral_level1(G, 10, Uk.copy(), lk.copy())
 L = _lib.lib()
 L.fitgnn_debug_greedy_counters.argtypes = [ctypes.c_void_p, ctypes.c_int]
-buf = (ctypes.c_ulonglong * 8)()
+buf = (ctypes.c_ulonglong * 16)()
 coarsening.contract_level(G, A, 0.5); torch.cuda.synchronize()
 L.fitgnn_debug_greedy_counters(buf, 1)
 t0 = time.time(); res = coarsening.contract_level(G, A, 0.5); torch.cuda.synchronize(); dt = time.time() - t0
@@ -30,5 +30,6 @@ v = list(buf)
 names = ["pop", "mark check", "select+mark", "prune", "re-cost", "heap push"]
 tot = sum(v[:6])
 print(f"N={N} E={E}: contract_level {dt*1e3:.1f} ms, clusters {res.n}; pops {v[6]}, re-costs {v[7]}; stamped cycles {tot/1e6:.1f} M")
+print("  cost fn phases (cycles per call incl. the initial cost kernel's calls):", {k: v[8 + i] for i, k in enumerate(["gather+mean", "W_S rows", "-", "norm", "total"])})
 for n, c in zip(names, v[:6]):
     print(f"  {n:12s} {c/1e6:8.2f} Mcycles  {100*c/max(tot,1):5.1f} %  per event {c/max(v[7] if n in ('re-cost','heap push') else v[6],1):8.0f}")
