@@ -35,6 +35,15 @@ def mm(a, b, allow_split=True):
     return torch.mm(a, b)
 
 
+def mm_by_transposed(a, W):
+    """a @ W for a square-ish weight W [out, in]: the library's kernel for a row-major right operand (NN) takes 201 us on
+    the S-pubmed union, the one for a transposed right operand (the forward's x @ W^T form) 160 us -- materialise W^T
+    (1 MB) and use the latter.  Bit-identical result."""
+    if a.is_cuda and W.dim() == 2 and W.shape[0] >= 64 and W.shape[1] >= 64:
+        return mm(a, W.t().contiguous().t())
+    return mm(a, W)
+
+
 def mm_at_b(a, b):
     """a^T @ b for tall operands a [R, M], b [R, N] (the weight-gradient product dH^T @ X, reduction over all R
     rows).  hipBLASLt serves this huge-K / small-MN shape poorly as one GEMM (541 us for R = 90k, M = N = 512); as a
@@ -76,7 +85,7 @@ class Linear(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dh):
         x, W = ctx.saved_tensors
-        dx = mm(dh, W) if ctx.needs_input_grad[0] else None
+        dx = mm_by_transposed(dh, W) if ctx.needs_input_grad[0] else None
         dW = mm_at_b(dh, x) if ctx.needs_input_grad[1] else None
         return dx, dW
 
@@ -345,7 +354,7 @@ class FusedGCNLayer(torch.autograd.Function):
         epi = EPI_ELU | (EPI_DROPOUT if ctx.drop else 0)
         dH, db, _ = layer_backward(g, out, epi, ctx.p if ctx.drop else 0.0, ctx.seed, mask, ctx.has_bias, dOut=dOut)
         dW = mm_at_b(dH, X) if ctx.needs_input_grad[1] else None
-        dX = mm(dH, W) if ctx.needs_input_grad[0] else None
+        dX = mm_by_transposed(dH, W) if ctx.needs_input_grad[0] else None
         return dX, dW, (db if ctx.has_bias else None), None, None, None, None, None
 
 
@@ -384,7 +393,7 @@ class FusedGCNLayerHead(torch.autograd.Function):
         # tall 3-column matrix takes 50 us, this 10)
         dbl = dy.t().contiguous().sum(1) if ctx.has_bl and ctx.needs_input_grad[4] else None
         dW = mm_at_b(dH, X) if ctx.needs_input_grad[1] else None
-        dX = mm(dH, W) if ctx.needs_input_grad[0] else None
+        dX = mm_by_transposed(dH, W) if ctx.needs_input_grad[0] else None
         return dX, dW, (db if ctx.has_bias else None), dWl, dbl, None, None, None, None, None
 
 

@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""GPU-box probe: the three big products of the step under the 'high' policy, by operand layout."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "fit-gnn_amd")):
+    sys.path.insert(0, p)
+import torch
+from fitgnn_amd import ops
+R, H = 90549, 512
+dev = "cuda"
+x = torch.randn(R, H, device=dev) * 0.1; W = torch.randn(H, H, device=dev) * 0.05
+def timeit(fn, n=20):
+    fn(); torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(n): fn()
+    e.record(); torch.cuda.synchronize()
+    return s.elapsed_time(e) / n * 1e3
+Wt = W.t().contiguous()
+print("x @ W^T  (W row-major, as the forward)      ", min(timeit(lambda: ops.mm(x, W.t())) for _ in range(3)))
+print("x @ W    (W row-major, as dX)               ", min(timeit(lambda: ops.mm(x, W)) for _ in range(3)))
+print("x @ Wt^T (Wt = W^T materialised: same value)", min(timeit(lambda: ops.mm(x, Wt.t())) for _ in range(3)))
+print("max diff", float((ops.mm(x, W) - ops.mm(x, Wt.t())).abs().max()))
+for B in (32, 64, 128):
+    Kc = R // B
+    a = x[:B * Kc].view(B, Kc, H); b = x[:B * Kc].view(B, Kc, H)
+    torch.set_float32_matmul_precision("high")
+    print(f"bmm split-K B={B}", min(timeit(lambda: torch.bmm(a.transpose(1, 2), b)) for _ in range(3)))
+    torch.set_float32_matmul_precision("highest")
