@@ -27,3 +27,11 @@ for B in (32, 64, 128):
     torch.set_float32_matmul_precision("high")
     print(f"bmm split-K B={B}", min(timeit(lambda: torch.bmm(a.transpose(1, 2), b)) for _ in range(3)))
     torch.set_float32_matmul_precision("highest")
+print("-- split-K chunk sizes (weight gradient dH^T @ X, K = 90549 rows)")
+torch.set_float32_matmul_precision("high")
+y = torch.randn(R, H, device=dev) * 0.1
+for Kc in (1024, 1408, 1414, 1536, 2048, 2816, 4096):
+    B = R // Kc
+    a = x[:B * Kc].view(B, Kc, H); b = y[:B * Kc].view(B, Kc, H)
+    t1 = min(timeit(lambda: torch.bmm(a.transpose(1, 2), b)) for _ in range(3))
+    print(f"Kc={Kc:5d} B={B:3d} tail={R - B * Kc:5d}: bmm {t1:7.1f} us")
