@@ -281,3 +281,36 @@ def test_community_detection_substitute_and_merge():
     out = pipeline.merge_communities(data, truth, 75)       # 60 fits, 40 does not, 25 does not (85 > 75), 10 fits: 70 nodes
     assert out.num_nodes == 70 and out.x.flatten().tolist() == list(range(60)) + list(range(125, 135))
     assert int(out.edge_index.max()) < 70 and out.y.tolist() == [0] * 60 + [3] * 10
+
+
+def test_tile_makers_cover_rows_exactly_once_hypothesis():
+    """make_tiles / make_tiles_pair (host side of the SpMM): for random block structures every output row lies in
+    exactly one tile, tiles respect the row cap, and a tile's window is the operand range of the blocks it packs."""
+    from hypothesis import given, settings, strategies as st
+
+    from fitgnn_amd.csr import make_tiles, make_tiles_pair
+
+    @settings(max_examples=60, deadline=None)
+    @given(st.lists(st.tuples(st.integers(0, 40), st.integers(0, 40)), min_size=1, max_size=30), st.integers(4, 24))
+    def check(blocks, cap):
+        out_ptr = np.concatenate([[0], np.cumsum([b[0] for b in blocks])])
+        win_ptr = np.concatenate([[0], np.cumsum([b[1] for b in blocks])])
+        t = make_tiles_pair(out_ptr, win_ptr, cap)
+        cover = np.zeros(int(out_ptr[-1]), dtype=np.int64)
+        for tt in t:
+            rb, re, wb, wr = int(tt["row_begin"]), int(tt["row_end"]), int(tt["win_begin"]), int(tt["win_rows"])
+            assert 0 < re - rb <= cap
+            cover[rb:re] += 1
+            b0 = int(np.searchsorted(out_ptr, rb, side="right")) - 1          # first block with rows in the tile
+            while out_ptr[b0 + 1] == out_ptr[b0] and out_ptr[b0] == rb and b0 + 1 < len(blocks) and win_ptr[b0] < wb:
+                b0 += 1
+            assert wb in win_ptr and wb + wr in win_ptr                       # windows are whole operand ranges of blocks
+        assert np.all(cover == 1)
+        sq = make_tiles(out_ptr, cap)                                         # the square case: window == own rows
+        cov2 = np.zeros(int(out_ptr[-1]), dtype=np.int64)
+        for tt in sq:
+            cov2[int(tt["row_begin"]):int(tt["row_end"])] += 1
+            assert int(tt["row_end"]) - int(tt["row_begin"]) <= cap
+        assert np.all(cov2 == 1)
+
+    check()
