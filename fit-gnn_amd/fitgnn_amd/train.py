@@ -121,12 +121,42 @@ class GDTrainer:
         if self.dist:
             torch.distributed.all_reduce(count, group=self.pg)
         self.global_count = float(count.item())
+        # Data parallel: the gradients of everything above the first layer are complete when the first layer's backward
+        # starts -- all-reduce that part of the flat buffer asynchronously (RCCL's own stream) under the first layer's
+        # backward kernels, the first layer's part afterwards.  xGMI is point-to-point: two latency-bound ~1 MB calls, no
+        # finer bucketing.
+        self._work, self._split = None, 0
+        if self.dist:
+            first = [p for n, p in model.named_parameters() if n.startswith("conv.0.")]
+            ids = {id(p) for p in first}
+            if first and all(id(p) in ids for p in self.flat.params[:len(first)]) and len(first) < len(self.flat.params):
+                self._split = self.flat.offsets[len(first)]
+                self._late = [p for p in self.flat.params[len(first):]]
+                self._pending = 0
+                for p in self._late:
+                    p.register_post_accumulate_grad_hook(self._grad_ready)
+
+    def _grad_ready(self, _p):
+        self._pending -= 1
+        if self._pending == 0:
+            self._work = torch.distributed.all_reduce(self.flat.buf[self._split:], group=self.pg, async_op=True)
+
+    def _reduce_grads(self):
+        """Finish the gradient all-reduce: the early bucket was launched from the hook, the first layer's follows here."""
+        if self._split and self._work is not None:
+            torch.distributed.all_reduce(self.flat.buf[:self._split], group=self.pg)
+            self._work.wait()
+            self._work = None
+        else:
+            torch.distributed.all_reduce(self.flat.buf, group=self.pg)  # one RCCL all-reduce per step
 
     def step(self):
         """One GD epoch (run.py:177-215).  Returns the (global) loss as a 0-dim device tensor."""
         m, b = self.model, self.batch
         m.train()
         self.flat.zero()  # optimizer.zero_grad(); grads live in the flat buffer
+        if self._split:
+            self._pending, self._work = len(self._late), None
         scale = 1.0 / self.global_count if self.reduction == "mean" else 1.0
         if self.fused_loss:   # logits -> loss and d(loss)/d(logits) in one kernel (same arithmetic as log_softmax + NLLLoss)
             from .ops import SoftmaxNLL
@@ -139,7 +169,7 @@ class GDTrainer:
                 loss = SoftmaxNLL.apply(z, b.train_idx, self._y_train, scale)
             loss.backward()
             if self.dist:
-                torch.distributed.all_reduce(self.flat.buf, group=self.pg)
+                self._reduce_grads()
             self.opt.step()
             return loss.detach()
         out = m(b.x_table, b.edge_index, x_index=b.row_index) if self.dedup else m(b.x, b.edge_index)
@@ -152,7 +182,7 @@ class GDTrainer:
         loss = loss_sum * scale
         loss.backward()
         if self.dist:
-            torch.distributed.all_reduce(self.flat.buf, group=self.pg)  # one RCCL all-reduce per step
+            self._reduce_grads()
         self.opt.step()
         return loss.detach()
 

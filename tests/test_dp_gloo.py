@@ -17,11 +17,11 @@ class TinyModel(torch.nn.Module):
 
     def __init__(self, F, C):
         super().__init__()
-        self.a = torch.nn.Linear(F, 16)
-        self.b = torch.nn.Linear(16, C)
+        self.conv = torch.nn.ModuleList([torch.nn.Linear(F, 16)])   # named like network.py's modules: the trainer
+        self.lt1 = torch.nn.Linear(16, C)                            # all-reduces `conv.0.*` as its own, later bucket
 
     def forward(self, x, edge_index):
-        return torch.log_softmax(self.b(torch.tanh(self.a(x))), dim=1)
+        return torch.log_softmax(self.lt1(torch.tanh(self.conv[0](x))), dim=1)
 
 
 class Shard:
@@ -49,6 +49,7 @@ def _worker(rank, world, port, out_q):
     model = TinyModel(8, 3)
     shard = Shard(x[lo:hi], y[lo:hi], torch.arange(0, hi - lo, 2))
     tr = train.GDTrainer(model, shard, lr=0.01, weight_decay=5e-4)
+    assert tr._split > 0   # two buckets: everything above conv.0 is reduced while conv.0's backward still runs
     losses = [float(tr.step()) for _ in range(3)]
     tot = torch.tensor(losses)
     torch.distributed.all_reduce(tot)  # sum of per-rank partial losses = global mean loss
