@@ -20,9 +20,11 @@ PROFILE = None
 # Dense GEMM policy (BASELINE.json north_star: MFMA only for the dense weight GEMMs, library GEMM allowed).
 # "high": hipBLASLt computes the [rows x in] @ [in x out] products (forward, dX) with the 3 x bf16 split of each
 # fp32 operand on the bf16 MFMA pipe (fp32 accumulate; measured 4-5e-6 relative error vs fp64, 2.2x faster than the
-# fp32 MFMA path on gfx950).  The weight-gradient products dH^T @ X (reduction over all rows) stay "highest": the
-# split kernels are slower for that shape.  "highest" everywhere = plain fp32 MFMA.
+# fp32 MFMA path on gfx950).  The weight-gradient products dH^T @ X (reduction over all rows) use the same precision
+# through a split-K batched product (mm_at_b): the library's single-call kernel for that shape is 2.7x slower.
+# "highest" everywhere = plain fp32 MFMA.
 GEMM_PRECISION = "high"
+
 
 def mm(a, b, allow_split=True):
     if GEMM_PRECISION == "high" and allow_split:

@@ -3,7 +3,7 @@
 
 Same flags and defaults as the reference's inference.py:221-254 (note its own defaults differ from main.py's:
 --lr 0.001, no --layer_name), same arg_correction, same CSV row appended to inference_results/<task>.csv
-(inference.py:826-874).  Node classification only in this round.  For every sampled test node the model runs on
+(inference.py:826-874).  Node classification (the task the reference's script is written around).  For every sampled test node the model runs on
 the ONE subgraph that contains it (inference.py:668-688) -- that is the "inference that FITs in memory" claim --
 and, with --baseline, on the full graph (inference.py:651-666).  Unlike the reference, the timed region is
 bracketed by a device synchronisation (the reference's time() around an asynchronous launch measures launch time).

@@ -4,7 +4,8 @@
 Same flags, defaults and `store_true` semantics as the reference's main.py:176-208, same post-parse corrections
 (arg_correction, main.py:117-129), same outputs: best-val `model.pt` under save/<task>/[baseline/]<output_dir>/ and a
 row appended to results/<dataset>.csv (results/baseline/<dataset>.csv) with the reference's columns
-(run.py:480-485, :883-887).  Node-classification tasks only in this round (the hot path BASELINE.json names).
+(run.py:480-485, :883-887).  Tasks: node classification (GD / MB, all exp_setups), node regression, graph regression and
+graph classification, each with its --baseline; datasets below.
 
 Datasets: the reference downloads through torch_geometric / ogb, which are not available here.  Accepted:
   synthetic-{chameleon,squirrel,crocodile}   node-regression stand-ins (dataset_info.csv:8-10)
