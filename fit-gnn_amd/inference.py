@@ -3,7 +3,8 @@
 
 Same flags and defaults as the reference's inference.py:221-254 (note its own defaults differ from main.py's:
 --lr 0.001, no --layer_name), same arg_correction, same CSV row appended to inference_results/<task>.csv
-(inference.py:826-874).  Node classification (the task the reference's script is written around).  For every sampled test node the model runs on
+(inference.py:826-874).  Node classification (per-query: the one subgraph holding the node) and the graph-level tasks (per sampled graph: its
+subgraph set or coarsened graph).  For every sampled test node the model runs on
 the ONE subgraph that contains it (inference.py:668-688) -- that is the "inference that FITs in memory" claim --
 and, with --baseline, on the full graph (inference.py:651-666).  Unlike the reference, the timed region is
 bracketed by a device synchronisation (the reference's time() around an asynchronous launch measures launch time).
@@ -64,6 +65,8 @@ def build_parser():
     p.add_argument('--data_root', type=str, default='./dataset')
     p.add_argument('--device', type=str, default='cuda')
     p.add_argument('--layer_name', type=str, default='GCNConv')
+    p.add_argument('--n_graphs', type=int, default=2000)
+    p.add_argument('--community_nodes', type=int, default=165000)
     return p
 
 
@@ -86,6 +89,75 @@ def timed_forward(model, x, ei, device):
     return out, time.time() - t0
 
 
+def graph_inference(args, mol):
+    """inference.py:288-538 (graph_cls / graph_reg): per sampled dataset graph, one timed forward of the FIT-GNN model on
+    the graph's subgraph set (or its coarsened graph for Gc_train_2_Gc_infer) and, with --baseline, of the baseline on
+    the uncoarsened graph; accuracy (graph_cls) or L1 loss (graph_reg) over the samples; one CSV row per model."""
+    import types
+
+    from fitgnn_amd import graph_data, network
+    from fitgnn_amd.train import _cat_pieces
+
+    dev = torch.device(args.device)
+    cls_task = args.task == "graph_cls"
+    gset = graph_data.GraphSet(mol, ratio=args.coarsening_ratio, extra_node=bool(args.extra_node), device=dev,
+                               cluster_node=bool(args.cluster_node))
+    rng = np.random.default_rng(args.seed)
+    ids = rng.choice(gset.n_graphs, size=min(args.num_test_samples, gset.n_graphs), replace=False).tolist()
+    use_gc = args.exp_setup == "Gc_train_2_Gc_infer"
+    kind = "gc" if use_gc else "gs"
+    args.num_layers1 = args.num_layers2
+    if not cls_task:
+        args.num_classes = 1
+    Model = {(True, True): network.Classify_graph_gc, (True, False): network.Classify_graph_gs,
+             (False, True): network.Regress_graph_gc, (False, False): network.Regress_graph_gs}[(cls_task, use_gc)]
+
+    def run(model, kind):
+        model.eval()
+        times, losses, hits = [], [], 0
+        with torch.no_grad():
+            for g in ids:
+                b = _cat_pieces([gset.batch(g, g + 1, kind)], kind, types)
+                torch.cuda.synchronize(dev)
+                t0 = time.time()
+                out = model(b, b["graph_of_masked"]) if kind == "gs" else model(b["gc"])
+                torch.cuda.synchronize(dev)
+                times.append(time.time() - t0)
+                y = b["y"].long()
+                if cls_task:
+                    losses.append(float(F.cross_entropy(out, y.flatten())))
+                    hits += int(out.argmax(1) == y.flatten())
+                else:
+                    losses.append(float(F.l1_loss(out, y[:, args.property].view(-1, 1).float())))
+        t = float(np.mean(times[1:])) if len(times) > 1 else float(times[0])
+        return t, float(np.mean(losses)), hits / len(ids)
+
+    model = Model(args).to(dev)
+    model.load_state_dict(torch.load(os.path.join(args.path_gc if use_gc else args.path_gs, args.model_name_gc if use_gc else args.model_name_gs),
+                                     map_location=dev))
+    t_f, loss_f, acc_f = run(model, kind)
+    print(f"\nAverage time (FIT-GNN - {'coarsened graph' if use_gc else 'subgraph'}): {t_f}\n"
+          + (f"Accuracy: {acc_f}" if cls_task else f"L1 loss: {loss_f}"))
+    rows = []
+    if args.baseline:
+        model_b = (network.Classify_graph_gc if cls_task else network.Regress_graph_gc)(args).to(dev)
+        model_b.load_state_dict(torch.load(os.path.join(args.path_b, args.model_name_b), map_location=dev))
+        t_b, loss_b, acc_b = run(model_b, "orig")
+        print(f"Average time (baseline): {t_b}\n" + (f"Accuracy (baseline): {acc_b}" if cls_task else f"L1 loss (baseline): {loss_b}"))
+        rows.append(f"{args.dataset},True,{args.experiment},None,None,None,None,None,{args.hidden},{len(ids)},{args.num_layers2},None,{args.lr},{t_b},{loss_b},{acc_b}\n")
+    rows.append(f"{args.dataset},False,{args.experiment},{args.exp_setup},{args.coarsening_method},{args.coarsening_ratio},{args.extra_node},"
+                f"{args.cluster_node},{args.hidden},{len(ids)},{args.num_layers2},{args.batch_size},{args.lr},{t_f},{loss_f},{acc_f}\n")
+    os.makedirs("inference_results", exist_ok=True)
+    fn = f"inference_results/{args.task}.csv"
+    if not os.path.exists(fn):
+        with open(fn, 'w') as f:
+            f.write("dataset,baseline,experiment,exp_setup,coarsening_method,coarsening_ratio,extra_node,cluster_node,hidden,"
+                    "num_test_samples,num_layers,batch_size,lr,avg_inf_time,avg_loss,acc\n")
+    with open(fn, 'a') as f:
+        f.writelines(rows)
+    return t_f, (acc_f if cls_task else loss_f)
+
+
 def main(argv=None):
     args = arg_correction(build_parser().parse_args(argv))
     if args.seed is not None:
@@ -93,6 +165,8 @@ def main(argv=None):
         torch.manual_seed(args.seed)
     args.train_fitgnn = True
     data, args = train_cli.process_dataset(args)
+    if args.task in ("graph_cls", "graph_reg"):
+        return graph_inference(args, data)
     from fitgnn_amd import network, pipeline
     from fitgnn_amd.csr import csr_for
 

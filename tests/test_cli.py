@@ -154,6 +154,12 @@ def test_cli_graph_classification_on_synthetic_proteins(tmp_path, monkeypatch):
         assert np.isfinite(loss) and acc > 0.6, (setup, loss, acc)
     rows = open("results/synthetic-proteins.csv").read().strip().split("\n")
     assert rows[0].endswith("best_test_loss,best_test_acc") and len(rows) == 3
+    # inference.py on the last checkpoint (Gc_train_2_Gc_infer wrote save/graph_cls/p/model.pt)
+    import inference as icli
+    t, acc = icli.main(["--dataset", "synthetic-proteins", "--n_graphs", "400", "--hidden", "64", "--seed", "0", "--num_test_samples", "25",
+                        "--exp_setup", "Gc_train_2_Gc_infer", "--path_gc", "save/graph_cls/p/", "--model_name_gc", "model.pt"])
+    assert acc > 0.6 and t < 0.05
+    assert os.path.exists("inference_results/graph_cls.csv")
 
 
 @pytest.mark.gpu
