@@ -172,9 +172,19 @@ def main(argv=None):
 
     dev = torch.device(args.device)
     rng = np.random.default_rng(args.seed)
-    data = pipeline.splits_classification(data, args.num_classes, args.experiment, rng)
+    reg = args.task == "node_reg"
+    if reg:
+        data = pipeline.splits_regression(data, args.train_ratio, args.val_ratio, rng)
+    else:
+        data = pipeline.splits_classification(data, args.num_classes, args.experiment, rng)
+    Model = network.Regress_node if reg else network.Classify_node
+
+    def query_loss(out_row, y):   # node_reg: L1 on the scalar output (inference.py:705-707); node_cls: NLL + hit
+        if reg:
+            return float((out_row.flatten()[0] - y.float()).abs()), 0
+        return float(F.nll_loss(out_row.reshape(1, -1), y.reshape(1))), int(out_row.argmax() == y)
     co = pipeline.coarsening_classification(args, data, 1 - args.coarsening_ratio, args.coarsening_method, device=dev)
-    batch = pipeline.build_gs(args, data, co, dev)
+    batch = pipeline.build_gs(args, data, co, dev, float_targets=reg)
     ptr = batch.ptr
     # one query = (union row of a cluster's own node, its subgraph); sampled over subgraphs as inference.py:561-634
     core_rows = torch.nonzero(batch.core).flatten().cpu().numpy()
@@ -184,7 +194,7 @@ def main(argv=None):
     num = len(queries)
 
     args.num_layers1 = args.num_layers2  # inference.py builds Net1(..., args.num_layers2, ...)
-    model = network.Classify_node(args).to(dev)
+    model = Model(args).to(dev)
     model.load_state_dict(torch.load(os.path.join(args.path_gs, args.model_name_gs), map_location=dev))
     model.eval()
     ei = batch.edge_index
@@ -200,15 +210,16 @@ def main(argv=None):
             x, e, r0 = cache[s]
             out, dt = timed_forward(model, x, e, dev)
             j = row - r0
-            losses.append(float(F.nll_loss(out[j].reshape(1, -1), batch.y[row].reshape(1))))
-            hits += int(out[j].argmax() == batch.y[row])
+            l, h = query_loss(out[j], batch.y[row])
+            losses.append(l)
+            hits += h
             times.append(dt)
     t_gs = float(np.mean(times[1:])) if len(times) > 1 else float(times[0])
     print(f"\nAverage time (FIT-GNN): {t_gs}\nAccuracy (FIT-GNN): {hits}/{num}")
 
     rows = []
     if args.baseline:
-        model_b = network.Classify_node(args).to(dev)
+        model_b = Model(args).to(dev)
         model_b.load_state_dict(torch.load(os.path.join(args.path_b, args.model_name_b), map_location=dev))
         model_b.eval()
         xb = data.x.to(dev).float()
@@ -219,8 +230,9 @@ def main(argv=None):
             for row, _ in queries:
                 node = int(batch.node_id[row])
                 out, dt = timed_forward(model_b, xb, eb, dev)
-                lb.append(float(F.nll_loss(out[node].reshape(1, -1), yb[node].reshape(1))))
-                hb += int(out[node].argmax() == yb[node])
+                l, h = query_loss(out[node], yb[node])
+                lb.append(l)
+                hb += h
                 tb.append(dt)
         t_b = float(np.mean(tb[1:])) if len(tb) > 1 else float(tb[0])
         print(f"Average time (baseline): {t_b}\nAccuracy (baseline): {hb}/{num}")

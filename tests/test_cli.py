@@ -139,6 +139,10 @@ def test_cli_node_regression_on_synthetic_chameleon(tmp_path, monkeypatch):
     assert losses[0] < 0.76, losses  # constant predictor: ~0.80
     rows = open("results/synthetic-chameleon.csv").read().strip().split("\n")
     assert rows[0].startswith("dataset,coarsening_method,coarsening_ratio,layer_name") and len(rows) == 2
+    import inference as icli
+    t, _ = icli.main(["--dataset", "synthetic-chameleon", "--hidden", "64", "--seed", "0", "--extra_node", "--num_test_samples", "20",
+                      "--path_gs", "save/node_reg/r/", "--coarsening_ratio", "0.5"])
+    assert t < 0.05 and os.path.exists("inference_results/node_reg.csv")
 
 
 @pytest.mark.gpu
