@@ -408,6 +408,38 @@ def _dense_prelude(W, b, e, K):
     return Uk @ np.diag(lsinv)
 
 
+def _dense_prelude_batch(W, off, comps, K, A, Kc):
+    """_dense_prelude for many components at once: components of equal size are stacked into one [G, n, n] array and
+    handed to a single batched np.linalg.eigh (the same LAPACK routine per matrix as the one-at-a-time form).  Fills
+    A[rows of c, :k] and Kc[c] in place."""
+    coo = W.tocoo()
+    comp_of = np.searchsorted(off, coo.row, side="right") - 1
+    size = np.diff(off)
+    todo = np.zeros(len(size), dtype=bool)
+    todo[comps] = True
+    for n in np.unique(size[comps]):
+        ids = np.nonzero(todo & (size == n))[0]
+        slot = np.full(len(size), -1, dtype=np.int64)
+        slot[ids] = np.arange(len(ids))
+        sel = slot[comp_of] >= 0
+        g, r, c = slot[comp_of[sel]], coo.row[sel] - off[comp_of[sel]], coo.col[sel] - off[comp_of[sel]]
+        Wd = np.zeros((len(ids), n, n))
+        np.add.at(Wd, (g, r, c), coo.data[sel])
+        Ld = -Wd
+        Ld[:, np.arange(n), np.arange(n)] += Wd.sum(1)
+        lk, Uk = np.linalg.eigh(Ld)
+        k = int(min(K, n))
+        lk, Uk = lk[:, :k].copy(), Uk[:, :, :k]
+        mask = lk < 1e-10
+        lk[mask] = 1
+        lsinv = lk ** (-0.5)
+        lsinv[mask] = 0
+        Ag = Uk * lsinv[:, None, :]
+        rows = (off[ids][:, None] + np.arange(n)[None, :]).ravel()
+        A[rows, :k] = Ag.reshape(-1, k)
+        Kc[ids] = k
+
+
 def coarsen_batch(W, comp_off, r=0.5, K=10, max_levels=10, A0=None, max_level_r=0.99, device="cuda", spectral="arpack"):
     """coarsen() (coarsening_utils.py:18-182, method variation_neighborhoods) applied independently to every connected
     component of the block-diagonal adjacency W (scipy sparse [N x N]); component c = node range
@@ -450,14 +482,18 @@ def coarsen_batch(W, comp_off, r=0.5, K=10, max_levels=10, A0=None, max_level_r=
             Kc = np.where(size0 <= K, size0, K).astype(np.int32)  # eigsh(dense, k=K >= N) returns N pairs (:85-86)
             Kmax = int(max(K, Kc.max()))
             A = np.zeros((N, Kmax))
+            todo = [c for c in np.nonzero(active)[0] if A0 is None or A0[c] is None]
+            if spectral == "dense" and todo:
+                _dense_prelude_batch(W, off, np.asarray(todo), K, A, Kc)
+                todo = []
             for c in np.nonzero(active)[0]:
                 b, e = int(off[c]), int(off[c + 1])
                 if A0 is not None and A0[c] is not None:
                     Ac = np.asarray(A0[c], dtype=np.float64)
-                elif spectral == "dense":
-                    Ac = _dense_prelude(W, b, e, K)
-                else:
+                elif c in todo:
                     Ac = _spectral_level1(Graph(W[b:e, b:e]), K, None, None)
+                else:
+                    continue
                 Kc[c] = Ac.shape[1]
                 A[b:e, :Ac.shape[1]] = np.real(Ac)
             node_K_comp = Kc

@@ -314,3 +314,23 @@ def test_tile_makers_cover_rows_exactly_once_hypothesis():
         assert np.all(cov2 == 1)
 
     check()
+
+
+def test_batched_dense_prelude_equals_one_at_a_time():
+    """coarsening._dense_prelude_batch (components of equal size through one batched eigh) == _dense_prelude per component."""
+    import scipy.sparse as sp
+
+    from fitgnn_amd import coarsening as co
+    from fitgnn_amd.graph_data import synthetic_molecules
+
+    mol = synthetic_molecules(40, seed=2)
+    ei, off = mol["edge_index"], mol["node_ptr"]
+    N = int(off[-1])
+    W = sp.csr_matrix((np.ones(ei.shape[1]), (ei[0], ei[1])), shape=(N, N))
+    A = np.zeros((N, 10)); Kc = np.zeros(40, dtype=np.int32)
+    co._dense_prelude_batch(W, off, np.arange(40), 10, A, Kc)
+    for c in range(40):
+        b, e = int(off[c]), int(off[c + 1])
+        ref = co._dense_prelude(W, b, e, 10)
+        assert Kc[c] == ref.shape[1]
+        assert np.array_equal(A[b:e, :ref.shape[1]], ref), c
