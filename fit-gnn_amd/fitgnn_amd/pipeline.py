@@ -138,7 +138,7 @@ class Coarsened:
     pass
 
 
-def coarsening_classification(args, data, coarsening_ratio, coarsening_method, device="cuda"):
+def coarsening_classification(args, data, coarsening_ratio, coarsening_method, device="cuda", batched=True):
     """utils.py:143-184: components sorted by size (descending, stable), coarsen() on every component with more
     than one node (Loukas r = 1 - --coarsening_ratio is passed by main.py:278), node -> cluster map from the
     level mapping dicts; single nodes are their own cluster."""
@@ -152,13 +152,31 @@ def coarsening_classification(args, data, coarsening_ratio, coarsening_method, d
     out.components, out.C_list, out.Gc_list = comps, [], []   # *_list: components with > 10 nodes only (:164-166)
     out.all_C, out.all_Gc = [], []
     assign = np.zeros(N, dtype=np.int64)
-    off = 0
     out.comp_cluster_off = []
+    multi = [H for H in comps if len(H.info["orig_idx"]) > 1]
+    if len(multi) > 4 and batched:
+        # many components (Cora: 78, CiteSeer: 438): ONE batched contraction instead of a device round trip per component
+        # (same per-component prelude, same kernels with one wavefront per component: identical partitions)
+        idxs = [np.asarray(H.info["orig_idx"], dtype=np.int64) for H in multi]
+        perm = np.concatenate(idxs)
+        comp_off = np.concatenate([[0], np.cumsum([len(i) for i in idxs])])
+        bc = coarsening.coarsen_batch(W[perm][:, perm], comp_off, r=coarsening_ratio, device=device)
+        per = {}
+        for c, (H, idx) in enumerate(zip(multi, idxs)):
+            b, e, cb, ce = int(comp_off[c]), int(comp_off[c + 1]), int(bc.cluster_off[c]), int(bc.cluster_off[c + 1])
+            C = coarsening.CoarseningMatrix(sp.csc_matrix((bc.cval[b:e], (bc.assign[b:e] - cb, np.arange(e - b))), shape=(ce - cb, e - b)))
+            per[id(H)] = (C, coarsening.Graph(bc.Wc[cb:ce, cb:ce].tocsr()))
+    else:
+        per = None
+    off = 0
     for H in comps:
         idx = np.asarray(H.info["orig_idx"], dtype=np.int64)
         out.comp_cluster_off.append(off)
         if len(idx) > 1:
-            C, Gc, maps = coarsening.coarsen(H, r=coarsening_ratio, method=coarsening_method, device=device)
+            if per is not None:
+                C, Gc = per[id(H)]
+            else:
+                C, Gc, maps = coarsening.coarsen(H, r=coarsening_ratio, method=coarsening_method, device=device)
             a = sp.csc_matrix(C).indices.astype(np.int64)  # composed mapping dicts == row of C's single entry
             assign[idx] = off + a
             off += C.shape[0]

@@ -193,3 +193,37 @@ def test_device_eigensolver_feeds_the_contraction(mods):
     Cc = sp.csc_matrix(C)
     assert np.all(np.diff(Cc.indptr) == 1) and Cc.shape[0] == int(np.ceil(0.5 * g.N))
     assert np.allclose(np.asarray(Cc.power(2).sum(1)).ravel(), 1.0)
+
+
+def test_pipeline_batched_components_equal_per_component_loop(mods):
+    """pipeline.coarsening_classification on a dataset with many components (a block-diagonal union of golden graphs plus
+    isolated nodes): the batched contraction gives the same clusters, C and Gc per component as the per-component loop."""
+    import argparse
+
+    from fitgnn_amd import pipeline
+
+    gs = [G(n) for n in ("ring100", "cora26", "cora9", "star40", "cora2", "ring400", "ba600w")]
+    W = sp.block_diag([g.W for g in gs] + [sp.csr_matrix((3, 3))], format="csr")   # + three isolated nodes
+    W.data[:] = 1.0
+    coo = W.tocoo()
+    N = W.shape[0]
+    data = pipeline.NodeData(torch.zeros(N, 4), np.stack([coo.row, coo.col]), torch.zeros(N, dtype=torch.long))
+    args = argparse.Namespace()
+    _lib, co, orc = mods
+
+    def dense_prelude(Gr, K, Uk, lk):   # ARPACK starts from a random vector: give both paths the same exact eigenvectors
+        return co._dense_prelude(Gr.W, 0, Gr.N, K)
+
+    saved, co._spectral_level1 = co._spectral_level1, dense_prelude
+    try:
+        a = pipeline.coarsening_classification(args, data, 0.5, "variation_neighborhoods", batched=True)
+        b = pipeline.coarsening_classification(args, data, 0.5, "variation_neighborhoods", batched=False)
+    finally:
+        co._spectral_level1 = saved
+    assert a.n_clusters == b.n_clusters and np.array_equal(a.assign, b.assign)
+    assert len(a.all_C) == len(b.all_C) == len(a.components)
+    for Ca, Cb, Ga, Gb in zip(a.all_C, b.all_C, a.all_Gc, b.all_Gc):
+        if Ca is None:
+            assert Cb is None
+            continue
+        assert (sp.csc_matrix(Ca) != sp.csc_matrix(Cb)).nnz == 0 and (Ga.W != Gb.W).nnz == 0
