@@ -24,6 +24,8 @@ PROFILE = None
 # through a split-K batched product (mm_at_b): the library's single-call kernel for that shape is 2.7x slower.
 # "highest" everywhere = plain fp32 MFMA.
 GEMM_PRECISION = "high"
+# a^T @ b (weight gradients) through csrc/gemm_atb.hip instead of the library's batched split-K form
+ATB_KERNEL = True
 
 
 def mm(a, b, allow_split=True):
@@ -46,12 +48,31 @@ def mm_by_transposed(a, W):
     return mm(a, W)
 
 
+def _atb_ok(t):
+    return (t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 and t.stride(1) == 1 and t.stride(0) % 4 == 0
+            and t.shape[1] % 4 == 0 and t.shape[1] >= 4 and t.data_ptr() % 16 == 0)
+
+
+def gemm_atb(a, b):
+    """a^T @ b through the hand-written split-K MFMA kernel (csrc/gemm_atb.hip): 3 x bf16 products, fp32 accumulate,
+    fixed-order sum of the row chunks."""
+    L = _lib.lib()
+    R, M, N = a.shape[0], a.shape[1], b.shape[1]
+    ws = torch.empty(int(L.fitgnn_gemm_atb_workspace_bytes(R, M, N)) // 4, dtype=torch.float32, device=a.device)
+    out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    _lib.check(L.fitgnn_gemm_atb_f32(_lib.dptr(a), a.stride(0), _lib.dptr(b), b.stride(0), R, M, N, _lib.dptr(out),
+                                     _lib.dptr(ws), _lib.stream_ptr(a.device)), "fitgnn_gemm_atb_f32")
+    return out
+
+
 def mm_at_b(a, b):
     """a^T @ b for tall operands a [R, M], b [R, N] (the weight-gradient product dH^T @ X, reduction over all R
     rows).  hipBLASLt serves this huge-K / small-MN shape poorly as one GEMM (541 us for R = 90k, M = N = 512); as a
     batched GEMM over ~1400-row slices plus a sum of the partial products it takes 232 us (3xbf16 split) / 394 us
     (fp32) -- split-K by hand.  The partials are summed in a fixed order: reproducible."""
     R = a.shape[0]
+    if GEMM_PRECISION == "high" and ATB_KERNEL and R >= 256 and _atb_ok(a) and _atb_ok(b):
+        return gemm_atb(a, b)
     B = R // 1408
     if B < 4:
         return mm(a.t(), b, allow_split=False)

@@ -119,6 +119,17 @@ int fitgnn_segment_sum_f32(const int32_t *seg_off, const int32_t *members, int32
  * of the split-K weight-gradient GEMM dH^T @ X (the library has no deterministic split-K for K = number of rows). */
 int fitgnn_sum_leading_f32(const float *part, int32_t B, int64_t W, float *out, void *stream);
 
+/* out [M x N] = a^T @ b for tall row-major operands a [R x M] (row stride lda), b [R x N] (row stride ldb): the
+ * weight-gradient product grad_W = grad_h^T @ x that `loss.backward()` (run.py:207, :246) runs for every Linear on the
+ * path (GCNConv.lin, lt1; network.py:31-33).  Hand-written split-K MFMA kernel: each fp32 operand is split into two
+ * bf16 (hi by truncation, lo = bf16(x - hi)) and the product is hi.hi + hi.lo + lo.hi on v_mfma_f32_32x32x16_bf16 with
+ * fp32 accumulation (~5e-6 relative error against fp64); the row chunks' partial tiles go to `workspace`
+ * (fitgnn_gemm_atb_workspace_bytes) and are added in a fixed order -- reproducible, no atomics.
+ * M, N, lda, ldb multiples of 4; all pointers 16-byte aligned. */
+size_t fitgnn_gemm_atb_workspace_bytes(int64_t R, int32_t M, int32_t N);
+int fitgnn_gemm_atb_f32(const float *a, int64_t lda, const float *b, int64_t ldb, int64_t R, int32_t M, int32_t N,
+                        float *out, void *workspace, void *stream);
+
 /* loss[0] = scale * sum_t NLL(log_softmax(z[idx[t]]), labels[t]) over n selected rows (Classify_node's log_softmax,
  * network.py:35, followed by NLLLoss, run.py:341; scale = 1/n for reduction='mean', 1/global count under data
  * parallelism), and dz [n_rows x ldz] = its gradient w.r.t. the logits z (zero on rows that are not selected).

@@ -38,6 +38,10 @@ def test_error_strings_and_size_queries():
     assert L.fitgnn_lift_adjacency_workspace_bytes(10, 50, 5) > 0
     assert L.fitgnn_pool_rows_workspace_bytes(100, 50) > 0
     assert L.fitgnn_build_assignment_workspace_bytes(100) >= 2 * 101 * 4
+    # split-K weight-gradient GEMM: a multiple of 8 row chunks of one [M x N] partial each, ~256 workgroups
+    assert L.fitgnn_gemm_atb_workspace_bytes(90549, 512, 512) == 64 * 512 * 512 * 4
+    assert L.fitgnn_gemm_atb_workspace_bytes(33, 8, 4) == 8 * 8 * 4 * 4
+    assert L.fitgnn_gemm_atb_workspace_bytes(0, 8, 4) == 0
 
 
 def test_bad_arguments_are_rejected_without_touching_the_gpu():
@@ -47,6 +51,8 @@ def test_bad_arguments_are_rejected_without_touching_the_gpu():
     assert L.fitgnn_variation_costs_f64(None, None, None, None, None, 17, 17, None, None, None, 1, None, None) == -1
     assert L.fitgnn_variation_costs_f64(None, None, None, None, None, 10, 10, None, None, None, 0, None, None) == 0
     assert L.fitgnn_pool_rows_f32(None, None, 5, 0, None, 4, 4, None, 4, None, None, 0, None) == 0
+    assert L.fitgnn_gemm_atb_f32(None, 8, None, 8, 100, 8, 8, None, None, None) == -1
+    assert L.fitgnn_gemm_atb_f32(None, 6, None, 8, 100, 6, 8, None, None, None) == -1  # M % 4 != 0
 
 
 def test_no_cpu_fallback():

@@ -282,3 +282,39 @@ def test_torch_ops_namespace(mods):
     Xc = torch.ops.fitgnn.pool_rows(assign, cval, 2, Xs)
     ref = torch.stack([(Xs[:2].double() * 2 ** -0.5).sum(0), (Xs[2:].double() * 3 ** -0.5).sum(0)]).float()
     assert torch.allclose(Xc, ref, rtol=1e-6)
+
+
+# grad_W = grad_h^T @ x (csrc/gemm_atb.hip): row counts around the 32-row stage and the chunking, ragged column
+# counts (500 = PubMed's feature width, not a multiple of the 256 tile), row strides wider than the operand
+@pytest.mark.parametrize("R,M,N", [(90549, 512, 512), (19717, 512, 500), (4097, 260, 36), (1000, 64, 128),
+                                   (256, 512, 4), (33, 8, 4), (31, 8, 8), (32, 4, 4), (1, 4, 4)])
+def test_weight_gradient_gemm_matches_f64(mods, R, M, N):
+    _lib, csr, ops, orc, gorc = mods
+    g = torch.Generator().manual_seed(R + M + N)
+    a = torch.randn(R, M, generator=g).cuda()
+    b = torch.randn(R, N, generator=g).cuda()
+    ref = (a.double().t() @ b.double())
+    got = ops.gemm_atb(a, b)
+    # three-product bf16 split, fp32 accumulate: ~5e-6 of the largest entry (the library's "high" path gives the same)
+    assert float((got - ref).abs().max() / ref.abs().max()) < 2e-5
+    assert torch.equal(got, ops.gemm_atb(a, b)), "fixed-order chunk sum: bit-reproducible"
+    # strided operands: column windows of wider matrices
+    wide_a = torch.randn(R, M + 8, generator=g).cuda()
+    wide_b = torch.randn(R, N + 4, generator=g).cuda()
+    va, vb = wide_a[:, 4:4 + M], wide_b[:, :N]
+    got = ops.gemm_atb(va, vb)
+    ref = va.double().t() @ vb.double()
+    assert float((got - ref).abs().max() / ref.abs().max()) < 2e-5
+
+
+def test_weight_gradient_gemm_is_the_default_path(mods):
+    _lib, csr, ops, orc, gorc = mods
+    a = torch.randn(3000, 64).cuda()
+    b = torch.randn(3000, 32).cuda()
+    assert ops.ATB_KERNEL
+    assert torch.equal(ops.mm_at_b(a, b), ops.gemm_atb(a, b))
+    ref = a.double().t() @ b.double()
+    assert float((ops.mm_at_b(a, b) - ref).abs().max() / ref.abs().max()) < 2e-5
+    # exact zeros and signed values survive the hi/lo split
+    z = torch.zeros(512, 8).cuda()
+    assert float(ops.gemm_atb(z, b[:512]).abs().max()) == 0.0
