@@ -71,7 +71,8 @@ def mm_at_b(a, b):
     batched GEMM over ~1400-row slices plus a sum of the partial products it takes 232 us (3xbf16 split) / 394 us
     (fp32) -- split-K by hand.  The partials are summed in a fixed order: reproducible."""
     R = a.shape[0]
-    if GEMM_PRECISION == "high" and ATB_KERNEL and R >= 256 and _atb_ok(a) and _atb_ok(b):
+    if (GEMM_PRECISION == "high" and ATB_KERNEL and R >= 256 and min(a.shape[1], b.shape[1]) >= 64 and _atb_ok(a)
+            and _atb_ok(b)):  # narrower operands would leave most of a 256 x 256 tile multiplying padding
         return gemm_atb(a, b)
     B = R // 1408
     if B < 4:
