@@ -130,6 +130,13 @@ size_t fitgnn_gemm_atb_workspace_bytes(int64_t R, int32_t M, int32_t N);
 int fitgnn_gemm_atb_f32(const float *a, int64_t lda, const float *b, int64_t ldb, int64_t R, int32_t M, int32_t N,
                         float *out, void *workspace, void *stream);
 
+/* c [R x N] (row stride ldc) = a [R x K] @ b [N x K]^T, row-major fp32, K a multiple of 32, lda/ldb multiples of 4,
+ * a and b 16-byte aligned: the forward of GCNConv's bias-free Linear, h = x W^T (network.py:31 via torch_geometric), and
+ * with b = W^T the input gradient grad_x = grad_h @ W of its backward.  Same three-product bf16 split on the MFMA pipe
+ * as fitgnn_gemm_atb_f32 (~5e-6 relative error against fp64), 256 x 256 output tiles, no split over K. */
+int fitgnn_gemm_nt_f32(const float *a, int64_t lda, const float *b, int64_t ldb, int64_t R, int32_t N, int32_t K,
+                       float *c, int64_t ldc, void *stream);
+
 /* loss[0] = scale * sum_t NLL(log_softmax(z[idx[t]]), labels[t]) over n selected rows (Classify_node's log_softmax,
  * network.py:35, followed by NLLLoss, run.py:341; scale = 1/n for reduction='mean', 1/global count under data
  * parallelism), and dz [n_rows x ldz] = its gradient w.r.t. the logits z (zero on rows that are not selected).

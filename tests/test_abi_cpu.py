@@ -53,6 +53,8 @@ def test_bad_arguments_are_rejected_without_touching_the_gpu():
     assert L.fitgnn_pool_rows_f32(None, None, 5, 0, None, 4, 4, None, 4, None, None, 0, None) == 0
     assert L.fitgnn_gemm_atb_f32(None, 8, None, 8, 100, 8, 8, None, None, None) == -1
     assert L.fitgnn_gemm_atb_f32(None, 6, None, 8, 100, 6, 8, None, None, None) == -1  # M % 4 != 0
+    assert L.fitgnn_gemm_nt_f32(None, 48, None, 48, 100, 8, 48, None, 8, None) == -1   # K % 32 != 0
+    assert L.fitgnn_gemm_nt_f32(None, 64, None, 64, 0, 8, 64, None, 8, None) == 0       # no rows: nothing to do
 
 
 def test_no_cpu_fallback():

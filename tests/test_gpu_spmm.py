@@ -310,7 +310,7 @@ def test_weight_gradient_gemm_matches_f64(mods, R, M, N):
 def test_weight_gradient_gemm_is_the_default_path(mods):
     _lib, csr, ops, orc, gorc = mods
     a = torch.randn(3000, 64).cuda()
-    b = torch.randn(3000, 32).cuda()
+    b = torch.randn(3000, 96).cuda()   # operands narrower than 64 columns stay on the library path (mostly padding in a tile)
     assert ops.ATB_KERNEL
     assert torch.equal(ops.mm_at_b(a, b), ops.gemm_atb(a, b))
     ref = a.double().t() @ b.double()
@@ -318,3 +318,39 @@ def test_weight_gradient_gemm_is_the_default_path(mods):
     # exact zeros and signed values survive the hi/lo split
     z = torch.zeros(512, 8).cuda()
     assert float(ops.gemm_atb(z, b[:512]).abs().max()) == 0.0
+    narrow = torch.randn(3000, 8).cuda()
+    ref = narrow.double().t() @ b.double()
+    assert float((ops.mm_at_b(narrow, b) - ref).abs().max() / ref.abs().max()) < 2e-5
+
+
+# h = x W^T and dX = dH W (csrc/gemm_nt.hip): row counts around the 256-row tile, ragged N, K = 32..512, strided operands
+@pytest.mark.parametrize("R,N,K", [(90549, 512, 512), (4097, 260, 96), (1024, 512, 32), (257, 64, 64), (5, 4, 32),
+                                   (19717, 500, 512)])
+def test_linear_gemm_matches_f64(mods, R, N, K):
+    _lib, csr, ops, orc, gorc = mods
+    g = torch.Generator().manual_seed(R + N + K)
+    a = torch.randn(R, K, generator=g).cuda()
+    b = torch.randn(N, K, generator=g).cuda()
+    ref = a.double() @ b.double().t()
+    got = ops.gemm_nt(a, b)
+    assert float((got - ref).abs().max() / ref.abs().max()) < 2e-5
+    assert torch.equal(got, ops.gemm_nt(a, b))
+    wide_a = torch.randn(R, K + 8, generator=g).cuda()
+    wide_b = torch.randn(N, K + 4, generator=g).cuda()
+    va, vb = wide_a[:, 4:4 + K], wide_b[:, :K]
+    ref = va.double() @ vb.double().t()
+    assert float((ops.gemm_nt(va, vb) - ref).abs().max() / ref.abs().max()) < 2e-5
+
+
+def test_linear_gemm_is_the_default_path_and_differentiates(mods):
+    _lib, csr, ops, orc, gorc = mods
+    assert ops.NT_KERNEL
+    x = torch.randn(2048, 128, device="cuda", requires_grad=True)
+    W = torch.randn(96, 128, device="cuda", requires_grad=True)
+    y = ops.Linear.apply(x, W)
+    assert torch.equal(y, ops.gemm_nt(x.detach(), W.detach()))
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    xd, Wd = x.detach().double(), W.detach().double()
+    assert float((x.grad - gy.double() @ Wd).abs().max()) < 2e-5 * float((gy.double() @ Wd).abs().max())
+    assert float((W.grad - gy.double().t() @ xd).abs().max()) < 2e-5 * float((gy.double().t() @ xd).abs().max())
