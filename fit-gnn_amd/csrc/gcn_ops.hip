@@ -342,6 +342,13 @@ extern "C" int fitgnn_adam_step_f32(float *param, const float *grad, float *exp_
     return (int)hipGetLastError();
 }
 
+extern "C" int fitgnn_colsum_partials_f32(const float *partial, int32_t n_chunks, int32_t H, float *out, void *stream) {
+    if (n_chunks < 1 || H < 1 || !partial || !out) return FITGNN_E_BADARG;
+    hipLaunchKernelGGL(colsum_partials_kernel, dim3((H + kColsumCols - 1) / kColsumCols), dim3(kColsumPhases * kColsumCols), 0,
+                       (hipStream_t)stream, partial, n_chunks, H, out);
+    return (int)hipGetLastError();
+}
+
 extern "C" int fitgnn_sum_leading_f32(const float *part, int32_t B, int64_t W, float *out, void *stream) {
     if (B < 1 || W < 0 || (W % 4) != 0) return FITGNN_E_BADARG;
     if (W == 0) return 0;

@@ -41,9 +41,17 @@ __device__ __forceinline__ uint32_t pack_bf16_rne(float x0, float x1) {
     return __builtin_bit_cast(uint32_t, r);
 }
 
+// EPI: the product is the gradient dOut of a fused layer output  out = dropout(ELU(z))  and what is stored is
+//   dZ = keep ? dOut / (1 - p) * (o > 0 ? 1 : o + 1) : 0,   o = out * (1 - p)
+// (the arithmetic of epilogue_bwd_kernel, gcn_ops.hip), with the per-tile column sums of dZ written to `col_part`
+// [tiles_m x N] for the bias gradient -- the [R x N] gradient is never written and re-read un-transformed.
+template <bool EPI>
 __global__ __launch_bounds__(kThreads, 1) void gemm_nt_kernel(const float *__restrict__ a, long lda,
                                                               const float *__restrict__ b, long ldb, long R, int N, int K,
-                                                              int tiles_m, int tiles_n, float *__restrict__ c, long ldc) {
+                                                              int tiles_m, int tiles_n, float *__restrict__ c, long ldc,
+                                                              const float *__restrict__ out, float *__restrict__ col_part,
+                                                              uint32_t epi, float p_drop, uint64_t seed_arg,
+                                                              const uint8_t *__restrict__ mask) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // the column tiles of one row tile sit on consecutive slots of one XCD: the a slab's second reader hits that L2
@@ -161,25 +169,105 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_nt_kernel(const float *__res
                  : "memory");
 
     // C/D layout of the 32x32 MFMA: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    if (!EPI) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const int n = tn * kTile + (4 * wn + jj) * 32 + (lane & 31);
+                const long m0 = (long)tm * kTile + (2 * wm + i) * 32 + 4 * (lane >> 5);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const long m = m0 + (r & 3) + 8 * (r >> 2);
+                    if (m < R && n < N) c[m * ldc + n] = acc[i][jj][r];
+                }
+            }
+        }
+        return;
+    }
+    const uint64_t seed = fitgnn::resolve_seed(seed_arg, epi);
+    const bool drop = (epi & FITGNN_EPI_DROPOUT) != 0, elu = (epi & FITGNN_EPI_ELU) != 0;
+    const float scale = drop ? 1.0f / (1.0f - p_drop) : 1.0f;
+    const float unscale = drop ? (1.0f - p_drop) : 1.0f;
+    const uint32_t thresh = fitgnn::dropout_threshold(p_drop);
+    // The accumulators go through LDS once (each wave its own 32 x 128 block per pass) so that the epilogue runs on
+    // rows: a lane then owns 4 consecutive columns -- exactly one dropout group (one hash per float4, as in
+    // epilogue_bwd_kernel) -- and `out` / dZ move as 16-byte accesses, 512 contiguous bytes per half wave.
+    float colsum[4] = {0.f, 0.f, 0.f, 0.f};
+    float *blk = reinterpret_cast<float *>(lds) + wave * (32 * 128);
+    const int n = tn * kTile + wn * 128 + 4 * (lane & 31);
+    const int nc = n < N ? n : N - 4;  // N % 4 == 0
+    const uint64_t n4 = (uint64_t)(N >> 2);
+    __syncthreads();  // every wave has left the last LDS stage
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-            const int n = tn * kTile + (4 * wn + jj) * 32 + (lane & 31);
-            const long m0 = (long)tm * kTile + (2 * wm + i) * 32 + 4 * (lane >> 5);
+        for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const long m = m0 + (r & 3) + 8 * (r >> 2);
-                if (m < R && n < N) c[m * ldc + n] = acc[i][jj][r];
+            for (int r = 0; r < 16; ++r)
+                blk[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 128 + jj * 32 + (lane & 31)] = acc[i][jj][r];
+        const long mrow = (long)tm * kTile + (2 * wm + i) * 32 + (lane >> 5);
+        float4 o[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {  // the 16 loads of this pass before the first use
+            long m = mrow + 2 * k;
+            m = m < R ? m : R - 1;
+            o[k] = *reinterpret_cast<const float4 *>(out + m * (long)N + nc);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const long m = mrow + 2 * k;
+            const float4 v = *reinterpret_cast<const float4 *>(blk + (2 * k + (lane >> 5)) * 128 + 4 * (lane & 31));
+            float d[4] = {v.x, v.y, v.z, v.w};
+            const float ov[4] = {o[k].x, o[k].y, o[k].z, o[k].w};
+            const bool live = m < R && n < N;
+            const uint64_t idx = (uint64_t)m * (uint64_t)N + (uint64_t)n;
+            uint64_t bits = 0;
+            if (drop && !mask) bits = fitgnn::dropout_bits(seed, (uint64_t)m * n4 + (uint64_t)(n >> 2));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (drop) {
+                    const bool keep = mask ? (live && mask[idx + e] != 0) : fitgnn::dropout_keep(bits, e, thresh);
+                    d[e] = keep ? d[e] * scale : 0.f;
+                }
+                if (elu) {
+                    const float ev = ov[e] * unscale;
+                    d[e] = ev > 0.f ? d[e] : d[e] * (ev + 1.0f);
+                }
+            }
+            if (live) {
+                *reinterpret_cast<float4 *>(c + m * ldc + n) = make_float4(d[0], d[1], d[2], d[3]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) colsum[e] += d[e];
             }
         }
+        __builtin_amdgcn_wave_barrier();  // the block is rewritten by the next pass
+    }
+    // bias gradient: this workgroup's 256 rows per column, in a fixed order: lane halves, then the 4 row-waves
+    __syncthreads();
+    float *red = reinterpret_cast<float *>(lds);  // [4 wm][256 columns]
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float other = __shfl_xor(colsum[e], 32);
+        if (lane < 32) red[wm * kTile + wn * 128 + 4 * lane + e] = colsum[e] + other;
+    }
+    __syncthreads();
+    if (tid < kTile) {
+        const int nn = tn * kTile + tid;
+        if (nn < N) col_part[(long)tm * N + nn] = (red[tid] + red[kTile + tid]) + (red[2 * kTile + tid] + red[3 * kTile + tid]);
     }
 }
 
 }  // namespace
 
-extern "C" int fitgnn_gemm_nt_f32(const float *a, int64_t lda, const float *b, int64_t ldb, int64_t R, int32_t N, int32_t K,
-                                  float *c, int64_t ldc, void *stream) {
+extern "C" int fitgnn_colsum_partials_f32(const float *partial, int32_t n_chunks, int32_t H, float *out, void *stream);
+
+namespace {
+int launch_nt(bool epi_on, const float *a, int64_t lda, const float *b, int64_t ldb, int64_t R, int32_t N, int32_t K, float *c,
+              int64_t ldc, const float *out, float *col_part, uint32_t epi, float p_drop, uint64_t seed, const uint8_t *mask,
+              void *stream) {
     if (R < 0 || N <= 0 || K < kStage || (K % kStage) != 0 || lda < K || ldb < K || ldc < N || (lda % 4) != 0 || (ldb % 4) != 0)
         return FITGNN_E_BADARG;
     if (R == 0) return 0;
@@ -187,9 +275,35 @@ extern "C" int fitgnn_gemm_nt_f32(const float *a, int64_t lda, const float *b, i
     if ((((uintptr_t)a | (uintptr_t)b) % 16) != 0) return FITGNN_E_ALIGN;
     const int tiles_m = (int)((R + kTile - 1) / kTile), tiles_n = (N + kTile - 1) / kTile;
     const int groups = (tiles_m + 7) / 8;
-    FITGNN_RETURN_IF_HIP(
-        hipFuncSetAttribute((const void *)gemm_nt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
-    hipLaunchKernelGGL(gemm_nt_kernel, dim3((unsigned)(groups * 8 * tiles_n)), dim3(kThreads), kLdsBytes, (hipStream_t)stream,
-                       a, (long)lda, b, (long)ldb, (long)R, N, K, tiles_m, tiles_n, c, (long)ldc);
+    auto kern = epi_on ? gemm_nt_kernel<true> : gemm_nt_kernel<false>;
+    FITGNN_RETURN_IF_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
+    hipLaunchKernelGGL(kern, dim3((unsigned)(groups * 8 * tiles_n)), dim3(kThreads), kLdsBytes, (hipStream_t)stream, a,
+                       (long)lda, b, (long)ldb, (long)R, N, K, tiles_m, tiles_n, c, (long)ldc, out, col_part, epi, p_drop, seed,
+                       mask);
     return (int)hipGetLastError();
+}
+}  // namespace
+
+extern "C" int fitgnn_gemm_nt_f32(const float *a, int64_t lda, const float *b, int64_t ldb, int64_t R, int32_t N, int32_t K,
+                                  float *c, int64_t ldc, void *stream) {
+    return launch_nt(false, a, lda, b, ldb, R, N, K, c, ldc, nullptr, nullptr, 0u, 0.f, 0ull, nullptr, stream);
+}
+
+extern "C" size_t fitgnn_gemm_nt_epilogue_bwd_workspace_bytes(int64_t R, int32_t N) {
+    if (R <= 0 || N <= 0) return 0;
+    return (size_t)((R + kTile - 1) / kTile) * (size_t)N * sizeof(float);
+}
+
+extern "C" int fitgnn_gemm_nt_epilogue_bwd_f32(const float *a, int64_t lda, const float *b, int64_t ldb, int64_t R, int32_t N,
+                                               int32_t K, const float *out, float *dZ, uint32_t epilogue, float p_drop,
+                                               uint64_t seed, const uint8_t *mask, float *db, void *work, size_t work_bytes,
+                                               void *stream) {
+    if (R > 0 && (!out || !dZ || !work)) return FITGNN_E_BADARG;
+    if ((epilogue & FITGNN_EPI_DROPOUT) && !(p_drop >= 0.f && p_drop < 1.f)) return FITGNN_E_BADARG;
+    if ((N % 4) != 0) return FITGNN_E_BADARG;  // the dropout groups of 4 columns must not straddle rows
+    if ((((uintptr_t)out | (uintptr_t)dZ) % 16) != 0) return FITGNN_E_ALIGN;
+    if (work_bytes < fitgnn_gemm_nt_epilogue_bwd_workspace_bytes(R, N)) return FITGNN_E_WORKSPACE;
+    const int rc = launch_nt(true, a, lda, b, ldb, R, N, K, dZ, N, out, (float *)work, epilogue, p_drop, seed, mask, stream);
+    if (rc != 0 || R == 0 || !db) return rc;
+    return fitgnn_colsum_partials_f32((const float *)work, (int32_t)((R + kTile - 1) / kTile), N, db, stream);
 }

@@ -52,7 +52,7 @@ class _Base(nn.Module):
             m.reset_parameters()
         self.lt1.reset_parameters()
 
-    def _first_layer_dedup(self, x_table, edge_index, x_index):
+    def _first_layer_dedup(self, x_table, edge_index, x_index, link_out=None):
         """Layer 0 on a de-duplicated feature table (x_index: ops.RowIndex mapping union rows to table rows)."""
         conv = self.conv[0]
         if not (isinstance(conv, fnn.GCNConv) and x_table.is_cuda):
@@ -61,7 +61,7 @@ class _Base(nn.Module):
         g = conv.graph(edge_index, int(x_index.index.numel()))
         seed = ops.next_seed() if (self.training and self.dropout_p > 0 and mask is None) else 0
         return ops.FusedGCNLayerDedup.apply(x_table.float(), conv.lin.weight, conv.bias, g, x_index, float(self.dropout_p),
-                                            bool(self.training), seed, mask)
+                                            bool(self.training), seed, mask, link_out)
 
     def embed(self, x, edge_index, x_index=None, first=0):
         x = x.float()
@@ -86,28 +86,39 @@ class _Base(nn.Module):
         if out_rows is not None:
             return self._embed_and_head_rows(x, edge_index, x_index, out_rows)
         first = 0
+        last = self.conv[L - 1] if L > 0 else None
+        fused_tail = L > 0 and x.is_cuda and isinstance(last, fnn.GCNConv) and self.lt1.out_features <= ops.head_max_classes()
+        # the conv stack is strictly sequential (network.py:29-33): consecutive fused GCN layers share an EpilogueLink, so
+        # that the backward GEMM dH @ W of layer i+1 applies layer i's ELU'/dropout' in its epilogue
+        link = ops.EpilogueLink() if (fused_tail and L > 1) else None
         if x_index is not None:
-            h = self._first_layer_dedup(x, edge_index, x_index) if L > 1 else None
+            h = self._first_layer_dedup(x, edge_index, x_index, link_out=link) if L > 1 else None
             if h is None:
                 x = x.index_select(0, x_index.index.long())  # materialise the union rows
+                link = None
             else:
                 x, first = h, 1
-        last = self.conv[L - 1] if L > 0 else None
-        if not (L > 0 and x.is_cuda and isinstance(last, fnn.GCNConv) and self.lt1.out_features <= ops.head_max_classes()):
+        else:
+            link = None
+        if not fused_tail:
             return self.head(self.embed(x, edge_index, first=first))
         x = x.float()
         for i in range(first, L - 1):
             conv = self.conv[i]
             if isinstance(conv, fnn.GCNConv):
                 mask = self._inject_masks[i] if self._inject_masks is not None else None
-                x = conv.forward_elu_dropout(x, edge_index, p=self.dropout_p, training=self.training, mask=mask)
+                nxt = ops.EpilogueLink()
+                x = conv.forward_elu_dropout(x, edge_index, p=self.dropout_p, training=self.training, mask=mask, link_in=link,
+                                             link_out=nxt)
+                link = nxt
             else:
                 x = F.dropout(F.elu(conv(x, edge_index)), p=self.dropout_p, training=self.training)
+                link = None
         mask = self._inject_masks[L - 1] if self._inject_masks is not None else None
         g = last.graph(edge_index, x.shape[0])
         seed = ops.next_seed() if (self.training and self.dropout_p > 0 and mask is None) else 0
         return ops.FusedGCNLayerHead.apply(x, last.lin.weight, last.bias, self.lt1.weight, self.lt1.bias, g,
-                                           float(self.dropout_p), bool(self.training), seed, mask)
+                                           float(self.dropout_p), bool(self.training), seed, mask, link)
 
     def _embed_and_head_rows(self, x, edge_index, x_index, sub):
         L = self.num_layers

@@ -45,11 +45,13 @@ class GCNConv(nn.Module):
         h = ops.Linear.apply(x.float(), self.lin.weight)
         return ops.SpMM.apply(h, self.bias, g)
 
-    def forward_elu_dropout(self, x, edge_index, p=0.5, training=False, mask=None, graph=None):
-        """conv -> F.elu -> F.dropout (network.py:31-33) as one GEMM + one SpMM with fused epilogue."""
+    def forward_elu_dropout(self, x, edge_index, p=0.5, training=False, mask=None, graph=None, link_in=None, link_out=None):
+        """conv -> F.elu -> F.dropout (network.py:31-33) as one GEMM + one SpMM with fused epilogue.
+        link_in / link_out (ops.EpilogueLink): x is the un-shared output of the previous fused layer / the output goes to
+        exactly one next fused layer (sequential stacks only, see ops.EpilogueLink)."""
         g = graph if graph is not None else self.graph(edge_index, x.shape[0])
         seed = ops.next_seed() if (training and p > 0 and mask is None) else 0
-        return ops.FusedGCNLayer.apply(x, self.lin.weight, self.bias, g, float(p), bool(training), seed, mask)
+        return ops.FusedGCNLayer.apply(x, self.lin.weight, self.bias, g, float(p), bool(training), seed, mask, link_in, link_out)
 
     def extra_repr(self):
         return f"{self.in_channels}, {self.out_channels}"

@@ -96,6 +96,24 @@ def gemm_nt(a, b):
     return out
 
 
+def gemm_nt_epilogue_bwd(a, b, out, epilogue, p=0.0, seed=0, mask=None, want_db=True):
+    """(dZ, db) with dOut = a @ b^T formed inside the GEMM and transformed in its epilogue (csrc/gemm_nt.hip, EPI):
+    what mm + epilogue_bwd_raw compute, without the [R x N] round trip of dOut."""
+    _lib.require_cuda(a, b, out, mask)
+    L = _lib.lib()
+    R, K, N = a.shape[0], a.shape[1], b.shape[0]
+    seed, epilogue = _seed_arg(seed, epilogue)
+    dZ = torch.empty((R, N), dtype=torch.float32, device=a.device)
+    db = torch.empty(N, dtype=torch.float32, device=a.device) if want_db else None
+    wb = int(L.fitgnn_gemm_nt_epilogue_bwd_workspace_bytes(R, N))
+    work = torch.empty(max(wb, 4), dtype=torch.uint8, device=a.device)
+    rc = L.fitgnn_gemm_nt_epilogue_bwd_f32(_lib.dptr(a), a.stride(0), _lib.dptr(b), b.stride(0), R, N, K, _lib.dptr(out),
+                                           _lib.dptr(dZ), epilogue, float(p), seed, _lib.dptr(mask), _lib.dptr(db),
+                                           _lib.dptr(work), wb, _lib.stream_ptr(a.device))
+    _lib.check(rc, "fitgnn_gemm_nt_epilogue_bwd_f32")
+    return dZ, db
+
+
 def mm_at_b(a, b):
     """a^T @ b for tall operands a [R, M], b [R, N] (the weight-gradient product dH^T @ X, reduction over all R
     rows).  hipBLASLt serves this huge-K / small-MN shape poorly as one GEMM (541 us for R = 90k, M = N = 512); as a
@@ -385,12 +403,55 @@ class SpMMRows(torch.autograd.Function):
         return spmm_raw(t.rowptr, t.col, t.val, t.tiles, _f32c(dY), ctx.sub.n, window_rows=ctx.sub.window_rows), None
 
 
+# dX = dH @ W of a layer whose input is the fused output of the previous layer: let the GEMM's epilogue apply that layer's
+# ELU'/dropout' (csrc/gemm_nt.hip, EPI) instead of writing dOut and running the epilogue-backward kernel over it
+FUSE_DX_EPILOGUE = True
+
+
+class EpilogueLink:
+    """Connects a fused layer (producer of out = dropout(ELU(z))) with the ONE layer that consumes `out` as its input.
+    The producer's forward records its epilogue here; the consumer's backward (which runs first) may then return
+    dZ = epilogue'(dOut) in place of dOut, with the bias gradient, and marks the link; the producer's backward skips its
+    own epilogue-backward kernel.  Only for strictly sequential stacks (network.py:29-33): `out` must have no other
+    consumer, since what travels through autograd on this edge is no longer the plain gradient."""
+    __slots__ = ("epi", "p", "seed", "mask", "want_db", "fused", "db")
+
+    def __init__(self):
+        self.epi, self.p, self.seed, self.mask, self.want_db, self.fused, self.db = 0, 0.0, 0, None, False, False, None
+
+    def record(self, drop, p, seed, mask, want_db):
+        self.epi = EPI_ELU | (EPI_DROPOUT if drop else 0)
+        self.p, self.seed, self.mask, self.want_db = (p if drop else 0.0), seed, (mask if drop else None), bool(want_db)
+        self.fused, self.db = False, None
+
+
+def _dx_through_link(link, dH, W, X):
+    """dX for the consumer of a linked layer: (tensor to return as the input gradient)."""
+    if link is not None and FUSE_DX_EPILOGUE and W.shape[1] % 4 == 0 and X.is_contiguous() and X.dtype == torch.float32:
+        Wt = W.t().contiguous()
+        dH = _f32c(dH)
+        if _nt_ok(dH, Wt):
+            dZ, db = gemm_nt_epilogue_bwd(dH, Wt, X, link.epi, p=link.p, seed=link.seed, mask=link.mask, want_db=link.want_db)
+            link.fused, link.db = True, db
+            return dZ
+    return mm_by_transposed(dH, W)
+
+
+def _producer_backward(link, g, out, epi, p, seed, mask, has_bias, dOut):
+    """(dH, db) of a fused layer: through the link when its consumer already applied the epilogue's derivative."""
+    if link is not None and link.fused:
+        db, link.fused, link.db = link.db, False, None
+        return spmm_graph(g, _f32c(dOut), transposed=True), db
+    dH, db, _ = layer_backward(g, out, epi, p, seed, mask, has_bias, dOut=dOut)
+    return dH, db
+
+
 class FusedGCNLayer(torch.autograd.Function):
     """out = dropout(ELU(A_hat (X W^T) + b)): GCNConv (network.py:31) + F.elu (:32) + F.dropout (:33) as
     one GEMM + one SpMM with fused epilogue.  `mask` (uint8 [N,H]) injects a dropout pattern for tests."""
 
     @staticmethod
-    def forward(ctx, X, W, b, g, p, training, seed, mask):
+    def forward(ctx, X, W, b, g, p, training, seed, mask, link_in=None, link_out=None):
         X = _f32c(X)
         Hm = mm_xwt(X, W)
         epi = EPI_ELU | (EPI_BIAS if b is not None else 0)
@@ -400,6 +461,9 @@ class FusedGCNLayer(torch.autograd.Function):
         out = spmm_graph(g, Hm, bias=b, epilogue=epi, p=p if drop else 0.0, seed=seed, mask=mask if drop else None)
         ctx.save_for_backward(X, W, out, mask if drop else None)
         ctx.g, ctx.p, ctx.drop, ctx.seed, ctx.has_bias = g, p, drop, seed, b is not None
+        ctx.link_in, ctx.link_out = link_in, link_out
+        if link_out is not None:
+            link_out.record(drop, p, seed, mask, b is not None)
         return out
 
     @staticmethod
@@ -407,10 +471,10 @@ class FusedGCNLayer(torch.autograd.Function):
         X, W, out, mask = ctx.saved_tensors
         g = ctx.g
         epi = EPI_ELU | (EPI_DROPOUT if ctx.drop else 0)
-        dH, db, _ = layer_backward(g, out, epi, ctx.p if ctx.drop else 0.0, ctx.seed, mask, ctx.has_bias, dOut=dOut)
+        dH, db = _producer_backward(ctx.link_out, g, out, epi, ctx.p if ctx.drop else 0.0, ctx.seed, mask, ctx.has_bias, dOut)
         dW = mm_at_b(dH, X) if ctx.needs_input_grad[1] else None
-        dX = mm_by_transposed(dH, W) if ctx.needs_input_grad[0] else None
-        return dX, dW, (db if ctx.has_bias else None), None, None, None, None, None
+        dX = _dx_through_link(ctx.link_in, dH, W, X) if ctx.needs_input_grad[0] else None
+        return dX, dW, (db if ctx.has_bias else None), None, None, None, None, None, None, None
 
 
 class FusedGCNLayerHead(torch.autograd.Function):
@@ -421,8 +485,9 @@ class FusedGCNLayerHead(torch.autograd.Function):
     the epilogue-backward kernel forms it on the fly.  Requires num_classes <= fitgnn_head_max_classes()."""
 
     @staticmethod
-    def forward(ctx, X, W, b, Wl, bl, g, p, training, seed, mask):
+    def forward(ctx, X, W, b, Wl, bl, g, p, training, seed, mask, link_in=None):
         X = _f32c(X)
+        ctx.link_in = link_in
         Hm = mm_xwt(X, W)
         epi = EPI_ELU | (EPI_BIAS if b is not None else 0)
         drop = bool(training) and p > 0.0
@@ -448,8 +513,8 @@ class FusedGCNLayerHead(torch.autograd.Function):
         # tall 3-column matrix takes 50 us, this 10)
         dbl = dy.t().contiguous().sum(1) if ctx.has_bl and ctx.needs_input_grad[4] else None
         dW = mm_at_b(dH, X) if ctx.needs_input_grad[1] else None
-        dX = mm_by_transposed(dH, W) if ctx.needs_input_grad[0] else None
-        return dX, dW, (db if ctx.has_bias else None), dWl, dbl, None, None, None, None, None
+        dX = _dx_through_link(ctx.link_in, dH, W, X) if ctx.needs_input_grad[0] else None
+        return dX, dW, (db if ctx.has_bias else None), dWl, dbl, None, None, None, None, None, None
 
 
 class FusedGCNLayerDedup(torch.autograd.Function):
@@ -459,8 +524,9 @@ class FusedGCNLayerDedup(torch.autograd.Function):
     (fitgnn_segment_sum_f32) before the weight-gradient GEMM.  Same arithmetic as FusedGCNLayer on X_union."""
 
     @staticmethod
-    def forward(ctx, Xt, W, b, g, ridx, p, training, seed, mask):
+    def forward(ctx, Xt, W, b, g, ridx, p, training, seed, mask, link_out=None):
         Xt = _f32c(Xt)
+        ctx.link_out = link_out
         Ht = mm_xwt(Xt, W)  # [N0, H]
         epi = EPI_ELU | (EPI_BIAS if b is not None else 0)
         drop = bool(training) and p > 0.0
@@ -470,6 +536,8 @@ class FusedGCNLayerDedup(torch.autograd.Function):
                          xrow=ridx.index)
         ctx.save_for_backward(Xt, W, out, mask if drop else None)
         ctx.g, ctx.ridx, ctx.p, ctx.drop, ctx.seed, ctx.has_bias = g, ridx, p, drop, seed, b is not None
+        if link_out is not None:
+            link_out.record(drop, p, seed, mask, b is not None)
         return out
 
     @staticmethod
@@ -477,11 +545,11 @@ class FusedGCNLayerDedup(torch.autograd.Function):
         Xt, W, out, mask = ctx.saved_tensors
         g, ridx = ctx.g, ctx.ridx
         epi = EPI_ELU | (EPI_DROPOUT if ctx.drop else 0)
-        dH, db, _ = layer_backward(g, out, epi, ctx.p if ctx.drop else 0.0, ctx.seed, mask, ctx.has_bias, dOut=dOut)  # [R, H]
+        dH, db = _producer_backward(ctx.link_out, g, out, epi, ctx.p if ctx.drop else 0.0, ctx.seed, mask, ctx.has_bias, dOut)  # [R, H]
         dHt = segment_sum(ridx.seg_off, ridx.members, dH, ridx.n_table)  # [N0, H] per original node
         dW = mm_at_b(dHt, Xt) if ctx.needs_input_grad[1] else None
         dXt = mm(dHt, W) if ctx.needs_input_grad[0] else None
-        return dXt, dW, (db if ctx.has_bias else None), None, None, None, None, None, None
+        return dXt, dW, (db if ctx.has_bias else None), None, None, None, None, None, None, None
 
 
 _seed_state = [0x1234ABCD]

@@ -137,6 +137,18 @@ int fitgnn_gemm_atb_f32(const float *a, int64_t lda, const float *b, int64_t ldb
 int fitgnn_gemm_nt_f32(const float *a, int64_t lda, const float *b, int64_t ldb, int64_t R, int32_t N, int32_t K,
                        float *c, int64_t ldc, void *stream);
 
+/* The same product taken as the gradient dOut of a fused layer output out = dropout(ELU(z)) (network.py:32-33), with
+ * fitgnn_epilogue_bwd_f32's transformation applied to the accumulators before they are stored:
+ *   dZ [R x N] = keep ? (a @ b^T) / (1 - p) * (o > 0 ? 1 : o + 1) : 0,  o = out * (1 - p);  db[n] = sum_rows dZ (may be NULL).
+ * dOut itself is never written.  out, dZ and mask are contiguous [R x N]; flags/seed/mask as in the forward. */
+size_t fitgnn_gemm_nt_epilogue_bwd_workspace_bytes(int64_t R, int32_t N);
+int fitgnn_gemm_nt_epilogue_bwd_f32(const float *a, int64_t lda, const float *b, int64_t ldb, int64_t R, int32_t N, int32_t K,
+                                    const float *out, float *dZ, uint32_t epilogue, float p_drop, uint64_t seed,
+                                    const uint8_t *mask, float *db, void *work, size_t work_bytes, void *stream);
+
+/* out[h] = sum over c < n_chunks of partial[c][h] in a fixed order (the second pass of the bias-gradient reductions). */
+int fitgnn_colsum_partials_f32(const float *partial, int32_t n_chunks, int32_t H, float *out, void *stream);
+
 /* loss[0] = scale * sum_t NLL(log_softmax(z[idx[t]]), labels[t]) over n selected rows (Classify_node's log_softmax,
  * network.py:35, followed by NLLLoss, run.py:341; scale = 1/n for reduction='mean', 1/global count under data
  * parallelism), and dz [n_rows x ldz] = its gradient w.r.t. the logits z (zero on rows that are not selected).

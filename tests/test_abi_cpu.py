@@ -75,3 +75,12 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 txt = open(os.path.join(d, f)).read()
                 assert "oracle" not in txt.replace("no oracle", ""), f"{f} mentions the oracle"
+
+
+def test_fused_gemm_epilogue_entry_points():
+    L = _lib.lib()
+    assert L.fitgnn_gemm_nt_epilogue_bwd_workspace_bytes(90549, 512) == 354 * 512 * 4   # one partial row per 256-row tile
+    assert L.fitgnn_gemm_nt_epilogue_bwd_workspace_bytes(0, 512) == 0
+    # too small a workspace and N % 4 != 0 are refused before any launch
+    assert L.fitgnn_gemm_nt_epilogue_bwd_f32(None, 64, None, 64, 100, 8, 64, None, None, 0, 0.0, 0, None, None, None, 0, None) == -1
+    assert L.fitgnn_colsum_partials_f32(None, 1, 8, None, None) == -1

@@ -472,3 +472,58 @@ def test_graph_trainer_reshuffle_option(mods):
     assert not torch.equal(seen[0], seen[1])                                    # a different order ...
     assert torch.equal(seen[0].sort().values, seen[1].sort().values)            # ... of the same graphs
     assert losses[-1] < losses[0]
+
+
+@pytest.mark.parametrize("layers,dedup", [(2, False), (3, False), (2, True)])
+@pytest.mark.parametrize("inject", [True, False])
+def test_dx_gemm_with_the_previous_layers_epilogue(mods, layers, dedup, inject):
+    """Consecutive fused GCN layers: the backward GEMM dH @ W applies the previous layer's ELU'/dropout' in its epilogue
+    (ops.EpilogueLink, csrc/gemm_nt.hip EPI).  Same gradients as the two-kernel path and as the oracle."""
+    network, fnn, gorc = mods
+    from fitgnn_amd import ops
+
+    n = 1500   # the GEMM kernels take over from 1024 rows
+    ei, n = graph(n=n, m=4500, seed=31)
+    args = argparse.Namespace(num_layers1=layers, layer_name="GCNConv", num_features=64, hidden=128, num_classes=5)
+    torch.manual_seed(9)
+    model = network.Classify_node(args).cuda().train()
+    x = torch.rand(n, 64)
+    y = torch.randint(0, 5, (n,))
+    masks = [(torch.rand(n, 128) > 0.5).to(torch.uint8) for _ in range(layers)]
+    ridx = None
+    xin = x.cuda()
+    if dedup:
+        N0 = 400
+        idx = torch.randint(0, N0, (n,)); idx[:N0] = torch.arange(N0)
+        xt = torch.rand(N0, 64)
+        x, xin, ridx = xt[idx], xt.cuda(), ops.RowIndex(idx.cuda(), N0)
+    calls = []
+    real = ops.gemm_nt_epilogue_bwd
+
+    def counting(*a, **k):
+        calls.append(1)
+        return real(*a, **k)
+
+    grads = {}
+    for fuse in (True, False):
+        ops.FUSE_DX_EPILOGUE, ops.gemm_nt_epilogue_bwd = fuse, counting
+        try:
+            model.zero_grad()
+            if inject:
+                model._inject_masks = [m.cuda() for m in masks]
+            else:
+                model._inject_masks = None
+                torch.manual_seed(777)   # ops.next_seed draws from torch's generator: same dropout stream in both runs
+            out = model(xin, ei.cuda(), x_index=ridx) if dedup else model(xin, ei.cuda())
+            torch.nn.functional.nll_loss(out, y.cuda()).backward()
+            grads[fuse] = {k: p.grad.clone() for k, p in model.named_parameters()}
+        finally:
+            ops.FUSE_DX_EPILOGUE, ops.gemm_nt_epilogue_bwd = True, real
+    assert len(calls) == layers - 1, "one fused GEMM per linked pair of layers, none with the switch off"
+    for k in grads[True]:
+        assert rel(grads[True][k].cpu(), grads[False][k].cpu()) < 1e-6, k
+    if inject:
+        sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+        _, _, g_ref = gorc.classify_node_fwd_bwd(sd, x, ei, y, num_layers=layers, train_mask=torch.ones(n, dtype=torch.bool), masks=masks)
+        for k, p in model.named_parameters():
+            assert rel(grads[True][k].cpu(), g_ref[k]) < 1e-3, k
