@@ -213,8 +213,10 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.workload}: variation_neighborhoods r={WORKLOADS[args.workload][4]}, extra-node subgraphs, one block-diagonal "
                                f"union per GPU, 2-layer GCN hidden {H}, GD step + Adam", "parallelism": f"dp{world}",
-                   "dense_gemm": ("hipBLASLt fp32 operands, 3xbf16-split MFMA for X@W^T and dH@W (rel err ~5e-6 vs fp64), "
-                                  "dH^T@X as a split-K batched GEMM of the same precision + fixed-order sum") if args.gemm_precision == "high" else "hipBLASLt fp32 MFMA",
+                   "dense_gemm": ("fp32 operands split to 3 bf16 products on the MFMA pipe, fp32 accumulate (rel err ~5e-6 vs fp64): "
+                                  "hand-written kernels gemm_nt.hip (X@W^T, dH@W with the previous layer's epilogue backward fused) and "
+                                  "gemm_atb.hip (dH^T@X, split-K with a fixed-order sum); library GEMM only where K % 32 != 0 or the "
+                                  "output is a few columns wide") if args.gemm_precision == "high" else "hipBLASLt fp32 MFMA",
                    "layer0_features": f"de-duplicated table ({info['nodes']} rows) + row indirection in the SpMM" if trainer.dedup
                    else "materialised union rows",
                    **info},
