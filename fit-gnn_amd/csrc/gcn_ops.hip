@@ -239,6 +239,40 @@ __global__ __launch_bounds__(256) void sum_leading_kernel(const float4 *__restri
                          (s[0].z + s[1].z) + (s[2].z + s[3].z), (s[0].w + s[1].w) + (s[2].w + s[3].w));
 }
 
+// Column sums of a tall matrix with a few columns (the head's bias gradient, sum over rows of dy [rows x classes]):
+// block b sums rows [b * rows_per_block, ...) -- thread t takes rows t, t + 256, ... of the range, then a fixed tree
+// over the 256 threads -- into partial[b][C]; colsum_partials_kernel adds the blocks.  C <= kNarrowMaxC.
+constexpr int kNarrowMaxC = 16;
+__global__ __launch_bounds__(256) void narrow_colsum_kernel(const float *__restrict__ x, int64_t ldx, int32_t n_rows, int32_t C,
+                                                            int32_t rows_per_block, float *__restrict__ partial) {
+    __shared__ float red[256];
+    float acc[kNarrowMaxC];
+#pragma unroll
+    for (int c = 0; c < kNarrowMaxC; ++c) acc[c] = 0.f;
+    const int r0 = blockIdx.x * rows_per_block;
+    const int r1 = min(r0 + rows_per_block, n_rows);
+    for (int r = r0 + (int)threadIdx.x; r < r1; r += 256) {
+        const float *xr = x + (int64_t)r * ldx;
+#pragma unroll
+        for (int c = 0; c < kNarrowMaxC; ++c)
+            if (c < C) acc[c] += xr[c];
+    }
+    for (int c = 0; c < C; ++c) {
+        float v = 0.f;
+#pragma unroll
+        for (int k = 0; k < kNarrowMaxC; ++k)
+            if (k == c) v = acc[k];
+        red[threadIdx.x] = v;
+        __syncthreads();
+        for (int w = 128; w >= 1; w >>= 1) {
+            if ((int)threadIdx.x < w) red[threadIdx.x] = red[threadIdx.x] + red[threadIdx.x + w];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) partial[(int64_t)blockIdx.x * C + c] = red[0];
+        __syncthreads();
+    }
+}
+
 // torch.optim.Adam (amsgrad=False, maximize=False) over one flat parameter buffer: g += wd * p (L2, as torch's
 // weight_decay), m = b1 m + (1-b1) g, v = b2 v + (1-b2) g^2, p -= (lr / (1-b1^t)) * m / (sqrt(v) / sqrt(1-b2^t) + eps).
 // `step` is a device counter (float, as torch keeps it) advanced by thread 0: the update can sit in a captured graph.
@@ -339,6 +373,27 @@ extern "C" int fitgnn_adam_step_f32(float *param, const float *grad, float *exp_
     hipLaunchKernelGGL(adam_flat_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, (float4 *)param, (const float4 *)grad,
                        (float4 *)exp_avg, (float4 *)exp_avg_sq, n4, lr, beta1, beta2, eps, weight_decay, step);
     hipLaunchKernelGGL(adam_step_advance_kernel, dim3(1), dim3(1), 0, s, step);
+    return (int)hipGetLastError();
+}
+
+extern "C" size_t fitgnn_colsum_narrow_workspace_bytes(int32_t n_rows, int32_t C) {
+    if (n_rows <= 0 || C <= 0) return 0;
+    const int blocks = std::min(256, (n_rows + 255) / 256);
+    return (size_t)blocks * C * sizeof(float);
+}
+
+extern "C" int fitgnn_colsum_narrow_f32(const float *x, int64_t ldx, int32_t n_rows, int32_t C, float *out, void *work,
+                                        size_t work_bytes, void *stream) {
+    if (n_rows < 0 || C < 1 || C > kNarrowMaxC || ldx < C || !out) return FITGNN_E_BADARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (n_rows == 0) return (int)hipMemsetAsync(out, 0, (size_t)C * sizeof(float), s);
+    if (!x || !work) return FITGNN_E_BADARG;
+    if (work_bytes < fitgnn_colsum_narrow_workspace_bytes(n_rows, C)) return FITGNN_E_WORKSPACE;
+    const int blocks = std::min(256, (n_rows + 255) / 256);
+    const int rows_per_block = (n_rows + blocks - 1) / blocks;
+    hipLaunchKernelGGL(narrow_colsum_kernel, dim3(blocks), dim3(256), 0, s, x, ldx, n_rows, C, rows_per_block, (float *)work);
+    hipLaunchKernelGGL(colsum_partials_kernel, dim3((C + kColsumCols - 1) / kColsumCols), dim3(kColsumPhases * kColsumCols), 0, s,
+                       (const float *)work, blocks, C, out);
     return (int)hipGetLastError();
 }
 

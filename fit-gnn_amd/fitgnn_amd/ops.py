@@ -163,6 +163,20 @@ class Linear(torch.autograd.Function):
         return dx, dW
 
 
+def colsum_narrow(x):
+    """Column sums of a tall [rows, C <= 16] matrix (the head's bias gradient) through fitgnn_colsum_narrow_f32."""
+    if not (x.is_cuda and x.dim() == 2 and x.shape[1] <= 16 and x.dtype == torch.float32 and x.stride(1) == 1):
+        return x.sum(0)
+    L = _lib.lib()
+    n, C = x.shape
+    out = torch.empty(C, dtype=torch.float32, device=x.device)
+    wb = int(L.fitgnn_colsum_narrow_workspace_bytes(n, C))
+    work = torch.empty(max(wb, 4), dtype=torch.uint8, device=x.device)
+    _lib.check(L.fitgnn_colsum_narrow_f32(_lib.dptr(x), x.stride(0), n, C, _lib.dptr(out), _lib.dptr(work), wb,
+                                          _lib.stream_ptr(x.device)), "fitgnn_colsum_narrow_f32")
+    return out
+
+
 class SmallLinear(torch.autograd.Function):
     """y = x W^T + b for a narrow output (lt1: hidden -> classes, network.py:34).  nn.Linear's addmm picks a 340 us
     kernel for [90k x 512] @ [512 x 3]; mm + a broadcast add is 10x faster.  Same arithmetic."""
@@ -180,7 +194,7 @@ class SmallLinear(torch.autograd.Function):
         # dy^T x is [classes x rows] @ [rows x hidden]: the library's kernel for that shape takes 340 us on a 90 k-row batch,
         # the split-K batched product 20
         dW = mm_at_b(_f32c(dy), _f32c(x)) if ctx.needs_input_grad[1] else None
-        db = dy.t().contiguous().sum(1) if ctx.needs_input_grad[2] else None
+        db = colsum_narrow(dy) if ctx.needs_input_grad[2] else None
         return dx, dW, db
 
 
@@ -509,9 +523,9 @@ class FusedGCNLayerHead(torch.autograd.Function):
         epi = EPI_ELU | (EPI_DROPOUT if ctx.drop else 0)
         dH, db, dWl = layer_backward(g, out, epi, ctx.p if ctx.drop else 0.0, ctx.seed, mask, ctx.has_bias, dy=dy, Wl=Wl,
                                      want_dWl=ctx.needs_input_grad[3])
-        # [R, C] column sums: reduce over the contiguous axis of the transposed copy (torch's dim-0 reduction of a
-        # tall 3-column matrix takes 50 us, this 10)
-        dbl = dy.t().contiguous().sum(1) if ctx.has_bl and ctx.needs_input_grad[4] else None
+        # [R, C] column sums: torch's dim-0 reduction of a tall 3-column matrix takes 50 us, a transposed copy + dim-1
+        # reduction 23, the two-pass kernel 9
+        dbl = colsum_narrow(dy) if ctx.has_bl and ctx.needs_input_grad[4] else None
         dW = mm_at_b(dH, X) if ctx.needs_input_grad[1] else None
         dX = _dx_through_link(ctx.link_in, dH, W, X) if ctx.needs_input_grad[0] else None
         return dX, dW, (db if ctx.has_bias else None), dWl, dbl, None, None, None, None, None, None

@@ -354,3 +354,13 @@ def test_linear_gemm_is_the_default_path_and_differentiates(mods):
     xd, Wd = x.detach().double(), W.detach().double()
     assert float((x.grad - gy.double() @ Wd).abs().max()) < 2e-5 * float((gy.double() @ Wd).abs().max())
     assert float((W.grad - gy.double().t() @ xd).abs().max()) < 2e-5 * float((gy.double().t() @ xd).abs().max())
+
+
+@pytest.mark.parametrize("n,C,wide", [(90549, 3, 0), (1000, 16, 4), (255, 1, 0), (257, 7, 1), (1, 5, 0)])
+def test_narrow_column_sums(mods, n, C, wide):
+    _lib, csr, ops, orc, gorc = mods
+    x = torch.randn(n, C + wide).cuda()[:, :C]
+    got = ops.colsum_narrow(x)
+    ref = x.double().sum(0)
+    assert float((got - ref).abs().max()) < 1e-5 * max(1.0, float(ref.abs().max())) * (n ** 0.5)
+    assert torch.equal(got, ops.colsum_narrow(x))
