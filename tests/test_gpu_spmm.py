@@ -364,3 +364,26 @@ def test_narrow_column_sums(mods, n, C, wide):
     ref = x.double().sum(0)
     assert float((got - ref).abs().max()) < 1e-5 * max(1.0, float(ref.abs().max())) * (n ** 0.5)
     assert torch.equal(got, ops.colsum_narrow(x))
+
+
+def test_gemm_kernels_inside_a_captured_graph(mods):
+    """MBTrainer / GraphTrainer capture whole steps in hipGraphs: the GEMM launchers (which raise the dynamic-LDS limit of
+    their kernels on every call) must be capturable and replay to the same bits."""
+    _lib, csr, ops, orc, gorc = mods
+    a = torch.randn(4096, 128).cuda(); b = torch.randn(4096, 192).cuda(); w = torch.randn(192, 128).cuda()
+    out = torch.randn(4096, 192).cuda()
+    epi = _lib.EPI_ELU | _lib.EPI_DROPOUT
+    eager = (ops.gemm_atb(a, b), ops.gemm_nt(a, w), *ops.gemm_nt_epilogue_bwd(a, w, out, epi, p=0.5, seed=99))
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):   # warm-up on the capture stream, as torch requires
+        ops.gemm_atb(a, b); ops.gemm_nt(a, w); ops.gemm_nt_epilogue_bwd(a, w, out, epi, p=0.5, seed=99)
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        cap = (ops.gemm_atb(a, b), ops.gemm_nt(a, w), *ops.gemm_nt_epilogue_bwd(a, w, out, epi, p=0.5, seed=99))
+    for _ in range(2):
+        g.replay()
+    torch.cuda.synchronize()
+    for e, c in zip(eager, cap):
+        assert torch.equal(e, c)
