@@ -8,6 +8,8 @@ as PyTorch-ROCm custom ops").  Importing this module registers
     fitgnn::pool_rows(assign, cval, n, X) -> Xc
     fitgnn::variation_costs(rowptr, col, w?, dw, A, set_off, set_mem) -> cost
     fitgnn::lift_adjacency(rowptr, col, w, assign, cval, n) -> (rowptr_c, col_c, w_c)
+    fitgnn::gemm_nt(a, b) -> a @ b^T          fitgnn::gemm_atb(a, b) -> a^T @ b      (3 x bf16 MFMA kernels, fp32 in/out)
+    fitgnn::linear(x, W) -> x @ W^T           differentiable: dX = gemm_nt(dY, W^T), dW = gemm_atb(dY, x)
 
 for the CUDA (HIP) dispatch key only -- there is no CPU kernel, a CPU tensor fails in the dispatcher -- with fake
 (meta) kernels for shape inference and an autograd formula for spmm_csr over a pair of forward / transposed
@@ -27,6 +29,9 @@ _LIB.define("epilogue_bwd(Tensor dOut, Tensor out, int epilogue, float p, int se
 _LIB.define("pool_rows(Tensor assign, Tensor cval, int n, Tensor X) -> Tensor")
 _LIB.define("variation_costs(Tensor rowptr, Tensor col, Tensor? w, Tensor dw, Tensor A, Tensor set_off, Tensor set_mem) -> Tensor")
 _LIB.define("lift_adjacency(Tensor rowptr, Tensor col, Tensor w, Tensor assign, Tensor cval, int n) -> (Tensor, Tensor, Tensor)")
+_LIB.define("gemm_nt(Tensor a, Tensor b) -> Tensor")
+_LIB.define("gemm_atb(Tensor a, Tensor b) -> Tensor")
+_LIB.define("linear(Tensor x, Tensor W) -> Tensor")
 
 
 def _spmm_csr(rowptr, col, val, X, tiles, window_rows, bias, epilogue, p, seed, mask):
@@ -78,7 +83,17 @@ def _lift_adjacency(rowptr, col, w, assign, cval, n):
             torch.from_numpy(Wc.data).to(dev))
 
 
-for _name, _fn in (("spmm_csr", _spmm_csr), ("spmm_csr_pair", _spmm_csr_pair), ("gcn_norm_csr", _gcn_norm_csr),
+def _gemm_nt(a, b):
+    _lib.require_cuda(a, b)
+    return ops.gemm_nt(a.contiguous(), b.contiguous())
+
+
+def _gemm_atb(a, b):
+    _lib.require_cuda(a, b)
+    return ops.gemm_atb(a.contiguous(), b.contiguous())
+
+
+for _name, _fn in (("gemm_nt", _gemm_nt), ("gemm_atb", _gemm_atb), ("linear", _gemm_nt), ("spmm_csr", _spmm_csr), ("spmm_csr_pair", _spmm_csr_pair), ("gcn_norm_csr", _gcn_norm_csr),
                    ("epilogue_bwd", _epilogue_bwd), ("pool_rows", _pool_rows), ("variation_costs", _variation_costs),
                    ("lift_adjacency", _lift_adjacency)):
     _LIB.impl(_name, _fn, "CUDA")
@@ -113,6 +128,36 @@ def _(assign, cval, n, X):
 @torch.library.register_fake("fitgnn::variation_costs")
 def _(rowptr, col, w, dw, A, set_off, set_mem):
     return A.new_empty((set_off.shape[0] - 1,), dtype=torch.float64)
+
+
+@torch.library.register_fake("fitgnn::gemm_nt")
+def _(a, b):
+    return a.new_empty((a.shape[0], b.shape[0]))
+
+
+@torch.library.register_fake("fitgnn::gemm_atb")
+def _(a, b):
+    return a.new_empty((a.shape[1], b.shape[1]))
+
+
+@torch.library.register_fake("fitgnn::linear")
+def _(x, W):
+    return x.new_empty((x.shape[0], W.shape[0]))
+
+
+def _linear_setup(ctx, inputs, output):
+    ctx.save_for_backward(*inputs)
+
+
+def _linear_backward(ctx, dY):
+    x, W = ctx.saved_tensors
+    dY = dY.contiguous()
+    dX = torch.ops.fitgnn.gemm_nt(dY, W.t().contiguous()) if ctx.needs_input_grad[0] else None
+    dW = torch.ops.fitgnn.gemm_atb(dY, x) if ctx.needs_input_grad[1] else None
+    return dX, dW
+
+
+torch.library.register_autograd("fitgnn::linear", _linear_backward, setup_context=_linear_setup)
 
 
 # ---- autograd: d/dX of Y = A X is A^T dY -- the same kernel on the transposed pattern ----

@@ -282,6 +282,19 @@ def test_torch_ops_namespace(mods):
     Xc = torch.ops.fitgnn.pool_rows(assign, cval, 2, Xs)
     ref = torch.stack([(Xs[:2].double() * 2 ** -0.5).sum(0), (Xs[2:].double() * 3 ** -0.5).sum(0)]).float()
     assert torch.allclose(Xc, ref, rtol=1e-6)
+    # the GEMM kernels: a differentiable linear layer whose three products all run on them
+    x = torch.randn(2048, 96, device="cuda", requires_grad=True)
+    W = torch.randn(160, 96, device="cuda", requires_grad=True)
+    y = torch.ops.fitgnn.linear(x, W)
+    assert torch.equal(y, ops.gemm_nt(x.detach(), W.detach()))
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    assert torch.equal(W.grad, ops.gemm_atb(gy, x.detach()))
+    assert float((x.grad - gy.double() @ W.detach().double()).abs().max()) < 2e-5 * float((gy.double() @ W.detach().double()).abs().max())
+    with torch.device("meta"):
+        assert torch.ops.fitgnn.gemm_atb(torch.empty(64, 8), torch.empty(64, 12)).shape == (8, 12)
+    with pytest.raises((NotImplementedError, RuntimeError)):
+        torch.ops.fitgnn.gemm_nt(x.detach().cpu(), W.detach().cpu())
 
 
 # grad_W = grad_h^T @ x (csrc/gemm_atb.hip): row counts around the 32-row stage and the chunking, ragged column
