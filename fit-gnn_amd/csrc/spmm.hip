@@ -298,11 +298,14 @@ __global__ __launch_bounds__(kThreads) void spmm_gather_kernel(
     const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col, const float *__restrict__ val,
     const float *__restrict__ X, int64_t ldx, float *__restrict__ Y, int64_t ldy, int32_t H,
     const fitgnn_tile_t *__restrict__ tiles, int32_t n_tiles, int32_t tiles_per_xcd, int32_t n_slabs,
-    const float *__restrict__ bias, uint32_t epi, float p_drop, uint64_t seed_arg, const uint8_t *__restrict__ mask) {
+    const float *__restrict__ bias, uint32_t epi, float p_drop, uint64_t seed_arg, const uint8_t *__restrict__ mask,
+    const int32_t *__restrict__ xrow) {
     const uint64_t seed = fitgnn::resolve_seed(seed_arg, epi);
     using P = Pack<VEC>;
     using T = typename P::T;
     constexpr int SLAB = 64 * VEC;
+    // xrow (optional): operand row of column c is X[xrow[c]] (a de-duplicated feature table: the gathers then hit a table
+    // that stays in L2 / MALL, which is where this variant beats the LDS-window kernel).
     // 1-D grid; block -> (tile, slab).  Blocks are dispatched in id order, round-robin over the 8 XCDs: give each
     // XCD a contiguous range of tiles, and make the slab the FASTEST index inside it, so that both halves of
     // every operand/output row are in flight at the same time (a slab-major order streams bytes [0,1K) of
@@ -343,7 +346,7 @@ __global__ __launch_bounds__(kThreads) void spmm_gather_kernel(
         // ---- fast path: the wave's whole CSR slice sits in two registers ----
         int my_c = 0;
         float my_v = 0.f;
-        if (lane < E1 - E0) { my_c = col[E0 + lane]; my_v = val[E0 + lane]; }
+        if (lane < E1 - E0) { my_c = col[E0 + lane]; my_v = val[E0 + lane]; if (xrow) my_c = xrow[my_c]; }
         RowQuad<VEC> qa, qb;
         issue_row<VEC>(qa, 0, rp_v, E0, my_c, my_v, Xs, ldx, live);
         int i = 0;
@@ -370,7 +373,7 @@ __global__ __launch_bounds__(kThreads) void spmm_gather_kernel(
             const int cnt = min(64, e1 - base);
             int my_c = 0;
             float my_v = 0.f;
-            if (lane < cnt) { my_c = col[base + lane]; my_v = val[base + lane]; }
+            if (lane < cnt) { my_c = col[base + lane]; my_v = val[base + lane]; if (xrow) my_c = xrow[my_c]; }
             int k = 0;
             for (; k + 4 <= cnt; k += 4) {
                 const int c0 = __builtin_amdgcn_readlane(my_c, k), c1 = __builtin_amdgcn_readlane(my_c, k + 1);
@@ -430,11 +433,10 @@ int launch(const int32_t *rowptr, const int32_t *col, const float *val, const fl
     constexpr int SLAB = 64 * VEC;
     const int n_slabs = (H + SLAB - 1) / SLAB;
     const int tiles_per_xcd = (n_tiles + 7) / 8;
-    if ((epi & FITGNN_SPMM_GATHER) && xrow) return FITGNN_E_BADARG;  // the gather variant has no row indirection
     if (epi & FITGNN_SPMM_GATHER) {
         dim3 grid(tiles_per_xcd * 8 * n_slabs);
         hipLaunchKernelGGL(spmm_gather_kernel<VEC>, grid, dim3(kThreads), 0, s, rowptr, col, val, X, ldx, Y, ldy, H, tiles,
-                           n_tiles, tiles_per_xcd, n_slabs, bias, epi, p_drop, seed, mask);
+                           n_tiles, tiles_per_xcd, n_slabs, bias, epi, p_drop, seed, mask, xrow);
         return (int)hipGetLastError();
     }
     const int lds_rows = window_rows > 0 ? std::min(window_rows, kMaxWindowRows) : kDefaultWindowRows;

@@ -531,6 +531,11 @@ class FusedGCNLayerHead(torch.autograd.Function):
         return dX, dW, (db if ctx.has_bias else None), dWl, dbl, None, None, None, None, None, None
 
 
+# layer 0 on a de-duplicated table: the direct-gather SpMM variant (its operand table stays in L2 / MALL; 5-12 us per step over
+# the LDS-window kernel, same bits)
+DEDUP_GATHER = True
+
+
 class FusedGCNLayerDedup(torch.autograd.Function):
     """First GCN layer on a de-duplicated feature table: the union batch's rows are copies of N0 original nodes
     (X_union = Xt[index]), so  X_union W^T = (Xt W^T)[index]: one GEMM on N0 rows, the copies are resolved by the
@@ -546,8 +551,8 @@ class FusedGCNLayerDedup(torch.autograd.Function):
         drop = bool(training) and p > 0.0
         if drop:
             epi |= EPI_DROPOUT
-        out = spmm_graph(g, Ht, bias=b, epilogue=epi, p=p if drop else 0.0, seed=seed, mask=mask if drop else None,
-                         xrow=ridx.index)
+        out = spmm_graph(g, Ht, bias=b, epilogue=epi | (_lib.SPMM_GATHER if DEDUP_GATHER else 0), p=p if drop else 0.0, seed=seed,
+                         mask=mask if drop else None, xrow=ridx.index)
         ctx.save_for_backward(Xt, W, out, mask if drop else None)
         ctx.g, ctx.ridx, ctx.p, ctx.drop, ctx.seed, ctx.has_bias = g, ridx, p, drop, seed, b is not None
         if link_out is not None:

@@ -400,3 +400,24 @@ def test_gemm_kernels_inside_a_captured_graph(mods):
     torch.cuda.synchronize()
     for e, c in zip(eager, cap):
         assert torch.equal(e, c)
+
+
+@pytest.mark.parametrize("H", [512, 96])
+@pytest.mark.parametrize("sizes", [[3, 9, 1, 30, 64, 2, 2, 5] * 6, [200, 3, 90]])
+def test_row_indirection_in_both_spmm_variants(mods, H, sizes):
+    """Y = A_hat @ X_table[xrow] without materialising the gathered rows: the LDS-window kernel and the direct-gather
+    kernel (used for layer 0 on a de-duplicated feature table) against the plain product on the gathered rows."""
+    _lib, csr, ops, orc, gorc = mods
+    ei, n = block_graph(sizes, seed=11, p=0.3)
+    g = csr.CSRGraph(ei.cuda(), n, mode="gcn")
+    n_table = max(4, n // 3)
+    xrow = torch.randint(0, n_table, (n,), dtype=torch.int32).cuda()
+    table = torch.randn(n_table, H).cuda()
+    ref = ops.spmm_graph(g, table[xrow.long()].contiguous())
+    for flag in (0, _lib.SPMM_GATHER):
+        bias = torch.randn(H).cuda()
+        got = ops.spmm_graph(g, table, xrow=xrow, epilogue=flag)
+        assert torch.allclose(got, ref, rtol=1e-5, atol=1e-6), flag
+        got_b = ops.spmm_graph(g, table, xrow=xrow, epilogue=flag | _lib.EPI_BIAS | _lib.EPI_ELU, bias=bias)
+        ref_b = ops.spmm_graph(g, table[xrow.long()].contiguous(), epilogue=_lib.EPI_BIAS | _lib.EPI_ELU, bias=bias)
+        assert torch.allclose(got_b, ref_b, rtol=1e-5, atol=1e-6), flag
