@@ -183,7 +183,9 @@ def main():
     # SpMM roofline: algorithmic bytes of one launch / mean HIP-event duration of the launches in the timed region
     H, R = args.hidden, batch.n_rows
     bytes_spmm = 4 * H * R + 4 * H * R + 8 * batch.nnz + 4 * (R + 1)
-    durs_ms = [a.elapsed_time(b) for a, b in events]
+    # (the launches of the LDS-window kernel only: layer 0's forward on the de-duplicated table runs the direct-gather
+    # variant, whose operand is a 40-MB table, not an [R x H] matrix)
+    durs_ms = [a.elapsed_time(b) for a, b, kind in events if kind == "tile"]
     spmm_ms = float(np.mean(durs_ms)) if durs_ms else float("nan")
     achieved = bytes_spmm / (spmm_ms * 1e-3) / 1e9
     # HBM traffic of one SpMM launch from the committed PMC profile of this same command (rocprofv3 --pmc, separate

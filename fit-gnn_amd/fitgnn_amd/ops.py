@@ -252,7 +252,7 @@ def spmm_raw(rowptr, col, val, tiles, X, n_rows, bias=None, epilogue=0, p=0.0, s
                                _lib.stream_ptr(X.device))
     if ev is not None:
         ev[1].record()
-        PROFILE.append(ev)
+        PROFILE.append((ev[0], ev[1], "gather" if (epilogue & _lib.SPMM_GATHER) else "tile"))
     _lib.check(rc, "fitgnn_spmm_csr_f32")
     return Y
 
