@@ -17,7 +17,7 @@ for (R, N, K) in [(90549, 512, 512), (300, 512, 512), (1000, 100, 64), (19717, 5
     a = torch.randn(R, K, device="cuda"); b = torch.randn(N, K, device="cuda")
     ref = a.double() @ b.double().t()
     got = ops.gemm_nt(a, b)
-    lib = ops.mm(a, b.t())
+    lib = ops.mm(a, b.t())   # torch.mm under the "high" precision policy: the library's 3 x bf16 kernel
     den = ref.abs().max()
     print(R, N, K, "err hip %.2e lib %.2e" % (float((got - ref).abs().max() / den), float((lib - ref).abs().max() / den)),
           "hip %.1f us  lib %.1f us" % (t_us(lambda: ops.gemm_nt(a, b)), t_us(lambda: ops.mm(a, b.t()))), flush=True)
