@@ -25,15 +25,20 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kTile = 256;
 constexpr int kStage = 32;
-constexpr int kThreads = 512;
 constexpr int kBlk = 64 * 16;        // [k-half 2][row 32] x 16 B: the operand of one MFMA
-constexpr int kPart = 8 * kBlk;      // 8 row tiles
-constexpr int kStep = 2 * kPart;     // hi, lo
-constexpr int kOperand = 2 * kStep;  // two k16 steps
-constexpr int kBuf = 2 * kOperand;   // a side, b side: 64 KB
-constexpr int kLdsBytes = 2 * kBuf;
+// WMN = waves along a tile edge / 64-row blocks per side: 4 -> 256 x 256 tile, 8 waves of 64 x 128, 128 KB LDS (one workgroup
+// per CU); 2 -> 128 x 128 tile, 4 waves of 64 x 64, 64 KB LDS (two workgroups per CU, whose barriers are independent)
+template <int WMN>
+struct Geo {
+    static constexpr int kTile = 64 * WMN;
+    static constexpr int kThreads = 128 * WMN;
+    static constexpr int kPart = 2 * WMN * kBlk;   // row tiles of one side
+    static constexpr int kStep = 2 * kPart;        // hi, lo
+    static constexpr int kOperand = 2 * kStep;     // two k16 steps
+    static constexpr int kBuf = 2 * kOperand;      // a side, b side
+    static constexpr int kLdsBytes = 2 * kBuf;
+};
 
 __device__ __forceinline__ uint32_t pack_bf16_rne(float x0, float x1) {
     f32x2 v = {x0, x1};
@@ -45,13 +50,16 @@ __device__ __forceinline__ uint32_t pack_bf16_rne(float x0, float x1) {
 //   dZ = keep ? dOut / (1 - p) * (o > 0 ? 1 : o + 1) : 0,   o = out * (1 - p)
 // (the arithmetic of epilogue_bwd_kernel, gcn_ops.hip), with the per-tile column sums of dZ written to `col_part`
 // [tiles_m x N] for the bias gradient -- the [R x N] gradient is never written and re-read un-transformed.
-template <bool EPI>
-__global__ __launch_bounds__(kThreads, 1) void gemm_nt_kernel(const float *__restrict__ a, long lda,
+template <int WMN, bool EPI>
+__global__ __launch_bounds__(128 * WMN, WMN == 2 ? 2 : 1) void gemm_nt_kernel(const float *__restrict__ a, long lda,
                                                               const float *__restrict__ b, long ldb, long R, int N, int K,
                                                               int tiles_m, int tiles_n, float *__restrict__ c, long ldc,
                                                               const float *__restrict__ out, float *__restrict__ col_part,
                                                               uint32_t epi, float p_drop, uint64_t seed_arg,
                                                               const uint8_t *__restrict__ mask) {
+    static_assert(!EPI || WMN == 4, "the fused epilogue is written for the 256 x 256 tile");
+    constexpr int kTile = Geo<WMN>::kTile, kPart = Geo<WMN>::kPart, kStep = Geo<WMN>::kStep, kOperand = Geo<WMN>::kOperand,
+                  kBuf = Geo<WMN>::kBuf, JT = WMN;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // the column tiles of one row tile sit on consecutive slots of one XCD: the a slab's second reader hits that L2
@@ -60,7 +68,7 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_nt_kernel(const float *__res
     if (tm >= tiles_m) return;
 
     // staging role: waves 0-3 the a side, 4-7 the b side; a wave owns 64 rows of the tile, 8 per load
-    const int side = wave >> 2;
+    const int side = wave / WMN, ws = wave % WMN;
     const float *src = side ? b : a;
     const long ld = side ? ldb : lda;
     const long nrows = side ? (long)N : R;
@@ -69,7 +77,7 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_nt_kernel(const float *__res
     const int ks_w = f >> 2, h_w = (f >> 1) & 1;  // its k16 step, k-half; (f & 1): which half of the fragment
     const int j = lane >> 3;                      // row within the group of 8: r0..r2
     const int slot_j = ((j >> 2) & 1) | ((j & 1) << 2) | (((j >> 1) & 1) << 3) | ((j & 1) << 4);
-    const int wr_lane = side * kOperand + ks_w * kStep + (2 * (wave & 3)) * kBlk + h_w * 512 + 8 * (f & 1) +
+    const int wr_lane = side * kOperand + ks_w * kStep + (2 * ws) * kBlk + h_w * 512 + 8 * (f & 1) +
                         ((slot_j ^ (ks_w << 1 | h_w)) * 16);
     // addresses: wave-uniform base (tile's first row, stage's k) + a 32-bit lane offset per load (row within the tile,
     // clamped into the operand: rows past its end only feed outputs that are never stored)
@@ -77,7 +85,7 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_nt_kernel(const float *__res
     unsigned voff[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        long row = tile_base + 64 * (wave & 3) + 8 * i + (lane >> 3);
+        long row = tile_base + 64 * ws + 8 * i + (lane >> 3);
         row = row < nrows ? row : nrows - 1;
         voff[i] = (unsigned)((row - tile_base) * ld * 4 + f * 16);
     }
@@ -112,40 +120,40 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_nt_kernel(const float *__res
     for (int ks = 0; ks < 2; ++ks) rd_lane[ks] = ks * kStep + hh * 512 + ((slot_r ^ (ks << 1 | hh)) * 16);
 
     const int wm = wave >> 1, wn = wave & 1;
-    f32x16 acc[2][4];
+    f32x16 acc[2][JT];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj)
+        for (int jj = 0; jj < JT; ++jj)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][jj][r] = 0.f;
 
     auto compute = [&](const unsigned char *buf, int ks) {
         const unsigned char *pa = buf + (2 * wm) * kBlk + rd_lane[ks];
-        const unsigned char *pb = buf + kOperand + (4 * wn) * kBlk + rd_lane[ks];
-        bf16x8 fa[2], fb[4];
+        const unsigned char *pb = buf + kOperand + (JT * wn) * kBlk + rd_lane[ks];
+        bf16x8 fa[2], fb[JT];
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) fb[jj] = *reinterpret_cast<const bf16x8 *>(pb + jj * kBlk);
+        for (int jj = 0; jj < JT; ++jj) fb[jj] = *reinterpret_cast<const bf16x8 *>(pb + jj * kBlk);
 #pragma unroll
         for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const bf16x8 *>(pa + kPart + i * kBlk);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj)
+            for (int jj = 0; jj < JT; ++jj)
                 acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[jj], acc[i][jj], 0, 0, 0);
 #pragma unroll
         for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const bf16x8 *>(pa + i * kBlk);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj)
+            for (int jj = 0; jj < JT; ++jj)
                 acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[jj], acc[i][jj], 0, 0, 0);
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) fb[jj] = *reinterpret_cast<const bf16x8 *>(pb + kPart + jj * kBlk);
+        for (int jj = 0; jj < JT; ++jj) fb[jj] = *reinterpret_cast<const bf16x8 *>(pb + kPart + jj * kBlk);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj)
+            for (int jj = 0; jj < JT; ++jj)
                 acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[jj], acc[i][jj], 0, 0, 0);
     };
 
@@ -173,8 +181,8 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_nt_kernel(const float *__res
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-                const int n = tn * kTile + (4 * wn + jj) * 32 + (lane & 31);
+            for (int jj = 0; jj < JT; ++jj) {
+                const int n = tn * kTile + (JT * wn + jj) * 32 + (lane & 31);
                 const long m0 = (long)tm * kTile + (2 * wm + i) * 32 + 4 * (lane >> 5);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -185,6 +193,7 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_nt_kernel(const float *__res
         }
         return;
     }
+    if constexpr (EPI) {
     const uint64_t seed = fitgnn::resolve_seed(seed_arg, epi);
     const bool drop = (epi & FITGNN_EPI_DROPOUT) != 0, elu = (epi & FITGNN_EPI_ELU) != 0;
     const float scale = drop ? 1.0f / (1.0f - p_drop) : 1.0f;
@@ -258,6 +267,7 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_nt_kernel(const float *__res
         const int nn = tn * kTile + tid;
         if (nn < N) col_part[(long)tm * N + nn] = (red[tid] + red[kTile + tid]) + (red[2 * kTile + tid] + red[3 * kTile + tid]);
     }
+    }
 }
 
 }  // namespace
@@ -273,11 +283,17 @@ int launch_nt(bool epi_on, const float *a, int64_t lda, const float *b, int64_t 
     if (R == 0) return 0;
     if (!a || !b || !c) return FITGNN_E_BADARG;
     if ((((uintptr_t)a | (uintptr_t)b) % 16) != 0) return FITGNN_E_ALIGN;
-    const int tiles_m = (int)((R + kTile - 1) / kTile), tiles_n = (N + kTile - 1) / kTile;
+    // 128 x 128 tiles (two independent workgroups per CU) lose to 256 x 256 on a full grid (208 vs 175 us at R = 90 549:
+    // twice the L2 -> LDS traffic per flop) and win when the large tiles would leave most CUs idle (18 vs 36 us at R = 300)
+    const int64_t big_grid = ((R + Geo<4>::kTile - 1) / Geo<4>::kTile) * ((N + Geo<4>::kTile - 1) / Geo<4>::kTile);
+    const bool small = !epi_on && big_grid < 128;
+    const int T = small ? Geo<2>::kTile : Geo<4>::kTile;
+    const int lds_bytes = small ? Geo<2>::kLdsBytes : Geo<4>::kLdsBytes;
+    const int tiles_m = (int)((R + T - 1) / T), tiles_n = (N + T - 1) / T;
     const int groups = (tiles_m + 7) / 8;
-    auto kern = epi_on ? gemm_nt_kernel<true> : gemm_nt_kernel<false>;
-    FITGNN_RETURN_IF_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
-    hipLaunchKernelGGL(kern, dim3((unsigned)(groups * 8 * tiles_n)), dim3(kThreads), kLdsBytes, (hipStream_t)stream, a,
+    auto kern = epi_on ? gemm_nt_kernel<4, true> : small ? gemm_nt_kernel<2, false> : gemm_nt_kernel<4, false>;
+    FITGNN_RETURN_IF_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    hipLaunchKernelGGL(kern, dim3((unsigned)(groups * 8 * tiles_n)), dim3(small ? Geo<2>::kThreads : Geo<4>::kThreads), lds_bytes, (hipStream_t)stream, a,
                        (long)lda, b, (long)ldb, (long)R, N, K, tiles_m, tiles_n, c, (long)ldc, out, col_part, epi, p_drop, seed,
                        mask);
     return (int)hipGetLastError();
@@ -291,7 +307,7 @@ extern "C" int fitgnn_gemm_nt_f32(const float *a, int64_t lda, const float *b, i
 
 extern "C" size_t fitgnn_gemm_nt_epilogue_bwd_workspace_bytes(int64_t R, int32_t N) {
     if (R <= 0 || N <= 0) return 0;
-    return (size_t)((R + kTile - 1) / kTile) * (size_t)N * sizeof(float);
+    return (size_t)((R + Geo<4>::kTile - 1) / Geo<4>::kTile) * (size_t)N * sizeof(float);
 }
 
 extern "C" int fitgnn_gemm_nt_epilogue_bwd_f32(const float *a, int64_t lda, const float *b, int64_t ldb, int64_t R, int32_t N,
@@ -305,5 +321,5 @@ extern "C" int fitgnn_gemm_nt_epilogue_bwd_f32(const float *a, int64_t lda, cons
     if (work_bytes < fitgnn_gemm_nt_epilogue_bwd_workspace_bytes(R, N)) return FITGNN_E_WORKSPACE;
     const int rc = launch_nt(true, a, lda, b, ldb, R, N, K, dZ, N, out, (float *)work, epilogue, p_drop, seed, mask, stream);
     if (rc != 0 || R == 0 || !db) return rc;
-    return fitgnn_colsum_partials_f32((const float *)work, (int32_t)((R + kTile - 1) / kTile), N, db, stream);
+    return fitgnn_colsum_partials_f32((const float *)work, (int32_t)((R + Geo<4>::kTile - 1) / Geo<4>::kTile), N, db, stream);
 }
