@@ -50,7 +50,10 @@ __device__ __forceinline__ uint32_t pack_bf16_rne(float x0, float x1) {
 //   dZ = keep ? dOut / (1 - p) * (o > 0 ? 1 : o + 1) : 0,   o = out * (1 - p)
 // (the arithmetic of epilogue_bwd_kernel, gcn_ops.hip), with the per-tile column sums of dZ written to `col_part`
 // [tiles_m x N] for the bias gradient -- the [R x N] gradient is never written and re-read un-transformed.
-template <int WMN, bool EPI>
+// PRE: the b operand arrives pre-split (nt_presplit_kernel below): for every (column tile, 32-wide k stage) the exact 32-KB
+// LDS image of the b side, so its staging is 4 LDS-DMA instructions per wave and stage (global_load_lds_dwordx4: no
+// registers, no conversion, no ds_write) and all 8 waves share the a side (4 loads each instead of 8).
+template <int WMN, bool EPI, bool PRE>
 __global__ __launch_bounds__(128 * WMN, WMN == 2 ? 2 : 1) void gemm_nt_kernel(const float *__restrict__ a, long lda,
                                                               const float *__restrict__ b, long ldb, long R, int N, int K,
                                                               int tiles_m, int tiles_n, float *__restrict__ c, long ldc,
@@ -58,6 +61,8 @@ __global__ __launch_bounds__(128 * WMN, WMN == 2 ? 2 : 1) void gemm_nt_kernel(co
                                                               uint32_t epi, float p_drop, uint64_t seed_arg,
                                                               const uint8_t *__restrict__ mask) {
     static_assert(!EPI || WMN == 4, "the fused epilogue is written for the 256 x 256 tile");
+    static_assert(!PRE || WMN == 4, "the pre-split b image is laid out for the 256 x 256 tile");
+    constexpr int NG = PRE ? 4 : 8;  // float4 loads per lane and stage
     constexpr int kTile = Geo<WMN>::kTile, kPart = Geo<WMN>::kPart, kStep = Geo<WMN>::kStep, kOperand = Geo<WMN>::kOperand,
                   kBuf = Geo<WMN>::kBuf, JT = WMN;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -67,8 +72,9 @@ __global__ __launch_bounds__(128 * WMN, WMN == 2 ? 2 : 1) void gemm_nt_kernel(co
     const int tn = slot % tiles_n, tm = xcd + 8 * (slot / tiles_n);
     if (tm >= tiles_m) return;
 
-    // staging role: waves 0-3 the a side, 4-7 the b side; a wave owns 64 rows of the tile, 8 per load
-    const int side = wave / WMN, ws = wave % WMN;
+    // staging role: waves 0-3 the a side, 4-7 the b side, a wave owns 64 rows of the tile, 8 per load; with PRE every wave
+    // stages 32 rows of the a side (4 loads) and a quarter... an eighth of the b image by DMA
+    const int side = PRE ? 0 : wave / WMN, ws = wave % WMN;
     const float *src = side ? b : a;
     const long ld = side ? ldb : lda;
     const long nrows = side ? (long)N : R;
@@ -77,30 +83,36 @@ __global__ __launch_bounds__(128 * WMN, WMN == 2 ? 2 : 1) void gemm_nt_kernel(co
     const int ks_w = f >> 2, h_w = (f >> 1) & 1;  // its k16 step, k-half; (f & 1): which half of the fragment
     const int j = lane >> 3;                      // row within the group of 8: r0..r2
     const int slot_j = ((j >> 2) & 1) | ((j & 1) << 2) | (((j >> 1) & 1) << 3) | ((j & 1) << 4);
-    const int wr_lane = side * kOperand + ks_w * kStep + (2 * ws) * kBlk + h_w * 512 + 8 * (f & 1) +
+    const int row_tile0 = PRE ? wave : 2 * ws;    // first 32-row tile this wave stages
+    const int wr_lane = side * kOperand + ks_w * kStep + row_tile0 * kBlk + h_w * 512 + 8 * (f & 1) +
                         ((slot_j ^ (ks_w << 1 | h_w)) * 16);
     // addresses: wave-uniform base (tile's first row, stage's k) + a 32-bit lane offset per load (row within the tile,
     // clamped into the operand: rows past its end only feed outputs that are never stored)
     const float *tile_src = src + tile_base * ld;
-    unsigned voff[8];
+    unsigned voff[NG];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        long row = tile_base + 64 * ws + 8 * i + (lane >> 3);
+    for (int i = 0; i < NG; ++i) {
+        long row = tile_base + 32 * row_tile0 + 8 * i + (lane >> 3);
         row = row < nrows ? row : nrows - 1;
         voff[i] = (unsigned)((row - tile_base) * ld * 4 + f * 16);
     }
 
-    f32x4 g[8];
+    f32x4 g[NG];
     // hand-placed loads and counted waits, as in gemm_atb.hip (`after`: fake dependence on the conversion of the
     // registers being refilled)
     auto load_row = [&](int k0, int i, uint32_t after) {
         const float *base = tile_src + k0;
         asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(g[i]) : "v"(voff[i]), "s"(base), "v"(after));
     };
+    // Outstanding vector-memory operations when g[i] is converted, oldest first: the rest of the stage held in g, (PRE) the 4
+    // DMA instructions of this iteration, the i loads already refilled -- NG - 1 (+ 4) in every case.
     auto convert_and_reload = [&](unsigned char *buf, int k_next) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            asm volatile("s_waitcnt vmcnt(7)" : "+v"(g[i]));
+        for (int i = 0; i < NG; ++i) {
+            if (PRE)
+                asm volatile("s_waitcnt vmcnt(7)" : "+v"(g[i]));
+            else
+                asm volatile("s_waitcnt vmcnt(7)" : "+v"(g[i]));
             const uint32_t h0 = pack_bf16_rne(g[i][0], g[i][1]), h1 = pack_bf16_rne(g[i][2], g[i][3]);
             const uint32_t l0 = pack_bf16_rne(g[i][0] - __uint_as_float(h0 << 16), g[i][1] - __uint_as_float(h0 & 0xffff0000u));
             const uint32_t l1 = pack_bf16_rne(g[i][2] - __uint_as_float(h1 << 16), g[i][3] - __uint_as_float(h1 & 0xffff0000u));
@@ -109,6 +121,22 @@ __global__ __launch_bounds__(128 * WMN, WMN == 2 ? 2 : 1) void gemm_nt_kernel(co
             *reinterpret_cast<uint2 *>(buf + off) = make_uint2(h0, h1);
             *reinterpret_cast<uint2 *>(buf + off + kPart) = make_uint2(l0, l1);
             load_row(k_next, i, l0 ^ l1);
+        }
+    };
+    // PRE: this wave's 4 KB of the b side's stage image, global -> LDS (destination = M0 + 16 * lane: the image is stored
+    // in LDS order, so consecutive lanes copy consecutive 16 bytes)
+    const unsigned char *bimg = reinterpret_cast<const unsigned char *>(b) + (long)tn * (K / kStage) * kOperand +
+                                wave * 4096 + lane * 16;
+    auto dma_stage = [&](unsigned char *buf, int stage) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const unsigned char *gsrc = bimg + (long)stage * kOperand + q * 1024;
+            const unsigned lds_dst = (unsigned)(uintptr_t)(buf + kOperand + wave * 4096 + q * 1024);  // LDS byte address
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep)
+                         : "v"(gsrc), "s"(lds_dst)
+                         : "memory");
         }
     };
 
@@ -161,20 +189,28 @@ __global__ __launch_bounds__(128 * WMN, WMN == 2 ? 2 : 1) void gemm_nt_kernel(co
     // prefetches past the last stage re-read the last one (never converted into a buffer that is multiplied)
     auto k_of = [&](int s) { return (s < nstage ? s : nstage - 1) * kStage; };
 #pragma unroll
-    for (int i = 0; i < 8; ++i) load_row(0, i, 0u);
+    for (int i = 0; i < NG; ++i) load_row(0, i, 0u);
+    if (PRE) dma_stage(lds, 0);
     convert_and_reload(lds, k_of(1));
     for (int s = 0; s < nstage; ++s) {
         const unsigned char *cur = lds + (s & 1) * kBuf;
         unsigned char *nxt = lds + ((s + 1) & 1) * kBuf;
+        if (PRE) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // the DMA of stage s has landed (4 younger loads may fly)
         __syncthreads();
+        if (PRE) dma_stage(nxt, s + 1 < nstage ? s + 1 : nstage - 1);
         compute(cur, 0);
         convert_and_reload(nxt, k_of(s + 2));
         compute(cur, 1);
     }
-    asm volatile("s_waitcnt vmcnt(0)"
-                 : "+v"(g[0]), "+v"(g[1]), "+v"(g[2]), "+v"(g[3]), "+v"(g[4]), "+v"(g[5]), "+v"(g[6]), "+v"(g[7])
-                 :
-                 : "memory");
+    // prefetches (and the last DMA) are still in flight: g stays allocated until they have landed
+    if constexpr (PRE) {
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(g[0]), "+v"(g[1]), "+v"(g[2]), "+v"(g[3]) : : "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)"
+                     : "+v"(g[0]), "+v"(g[1]), "+v"(g[2]), "+v"(g[3]), "+v"(g[NG - 4]), "+v"(g[NG - 3]), "+v"(g[NG - 2]), "+v"(g[NG - 1])
+                     :
+                     : "memory");
+    }
 
     // C/D layout of the 32x32 MFMA: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
     if (!EPI) {
@@ -270,28 +306,58 @@ __global__ __launch_bounds__(128 * WMN, WMN == 2 ? 2 : 1) void gemm_nt_kernel(co
     }
 }
 
+// b [N x K] (element (n, k) at b[n * sn + k * sk]: also serves b = W^T without materialising it) -> for every column tile
+// and 32-wide k stage the 32-KB b-side LDS image of gemm_nt_kernel<4, *, true>; rows past N are zero.  One thread per
+// (row, 4 consecutive k).
+__global__ __launch_bounds__(256) void nt_presplit_kernel(const float *__restrict__ b, long sn, long sk, int N, int K,
+                                                          unsigned char *__restrict__ img) {
+    constexpr int kPart = Geo<4>::kPart, kStep = Geo<4>::kStep, kOperand = Geo<4>::kOperand, kTile = Geo<4>::kTile;
+    const int k4 = K / 4;
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    const int tiles_n = (N + kTile - 1) / kTile;
+    if (t >= (long)tiles_n * kTile * k4) return;
+    const int n = (int)(t / k4), k = (int)(t % k4) * 4;
+    float x[4] = {0.f, 0.f, 0.f, 0.f};
+    if (n < N) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) x[e] = b[n * sn + (k + e) * sk];
+    }
+    const uint32_t h0 = pack_bf16_rne(x[0], x[1]), h1 = pack_bf16_rne(x[2], x[3]);
+    const uint32_t l0 = pack_bf16_rne(x[0] - __uint_as_float(h0 << 16), x[1] - __uint_as_float(h0 & 0xffff0000u));
+    const uint32_t l1 = pack_bf16_rne(x[2] - __uint_as_float(h1 << 16), x[3] - __uint_as_float(h1 & 0xffff0000u));
+    const int tn = n / kTile, row = n % kTile, r = row & 31;
+    const int stage = k / kStage, kk = k % kStage, ks = kk >> 4, h = (kk >> 3) & 1, q = (kk >> 2) & 1;
+    const int slot = ((r >> 2) & 1) | (((r >> 3) & 1) << 1) | ((((r >> 4) ^ r) & 1) << 2) | (((r >> 1) & 1) << 3) | ((r & 1) << 4);
+    unsigned char *dst = img + ((long)tn * (K / kStage) + stage) * kOperand + ks * kStep + (row >> 5) * kBlk + h * 512 +
+                         ((slot ^ (ks << 1 | h)) * 16) + 8 * q;
+    *reinterpret_cast<uint2 *>(dst) = make_uint2(h0, h1);
+    *reinterpret_cast<uint2 *>(dst + kPart) = make_uint2(l0, l1);
+}
+
 }  // namespace
 
 extern "C" int fitgnn_colsum_partials_f32(const float *partial, int32_t n_chunks, int32_t H, float *out, void *stream);
 
 namespace {
-int launch_nt(bool epi_on, const float *a, int64_t lda, const float *b, int64_t ldb, int64_t R, int32_t N, int32_t K, float *c,
-              int64_t ldc, const float *out, float *col_part, uint32_t epi, float p_drop, uint64_t seed, const uint8_t *mask,
-              void *stream) {
-    if (R < 0 || N <= 0 || K < kStage || (K % kStage) != 0 || lda < K || ldb < K || ldc < N || (lda % 4) != 0 || (ldb % 4) != 0)
-        return FITGNN_E_BADARG;
+// b_is_image: b points at the pre-split image of nt_presplit_kernel (256 x 256 tiles only)
+int launch_nt(bool epi_on, bool b_is_image, const float *a, int64_t lda, const float *b, int64_t ldb, int64_t R, int32_t N, int32_t K,
+              float *c, int64_t ldc, const float *out, float *col_part, uint32_t epi, float p_drop, uint64_t seed,
+              const uint8_t *mask, void *stream) {
+    if (R < 0 || N <= 0 || K < kStage || (K % kStage) != 0 || lda < K || ldc < N || (lda % 4) != 0) return FITGNN_E_BADARG;
+    if (!b_is_image && (ldb < K || (ldb % 4) != 0)) return FITGNN_E_BADARG;
     if (R == 0) return 0;
     if (!a || !b || !c) return FITGNN_E_BADARG;
     if ((((uintptr_t)a | (uintptr_t)b) % 16) != 0) return FITGNN_E_ALIGN;
     // 128 x 128 tiles (two independent workgroups per CU) lose to 256 x 256 on a full grid (208 vs 175 us at R = 90 549:
     // twice the L2 -> LDS traffic per flop) and win when the large tiles would leave most CUs idle (18 vs 36 us at R = 300)
     const int64_t big_grid = ((R + Geo<4>::kTile - 1) / Geo<4>::kTile) * ((N + Geo<4>::kTile - 1) / Geo<4>::kTile);
-    const bool small = !epi_on && big_grid < 128;
+    const bool small = !epi_on && !b_is_image && big_grid < 128;
     const int T = small ? Geo<2>::kTile : Geo<4>::kTile;
     const int lds_bytes = small ? Geo<2>::kLdsBytes : Geo<4>::kLdsBytes;
     const int tiles_m = (int)((R + T - 1) / T), tiles_n = (N + T - 1) / T;
     const int groups = (tiles_m + 7) / 8;
-    auto kern = epi_on ? gemm_nt_kernel<4, true> : small ? gemm_nt_kernel<2, false> : gemm_nt_kernel<4, false>;
+    auto kern = b_is_image ? (epi_on ? gemm_nt_kernel<4, true, true> : gemm_nt_kernel<4, false, true>)
+                           : (epi_on ? gemm_nt_kernel<4, true, false> : small ? gemm_nt_kernel<2, false, false> : gemm_nt_kernel<4, false, false>);
     FITGNN_RETURN_IF_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
     hipLaunchKernelGGL(kern, dim3((unsigned)(groups * 8 * tiles_n)), dim3(small ? Geo<2>::kThreads : Geo<4>::kThreads), lds_bytes, (hipStream_t)stream, a,
                        (long)lda, b, (long)ldb, (long)R, N, K, tiles_m, tiles_n, c, (long)ldc, out, col_part, epi, p_drop, seed,
@@ -302,7 +368,28 @@ int launch_nt(bool epi_on, const float *a, int64_t lda, const float *b, int64_t 
 
 extern "C" int fitgnn_gemm_nt_f32(const float *a, int64_t lda, const float *b, int64_t ldb, int64_t R, int32_t N, int32_t K,
                                   float *c, int64_t ldc, void *stream) {
-    return launch_nt(false, a, lda, b, ldb, R, N, K, c, ldc, nullptr, nullptr, 0u, 0.f, 0ull, nullptr, stream);
+    return launch_nt(false, false, a, lda, b, ldb, R, N, K, c, ldc, nullptr, nullptr, 0u, 0.f, 0ull, nullptr, stream);
+}
+
+extern "C" size_t fitgnn_gemm_nt_presplit_bytes(int32_t N, int32_t K) {
+    if (N <= 0 || K < kStage || (K % kStage) != 0) return 0;
+    return (size_t)((N + Geo<4>::kTile - 1) / Geo<4>::kTile) * (size_t)(K / kStage) * Geo<4>::kOperand;
+}
+
+extern "C" int fitgnn_gemm_nt_presplit_f32(const float *b, int64_t stride_n, int64_t stride_k, int32_t N, int32_t K, void *image,
+                                           void *stream) {
+    if (N <= 0 || K < kStage || (K % kStage) != 0 || !b || !image) return FITGNN_E_BADARG;
+    if (((uintptr_t)image % 16) != 0) return FITGNN_E_ALIGN;
+    const long threads = (long)((N + Geo<4>::kTile - 1) / Geo<4>::kTile) * Geo<4>::kTile * (K / 4);
+    hipLaunchKernelGGL(nt_presplit_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, b,
+                       (long)stride_n, (long)stride_k, N, K, (unsigned char *)image);
+    return (int)hipGetLastError();
+}
+
+extern "C" int fitgnn_gemm_nt_pre_f32(const float *a, int64_t lda, const void *b_image, int64_t R, int32_t N, int32_t K, float *c,
+                                      int64_t ldc, void *stream) {
+    return launch_nt(false, true, a, lda, (const float *)b_image, 0, R, N, K, c, ldc, nullptr, nullptr, 0u, 0.f, 0ull, nullptr,
+                     stream);
 }
 
 extern "C" size_t fitgnn_gemm_nt_epilogue_bwd_workspace_bytes(int64_t R, int32_t N) {
@@ -319,7 +406,8 @@ extern "C" int fitgnn_gemm_nt_epilogue_bwd_f32(const float *a, int64_t lda, cons
     if ((N % 4) != 0) return FITGNN_E_BADARG;  // the dropout groups of 4 columns must not straddle rows
     if ((((uintptr_t)out | (uintptr_t)dZ) % 16) != 0) return FITGNN_E_ALIGN;
     if (work_bytes < fitgnn_gemm_nt_epilogue_bwd_workspace_bytes(R, N)) return FITGNN_E_WORKSPACE;
-    const int rc = launch_nt(true, a, lda, b, ldb, R, N, K, dZ, N, out, (float *)work, epilogue, p_drop, seed, mask, stream);
+    const bool image = ldb == 0;  // ldb == 0: b is a pre-split image (fitgnn_gemm_nt_presplit_f32)
+    const int rc = launch_nt(true, image, a, lda, b, ldb, R, N, K, dZ, N, out, (float *)work, epilogue, p_drop, seed, mask, stream);
     if (rc != 0 || R == 0 || !db) return rc;
     return fitgnn_colsum_partials_f32((const float *)work, (int32_t)((R + Geo<4>::kTile - 1) / Geo<4>::kTile), N, db, stream);
 }

@@ -43,11 +43,20 @@ def mm(a, b, allow_split=True):
 NT_KERNEL = True
 
 
+def _full_grid(R, N):
+    return ((R + 255) // 256) * ((N + 255) // 256) >= 128
+
+
 def _nt_ok(a, b):
-    return (NT_KERNEL and GEMM_PRECISION == "high" and a.is_cuda and a.dtype == torch.float32 and b.dtype == torch.float32
-            and a.dim() == 2 and b.dim() == 2 and a.stride(1) == 1 and b.stride(1) == 1 and a.shape[1] % 32 == 0
-            and a.shape[0] >= 1024 and b.shape[0] >= 64 and a.stride(0) % 4 == 0 and b.stride(0) % 4 == 0
-            and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0)
+    """a [R, K] @ b [N, K]^T can run on csrc/gemm_nt.hip.  b may be a strided view (e.g. W.t()) when the pre-split path
+    applies: it reads b through its strides."""
+    if not (NT_KERNEL and GEMM_PRECISION == "high" and a.is_cuda and a.dtype == torch.float32 and b.dtype == torch.float32
+            and a.dim() == 2 and b.dim() == 2 and a.stride(1) == 1 and a.shape[1] % 32 == 0 and a.shape[0] >= 1024
+            and b.shape[0] >= 64 and a.stride(0) % 4 == 0 and a.data_ptr() % 16 == 0):
+        return False
+    if NT_PRESPLIT and _full_grid(a.shape[0], b.shape[0]):
+        return True
+    return b.stride(1) == 1 and b.stride(0) % 4 == 0 and b.data_ptr() % 16 == 0
 
 
 def mm_xwt(x, W):
@@ -57,15 +66,23 @@ def mm_xwt(x, W):
     return mm(x, W.t())
 
 
+def _wt_operand(a, W):
+    """W^T as the b operand of a @ W: the strided view when the pre-split path will read it through its strides (no copy),
+    else a contiguous transpose."""
+    if NT_PRESPLIT and NT_KERNEL and _full_grid(a.shape[0], W.shape[1]):
+        return W.t()
+    return W.t().contiguous()
+
+
 def mm_by_transposed(a, W):
     """a @ W for a square-ish weight W [out, in]: the library's kernel for a row-major right operand (NN) takes 201 us on
     the S-pubmed union, the one for a transposed right operand (the forward's x @ W^T form) 160 us -- materialise W^T
     (1 MB) and use the latter.  Bit-identical result."""
     if a.is_cuda and W.dim() == 2 and W.shape[0] >= 64 and W.shape[1] >= 64:
-        Wt = W.t().contiguous()
+        Wt = _wt_operand(a, W)
         if _nt_ok(a, Wt):
             return gemm_nt(a, Wt)
-        return mm(a, Wt.t())
+        return mm(a, W.t().contiguous().t())
     return mm(a, W)
 
 
@@ -86,11 +103,30 @@ def gemm_atb(a, b):
     return out
 
 
+NT_PRESPLIT = True   # pre-split the small operand once per call and stage it by LDS-DMA (full 256 x 256 grids only)
+
+
+def _presplit(b):
+    """The kernel's LDS image of b [N, K] (any strides: pass W.t() for the backward product) -- bf16 hi/lo fragments."""
+    L = _lib.lib()
+    N, K = b.shape
+    img = torch.empty(int(L.fitgnn_gemm_nt_presplit_bytes(N, K)), dtype=torch.uint8, device=b.device)
+    _lib.check(L.fitgnn_gemm_nt_presplit_f32(_lib.dptr(b), b.stride(0), b.stride(1), N, K, _lib.dptr(img), _lib.stream_ptr(b.device)),
+               "fitgnn_gemm_nt_presplit_f32")
+    return img
+
+
 def gemm_nt(a, b):
-    """a [R, K] @ b [N, K]^T through the hand-written MFMA kernel (csrc/gemm_nt.hip)."""
+    """a [R, K] @ b [N, K]^T through the hand-written MFMA kernel (csrc/gemm_nt.hip).  b may be any strided view."""
     L = _lib.lib()
     R, K, N = a.shape[0], a.shape[1], b.shape[0]
     out = torch.empty((R, N), dtype=torch.float32, device=a.device)
+    if NT_PRESPLIT and _full_grid(R, N):
+        img = _presplit(b)
+        _lib.check(L.fitgnn_gemm_nt_pre_f32(_lib.dptr(a), a.stride(0), _lib.dptr(img), R, N, K, _lib.dptr(out), N,
+                                            _lib.stream_ptr(a.device)), "fitgnn_gemm_nt_pre_f32")
+        return out
+    b = b.contiguous()
     _lib.check(L.fitgnn_gemm_nt_f32(_lib.dptr(a), a.stride(0), _lib.dptr(b), b.stride(0), R, N, K, _lib.dptr(out), N,
                                     _lib.stream_ptr(a.device)), "fitgnn_gemm_nt_f32")
     return out
@@ -107,7 +143,12 @@ def gemm_nt_epilogue_bwd(a, b, out, epilogue, p=0.0, seed=0, mask=None, want_db=
     db = torch.empty(N, dtype=torch.float32, device=a.device) if want_db else None
     wb = int(L.fitgnn_gemm_nt_epilogue_bwd_workspace_bytes(R, N))
     work = torch.empty(max(wb, 4), dtype=torch.uint8, device=a.device)
-    rc = L.fitgnn_gemm_nt_epilogue_bwd_f32(_lib.dptr(a), a.stride(0), _lib.dptr(b), b.stride(0), R, N, K, _lib.dptr(out),
+    if NT_PRESPLIT and _full_grid(R, N):
+        b_arg, ldb = _presplit(b), 0
+    else:
+        b_arg = b.contiguous()
+        ldb = b_arg.stride(0)
+    rc = L.fitgnn_gemm_nt_epilogue_bwd_f32(_lib.dptr(a), a.stride(0), _lib.dptr(b_arg), ldb, R, N, K, _lib.dptr(out),
                                            _lib.dptr(dZ), epilogue, float(p), seed, _lib.dptr(mask), _lib.dptr(db),
                                            _lib.dptr(work), wb, _lib.stream_ptr(a.device))
     _lib.check(rc, "fitgnn_gemm_nt_epilogue_bwd_f32")
@@ -442,8 +483,8 @@ class EpilogueLink:
 def _dx_through_link(link, dH, W, X):
     """dX for the consumer of a linked layer: (tensor to return as the input gradient)."""
     if link is not None and FUSE_DX_EPILOGUE and W.shape[1] % 4 == 0 and X.is_contiguous() and X.dtype == torch.float32:
-        Wt = W.t().contiguous()
         dH = _f32c(dH)
+        Wt = _wt_operand(dH, W)
         if _nt_ok(dH, Wt):
             dZ, db = gemm_nt_epilogue_bwd(dH, Wt, X, link.epi, p=link.p, seed=link.seed, mask=link.mask, want_db=link.want_db)
             link.fused, link.db = True, db

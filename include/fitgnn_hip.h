@@ -137,6 +137,16 @@ int fitgnn_gemm_atb_f32(const float *a, int64_t lda, const float *b, int64_t ldb
 int fitgnn_gemm_nt_f32(const float *a, int64_t lda, const float *b, int64_t ldb, int64_t R, int32_t N, int32_t K,
                        float *c, int64_t ldc, void *stream);
 
+/* Pre-split b operand for the tall-GEMM kernels: b [N x K] given by element strides (b[n * stride_n + k * stride_k]; so
+ * b = W^T needs no transposed copy) is converted ONCE per call into bf16 hi/lo fragments laid out as the kernel's LDS image,
+ * per (256-column tile, 32-wide k stage).  fitgnn_gemm_nt_pre_f32 then stages that side by LDS-DMA (no registers, no
+ * conversion in the loop).  fitgnn_gemm_nt_epilogue_bwd_f32 takes such an image as `b` when ldb == 0. */
+size_t fitgnn_gemm_nt_presplit_bytes(int32_t N, int32_t K);
+int fitgnn_gemm_nt_presplit_f32(const float *b, int64_t stride_n, int64_t stride_k, int32_t N, int32_t K, void *image,
+                                void *stream);
+int fitgnn_gemm_nt_pre_f32(const float *a, int64_t lda, const void *b_image, int64_t R, int32_t N, int32_t K, float *c,
+                           int64_t ldc, void *stream);
+
 /* The same product taken as the gradient dOut of a fused layer output out = dropout(ELU(z)) (network.py:32-33), with
  * fitgnn_epilogue_bwd_f32's transformation applied to the accumulators before they are stored:
  *   dZ [R x N] = keep ? (a @ b^T) / (1 - p) * (o > 0 ? 1 : o + 1) : 0,  o = out * (1 - p);  db[n] = sum_rows dZ (may be NULL).
