@@ -527,3 +527,28 @@ def test_dx_gemm_with_the_previous_layers_epilogue(mods, layers, dedup, inject):
         _, _, g_ref = gorc.classify_node_fwd_bwd(sd, x, ei, y, num_layers=layers, train_mask=torch.ones(n, dtype=torch.bool), masks=masks)
         for k, p in model.named_parameters():
             assert rel(grads[True][k].cpu(), g_ref[k]) < 1e-3, k
+
+
+@pytest.mark.parametrize("hidden,classes,layers", [(256, 16, 3), (64, 2, 2), (32, 4, 2)])
+def test_other_widths_through_the_gemm_kernels(mods, hidden, classes, layers):
+    """Hidden sizes on either side of the GEMM kernels' limits (64 columns, K % 32) against the oracle, training mode with
+    injected dropout masks, 4000 rows (a 16 x 1 grid of 256-row tiles: the 128 x 128 tile variant)."""
+    network, fnn, gorc = mods
+    ei, n = graph(n=4000, m=12000, seed=41)
+    args = argparse.Namespace(num_layers1=layers, layer_name="GCNConv", num_features=96, hidden=hidden, num_classes=classes)
+    torch.manual_seed(3)
+    model = network.Classify_node(args).cuda().train()
+    x = torch.rand(n, 96)
+    y = torch.randint(0, classes, (n,))
+    tm = torch.rand(n) < 0.4
+    masks = [(torch.rand(n, hidden) > 0.5).to(torch.uint8) for _ in range(layers)]
+    model._inject_masks = [m.cuda() for m in masks]
+    out = model(x.cuda(), ei.cuda())
+    loss = torch.nn.functional.nll_loss(out[tm.cuda()], y.cuda()[tm.cuda()])
+    loss.backward()
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    o_ref, l_ref, g_ref = gorc.classify_node_fwd_bwd(sd, x, ei, y, num_layers=layers, train_mask=tm, masks=masks)
+    assert rel(out.detach().cpu(), o_ref) < 1e-4
+    assert abs(float(loss.detach()) - float(l_ref)) < 1e-4 * abs(float(l_ref))
+    for k, p in model.named_parameters():
+        assert rel(p.grad.cpu(), g_ref[k]) < 1e-3, k
