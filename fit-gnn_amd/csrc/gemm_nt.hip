@@ -1,8 +1,11 @@
 // gemm_nt.hip -- c[R x N] = a[R x K] @ b[N x K]^T for row-major fp32 operands (gfx950 only).
 //
 // The two remaining tall GEMMs of a hidden layer on the train path: the forward h = x W^T of GCNConv's bias-free Linear
-// (network.py:31 through torch_geometric's GCNConv) and, with b = W^T materialised (1 MB), the input
-// gradient dX = dH @ W of its backward (run.py:207 / :246 `loss.backward()`).  R ~ 1e5 union rows, N = K = 512.
+// (network.py:31 through torch_geometric's GCNConv) and, with b = W^T, the input gradient
+// dX = dH @ W of its backward (run.py:207 / :246 `loss.backward()`).  R ~ 1e5 union rows, N = K = 512.
+// Variants (template arguments): tile edge 256 or 128; EPI = the previous fused layer's epilogue backward applied to the
+// accumulators (dOut never written); PRE = b given as a pre-split LDS image (nt_presplit_kernel reads it through its
+// strides: W^T is never materialised) and staged by LDS-DMA.
 //
 // Same arithmetic and machinery as gemm_atb.hip (read its header first): every fp32 operand is split into bf16 hi
 // (round to nearest) and lo = bf16(x - hi); hi.hi + hi.lo + lo.hi on v_mfma_f32_32x32x16_bf16, fp32 accumulate.  What
@@ -73,7 +76,7 @@ __global__ __launch_bounds__(128 * WMN, WMN == 2 ? 2 : 1) void gemm_nt_kernel(co
     if (tm >= tiles_m) return;
 
     // staging role: waves 0-3 the a side, 4-7 the b side, a wave owns 64 rows of the tile, 8 per load; with PRE every wave
-    // stages 32 rows of the a side (4 loads) and a quarter... an eighth of the b image by DMA
+    // stages 32 rows of the a side (4 loads) and an eighth of the b side's stage image by DMA
     const int side = PRE ? 0 : wave / WMN, ws = wave % WMN;
     const float *src = side ? b : a;
     const long ld = side ? ldb : lda;
@@ -109,10 +112,7 @@ __global__ __launch_bounds__(128 * WMN, WMN == 2 ? 2 : 1) void gemm_nt_kernel(co
     auto convert_and_reload = [&](unsigned char *buf, int k_next) {
 #pragma unroll
         for (int i = 0; i < NG; ++i) {
-            if (PRE)
-                asm volatile("s_waitcnt vmcnt(7)" : "+v"(g[i]));
-            else
-                asm volatile("s_waitcnt vmcnt(7)" : "+v"(g[i]));
+            asm volatile("s_waitcnt vmcnt(7)" : "+v"(g[i]));
             const uint32_t h0 = pack_bf16_rne(g[i][0], g[i][1]), h1 = pack_bf16_rne(g[i][2], g[i][3]);
             const uint32_t l0 = pack_bf16_rne(g[i][0] - __uint_as_float(h0 << 16), g[i][1] - __uint_as_float(h0 & 0xffff0000u));
             const uint32_t l1 = pack_bf16_rne(g[i][2] - __uint_as_float(h1 << 16), g[i][3] - __uint_as_float(h1 & 0xffff0000u));
