@@ -91,6 +91,23 @@ def _atb_ok(t):
             and t.shape[1] % 4 == 0 and t.shape[1] >= 4 and t.data_ptr() % 16 == 0)
 
 
+PROFILE_GEMM = None   # bench.py: list of (start event, end event, kernel name, bf16 flops) per hand-written GEMM launch
+
+
+def _gemm_events(name, flops):
+    if PROFILE_GEMM is None:
+        return None
+    ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), name, flops)
+    ev[0].record()
+    return ev
+
+
+def _gemm_done(ev):
+    if ev is not None:
+        ev[1].record()
+        PROFILE_GEMM.append(ev)
+
+
 def gemm_atb(a, b):
     """a^T @ b through the hand-written split-K MFMA kernel (csrc/gemm_atb.hip): 3 x bf16 products, fp32 accumulate,
     fixed-order sum of the row chunks."""
@@ -98,8 +115,11 @@ def gemm_atb(a, b):
     R, M, N = a.shape[0], a.shape[1], b.shape[1]
     ws = torch.empty(int(L.fitgnn_gemm_atb_workspace_bytes(R, M, N)) // 4, dtype=torch.float32, device=a.device)
     out = torch.empty((M, N), dtype=torch.float32, device=a.device)
-    _lib.check(L.fitgnn_gemm_atb_f32(_lib.dptr(a), a.stride(0), _lib.dptr(b), b.stride(0), R, M, N, _lib.dptr(out),
-                                     _lib.dptr(ws), _lib.stream_ptr(a.device)), "fitgnn_gemm_atb_f32")
+    ev = _gemm_events("gemm_atb_kernel+atb_reduce_kernel", 6.0 * R * M * N)
+    rc = L.fitgnn_gemm_atb_f32(_lib.dptr(a), a.stride(0), _lib.dptr(b), b.stride(0), R, M, N, _lib.dptr(out), _lib.dptr(ws),
+                               _lib.stream_ptr(a.device))
+    _gemm_done(ev)
+    _lib.check(rc, "fitgnn_gemm_atb_f32")
     return out
 
 
@@ -123,8 +143,10 @@ def gemm_nt(a, b):
     out = torch.empty((R, N), dtype=torch.float32, device=a.device)
     if NT_PRESPLIT and _full_grid(R, N):
         img = _presplit(b)
-        _lib.check(L.fitgnn_gemm_nt_pre_f32(_lib.dptr(a), a.stride(0), _lib.dptr(img), R, N, K, _lib.dptr(out), N,
-                                            _lib.stream_ptr(a.device)), "fitgnn_gemm_nt_pre_f32")
+        ev = _gemm_events("gemm_nt_kernel<4,false,true>", 6.0 * R * N * K)
+        rc = L.fitgnn_gemm_nt_pre_f32(_lib.dptr(a), a.stride(0), _lib.dptr(img), R, N, K, _lib.dptr(out), N, _lib.stream_ptr(a.device))
+        _gemm_done(ev)
+        _lib.check(rc, "fitgnn_gemm_nt_pre_f32")
         return out
     b = b.contiguous()
     _lib.check(L.fitgnn_gemm_nt_f32(_lib.dptr(a), a.stride(0), _lib.dptr(b), b.stride(0), R, N, K, _lib.dptr(out), N,
@@ -148,9 +170,11 @@ def gemm_nt_epilogue_bwd(a, b, out, epilogue, p=0.0, seed=0, mask=None, want_db=
     else:
         b_arg = b.contiguous()
         ldb = b_arg.stride(0)
+    ev = _gemm_events("gemm_nt_kernel<4,true,%s>" % ("true" if ldb == 0 else "false"), 6.0 * R * N * K)
     rc = L.fitgnn_gemm_nt_epilogue_bwd_f32(_lib.dptr(a), a.stride(0), _lib.dptr(b_arg), ldb, R, N, K, _lib.dptr(out),
                                            _lib.dptr(dZ), epilogue, float(p), seed, _lib.dptr(mask), _lib.dptr(db),
                                            _lib.dptr(work), wb, _lib.stream_ptr(a.device))
+    _gemm_done(ev)
     _lib.check(rc, "fitgnn_gemm_nt_epilogue_bwd_f32")
     return dZ, db
 
