@@ -5,6 +5,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "fit-gnn_amd")):
     sys.path.insert(0, p)
 import numpy as np, torch
+import os as _os
+from fitgnn_amd import ops as _ops
+if _os.environ.get("FITGNN_NO_HAND_GEMM"):   # A/B: the library GEMMs instead of csrc/gemm_*.hip
+    _ops.ATB_KERNEL = _ops.NT_KERNEL = False
 from fitgnn_amd import graph_data, network, train
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
