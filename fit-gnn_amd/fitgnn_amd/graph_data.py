@@ -140,6 +140,46 @@ class GraphSet:
         self.gs_ptr = self.sub_ptr[self.cluster_ptr]                  # union rows of every graph
 
     # ---- batches: contiguous graph ranges ------------------------------------------------------------------
+    def _flat(self, kind):
+        """(row pointer per graph, x, mask | None, edge list grouped by graph, edge pointer per graph) of one view, cached."""
+        cache = self.__dict__.setdefault("_flat_cache", {})
+        if kind not in cache:
+            dev = self.x.device
+            if kind == "orig":
+                ptr, x, mask, ei = self.node_ptr, self.x, None, self.edge_index
+            elif kind == "gs":
+                ptr, x, mask, ei = self.gs_ptr, self.gs_x, self.gs_mask, self.gs_edge_index
+            else:
+                ptr, x, mask, ei = self.cluster_ptr, self.gc_x, None, self.gc_edge_index
+            ptr_t = torch.as_tensor(np.asarray(ptr), dtype=torch.int64, device=dev)
+            eg = torch.searchsorted(ptr_t, ei[0].contiguous(), right=True) - 1       # graph of every edge (by its source row)
+            order = torch.argsort(eg, stable=True)
+            eptr = torch.searchsorted(eg[order].contiguous(), torch.arange(self.n_graphs + 1, device=dev))
+            cache[kind] = (ptr_t, x, mask, ei[:, order].contiguous(), eptr)
+        return cache[kind]
+
+    def batch_ids(self, ids, kind):
+        """The graphs `ids` (any order, no repeats needed) as one block-diagonal piece, like batch(): rows and edges are
+        gathered with two index vectors built from the per-graph pointers -- no per-graph scan of the edge list, which is
+        what GraphTrainer(reshuffle=True) pays for when it re-draws the batches every epoch (run.py:710)."""
+        dev = self.x.device
+        ptr, x, mask, ei, eptr = self._flat(kind)
+        ids_t = torch.as_tensor(ids, dtype=torch.int64, device=dev)
+        starts, lens = ptr[ids_t], ptr[ids_t + 1] - ptr[ids_t]
+        new0 = torch.cumsum(lens, 0) - lens                                            # first new row of every graph
+        shift = starts - new0
+        total = int(lens.sum())
+        rows = torch.repeat_interleave(shift, lens) + torch.arange(total, device=dev)
+        es, el = eptr[ids_t], eptr[ids_t + 1] - eptr[ids_t]
+        n_e = int(el.sum())
+        eidx = torch.repeat_interleave(es - (torch.cumsum(el, 0) - el), el) + torch.arange(n_e, device=dev)
+        e = (ei[:, eidx] - torch.repeat_interleave(shift, el)).contiguous()
+        graph = torch.repeat_interleave(torch.arange(len(ids), device=dev), lens)
+        if dev.type == "cuda" and total > 0:
+            register(e, CSRGraph(e, total, mode="gcn"), "gcn")
+        return dict(x=x[rows], edge_index=e, graph=graph, mask=None if mask is None else mask[rows], y=self.y[ids_t],
+                    n_graphs=len(ids))
+
     def batch(self, g0, g1, kind):
         """Graphs g0:g1 as one block-diagonal piece: dict(x, edge_index, graph (0-based), mask, y, n_graphs) for
         kind 'gs' (subgraph union), 'gc' (coarse graphs) or 'orig' (the uncoarsened graphs: baselines).  The piece's CSR is

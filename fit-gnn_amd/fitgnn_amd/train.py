@@ -425,7 +425,7 @@ class GraphTrainer(_CapturedSteps):
             ids_all = graphs[b0:b0 + batch_size]
             ids = ids_all[self.rank::self.world]
             self.global_sizes.append(len(ids_all))
-            self.batches.append(_cat_pieces([gset.batch(g, g + 1, kind) for g in ids], kind, types) if ids else None)
+            self.batches.append(_cat_pieces([gset.batch_ids(ids, kind)], kind, types) if ids else None)
 
     def step(self):
         self.model.train()

@@ -552,3 +552,24 @@ def test_other_widths_through_the_gemm_kernels(mods, hidden, classes, layers):
     assert abs(float(loss.detach()) - float(l_ref)) < 1e-4 * abs(float(l_ref))
     for k, p in model.named_parameters():
         assert rel(p.grad.cpu(), g_ref[k]) < 1e-3, k
+
+
+@pytest.mark.parametrize("kind", ["gs", "gc", "orig"])
+def test_batch_of_arbitrary_graph_ids_equals_per_graph_pieces(mods, kind):
+    """GraphSet.batch_ids (two gathers from the per-graph pointers) == the concatenation of single-graph batch() pieces."""
+    import types
+    from fitgnn_amd import graph_data, train
+
+    mol = graph_data.synthetic_molecules(40, seed=3)
+    gset = graph_data.GraphSet(mol, ratio=0.5, extra_node=True, device="cuda")
+    ids = [17, 3, 39, 0, 22, 23, 8]
+    a = train._cat_pieces([gset.batch_ids(ids, kind)], kind, types)
+    b = train._cat_pieces([gset.batch(g, g + 1, kind) for g in ids], kind, types)
+    assert torch.equal(a["x"], b["x"]) and torch.equal(a["y"], b["y"])
+    ea = a["edge_index"][:, torch.argsort(a["edge_index"][0] * 10 ** 6 + a["edge_index"][1])]
+    eb = b["edge_index"][:, torch.argsort(b["edge_index"][0] * 10 ** 6 + b["edge_index"][1])]
+    assert torch.equal(ea, eb)
+    if kind == "gs":
+        assert torch.equal(a["mask"], b["mask"]) and torch.equal(a["graph_of_masked"], b["graph_of_masked"])
+    else:
+        assert torch.equal(a["gc"].batch, b["gc"].batch)
