@@ -370,7 +370,7 @@ class GraphTrainer(_CapturedSteps):
                 if not ids:
                     self.batches.append(None)   # this rank holds no graph of a short last batch: it still joins the step
                     continue
-                pieces = [gset.batch(g, g + 1, kind) for g in ids] if not _is_range(ids) else [gset.batch(ids[0], ids[-1] + 1, kind)]
+                pieces = [gset.batch_ids(ids, kind)] if not _is_range(ids) else [gset.batch(ids[0], ids[-1] + 1, kind)]
                 self.batches.append(_cat_pieces(pieces, kind, types))
         if self.world > 1:
             self.capture = False   # the per-step collective is issued eagerly
