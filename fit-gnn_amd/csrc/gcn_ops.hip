@@ -241,8 +241,8 @@ __global__ __launch_bounds__(256) void sum_leading_kernel(const float4 *__restri
 
 // Column sums of a tall matrix with a few columns (the head's bias gradient, sum over rows of dy [rows x classes]):
 // block b sums rows [b * rows_per_block, ...) -- thread t takes rows t, t + 256, ... of the range, then a fixed tree
-// over the 256 threads -- into partial[b][C]; colsum_partials_kernel adds the blocks.  C <= kNarrowMaxC.
-constexpr int kNarrowMaxC = 16;
+// over the 256 threads -- into partial[b][C]; colsum_partials_kernel adds the blocks.  C <= kNarrowMaxC (ogbn-products: 47).
+constexpr int kNarrowMaxC = 64;
 __global__ __launch_bounds__(256) void narrow_colsum_kernel(const float *__restrict__ x, int64_t ldx, int32_t n_rows, int32_t C,
                                                             int32_t rows_per_block, float *__restrict__ partial) {
     __shared__ float red[256];

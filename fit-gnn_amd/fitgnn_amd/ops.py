@@ -229,9 +229,10 @@ class Linear(torch.autograd.Function):
 
 
 def colsum_narrow(x):
-    """Column sums of a tall [rows, C <= 16] matrix (the head's bias gradient) through fitgnn_colsum_narrow_f32."""
-    if not (x.is_cuda and x.dim() == 2 and x.shape[1] <= 16 and x.dtype == torch.float32 and x.stride(1) == 1):
-        return x.sum(0)
+    """Column sums of a tall [rows, C <= 64] matrix (the head's bias gradient) through fitgnn_colsum_narrow_f32."""
+    if not (x.is_cuda and x.dim() == 2 and x.shape[1] <= 64 and x.dtype == torch.float32 and x.stride(1) == 1):
+        # torch's dim-0 reduction of a tall narrow matrix is slow (50 us for 90 k x 3): reduce the transposed copy instead
+        return x.t().contiguous().sum(1) if (x.dim() == 2 and x.shape[0] > 4 * x.shape[1]) else x.sum(0)
     L = _lib.lib()
     n, C = x.shape
     out = torch.empty(C, dtype=torch.float32, device=x.device)

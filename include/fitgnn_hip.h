@@ -156,7 +156,7 @@ int fitgnn_gemm_nt_epilogue_bwd_f32(const float *a, int64_t lda, const float *b,
                                     const float *out, float *dZ, uint32_t epilogue, float p_drop, uint64_t seed,
                                     const uint8_t *mask, float *db, void *work, size_t work_bytes, void *stream);
 
-/* out[c] = sum over rows of x[row][c] for a tall matrix with C <= 16 columns (row stride ldx), fixed order: the bias gradient
+/* out[c] = sum over rows of x[row][c] for a tall matrix with C <= 64 columns (row stride ldx), fixed order: the bias gradient
  * of the output head lt1 (network.py:34), grad_b = sum_rows grad_y.  torch's dim-0 reduction of such a matrix takes 19-50 us. */
 size_t fitgnn_colsum_narrow_workspace_bytes(int32_t n_rows, int32_t C);
 int fitgnn_colsum_narrow_f32(const float *x, int64_t ldx, int32_t n_rows, int32_t C, float *out, void *work, size_t work_bytes,

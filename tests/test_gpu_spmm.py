@@ -369,7 +369,8 @@ def test_linear_gemm_is_the_default_path_and_differentiates(mods):
     assert float((W.grad - gy.double().t() @ xd).abs().max()) < 2e-5 * float((gy.double().t() @ xd).abs().max())
 
 
-@pytest.mark.parametrize("n,C,wide", [(90549, 3, 0), (1000, 16, 4), (255, 1, 0), (257, 7, 1), (1, 5, 0)])
+@pytest.mark.parametrize("n,C,wide", [(90549, 3, 0), (1000, 16, 4), (255, 1, 0), (257, 7, 1), (1, 5, 0), (70000, 47, 1), (3000, 64, 0),
+                                      (5000, 80, 0)])
 def test_narrow_column_sums(mods, n, C, wide):
     _lib, csr, ops, orc, gorc = mods
     x = torch.randn(n, C + wide).cuda()[:, :C]
