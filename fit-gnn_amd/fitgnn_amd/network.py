@@ -63,17 +63,27 @@ class _Base(nn.Module):
         return ops.FusedGCNLayerDedup.apply(x_table.float(), conv.lin.weight, conv.bias, g, x_index, float(self.dropout_p),
                                             bool(self.training), seed, mask, link_out)
 
-    def embed(self, x, edge_index, x_index=None, first=0):
+    def embed(self, x, edge_index, x_index=None, first=0, link=None):
+        """conv -> ELU -> dropout, num_layers times (network.py:29-33).  link: the EpilogueLink recorded by the layer that
+        produced x (consecutive fused GCN layers are linked: see ops.EpilogueLink; the stack is strictly sequential)."""
         x = x.float()
         for i in range(first, self.num_layers):
             conv = self.conv[i]
-            if isinstance(conv, (fnn.GCNConv, fnn.GATConv)) and x.is_cuda:
+            if isinstance(conv, fnn.GCNConv) and x.is_cuda:
+                mask = self._inject_masks[i] if self._inject_masks is not None else None
+                nxt = ops.EpilogueLink() if i + 1 < self.num_layers else None   # the last output goes to lt1: plain gradient
+                x = conv.forward_elu_dropout(x, edge_index, p=self.dropout_p, training=self.training, mask=mask, link_in=link,
+                                             link_out=nxt)
+                link = nxt
+            elif isinstance(conv, fnn.GATConv) and x.is_cuda:
                 mask = self._inject_masks[i] if self._inject_masks is not None else None
                 x = conv.forward_elu_dropout(x, edge_index, p=self.dropout_p, training=self.training, mask=mask)
+                link = None
             else:
                 x = conv(x, edge_index)
                 x = F.elu(x)
                 x = F.dropout(x, p=self.dropout_p, training=self.training)
+                link = None
         return x
 
     def embed_and_head(self, x, edge_index, x_index=None, out_rows=None):
@@ -90,7 +100,7 @@ class _Base(nn.Module):
         fused_tail = L > 0 and x.is_cuda and isinstance(last, fnn.GCNConv) and self.lt1.out_features <= ops.head_max_classes()
         # the conv stack is strictly sequential (network.py:29-33): consecutive fused GCN layers share an EpilogueLink, so
         # that the backward GEMM dH @ W of layer i+1 applies layer i's ELU'/dropout' in its epilogue
-        link = ops.EpilogueLink() if (fused_tail and L > 1) else None
+        link = ops.EpilogueLink() if (L > 1 and x.is_cuda and isinstance(self.conv[1], fnn.GCNConv)) else None
         if x_index is not None:
             h = self._first_layer_dedup(x, edge_index, x_index, link_out=link) if L > 1 else None
             if h is None:
@@ -101,7 +111,7 @@ class _Base(nn.Module):
         else:
             link = None
         if not fused_tail:
-            return self.head(self.embed(x, edge_index, first=first))
+            return self.head(self.embed(x, edge_index, first=first, link=link))
         x = x.float()
         for i in range(first, L - 1):
             conv = self.conv[i]
