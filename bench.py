@@ -108,8 +108,8 @@ def cpu_baseline(batch, sd, num_layers, budget_s=20.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)   # 0.25 s of timed region: the clock and the caches have settled
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="S-pubmed")
     ap.add_argument("--hidden", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
