@@ -5,7 +5,7 @@ set -e
 tag=$1
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out/$tag
-python3 $R/bench.py --steps 30 --warmup 5 > $R/gpurun_out/$tag/bench.json 2> $R/gpurun_out/$tag/bench.err
+python3 $R/bench.py > $R/gpurun_out/$tag/bench.json 2> $R/gpurun_out/$tag/bench.err
 echo "bench done"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/$tag/stats -o run -- python3 $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline > $R/gpurun_out/$tag/bench_under_rocprof.json 2> $R/gpurun_out/$tag/rocprof.err
