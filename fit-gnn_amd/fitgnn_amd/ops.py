@@ -17,12 +17,13 @@ from ._lib import EPI_BIAS, EPI_DROPOUT, EPI_ELU
 PROFILE = None
 
 
-# Dense GEMM policy (BASELINE.json north_star: MFMA only for the dense weight GEMMs, library GEMM allowed).
-# "high": hipBLASLt computes the [rows x in] @ [in x out] products (forward, dX) with the 3 x bf16 split of each
-# fp32 operand on the bf16 MFMA pipe (fp32 accumulate; measured 4-5e-6 relative error vs fp64, 2.2x faster than the
-# fp32 MFMA path on gfx950).  The weight-gradient products dH^T @ X (reduction over all rows) use the same precision
-# through a split-K batched product (mm_at_b): the library's single-call kernel for that shape is 2.7x slower.
-# "highest" everywhere = plain fp32 MFMA.
+# Dense GEMM policy (BASELINE.json north_star: MFMA for the dense weight GEMMs).
+# "high": every fp32 product as three bf16 products (hi.hi + hi.lo + lo.hi of the two-term split of each operand) on the
+# bf16 MFMA pipe with fp32 accumulation -- measured 4-5e-6 relative error vs fp64.  The tall products of a Linear run on
+# the hand-written kernels csrc/gemm_nt.hip (x @ W^T, dH @ W) and csrc/gemm_atb.hip (dH^T @ x); shapes they do not take
+# (K % 32 != 0, operands narrower than 64 columns, fewer than 1024 rows) go to hipBLASLt in its equivalent mode (2.2x
+# faster than its fp32 MFMA kernels), the weight-gradient fallback as a split-K batched product (mm_at_b).
+# "highest" everywhere = the library's plain fp32 MFMA kernels.
 GEMM_PRECISION = "high"
 # a^T @ b (weight gradients) through csrc/gemm_atb.hip instead of the library's batched split-K form
 ATB_KERNEL = True
