@@ -310,7 +310,7 @@ __global__ __launch_bounds__(128 * WMN, WMN == 2 ? 2 : 1) void gemm_nt_kernel(co
 // and 32-wide k stage the 32-KB b-side LDS image of gemm_nt_kernel<4, *, true>; rows past N are zero.  One thread per
 // (row, 4 consecutive k).
 __global__ __launch_bounds__(256) void nt_presplit_kernel(const float *__restrict__ b, long sn, long sk, int N, int K,
-                                                          unsigned char *__restrict__ img) {
+                                                          int K_valid, unsigned char *__restrict__ img) {
     constexpr int kPart = Geo<4>::kPart, kStep = Geo<4>::kStep, kOperand = Geo<4>::kOperand, kTile = Geo<4>::kTile;
     const int k4 = K / 4;
     const long t = (long)blockIdx.x * 256 + threadIdx.x;
@@ -320,7 +320,8 @@ __global__ __launch_bounds__(256) void nt_presplit_kernel(const float *__restric
     float x[4] = {0.f, 0.f, 0.f, 0.f};
     if (n < N) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) x[e] = b[n * sn + (k + e) * sk];
+        for (int e = 0; e < 4; ++e)
+            if (k + e < K_valid) x[e] = b[n * sn + (k + e) * sk];  // k >= K_valid: zero padding up to the stage width
     }
     const uint32_t h0 = pack_bf16_rne(x[0], x[1]), h1 = pack_bf16_rne(x[2], x[3]);
     const uint32_t l0 = pack_bf16_rne(x[0] - __uint_as_float(h0 << 16), x[1] - __uint_as_float(h0 & 0xffff0000u));
@@ -376,13 +377,13 @@ extern "C" size_t fitgnn_gemm_nt_presplit_bytes(int32_t N, int32_t K) {
     return (size_t)((N + Geo<4>::kTile - 1) / Geo<4>::kTile) * (size_t)(K / kStage) * Geo<4>::kOperand;
 }
 
-extern "C" int fitgnn_gemm_nt_presplit_f32(const float *b, int64_t stride_n, int64_t stride_k, int32_t N, int32_t K, void *image,
-                                           void *stream) {
-    if (N <= 0 || K < kStage || (K % kStage) != 0 || !b || !image) return FITGNN_E_BADARG;
+extern "C" int fitgnn_gemm_nt_presplit_f32(const float *b, int64_t stride_n, int64_t stride_k, int32_t N, int32_t K,
+                                           int32_t K_valid, void *image, void *stream) {
+    if (N <= 0 || K < kStage || (K % kStage) != 0 || K_valid < 1 || K_valid > K || !b || !image) return FITGNN_E_BADARG;
     if (((uintptr_t)image % 16) != 0) return FITGNN_E_ALIGN;
     const long threads = (long)((N + Geo<4>::kTile - 1) / Geo<4>::kTile) * Geo<4>::kTile * (K / 4);
     hipLaunchKernelGGL(nt_presplit_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, b,
-                       (long)stride_n, (long)stride_k, N, K, (unsigned char *)image);
+                       (long)stride_n, (long)stride_k, N, K, K_valid, (unsigned char *)image);
     return (int)hipGetLastError();
 }
 

@@ -127,14 +127,52 @@ def gemm_atb(a, b):
 NT_PRESPLIT = True   # pre-split the small operand once per call and stage it by LDS-DMA (full 256 x 256 grids only)
 
 
-def _presplit(b):
-    """The kernel's LDS image of b [N, K] (any strides: pass W.t() for the backward product) -- bf16 hi/lo fragments."""
+def _presplit(b, K_pad=None):
+    """The kernel's LDS image of b [N, K] (any strides: pass W.t() for the backward product) -- bf16 hi/lo fragments.
+    K_pad (multiple of 32, >= K): the image's k extent, zero beyond K."""
     L = _lib.lib()
     N, K = b.shape
-    img = torch.empty(int(L.fitgnn_gemm_nt_presplit_bytes(N, K)), dtype=torch.uint8, device=b.device)
-    _lib.check(L.fitgnn_gemm_nt_presplit_f32(_lib.dptr(b), b.stride(0), b.stride(1), N, K, _lib.dptr(img), _lib.stream_ptr(b.device)),
-               "fitgnn_gemm_nt_presplit_f32")
+    Kp = K if K_pad is None else int(K_pad)
+    img = torch.empty(int(L.fitgnn_gemm_nt_presplit_bytes(N, Kp)), dtype=torch.uint8, device=b.device)
+    _lib.check(L.fitgnn_gemm_nt_presplit_f32(_lib.dptr(b), b.stride(0), b.stride(1), N, Kp, K, _lib.dptr(img),
+                                             _lib.stream_ptr(b.device)), "fitgnn_gemm_nt_presplit_f32")
     return img
+
+
+def padded_table(x):
+    """A static operand table whose width is not a multiple of 32 (real feature widths: 500, 1 433, 8 415), zero-padded once
+    to the next multiple so that the hand-written GEMM kernels can take it; cached on the tensor object."""
+    pad = getattr(x, "_fitgnn_pad", None)
+    if pad is None or pad[0] != x._version:
+        Kp = (x.shape[1] + 31) // 32 * 32
+        xp = torch.zeros((x.shape[0], Kp), dtype=torch.float32, device=x.device)
+        xp[:, : x.shape[1]] = x
+        x._fitgnn_pad = pad = (x._version, xp)
+    return pad[1]
+
+
+def gemm_nt_padded_k(a_pad, b):
+    """a_pad [R, K'] (zero columns from K = b.shape[1] on) @ b [N, K]^T through the pre-split path."""
+    L = _lib.lib()
+    R, Kp, N = a_pad.shape[0], a_pad.shape[1], b.shape[0]
+    out = torch.empty((R, N), dtype=torch.float32, device=a_pad.device)
+    img = _presplit(b, K_pad=Kp)
+    ev = _gemm_events("gemm_nt_kernel<4,false,true>", 6.0 * R * N * Kp)
+    rc = L.fitgnn_gemm_nt_pre_f32(_lib.dptr(a_pad), a_pad.stride(0), _lib.dptr(img), R, N, Kp, _lib.dptr(out), N,
+                                  _lib.stream_ptr(a_pad.device))
+    _gemm_done(ev)
+    _lib.check(rc, "fitgnn_gemm_nt_pre_f32")
+    return out
+
+
+# layer 0 on a wide, static feature table whose width is not a multiple of 32: run the products on a zero-padded copy
+WIDE_TABLE_MIN_K = 1024
+
+
+def _wide_table(Xt, W):
+    return (NT_KERNEL and ATB_KERNEL and NT_PRESPLIT and GEMM_PRECISION == "high" and Xt.is_cuda and Xt.dtype == torch.float32
+            and Xt.shape[1] % 32 != 0 and Xt.shape[1] >= WIDE_TABLE_MIN_K and not Xt.requires_grad and W.shape[0] % 4 == 0
+            and W.shape[0] >= 64 and _full_grid(Xt.shape[0], W.shape[0]))
 
 
 def gemm_nt(a, b):
@@ -613,7 +651,8 @@ class FusedGCNLayerDedup(torch.autograd.Function):
     def forward(ctx, Xt, W, b, g, ridx, p, training, seed, mask, link_out=None):
         Xt = _f32c(Xt)
         ctx.link_out = link_out
-        Ht = mm_xwt(Xt, W)  # [N0, H]
+        ctx.wide = _wide_table(Xt, W)
+        Ht = gemm_nt_padded_k(padded_table(Xt), W) if ctx.wide else mm_xwt(Xt, W)  # [N0, H]
         epi = EPI_ELU | (EPI_BIAS if b is not None else 0)
         drop = bool(training) and p > 0.0
         if drop:
@@ -633,7 +672,10 @@ class FusedGCNLayerDedup(torch.autograd.Function):
         epi = EPI_ELU | (EPI_DROPOUT if ctx.drop else 0)
         dH, db = _producer_backward(ctx.link_out, g, out, epi, ctx.p if ctx.drop else 0.0, ctx.seed, mask, ctx.has_bias, dOut)  # [R, H]
         dHt = segment_sum(ridx.seg_off, ridx.members, dH, ridx.n_table)  # [N0, H] per original node
-        dW = mm_at_b(dHt, Xt) if ctx.needs_input_grad[1] else None
+        if ctx.wide and ctx.needs_input_grad[1]:
+            dW = gemm_atb(_f32c(dHt), padded_table(Xt))[:, : Xt.shape[1]]   # [H, F'] on the padded table, F' - F zero columns dropped
+        else:
+            dW = mm_at_b(dHt, Xt) if ctx.needs_input_grad[1] else None
         dXt = mm(dHt, W) if ctx.needs_input_grad[0] else None
         return dXt, dW, (db if ctx.has_bias else None), None, None, None, None, None, None, None
 

@@ -139,11 +139,12 @@ int fitgnn_gemm_nt_f32(const float *a, int64_t lda, const float *b, int64_t ldb,
 
 /* Pre-split b operand for the tall-GEMM kernels: b [N x K] given by element strides (b[n * stride_n + k * stride_k]; so
  * b = W^T needs no transposed copy) is converted ONCE per call into bf16 hi/lo fragments laid out as the kernel's LDS image,
- * per (256-column tile, 32-wide k stage).  fitgnn_gemm_nt_pre_f32 then stages that side by LDS-DMA (no registers, no
+ * per (256-column tile, 32-wide k stage); b has K_valid <= K columns, the image is zero from there to K (a multiple of 32:
+ * a feature width like 8 415 runs against an `a` operand zero-padded to 8 448 columns).  fitgnn_gemm_nt_pre_f32 then stages that side by LDS-DMA (no registers, no
  * conversion in the loop).  fitgnn_gemm_nt_epilogue_bwd_f32 takes such an image as `b` when ldb == 0. */
 size_t fitgnn_gemm_nt_presplit_bytes(int32_t N, int32_t K);
-int fitgnn_gemm_nt_presplit_f32(const float *b, int64_t stride_n, int64_t stride_k, int32_t N, int32_t K, void *image,
-                                void *stream);
+int fitgnn_gemm_nt_presplit_f32(const float *b, int64_t stride_n, int64_t stride_k, int32_t N, int32_t K, int32_t K_valid,
+                                void *image, void *stream);
 int fitgnn_gemm_nt_pre_f32(const float *a, int64_t lda, const void *b_image, int64_t R, int32_t N, int32_t K, float *c,
                            int64_t ldc, void *stream);
 

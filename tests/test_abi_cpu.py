@@ -87,4 +87,5 @@ def test_fused_gemm_epilogue_entry_points():
     assert L.fitgnn_gemm_nt_presplit_bytes(512, 512) == 2 * 16 * 32768   # 2 column tiles x 16 stages x 32-KB LDS image
     assert L.fitgnn_gemm_nt_presplit_bytes(500, 64) == 2 * 2 * 32768
     assert L.fitgnn_gemm_nt_presplit_bytes(512, 48) == 0                  # K % 32 != 0: not supported
-    assert L.fitgnn_gemm_nt_presplit_f32(None, 1, 1, 8, 64, None, None) == -1
+    assert L.fitgnn_gemm_nt_presplit_f32(None, 1, 1, 8, 64, 64, None, None) == -1
+    assert L.fitgnn_gemm_nt_presplit_f32(None, 1, 1, 8, 64, 65, None, None) == -1   # K_valid > K

@@ -573,3 +573,37 @@ def test_batch_of_arbitrary_graph_ids_equals_per_graph_pieces(mods, kind):
         assert torch.equal(a["mask"], b["mask"]) and torch.equal(a["graph_of_masked"], b["graph_of_masked"])
     else:
         assert torch.equal(a["gc"].batch, b["gc"].batch)
+
+
+def test_wide_unaligned_feature_table_runs_on_the_gemm_kernels(mods):
+    """Real feature widths are not multiples of 32 (500, 1 433, 8 415).  For a wide, static table layer 0's two products run
+    on a zero-padded copy (ops.padded_table) through the pre-split GEMM path: same outputs and gradients as the library path."""
+    network, fnn, gorc = mods
+    from fitgnn_amd import ops
+
+    N0, F, H, n = 17000, 1100, 512, 20000
+    ei, n = graph(n=n, m=60000, seed=51)
+    torch.manual_seed(8)
+    idx = torch.randint(0, N0, (n,)); idx[:N0] = torch.arange(N0)
+    Xt = torch.rand(N0, F).cuda()
+    args = argparse.Namespace(num_layers1=2, layer_name="GCNConv", num_features=F, hidden=H, num_classes=5)
+    model = network.Classify_node(args).cuda().train()
+    masks = [(torch.rand(n, H) > 0.5).to(torch.uint8).cuda() for _ in range(2)]
+    model._inject_masks = masks
+    y = torch.randint(0, 5, (n,)).cuda()
+    ridx = ops.RowIndex(idx.cuda(), N0)
+    res = {}
+    for wide in (True, False):
+        saved, ops.WIDE_TABLE_MIN_K = ops.WIDE_TABLE_MIN_K, (1024 if wide else 10 ** 9)
+        try:
+            model.zero_grad()
+            out = model(Xt, ei.cuda(), x_index=ridx)
+            torch.nn.functional.nll_loss(out, y).backward()
+            res[wide] = (out.detach().clone(), {k: p.grad.clone() for k, p in model.named_parameters()})
+        finally:
+            ops.WIDE_TABLE_MIN_K = saved
+    assert getattr(Xt, "_fitgnn_pad")[1].shape == (N0, 1120)
+    assert rel(res[True][0].cpu(), res[False][0].cpu()) < 1e-5
+    for k in res[True][1]:
+        assert res[True][1][k].shape == res[False][1][k].shape
+        assert rel(res[True][1][k].cpu(), res[False][1][k].cpu()) < 1e-4, k
