@@ -50,7 +50,8 @@ inline int chunk_rows_for(int n_rows) {
 }
 
 // dZ = dOut * dropout' * elu'  and per-(row chunk) column partial sums for the bias gradient.
-constexpr int kMaxHeadC = 16;  // widest head (classes) whose backward is folded into this kernel
+constexpr int kMaxHeadC = 16;     // widest head (classes) whose weight gradient is accumulated in this kernel's registers
+constexpr int kMaxHeadWide = 48;  // widest head whose dOut = dy @ Wl is formed here (CW == 0: dWl computed elsewhere)
 
 // dOut is either read (HEAD == false) or formed on the fly as dy @ Wl (HEAD == true: the backward of the output
 // head lt1, network.py:34, whose K = num_classes GEMM would otherwise write and re-read a full [rows x H] matrix).
@@ -66,7 +67,7 @@ __global__ __launch_bounds__(256) void epilogue_bwd_kernel(const float *__restri
     const uint64_t seed = fitgnn::resolve_seed(seed_arg, epi);
     constexpr int SLAB = 64 * VEC;
     __shared__ float red[4][SLAB];
-    __shared__ float s_w[HEAD ? kMaxHeadC * SLAB : 1];
+    __shared__ float s_w[HEAD ? (CW == 0 ? kMaxHeadWide : kMaxHeadC) * SLAB : 1];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int col0 = blockIdx.x * SLAB + lane * VEC;
@@ -436,6 +437,16 @@ extern "C" size_t fitgnn_epilogue_bwd_workspace_bytes(int32_t n_rows, int32_t H)
 }
 
 namespace {
+// Class c's dy value is fetched by lane c of every wave, and only the lanes that own columns of the wave's slab are active:
+// the head must not have more classes than the narrowest (= last) slab has active lanes.
+bool head_supported(int32_t H, int32_t C, bool with_dWl) {
+    if (H < 1 || C < 1 || C > (with_dWl ? kMaxHeadC : kMaxHeadWide)) return false;
+    const bool vec = (H % 4) == 0;
+    const int slab = vec ? 256 : 64, per_lane = vec ? 4 : 1;
+    const int last_cols = (H - 1) % slab + 1;
+    return C <= last_cols / per_lane;
+}
+
 int epilogue_bwd_launch(const float *dOut, const float *dy, const float *Wl, int32_t C, const float *out, float *dZ,
                         int32_t n_rows, int32_t H, uint32_t epilogue, float p_drop, uint64_t seed, const uint8_t *mask,
                         float *db, float *dWl, void *work, size_t work_bytes, void *stream) {
@@ -443,7 +454,7 @@ int epilogue_bwd_launch(const float *dOut, const float *dy, const float *Wl, int
     if (n_rows == 0 || H == 0) return 0;
     const bool head = dOut == nullptr;
     if (!out || !dZ) return FITGNN_E_BADARG;
-    if (head && (!dy || !Wl || C < 1 || C > kMaxHeadC)) return FITGNN_E_BADARG;
+    if (head && (!dy || !Wl || !head_supported(H, C, dWl != nullptr))) return FITGNN_E_BADARG;
     if (!head && dWl) return FITGNN_E_BADARG;
     if ((epilogue & FITGNN_EPI_DROPOUT) && !(p_drop >= 0.f && p_drop < 1.f)) return FITGNN_E_BADARG;
     hipStream_t s = (hipStream_t)stream;
@@ -485,6 +496,8 @@ extern "C" int fitgnn_epilogue_bwd_f32(const float *dOut, const float *out, floa
 }
 
 extern "C" int fitgnn_head_max_classes(void) { return kMaxHeadC; }
+extern "C" int fitgnn_head_max_classes_wide(void) { return kMaxHeadWide; }
+extern "C" int fitgnn_epilogue_bwd_head_supported(int32_t H, int32_t C, int32_t with_dWl) { return head_supported(H, C, with_dWl != 0) ? 1 : 0; }
 
 extern "C" size_t fitgnn_epilogue_bwd_head_workspace_bytes(int32_t n_rows, int32_t H, int32_t C) {
     if (n_rows <= 0 || H <= 0 || C < 0) return 0;

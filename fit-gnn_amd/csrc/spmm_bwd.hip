@@ -289,7 +289,10 @@ extern "C" size_t fitgnn_spmm_epilogue_bwd_workspace_bytes(int32_t n_tiles, int3
 }
 
 extern "C" int fitgnn_spmm_epilogue_bwd_supported(int32_t H, int32_t C, int32_t window_rows) {
-    return (H > 0 && H % 4 == 0 && C >= 0 && C <= kHeadC && window_rows > 0 && window_rows <= kRows) ? 1 : 0;
+    // (a head's dy values are fetched one class per lane by the lanes that own columns of the slab: not more classes than
+    // the last 256-column slab has such lanes -- the condition of fitgnn_epilogue_bwd_head_supported)
+    return (H > 0 && H % 4 == 0 && C >= 0 && C <= kHeadC && C <= ((H - 1) % 256 + 1) / 4 && window_rows > 0 &&
+            window_rows <= kRows) ? 1 : 0;
 }
 
 extern "C" int fitgnn_spmm_epilogue_bwd_f32(const int32_t *rowptr, const int32_t *col, const float *val,

@@ -97,7 +97,8 @@ class _Base(nn.Module):
             return self._embed_and_head_rows(x, edge_index, x_index, out_rows)
         first = 0
         last = self.conv[L - 1] if L > 0 else None
-        fused_tail = L > 0 and x.is_cuda and isinstance(last, fnn.GCNConv) and self.lt1.out_features <= ops.head_max_classes()
+        fused_tail = (L > 0 and x.is_cuda and isinstance(last, fnn.GCNConv) and
+                      ops.head_fusable(self.lt1.in_features, self.lt1.out_features))
         # the conv stack is strictly sequential (network.py:29-33): consecutive fused GCN layers share an EpilogueLink, so
         # that the backward GEMM dH @ W of layer i+1 applies layer i's ELU'/dropout' in its epilogue
         link = ops.EpilogueLink() if (L > 1 and x.is_cuda and isinstance(self.conv[1], fnn.GCNConv)) else None

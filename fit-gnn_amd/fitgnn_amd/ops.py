@@ -478,7 +478,10 @@ def layer_backward(g, out, epi, p, seed, mask, want_db, dOut=None, dy=None, Wl=N
         _lib.check(rc, "fitgnn_spmm_epilogue_bwd_f32")
         return dH, db, dWl
     if head:
-        dZ, db, dWl = epilogue_bwd_head_raw(dy, Wl, out, epi, p=p, seed=seed, mask=mask, want_db=want_db, want_dWl=want_dWl)
+        inside = want_dWl and bool(L.fitgnn_epilogue_bwd_head_supported(H, C, 1))
+        dZ, db, dWl = epilogue_bwd_head_raw(dy, Wl, out, epi, p=p, seed=seed, mask=mask, want_db=want_db, want_dWl=inside)
+        if want_dWl and not inside:   # a wide head (ogbn-products: 47 classes): the kernel's registers hold 16 class rows
+            dWl = mm_at_b(_f32c(dy), out)
     else:
         dZ, db = epilogue_bwd_raw(dOut, out, epi, p=p, seed=seed, mask=mask, want_db=want_db)
         dWl = None
@@ -796,10 +799,23 @@ _HEAD_MAX = None
 
 
 def head_max_classes():
+    """Widest head whose weight gradient the fused head-backward kernel accumulates itself."""
     global _HEAD_MAX
     if _HEAD_MAX is None:
         _HEAD_MAX = int(_lib.lib().fitgnn_head_max_classes())
     return _HEAD_MAX
+
+
+def head_fusable(H, C):
+    """The fused head-backward kernel takes a head of C classes on H hidden columns (its weight gradient inside the kernel up
+    to head_max_classes(), as a separate product above)."""
+    L = _lib.lib()
+    return bool(L.fitgnn_epilogue_bwd_head_supported(int(H), int(C), 1) or L.fitgnn_epilogue_bwd_head_supported(int(H), int(C), 0))
+
+
+def head_max_classes_wide():
+    """Widest head the fused head-backward kernel takes at all (dOut = dy @ Wl formed on the fly; dWl separately)."""
+    return int(_lib.lib().fitgnn_head_max_classes_wide())
 
 
 class SeedBank:

@@ -194,8 +194,13 @@ int fitgnn_epilogue_bwd_f32(const float *dOut, const float *out, float *dZ, int3
  * read but formed on the fly as dy[n_rows x C] @ Wl[C x H], 1 <= C <= fitgnn_head_max_classes().  Replaces the
  * K = num_classes GEMM dy @ Wl and the [n_rows x H] matrix it would write and this kernel would re-read.
  * dWl (f32[C x H], may be NULL) receives the head's weight gradient dy^T @ out, accumulated while `out` streams by
- * (the library GEMM for this [C x rows] @ [rows x H] shape takes 220-340 us on its own). */
+ * (the library GEMM for this [C x rows] @ [rows x H] shape takes 220-340 us on its own).  With dWl == NULL the head may be
+ * as wide as fitgnn_head_max_classes_wide() (ogbn-products: 47 classes); its weight gradient is then a separate product. */
 int fitgnn_head_max_classes(void);
+int fitgnn_head_max_classes_wide(void);
+/* 1 when fitgnn_epilogue_bwd_head_f32 takes a head of C classes on H hidden columns (with / without dWl): besides the two
+ * limits above, C may not exceed the number of lanes that own columns of the last 256-column slab (H = 16 -> 4 classes). */
+int fitgnn_epilogue_bwd_head_supported(int32_t H, int32_t C, int32_t with_dWl);
 size_t fitgnn_epilogue_bwd_head_workspace_bytes(int32_t n_rows, int32_t H, int32_t C);
 int fitgnn_epilogue_bwd_head_f32(const float *dy, const float *Wl, int32_t C, const float *out, float *dZ,
                                  int32_t n_rows, int32_t H, uint32_t epilogue, float p_drop, uint64_t seed,

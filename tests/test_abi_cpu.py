@@ -84,6 +84,12 @@ def test_fused_gemm_epilogue_entry_points():
     # too small a workspace and N % 4 != 0 are refused before any launch
     assert L.fitgnn_gemm_nt_epilogue_bwd_f32(None, 64, None, 64, 100, 8, 64, None, None, 0, 0.0, 0, None, None, None, 0, None) == -1
     assert L.fitgnn_colsum_partials_f32(None, 1, 8, None, None) == -1
+    assert L.fitgnn_head_max_classes() == 16 and L.fitgnn_head_max_classes_wide() == 48
+    S = L.fitgnn_epilogue_bwd_head_supported
+    assert S(512, 16, 1) and S(512, 47, 0) and not S(512, 47, 1) and not S(512, 49, 0)
+    assert S(16, 4, 1) and not S(16, 7, 1)        # hidden 16: 4 lanes own columns -> at most 4 classes (Cora has 7)
+    assert S(320, 16, 1) and not S(320, 17, 0)    # last slab 64 columns = 16 lanes
+    assert S(33, 7, 1) and not S(3, 4, 1)
     assert L.fitgnn_gemm_nt_presplit_bytes(512, 512) == 2 * 16 * 32768   # 2 column tiles x 16 stages x 32-KB LDS image
     assert L.fitgnn_gemm_nt_presplit_bytes(500, 64) == 2 * 2 * 32768
     assert L.fitgnn_gemm_nt_presplit_bytes(512, 48) == 0                  # K % 32 != 0: not supported

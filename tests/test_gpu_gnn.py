@@ -529,10 +529,12 @@ def test_dx_gemm_with_the_previous_layers_epilogue(mods, layers, dedup, inject):
             assert rel(grads[True][k].cpu(), g_ref[k]) < 1e-3, k
 
 
-@pytest.mark.parametrize("hidden,classes,layers", [(256, 16, 3), (64, 2, 2), (32, 4, 2)])
+@pytest.mark.parametrize("hidden,classes,layers", [(256, 16, 3), (64, 2, 2), (32, 4, 2), (128, 47, 2), (256, 47, 2), (512, 48, 2), (256, 49, 2), (16, 7, 2), (32, 16, 2),
+                                                   (320, 17, 2)])
 def test_other_widths_through_the_gemm_kernels(mods, hidden, classes, layers):
-    """Hidden sizes on either side of the GEMM kernels' limits (64 columns, K % 32) against the oracle, training mode with
-    injected dropout masks, 4000 rows (a 16 x 1 grid of 256-row tiles: the 128 x 128 tile variant)."""
+    """Hidden sizes on either side of the GEMM kernels' limits (64 columns, K % 32) and head widths on either side of the fused
+    head-backward kernel's (16 classes with its own weight gradient, 48 without: ogbn-products has 47) against the oracle,
+    training mode with injected dropout masks, 4000 rows (a 16 x 1 grid of 256-row tiles: the 128 x 128 tile variant)."""
     network, fnn, gorc = mods
     ei, n = graph(n=4000, m=12000, seed=41)
     args = argparse.Namespace(num_layers1=layers, layer_name="GCNConv", num_features=96, hidden=hidden, num_classes=classes)
