@@ -1,118 +1,50 @@
 #!/usr/bin/env python3
 """bench.py -- edges aggregated/sec (GCN fwd+bwd) on coarsened subgraphs (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload S-products]
 
-Workload (config.workload): S-pubmed = BASELINE.json configs[1] "PubMed node_cls FIT-GNN,
-variation_neighborhoods r=0.5" on synthetic data of PubMed's shape: preferential-
-attachment graph N=19717, E=44324 (graph seed = rank), features U[0,1) row-L1-normalised F=500, 3 classes,
-coarsened by the HIP contraction step (r=0.5), one 1-hop "extra node" subgraph per cluster, all
-subgraph batches merged into one device-resident block-diagonal CSR.  A step = one GD training epoch of
-run.py:177-215: forward over every subgraph (2-layer GCN, hidden 512), one NLL loss, backward, Adam step
-(4 SpMM launches; edges aggregated = 4 * nnz').  N>1 = data parallel over subgraph shards: every rank
-holds its own S-pubmed-sized shard (weak scaling), one flat RCCL gradient all-reduce per step.
+Workload (config.workload), default S-products = BASELINE.json configs[3], the north_star target: "ogbn-products
+use_community_detection, subgraph-batch DP" on synthetic data of that shape: one community graph of
+165 000 nodes (main.py:264) with mean degree 50 (assumed; E = 4 125 000), features U[0,1) row-L1-normalised F=100, 47
+classes (main.py:243), coarsened by the HIP contraction step (variation_neighborhoods, r=0.5), one 1-hop "extra node"
+subgraph per cluster (82.5 k subgraphs, 8.2 M union rows), all loader batches merged into ONE device-resident
+block-diagonal CSR.  A step = one GD training epoch of run.py:177-215: forward over every subgraph (2-layer GCN,
+hidden 512), one NLL loss, backward, Adam step (4 SpMM launches; edges aggregated = 4 * nnz').  The other configs
+(--workload S-pubmed | S-physics | S-cora) are parity-test cases, selectable for A/B work.
 
-Prints ONE JSON line (rank 0) with `roofline` for the SpMM kernel (HIP-event timed inside the timed
-region) and `cpu_baseline` (the torch-CPU oracle of the same step, timed on this host's cores).
+N>1 = data parallel, STRONG scaling: the ONE union is sharded by whole subgraphs (data.shard_clusters: LPT over
+nnz'), every rank steps on its shard, one flat RCCL gradient all-reduce per step (train.GDTrainer).  Launch either
+under torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE in the environment) or plainly as `python bench.py --gpus N`:
+the parent then spawns N fresh children itself BEFORE it touches torch or the GPU and relays rank 0's line.
+
+Prints ONE JSON line (rank 0): the metric, `roofline` for the SpMM kernel (HIP events around its launches inside the
+timed region), `ms_per_step_fp32` (the same step with the dense products in plain fp32 instead of the 3 x bf16 split),
+and at N=1 `cpu_baseline` (the torch-CPU oracle of the same step + the C oracle of the contraction, on this host).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-for p in (ROOT, os.path.join(ROOT, "fit-gnn_amd")):
-    if p not in sys.path:
-        sys.path.insert(0, p)
-
-import numpy as np  # noqa: E402
-import scipy.sparse as sp  # noqa: E402
-import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy ceiling is ~6300
 
-WORKLOADS = {
-    # name: (N, E, F, classes, Loukas r)
-    "S-pubmed": (19717, 44324, 500, 3, 0.5),
-    "S-cora": (2708, 5278, 1433, 7, 0.5),
-    "S-physics": (34493, 247962, 8415, 5, 0.7),     # CLI --coarsening_ratio 0.3 (main.py:278 passes 1 - ratio)
-    "S-products": (165000, 4125000, 100, 47, 0.5),  # one ogbn-products community (<= 165 000 nodes, main.py:264), mean degree 50 assumed
-}
+# default (timed steps, warm-up steps) per workload; shapes: fitgnn_amd/workloads.py
+DEFAULT_STEPS = {"S-products": (30, 5), "S-pubmed": (200, 20), "S-cora": (200, 20), "S-physics": (100, 10)}
 
 
-def build_workload(name, seed, device, hidden=512):
-    from fitgnn_amd import coarsening, data
-
-    N, E, F, C, r = WORKLOADS[name]
-    t0 = time.time()
-    ei = data.synthetic_graph(N, E, seed=seed)
-    W = sp.csr_matrix((np.ones(ei.shape[1]), (ei[0], ei[1])), shape=(N, N))
-    G = coarsening.Graph(W)
-    # spectral input of the contraction step (host prelude, coarsening_utils.py:83-90), deterministic start vector
-    import scipy.sparse.linalg as spla
-    offset = 2 * max(G.dw)
-    T = offset * sp.eye(N, format="csc") - G.L
-    lk, Uk = spla.eigsh(T, k=10, which="LM", tol=1e-5, v0=np.random.default_rng(seed).standard_normal(N))
-    lk, Uk = (offset - lk)[::-1], Uk[:, ::-1]
-    t1 = time.time()
-    torch.cuda.synchronize()
-    Cmat, Gc, _ = coarsening.coarsen(G, r=r, method="variation_neighborhoods", Uk=np.ascontiguousarray(Uk), lk=lk.copy(),
-                                     device=device)
-    torch.cuda.synchronize()
-    t2 = time.time()
-    assign = sp.csc_matrix(Cmat).indices
-    sub = data.assemble_subgraphs_torch(torch.from_numpy(ei).to(device), N, assign, Cmat.shape[0], extra_node=True)
-    torch.cuda.synchronize()
-    t3 = time.time()
-    rng = np.random.default_rng(seed + 1)
-    X = rng.random((N, F), dtype=np.float32)
-    X /= X.sum(1, keepdims=True)  # --normalize_features (main.py:48)
-    y = rng.integers(0, C, size=N)
-    train_mask = np.ones(N, dtype=bool)  # every cluster node labelled: every subgraph takes part in the GD step
-    batch = data.SubgraphBatch(sub, X, y, train_mask, device=device)
-    info = dict(nodes=N, undirected_edges=E, features=F, classes=C, clusters=int(Cmat.shape[0]),
-                union_rows=batch.n_rows, nnz_prime=batch.nnz, t_graph_eig_s=round(t1 - t0, 2),
-                t_coarsen_hip_s=round(t2 - t1, 3), t_assemble_s=round(t3 - t2, 2), t_batch_csr_s=round(time.time() - t3, 2))
-    info["_coarsen_inputs"] = (W, np.ascontiguousarray(Uk), lk.copy(), r)
-    return batch, (F, C), info
-
-
-def cpu_baseline(batch, sd, num_layers, budget_s=20.0):
-    """The torch-CPU oracle of the same step (fwd + loss + bwd), timed on this host.  Sample = as many of the
-    reference's 128-subgraph loader batches (run.py:336) as fit the time budget, at least 8."""
-    from oracle import gnn_oracle as gorc
-
-    x, ei, y = batch.x.cpu(), batch.edge_index.cpu(), batch.y.cpu()
-    tm = batch.train_mask.cpu()
-    spans = batch.slice_batches(128)
-
-    def run(k):
-        r1 = spans[k - 1][1]
-        keep = ei[0] < r1
-        e = ei[:, keep]
-        t0 = time.time()
-        gorc.classify_node_fwd_bwd(sd, x[:r1], e, y[:r1], num_layers=num_layers, train_mask=tm[:r1])
-        return time.time() - t0, 4 * (int(e.shape[1]) + r1)
-
-    run(min(2, len(spans)))  # warm-up (thread pools, allocator)
-    k = min(8, len(spans))
-    dt, edges = run(k)
-    if dt < budget_s / 4 and k < len(spans):
-        k = min(len(spans), max(k + 1, int(k * (budget_s / 2) / max(dt, 1e-3))))
-        dt, edges = run(k)
-    return dict(value=edges / dt, unit="edges/s", cores=torch.get_num_threads(), kind="port",
-                sample=f"first {k} of {len(spans)} loader batches (128 subgraphs each), 1 fwd+bwd step, {dt:.2f} s")
-
-
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)   # 0.25 s of timed region: the clock and the caches have settled
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="S-pubmed")
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default per workload: S-products 30)")
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--workload", default="S-products", choices=sorted(DEFAULT_STEPS))
     ap.add_argument("--hidden", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fp32", action="store_true", help="skip the plain-fp32 re-timing of the step")
     ap.add_argument("--fold", action="store_true", help="A/B: epilogue backward folded into the transposed SpMM (slower, see DESIGN.md)")
     ap.add_argument("--prune-unused-rows", action="store_true",
                     help="NOT the headline configuration: last layer only on the clusters' own nodes (the extra nodes' outputs "
@@ -121,89 +53,220 @@ def main():
                     help="run layer 0's X@W^T on the materialised union rows (one copy per subgraph membership) instead of "
                          "the de-duplicated feature table")
     ap.add_argument("--gemm-precision", default="high", choices=["high", "highest"],
-                    help="dense GEMM policy (fitgnn_amd.ops.GEMM_PRECISION): high = fp32 via 3xbf16 split on the forward/dX "
-                         "products (rel err ~5e-6), highest = plain fp32 MFMA everywhere")
+                    help="dense GEMM policy of the timed region (ops.OpConfig.gemm_precision): high = fp32 via 3 x bf16 split "
+                         "(rel err ~5e-6), highest = plain fp32 MFMA everywhere")
+    ap.add_argument("--spectral", default="device", choices=["device", "arpack"],
+                    help="spectral prelude of the contraction (not timed): thick-restart Lanczos on the GPU, or ARPACK on the host")
     args = ap.parse_args()
+    if args.steps is None:
+        args.steps = DEFAULT_STEPS[args.workload][0]
+    if args.warmup is None:
+        args.warmup = DEFAULT_STEPS[args.workload][1]
+    return args
 
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N fresh children (one per GPU) and relay rank 0's output.
+    The parent has imported neither torch nor HIP at this point (a process that has initialised the GPU must never be the one
+    that forks / execs the ranks)."""
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   FITGNN_BENCH_CHILD="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    try:
+        while procs and rc == 0:
+            for p in list(procs):
+                code = p.poll()
+                if code is None:
+                    continue
+                procs.remove(p)
+                if code != 0:
+                    rc = code
+            time.sleep(0.2)
+    finally:
+        for p in procs:   # a rank failed (or we were interrupted): stop exactly the children started here
+            p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=30)
+            except subprocess.TimeoutExpired:
+                p.kill()
+    return rc
+
+
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def main():
+    args = parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    for p in (ROOT, os.path.join(ROOT, "fit-gnn_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import numpy as np
+    import torch
+
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     n_dev = torch.cuda.device_count()
     local_rank %= max(n_dev, 1)   # rehearsal on a box with fewer GPUs than ranks (FITGNN_BENCH_BACKEND=gloo)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    backend = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = os.environ.get("FITGNN_BENCH_BACKEND", "nccl")   # nccl = RCCL over xGMI; gloo only to rehearse the
-        if backend == "nccl":                                       # multi-process path on a single-GPU box
+        # nccl = RCCL over xGMI; gloo only to rehearse the multi-process path on a box with fewer GPUs than ranks
+        backend = os.environ.get("FITGNN_BENCH_BACKEND", "nccl" if n_dev >= world else "gloo")
+        if backend == "nccl":
             torch.distributed.init_process_group("nccl", device_id=device)
         else:
             torch.distributed.init_process_group(backend)
-    assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
-    from fitgnn_amd import network, ops, train
+    from fitgnn_amd import data, network, ops, train, workloads
 
-    ops.GEMM_PRECISION = args.gemm_precision
-    ops.FOLD_BACKWARD = args.fold
+    N, E, F, C, r = workloads.SHAPES[args.workload]
+    H = args.hidden
+    info = dict(nodes=N, undirected_edges=E, features=F, classes=C)
 
-    batch, (F, C), info = build_workload(args.workload, seed=rank, device=device, hidden=args.hidden)
-    coarsen_inputs = info.pop("_coarsen_inputs")
-    margs = argparse.Namespace(num_layers1=2, layer_name="GCNConv", num_features=F, hidden=args.hidden, num_classes=C)
-    torch.manual_seed(2)  # weight seed; identical on every rank
-    model = network.Classify_node(margs).to(device)
-    sd0 = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
-    trainer = train.GDTrainer(model, batch, lr=0.01, weight_decay=5e-4, dedup=not args.no_dedup, prune_unused_rows=args.prune_unused_rows)
+    def bcast(t):
+        """Broadcast a device tensor from rank 0 (through the host under gloo)."""
+        if backend == "gloo":
+            h = t.cpu()
+            torch.distributed.broadcast(h, 0)
+            return h.to(device)
+        torch.distributed.broadcast(t, 0)
+        return t
+
+    # ---- the ONE graph, coarsened once (rank 0), known to every rank -------------------------------------------------
+    coarsen_inputs = None
+    if rank == 0:
+        wl = workloads.coarsen_workload(args.workload, device, spectral=args.spectral)
+        coarsen_inputs = (wl["W"], wl["Uk"], wl["lk"], wl["r"])
+        info.update(wl["timings"])
+        ei_d, assign_d = torch.from_numpy(wl["ei"]).to(device), torch.from_numpy(wl["assign"]).to(device)
+        head = torch.tensor([wl["ei"].shape[1], wl["n_clusters"]], dtype=torch.int64, device=device)
+        del wl
+    else:
+        head = torch.zeros(2, dtype=torch.int64, device=device)
+    if world > 1:
+        head = bcast(head)
+        if rank != 0:
+            ei_d = torch.empty((2, int(head[0])), dtype=torch.int64, device=device)
+            assign_d = torch.empty(N, dtype=torch.int64, device=device)
+        ei_d, assign_d = bcast(ei_d), bcast(assign_d)
+    n_clusters = int(head[1])
+    info["clusters"] = n_clusters
+
+    # ---- subgraphs of every cluster (device), this rank's shard, the block-diagonal batch ----------------------------
+    t4 = time.time()
+    sub, nnz_c = workloads.assemble(args.workload, ei_d, assign_d, n_clusters)
+    torch.cuda.synchronize()
+    t5 = time.time()
+    info.update(union_rows=int(sub["ptr"][-1]), nnz_prime=int(nnz_c.sum()), t_assemble_s=round(t5 - t4, 2))
+    if world > 1:
+        owner = data.shard_clusters(None, nnz_c, world)         # LPT over nnz' (SURVEY §8e); same on every rank
+        sub = data.select_clusters(sub, np.nonzero(owner == rank)[0])
+        info["shard_nnz_prime"] = [int(nnz_c[owner == k].sum()) for k in range(world)]
+    del ei_d
+    batch = workloads.batch_from_subgraphs(args.workload, sub, device)
+    torch.cuda.synchronize()
+    info["t_batch_csr_s"] = round(time.time() - t5, 2)
+    del sub
+
+    def make_trainer(precision, profile=False):
+        margs = argparse.Namespace(num_layers1=2, layer_name="GCNConv", num_features=F, hidden=H, num_classes=C)
+        torch.manual_seed(2)  # weight seed (SURVEY §8d); identical on every rank
+        model = network.Classify_node(margs).to(device)
+        sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+        cfg = ops.OpConfig(gemm_precision=precision, fold_backward=args.fold)
+        tr = train.GDTrainer(model, batch, lr=0.01, weight_decay=5e-4, dedup=not args.no_dedup,
+                             prune_unused_rows=args.prune_unused_rows, op_config=cfg)
+        return tr, sd
 
     def barrier():
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        trainer.step()
-    barrier()
-    events = []  # HIP-event pairs around the SpMM launches of every 4th step of the timed region (each marker costs ~1 us)
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        ops.PROFILE = events if i % 4 == 0 else None
-        loss = trainer.step()
-    ops.PROFILE = None
-    barrier()
-    dt = time.perf_counter() - t0
+    def timed(tr, steps, warmup, events=None):
+        for _ in range(warmup):
+            tr.step()
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            # HIP-event pairs around the SpMM launches of every 4th step of the timed region (each marker costs ~1 us)
+            tr.cfg.profile = events if (events is not None and i % 4 == 0) else None
+            loss = tr.step()
+        tr.cfg.profile = None
+        barrier()
+        dt = torch.tensor([time.perf_counter() - t0], device=device, dtype=torch.float64)
+        if world > 1:
+            torch.distributed.all_reduce(dt, op=torch.distributed.ReduceOp.MAX)
+        return float(dt.item()), loss
+
+    trainer, sd0 = make_trainer(args.gemm_precision)
+    events = []
+    dt, loss = timed(trainer, args.steps, args.warmup, events)
     # a few more steps, outside the timed region, with events around the hand-written GEMM launches (secondary figures:
     # their markers would cost the headline 1 %)
-    ops.PROFILE_GEMM = []
+    trainer.cfg.profile_gemm = []
     for _ in range(min(args.steps, 5)):
         trainer.step()
     torch.cuda.synchronize()
-    gemm_events, ops.PROFILE_GEMM = ops.PROFILE_GEMM, None
-    tmax = torch.tensor([dt], device=device, dtype=torch.float64)
+    gemm_events, trainer.cfg.profile_gemm = trainer.cfg.profile_gemm, None
+
     edges_per_step = 4.0 * batch.nnz
     if trainer.sub is not None:   # two full SpMMs (layer 0) + the own-node rows of A_hat twice (layer 1 forward / backward)
         edges_per_step = 2.0 * batch.nnz + 2.0 * int(trainer.sub.f.col.numel())
-    edges = torch.tensor([edges_per_step * args.steps], device=device, dtype=torch.float64)
+    edges = torch.tensor([edges_per_step], device=device, dtype=torch.float64)
     if world > 1:
-        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         torch.distributed.all_reduce(edges)
-    dt, total_edges = float(tmax.item()), float(edges.item())
+    edges_per_step_total = float(edges.item())
+
+    # the same step with every dense product in plain fp32 (library MFMA fp32 kernels): what the 3 x bf16 split buys
+    fp32 = None
+    if not args.no_fp32 and args.gemm_precision == "high":
+        loss_final = float(loss)
+        tr32, _ = make_trainer("highest")
+        k32 = max(3, min(args.steps, 10))
+        dt32, _ = timed(tr32, k32, 2)
+        fp32 = dict(ms_per_step=dt32 / k32 * 1e3, value=edges_per_step_total * k32 / dt32, steps=k32)
+        del tr32
+    else:
+        loss_final = float(loss)
 
     # SpMM roofline: algorithmic bytes of one launch / mean HIP-event duration of the launches in the timed region
-    H, R = args.hidden, batch.n_rows
-    bytes_spmm = 4 * H * R + 4 * H * R + 8 * batch.nnz + 4 * (R + 1)
     # (the launches of the LDS-window kernel only: layer 0's forward on the de-duplicated table runs the direct-gather
-    # variant, whose operand is a 40-MB table, not an [R x H] matrix)
+    # variant, whose operand is a table that stays in L2 / MALL, not an [R x H] matrix)
+    R = batch.n_rows
+    bytes_spmm = 4 * H * R + 4 * H * R + 8 * batch.nnz + 4 * (R + 1)
     durs_ms = [a.elapsed_time(b) for a, b, kind in events if kind == "tile"]
     spmm_ms = float(np.mean(durs_ms)) if durs_ms else float("nan")
     achieved = bytes_spmm / (spmm_ms * 1e-3) / 1e9
-    # HBM traffic of one SpMM launch from the committed PMC profile of this same command (rocprofv3 --pmc, separate
-    # passes; gfx950 correction: FETCH_SIZE counts half of a wide coalesced read; both counters in KiB)
-    traffic = None
-    pmc_file = os.path.join(ROOT, "profiles", "r01_pmc_spmm_tile_kernel.json")
-    if args.workload == "S-pubmed" and H == 512 and os.path.exists(pmc_file):
-        with open(pmc_file) as f:
-            pmc = json.load(f)
-        traffic = (2.0 * pmc["FETCH_SIZE"]["mean"] + pmc["WRITE_SIZE"]["mean"]) * 1024.0
+    gather_ms = [a.elapsed_time(b) for a, b, kind in events if kind == "gather"]
     # the hand-written MFMA GEMM kernels of the step (secondary: the step's dominant kernel class by time, not by launch):
     # bf16 flops actually issued (three products per fp32 product) / mean HIP-event duration, against the dense bf16 peak
     by_kernel = {}
@@ -227,30 +290,44 @@ def main():
     torch.cuda.synchronize()
     copy_gbs = 10 * 2 * src.numel() * 4 / (c0.elapsed_time(c1) * 1e-3) / 1e9
     del src, dst
+
+    split = args.gemm_precision == "high"
     out = {
         "metric": "edges aggregated/sec (GCN fwd+bwd) on coarsened subgraphs",
-        "value": total_edges / dt, "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "value": edges_per_step_total * args.steps / dt, "unit": "edges/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{args.workload}: variation_neighborhoods r={WORKLOADS[args.workload][4]}, extra-node subgraphs, one block-diagonal "
-                               f"union per GPU, 2-layer GCN hidden {H}, GD step + Adam", "parallelism": f"dp{world}",
-                   "dense_gemm": ("fp32 operands split to 3 bf16 products on the MFMA pipe, fp32 accumulate (rel err ~5e-6 vs fp64): "
-                                  "hand-written kernels gemm_nt.hip (X@W^T, dH@W with the previous layer's epilogue backward fused) and "
-                                  "gemm_atb.hip (dH^T@X, split-K with a fixed-order sum); library GEMM only where K % 32 != 0 or the "
-                                  "output is a few columns wide") if args.gemm_precision == "high" else "hipBLASLt fp32 MFMA",
+        "ms_per_step_fp32": None if fp32 is None else fp32["ms_per_step"],
+        "value_fp32": None if fp32 is None else fp32["value"],
+        "config": {"workload": f"{args.workload}: variation_neighborhoods r={r}, extra-node subgraphs, ONE block-diagonal union "
+                               f"sharded over the ranks by whole subgraphs, 2-layer GCN hidden {H}, GD step + Adam",
+                   "parallelism": f"dp{world}", "backend": backend, "ranks_in_group": world if world == 1 else torch.distributed.get_world_size(),
+                   "precision": ("f32 storage and accumulation; SpMM, epilogues, loss, Adam in f32; the tall dense products as a "
+                                 "3 x bf16 split (hi.hi + hi.lo + lo.hi) on the bf16 MFMA pipe, measured 4-5e-6 relative error vs "
+                                 "fp64 (north_star tolerance 1e-4); ms_per_step_fp32 = the same step with plain fp32 MFMA library products")
+                   if split else "f32 everywhere (library fp32 MFMA products)",
+                   "dense_gemm": ("hand-written kernels gemm_nt.hip (X@W^T, dH@W with the previous layer's epilogue backward fused) and "
+                                  "gemm_atb.hip (dH^T@X, split-K with a fixed-order sum); layer 0's table zero-padded to K % 32 == 0; "
+                                  "library fp32 GEMM only for the few-column head") if split else "hipBLASLt fp32 MFMA",
                    "layer0_features": f"de-duplicated table ({info['nodes']} rows) + row indirection in the SpMM" if trainer.dedup
                    else "materialised union rows",
+                   "rank0_union_rows": R, "rank0_nnz_prime": batch.nnz,
                    **info},
-        "roofline": {"kernel": "spmm_tile_kernel<VEC=4,B=4,MPR=16> (CSR SpMM, LDS row windows, H=%d, f32)" % H, "bound": "hbm", "achieved": achieved,
-                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+        "roofline": {"kernel": "spmm_tile_kernel (CSR SpMM, LDS row windows, H=%d, f32)" % H, "bound": "hbm", "achieved": achieved,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": None,   # PMC bytes cannot be read inside the run: profiles/ holds the rocprofv3 --pmc passes of this command
                      "algorithmic_bytes_per_launch": bytes_spmm, "avg_launch_us": spmm_ms * 1e3,
                      "launches_timed": len(durs_ms), "spmm_edges_per_s": batch.nnz / (spmm_ms * 1e-3),
+                     "gather_variant_avg_launch_us": float(np.mean(gather_ms)) * 1e3 if gather_ms else None,
                      "copy_ceiling_GBps": copy_gbs, "frac_of_copy_ceiling": achieved / copy_gbs},
         "gemm_kernels": gemm_summary,
-        "loss": float(loss),
+        "loss": loss_final,
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(batch, sd0, 2)
+        out["cpu_baseline"]["cpu_model"] = cpu_model()
+        out["cpu_baseline"]["host_cores"] = os.cpu_count()
         # the contraction step of the same graph on the host: the C restatement (one core), next to the HIP time above
         from oracle import coarsen_oracle as corc
         Wc, Ukc, lkc, rc = coarsen_inputs
@@ -258,11 +335,43 @@ def main():
         corc.coarsen_oracle(Wc, K=10, r=rc, Uk=Ukc.copy(), lk=lkc.copy())
         out["cpu_baseline"]["coarsen_port_s"] = round(time.time() - t0, 3)
         out["cpu_baseline"]["coarsen_port_cores"] = 1
-        out["cpu_baseline"]["coarsen_reference_probe"] = "profiles/reference_probe_timings.json (reference Python, 8 cores: 17.97 s at this size)"
+        out["cpu_baseline"]["coarsen_reference_probe"] = ("profiles/reference_probe_timings.json (reference Python, 8 cores: "
+                                                          "17.97 s at PubMed size)")
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()
+
+
+def cpu_baseline(batch, sd, num_layers, budget_s=20.0):
+    """The torch-CPU oracle of the same step (fwd + loss + bwd), timed on this host.  Sample = as many of the
+    reference's 128-subgraph loader batches (run.py:336) as fit the time budget, at least 8."""
+    import torch
+    from oracle import gnn_oracle as gorc
+
+    spans = batch.slice_batches(128)
+    k_max = min(len(spans), 64)     # host copies of the first loader batches only (the whole union is 17 GB at S-products)
+    r_max = spans[k_max - 1][1]
+    ei_all = batch.edge_index
+    keep_all = ei_all[0] < r_max
+    x, ei, y = batch.x[:r_max].cpu(), ei_all[:, keep_all].cpu(), batch.y[:r_max].cpu()
+    tm = batch.train_mask[:r_max].cpu()
+
+    def run(k):
+        r1 = spans[k - 1][1]
+        e = ei[:, ei[0] < r1]
+        t0 = time.time()
+        gorc.classify_node_fwd_bwd(sd, x[:r1], e, y[:r1], num_layers=num_layers, train_mask=tm[:r1])
+        return time.time() - t0, 4 * (int(e.shape[1]) + r1)
+
+    run(min(2, k_max))  # warm-up (thread pools, allocator)
+    k = min(8, k_max)
+    dt, edges = run(k)
+    if dt < budget_s / 4 and k < k_max:
+        k = min(k_max, max(k + 1, int(k * (budget_s / 2) / max(dt, 1e-3))))
+        dt, edges = run(k)
+    return dict(value=edges / dt, unit="edges/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"first {k} of {len(spans)} loader batches (128 subgraphs each), 1 fwd+bwd step, {dt:.2f} s")
 
 
 if __name__ == "__main__":

@@ -266,11 +266,62 @@ class SubgraphBatch:
 
 def shard_clusters(ptr, nnz_per_cluster, world_size):
     """Static longest-processing-time assignment of whole subgraphs to ranks, balancing nnz' (SURVEY §8e)."""
-    order = np.argsort(-np.asarray(nnz_per_cluster), kind="stable")
-    load = np.zeros(world_size, dtype=np.int64)
+    import heapq
+
+    nnz = np.asarray(nnz_per_cluster, dtype=np.int64)
+    order = np.argsort(-nnz, kind="stable")
     owner = np.zeros(len(order), dtype=np.int64)
+    heap = [(0, r) for r in range(world_size)]   # (load, rank): ties go to the lowest rank, as argmin would
     for c in order:
-        r = int(np.argmin(load))
+        load, r = heapq.heappop(heap)
         owner[c] = r
-        load[r] += int(nnz_per_cluster[c])
+        heapq.heappush(heap, (load + int(nnz[c]), r))
     return owner
+
+
+def cluster_nnz(sub):
+    """nnz' of every cluster subgraph of an assemble_subgraphs* result: its directed edges + one self loop per row (the
+    non-zeros of A_hat a SpMM over the subgraph consumes; the unit shard_clusters balances)."""
+    ptr = sub["ptr"]
+    if torch.is_tensor(ptr):
+        n = int(ptr.numel()) - 1
+        src = sub["edge_index"][0]
+        owner = torch.searchsorted(ptr, src, right=True) - 1
+        return (torch.bincount(owner, minlength=n) + (ptr[1:] - ptr[:-1])).cpu().numpy()
+    n = len(ptr) - 1
+    owner = np.searchsorted(ptr, sub["edge_index"][0], side="right") - 1
+    return np.bincount(owner, minlength=n) + np.diff(ptr)
+
+
+def select_clusters(sub, clusters):
+    """The sub-union holding only `clusters` (ascending cluster ids) of an assemble_subgraphs* result, rows renumbered:
+    a rank's shard of ONE union (whole subgraphs are the unit; no edge crosses subgraphs, utils.py:248).
+    Works on the NumPy and on the torch (device) form; returns the same dict layout."""
+    if torch.is_tensor(sub["ptr"]):
+        dev = sub["ptr"].device
+        ptr = sub["ptr"].long()
+        c = torch.as_tensor(np.asarray(clusters, dtype=np.int64), device=dev)
+        size = ptr[c + 1] - ptr[c]
+        new_ptr = torch.zeros(int(c.numel()) + 1, dtype=torch.int64, device=dev)
+        new_ptr[1:] = torch.cumsum(size, 0)
+        R = int(new_ptr[-1])
+        rows = torch.repeat_interleave(ptr[c] - new_ptr[:-1], size) + torch.arange(R, device=dev)   # old row of every new row
+        new_of_old = torch.full((int(ptr[-1]),), -1, dtype=torch.int64, device=dev)
+        new_of_old[rows] = torch.arange(R, device=dev)
+        e = sub["edge_index"]
+        keep = new_of_old[e[0]] >= 0
+        e2 = torch.stack([new_of_old[e[0][keep]], new_of_old[e[1][keep]]])
+        return dict(ptr=new_ptr, node_id=sub["node_id"][rows], core=sub["core"][rows], edge_index=e2)
+    ptr = np.asarray(sub["ptr"], dtype=np.int64)
+    c = np.asarray(clusters, dtype=np.int64)
+    size = ptr[c + 1] - ptr[c]
+    new_ptr = np.zeros(len(c) + 1, dtype=np.int64)
+    np.cumsum(size, out=new_ptr[1:])
+    R = int(new_ptr[-1])
+    rows = np.repeat(ptr[c] - new_ptr[:-1], size) + np.arange(R, dtype=np.int64)
+    new_of_old = np.full(int(ptr[-1]), -1, dtype=np.int64)
+    new_of_old[rows] = np.arange(R, dtype=np.int64)
+    e = np.asarray(sub["edge_index"])
+    keep = new_of_old[e[0]] >= 0
+    return dict(ptr=new_ptr, node_id=np.asarray(sub["node_id"])[rows], core=np.asarray(sub["core"])[rows],
+                edge_index=np.stack([new_of_old[e[0][keep]], new_of_old[e[1][keep]]]))

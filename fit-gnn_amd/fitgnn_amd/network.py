@@ -44,8 +44,18 @@ class _Base(nn.Module):
         self.num_layers = args.num_layers1
         self.conv = _make_convs(args)
         self.lt1 = nn.Linear(args.hidden, args.num_classes if self.out_dim_from_classes else 1)
-        self.dropout_p = 0.5  # F.dropout default used by the reference
+        self.dropout_p = float(getattr(args, "dropout", 0.5))  # F.dropout's default p, which is what the reference uses
         self._inject_masks = None  # tests: list of uint8 masks, one per layer
+        self.op_config = ops.DEFAULT
+
+    def set_op_config(self, cfg):
+        """Run this model's kernels under `cfg` (ops.OpConfig): GEMM policy, kernel A/B switches, profiling hooks, seed
+        bank.  Per model: two models in one process keep their own."""
+        self.op_config = cfg
+        for m in self.modules():
+            if isinstance(m, fnn._OpConfigured):
+                m.op_config = cfg
+        return self
 
     def reset_parameters(self):
         for m in self.conv:
@@ -59,9 +69,10 @@ class _Base(nn.Module):
             return None
         mask = self._inject_masks[0] if self._inject_masks is not None else None
         g = conv.graph(edge_index, int(x_index.index.numel()))
-        seed = ops.next_seed() if (self.training and self.dropout_p > 0 and mask is None) else 0
+        cfg = self.op_config
+        seed = ops.next_seed(cfg) if (self.training and self.dropout_p > 0 and mask is None) else 0
         return ops.FusedGCNLayerDedup.apply(x_table.float(), conv.lin.weight, conv.bias, g, x_index, float(self.dropout_p),
-                                            bool(self.training), seed, mask, link_out)
+                                            bool(self.training), seed, mask, link_out, cfg)
 
     def embed(self, x, edge_index, x_index=None, first=0, link=None):
         """conv -> ELU -> dropout, num_layers times (network.py:29-33).  link: the EpilogueLink recorded by the layer that
@@ -127,9 +138,10 @@ class _Base(nn.Module):
                 link = None
         mask = self._inject_masks[L - 1] if self._inject_masks is not None else None
         g = last.graph(edge_index, x.shape[0])
-        seed = ops.next_seed() if (self.training and self.dropout_p > 0 and mask is None) else 0
+        cfg = self.op_config
+        seed = ops.next_seed(cfg) if (self.training and self.dropout_p > 0 and mask is None) else 0
         return ops.FusedGCNLayerHead.apply(x, last.lin.weight, last.bias, self.lt1.weight, self.lt1.bias, g,
-                                           float(self.dropout_p), bool(self.training), seed, mask, link)
+                                           float(self.dropout_p), bool(self.training), seed, mask, link, cfg)
 
     def _embed_and_head_rows(self, x, edge_index, x_index, sub):
         L = self.num_layers
@@ -149,8 +161,8 @@ class _Base(nn.Module):
             mask = self._inject_masks[i] if self._inject_masks is not None else None
             x = conv.forward_elu_dropout(x, edge_index, p=self.dropout_p, training=self.training, mask=mask) \
                 if isinstance(conv, fnn.GCNConv) else F.dropout(F.elu(conv(x, edge_index)), p=self.dropout_p, training=self.training)
-        agg = ops.SpMMRows.apply(x, sub)                                   # [m, H_in]
-        z = ops.Linear.apply(agg, last.lin.weight)
+        agg = ops.SpMMRows.apply(x, sub, self.op_config)                   # [m, H_in]
+        z = ops.Linear.apply(agg, last.lin.weight, self.op_config)
         if last.bias is not None:
             z = z + last.bias
         mask = self._inject_masks[L - 1] if self._inject_masks is not None else None
@@ -164,7 +176,7 @@ class _Base(nn.Module):
     def head(self, x):
         """lt1 (network.py:34): same parameters as nn.Linear, evaluated as mm + broadcast add."""
         if x.is_cuda:
-            return ops.SmallLinear.apply(x, self.lt1.weight, self.lt1.bias)
+            return ops.SmallLinear.apply(x, self.lt1.weight, self.lt1.bias, self.op_config)
         return self.lt1(x)
 
 

@@ -16,13 +16,19 @@ from . import ops
 from .csr import csr_for
 
 
+class _OpConfigured:
+    """Mixin: the ops.OpConfig a layer's kernels run under (`op_config`; the package default unless set on the instance,
+    e.g. by network._Base.set_op_config)."""
+    op_config = ops.DEFAULT
+
+
 def glorot_(w):
     a = math.sqrt(6.0 / (w.size(-2) + w.size(-1)))
     with torch.no_grad():
         w.uniform_(-a, a)
 
 
-class GCNConv(nn.Module):
+class GCNConv(_OpConfigured, nn.Module):
     """out = D^-1/2 (A+I) D^-1/2 (x W^T) + b   (PyG GCNConv defaults: add_self_loops, normalize, bias)."""
 
     def __init__(self, in_channels, out_channels, bias=True):
@@ -42,34 +48,35 @@ class GCNConv(nn.Module):
 
     def forward(self, x, edge_index):
         g = self.graph(edge_index, x.shape[0])
-        h = ops.Linear.apply(x.float(), self.lin.weight)
-        return ops.SpMM.apply(h, self.bias, g)
+        h = ops.Linear.apply(x.float(), self.lin.weight, self.op_config)
+        return ops.SpMM.apply(h, self.bias, g, self.op_config)
 
     def forward_elu_dropout(self, x, edge_index, p=0.5, training=False, mask=None, graph=None, link_in=None, link_out=None):
         """conv -> F.elu -> F.dropout (network.py:31-33) as one GEMM + one SpMM with fused epilogue.
         link_in / link_out (ops.EpilogueLink): x is the un-shared output of the previous fused layer / the output goes to
         exactly one next fused layer (sequential stacks only, see ops.EpilogueLink)."""
         g = graph if graph is not None else self.graph(edge_index, x.shape[0])
-        seed = ops.next_seed() if (training and p > 0 and mask is None) else 0
-        return ops.FusedGCNLayer.apply(x, self.lin.weight, self.bias, g, float(p), bool(training), seed, mask, link_in, link_out)
+        cfg = self.op_config
+        seed = ops.next_seed(cfg) if (training and p > 0 and mask is None) else 0
+        return ops.FusedGCNLayer.apply(x, self.lin.weight, self.bias, g, float(p), bool(training), seed, mask, link_in, link_out, cfg)
 
     def extra_repr(self):
         return f"{self.in_channels}, {self.out_channels}"
 
 
-class Linear(nn.Linear):
+class Linear(_OpConfigured, nn.Linear):
     """torch.nn.Linear (same parameters, same state_dict keys) whose products run under ops' GEMM policy on the GPU:
     3 x bf16-split MFMA for x W^T and dy W, the split-K batched product for the weight gradient dy^T x (torch's own
     fp32 path takes 400-540 us per product on a 90 k-row batch, 2.5x longer)."""
 
     def forward(self, x):
         if x.is_cuda and x.dim() == 2:
-            y = ops.Linear.apply(x.float(), self.weight)
+            y = ops.Linear.apply(x.float(), self.weight, self.op_config)
             return y if self.bias is None else y + self.bias
         return super().forward(x)
 
 
-class SAGEConv(nn.Module):
+class SAGEConv(_OpConfigured, nn.Module):
     """out = W_l mean_{j in N(i)} x_j + b_l + W_r x_i   (PyG SAGEConv defaults: aggr='mean', root_weight)."""
 
     def __init__(self, in_channels, out_channels, bias=True):
@@ -87,13 +94,13 @@ class SAGEConv(nn.Module):
         g = csr_for(edge_index, x.shape[0], "mean")
         x = x.float()
         if self.in_channels <= self.out_channels:  # aggregate in the narrower space; mean and Linear commute
-            agg = ops.SpMM.apply(x, None, g)
+            agg = ops.SpMM.apply(x, None, g, self.op_config)
             return self.lin_l(agg) + self.lin_r(x)
-        h = ops.Linear.apply(x, self.lin_l.weight)
-        return ops.SpMM.apply(h, None, g) + (self.lin_l.bias if self.lin_l.bias is not None else 0.0) + self.lin_r(x)
+        h = ops.Linear.apply(x, self.lin_l.weight, self.op_config)
+        return ops.SpMM.apply(h, None, g, self.op_config) + (self.lin_l.bias if self.lin_l.bias is not None else 0.0) + self.lin_r(x)
 
 
-class GINConv(nn.Module):
+class GINConv(_OpConfigured, nn.Module):
     """out = nn((1 + eps) x_i + sum_{j in N(i)} x_j)   (PyG GINConv; FIT-GNN passes train_eps=True)."""
 
     def __init__(self, nn_module, eps=0.0, train_eps=False):
@@ -116,10 +123,10 @@ class GINConv(nn.Module):
     def forward(self, x, edge_index):
         g = csr_for(edge_index, x.shape[0], "sum")
         x = x.float()
-        return self.nn((1.0 + self.eps) * x + ops.SpMM.apply(x, None, g))
+        return self.nn((1.0 + self.eps) * x + ops.SpMM.apply(x, None, g, self.op_config))
 
 
-class GATConv(nn.Module):
+class GATConv(_OpConfigured, nn.Module):
     """PyG GATConv with the arguments FIT-GNN passes (network.py:13-17: `GATConv(in, out)` -> heads=1, concat,
     negative_slope=0.2, dropout=0, add_self_loops, bias).  Parameters: lin.weight [out,in], att_src [1,1,out],
     att_dst [1,1,out], bias [out] (PyG >= 2.4 naming)."""
@@ -144,19 +151,22 @@ class GATConv(nn.Module):
 
     def forward(self, x, edge_index):
         g = csr_for(edge_index, x.shape[0], "gat")
-        h = ops.Linear.apply(x.float(), self.lin.weight)
-        return ops.GATAggregate.apply(h, self.att_src.view(-1), self.att_dst.view(-1), self.bias, g, self.negative_slope)
+        cfg = self.op_config
+        h = ops.Linear.apply(x.float(), self.lin.weight, cfg)
+        return ops.GATAggregate.apply(h, self.att_src.view(-1), self.att_dst.view(-1), self.bias, g, self.negative_slope,
+                                      False, 0.0, False, 0, None, cfg)
 
     def forward_elu_dropout(self, x, edge_index, p=0.5, training=False, mask=None):
         """conv -> F.elu -> F.dropout (network.py:31-33) with the activation in the aggregation kernel's epilogue."""
         g = csr_for(edge_index, x.shape[0], "gat")
-        h = ops.Linear.apply(x.float(), self.lin.weight)
-        seed = ops.next_seed() if (training and p > 0 and mask is None) else 0
+        cfg = self.op_config
+        h = ops.Linear.apply(x.float(), self.lin.weight, cfg)
+        seed = ops.next_seed(cfg) if (training and p > 0 and mask is None) else 0
         return ops.GATAggregate.apply(h, self.att_src.view(-1), self.att_dst.view(-1), self.bias, g, self.negative_slope,
-                                      True, float(p), bool(training), seed, mask)
+                                      True, float(p), bool(training), seed, mask, cfg)
 
 
-class APPNP(nn.Module):
+class APPNP(_OpConfigured, nn.Module):
     """z <- (1-alpha) A_hat z + alpha z0, K times (Baselines/SGGC/APPNP/networks.py:11,23: K=10, alpha=0.1)."""
 
     def __init__(self, K, alpha, dropout=0.0):
@@ -173,7 +183,7 @@ class APPNP(nn.Module):
             return ops.APPNPPropagate.apply(z0, g, int(self.K), float(self.alpha))
         z = z0
         for _ in range(self.K):
-            z = ops.SpMM.apply(z, None, g) * (1.0 - self.alpha) + self.alpha * z0
+            z = ops.SpMM.apply(z, None, g, self.op_config) * (1.0 - self.alpha) + self.alpha * z0
         return z
 
 

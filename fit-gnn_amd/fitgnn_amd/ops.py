@@ -1,8 +1,9 @@
 """torch-facing wrappers over the C ABI (include/fitgnn_hip.h) + the autograd Functions built on them.
 
 torch supplies device memory, the current HIP stream and autograd bookkeeping; all arithmetic of the
-message-passing path is done by libfitgnn_hip.so.  Dense `X @ W^T` stays a library GEMM (torch.mm ->
-hipBLASLt on MFMA), as BASELINE.json's north_star prescribes.
+message-passing path is done by libfitgnn_hip.so, the tall dense products of a layer included (MFMA kernels
+csrc/gemm_nt.hip / gemm_atb.hip; BASELINE.json's north_star: MFMA for the dense weight GEMM).  Nothing here is
+process-wide mutable state: switches travel in an OpConfig argument.
 """
 import ctypes
 
@@ -12,77 +13,95 @@ from . import _lib
 from ._lib import EPI_BIAS, EPI_DROPOUT, EPI_ELU
 
 
-# bench.py sets this to a list to collect a (start, end) HIP-event pair around every SpMM launch; the events are
-# recorded on the stream the kernel is launched on (torch's current stream).
-PROFILE = None
+class OpConfig:
+    """Switches of the op layer, owned by whoever issues the ops (a trainer, a model, one call) -- there is no
+    process-wide mutable state: every wrapper and autograd Function below takes the config it runs under as an
+    argument (the Functions keep it on `ctx` for their backward, which autograd runs on another thread), so two
+    trainers / streams / devices in one process never see each other's settings (re-entrant).
+
+    gemm_precision   dense GEMM policy (BASELINE.json north_star: MFMA for the dense weight GEMMs).
+                     "high": the tall fp32 products of a Linear as three bf16 products (hi.hi + hi.lo + lo.hi of the
+                     two-term split of each operand) on the bf16 MFMA pipe with fp32 accumulation -- measured 4-5e-6
+                     relative error vs fp64 -- through the hand-written kernels csrc/gemm_nt.hip (x @ W^T, dH @ W) and
+                     csrc/gemm_atb.hip (dH^T @ x).  Shapes they do not take (operands narrower than 64 columns, fewer
+                     than 1024 rows, a non-static operand whose K is not a multiple of 32) run as plain fp32 library
+                     products.  "highest": the library's fp32 MFMA kernels everywhere.
+    atb_kernel / nt_kernel / nt_presplit / fuse_dx_epilogue   switch the hand-written kernels off one by one (A/B).
+    fold_backward    use fitgnn_spmm_epilogue_bwd_f32 (dZ kept in LDS) when the graph / shape allow it.  Off: measured
+                     no faster than the two kernels (DESIGN.md "folded backward").
+    dedup_gather     layer 0 on a de-duplicated table through the direct-gather SpMM variant.
+    pad_table_min_k  static feature tables at least this wide whose width is not a multiple of 32 run layer 0's
+                     products on a copy zero-padded once (real feature widths: 100, 500, 1 433, 8 415).
+    profile / profile_gemm / profile_fused   None, or a list that collects HIP-event pairs around the SpMM / hand-written
+                     GEMM / folded-backward launches (recorded on the stream the kernel is launched on).
+    seed_bank        None, or a SeedBank supplying device-resident dropout seeds (steps captured in a hipGraph)."""
+    __slots__ = ("gemm_precision", "atb_kernel", "nt_kernel", "nt_presplit", "fuse_dx_epilogue", "fold_backward",
+                 "dedup_gather", "pad_table_min_k", "profile", "profile_gemm", "profile_fused", "seed_bank")
+
+    def __init__(self, gemm_precision="high", atb_kernel=True, nt_kernel=True, nt_presplit=True, fuse_dx_epilogue=True,
+                 fold_backward=False, dedup_gather=True, pad_table_min_k=0, profile=None, profile_gemm=None,
+                 profile_fused=None, seed_bank=None):
+        if gemm_precision not in ("high", "highest"):
+            raise ValueError(f"gemm_precision {gemm_precision!r}: 'high' or 'highest'")
+        self.gemm_precision, self.atb_kernel, self.nt_kernel, self.nt_presplit = gemm_precision, atb_kernel, nt_kernel, nt_presplit
+        self.fuse_dx_epilogue, self.fold_backward, self.dedup_gather = fuse_dx_epilogue, fold_backward, dedup_gather
+        self.pad_table_min_k = pad_table_min_k
+        self.profile, self.profile_gemm, self.profile_fused, self.seed_bank = profile, profile_gemm, profile_fused, seed_bank
+
+    def replace(self, **kw):
+        """A copy with some fields changed."""
+        cur = {k: getattr(self, k) for k in self.__slots__}
+        cur.update(kw)
+        return OpConfig(**cur)
 
 
-# Dense GEMM policy (BASELINE.json north_star: MFMA for the dense weight GEMMs).
-# "high": every fp32 product as three bf16 products (hi.hi + hi.lo + lo.hi of the two-term split of each operand) on the
-# bf16 MFMA pipe with fp32 accumulation -- measured 4-5e-6 relative error vs fp64.  The tall products of a Linear run on
-# the hand-written kernels csrc/gemm_nt.hip (x @ W^T, dH @ W) and csrc/gemm_atb.hip (dH^T @ x); shapes they do not take
-# (K % 32 != 0, operands narrower than 64 columns, fewer than 1024 rows) go to hipBLASLt in its equivalent mode (2.2x
-# faster than its fp32 MFMA kernels), the weight-gradient fallback as a split-K batched product (mm_at_b).
-# "highest" everywhere = the library's plain fp32 MFMA kernels.
-GEMM_PRECISION = "high"
-# a^T @ b (weight gradients) through csrc/gemm_atb.hip instead of the library's batched split-K form
-ATB_KERNEL = True
+DEFAULT = OpConfig()   # what ops run under when their caller names no config; never modified by this package
 
 
-def mm(a, b, allow_split=True):
-    if GEMM_PRECISION == "high" and allow_split:
-        prev = torch.get_float32_matmul_precision()
-        torch.set_float32_matmul_precision("high")
-        try:
-            return torch.mm(a, b)
-        finally:
-            torch.set_float32_matmul_precision(prev)
+def mm(a, b):
+    """Library fp32 product (hipBLASLt fp32 MFMA kernels): the fallback for shapes the hand-written kernels do not take."""
     return torch.mm(a, b)
-
-
-# x @ W^T and dH @ W through csrc/gemm_nt.hip instead of the library: 174 vs 188 us alone, 1.35 -> 1.30 ms per step
-NT_KERNEL = True
 
 
 def _full_grid(R, N):
     return ((R + 255) // 256) * ((N + 255) // 256) >= 128
 
 
-def _nt_ok(a, b):
+def _nt_ok(a, b, cfg):
     """a [R, K] @ b [N, K]^T can run on csrc/gemm_nt.hip.  b may be a strided view (e.g. W.t()) when the pre-split path
     applies: it reads b through its strides."""
-    if not (NT_KERNEL and GEMM_PRECISION == "high" and a.is_cuda and a.dtype == torch.float32 and b.dtype == torch.float32
+    if not (cfg.nt_kernel and cfg.gemm_precision == "high" and a.is_cuda and a.dtype == torch.float32 and b.dtype == torch.float32
             and a.dim() == 2 and b.dim() == 2 and a.stride(1) == 1 and a.shape[1] % 32 == 0 and a.shape[0] >= 1024
             and b.shape[0] >= 64 and a.stride(0) % 4 == 0 and a.data_ptr() % 16 == 0):
         return False
-    if NT_PRESPLIT and _full_grid(a.shape[0], b.shape[0]):
+    if cfg.nt_presplit and _full_grid(a.shape[0], b.shape[0]):
         return True
     return b.stride(1) == 1 and b.stride(0) % 4 == 0 and b.data_ptr() % 16 == 0
 
 
-def mm_xwt(x, W):
+def mm_xwt(x, W, cfg=DEFAULT):
     """x [R, K] @ W [N, K]^T (a Linear's forward) under the GEMM policy."""
-    if _nt_ok(x, W):
-        return gemm_nt(x, W)
+    if _nt_ok(x, W, cfg):
+        return gemm_nt(x, W, cfg)
     return mm(x, W.t())
 
 
-def _wt_operand(a, W):
+def _wt_operand(a, W, cfg):
     """W^T as the b operand of a @ W: the strided view when the pre-split path will read it through its strides (no copy),
     else a contiguous transpose."""
-    if NT_PRESPLIT and NT_KERNEL and _full_grid(a.shape[0], W.shape[1]):
+    if cfg.nt_presplit and cfg.nt_kernel and _full_grid(a.shape[0], W.shape[1]):
         return W.t()
     return W.t().contiguous()
 
 
-def mm_by_transposed(a, W):
+def mm_by_transposed(a, W, cfg=DEFAULT):
     """a @ W for a square-ish weight W [out, in]: the library's kernel for a row-major right operand (NN) takes 201 us on
     the S-pubmed union, the one for a transposed right operand (the forward's x @ W^T form) 160 us -- materialise W^T
     (1 MB) and use the latter.  Bit-identical result."""
     if a.is_cuda and W.dim() == 2 and W.shape[0] >= 64 and W.shape[1] >= 64:
-        Wt = _wt_operand(a, W)
-        if _nt_ok(a, Wt):
-            return gemm_nt(a, Wt)
+        Wt = _wt_operand(a, W, cfg)
+        if _nt_ok(a, Wt, cfg):
+            return gemm_nt(a, Wt, cfg)
         return mm(a, W.t().contiguous().t())
     return mm(a, W)
 
@@ -92,39 +111,34 @@ def _atb_ok(t):
             and t.shape[1] % 4 == 0 and t.shape[1] >= 4 and t.data_ptr() % 16 == 0)
 
 
-PROFILE_GEMM = None   # bench.py: list of (start event, end event, kernel name, bf16 flops) per hand-written GEMM launch
-
-
-def _gemm_events(name, flops):
-    if PROFILE_GEMM is None:
+def _gemm_events(cfg, name, flops):
+    """cfg.profile_gemm: list of (start event, end event, kernel name, bf16 flops) per hand-written GEMM launch."""
+    if cfg.profile_gemm is None:
         return None
     ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), name, flops)
     ev[0].record()
     return ev
 
 
-def _gemm_done(ev):
+def _gemm_done(cfg, ev):
     if ev is not None:
         ev[1].record()
-        PROFILE_GEMM.append(ev)
+        cfg.profile_gemm.append(ev)
 
 
-def gemm_atb(a, b):
+def gemm_atb(a, b, cfg=DEFAULT):
     """a^T @ b through the hand-written split-K MFMA kernel (csrc/gemm_atb.hip): 3 x bf16 products, fp32 accumulate,
     fixed-order sum of the row chunks."""
     L = _lib.lib()
     R, M, N = a.shape[0], a.shape[1], b.shape[1]
     ws = torch.empty(int(L.fitgnn_gemm_atb_workspace_bytes(R, M, N)) // 4, dtype=torch.float32, device=a.device)
     out = torch.empty((M, N), dtype=torch.float32, device=a.device)
-    ev = _gemm_events("gemm_atb_kernel+atb_reduce_kernel", 6.0 * R * M * N)
+    ev = _gemm_events(cfg, "gemm_atb_kernel+atb_reduce_kernel", 6.0 * R * M * N)
     rc = L.fitgnn_gemm_atb_f32(_lib.dptr(a), a.stride(0), _lib.dptr(b), b.stride(0), R, M, N, _lib.dptr(out), _lib.dptr(ws),
                                _lib.stream_ptr(a.device))
-    _gemm_done(ev)
+    _gemm_done(cfg, ev)
     _lib.check(rc, "fitgnn_gemm_atb_f32")
     return out
-
-
-NT_PRESPLIT = True   # pre-split the small operand once per call and stage it by LDS-DMA (full 256 x 256 grids only)
 
 
 def _presplit(b, K_pad=None):
@@ -140,8 +154,8 @@ def _presplit(b, K_pad=None):
 
 
 def padded_table(x):
-    """A static operand table whose width is not a multiple of 32 (real feature widths: 500, 1 433, 8 415), zero-padded once
-    to the next multiple so that the hand-written GEMM kernels can take it; cached on the tensor object."""
+    """A static operand table whose width is not a multiple of 32 (real feature widths: 100, 500, 1 433, 8 415), zero-padded
+    once to the next multiple so that the hand-written GEMM kernels can take it; cached on the tensor object."""
     pad = getattr(x, "_fitgnn_pad", None)
     if pad is None or pad[0] != x._version:
         Kp = (x.shape[1] + 31) // 32 * 32
@@ -151,40 +165,37 @@ def padded_table(x):
     return pad[1]
 
 
-def gemm_nt_padded_k(a_pad, b):
+def gemm_nt_padded_k(a_pad, b, cfg=DEFAULT):
     """a_pad [R, K'] (zero columns from K = b.shape[1] on) @ b [N, K]^T through the pre-split path."""
     L = _lib.lib()
     R, Kp, N = a_pad.shape[0], a_pad.shape[1], b.shape[0]
     out = torch.empty((R, N), dtype=torch.float32, device=a_pad.device)
     img = _presplit(b, K_pad=Kp)
-    ev = _gemm_events("gemm_nt_kernel<4,false,true>", 6.0 * R * N * Kp)
+    ev = _gemm_events(cfg, "gemm_nt_kernel<4,false,true>", 6.0 * R * N * Kp)
     rc = L.fitgnn_gemm_nt_pre_f32(_lib.dptr(a_pad), a_pad.stride(0), _lib.dptr(img), R, N, Kp, _lib.dptr(out), N,
                                   _lib.stream_ptr(a_pad.device))
-    _gemm_done(ev)
+    _gemm_done(cfg, ev)
     _lib.check(rc, "fitgnn_gemm_nt_pre_f32")
     return out
 
 
-# layer 0 on a wide, static feature table whose width is not a multiple of 32: run the products on a zero-padded copy
-WIDE_TABLE_MIN_K = 1024
+def _padded_table_path(Xt, W, cfg):
+    """Layer 0 on a static feature table whose width is not a multiple of 32: run its two products on a zero-padded copy."""
+    return (cfg.nt_kernel and cfg.atb_kernel and cfg.nt_presplit and cfg.gemm_precision == "high" and Xt.is_cuda
+            and Xt.dtype == torch.float32 and Xt.shape[1] % 32 != 0 and Xt.shape[1] >= cfg.pad_table_min_k and not Xt.requires_grad
+            and W.shape[0] % 4 == 0 and W.shape[0] >= 64 and Xt.shape[0] >= 1024)
 
 
-def _wide_table(Xt, W):
-    return (NT_KERNEL and ATB_KERNEL and NT_PRESPLIT and GEMM_PRECISION == "high" and Xt.is_cuda and Xt.dtype == torch.float32
-            and Xt.shape[1] % 32 != 0 and Xt.shape[1] >= WIDE_TABLE_MIN_K and not Xt.requires_grad and W.shape[0] % 4 == 0
-            and W.shape[0] >= 64 and _full_grid(Xt.shape[0], W.shape[0]))
-
-
-def gemm_nt(a, b):
+def gemm_nt(a, b, cfg=DEFAULT):
     """a [R, K] @ b [N, K]^T through the hand-written MFMA kernel (csrc/gemm_nt.hip).  b may be any strided view."""
     L = _lib.lib()
     R, K, N = a.shape[0], a.shape[1], b.shape[0]
     out = torch.empty((R, N), dtype=torch.float32, device=a.device)
-    if NT_PRESPLIT and _full_grid(R, N):
+    if cfg.nt_presplit and _full_grid(R, N):
         img = _presplit(b)
-        ev = _gemm_events("gemm_nt_kernel<4,false,true>", 6.0 * R * N * K)
+        ev = _gemm_events(cfg, "gemm_nt_kernel<4,false,true>", 6.0 * R * N * K)
         rc = L.fitgnn_gemm_nt_pre_f32(_lib.dptr(a), a.stride(0), _lib.dptr(img), R, N, K, _lib.dptr(out), N, _lib.stream_ptr(a.device))
-        _gemm_done(ev)
+        _gemm_done(cfg, ev)
         _lib.check(rc, "fitgnn_gemm_nt_pre_f32")
         return out
     b = b.contiguous()
@@ -193,7 +204,7 @@ def gemm_nt(a, b):
     return out
 
 
-def gemm_nt_epilogue_bwd(a, b, out, epilogue, p=0.0, seed=0, mask=None, want_db=True):
+def gemm_nt_epilogue_bwd(a, b, out, epilogue, p=0.0, seed=0, mask=None, want_db=True, cfg=DEFAULT):
     """(dZ, db) with dOut = a @ b^T formed inside the GEMM and transformed in its epilogue (csrc/gemm_nt.hip, EPI):
     what mm + epilogue_bwd_raw compute, without the [R x N] round trip of dOut."""
     _lib.require_cuda(a, b, out, mask)
@@ -204,50 +215,45 @@ def gemm_nt_epilogue_bwd(a, b, out, epilogue, p=0.0, seed=0, mask=None, want_db=
     db = torch.empty(N, dtype=torch.float32, device=a.device) if want_db else None
     wb = int(L.fitgnn_gemm_nt_epilogue_bwd_workspace_bytes(R, N))
     work = torch.empty(max(wb, 4), dtype=torch.uint8, device=a.device)
-    if NT_PRESPLIT and _full_grid(R, N):
+    if cfg.nt_presplit and _full_grid(R, N):
         b_arg, ldb = _presplit(b), 0
     else:
         b_arg = b.contiguous()
         ldb = b_arg.stride(0)
-    ev = _gemm_events("gemm_nt_kernel<4,true,%s>" % ("true" if ldb == 0 else "false"), 6.0 * R * N * K)
+    ev = _gemm_events(cfg, "gemm_nt_kernel<4,true,%s>" % ("true" if ldb == 0 else "false"), 6.0 * R * N * K)
     rc = L.fitgnn_gemm_nt_epilogue_bwd_f32(_lib.dptr(a), a.stride(0), _lib.dptr(b_arg), ldb, R, N, K, _lib.dptr(out),
                                            _lib.dptr(dZ), epilogue, float(p), seed, _lib.dptr(mask), _lib.dptr(db),
                                            _lib.dptr(work), wb, _lib.stream_ptr(a.device))
-    _gemm_done(ev)
+    _gemm_done(cfg, ev)
     _lib.check(rc, "fitgnn_gemm_nt_epilogue_bwd_f32")
     return dZ, db
 
 
-def mm_at_b(a, b):
+def mm_at_b(a, b, cfg=DEFAULT):
     """a^T @ b for tall operands a [R, M], b [R, N] (the weight-gradient product dH^T @ X, reduction over all R
-    rows).  hipBLASLt serves this huge-K / small-MN shape poorly as one GEMM (541 us for R = 90k, M = N = 512); as a
-    batched GEMM over ~1400-row slices plus a sum of the partial products it takes 232 us (3xbf16 split) / 394 us
-    (fp32) -- split-K by hand.  The partials are summed in a fixed order: reproducible."""
+    rows): the hand-written split-K kernel where it applies.  Otherwise the library: hipBLASLt serves this huge-K /
+    small-MN shape poorly as one GEMM (541 us for R = 90k, M = N = 512); as a batched GEMM over ~1400-row slices plus
+    a sum of the partial products it takes 394 us -- split-K by hand.  The partials are summed in a fixed order:
+    reproducible."""
     R = a.shape[0]
-    if (GEMM_PRECISION == "high" and ATB_KERNEL and R >= 256 and min(a.shape[1], b.shape[1]) >= 64 and _atb_ok(a)
+    if (cfg.gemm_precision == "high" and cfg.atb_kernel and R >= 256 and min(a.shape[1], b.shape[1]) >= 64 and _atb_ok(a)
             and _atb_ok(b)):  # narrower operands would leave most of a 256 x 256 tile multiplying padding
-        return gemm_atb(a, b)
+        return gemm_atb(a, b, cfg)
     B = R // 1408
     if B < 4:
-        return mm(a.t(), b, allow_split=False)
+        return mm(a.t(), b)
     Kc = R // B
     main = B * Kc
-    prev = torch.get_float32_matmul_precision()
-    if GEMM_PRECISION == "high":
-        torch.set_float32_matmul_precision("high")
-    try:
-        part = torch.bmm(a[:main].view(B, Kc, a.shape[1]).transpose(1, 2), b[:main].view(B, Kc, b.shape[1]))
-        W = part.shape[1] * part.shape[2]
-        if part.is_cuda and W % 4 == 0:
-            out = torch.empty(part.shape[1:], dtype=torch.float32, device=part.device)
-            _lib.check(_lib.lib().fitgnn_sum_leading_f32(_lib.dptr(part), B, W, _lib.dptr(out), _lib.stream_ptr(part.device)),
-                       "fitgnn_sum_leading_f32")
-        else:
-            out = part.sum(0)
-        if main < R:
-            out = out + torch.mm(a[main:].t(), b[main:])
-    finally:
-        torch.set_float32_matmul_precision(prev)
+    part = torch.bmm(a[:main].view(B, Kc, a.shape[1]).transpose(1, 2), b[:main].view(B, Kc, b.shape[1]))
+    W = part.shape[1] * part.shape[2]
+    if part.is_cuda and W % 4 == 0:
+        out = torch.empty(part.shape[1:], dtype=torch.float32, device=part.device)
+        _lib.check(_lib.lib().fitgnn_sum_leading_f32(_lib.dptr(part), B, W, _lib.dptr(out), _lib.stream_ptr(part.device)),
+                   "fitgnn_sum_leading_f32")
+    else:
+        out = part.sum(0)
+    if main < R:
+        out = out + torch.mm(a[main:].t(), b[main:])
     return out
 
 
@@ -255,16 +261,17 @@ class Linear(torch.autograd.Function):
     """h = x W^T (GCNConv's bias-free Linear) under the GEMM policy above."""
 
     @staticmethod
-    def forward(ctx, x, W):
+    def forward(ctx, x, W, cfg):
         ctx.save_for_backward(x, W)
-        return mm_xwt(x, W)
+        ctx.cfg = cfg
+        return mm_xwt(x, W, cfg)
 
     @staticmethod
     def backward(ctx, dh):
         x, W = ctx.saved_tensors
-        dx = mm_by_transposed(dh, W) if ctx.needs_input_grad[0] else None
-        dW = mm_at_b(dh, x) if ctx.needs_input_grad[1] else None
-        return dx, dW
+        dx = mm_by_transposed(dh, W, ctx.cfg) if ctx.needs_input_grad[0] else None
+        dW = mm_at_b(dh, x, ctx.cfg) if ctx.needs_input_grad[1] else None
+        return dx, dW, None
 
 
 def colsum_narrow(x):
@@ -287,8 +294,9 @@ class SmallLinear(torch.autograd.Function):
     kernel for [90k x 512] @ [512 x 3]; mm + a broadcast add is 10x faster.  Same arithmetic."""
 
     @staticmethod
-    def forward(ctx, x, W, b):
+    def forward(ctx, x, W, b, cfg):
         ctx.save_for_backward(x, W)
+        ctx.cfg = cfg
         y = torch.mm(x, W.t())
         return y if b is None else y + b
 
@@ -298,9 +306,9 @@ class SmallLinear(torch.autograd.Function):
         dx = torch.mm(dy, W) if ctx.needs_input_grad[0] else None
         # dy^T x is [classes x rows] @ [rows x hidden]: the library's kernel for that shape takes 340 us on a 90 k-row batch,
         # the split-K batched product 20
-        dW = mm_at_b(_f32c(dy), _f32c(x)) if ctx.needs_input_grad[1] else None
+        dW = mm_at_b(_f32c(dy), _f32c(x), ctx.cfg) if ctx.needs_input_grad[1] else None
         db = colsum_narrow(dy) if ctx.needs_input_grad[2] else None
-        return dx, dW, db
+        return dx, dW, db, None
 
 
 class SoftmaxNLL(torch.autograd.Function):
@@ -339,7 +347,7 @@ def _f32c(t):
 
 
 def spmm_raw(rowptr, col, val, tiles, X, n_rows, bias=None, epilogue=0, p=0.0, seed=0, mask=None, out=None, window_rows=0,
-             lcol=None, win_cols=None, xrow=None):
+             lcol=None, win_cols=None, xrow=None, cfg=DEFAULT):
     """Y = epilogue(A @ X) through fitgnn_spmm_csr_f32.  X: [n_cols_of_A, H] f32 contiguous."""
     _lib.require_cuda(rowptr, col, val, tiles, X, bias, mask)
     L = _lib.lib()
@@ -348,7 +356,7 @@ def spmm_raw(rowptr, col, val, tiles, X, n_rows, bias=None, epilogue=0, p=0.0, s
     seed, epilogue = _seed_arg(seed, epilogue)
     Y = out if out is not None else torch.empty((n_rows, H), dtype=torch.float32, device=X.device)
     ev = None
-    if PROFILE is not None:
+    if cfg.profile is not None:
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         ev[0].record()
     rc = L.fitgnn_spmm_csr_f32(_lib.dptr(rowptr), _lib.dptr(col), _lib.dptr(val), _lib.dptr(X), X.stride(0) if X.numel() else H,
@@ -357,7 +365,7 @@ def spmm_raw(rowptr, col, val, tiles, X, n_rows, bias=None, epilogue=0, p=0.0, s
                                _lib.stream_ptr(X.device))
     if ev is not None:
         ev[1].record()
-        PROFILE.append((ev[0], ev[1], "gather" if (epilogue & _lib.SPMM_GATHER) else "tile"))
+        cfg.profile.append((ev[0], ev[1], "gather" if (epilogue & _lib.SPMM_GATHER) else "tile"))
     _lib.check(rc, "fitgnn_spmm_csr_f32")
     return Y
 
@@ -435,22 +443,18 @@ class RowIndex:
         self.seg_off = off.to(torch.int32).contiguous()
 
 
-# Use fitgnn_spmm_epilogue_bwd_f32 (dZ kept in LDS) when the graph / shape allow it.  Off by default: measured on the
-# S-pubmed union it is no faster than the two kernels (254 vs 223 us per hidden layer, 262 vs 263 us with the head; see
-# DESIGN.md "folded backward"), because the extra operand stream and the transform sit on the tile's critical path
-# (descriptor -> window loads -> barrier -> row loop) while the separate elementwise kernel streams at HBM rate.
-FOLD_BACKWARD = False
-
-
-def layer_backward(g, out, epi, p, seed, mask, want_db, dOut=None, dy=None, Wl=None, want_dWl=False):
+def layer_backward(g, out, epi, p, seed, mask, want_db, dOut=None, dy=None, Wl=None, want_dWl=False, cfg=DEFAULT):
     """(dH, db, dWl) of one fused layer: dZ = epilogue'(dOut or dy @ Wl), db = colsum dZ, dH = A^T dZ.
-    One kernel (dZ stays in LDS) when supported, else epilogue-backward kernel + SpMM."""
+    Epilogue-backward kernel + SpMM; with cfg.fold_backward one kernel (dZ stays in LDS) when the graph / shape allow it --
+    measured on the S-pubmed union no faster than the two kernels (254 vs 223 us per hidden layer, 262 vs 263 us with the
+    head; DESIGN.md "folded backward"): the extra operand stream and the transform sit on the tile's critical path
+    (descriptor -> window loads -> barrier -> row loop) while the separate elementwise kernel streams at HBM rate."""
     L = _lib.lib()
     out = _f32c(out)
     n, H = out.shape
     head = dOut is None
     C = int(Wl.shape[0]) if head else 0
-    if FOLD_BACKWARD and getattr(g, "fold_ok", False) and L.fitgnn_spmm_epilogue_bwd_supported(H, C, g.window_rows):
+    if cfg.fold_backward and getattr(g, "fold_ok", False) and L.fitgnn_spmm_epilogue_bwd_supported(H, C, g.window_rows):
         side = g.t
         dev = out.device
         dH = torch.empty_like(out)
@@ -464,7 +468,7 @@ def layer_backward(g, out, epi, p, seed, mask, want_db, dOut=None, dy=None, Wl=N
         else:
             dOut = _f32c(dOut)
         ev = None
-        if PROFILE is not None:
+        if cfg.profile_fused is not None:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
         seed_v, epi_v = _seed_arg(seed, epi)
@@ -474,60 +478,52 @@ def layer_backward(g, out, epi, p, seed, mask, want_db, dOut=None, dy=None, Wl=N
                                             _lib.dptr(db), _lib.dptr(dWl), _lib.dptr(work), wb, _lib.stream_ptr(dev))
         if ev is not None:
             ev[1].record()
-            PROFILE_FUSED.append(ev)
+            cfg.profile_fused.append(ev)
         _lib.check(rc, "fitgnn_spmm_epilogue_bwd_f32")
         return dH, db, dWl
     if head:
         inside = want_dWl and bool(L.fitgnn_epilogue_bwd_head_supported(H, C, 1))
         dZ, db, dWl = epilogue_bwd_head_raw(dy, Wl, out, epi, p=p, seed=seed, mask=mask, want_db=want_db, want_dWl=inside)
         if want_dWl and not inside:   # a wide head (ogbn-products: 47 classes): the kernel's registers hold 16 class rows
-            dWl = mm_at_b(_f32c(dy), out)
+            dWl = mm_at_b(_f32c(dy), out, cfg)
     else:
         dZ, db = epilogue_bwd_raw(dOut, out, epi, p=p, seed=seed, mask=mask, want_db=want_db)
         dWl = None
-    return spmm_graph(g, dZ, transposed=True), db, dWl
-
-
-PROFILE_FUSED = []
+    return spmm_graph(g, dZ, transposed=True, cfg=cfg), db, dWl
 
 
 class SpMM(torch.autograd.Function):
     """Y = A @ X (+ bias).  Backward: dX = A^T @ dY (same kernel on the transposed CSR), db = sum rows."""
 
     @staticmethod
-    def forward(ctx, X, bias, g):
-        ctx.g = g
+    def forward(ctx, X, bias, g, cfg):
+        ctx.g, ctx.cfg = g, cfg
         ctx.has_bias = bias is not None
         epi = EPI_BIAS if bias is not None else 0
-        return spmm_graph(g, X, bias=bias, epilogue=epi)
+        return spmm_graph(g, X, bias=bias, epilogue=epi, cfg=cfg)
 
     @staticmethod
     def backward(ctx, dY):
         g = ctx.g
         dY = _f32c(dY)
-        dX = spmm_graph(g, dY, transposed=True) if ctx.needs_input_grad[0] else None
+        dX = spmm_graph(g, dY, transposed=True, cfg=ctx.cfg) if ctx.needs_input_grad[0] else None
         db = dY.sum(0) if ctx.has_bias and ctx.needs_input_grad[1] else None
-        return dX, db, None
+        return dX, db, None, None
 
 
 class SpMMRows(torch.autograd.Function):
     """Y = A_hat[rows, :] X for a csr.RowSubset (only the rows whose outputs are consumed); backward = its adjoint."""
 
     @staticmethod
-    def forward(ctx, X, sub):
-        ctx.sub = sub
+    def forward(ctx, X, sub, cfg):
+        ctx.sub, ctx.cfg = sub, cfg
         f = sub.f
-        return spmm_raw(f.rowptr, f.col, f.val, f.tiles, X, sub.m, window_rows=sub.window_rows)
+        return spmm_raw(f.rowptr, f.col, f.val, f.tiles, X, sub.m, window_rows=sub.window_rows, cfg=cfg)
 
     @staticmethod
     def backward(ctx, dY):
         t = ctx.sub.t
-        return spmm_raw(t.rowptr, t.col, t.val, t.tiles, _f32c(dY), ctx.sub.n, window_rows=ctx.sub.window_rows), None
-
-
-# dX = dH @ W of a layer whose input is the fused output of the previous layer: let the GEMM's epilogue apply that layer's
-# ELU'/dropout' (csrc/gemm_nt.hip, EPI) instead of writing dOut and running the epilogue-backward kernel over it
-FUSE_DX_EPILOGUE = True
+        return spmm_raw(t.rowptr, t.col, t.val, t.tiles, _f32c(dY), ctx.sub.n, window_rows=ctx.sub.window_rows, cfg=ctx.cfg), None, None
 
 
 class EpilogueLink:
@@ -547,24 +543,27 @@ class EpilogueLink:
         self.fused, self.db = False, None
 
 
-def _dx_through_link(link, dH, W, X):
-    """dX for the consumer of a linked layer: (tensor to return as the input gradient)."""
-    if link is not None and FUSE_DX_EPILOGUE and W.shape[1] % 4 == 0 and X.is_contiguous() and X.dtype == torch.float32:
+def _dx_through_link(cfg, link, dH, W, X):
+    """dX = dH @ W for the consumer of a linked layer (tensor to return as the input gradient): with cfg.fuse_dx_epilogue
+    the GEMM's epilogue applies the producing layer's ELU'/dropout' (csrc/gemm_nt.hip, EPI) instead of writing dOut and
+    running the epilogue-backward kernel over it."""
+    if link is not None and cfg.fuse_dx_epilogue and W.shape[1] % 4 == 0 and X.is_contiguous() and X.dtype == torch.float32:
         dH = _f32c(dH)
-        Wt = _wt_operand(dH, W)
-        if _nt_ok(dH, Wt):
-            dZ, db = gemm_nt_epilogue_bwd(dH, Wt, X, link.epi, p=link.p, seed=link.seed, mask=link.mask, want_db=link.want_db)
+        Wt = _wt_operand(dH, W, cfg)
+        if _nt_ok(dH, Wt, cfg):
+            dZ, db = gemm_nt_epilogue_bwd(dH, Wt, X, link.epi, p=link.p, seed=link.seed, mask=link.mask, want_db=link.want_db,
+                                          cfg=cfg)
             link.fused, link.db = True, db
             return dZ
-    return mm_by_transposed(dH, W)
+    return mm_by_transposed(dH, W, cfg)
 
 
-def _producer_backward(link, g, out, epi, p, seed, mask, has_bias, dOut):
+def _producer_backward(cfg, link, g, out, epi, p, seed, mask, has_bias, dOut):
     """(dH, db) of a fused layer: through the link when its consumer already applied the epilogue's derivative."""
     if link is not None and link.fused:
         db, link.fused, link.db = link.db, False, None
-        return spmm_graph(g, _f32c(dOut), transposed=True), db
-    dH, db, _ = layer_backward(g, out, epi, p, seed, mask, has_bias, dOut=dOut)
+        return spmm_graph(g, _f32c(dOut), transposed=True, cfg=cfg), db
+    dH, db, _ = layer_backward(g, out, epi, p, seed, mask, has_bias, dOut=dOut, cfg=cfg)
     return dH, db
 
 
@@ -573,16 +572,16 @@ class FusedGCNLayer(torch.autograd.Function):
     one GEMM + one SpMM with fused epilogue.  `mask` (uint8 [N,H]) injects a dropout pattern for tests."""
 
     @staticmethod
-    def forward(ctx, X, W, b, g, p, training, seed, mask, link_in=None, link_out=None):
+    def forward(ctx, X, W, b, g, p, training, seed, mask, link_in, link_out, cfg):
         X = _f32c(X)
-        Hm = mm_xwt(X, W)
+        Hm = mm_xwt(X, W, cfg)
         epi = EPI_ELU | (EPI_BIAS if b is not None else 0)
         drop = bool(training) and p > 0.0
         if drop:
             epi |= EPI_DROPOUT
-        out = spmm_graph(g, Hm, bias=b, epilogue=epi, p=p if drop else 0.0, seed=seed, mask=mask if drop else None)
+        out = spmm_graph(g, Hm, bias=b, epilogue=epi, p=p if drop else 0.0, seed=seed, mask=mask if drop else None, cfg=cfg)
         ctx.save_for_backward(X, W, out, mask if drop else None)
-        ctx.g, ctx.p, ctx.drop, ctx.seed, ctx.has_bias = g, p, drop, seed, b is not None
+        ctx.g, ctx.p, ctx.drop, ctx.seed, ctx.has_bias, ctx.cfg = g, p, drop, seed, b is not None, cfg
         ctx.link_in, ctx.link_out = link_in, link_out
         if link_out is not None:
             link_out.record(drop, p, seed, mask, b is not None)
@@ -593,10 +592,11 @@ class FusedGCNLayer(torch.autograd.Function):
         X, W, out, mask = ctx.saved_tensors
         g = ctx.g
         epi = EPI_ELU | (EPI_DROPOUT if ctx.drop else 0)
-        dH, db = _producer_backward(ctx.link_out, g, out, epi, ctx.p if ctx.drop else 0.0, ctx.seed, mask, ctx.has_bias, dOut)
-        dW = mm_at_b(dH, X) if ctx.needs_input_grad[1] else None
-        dX = _dx_through_link(ctx.link_in, dH, W, X) if ctx.needs_input_grad[0] else None
-        return dX, dW, (db if ctx.has_bias else None), None, None, None, None, None, None, None
+        cfg = ctx.cfg
+        dH, db = _producer_backward(cfg, ctx.link_out, g, out, epi, ctx.p if ctx.drop else 0.0, ctx.seed, mask, ctx.has_bias, dOut)
+        dW = mm_at_b(dH, X, cfg) if ctx.needs_input_grad[1] else None
+        dX = _dx_through_link(cfg, ctx.link_in, dH, W, X) if ctx.needs_input_grad[0] else None
+        return dX, dW, (db if ctx.has_bias else None), None, None, None, None, None, None, None, None
 
 
 class FusedGCNLayerHead(torch.autograd.Function):
@@ -607,15 +607,15 @@ class FusedGCNLayerHead(torch.autograd.Function):
     the epilogue-backward kernel forms it on the fly.  Requires num_classes <= fitgnn_head_max_classes()."""
 
     @staticmethod
-    def forward(ctx, X, W, b, Wl, bl, g, p, training, seed, mask, link_in=None):
+    def forward(ctx, X, W, b, Wl, bl, g, p, training, seed, mask, link_in, cfg):
         X = _f32c(X)
-        ctx.link_in = link_in
-        Hm = mm_xwt(X, W)
+        ctx.link_in, ctx.cfg = link_in, cfg
+        Hm = mm_xwt(X, W, cfg)
         epi = EPI_ELU | (EPI_BIAS if b is not None else 0)
         drop = bool(training) and p > 0.0
         if drop:
             epi |= EPI_DROPOUT
-        out = spmm_graph(g, Hm, bias=b, epilogue=epi, p=p if drop else 0.0, seed=seed, mask=mask if drop else None)
+        out = spmm_graph(g, Hm, bias=b, epilogue=epi, p=p if drop else 0.0, seed=seed, mask=mask if drop else None, cfg=cfg)
         y = torch.mm(out, Wl.t())
         if bl is not None:
             y = y + bl
@@ -629,19 +629,15 @@ class FusedGCNLayerHead(torch.autograd.Function):
         g = ctx.g
         dy = _f32c(dy)
         epi = EPI_ELU | (EPI_DROPOUT if ctx.drop else 0)
+        cfg = ctx.cfg
         dH, db, dWl = layer_backward(g, out, epi, ctx.p if ctx.drop else 0.0, ctx.seed, mask, ctx.has_bias, dy=dy, Wl=Wl,
-                                     want_dWl=ctx.needs_input_grad[3])
+                                     want_dWl=ctx.needs_input_grad[3], cfg=cfg)
         # [R, C] column sums: torch's dim-0 reduction of a tall 3-column matrix takes 50 us, a transposed copy + dim-1
         # reduction 23, the two-pass kernel 9
         dbl = colsum_narrow(dy) if ctx.has_bl and ctx.needs_input_grad[4] else None
-        dW = mm_at_b(dH, X) if ctx.needs_input_grad[1] else None
-        dX = _dx_through_link(ctx.link_in, dH, W, X) if ctx.needs_input_grad[0] else None
-        return dX, dW, (db if ctx.has_bias else None), dWl, dbl, None, None, None, None, None, None
-
-
-# layer 0 on a de-duplicated table: the direct-gather SpMM variant (its operand table stays in L2 / MALL; 5-12 us per step over
-# the LDS-window kernel, same bits)
-DEDUP_GATHER = True
+        dW = mm_at_b(dH, X, cfg) if ctx.needs_input_grad[1] else None
+        dX = _dx_through_link(cfg, ctx.link_in, dH, W, X) if ctx.needs_input_grad[0] else None
+        return dX, dW, (db if ctx.has_bias else None), dWl, dbl, None, None, None, None, None, None, None
 
 
 class FusedGCNLayerDedup(torch.autograd.Function):
@@ -651,17 +647,19 @@ class FusedGCNLayerDedup(torch.autograd.Function):
     (fitgnn_segment_sum_f32) before the weight-gradient GEMM.  Same arithmetic as FusedGCNLayer on X_union."""
 
     @staticmethod
-    def forward(ctx, Xt, W, b, g, ridx, p, training, seed, mask, link_out=None):
+    def forward(ctx, Xt, W, b, g, ridx, p, training, seed, mask, link_out, cfg):
         Xt = _f32c(Xt)
-        ctx.link_out = link_out
-        ctx.wide = _wide_table(Xt, W)
-        Ht = gemm_nt_padded_k(padded_table(Xt), W) if ctx.wide else mm_xwt(Xt, W)  # [N0, H]
+        ctx.link_out, ctx.cfg = link_out, cfg
+        ctx.wide = _padded_table_path(Xt, W, cfg)
+        Ht = gemm_nt_padded_k(padded_table(Xt), W, cfg) if ctx.wide else mm_xwt(Xt, W, cfg)  # [N0, H]
         epi = EPI_ELU | (EPI_BIAS if b is not None else 0)
         drop = bool(training) and p > 0.0
         if drop:
             epi |= EPI_DROPOUT
-        out = spmm_graph(g, Ht, bias=b, epilogue=epi | (_lib.SPMM_GATHER if DEDUP_GATHER else 0), p=p if drop else 0.0, seed=seed,
-                         mask=mask if drop else None, xrow=ridx.index)
+        # the direct-gather SpMM variant: its operand table stays in L2 / MALL (5-12 us per S-pubmed step over the LDS-window
+        # kernel, same bits)
+        out = spmm_graph(g, Ht, bias=b, epilogue=epi | (_lib.SPMM_GATHER if cfg.dedup_gather else 0), p=p if drop else 0.0, seed=seed,
+                         mask=mask if drop else None, xrow=ridx.index, cfg=cfg)
         ctx.save_for_backward(Xt, W, out, mask if drop else None)
         ctx.g, ctx.ridx, ctx.p, ctx.drop, ctx.seed, ctx.has_bias = g, ridx, p, drop, seed, b is not None
         if link_out is not None:
@@ -673,17 +671,15 @@ class FusedGCNLayerDedup(torch.autograd.Function):
         Xt, W, out, mask = ctx.saved_tensors
         g, ridx = ctx.g, ctx.ridx
         epi = EPI_ELU | (EPI_DROPOUT if ctx.drop else 0)
-        dH, db = _producer_backward(ctx.link_out, g, out, epi, ctx.p if ctx.drop else 0.0, ctx.seed, mask, ctx.has_bias, dOut)  # [R, H]
+        cfg = ctx.cfg
+        dH, db = _producer_backward(cfg, ctx.link_out, g, out, epi, ctx.p if ctx.drop else 0.0, ctx.seed, mask, ctx.has_bias, dOut)  # [R, H]
         dHt = segment_sum(ridx.seg_off, ridx.members, dH, ridx.n_table)  # [N0, H] per original node
         if ctx.wide and ctx.needs_input_grad[1]:
-            dW = gemm_atb(_f32c(dHt), padded_table(Xt))[:, : Xt.shape[1]]   # [H, F'] on the padded table, F' - F zero columns dropped
+            dW = gemm_atb(_f32c(dHt), padded_table(Xt), cfg)[:, : Xt.shape[1]]   # [H, F'] on the padded table, F' - F zero columns dropped
         else:
-            dW = mm_at_b(dHt, Xt) if ctx.needs_input_grad[1] else None
+            dW = mm_at_b(dHt, Xt, cfg) if ctx.needs_input_grad[1] else None
         dXt = mm(dHt, W) if ctx.needs_input_grad[0] else None
-        return dXt, dW, (db if ctx.has_bias else None), None, None, None, None, None, None, None
-
-
-_seed_state = [0x1234ABCD]
+        return dXt, dW, (db if ctx.has_bias else None), None, None, None, None, None, None, None, None
 
 
 class GATAggregate(torch.autograd.Function):
@@ -692,7 +688,7 @@ class GATAggregate(torch.autograd.Function):
     (CSRGraph(mode='gat')); attention weights replace its values."""
 
     @staticmethod
-    def forward(ctx, h, att_src, att_dst, bias, g, slope, act=False, p=0.0, training=False, seed=0, mask=None):
+    def forward(ctx, h, att_src, att_dst, bias, g, slope, act, p, training, seed, mask, cfg):
         """act=True fuses F.elu and F.dropout(p) (network.py:32-33) into the aggregation's epilogue, as for GCNConv."""
         L = _lib.lib()
         h = _f32c(h)
@@ -712,9 +708,9 @@ class GATAggregate(torch.autograd.Function):
         if act:
             epi |= EPI_ELU | (EPI_DROPOUT if drop else 0)
         out = spmm_raw(g.f.rowptr, g.f.col, alpha, g.f.tiles, h, n, bias=bias, epilogue=epi, p=p if drop else 0.0, seed=seed,
-                       mask=mask if drop else None, window_rows=g.window_rows, lcol=g.f.lcol, win_cols=g.f.win_cols)
+                       mask=mask if drop else None, window_rows=g.window_rows, lcol=g.f.lcol, win_cols=g.f.win_cols, cfg=cfg)
         ctx.save_for_backward(h, att_src, att_dst, a_src, a_dst, alpha, out if act else None, mask if drop else None)
-        ctx.g, ctx.slope, ctx.has_bias = g, slope, bias is not None
+        ctx.g, ctx.slope, ctx.has_bias, ctx.cfg = g, slope, bias is not None, cfg
         ctx.act, ctx.drop, ctx.p, ctx.seed = bool(act), drop, p, seed
         return out
 
@@ -744,18 +740,18 @@ class GATAggregate(torch.autograd.Function):
         # dh = A_alpha^T dOut + da_src (x) att_src + da_dst (x) att_dst
         alpha_t = alpha[g._perm_t].contiguous()
         dh = spmm_raw(g.t.rowptr, g.t.col, alpha_t, g.t.tiles, dOut, n, window_rows=g.window_rows, lcol=g.t.lcol,
-                      win_cols=g.t.win_cols)
+                      win_cols=g.t.win_cols, cfg=ctx.cfg)
         dh.addcmul_(da_src.unsqueeze(1), att_src.unsqueeze(0)).addcmul_(da_dst.unsqueeze(1), att_dst.unsqueeze(0))
         # d(att) = h^T da: both vectors in ONE tall-skinny product through the split-K path (two rocBLAS gemv calls on
         # [R x C]^T took 1.5 ms each on the S-pubmed union)
-        datt = mm_at_b(torch.stack([da_src, da_dst], dim=1), h) if (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]) else None
+        datt = mm_at_b(torch.stack([da_src, da_dst], dim=1), h, ctx.cfg) if (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]) else None
         datt_src = datt[0] if ctx.needs_input_grad[1] else None
         datt_dst = datt[1] if ctx.needs_input_grad[2] else None
         if ctx.act:
             db = db_fused if ctx.has_bias else None
         else:
             db = dOut.sum(0) if ctx.has_bias and ctx.needs_input_grad[3] else None
-        return dh, datt_src, datt_dst, db, None, None, None, None, None, None, None
+        return dh, datt_src, datt_dst, db, None, None, None, None, None, None, None, None
 
 
 class APPNPPropagate(torch.autograd.Function):
@@ -841,14 +837,11 @@ class SeedBank:
         return s
 
 
-SEED_BANK = None  # set to a SeedBank while building / replaying captured steps
-
-
-def next_seed():
-    """Per-call dropout seed: drawn from torch's generator (so torch.manual_seed controls it), or -- under a SeedBank --
-    a one-element device tensor the kernels dereference."""
-    if SEED_BANK is not None:
-        return SEED_BANK.take()
+def next_seed(cfg=DEFAULT):
+    """Per-call dropout seed: drawn from torch's generator (so torch.manual_seed controls it), or -- when the config carries
+    a SeedBank (steps captured in a hipGraph) -- a one-element device tensor the kernels dereference."""
+    if cfg.seed_bank is not None:
+        return cfg.seed_bank.take()
     return int(torch.randint(0, 2 ** 62, (1,)).item())
 
 

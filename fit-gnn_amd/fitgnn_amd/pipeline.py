@@ -191,8 +191,17 @@ def coarsening_classification(args, data, coarsening_ratio, coarsening_method, d
     return out
 
 
-def build_gs(args, data, co, device="cuda", float_targets=False):
-    """Subgraphs Gs (utils.py:186-267) + their masks (utils.py:683-703) as one block-diagonal SubgraphBatch."""
+def dist_world():
+    """(rank, world) of the initialised default process group, (0, 1) without one."""
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
+        return torch.distributed.get_rank(), torch.distributed.get_world_size()
+    return 0, 1
+
+
+def build_gs(args, data, co, device="cuda", float_targets=False, shard=None):
+    """Subgraphs Gs (utils.py:186-267) + their masks (utils.py:683-703) as one block-diagonal SubgraphBatch.
+    shard = (rank, world): keep only this rank's whole subgraphs of the union (data.shard_clusters: LPT over nnz';
+    SURVEY §8e -- no edge crosses subgraphs, utils.py:248, and GD mode sums ONE loss over all of them, run.py:184-204)."""
     N, n = data.num_nodes, co.n_clusters
     x, y = data.x, data.y.flatten()
     masks = [data.train_mask, data.val_mask, data.test_mask]
@@ -217,6 +226,9 @@ def build_gs(args, data, co, device="cuda", float_targets=False):
     else:
         ei_dev = torch.as_tensor(np.asarray(data.edge_index)).to(device)
         sub = fdata.assemble_subgraphs_torch(ei_dev, N, co.assign, n, extra_node=bool(getattr(args, "extra_node", False)))
+    if shard is not None and shard[1] > 1:
+        owner = fdata.shard_clusters(None, fdata.cluster_nnz(sub), shard[1])   # the same on every rank
+        sub = fdata.select_clusters(sub, np.nonzero(owner == shard[0])[0])
     batch = fdata.SubgraphBatch(sub, x, y, masks[0], device=device, float_targets=float_targets)
     core = batch.core
     batch.val_idx = torch.nonzero(masks[1].to(device)[batch.node_id] & core).flatten()
@@ -284,7 +296,9 @@ def _nll(model, x, ei, idx, labels, reduction):
 
 @torch.no_grad()
 def infer_gs(model, batch, idx, reduction="mean"):
-    """node_infer_Gs_GD (run.py:49-115): loss, accuracy and forward wall time over the subgraphs."""
+    """node_infer_Gs_GD (run.py:49-115): loss, accuracy and forward wall time over the subgraphs.  Under an initialised
+    process group `batch` is this rank's shard: loss sums, hit counts and node counts are all-reduced, so every rank returns
+    the figures of the whole union."""
     model.eval()
     torch.cuda.synchronize()
     t0 = time.time()
@@ -292,8 +306,21 @@ def infer_gs(model, batch, idx, reduction="mean"):
     torch.cuda.synchronize()
     dt = time.time() - t0
     sel, y = out.index_select(0, idx), batch.y.index_select(0, idx)
-    loss = float(F.nll_loss(sel, y, reduction="mean"))
-    return loss, float((sel.argmax(1) == y).float().mean()), dt
+    tot = torch.stack([F.nll_loss(sel, y, reduction="sum").double(), (sel.argmax(1) == y).sum().double(),
+                       torch.tensor(float(idx.numel()), dtype=torch.float64, device=sel.device)])
+    if dist_world()[1] > 1:
+        torch.distributed.all_reduce(tot)
+    n = max(float(tot[2]), 1.0)
+    return float(tot[0]) / n, float(tot[1]) / n, dt
+
+
+def _keep(model, ckpt, rank):
+    """Best-val checkpoint (run.py:386-388): kept in memory on every rank (the validation loss is global, so all ranks keep
+    the same epoch), written to `ckpt` by rank 0."""
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    if rank == 0:
+        torch.save(sd, ckpt)
+    return sd
 
 
 def node_classification(args, path, data, co, device="cuda", log=print):
@@ -301,9 +328,16 @@ def node_classification(args, path, data, co, device="cuda", log=print):
     Gc_train_2_Gs_train}, gradient_method GD (one step per epoch over the union) or MB (one step per loader batch)."""
     if args.gradient_method not in ("GD", "MB"):
         raise ValueError(f"--gradient_method {args.gradient_method}: GD or MB")
+    rank, world = dist_world()
+    if world > 1 and args.gradient_method != "GD" and args.exp_setup != "Gc_train_2_Gs_infer":
+        raise ValueError("--gradient_method MB steps once per loader batch, each step on the weights the previous batch left "
+                         "(run.py:217-252): sequential by construction, single GPU only.  Data parallel runs use GD "
+                         "(one loss over all subgraphs, run.py:184-204).")
     rng = np.random.default_rng(args.seed)
     data = splits_classification(data, args.num_classes, args.experiment, rng)
-    batch = build_gs(args, data, co, device)
+    # data parallel (SURVEY §8e): every rank holds a shard of the ONE subgraph union; the Gc phase (one small graph) is
+    # replicated -- same seeds, same data, same weights on every rank
+    batch = build_gs(args, data, co, device, shard=(rank, world))
     gc = build_gc(args, data, co, device) if args.exp_setup != "Gs_train_2_Gs_infer" else None
     all_loss, all_acc, all_time = [], [], []
     ckpt = os.path.join(path, "model.pt")
@@ -330,8 +364,8 @@ def node_classification(args, path, data, co, device="cuda", log=print):
                                              reduction=args.loss_reduction))
                 if vloss < best or epoch == 0:
                     best = vloss
-                    torch.save(model.state_dict(), ckpt)
-            model.load_state_dict(torch.load(ckpt))
+                    best_sd = _keep(model, ckpt, rank)
+            model.load_state_dict(best_sd)
         if args.exp_setup in ("Gs_train_2_Gs_infer", "Gc_train_2_Gs_train"):
             if args.gradient_method == "GD":
                 # the extra nodes' last-layer outputs never reach the loss: evaluate that layer on the own nodes only
@@ -348,8 +382,8 @@ def node_classification(args, path, data, co, device="cuda", log=print):
                 vloss, vacc, _ = infer_gs(model, batch, batch.val_idx)
                 if vloss < best or epoch == 0:
                     best = vloss
-                    torch.save(model.state_dict(), ckpt)
-            model.load_state_dict(torch.load(ckpt))
+                    best_sd = _keep(model, ckpt, rank)
+            model.load_state_dict(best_sd)
         tloss, tacc, ttime = infer_gs(model, batch, batch.test_idx)
         log(f"run {run + 1}: test_loss {tloss:.4f} test_acc {tacc:.4f} infer_time {ttime * 1e3:.2f} ms")
         all_loss.append(tloss); all_acc.append(tacc); all_time.append(ttime)

@@ -17,7 +17,9 @@ def _pad4(n):
 
 class FlatGrads:
     """All parameter gradients as views into one contiguous buffer -> one all-reduce per step.  Every parameter starts
-    on a 16-byte boundary (sizes padded to multiples of four floats; the padding stays zero)."""
+    on a 16-byte boundary (sizes padded to multiples of four floats; the padding stays zero).  `buf` = the `n` gradient
+    floats followed by a 4-float tail whose first slot carries the rank's loss share through the same all-reduce
+    ("+ scalars for loss / count packed in")."""
 
     def __init__(self, params):
         self.params = [p for p in params if p.requires_grad]
@@ -25,7 +27,9 @@ class FlatGrads:
         for p in self.params:
             self.offsets.append(n)
             n += _pad4(p.numel())
-        self.buf = torch.zeros(n, dtype=torch.float32, device=self.params[0].device)
+        self.n = n
+        self.buf = torch.zeros(n + 4, dtype=torch.float32, device=self.params[0].device)
+        self.grads, self.tail = self.buf[:n], self.buf[n:]
         for p, off in zip(self.params, self.offsets):
             p.grad = self.buf[off:off + p.numel()].view_as(p)
 
@@ -43,7 +47,7 @@ class FlatAdam:
     def __init__(self, flat, lr=0.01, weight_decay=5e-4, betas=(0.9, 0.999), eps=1e-8):
         self.flat, self.lr, self.wd, self.betas, self.eps = flat, float(lr), float(weight_decay), betas, float(eps)
         dev = flat.buf.device
-        self.P = torch.zeros_like(flat.buf)
+        self.P = torch.zeros_like(flat.grads)
         for p, off in zip(flat.params, flat.offsets):
             view = self.P[off:off + p.numel()].view_as(p)
             view.copy_(p.data)
@@ -54,7 +58,7 @@ class FlatAdam:
     def step(self):
         from . import _lib
 
-        b = self.flat.buf
+        b = self.flat.grads
         _lib.check(_lib.lib().fitgnn_adam_step_f32(_lib.dptr(self.P), _lib.dptr(b), _lib.dptr(self.m), _lib.dptr(self.v), int(b.numel()),
                                                    self.lr, self.betas[0], self.betas[1], self.eps, self.wd, _lib.dptr(self.step_count),
                                                    _lib.stream_ptr(b.device)), "fitgnn_adam_step_f32")
@@ -87,13 +91,18 @@ class FlatAdam:
 
 class GDTrainer:
     def __init__(self, model, batch, lr=0.01, weight_decay=5e-4, reduction="mean", process_group=None, dedup=True,
-                 task="node_cls", prune_unused_rows=False):
+                 task="node_cls", prune_unused_rows=False, op_config=None):
         """task 'node_cls': NLLLoss on log-probabilities (run.py:341); 'node_reg': L1Loss on the [n, 1] outputs (run.py:518).
+        op_config (ops.OpConfig): the switches this trainer's kernels run under (set on the model; default: the model's own).
         prune_unused_rows: evaluate the last layer only on the rows that can reach the loss (the clusters' own nodes: the
         reference computes and then discards the extra nodes' outputs, run.py:193-204).  Same loss and gradients; the
         last layer's GEMMs and both of its SpMMs shrink to the own-node rows.  Off by default: bench.py's metric counts
         every non-zero of A_hat in all four SpMMs."""
         self.model, self.batch, self.task = model, batch, task
+        if op_config is not None:
+            model.set_op_config(op_config)
+        from . import ops as _ops
+        self.cfg = getattr(model, "op_config", _ops.DEFAULT)
         self.sub = None
         # first layer on the de-duplicated feature table when the batch carries one (same arithmetic, fewer FLOPs)
         self.dedup = dedup and getattr(batch, "row_index", None) is not None
@@ -138,7 +147,7 @@ class GDTrainer:
 
     def _grad_ready(self, _p):
         self._pending -= 1
-        if self._pending == 0:
+        if self._pending == 0:   # the late bucket ends with the loss slot of the flat buffer
             self._work = torch.distributed.all_reduce(self.flat.buf[self._split:], group=self.pg, async_op=True)
 
     def _reduce_grads(self):
@@ -150,8 +159,19 @@ class GDTrainer:
         else:
             torch.distributed.all_reduce(self.flat.buf, group=self.pg)  # one RCCL all-reduce per step
 
+    def _backward_and_step(self, loss):
+        """loss = this rank's share (its sum-loss x 1 / global count): backward, gradient all-reduce with the loss riding in
+        the buffer's tail slot, replicated Adam.  Returns the GLOBAL loss (the sum of the ranks' shares)."""
+        if self.dist:
+            self.flat.tail[:1].copy_(loss.detach().view(1))   # before backward: the late bucket leaves from a backward hook
+        loss.backward()
+        if self.dist:
+            self._reduce_grads()
+        self.opt.step()
+        return self.flat.tail[0].clone() if self.dist else loss.detach()
+
     def step(self):
-        """One GD epoch (run.py:177-215).  Returns the (global) loss as a 0-dim device tensor."""
+        """One GD epoch (run.py:177-215).  Returns the global loss (over every rank's subgraphs) as a 0-dim device tensor."""
         m, b = self.model, self.batch
         m.train()
         self.flat.zero()  # optimizer.zero_grad(); grads live in the flat buffer
@@ -167,24 +187,14 @@ class GDTrainer:
             else:
                 z = m.embed_and_head(b.x_table, b.edge_index, b.row_index) if self.dedup else m.embed_and_head(b.x, b.edge_index)
                 loss = SoftmaxNLL.apply(z, b.train_idx, self._y_train, scale)
-            loss.backward()
-            if self.dist:
-                self._reduce_grads()
-            self.opt.step()
-            return loss.detach()
+            return self._backward_and_step(loss)
         out = m(b.x_table, b.edge_index, x_index=b.row_index) if self.dedup else m(b.x, b.edge_index)
         sel = out.index_select(0, b.train_idx)
         if self.task == "node_reg":
             loss_sum = F.l1_loss(sel.view(-1, 1), b.y.index_select(0, b.train_idx).view(-1, 1), reduction="sum")
         else:
             loss_sum = F.nll_loss(sel, b.y.index_select(0, b.train_idx), reduction="sum")
-        scale = 1.0 / self.global_count if self.reduction == "mean" else 1.0
-        loss = loss_sum * scale
-        loss.backward()
-        if self.dist:
-            self._reduce_grads()
-        self.opt.step()
-        return loss.detach()
+        return self._backward_and_step(loss_sum * scale)
 
     @torch.no_grad()
     def evaluate(self, mask_idx):
@@ -214,7 +224,10 @@ class _CapturedSteps:
         # Adam's moment / step tensors must EXIST before capture (a lazily initialised state would be allocated and
         # zeroed inside the first captured step, i.e. reset on every replay): warm up, then restore them in place
         saved_o = {p: {k: (v.clone() if torch.is_tensor(v) else v) for k, v in st.items()} for p, st in self.opt.state.items()}
-        prev, ops.SEED_BANK = ops.SEED_BANK, self._bank
+        # the captured kernels read their dropout seeds through the bank's device pointers: the model runs under a copy of
+        # its config that carries the bank while the steps are built (replays re-run no Python)
+        prev = self.model.op_config
+        self.model.set_op_config(prev.replace(seed_bank=self._bank))
         try:
             side = torch.cuda.Stream(device=dev)
             side.wait_stream(torch.cuda.current_stream(dev))
@@ -241,7 +254,7 @@ class _CapturedSteps:
             # capturing does not execute: the weights are untouched, but the gradient buffer was only zeroed eagerly
             self.flat.zero()
         finally:
-            ops.SEED_BANK = prev
+            self.model.set_op_config(prev)
 
 
     def _replay(self):

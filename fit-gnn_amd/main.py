@@ -13,7 +13,14 @@ Datasets: the reference downloads through torch_geometric / ogb, which are not a
   synthetic-qm9              QM9-shaped graph regression stand-in (--n_graphs molecules of ~18 nodes, 19 targets)
   cora | citeseer | pubmed   Planetoid raw files `ind.<name>.*` under --data_root/<name>/raw (PyG's own layout)
   synthetic-{cora,citeseer,pubmed,physics}   seeded stand-ins of the same shape (dataset_info.csv)
-Extra flags (not in the reference): --data_root, --device.
+Extra flags (not in the reference): --data_root, --device, --community_nodes, --n_graphs, --dropout.
+
+Data parallel (BASELINE.json config 4, "subgraph-batch DP on 8 x MI355X"; new functionality): launch one
+process per GPU, e.g. `python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 main.py
+--dataset ... --train_fitgnn --gradient_method GD`.  Rank 0 coarsens and broadcasts the partition; the subgraph union is
+sharded by whole subgraphs (data.shard_clusters), gradients are all-reduced over RCCL once per GD step
+(train.GDTrainer), validation / test figures are all-reduced sums; rank 0 writes model.pt and the results row.
+MB mode is sequential by construction (run.py:217-252) and stays single-GPU.
 """
 import argparse
 import os
@@ -67,6 +74,7 @@ def build_parser():
     p.add_argument('--device', type=str, default='cuda')
     p.add_argument('--community_nodes', type=int, default=165000)  # main.py:264 hard-codes 165000
     p.add_argument('--n_graphs', type=int, default=2000)  # size of the synthetic-qm9 stand-in (QM9 itself: 130 831)
+    p.add_argument('--dropout', type=float, default=0.5)  # the reference calls F.dropout with its default p = 0.5 (network.py:33)
     return p
 
 
@@ -161,14 +169,41 @@ def write_results(args, all_loss, all_acc, all_time, baseline):
     print("#############################################################################")
 
 
+def init_distributed(args):
+    """One process per GPU under torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE in the environment): join the group
+    (nccl = RCCL over xGMI; gloo when the box has fewer GPUs than ranks -- a rehearsal) and pin this rank's device.
+    Returns (rank, world); (0, 1) when not launched that way."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1:
+        return 0, 1
+    rank, local = int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+    n_dev = torch.cuda.device_count()
+    local %= max(n_dev, 1)
+    torch.cuda.set_device(local)
+    args.device = f"cuda:{local}"
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    backend = os.environ.get("FITGNN_DIST_BACKEND", "nccl" if n_dev >= world else "gloo")
+    if not torch.distributed.is_initialized():
+        if backend == "nccl":
+            torch.distributed.init_process_group("nccl", device_id=torch.device(args.device))
+        else:
+            torch.distributed.init_process_group(backend)
+    return rank, world
+
+
 def main(argv=None):
     args = build_parser().parse_args(argv)
     args = arg_correction(args)
+    rank, world = init_distributed(args)
     if args.seed is not None:
         np.random.seed(args.seed)
         torch.manual_seed(args.seed)
     data, args = process_dataset(args)
     from fitgnn_amd import pipeline
+
+    if world > 1 and (args.baseline or args.task != 'node_cls'):
+        raise NotImplementedError("data parallel runs cover the FIT-GNN node-classification path (--train_fitgnn, "
+                                  "--gradient_method GD); launch baselines and the other tasks as one process")
 
     path = f"save/{args.task}/" + (f"baseline/{args.output_dir}/" if args.baseline else f"{args.output_dir}/")
     os.makedirs(path, exist_ok=True)
@@ -189,16 +224,25 @@ def main(argv=None):
         res = pipeline.node_classification_baseline(args, path, data, device=args.device)
         write_results(args, *res, baseline=True)
     else:
-        co = pipeline.coarsening_classification(args, data, 1 - args.coarsening_ratio, args.coarsening_method,
-                                                device=args.device)  # main.py:278 passes 1 - rho as Loukas' r
-        print(f"coarsened {data.num_nodes} nodes in {len(co.components)} components into {co.n_clusters} clusters")
-        res = pipeline.node_classification(args, path, data, co, device=args.device)
-        # main.py:279 `save(...)`: the subgraph union as a flat, memory-mappable artefact (fitgnn_amd.store)
-        from fitgnn_amd import store
-        store.save_gs(store.artefact_dir(f"./dataset/{args.dataset}/saved/{args.coarsening_method}", args),
-                      pipeline.build_gs(args, pipeline.splits_classification(data, args.num_classes, args.experiment,
-                                                                             np.random.default_rng(args.seed)), co, args.device), co)
-        write_results(args, *res, baseline=False)
+        co = None
+        if rank == 0:
+            co = pipeline.coarsening_classification(args, data, 1 - args.coarsening_ratio, args.coarsening_method,
+                                                    device=args.device)  # main.py:278 passes 1 - rho as Loukas' r
+            print(f"coarsened {data.num_nodes} nodes in {len(co.components)} components into {co.n_clusters} clusters")
+        if world > 1:   # ONE partition for all ranks (the eigensolver's start vector is random: ranks would not agree)
+            box = [co]
+            torch.distributed.broadcast_object_list(box, src=0)
+            co = box[0]
+        res = pipeline.node_classification(args, path, data, co, device=args.device, log=print if rank == 0 else (lambda *a: None))
+        if rank == 0:
+            # main.py:279 `save(...)`: the subgraph union as a flat, memory-mappable artefact (fitgnn_amd.store)
+            from fitgnn_amd import store
+            store.save_gs(store.artefact_dir(f"./dataset/{args.dataset}/saved/{args.coarsening_method}", args),
+                          pipeline.build_gs(args, pipeline.splits_classification(data, args.num_classes, args.experiment,
+                                                                                 np.random.default_rng(args.seed)), co, args.device), co)
+            write_results(args, *res, baseline=False)
+        if world > 1:
+            torch.distributed.barrier()
     return res
 
 

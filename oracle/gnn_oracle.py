@@ -102,13 +102,14 @@ def classify_node_forward(sd, x, edge_index, num_layers, masks=None, p=0.5):
     return F.log_softmax(x, dim=1)
 
 
-def classify_node_fwd_bwd(sd, x, edge_index, y, num_layers=2, train_mask=None, masks=None, dtype=torch.float32):
-    """Forward, NLL loss (run.py:200,341) and gradients of every parameter."""
+def classify_node_fwd_bwd(sd, x, edge_index, y, num_layers=2, train_mask=None, masks=None, dtype=torch.float32, loss_scale=None):
+    """Forward, NLL loss (run.py:200,341) and gradients of every parameter.  loss_scale: the loss is loss_scale x the SUM
+    over the train nodes instead of their mean (a slice of a larger union under the union's 1 / count, run.py:184-204)."""
     params = {k: v.detach().clone().to(dtype).requires_grad_(True) for k, v in sd.items()}
     out = classify_node_forward(params, x.to(dtype), edge_index, num_layers, masks=masks)
     sel = out if train_mask is None else out[train_mask]
     tgt = y if train_mask is None else y[train_mask]
-    loss = F.nll_loss(sel, tgt.long())
+    loss = F.nll_loss(sel, tgt.long()) if loss_scale is None else F.nll_loss(sel, tgt.long(), reduction="sum") * loss_scale
     loss.backward()
     return out.detach(), loss.detach(), {k: v.grad for k, v in params.items()}
 

@@ -50,10 +50,8 @@ def _worker(rank, world, port, out_q):
     shard = Shard(x[lo:hi], y[lo:hi], torch.arange(0, hi - lo, 2))
     tr = train.GDTrainer(model, shard, lr=0.01, weight_decay=5e-4)
     assert tr._split > 0   # two buckets: everything above conv.0 is reduced while conv.0's backward still runs
-    losses = [float(tr.step()) for _ in range(3)]
-    tot = torch.tensor(losses)
-    torch.distributed.all_reduce(tot)  # sum of per-rank partial losses = global mean loss
-    out_q.put((rank, tot.tolist(), {k: v.numpy().copy() for k, v in model.state_dict().items()}))
+    losses = [float(tr.step()) for _ in range(3)]   # step() returns the GLOBAL loss: it rides in the gradient all-reduce
+    out_q.put((rank, losses, {k: v.numpy().copy() for k, v in model.state_dict().items()}))
     torch.distributed.destroy_process_group()
 
 
@@ -81,6 +79,7 @@ def test_two_rank_step_equals_single_process():
     tr = train.GDTrainer(model, Shard(x, y, idx), lr=0.01, weight_decay=5e-4)
     ref_losses = [float(tr.step()) for _ in range(3)]
     assert np.allclose(res[0][1], ref_losses, rtol=1e-5)
+    assert res[0][1] == res[1][1], "every rank reports the same (global) loss"
     for k, v in model.state_dict().items():
         assert np.allclose(res[0][2][k], v.numpy(), rtol=1e-5, atol=1e-6), k
         assert np.array_equal(res[0][2][k], res[1][2][k]), f"ranks diverged on {k}"

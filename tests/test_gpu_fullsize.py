@@ -11,10 +11,9 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(scope="module")
 def pubmed():
-    import bench
-    from fitgnn_amd import coarsening, data
+    from fitgnn_amd import coarsening, data, workloads
 
-    N, E, F, C, r = bench.WORKLOADS["S-pubmed"]
+    N, E, F, C, r = workloads.SHAPES["S-pubmed"]
     ei = data.synthetic_graph(N, E, seed=0)
     W = sp.csr_matrix((np.ones(ei.shape[1]), (ei[0], ei[1])), shape=(N, N))
     G = coarsening.Graph(W)

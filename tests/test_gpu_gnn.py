@@ -445,7 +445,7 @@ def test_pruned_last_layer_equals_full_evaluation(mods):
         assert rel(w, v) < 2e-4, k
     sub = t2.sub
     X, Z = torch.randn(batch.n_rows, 32, device="cuda"), torch.randn(sub.m, 32, device="cuda")
-    Y = ops.SpMMRows.apply(X, sub)
+    Y = ops.SpMMRows.apply(X, sub, ops.DEFAULT)
     full = ops.spmm_graph(batch.graph, X).index_select(0, sub.rows)
     assert rel(Y, full) < 1e-6
     XT = ops.spmm_raw(sub.t.rowptr, sub.t.col, sub.t.val, sub.t.tiles, Z, sub.n, window_rows=sub.window_rows)
@@ -506,7 +506,8 @@ def test_dx_gemm_with_the_previous_layers_epilogue(mods, layers, dedup, inject):
 
     grads = {}
     for fuse in (True, False):
-        ops.FUSE_DX_EPILOGUE, ops.gemm_nt_epilogue_bwd = fuse, counting
+        ops.gemm_nt_epilogue_bwd = counting
+        model.set_op_config(ops.OpConfig(fuse_dx_epilogue=fuse))   # per-model switch: no process-wide state
         try:
             model.zero_grad()
             if inject:
@@ -518,7 +519,8 @@ def test_dx_gemm_with_the_previous_layers_epilogue(mods, layers, dedup, inject):
             torch.nn.functional.nll_loss(out, y.cuda()).backward()
             grads[fuse] = {k: p.grad.clone() for k, p in model.named_parameters()}
         finally:
-            ops.FUSE_DX_EPILOGUE, ops.gemm_nt_epilogue_bwd = True, real
+            ops.gemm_nt_epilogue_bwd = real
+            model.set_op_config(ops.DEFAULT)
     assert len(calls) == layers - 1, "one fused GEMM per linked pair of layers, none with the switch off"
     for k in grads[True]:
         assert rel(grads[True][k].cpu(), grads[False][k].cpu()) < 1e-6, k
@@ -596,14 +598,11 @@ def test_wide_unaligned_feature_table_runs_on_the_gemm_kernels(mods):
     ridx = ops.RowIndex(idx.cuda(), N0)
     res = {}
     for wide in (True, False):
-        saved, ops.WIDE_TABLE_MIN_K = ops.WIDE_TABLE_MIN_K, (1024 if wide else 10 ** 9)
-        try:
-            model.zero_grad()
-            out = model(Xt, ei.cuda(), x_index=ridx)
-            torch.nn.functional.nll_loss(out, y).backward()
-            res[wide] = (out.detach().clone(), {k: p.grad.clone() for k, p in model.named_parameters()})
-        finally:
-            ops.WIDE_TABLE_MIN_K = saved
+        model.set_op_config(ops.OpConfig(pad_table_min_k=0 if wide else 10 ** 9))
+        model.zero_grad()
+        out = model(Xt, ei.cuda(), x_index=ridx)
+        torch.nn.functional.nll_loss(out, y).backward()
+        res[wide] = (out.detach().clone(), {k: p.grad.clone() for k, p in model.named_parameters()})
     assert getattr(Xt, "_fitgnn_pad")[1].shape == (N0, 1120)
     assert rel(res[True][0].cpu(), res[False][0].cpu()) < 1e-5
     for k in res[True][1]:

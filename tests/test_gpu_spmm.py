@@ -239,12 +239,10 @@ def test_folded_backward_equals_two_kernels(mods, head, use_mask):
     out = out.cuda()
     dOut, dy, Wl = torch.randn(n, H).cuda(), torch.randn(n, C).cuda(), torch.randn(C, H).cuda()
     epi = EPI_ELU | EPI_DROPOUT
-    ops.FOLD_BACKWARD = False
     ref = ops.layer_backward(g, out, epi, 0.5, 77, mask, True, dOut=None if head else dOut, dy=dy if head else None,
-                             Wl=Wl if head else None, want_dWl=head)
-    ops.FOLD_BACKWARD = True
+                             Wl=Wl if head else None, want_dWl=head, cfg=ops.OpConfig(fold_backward=False))
     got = ops.layer_backward(g, out, epi, 0.5, 77, mask, True, dOut=None if head else dOut, dy=dy if head else None,
-                             Wl=Wl if head else None, want_dWl=head)
+                             Wl=Wl if head else None, want_dWl=head, cfg=ops.OpConfig(fold_backward=True))
     assert rel_err(got[0].cpu(), ref[0].cpu()) < 1e-5
     assert rel_err(got[1].cpu(), ref[1].cpu()) < 1e-4
     if head:
@@ -324,7 +322,7 @@ def test_weight_gradient_gemm_is_the_default_path(mods):
     _lib, csr, ops, orc, gorc = mods
     a = torch.randn(3000, 64).cuda()
     b = torch.randn(3000, 96).cuda()   # operands narrower than 64 columns stay on the library path (mostly padding in a tile)
-    assert ops.ATB_KERNEL
+    assert ops.DEFAULT.atb_kernel
     assert torch.equal(ops.mm_at_b(a, b), ops.gemm_atb(a, b))
     ref = a.double().t() @ b.double()
     assert float((ops.mm_at_b(a, b) - ref).abs().max() / ref.abs().max()) < 2e-5
@@ -357,10 +355,10 @@ def test_linear_gemm_matches_f64(mods, R, N, K):
 
 def test_linear_gemm_is_the_default_path_and_differentiates(mods):
     _lib, csr, ops, orc, gorc = mods
-    assert ops.NT_KERNEL
+    assert ops.DEFAULT.nt_kernel
     x = torch.randn(2048, 128, device="cuda", requires_grad=True)
     W = torch.randn(96, 128, device="cuda", requires_grad=True)
-    y = ops.Linear.apply(x, W)
+    y = ops.Linear.apply(x, W, ops.DEFAULT)
     assert torch.equal(y, ops.gemm_nt(x.detach(), W.detach()))
     gy = torch.randn_like(y)
     y.backward(gy)
@@ -436,11 +434,8 @@ def test_presplit_operand_staged_by_lds_dma_gives_the_same_bits(mods, R, N, K):
     epi = _lib.EPI_ELU | _lib.EPI_DROPOUT
     res = {}
     for pre in (False, True):
-        ops.NT_PRESPLIT = pre
-        try:
-            res[pre] = (ops.gemm_nt(a, W.t()), *ops.gemm_nt_epilogue_bwd(a, W.t(), out, epi, p=0.5, seed=7))
-        finally:
-            ops.NT_PRESPLIT = True
+        cfg = ops.OpConfig(nt_presplit=pre)
+        res[pre] = (ops.gemm_nt(a, W.t(), cfg), *ops.gemm_nt_epilogue_bwd(a, W.t(), out, epi, p=0.5, seed=7, cfg=cfg))
     for x, y in zip(res[False], res[True]):
         assert torch.equal(x, y)
     ref = a.double() @ W.double()

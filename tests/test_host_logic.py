@@ -334,3 +334,62 @@ def test_batched_dense_prelude_equals_one_at_a_time():
         ref = co._dense_prelude(W, b, e, 10)
         assert Kc[c] == ref.shape[1]
         assert np.array_equal(A[b:e, :ref.shape[1]], ref), c
+
+
+def test_numpy_assembly_matches_the_reference_loop_on_cora():
+    """data.assemble_subgraphs (host NumPy) == the reference's per-cluster loop restated in oracle/gs_oracle.py, on the real
+    Cora giant component with the partition the reference recorded (tests/golden): node lists, own / extra flags, edges."""
+    from golden_util import Golden
+
+    from fitgnn_amd.data import assemble_subgraphs
+    from oracle import gs_oracle
+
+    g = Golden("cora_giant")
+    coo = g.W.tocoo()
+    ei = np.stack([coo.row, coo.col]).astype(np.int64)
+    assign = g.final(0.5)["assign"].astype(np.int64)
+    n = int(assign.max()) + 1
+    for extra in (True, False):
+        sub = assemble_subgraphs(ei, g.N, assign, n, extra_node=extra)
+        ref = gs_oracle.cluster_subgraphs(ei, g.N, assign, extra)
+        owner = np.searchsorted(sub["ptr"], sub["edge_index"][0], side="right") - 1
+        for c in range(0, n, 7):   # every 7th cluster keeps the CPU tier short
+            s = ref[c]
+            r0, r1 = int(sub["ptr"][c]), int(sub["ptr"][c + 1])
+            assert np.array_equal(sub["node_id"][r0:r1], s["orig_idx"])
+            assert np.array_equal(sub["core"][r0:r1], ~np.isin(s["orig_idx"], s["actual_ext"]))
+            mine = sub["edge_index"][:, owner == c] - r0
+            assert set(zip(mine[0].tolist(), mine[1].tolist())) == set(zip(s["edge_index"][0].tolist(), s["edge_index"][1].tolist()))
+
+
+def test_select_clusters_and_sharding_partition_the_union():
+    """data.select_clusters (NumPy and torch forms) keeps whole subgraphs intact; the shards of data.shard_clusters are a
+    partition of the union and balance nnz'."""
+    from fitgnn_amd import data
+
+    ei = data.synthetic_graph(300, 900, seed=3)
+    rng = np.random.default_rng(0)
+    _, assign = np.unique(rng.integers(0, 40, size=300), return_inverse=True)
+    n = int(assign.max()) + 1
+    sub = data.assemble_subgraphs(ei, 300, assign, n, extra_node=True)
+    subt = data.assemble_subgraphs_torch(torch.from_numpy(ei), 300, assign, n, extra_node=True)
+    nz = data.cluster_nnz(sub)
+    assert np.array_equal(nz, data.cluster_nnz(subt))
+    assert nz.sum() == sub["edge_index"].shape[1] + sub["ptr"][-1]
+    owner = data.shard_clusters(None, nz, 3)
+    load = np.bincount(owner, weights=nz, minlength=3)
+    assert load.max() - load.min() <= nz.max()
+    total_edges = 0
+    for r in range(3):
+        cl = np.nonzero(owner == r)[0]
+        a, b = data.select_clusters(sub, cl), data.select_clusters(subt, cl)
+        for k in a:
+            assert np.array_equal(np.asarray(a[k]), b[k].numpy()), k
+        for j, c in enumerate(cl):
+            r0, r1, o0, o1 = a["ptr"][j], a["ptr"][j + 1], sub["ptr"][c], sub["ptr"][c + 1]
+            assert np.array_equal(a["node_id"][r0:r1], sub["node_id"][o0:o1])
+            ea = a["edge_index"][:, (a["edge_index"][0] >= r0) & (a["edge_index"][0] < r1)] - r0
+            eo = sub["edge_index"][:, (sub["edge_index"][0] >= o0) & (sub["edge_index"][0] < o1)] - o0
+            assert np.array_equal(ea, eo)
+        total_edges += a["edge_index"].shape[1]
+    assert total_edges == sub["edge_index"].shape[1]
