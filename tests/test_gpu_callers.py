@@ -178,8 +178,12 @@ def test_cli_data_parallel_run_equals_the_single_process_run(tmp_path):
     a = torch.load(one / "save" / "node_cls" / "o" / "model.pt", map_location="cpu")
     b = torch.load(two / "save" / "node_cls" / "o" / "model.pt", map_location="cpu")
     assert a.keys() == b.keys()
+    # Adam divides by sqrt(v): an entry whose gradient is at rounding-noise level moves by up to lr per step in either run, so
+    # the comparison is "almost every entry to 1e-5, no entry beyond a few noise-driven steps"
     for k in a:
-        assert float((a[k] - b[k]).abs().max()) <= 1e-4 * float(a[k].abs().max()) + 1e-6, k
+        d, top = (a[k] - b[k]).abs(), float(a[k].abs().max())
+        assert float(d.max()) <= 2e-3 * top + 1e-6, k
+        assert float((d > 1e-5 * top + 1e-7).float().mean()) < 0.02, k
     ra = (one / "results" / "synthetic-cora.csv").read_text().splitlines()
     rb = (two / "results" / "synthetic-cora.csv").read_text().splitlines()
     assert len(ra) == len(rb) == 2, "rank 0 alone writes the results row"
