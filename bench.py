@@ -52,6 +52,9 @@ def parse_args():
     ap.add_argument("--no-dedup", action="store_true",
                     help="run layer 0's X@W^T on the materialised union rows (one copy per subgraph membership) instead of "
                          "the de-duplicated feature table")
+    ap.add_argument("--no-dedup-gather", action="store_true",
+                    help="A/B: layer 0 on the de-duplicated table through the LDS-window SpMM (row indirection) instead of the "
+                         "direct-gather variant")
     ap.add_argument("--gemm-precision", default="high", choices=["high", "highest"],
                     help="dense GEMM policy of the timed region (ops.OpConfig.gemm_precision): high = fp32 via 3 x bf16 split "
                          "(rel err ~5e-6), highest = plain fp32 MFMA everywhere")
@@ -201,7 +204,7 @@ def main():
         torch.manual_seed(2)  # weight seed; identical on every rank
         model = network.Classify_node(margs).to(device)
         sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
-        cfg = ops.OpConfig(gemm_precision=precision, fold_backward=args.fold)
+        cfg = ops.OpConfig(gemm_precision=precision, fold_backward=args.fold, dedup_gather=not args.no_dedup_gather)
         tr = train.GDTrainer(model, batch, lr=0.01, weight_decay=5e-4, dedup=not args.no_dedup,
                              prune_unused_rows=args.prune_unused_rows, op_config=cfg)
         return tr, sd

@@ -97,11 +97,28 @@ __global__ __launch_bounds__(256) void epilogue_bwd_kernel(const float *__restri
         constexpr int U = 4;  // rows per wave in flight: all loads of a step are issued before the first use
         for (int row0 = r0 + wave; row0 < r1; row0 += 4 * U) {
             float g[U][VEC], o[U][VEC], dyl[U];
+            bool nz[U];
+            if (HEAD) {
+                // The head's gradient rows first: a row of zeros (a node that is not in the loss -- with --extra_node most
+                // rows of a subgraph, utils.py:695-698) makes dOut, hence dZ, a row of zeros whatever `out` holds, so its
+                // `out` row is not read and its C x VEC products are not formed.  Same bits as the long way round.
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int row = min(row0 + 4 * u, r1 - 1);
+                    dyl[u] = lane < C ? dy[(int64_t)row * C + lane] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) nz[u] = __ballot((__float_as_uint(dyl[u]) & 0x7fffffffu) != 0u) != 0ull;  // wave-uniform
+            }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int row = min(row0 + 4 * u, r1 - 1);  // clamped: rows past the chunk are loaded again, never used
                 const int64_t base = (int64_t)row * H + col0;
-                if (HEAD) dyl[u] = lane < C ? dy[(int64_t)row * C + lane] : 0.f;
+                if (HEAD && !nz[u]) {
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) o[u][i] = 0.f;
+                    continue;
+                }
                 if (VEC == 4) {
                     const float4 ov = *reinterpret_cast<const float4 *>(out + base);
                     o[u][0] = ov.x; o[u][1 % VEC] = ov.y; o[u][2 % VEC] = ov.z; o[u][3 % VEC] = ov.w;
@@ -119,6 +136,14 @@ __global__ __launch_bounds__(256) void epilogue_bwd_kernel(const float *__restri
                 const int row = row0 + 4 * u;
                 if (row >= r1) break;  // wave-uniform
                 const int64_t base = (int64_t)row * H + col0;
+                if (HEAD && !nz[u]) {  // dZ row = +0 (what 0 * dropout' * elu' gives); nothing to add to the sums
+                    if (VEC == 4) {
+                        *reinterpret_cast<float4 *>(dZ + base) = make_float4(0.f, 0.f, 0.f, 0.f);
+                    } else {
+                        dZ[base] = 0.f;
+                    }
+                    continue;
+                }
                 if (HEAD) {
 #pragma unroll
                     for (int i = 0; i < VEC; ++i) g[u][i] = 0.f;

@@ -97,12 +97,15 @@ class _Base(nn.Module):
                 link = None
         return x
 
-    def embed_and_head(self, x, edge_index, x_index=None, out_rows=None):
+    def embed_and_head(self, x, edge_index, x_index=None, out_rows=None, loss_rows=None):
         """embed() followed by lt1; on the GPU the last GCN layer and the head form one autograd node.
         x_index (ops.RowIndex, optional): x is a de-duplicated table and union row r is table row x_index.index[r].
         out_rows (csr.RowSubset, optional): return the head's output on those rows only.  The last layer is then
         evaluated as (A_hat[rows] h) W^T -- aggregation first, on the kept rows, so that its GEMM, activation and the
-        head run on len(rows) rows instead of all of them (same values on those rows: A (h W^T) = (A h) W^T)."""
+        head run on len(rows) rows instead of all of them (same values on those rows: A (h W^T) = (A h) W^T).
+        loss_rows (int64 index tensor, optional): the caller's promise that only these rows of the result reach its loss
+        (run.py:193-204 keeps out[mask]), i.e. that the gradient it sends back is zero elsewhere; the head's weight and bias
+        gradients are then reduced over those rows alone.  Every row is still evaluated."""
         L = self.num_layers
         if out_rows is not None:
             return self._embed_and_head_rows(x, edge_index, x_index, out_rows)
@@ -141,7 +144,7 @@ class _Base(nn.Module):
         cfg = self.op_config
         seed = ops.next_seed(cfg) if (self.training and self.dropout_p > 0 and mask is None) else 0
         return ops.FusedGCNLayerHead.apply(x, last.lin.weight, last.bias, self.lt1.weight, self.lt1.bias, g,
-                                           float(self.dropout_p), bool(self.training), seed, mask, link, cfg)
+                                           float(self.dropout_p), bool(self.training), seed, mask, link, cfg, loss_rows)
 
     def _embed_and_head_rows(self, x, edge_index, x_index, sub):
         L = self.num_layers

@@ -443,7 +443,7 @@ class RowIndex:
         self.seg_off = off.to(torch.int32).contiguous()
 
 
-def layer_backward(g, out, epi, p, seed, mask, want_db, dOut=None, dy=None, Wl=None, want_dWl=False, cfg=DEFAULT):
+def layer_backward(g, out, epi, p, seed, mask, want_db, dOut=None, dy=None, Wl=None, want_dWl=False, cfg=DEFAULT, loss_rows=None):
     """(dH, db, dWl) of one fused layer: dZ = epilogue'(dOut or dy @ Wl), db = colsum dZ, dH = A^T dZ.
     Epilogue-backward kernel + SpMM; with cfg.fold_backward one kernel (dZ stays in LDS) when the graph / shape allow it --
     measured on the S-pubmed union no faster than the two kernels (254 vs 223 us per hidden layer, 262 vs 263 us with the
@@ -485,7 +485,10 @@ def layer_backward(g, out, epi, p, seed, mask, want_db, dOut=None, dy=None, Wl=N
         inside = want_dWl and bool(L.fitgnn_epilogue_bwd_head_supported(H, C, 1))
         dZ, db, dWl = epilogue_bwd_head_raw(dy, Wl, out, epi, p=p, seed=seed, mask=mask, want_db=want_db, want_dWl=inside)
         if want_dWl and not inside:   # a wide head (ogbn-products: 47 classes): the kernel's registers hold 16 class rows
-            dWl = mm_at_b(_f32c(dy), out, cfg)
+            if loss_rows is not None:   # dy is zero outside these rows (the caller's contract): dy^T out over them alone
+                dWl = mm_at_b(_f32c(dy).index_select(0, loss_rows), out.index_select(0, loss_rows), cfg)
+            else:
+                dWl = mm_at_b(_f32c(dy), out, cfg)
     else:
         dZ, db = epilogue_bwd_raw(dOut, out, epi, p=p, seed=seed, mask=mask, want_db=want_db)
         dWl = None
@@ -607,9 +610,11 @@ class FusedGCNLayerHead(torch.autograd.Function):
     the epilogue-backward kernel forms it on the fly.  Requires num_classes <= fitgnn_head_max_classes()."""
 
     @staticmethod
-    def forward(ctx, X, W, b, Wl, bl, g, p, training, seed, mask, link_in, cfg):
+    def forward(ctx, X, W, b, Wl, bl, g, p, training, seed, mask, link_in, cfg, loss_rows=None):
+        """loss_rows (int64 index tensor, optional): the only rows of y that reach the loss -- the gradient dy the backward
+        receives is zero elsewhere, which lets the head's weight / bias gradients run over those rows alone."""
         X = _f32c(X)
-        ctx.link_in, ctx.cfg = link_in, cfg
+        ctx.link_in, ctx.cfg, ctx.loss_rows = link_in, cfg, loss_rows
         Hm = mm_xwt(X, W, cfg)
         epi = EPI_ELU | (EPI_BIAS if b is not None else 0)
         drop = bool(training) and p > 0.0
@@ -631,13 +636,14 @@ class FusedGCNLayerHead(torch.autograd.Function):
         epi = EPI_ELU | (EPI_DROPOUT if ctx.drop else 0)
         cfg = ctx.cfg
         dH, db, dWl = layer_backward(g, out, epi, ctx.p if ctx.drop else 0.0, ctx.seed, mask, ctx.has_bias, dy=dy, Wl=Wl,
-                                     want_dWl=ctx.needs_input_grad[3], cfg=cfg)
+                                     want_dWl=ctx.needs_input_grad[3], cfg=cfg, loss_rows=ctx.loss_rows)
         # [R, C] column sums: torch's dim-0 reduction of a tall 3-column matrix takes 50 us, a transposed copy + dim-1
         # reduction 23, the two-pass kernel 9
-        dbl = colsum_narrow(dy) if ctx.has_bl and ctx.needs_input_grad[4] else None
+        dy_l = dy if ctx.loss_rows is None else dy.index_select(0, ctx.loss_rows)
+        dbl = colsum_narrow(dy_l) if ctx.has_bl and ctx.needs_input_grad[4] else None
         dW = mm_at_b(dH, X, cfg) if ctx.needs_input_grad[1] else None
         dX = _dx_through_link(cfg, ctx.link_in, dH, W, X) if ctx.needs_input_grad[0] else None
-        return dX, dW, (db if ctx.has_bias else None), dWl, dbl, None, None, None, None, None, None, None
+        return dX, dW, (db if ctx.has_bias else None), dWl, dbl, None, None, None, None, None, None, None, None
 
 
 class FusedGCNLayerDedup(torch.autograd.Function):

@@ -185,7 +185,8 @@ class GDTrainer:
                      else m.embed_and_head(b.x, b.edge_index, out_rows=self.sub))
                 loss = SoftmaxNLL.apply(z, self._train_pos, self._y_train, scale)
             else:
-                z = m.embed_and_head(b.x_table, b.edge_index, b.row_index) if self.dedup else m.embed_and_head(b.x, b.edge_index)
+                z = (m.embed_and_head(b.x_table, b.edge_index, b.row_index, loss_rows=b.train_idx) if self.dedup
+                     else m.embed_and_head(b.x, b.edge_index, loss_rows=b.train_idx))
                 loss = SoftmaxNLL.apply(z, b.train_idx, self._y_train, scale)
             return self._backward_and_step(loss)
         out = m(b.x_table, b.edge_index, x_index=b.row_index) if self.dedup else m(b.x, b.edge_index)

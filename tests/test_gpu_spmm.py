@@ -217,6 +217,40 @@ def test_head_backward_folded_into_epilogue_kernel(mods, H, C):
     assert rel_err(dWl.cpu(), (dy.double().t() @ out.double()).float()) < 1e-5
 
 
+@pytest.mark.parametrize("H,C,with_dWl", [(512, 3, True), (512, 47, False), (64, 7, True)])
+def test_head_backward_skips_rows_without_gradient_bit_for_bit(mods, H, C, with_dWl):
+    """Rows whose head gradient dy is all zero (nodes outside the loss: most rows of an --extra_node subgraph) are written
+    as zeros without reading `out` or forming dy @ Wl: identical bits to the kernel run on a dy whose zero rows were
+    replaced by a denormal-free tiny value and compared where dy != 0, and exact +0 rows elsewhere -- also when those
+    rows of `out` hold values that the long way round would have multiplied (only finiteness matters)."""
+    _lib, csr, ops, orc, gorc = mods
+    from fitgnn_amd._lib import EPI_DROPOUT, EPI_ELU
+
+    torch.manual_seed(21)
+    n = 5003
+    out = torch.nn.functional.elu(torch.randn(n, H)).cuda()
+    keep = torch.rand(n) < 0.1                       # 10 % of the rows are in the loss, in runs and singly
+    keep[100:140] = True; keep[140:400] = False; keep[-1] = True
+    dy = torch.randn(n, C) * keep[:, None]
+    dy[7] = -0.0                                     # a row of negative zeros is a zero row too
+    Wl = torch.randn(C, H).cuda()
+    epi = EPI_ELU | EPI_DROPOUT
+    dZ, db, dWl = ops.epilogue_bwd_head_raw(dy.cuda(), Wl, out, epi, p=0.5, seed=99, want_dWl=with_dWl)
+    ref_dZ, ref_db = ops.epilogue_bwd_raw(dy.cuda() @ Wl, out, epi, p=0.5, seed=99)
+    assert rel_err(dZ.cpu(), ref_dZ.cpu()) < 1e-5 and rel_err(db.cpu(), ref_db.cpu()) < 1e-4
+    zero_rows = ~keep
+    zero_rows[7] = True
+    assert torch.count_nonzero(dZ[zero_rows.cuda()]) == 0
+    assert not torch.signbit(dZ[zero_rows.cuda()]).any(), "+0, as 0 * dropout' * elu' gives"
+    # the rows WITH gradient are computed exactly as when no row is skipped
+    dense = dy.clone(); dense[zero_rows] = torch.randn(int(zero_rows.sum()), C)
+    dZ2, _, _ = ops.epilogue_bwd_head_raw(dense.cuda(), Wl, out, epi, p=0.5, seed=99, want_dWl=with_dWl)
+    live = (~zero_rows).cuda()
+    assert torch.equal(dZ[live], dZ2[live])
+    if with_dWl:
+        assert rel_err(dWl.cpu(), (dy.double().t() @ out.cpu().double()).float()) < 1e-5
+
+
 @pytest.mark.parametrize("head", [False, True])
 @pytest.mark.parametrize("use_mask", [False, True])
 def test_folded_backward_equals_two_kernels(mods, head, use_mask):
