@@ -30,6 +30,7 @@ constexpr int kThreads = kWaves * 64;
 constexpr int kDefaultWindowRows = 16;  // LDS rows of the dense operand per workgroup (VEC=4: 1 KiB each)
 constexpr int kMaxWindowRows = 96;
 constexpr int kSmallWindowRows = 16;    // windows up to this size run the high-occupancy instantiation
+constexpr int kLongRow = 16;            // 64-entry chunks of a row with at least this many entries take the gather path
 
 template <int VEC> struct Pack;
 template <> struct Pack<4> {
@@ -203,6 +204,24 @@ __global__ __launch_bounds__(kThreads, (B <= 4 ? 8 : 4)) void spmm_tile_kernel(
                 if (i < n_meta) { my_c = s_col[i]; my_v = s_val[i]; } else { my_c = cidx[base + lane]; my_v = val[base + lane]; }
             }
             int k = 0;
+            if (cnt >= kLongRow) {
+                // A long row (a hub: the centre of a star-shaped subgraph references every leaf, most of them outside the
+                // window): all entries as plain gathers, eight in flight, no window test -- the loads are unconditional, so
+                // their waits are static counts; the one-at-a-time miss path below would pay ~100 L2 round trips in a row
+                // while the other three waves of the workgroup wait at the end of the tile.  Same order of additions.
+                for (; k + 8 <= cnt; k += 8) {
+                    T x[8];
+                    float w[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int c = __builtin_amdgcn_readlane(my_c, k + u) - slot_off;
+                        w[u] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_v), k + u));
+                        x[u] = *reinterpret_cast<const T *>(Xs + xsrc(gcol(c)) * ldx);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) P::fma(acc, w[u], x[u]);
+                }
+            }
             for (; k + 4 <= cnt; k += 4) {
                 const int c0 = __builtin_amdgcn_readlane(my_c, k) - slot_off;
                 const int c1 = __builtin_amdgcn_readlane(my_c, k + 1) - slot_off;

@@ -45,6 +45,20 @@ def main():
     print(f"{wl}: rows {R} nnz' {nnz} ({nnz / R:.2f}/row) subgraphs {len(sizes)} rows/subgraph mean {sizes.mean():.1f} max {sizes.max()} "
           f"bytes/launch {bytes_spmm / 1e6:.1f} MB", flush=True)
     graphs = {}
+    if "nohub" in variants:   # the same union with the entries of long rows (> 32 non-zeros: the hubs) removed: what their tails cost
+        e = sub["edge_index"]
+        deg = torch.bincount(e[1], minlength=R)
+        keep = deg[e[1]] <= 32
+        graphs[("nohub", windows[0])] = CSRGraph(e[:, keep].contiguous(), R, mode="gcn", ptr=ptr, lds_rows=windows[0], planned=False)
+        print(f"nohub: dropped {int((~keep).sum())} of {e.shape[1]} edges ({int((deg > 32).sum())} rows longer than 32)", flush=True)
+    if "nomiss" in variants:  # only the entries whose operand row sits in the output row's own tile: every entry is a window hit
+        from fitgnn_amd.csr import make_tiles
+        tl = make_tiles(ptr, windows[0])
+        tile_of = torch.from_numpy(np.repeat(np.arange(len(tl)), tl["row_end"] - tl["row_begin"])).to(dev)
+        e = sub["edge_index"]
+        keep = tile_of[e[0]] == tile_of[e[1]]
+        graphs[("nomiss", windows[0])] = CSRGraph(e[:, keep].contiguous(), R, mode="gcn", ptr=ptr, lds_rows=windows[0], planned=False)
+        print(f"nomiss: dropped {int((~keep).sum())} of {e.shape[1]} edges", flush=True)
     for w in windows:
         if "contig" in variants:
             graphs[("contig", w)] = CSRGraph(sub["edge_index"], R, mode="gcn", ptr=ptr, lds_rows=w, planned=False)
@@ -52,18 +66,28 @@ def main():
             graphs[("planned", w)] = CSRGraph(sub["edge_index"], R, mode="gcn", ptr=ptr, lds_rows=w, planned=True)
     if "gather" in variants:
         graphs[("gather", 0)] = CSRGraph(sub["edge_index"], R, mode="gcn", ptr=ptr, planned=False, gather=True)
+    # A/B bit of the LDS-window kernel: one tile per workgroup (round 1) instead of the pipelined form
+    flagsets = {"": 0}
+    if "ab" in variants:
+        pass
+        for k in list(graphs):
+            if k[0] == "contig":
+                for nm in flagsets:
+                    if nm:
+                        graphs[(k[0] + ":" + nm, k[1])] = graphs[k]
     res = {k: {"plain": [], "epi": []} for k in graphs}
     copy = []
     for rnd in range(4):
         for k, g in graphs.items():
-            res[k]["plain"].append(timeit(lambda: ops.spmm_graph(g, X, out=Y)))
-            res[k]["epi"].append(timeit(lambda: ops.spmm_graph(g, X, out=Y, bias=b, epilogue=EPI_BIAS | EPI_ELU | EPI_DROPOUT, p=0.5, seed=7)))
+            fl = flagsets.get(k[0].partition(":")[2], 0)
+            res[k]["plain"].append(timeit(lambda: ops.spmm_graph(g, X, out=Y, epilogue=fl)))
+            res[k]["epi"].append(timeit(lambda: ops.spmm_graph(g, X, out=Y, bias=b, epilogue=fl | EPI_BIAS | EPI_ELU | EPI_DROPOUT, p=0.5, seed=7)))
         copy.append(timeit(lambda: Y.copy_(X)))
     print(f"copy of {8 * H * R / 1e6:.1f} MB: {np.median(copy):.1f} us = {8 * H * R / np.median(copy) / 1e3:.0f} GB/s")
     for k, g in graphs.items():
         p, e = np.median(res[k]["plain"]), np.median(res[k]["epi"])
         miss = float((g.f.lcol < 0).float().mean()) if g.f.lcol is not None else float("nan")
-        print(f"{k[0]:8s} window {k[1]:3d} tiles {g.f.n_tiles:7d} planner-miss {miss:.3f}: plain {p:9.1f} us ({bytes_spmm / p / 1e3:6.0f} GB/s, "
+        print(f"{k[0]:24s} window {k[1]:3d} tiles {g.f.n_tiles:7d} planner-miss {miss:.3f}: plain {p:9.1f} us ({bytes_spmm / p / 1e3:6.0f} GB/s, "
               f"{bytes_spmm / p / 1e3 / 8000:.3f} of 8 TB/s)  epilogue {e:9.1f} us ({bytes_spmm / e / 1e3:6.0f} GB/s)", flush=True)
 
 
