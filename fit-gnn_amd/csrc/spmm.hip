@@ -75,13 +75,18 @@ __device__ __forceinline__ void finish_row(typename Pack<VEC>::T acc, int row, i
 // B = window rows each wave keeps in flight per pass; MPR = staged CSR entries per window row (8 B each).
 // <B=4, MPR=16> needs <= 64 VGPRs and ~18 KiB of LDS for a 16-row window: 8 workgroups (32 waves) per CU, which is
 // what hides the fetch -> compute -> store-acknowledge latency chain of a tile (~8 us under load) at HBM rate.
-template <int VEC, int B, int MPR>
+// PLAIN: contiguous windows and no row indirection (lcol == win_cols == xrow == NULL), the hidden layers' production case:
+// the column -> operand-row translation folds to an addition and the row loop carries no per-entry scalar branches.
+template <int VEC, int B, int MPR, bool PLAIN>
 __global__ __launch_bounds__(kThreads, (B <= 4 ? 8 : 4)) void spmm_tile_kernel(
     const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col, const float *__restrict__ val,
     const float *__restrict__ X, int64_t ldx, float *__restrict__ Y, int64_t ldy, int32_t H,
     const fitgnn_tile_t *__restrict__ tiles, int32_t n_tiles, int32_t tiles_per_xcd, int32_t n_slabs, int32_t lds_rows,
-    const int32_t *__restrict__ lcol, const int32_t *__restrict__ win_cols, const int32_t *__restrict__ xrow,
+    const int32_t *__restrict__ lcol_arg, const int32_t *__restrict__ win_cols_arg, const int32_t *__restrict__ xrow_arg,
     const float *__restrict__ bias, uint32_t epi, float p_drop, uint64_t seed_arg, const uint8_t *__restrict__ mask) {
+    const int32_t *__restrict__ lcol = PLAIN ? nullptr : lcol_arg;
+    const int32_t *__restrict__ win_cols = PLAIN ? nullptr : win_cols_arg;
+    const int32_t *__restrict__ xrow = PLAIN ? nullptr : xrow_arg;
     const uint64_t seed = fitgnn::resolve_seed(seed_arg, epi);
     using P = Pack<VEC>;
     using T = typename P::T;
@@ -110,8 +115,8 @@ __global__ __launch_bounds__(kThreads, (B <= 4 ? 8 : 4)) void spmm_tile_kernel(
     const int col0 = slab * SLAB + lane * VEC;
     const bool live = col0 + VEC <= H;
     const float *Xs = X + (live ? col0 : max(H - VEC, 0));  // dead lanes load a valid column group (never stored)
-    const bool planned = lcol != nullptr;                 // columns are LDS slots (>= 0) or -(global col + 1)
-    const bool listed = tile.reserved[0] != 0;            // window rows come from win_cols[]
+    const bool planned = !PLAIN && lcol != nullptr;          // columns are LDS slots (>= 0) or -(global col + 1)
+    const bool listed = !PLAIN && tile.reserved[0] != 0;     // window rows come from win_cols[]
     const int win_begin = tile.win_begin;
     const int win_rows = min(tile.win_rows, lds_rows);
     const int tile_rows = tile.row_end - tile.row_begin;
@@ -222,15 +227,20 @@ __global__ __launch_bounds__(kThreads, (B <= 4 ? 8 : 4)) void spmm_tile_kernel(
                     for (int u = 0; u < 8; ++u) P::fma(acc, w[u], x[u]);
                 }
             }
-            for (; k + 4 <= cnt; k += 4) {
+            // groups of four entries, all four operand reads issued before the first is consumed; a last group of 1-3
+            // entries is padded with copies of its first entry at weight 0 (adds +-0: the sums are unchanged) -- most rows
+            // hold 2-4 entries (self loop + the cluster's centre), and taken one at a time every read, LDS or L2, would wait
+            // for the one before it
+            for (; k < cnt; k += 4) {
+                const int k1 = min(k + 1, cnt - 1), k2 = min(k + 2, cnt - 1), k3 = min(k + 3, cnt - 1);
                 const int c0 = __builtin_amdgcn_readlane(my_c, k) - slot_off;
-                const int c1 = __builtin_amdgcn_readlane(my_c, k + 1) - slot_off;
-                const int c2 = __builtin_amdgcn_readlane(my_c, k + 2) - slot_off;
-                const int c3 = __builtin_amdgcn_readlane(my_c, k + 3) - slot_off;
+                const int c1 = __builtin_amdgcn_readlane(my_c, k1) - slot_off;
+                const int c2 = __builtin_amdgcn_readlane(my_c, k2) - slot_off;
+                const int c3 = __builtin_amdgcn_readlane(my_c, k3) - slot_off;
                 const float w0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_v), k));
-                const float w1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_v), k + 1));
-                const float w2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_v), k + 2));
-                const float w3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_v), k + 3));
+                const float w1 = k + 1 < cnt ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_v), k1)) : 0.f;
+                const float w2 = k + 2 < cnt ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_v), k2)) : 0.f;
+                const float w3 = k + 3 < cnt ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_v), k3)) : 0.f;
                 const bool in0 = (unsigned)c0 < (unsigned)win_rows, in1 = (unsigned)c1 < (unsigned)win_rows;
                 const bool in2 = (unsigned)c2 < (unsigned)win_rows, in3 = (unsigned)c3 < (unsigned)win_rows;
                 T x0, x1, x2, x3;
@@ -245,14 +255,6 @@ __global__ __launch_bounds__(kThreads, (B <= 4 ? 8 : 4)) void spmm_tile_kernel(
                     if (in3) x3 = lds[c3 * 64 + lane]; else x3 = *reinterpret_cast<const T *>(Xs + xsrc(g3) * ldx);
                 }
                 P::fma(acc, w0, x0); P::fma(acc, w1, x1); P::fma(acc, w2, x2); P::fma(acc, w3, x3);
-            }
-            for (; k < cnt; ++k) {
-                const int c = __builtin_amdgcn_readlane(my_c, k) - slot_off;
-                const float w = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_v), k));
-                T x;
-                if ((unsigned)c < (unsigned)win_rows) x = lds[c * 64 + lane];
-                else x = *reinterpret_cast<const T *>(Xs + xsrc(gcol(c)) * ldx);
-                P::fma(acc, w, x);
             }
         }
         if (live) finish_row<VEC>(acc, row, col0, H, Y, ldy, bv, epi, keep_scale, thresh, seed, mask);
@@ -426,7 +428,7 @@ inline size_t lds_bytes_for(int lds_rows, int slab_floats, int mpr) {
     return (size_t)lds_rows * slab_floats * 4 + (size_t)((lds_rows + 1 + 3) / 4 * 4) * 4 + (size_t)lds_rows * mpr * 8;
 }
 
-template <int VEC, int B, int MPR>
+template <int VEC, int B, int MPR, bool PLAIN>
 int launch_tile(const int32_t *rowptr, const int32_t *col, const float *val, const float *X, int64_t ldx, float *Y,
                 int64_t ldy, int32_t H, const fitgnn_tile_t *tiles, int32_t n_tiles, const int32_t *lcol,
                 const int32_t *win_cols, const int32_t *xrow, int32_t lds_rows, int n_slabs, int tiles_per_xcd,
@@ -434,12 +436,12 @@ int launch_tile(const int32_t *rowptr, const int32_t *col, const float *val, con
     constexpr int SLAB = 64 * VEC;
     const size_t lds_bytes = lds_bytes_for(lds_rows, SLAB, MPR);
     if (lds_bytes > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void *)spmm_tile_kernel<VEC, B, MPR>,
+        hipError_t e = hipFuncSetAttribute((const void *)spmm_tile_kernel<VEC, B, MPR, PLAIN>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return (int)e;
     }
     dim3 grid(tiles_per_xcd * 8 * n_slabs);
-    hipLaunchKernelGGL((spmm_tile_kernel<VEC, B, MPR>), grid, dim3(kThreads), lds_bytes, s, rowptr, col, val, X, ldx, Y, ldy,
+    hipLaunchKernelGGL((spmm_tile_kernel<VEC, B, MPR, PLAIN>), grid, dim3(kThreads), lds_bytes, s, rowptr, col, val, X, ldx, Y, ldy,
                        H, tiles, n_tiles, tiles_per_xcd, n_slabs, lds_rows, lcol, win_cols, xrow, bias, epi, p_drop, seed, mask);
     return (int)hipGetLastError();
 }
@@ -459,10 +461,13 @@ int launch(const int32_t *rowptr, const int32_t *col, const float *val, const fl
         return (int)hipGetLastError();
     }
     const int lds_rows = window_rows > 0 ? std::min(window_rows, kMaxWindowRows) : kDefaultWindowRows;
+    if (lds_rows <= kSmallWindowRows && !lcol && !win_cols && !xrow)
+        return launch_tile<VEC, 4, 16, true>(rowptr, col, val, X, ldx, Y, ldy, H, tiles, n_tiles, lcol, win_cols, xrow, lds_rows, n_slabs,
+                                             tiles_per_xcd, bias, epi, p_drop, seed, mask, s);
     if (lds_rows <= kSmallWindowRows)
-        return launch_tile<VEC, 4, 16>(rowptr, col, val, X, ldx, Y, ldy, H, tiles, n_tiles, lcol, win_cols, xrow, lds_rows, n_slabs,
+        return launch_tile<VEC, 4, 16, false>(rowptr, col, val, X, ldx, Y, ldy, H, tiles, n_tiles, lcol, win_cols, xrow, lds_rows, n_slabs,
                                        tiles_per_xcd, bias, epi, p_drop, seed, mask, s);
-    return launch_tile<VEC, 8, 32>(rowptr, col, val, X, ldx, Y, ldy, H, tiles, n_tiles, lcol, win_cols, xrow, lds_rows, n_slabs,
+    return launch_tile<VEC, 8, 32, false>(rowptr, col, val, X, ldx, Y, ldy, H, tiles, n_tiles, lcol, win_cols, xrow, lds_rows, n_slabs,
                                    tiles_per_xcd, bias, epi, p_drop, seed, mask, s);
 }
 
