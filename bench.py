@@ -317,7 +317,9 @@ def main():
                    else "materialised union rows",
                    "rank0_union_rows": R, "rank0_nnz_prime": batch.nnz,
                    **info},
-        "roofline": {"kernel": "spmm_tile_kernel (CSR SpMM, LDS row windows, H=%d, f32)" % H, "bound": "hbm", "achieved": achieved,
+        "roofline": {"kernel": ("spmm_block_kernel + spmm_tile_kernel (CSR SpMM: whole-subgraph kernel over the stars, LDS row windows over "
+                                "the small ones; H=%d, f32)" if batch.graph.f.blocks is not None else
+                                "spmm_tile_kernel (CSR SpMM, LDS row windows, H=%d, f32)") % H, "bound": "hbm", "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": None,   # PMC bytes cannot be read inside the run: profiles/ holds the rocprofv3 --pmc passes of this command
                      "algorithmic_bytes_per_launch": bytes_spmm, "avg_launch_us": spmm_ms * 1e3,

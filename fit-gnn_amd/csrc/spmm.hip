@@ -261,6 +261,274 @@ __global__ __launch_bounds__(kThreads, (B <= 4 ? 8 : 4)) void spmm_tile_kernel(
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Whole-subgraph kernel for diagonal blocks LARGER than the window (fitgnn_spmm_csr_blocks_f32).
+//
+// Why: cut into window-sized tiles, a large subgraph re-reads its operand rows.  --extra_node subgraphs are stars (a
+// cluster's few own nodes, the centres, and their many neighbours, utils.py:235-239): every leaf row references the centres
+// and a centre's row references every leaf, and of those references only the ones inside the tile's own 16 rows are window
+// hits.  The rest are gathered again -- by the time a centre's row is processed its leaves' rows, streamed by other
+// workgroups, have left the 4-MiB L2: rocprofv3 --pmc on S-products (one ogbn-products community, 82.5 k subgraphs of ~100
+// rows) counts 49.7 GB at the memory side per launch against 34.0 GB algorithmic, 6.4 TB/s of real traffic for 4.4 TB/s of
+// useful work.  Here ONE workgroup walks a whole block in 16-row pieces and reads every operand row exactly once:
+//   * the rows of the block's LONG rows (the centres; up to kBlkLong per block) are pinned in LDS for the whole block, so a
+//     leaf's reference to a centre is an LDS hit in every piece;
+//   * a long row is not computed in its own piece: the wave that owns it carries its accumulator across ALL pieces and, as
+//     each piece's window sits in LDS, adds that piece's share of the row -- its CSR entries are sorted by column, so the
+//     pieces consume them in order and the additions happen in exactly the order of the one-row-at-a-time kernel (same bits);
+//   * the next piece (window rows, row pointers, CSR slice) is prefetched into registers while the current one is computed:
+//     the workgroup is persistent over its block, so operand bytes are in flight all the time.
+// Entries of short rows that point outside their piece at a row that is not pinned (leaf -- leaf edges across pieces) are
+// gathered from L2 / HBM as in the tile kernel.  A "block" is any run of consecutive rows (a SEGMENT): columns outside it are
+// legal and are gathered too, so a connected subgraph with many centres is cut into one segment per centre (its star) once
+// the rows are laid out star by star (data.SubgraphBatch, layout="star").  H % 4 == 0 only (callers tile otherwise).
+constexpr int kBlkRows = 16;   // rows per piece (== the tile kernel's default window)
+constexpr int kBlkLong = 8;    // long rows carried per block: two per wave
+constexpr int kBlkMeta = 128;  // CSR entries of a piece staged in LDS (threads 0..127 fetch one each): a piece of 16 short rows
+                               // holds ~50; with 256, on stars of ~50 rows, the staging itself was 8 % of the kernel's reads
+
+__global__ __launch_bounds__(kThreads, 6) void spmm_block_kernel(
+    const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col, const float *__restrict__ val,
+    const float *__restrict__ X, int64_t ldx, float *__restrict__ Y, int64_t ldy, int32_t H,
+    const fitgnn_block_t *__restrict__ blocks, int32_t n_blocks, const int32_t *__restrict__ long_rows, int32_t n_slabs,
+    const float *__restrict__ bias, uint32_t epi, float p_drop, uint64_t seed_arg, const uint8_t *__restrict__ mask) {
+    using P = Pack<4>;
+    using T = float4;
+    const uint64_t seed = fitgnn::resolve_seed(seed_arg, epi);
+    __shared__ T s_win[(kBlkRows + kBlkLong) * 64];  // piece window, then the pinned rows
+    __shared__ int32_t s_rp[kBlkRows + 4];
+    __shared__ int32_t s_col[kBlkMeta];
+    __shared__ float s_val[kBlkMeta];
+    __shared__ int32_t s_long[kBlkLong];
+    const int bid = blockIdx.x;
+    const int slab = bid % n_slabs;
+    const int b = bid / n_slabs;
+    if (b >= n_blocks) return;
+    const fitgnn_block_t blk = blocks[b];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int col0 = slab * 256 + lane * 4;
+    const bool live = col0 + 4 <= H;
+    const float *Xs = X + (live ? col0 : max(H - 4, 0));
+    const int n_long = min(blk.n_long, kBlkLong);
+    const float keep_scale = (epi & FITGNN_EPI_DROPOUT) ? 1.0f / (1.0f - p_drop) : 1.0f;
+    const uint32_t thresh = fitgnn::dropout_threshold(p_drop);
+    float bv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bv[i] = ((epi & FITGNN_EPI_BIAS) && live) ? bias[col0 + i] : 0.f;
+
+    // ---- the block's long rows: ids to LDS, their operand rows pinned, this wave's two accumulators and entry cursors ----
+    if ((int)threadIdx.x < kBlkLong) s_long[threadIdx.x] = (int)threadIdx.x < n_long ? long_rows[blk.long_off + threadIdx.x] : -1;
+    int my_long[2], cur[2], end[2], pos[2], lc[2];
+    float lv[2];
+    T acc_long[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int slot = wave + q * kWaves;
+        my_long[q] = slot < n_long ? long_rows[blk.long_off + slot] : -1;
+        my_long[q] = __builtin_amdgcn_readfirstlane(my_long[q]);
+        acc_long[q] = P::zero();
+        cur[q] = end[q] = 0;
+        pos[q] = 64;  // "chunk exhausted": the first use loads entries [cur, cur + 64)
+        lc[q] = 0x7fffffff;
+        lv[q] = 0.f;
+        if (my_long[q] >= 0) {
+            cur[q] = __builtin_amdgcn_readfirstlane(rowptr[my_long[q]]);
+            end[q] = __builtin_amdgcn_readfirstlane(rowptr[my_long[q] + 1]);
+            s_win[(kBlkRows + slot) * 64 + lane] = *reinterpret_cast<const T *>(Xs + (int64_t)my_long[q] * ldx);
+        }
+    }
+    __syncthreads();
+    int lid[kBlkLong];  // the long-row ids, wave-uniform
+#pragma unroll
+    for (int i = 0; i < kBlkLong; ++i) lid[i] = __builtin_amdgcn_readfirstlane(s_long[i]);
+
+    // ---- piece prefetch (registers): window rows wave, wave + 4, ...; row pointers; the piece's CSR slice ----
+    T pv[4];
+    int p_rp = 0, p_c = 0, p_E0 = 0, p_n = 0;
+    float p_v = 0.f;
+    auto prefetch = [&](int r0, int r1, int E0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = r0 + wave + j * kWaves;
+            pv[j] = P::zero();
+            if (r < r1) pv[j] = *reinterpret_cast<const T *>(Xs + (int64_t)r * ldx);
+        }
+        p_rp = 0;
+        if ((int)threadIdx.x <= r1 - r0) p_rp = rowptr[r0 + threadIdx.x];
+        // the slice's end is not known yet (it is rowptr[r1], in flight above): stage the next kBlkMeta entries of the block,
+        // clamped to the block's last entry; entries past the piece's end are ignored by the row loop
+        if ((int)threadIdx.x < kBlkMeta) {
+            const int e = min(E0 + (int)threadIdx.x, blk.nnz_end - 1);
+            p_c = col[e];
+            p_v = val[e];
+        }
+        p_E0 = E0;
+    };
+    const int n_pieces = (blk.row_end - blk.row_begin + kBlkRows - 1) / kBlkRows;
+    prefetch(blk.row_begin, min(blk.row_begin + kBlkRows, blk.row_end), blk.nnz_begin);
+
+    // A long row's entries OUTSIDE the segment (a segment need not be a whole connected subgraph: the stars of a large
+    // cluster are segments of their own, and their centres reference each other) are gathered, eight in flight, before
+    // (columns < row_begin) and after (columns >= row_end) the pieces -- in CSR order, like everything else.
+    auto gather_long = [&](int q, int bound) {  // consume the entries of long row q whose column is < bound
+        while (cur[q] < end[q]) {
+            if (pos[q] == 64) {
+                const int e = cur[q] + lane;
+                lc[q] = e < end[q] ? col[e] : 0x7fffffff;
+                lv[q] = e < end[q] ? val[e] : 0.f;
+                pos[q] = 0;
+            }
+            const unsigned long long in = __ballot(lc[q] < bound) >> pos[q];
+            const int n_in = in == 0 ? 0 : (int)__builtin_popcountll(in);
+            for (int k = pos[q]; k < pos[q] + n_in; k += 8) {
+                const int last = pos[q] + n_in - 1;
+                T x[8];
+                float w[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int kk = min(k + u, last);
+                    const int c = __builtin_amdgcn_readlane(lc[q], kk);
+                    w[u] = k + u <= last ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lv[q]), kk)) : 0.f;
+                    x[u] = *reinterpret_cast<const T *>(Xs + (int64_t)c * ldx);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) P::fma(acc_long[q], w[u], x[u]);
+            }
+            pos[q] += n_in;
+            cur[q] += n_in;
+            if (pos[q] < 64) break;
+        }
+    };
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+        if (my_long[q] >= 0) gather_long(q, blk.row_begin);
+    for (int p = 0; p < n_pieces; ++p) {
+        const int r0 = blk.row_begin + p * kBlkRows, r1 = min(r0 + kBlkRows, blk.row_end);
+        const int rows = r1 - r0;
+        // ---- publish the prefetched piece ----
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = wave + j * kWaves;
+            if (r < rows) s_win[r * 64 + lane] = pv[j];
+        }
+        if ((int)threadIdx.x <= rows) s_rp[threadIdx.x] = p_rp;
+        const int E0 = p_E0;
+        if ((int)threadIdx.x < kBlkMeta) {   // entry -> LDS row (window slot, pinned row) or -(operand row + 1): resolved once, by the thread that stages it
+            int sl = p_c - r0;
+            if ((unsigned)sl >= (unsigned)rows) {
+                sl = -(p_c + 1);
+#pragma unroll
+                for (int i = 0; i < kBlkLong; ++i)
+                    if (p_c == lid[i]) sl = kBlkRows + i;
+            }
+            s_col[threadIdx.x] = sl;
+            s_val[threadIdx.x] = p_v;
+        }
+        // Bare barriers inside the piece loop: __syncthreads() would drain vmcnt, i.e. wait for the NEXT piece's prefetch and
+        // for the acknowledgement of this piece's row stores.  The hand-off only involves LDS: lgkmcnt(0) covers this wave's
+        // ds_writes (above) / ds_reads (at the end of the piece).
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        const int E1 = __builtin_amdgcn_readfirstlane(s_rp[rows]);
+        const int n_meta = min(E1 - E0, kBlkMeta);
+        if (p + 1 < n_pieces) prefetch(r1, min(r1 + kBlkRows, blk.row_end), E1);
+
+        // ---- short rows of the piece ----
+        for (int row = r0 + wave; row < r1; row += kWaves) {
+            bool is_long = false;
+#pragma unroll
+            for (int i = 0; i < kBlkLong; ++i) is_long |= (row == lid[i]);
+            if (is_long) continue;  // wave-uniform
+            const int lr = row - r0;
+            const int e0 = __builtin_amdgcn_readfirstlane(s_rp[lr]);
+            const int e1 = __builtin_amdgcn_readfirstlane(s_rp[lr + 1]);
+            T acc = P::zero();
+            for (int base = e0; base < e1; base += 64) {
+                const int cnt = min(64, e1 - base);
+                int my_c = 0;
+                float my_v = 0.f;
+                if (lane < cnt) {
+                    const int i = base + lane - E0;
+                    if (i < n_meta) { my_c = s_col[i]; my_v = s_val[i]; }
+                    else {  // beyond the staged slice: resolve here
+                        const int c = col[base + lane];
+                        my_v = val[base + lane];
+                        my_c = c - r0;
+                        if ((unsigned)my_c >= (unsigned)rows) {
+                            my_c = -(c + 1);
+#pragma unroll
+                            for (int t = 0; t < kBlkLong; ++t)
+                                if (c == lid[t]) my_c = kBlkRows + t;
+                        }
+                    }
+                }
+                for (int k = 0; k < cnt; k += 4) {
+                    const int k1 = min(k + 1, cnt - 1), k2 = min(k + 2, cnt - 1), k3 = min(k + 3, cnt - 1);
+                    const int c0 = __builtin_amdgcn_readlane(my_c, k), c1 = __builtin_amdgcn_readlane(my_c, k1);
+                    const int c2 = __builtin_amdgcn_readlane(my_c, k2), c3 = __builtin_amdgcn_readlane(my_c, k3);
+                    const float w0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_v), k));
+                    const float w1 = k + 1 < cnt ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_v), k1)) : 0.f;
+                    const float w2 = k + 2 < cnt ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_v), k2)) : 0.f;
+                    const float w3 = k + 3 < cnt ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_v), k3)) : 0.f;
+                    T x0, x1, x2, x3;
+                    if ((c0 | c1 | c2 | c3) >= 0) {  // wave-uniform: four LDS reads in flight
+                        x0 = s_win[c0 * 64 + lane]; x1 = s_win[c1 * 64 + lane];
+                        x2 = s_win[c2 * 64 + lane]; x3 = s_win[c3 * 64 + lane];
+                    } else {
+                        if (c0 >= 0) x0 = s_win[c0 * 64 + lane]; else x0 = *reinterpret_cast<const T *>(Xs + (int64_t)(-(c0 + 1)) * ldx);
+                        if (c1 >= 0) x1 = s_win[c1 * 64 + lane]; else x1 = *reinterpret_cast<const T *>(Xs + (int64_t)(-(c1 + 1)) * ldx);
+                        if (c2 >= 0) x2 = s_win[c2 * 64 + lane]; else x2 = *reinterpret_cast<const T *>(Xs + (int64_t)(-(c2 + 1)) * ldx);
+                        if (c3 >= 0) x3 = s_win[c3 * 64 + lane]; else x3 = *reinterpret_cast<const T *>(Xs + (int64_t)(-(c3 + 1)) * ldx);
+                    }
+                    P::fma(acc, w0, x0); P::fma(acc, w1, x1); P::fma(acc, w2, x2); P::fma(acc, w3, x3);
+                }
+            }
+            if (live) finish_row<4>(acc, row, col0, H, Y, ldy, bv, epi, keep_scale, thresh, seed, mask);
+        }
+
+        // ---- this wave's long rows: the entries whose operand rows sit in this piece (columns < r1), in CSR order ----
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            if (my_long[q] < 0) continue;  // wave-uniform
+            while (cur[q] < end[q]) {
+                if (pos[q] == 64) {  // next 64 entries of the row into the lanes
+                    const int e = cur[q] + lane;
+                    lc[q] = e < end[q] ? col[e] : 0x7fffffff;
+                    lv[q] = e < end[q] ? val[e] : 0.f;
+                    pos[q] = 0;
+                }
+                // entries are sorted by column: those of this piece are the lanes >= pos with col < r1
+                const unsigned long long in = __ballot(lc[q] < r1) >> pos[q];
+                const int n_in = in == 0 ? 0 : (int)__builtin_popcountll(in);
+                for (int k = pos[q]; k < pos[q] + n_in; k += 4) {
+                    const int last = pos[q] + n_in - 1;
+                    const int k1 = min(k + 1, last), k2 = min(k + 2, last), k3 = min(k + 3, last);
+                    const int c0 = __builtin_amdgcn_readlane(lc[q], k) - r0, c1 = __builtin_amdgcn_readlane(lc[q], k1) - r0;
+                    const int c2 = __builtin_amdgcn_readlane(lc[q], k2) - r0, c3 = __builtin_amdgcn_readlane(lc[q], k3) - r0;
+                    const float w0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lv[q]), k));
+                    const float w1 = k + 1 <= last ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lv[q]), k1)) : 0.f;
+                    const float w2 = k + 2 <= last ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lv[q]), k2)) : 0.f;
+                    const float w3 = k + 3 <= last ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lv[q]), k3)) : 0.f;
+                    const T x0 = s_win[c0 * 64 + lane], x1 = s_win[c1 * 64 + lane];
+                    const T x2 = s_win[c2 * 64 + lane], x3 = s_win[c3 * 64 + lane];
+                    P::fma(acc_long[q], w0, x0); P::fma(acc_long[q], w1, x1); P::fma(acc_long[q], w2, x2); P::fma(acc_long[q], w3, x3);
+                }
+                pos[q] += n_in;
+                cur[q] += n_in;
+                if (pos[q] < 64) break;  // the rest of the chunk belongs to later pieces
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // the window is overwritten by the next piece
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        if (my_long[q] < 0) continue;
+        gather_long(q, 0x7fffffff);
+        if (live) finish_row<4>(acc_long[q], my_long[q], col0, H, Y, ldy, bv, epi, keep_scale, thresh, seed, mask);
+    }
+}
+
 // Direct-gather variant for very sparse batches (few non-zeros per row, e.g. PubMed-like subgraphs with
 // ~3 entries per row): no LDS phase, no barrier.  Each wave owns a CONTIGUOUS run of the tile's rows, so its
 // slice of the CSR is contiguous too: one vector load brings the run's row pointers, one more its (col, val)
@@ -497,4 +765,23 @@ extern "C" int fitgnn_spmm_csr_f32(const int32_t *rowptr, const int32_t *col, co
     const bool vec = (H % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) && (((uintptr_t)X | (uintptr_t)Y) % 16 == 0);
     if (vec) return launch<4>(rowptr, col, val, X, ldx, Y, ldy, H, tiles, n_tiles, lcol, win_cols, xrow, window_rows, bias, epilogue, p_drop, seed, mask, s);
     return launch<1>(rowptr, col, val, X, ldx, Y, ldy, H, tiles, n_tiles, lcol, win_cols, xrow, window_rows, bias, epilogue, p_drop, seed, mask, s);
+}
+
+extern "C" int fitgnn_spmm_csr_blocks_f32(const int32_t *rowptr, const int32_t *col, const float *val, const float *X,
+                                          int64_t ldx, float *Y, int64_t ldy, int32_t n_rows, int32_t H,
+                                          const fitgnn_block_t *blocks, int32_t n_blocks, const int32_t *long_rows,
+                                          const float *bias, uint32_t epilogue, float p_drop, uint64_t seed,
+                                          const uint8_t *mask, void *stream) {
+    if (n_rows < 0 || H < 0 || n_blocks < 0) return FITGNN_E_BADARG;
+    if (n_rows == 0 || H == 0 || n_blocks == 0) return 0;
+    if (!rowptr || !col || !val || !X || !Y || !blocks) return FITGNN_E_BADARG;
+    if ((epilogue & FITGNN_EPI_BIAS) && !bias) return FITGNN_E_BADARG;
+    if ((epilogue & FITGNN_EPI_DROPOUT) && !(p_drop >= 0.f && p_drop < 1.f)) return FITGNN_E_BADARG;
+    if (ldx < H || ldy < H) return FITGNN_E_BADARG;
+    if ((H % 4) != 0 || (ldx % 4) != 0 || (ldy % 4) != 0) return FITGNN_E_BADARG;
+    if ((((uintptr_t)X | (uintptr_t)Y) % 16) != 0) return FITGNN_E_ALIGN;
+    const int n_slabs = (H + 255) / 256;
+    hipLaunchKernelGGL(spmm_block_kernel, dim3((unsigned)n_blocks * n_slabs), dim3(kThreads), 0, (hipStream_t)stream, rowptr, col, val, X,
+                       ldx, Y, ldy, H, blocks, n_blocks, long_rows, n_slabs, bias, epilogue, p_drop, seed, mask);
+    return (int)hipGetLastError();
 }

@@ -82,7 +82,7 @@ def block_boundaries(rowptr, col, n_rows):
                       torch.tensor([n_rows], dtype=torch.int64, device=device)])
 
 
-def make_tiles(ptr, max_rows):
+def make_tiles(ptr, max_rows, whole=True):
     """Pack consecutive diagonal blocks into row tiles of at most `max_rows` rows (window == the tile's
     own row range, so every column of a block-diagonal batch is a window hit).  Blocks larger than
     `max_rows` are cut into `max_rows`-row pieces whose window is the piece itself (off-window columns
@@ -110,8 +110,62 @@ def make_tiles(ptr, max_rows):
     if tiles:
         arr = np.asarray(tiles, dtype=np.int32)
         out["row_begin"], out["row_end"], out["win_begin"], out["win_rows"] = arr[:, 0], arr[:, 1], arr[:, 2], arr[:, 3]
-    assert n == 0 or (out["row_begin"][0] == 0 and out["row_end"][-1] == n)
+    assert (not whole) or n == 0 or (out["row_begin"][0] == 0 and out["row_end"][-1] == n)
     return out
+
+
+BLOCK_INTS = 8     # sizeof(fitgnn_block_t) / 4
+LONG_ROW = 16      # rows with more non-zeros are a block's "long rows" (spmm.hip kLongRow)
+
+
+def split_blocks(ptr, rowptr, cap, limit=None):
+    """Diagonal blocks of cap < rows <= limit -> fitgnn_block_t records + their long rows (the whole-subgraph kernel: one
+    workgroup per block and column slab walks it in cap-row pieces); everything else -> tiles (consecutive blocks packed,
+    never across a whole-subgraph block; a block beyond `limit` is cut into cap-row tiles as before).  limit bounds the
+    longest-running workgroup: by default rows / 2048 (a 256-CU chip then holds >= 8 such blocks per CU), at least 4 pieces.
+    ptr: block row offsets (numpy); rowptr: device/host int tensor.
+    Returns (tiles TILE_DTYPE array, blocks int32 [NB, 8], long_rows int32 [NL]) as numpy."""
+    ptr = np.asarray(ptr, dtype=np.int64)
+    rp = rowptr.detach().cpu().numpy().astype(np.int64)
+    size = np.diff(ptr)
+    if limit is None:
+        limit = max(4 * cap, int(ptr[-1]) // 2048)
+    is_large = (size > cap) & (size <= limit)
+    large = np.nonzero(is_large)[0]
+    # tiles over the maximal runs of consecutive other blocks
+    tiles = []
+    nb = len(size)
+    b = 0
+    while b < nb:
+        if is_large[b]:
+            b += 1
+            continue
+        e = b
+        while e < nb and not is_large[e]:
+            e += 1
+        tiles.append(make_tiles(ptr[b:e + 1], cap, whole=False) if e > b else None)
+        b = e
+    small = np.concatenate([t for t in tiles if t is not None and len(t)]) if any(t is not None and len(t) for t in tiles) else np.zeros(0, dtype=TILE_DTYPE)
+    blocks = np.zeros((len(large), BLOCK_INTS), dtype=np.int32)
+    long_rows = np.zeros(0, dtype=np.int32)
+    if len(large):
+        deg = np.diff(rp)
+        r0, r1 = ptr[large], ptr[large + 1]
+        blocks[:, 0], blocks[:, 1] = r0, r1
+        blocks[:, 2], blocks[:, 3] = rp[r0], rp[r1]
+        block_of_row = np.repeat(np.arange(len(large)), r1 - r0)
+        rows = np.concatenate([np.arange(a, b_) for a, b_ in zip(r0, r1)]) if len(large) < 4096 else \
+            (np.repeat(r0, r1 - r0) + (np.arange(int((r1 - r0).sum())) - np.repeat(np.cumsum(r1 - r0) - (r1 - r0), r1 - r0)))
+        is_long = deg[rows] > LONG_ROW
+        lr, lb = rows[is_long], block_of_row[is_long]
+        cnt = np.bincount(lb, minlength=len(large))
+        off = np.cumsum(cnt) - cnt
+        blocks[:, 4], blocks[:, 5] = off, cnt
+        long_rows = lr.astype(np.int32)
+        # heaviest blocks first: the longest-running workgroups start early
+        order = np.argsort(-(r1 - r0), kind="stable")
+        blocks = blocks[order]
+    return small, blocks, long_rows
 
 
 def _csr_from_coo(row, col, n_rows):
@@ -125,12 +179,16 @@ def _csr_from_coo(row, col, n_rows):
 
 
 class _Side:
-    """One orientation of the pattern (forward or transposed) with its planned tiles."""
-    __slots__ = ("rowptr", "col", "val", "tiles", "lcol", "win_cols", "n_tiles")
+    """One orientation of the pattern (forward or transposed) with its planned tiles.
+    `tiles` covers every row.  `small_tiles` / `blocks` / `long_rows` (contiguous windows only) cover the rows once more, split
+    by block size: tiles that pack the diagonal blocks of at most a window, and the larger blocks as fitgnn_block_t records
+    for the whole-subgraph kernel (fitgnn_spmm_csr_blocks_f32), which reads each of their operand rows once."""
+    __slots__ = ("rowptr", "col", "val", "tiles", "lcol", "win_cols", "n_tiles", "small_tiles", "blocks", "long_rows")
 
     def __init__(self, rowptr, col):
         self.rowptr, self.col = rowptr, col
         self.val = self.tiles = self.lcol = self.win_cols = None
+        self.small_tiles = self.blocks = self.long_rows = None
         self.n_tiles = 0
 
 
@@ -163,7 +221,8 @@ class CSRGraph:
     rowptr/col/val/tiles and rowptr_t/col_t/val_t/tiles_t.
     """
 
-    def __init__(self, edge_index, num_nodes, mode="gcn", ptr=None, lds_rows=None, planned=False, gather=False):
+    def __init__(self, edge_index, num_nodes, mode="gcn", ptr=None, lds_rows=None, planned=False, gather=False, split_large=True,
+                 block_limit=None):
         """mode: 'gcn'  -> add_remaining_self_loops + D^-1/2 (A+I) D^-1/2      (GCNConv, APPNP)
                  'sum'  -> plain adjacency, value 1 per edge                  (GINConv aggregation)
                  'mean' -> plain adjacency, value 1/in_degree(target)         (SAGEConv aggregation)
@@ -175,7 +234,8 @@ class CSRGraph:
         assert edge_index.dim() == 2 and edge_index.shape[0] == 2
         device = edge_index.device
         self.device, self.n, self.mode = device, int(num_nodes), mode
-        self.planned, self.gather = planned, gather
+        self.planned, self.gather, self.split_large, self.block_limit = planned, gather, split_large, block_limit
+        self.split_min_rows = 1_000_000   # x 2 KiB rows = 2 GB at hidden 512: far beyond the 256-MiB Infinity Cache
         # tiles from make_tiles: contiguous windows covering their own rows -> the folded backward kernel applies
         self.fold_ok = (not planned) and (not gather)
         src, dst = edge_index[0].to(torch.int64), edge_index[1].to(torch.int64)
@@ -242,9 +302,22 @@ class CSRGraph:
                 side.n_tiles = int(tiles.shape[0])
         else:
             tiles = make_tiles(ptr_np, cap)
+            has_large = bool(len(ptr_np) > 1 and np.max(np.diff(ptr_np)) > cap)
             for side in (f, t):  # same diagonal blocks, each side its own CSR offsets
                 side.tiles = tiles_to_device(tiles, side.rowptr)
                 side.n_tiles = int(tiles.shape[0])
+                if has_large and self.split_large and not self.gather and self.nnz > 0:
+                    small, blocks, long_rows = split_blocks(ptr_np, side.rowptr, cap, self.block_limit)
+                    # the whole-subgraph kernel saves re-reads from HBM: it pays when a good part of the batch sits in such runs
+                    # and the operand is beyond the Infinity Cache (a launch on the 90 k-row PubMed union lasts 80 us: a second
+                    # launch and a few long-running workgroups cost more than the re-reads, which stay on-die there)
+                    in_blocks = int((blocks[:, 1] - blocks[:, 0]).sum()) if len(blocks) else 0
+                    if self.block_limit is None and (in_blocks * 5 < self.n * 3 or self.n < self.split_min_rows):
+                        continue   # measured: S-products (stars of ~50 rows) 8.27 -> 7.50 ms with the fused epilogue; S-physics
+                                   # (stars of ~14 rows, 40 % of the rows in such runs) 399 -> 441 us: tiles stay the default there
+                    side.small_tiles = tiles_to_device(small, side.rowptr) if len(small) else torch.zeros((0, TILE_INTS), dtype=torch.int32, device=dev)
+                    side.blocks = torch.from_numpy(blocks).to(dev)
+                    side.long_rows = torch.from_numpy(long_rows if len(long_rows) else np.zeros(1, dtype=np.int32)).to(dev)
         return self
 
 

@@ -110,11 +110,20 @@ def assemble_subgraphs(edge_index, num_nodes, assign, n_clusters, extra_node=Tru
     return dict(ptr=ptr, node_id=mem_n, core=core, edge_index=np.stack([e_src, e_dst]))
 
 
-def assemble_subgraphs_torch(edge_index, num_nodes, assign, n_clusters, extra_node=True, chunk_rows=1 << 20):
+def assemble_subgraphs_torch(edge_index, num_nodes, assign, n_clusters, extra_node=True, chunk_rows=1 << 20, layout="sorted"):
     """assemble_subgraphs with torch tensor ops on the device of `edge_index` (the reference's
     neighbour() scans all E edges per node, utils.py:52-56; here: one sort of the membership keys, one CSR gather and a
     binary search per (member, neighbour) pair, in chunks of `chunk_rows` members to bound memory).
-    Same dict as assemble_subgraphs, values are int64 / bool tensors on that device (ptr too)."""
+    Same dict as assemble_subgraphs, values are int64 / bool tensors on that device (ptr too).
+
+    layout: the order of a subgraph's rows in the union -- an internal choice: results per node do not depend on it.
+      "sorted"  ascending node id, the reference's order (utils.py:243).
+      "star"    star by star: every own node of the cluster (ascending) followed by the extra nodes whose lowest-numbered
+                own neighbour it is (ascending).  An --extra_node subgraph is a bundle of stars (the own nodes are the
+                centres: every extra node is there because it neighbours one); laid out like this each star is a run of
+                consecutive rows that references little outside itself, which is what the whole-subgraph SpMM kernel wants
+                (csrc/spmm.hip: every operand row read once).  The dict then also carries `seg_start` (bool per row: first
+                row of a star)."""
     dev = edge_index.device
     src, dst = edge_index[0].long(), edge_index[1].long()
     assign = torch.as_tensor(assign, device=dev).long()
@@ -129,6 +138,24 @@ def assemble_subgraphs_torch(edge_index, num_nodes, assign, n_clusters, extra_no
     ptr = torch.zeros(n + 1, dtype=torch.int64, device=dev)
     ptr[1:] = torch.cumsum(torch.bincount(mem_c, minlength=n), 0)
     core = assign[mem_n] == mem_c
+    inv = None
+    seg_start = None
+    if layout == "star":
+        R0 = int(key.numel())
+        hub = mem_n.clone()                                           # own node: its own star
+        if extra_node and bool(cut.any()):
+            pos_x = torch.searchsorted(key, assign[src[cut]] * N + dst[cut])       # row of (cluster of src, dst): an extra node
+            first = torch.full((R0,), N, dtype=torch.int64, device=dev).scatter_reduce(0, pos_x, src[cut], reduce="amin")
+            hub = torch.where(core, mem_n, first)
+        star_key = (mem_c * N + hub) * 2 + (~core).long()              # rows are already in (cluster, node) order: stable sort
+        perm = torch.argsort(star_key, stable=True)
+        inv = torch.empty_like(perm)
+        inv[perm] = torch.arange(R0, device=dev)
+        mem_c, mem_n, core, hub = mem_c[perm], mem_n[perm], core[perm], hub[perm]
+        seg_start = torch.ones(R0, dtype=torch.bool, device=dev)
+        seg_start[1:] = (mem_c[1:] != mem_c[:-1]) | (hub[1:] != hub[:-1])
+    elif layout != "sorted":
+        raise ValueError(f"layout {layout!r}: 'sorted' or 'star'")
     order = torch.argsort(src * N + dst)
     s_dst = dst[order]
     adj_ptr = torch.zeros(N + 1, dtype=torch.int64, device=dev)
@@ -146,8 +173,11 @@ def assemble_subgraphs_torch(edge_index, num_nodes, assign, n_clusters, extra_no
         want = mem_c[rows] * N + nbr
         pos = torch.searchsorted(key, want).clamp_(max=R - 1)
         hit = key[pos] == want
-        es.append(rows[hit]); ed.append(pos[hit])
-    return dict(ptr=ptr, node_id=mem_n, core=core, edge_index=torch.stack([torch.cat(es), torch.cat(ed)]))
+        es.append(rows[hit]); ed.append(pos[hit] if inv is None else inv[pos[hit]])   # key positions -> rows of the layout
+    out = dict(ptr=ptr, node_id=mem_n, core=core, edge_index=torch.stack([torch.cat(es), torch.cat(ed)]))
+    if seg_start is not None:
+        out["seg_start"] = seg_start
+    return out
 
 
 def assemble_subgraphs_cluster(edge_index, num_nodes, assign, n_clusters, coarse_adj):
@@ -253,8 +283,14 @@ class SubgraphBatch:
         self.train_mask = tm.to(dev)[self.node_id] & self.core          # utils.py:695-698
         self.train_idx = torch.nonzero(self.train_mask).flatten()
         self.graph = None
+        # row runs the SpMM kernels treat as units: the stars of a star-by-star layout, else the subgraphs themselves
+        self.seg_ptr = self.ptr
+        if sub.get("seg_start") is not None:
+            st = sub["seg_start"]
+            st = st.cpu().numpy() if torch.is_tensor(st) else np.asarray(st)
+            self.seg_ptr = np.concatenate([np.nonzero(st)[0], [self.n_rows]]).astype(np.int64)
         if dev.type == "cuda":
-            self.graph = CSRGraph(self.edge_index, self.n_rows, mode="gcn", ptr=self.ptr, lds_rows=lds_rows)
+            self.graph = CSRGraph(self.edge_index, self.n_rows, mode="gcn", ptr=self.seg_ptr, lds_rows=lds_rows)
             _csr.register(self.edge_index, self.graph, "gcn")  # model(x, edge_index) finds it by identity
         self.nnz = int(self.edge_index.shape[1]) + self.n_rows           # nnz' = directed edges + self loops
 
@@ -311,7 +347,10 @@ def select_clusters(sub, clusters):
         e = sub["edge_index"]
         keep = new_of_old[e[0]] >= 0
         e2 = torch.stack([new_of_old[e[0][keep]], new_of_old[e[1][keep]]])
-        return dict(ptr=new_ptr, node_id=sub["node_id"][rows], core=sub["core"][rows], edge_index=e2)
+        out = dict(ptr=new_ptr, node_id=sub["node_id"][rows], core=sub["core"][rows], edge_index=e2)
+        if "seg_start" in sub:
+            out["seg_start"] = sub["seg_start"][rows]
+        return out
     ptr = np.asarray(sub["ptr"], dtype=np.int64)
     c = np.asarray(clusters, dtype=np.int64)
     size = ptr[c + 1] - ptr[c]

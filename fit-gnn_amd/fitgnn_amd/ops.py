@@ -30,22 +30,24 @@ class OpConfig:
     fold_backward    use fitgnn_spmm_epilogue_bwd_f32 (dZ kept in LDS) when the graph / shape allow it.  Off: measured
                      no faster than the two kernels (DESIGN.md "folded backward").
     dedup_gather     layer 0 on a de-duplicated table through the direct-gather SpMM variant.
+    split_large_blocks  diagonal blocks larger than the SpMM window through the whole-subgraph kernel (every operand row read
+                     once) instead of window-sized tiles (A/B switch; identical bits).
     pad_table_min_k  static feature tables at least this wide whose width is not a multiple of 32 run layer 0's
                      products on a copy zero-padded once (real feature widths: 100, 500, 1 433, 8 415).
     profile / profile_gemm / profile_fused   None, or a list that collects HIP-event pairs around the SpMM / hand-written
                      GEMM / folded-backward launches (recorded on the stream the kernel is launched on).
     seed_bank        None, or a SeedBank supplying device-resident dropout seeds (steps captured in a hipGraph)."""
     __slots__ = ("gemm_precision", "atb_kernel", "nt_kernel", "nt_presplit", "fuse_dx_epilogue", "fold_backward",
-                 "dedup_gather", "pad_table_min_k", "profile", "profile_gemm", "profile_fused", "seed_bank")
+                 "dedup_gather", "pad_table_min_k", "split_large_blocks", "profile", "profile_gemm", "profile_fused", "seed_bank")
 
     def __init__(self, gemm_precision="high", atb_kernel=True, nt_kernel=True, nt_presplit=True, fuse_dx_epilogue=True,
-                 fold_backward=False, dedup_gather=True, pad_table_min_k=0, profile=None, profile_gemm=None,
-                 profile_fused=None, seed_bank=None):
+                 fold_backward=False, dedup_gather=True, pad_table_min_k=0, split_large_blocks=True, profile=None,
+                 profile_gemm=None, profile_fused=None, seed_bank=None):
         if gemm_precision not in ("high", "highest"):
             raise ValueError(f"gemm_precision {gemm_precision!r}: 'high' or 'highest'")
         self.gemm_precision, self.atb_kernel, self.nt_kernel, self.nt_presplit = gemm_precision, atb_kernel, nt_kernel, nt_presplit
         self.fuse_dx_epilogue, self.fold_backward, self.dedup_gather = fuse_dx_epilogue, fold_backward, dedup_gather
-        self.pad_table_min_k = pad_table_min_k
+        self.pad_table_min_k, self.split_large_blocks = pad_table_min_k, split_large_blocks
         self.profile, self.profile_gemm, self.profile_fused, self.seed_bank = profile, profile_gemm, profile_fused, seed_bank
 
     def replace(self, **kw):
@@ -388,12 +390,55 @@ def epilogue_bwd_raw(dOut, out, epilogue, p=0.0, seed=0, mask=None, want_db=True
     return dZ, db
 
 
+def spmm_blocks_raw(rowptr, col, val, blocks, long_rows, X, Y, bias=None, epilogue=0, p=0.0, seed=0, mask=None, cfg=DEFAULT):
+    """The rows of the listed large diagonal blocks of Y = epilogue(A @ X) through fitgnn_spmm_csr_blocks_f32 (one workgroup
+    walks a whole subgraph: every operand row read once)."""
+    _lib.require_cuda(rowptr, col, val, blocks, long_rows, X, Y, bias, mask)
+    L = _lib.lib()
+    seed, epilogue = _seed_arg(seed, epilogue)
+    H = X.shape[1]
+    ev = None
+    if cfg.profile is not None:
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
+    rc = L.fitgnn_spmm_csr_blocks_f32(_lib.dptr(rowptr), _lib.dptr(col), _lib.dptr(val), _lib.dptr(X), X.stride(0), _lib.dptr(Y), Y.stride(0),
+                                      int(Y.shape[0]), H, _lib.dptr(blocks), int(blocks.shape[0]), _lib.dptr(long_rows), _lib.dptr(bias),
+                                      epilogue, float(p), seed, _lib.dptr(mask), _lib.stream_ptr(X.device))
+    if ev is not None:
+        ev[1].record()
+        cfg.profile.append((ev[0], ev[1], "blocks"))
+    _lib.check(rc, "fitgnn_spmm_csr_blocks_f32")
+    return Y
+
+
 def spmm_graph(g, X, transposed=False, **kw):
-    """SpMM with a CSRGraph (forward or transposed pattern), using its planned tiles and kernel variant."""
+    """SpMM with a CSRGraph (forward or transposed pattern), using its planned tiles and kernel variant.  A batch with
+    diagonal blocks larger than the window is covered by two launches on the same stream: the tile kernel over the small
+    blocks' tiles, the whole-subgraph kernel over the large blocks (disjoint output rows)."""
     side = g.t if transposed else g.f
     epi = kw.pop("epilogue", 0) | (_lib.SPMM_GATHER if g.gather else 0)
-    return spmm_raw(side.rowptr, side.col, side.val, side.tiles, X, g.n, epilogue=epi, window_rows=g.window_rows,
-                    lcol=side.lcol, win_cols=side.win_cols, **kw)
+    Xc = _f32c(X)
+    split = (side.blocks is not None and kw.get("xrow") is None and not (epi & _lib.SPMM_GATHER) and Xc.shape[1] % 4 == 0
+             and Xc.data_ptr() % 16 == 0 and kw.get("cfg", DEFAULT).split_large_blocks)
+    if not split:
+        return spmm_raw(side.rowptr, side.col, side.val, side.tiles, Xc, g.n, epilogue=epi, window_rows=g.window_rows,
+                        lcol=side.lcol, win_cols=side.win_cols, **kw)
+    out = kw.pop("out", None)
+    kw.pop("xrow", None)
+    cfg = kw.pop("cfg", DEFAULT)
+    Y = out if out is not None else torch.empty((g.n, Xc.shape[1]), dtype=torch.float32, device=Xc.device)
+    ev = None
+    if cfg.profile is not None:   # ONE event pair around both launches: together they are the SpMM
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
+    quiet = cfg if cfg.profile is None else cfg.replace(profile=None)
+    if side.small_tiles.shape[0]:
+        spmm_raw(side.rowptr, side.col, side.val, side.small_tiles, Xc, g.n, epilogue=epi, window_rows=g.window_rows, out=Y, cfg=quiet, **kw)
+    spmm_blocks_raw(side.rowptr, side.col, side.val, side.blocks, side.long_rows, Xc, Y, epilogue=epi, cfg=quiet, **kw)
+    if ev is not None:
+        ev[1].record()
+        cfg.profile.append((ev[0], ev[1], "tile"))
+    return Y
 
 
 def epilogue_bwd_head_raw(dy, Wl, out, epilogue, p=0.0, seed=0, mask=None, want_db=True, want_dWl=True):

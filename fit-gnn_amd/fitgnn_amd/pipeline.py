@@ -225,7 +225,9 @@ def build_gs(args, data, co, device="cuda", float_targets=False, shard=None):
         masks = [torch.cat([m, torch.zeros(n, dtype=torch.bool)]) for m in masks]
     else:
         ei_dev = torch.as_tensor(np.asarray(data.edge_index)).to(device)
-        sub = fdata.assemble_subgraphs_torch(ei_dev, N, co.assign, n, extra_node=bool(getattr(args, "extra_node", False)))
+        # rows of a subgraph laid out star by star (an internal choice: per-node results do not depend on it; data.py)
+        sub = fdata.assemble_subgraphs_torch(ei_dev, N, co.assign, n, extra_node=bool(getattr(args, "extra_node", False)),
+                                             layout="star")
     if shard is not None and shard[1] > 1:
         owner = fdata.shard_clusters(None, fdata.cluster_nnz(sub), shard[1])   # the same on every rank
         sub = fdata.select_clusters(sub, np.nonzero(owner == shard[0])[0])

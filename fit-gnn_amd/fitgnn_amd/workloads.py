@@ -63,10 +63,11 @@ def features_and_labels(name):
     return X, y
 
 
-def assemble(name, ei_d, assign_d, n_clusters):
-    """All cluster subgraphs of the partition (device tensors) and their nnz'."""
+def assemble(name, ei_d, assign_d, n_clusters, layout="star"):
+    """All cluster subgraphs of the partition (device tensors) and their nnz'.  layout: the row order inside a subgraph
+    (data.assemble_subgraphs_torch): star by star by default, which is what the train path uses."""
     N = SHAPES[name][0]
-    sub = data.assemble_subgraphs_torch(ei_d, N, assign_d, n_clusters, extra_node=True)
+    sub = data.assemble_subgraphs_torch(ei_d, N, assign_d, n_clusters, extra_node=True, layout=layout)
     return sub, data.cluster_nnz(sub)
 
 

@@ -68,6 +68,27 @@ int fitgnn_plan_tiles_host(const int32_t *rowptr, const int32_t *col, int32_t n_
                            const int64_t *block_ptr, int32_t n_blocks, int32_t max_rows, int32_t max_window,
                            fitgnn_tile_t *tiles, int32_t *n_tiles, int32_t *win_cols, int32_t *n_win, int32_t *lcol);
 
+/* A run of consecutive rows LARGER than the SpMM window -- a diagonal block (one subgraph of a block-diagonal batch) or a
+ * mostly self-contained segment of one (a star: a centre row and the rows that reference it) -- handled whole by one
+ * workgroup per column slab (fitgnn_spmm_csr_blocks_f32): every operand row inside the run is read once; columns outside it
+ * are gathered.  long_rows[long_off .. long_off + n_long) are the run's rows with many non-zeros (ascending row ids; the
+ * first 8 are carried, see spmm.hip). */
+typedef struct fitgnn_block {
+    int32_t row_begin, row_end; /* rows of the run */
+    int32_t nnz_begin, nnz_end; /* = rowptr[row_begin], rowptr[row_end] */
+    int32_t long_off, n_long;   /* the block's long rows in long_rows[] */
+    int32_t reserved[2];        /* must be 0 */
+} fitgnn_block_t;
+
+/* Y[rows of the listed blocks] = epilogue(A @ X) for diagonal blocks larger than the window; same arguments and epilogue
+ * semantics as fitgnn_spmm_csr_f32, same bits as that kernel on the same rows.  A batch is covered by ONE call of each:
+ * fitgnn_spmm_csr_f32 over tiles that pack the small blocks, this one over the large blocks.  Requires H % 4 == 0, 16-byte
+ * aligned rows (FITGNN_E_BADARG / FITGNN_E_ALIGN otherwise: tile those blocks instead). */
+int fitgnn_spmm_csr_blocks_f32(const int32_t *rowptr, const int32_t *col, const float *val, const float *X, int64_t ldx,
+                               float *Y, int64_t ldy, int32_t n_rows, int32_t H, const fitgnn_block_t *blocks,
+                               int32_t n_blocks, const int32_t *long_rows, const float *bias, uint32_t epilogue,
+                               float p_drop, uint64_t seed, const uint8_t *mask, void *stream);
+
 /* LDS window sizes of the SpMM kernel (rows of the dense operand staged per workgroup): the default used
  * when window_rows == 0, and the largest accepted value.  Tiles should be built with win_rows <= the
  * window_rows later passed to fitgnn_spmm_csr_f32 (larger windows are clamped: still correct, slower). */

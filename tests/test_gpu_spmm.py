@@ -217,6 +217,60 @@ def test_head_backward_folded_into_epilogue_kernel(mods, H, C):
     assert rel_err(dWl.cpu(), (dy.double().t() @ out.double()).float()) < 1e-5
 
 
+def star_blocks(sizes, centres, seed, extra=0.02):
+    """Block-diagonal batch of star-shaped subgraphs: in every block the first `centres` rows link to all the others
+    (--extra_node subgraphs, utils.py:235-239), plus a few random leaf -- leaf edges."""
+    rng = np.random.default_rng(seed)
+    src, dst, off = [], [], 0
+    for s in sizes:
+        c = min(centres, max(s - 1, 0))
+        for h in range(c):
+            leaves = np.arange(c, s)
+            src += [off + h] * len(leaves) + (off + leaves).tolist()
+            dst += (off + leaves).tolist() + [off + h] * len(leaves)
+        m = int(extra * s * s)
+        if m and s > 2:
+            a, b = rng.integers(0, s, size=m), rng.integers(0, s, size=m)
+            k = a != b
+            src += (off + a[k]).tolist() + (off + b[k]).tolist()
+            dst += (off + b[k]).tolist() + (off + a[k]).tolist()
+        off += s
+    return torch.tensor(np.unique(np.array([src, dst]), axis=1), dtype=torch.long), off
+
+
+@pytest.mark.parametrize("H", [512, 256, 100])
+@pytest.mark.parametrize("sizes,centres", [([100, 7, 17, 300, 3, 3, 64, 33, 2, 1000], 2), ([40] * 30, 1), ([500, 90], 12),
+                                           ([18, 16, 17, 5, 5, 5, 2000], 3)])
+def test_whole_subgraph_kernel_gives_the_tile_kernel_bits(mods, H, sizes, centres):
+    """Diagonal blocks larger than the window run through fitgnn_spmm_csr_blocks_f32 (one workgroup walks the subgraph, the
+    centre rows' accumulators carried across its 16-row pieces, their operand rows pinned in LDS): same bits as the tiled
+    kernel, forward and transposed, with and without the fused epilogue -- blocks with 1, 2, 3 and more than 8 long rows,
+    long rows beyond 64 entries, pieces with more than 256 non-zeros, small blocks packed between large ones."""
+    _lib, csr, ops, orc, gorc = mods
+    from fitgnn_amd._lib import EPI_BIAS, EPI_DROPOUT, EPI_ELU
+
+    ei, n = star_blocks(sizes, centres, seed=H + len(sizes))
+    ptr = np.concatenate([[0], np.cumsum(sizes)])
+    g = csr.CSRGraph(ei.cuda(), n, mode="gcn", ptr=ptr)
+    assert g.f.blocks is None, "a batch this small stays on tiles (the kernel pays beyond the Infinity Cache)"
+    g64 = csr.CSRGraph(ei.cuda(), n, mode="gcn", ptr=ptr, block_limit=4096)   # an explicit limit forces the split
+    assert int(g64.f.blocks.shape[0]) == sum(1 for s_ in sizes if s_ > 16)
+    g = csr.CSRGraph(ei.cuda(), n, mode="gcn", ptr=ptr, block_limit=64)       # blocks beyond 4 pieces are tiled again
+    n_mid, in_mid = sum(1 for s_ in sizes if 16 < s_ <= 64), sum(s_ for s_ in sizes if 16 < s_ <= 64)
+    assert (g.f.blocks is None and in_mid * 4 < n) or int(g.f.blocks.shape[0]) == n_mid
+    torch.manual_seed(3)
+    X = torch.randn(n, H).cuda()
+    b = torch.randn(H).cuda()
+    off = ops.OpConfig(split_large_blocks=False)
+    for transposed in (False, True):
+        for kw in (dict(), dict(bias=b, epilogue=EPI_BIAS | EPI_ELU | EPI_DROPOUT, p=0.5, seed=123)):
+            tiled = ops.spmm_graph(g, X, transposed=transposed, cfg=off, **kw)
+            for gg in (g, g64):
+                assert torch.equal(ops.spmm_graph(gg, X, transposed=transposed, **kw), tiled)
+    ref = torch.from_numpy(orc.spmm_csr_f32(g.rowptr.cpu().numpy(), g.col.cpu().numpy(), g.val.cpu().numpy(), X.cpu().numpy()))
+    assert rel_err(ops.spmm_graph(g, X).cpu(), ref) < RTOL
+
+
 @pytest.mark.parametrize("H,C,with_dWl", [(512, 3, True), (512, 47, False), (64, 7, True)])
 def test_head_backward_skips_rows_without_gradient_bit_for_bit(mods, H, C, with_dWl):
     """Rows whose head gradient dy is all zero (nodes outside the loss: most rows of an --extra_node subgraph) are written

@@ -393,3 +393,43 @@ def test_select_clusters_and_sharding_partition_the_union():
             assert np.array_equal(ea, eo)
         total_edges += a["edge_index"].shape[1]
     assert total_edges == sub["edge_index"].shape[1]
+
+
+def test_star_layout_is_a_row_permutation_of_the_sorted_layout():
+    """assemble_subgraphs_torch(layout="star") holds the same subgraphs as the reference's sorted layout -- same member set per
+    cluster, same edges between the same (cluster, node) pairs -- with every subgraph's rows ordered star by star: an own node,
+    then the extra nodes whose lowest own neighbour it is; seg_start marks the first row of every star."""
+    from fitgnn_amd.data import assemble_subgraphs_torch, select_clusters, synthetic_graph
+
+    N = 700
+    ei = synthetic_graph(N, 2400, seed=11)
+    rng = np.random.default_rng(2)
+    _, assign = np.unique(rng.integers(0, 150, size=N), return_inverse=True)
+    n = int(assign.max()) + 1
+    a = assemble_subgraphs_torch(torch.from_numpy(ei), N, assign, n, extra_node=True)
+    b = assemble_subgraphs_torch(torch.from_numpy(ei), N, assign, n, extra_node=True, layout="star", chunk_rows=333)
+    assert torch.equal(a["ptr"], b["ptr"]) and "seg_start" in b and "seg_start" not in a
+    adj = {}
+    for u, v in zip(ei[0].tolist(), ei[1].tolist()):
+        adj.setdefault(u, set()).add(v)
+    ptr = a["ptr"].numpy()
+    pair = lambda d: set(zip(d["node_id"][d["edge_index"][0]].tolist(), d["node_id"][d["edge_index"][1]].tolist(),
+                            (torch.searchsorted(d["ptr"], d["edge_index"][0], right=True) - 1).tolist()))
+    assert pair(a) == pair(b) and a["edge_index"].shape == b["edge_index"].shape
+    for c in range(n):
+        r0, r1 = int(ptr[c]), int(ptr[c + 1])
+        ids, core, seg = b["node_id"][r0:r1].tolist(), b["core"][r0:r1].tolist(), b["seg_start"][r0:r1].tolist()
+        assert sorted(ids) == a["node_id"][r0:r1].tolist()
+        assert [i for i, k in zip(ids, core) if k] == sorted(np.nonzero(assign == c)[0].tolist()), "own nodes ascending, each opening a star"
+        own = set(np.nonzero(assign == c)[0].tolist())
+        hub = None
+        for i, k, s0 in zip(ids, core, seg):
+            if k:
+                assert s0
+                hub, last = i, -1
+            else:
+                assert not s0 and i > last and hub == min(adj[i] & own), "an extra node sits in the star of its lowest own neighbour"
+                last = i
+    # a shard keeps the star marks of its rows
+    sh = select_clusters(b, np.arange(0, n, 3))
+    assert int(sh["seg_start"].sum()) == int(sh["core"].sum())

@@ -16,4 +16,6 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
   echo "pmc $n done"
 done
 python3 $R/tools/summarize_pmc.py $OUT > $OUT/pmc_summary.json
+for d in $OUT/pmc_*/; do rm -rf "$d"; done   # per-dispatch CSVs are large; the summary travels back
+rm -f $OUT/stats/run_kernel_trace.csv
 echo "summary done"

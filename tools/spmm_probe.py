@@ -34,8 +34,13 @@ def main():
     dev = torch.device("cuda")
     w0 = workloads.coarsen_workload(wl, dev)
     sub, nnz_c = workloads.assemble(wl, torch.from_numpy(w0["ei"]).to(dev), torch.from_numpy(w0["assign"]).to(dev), w0["n_clusters"])
+    layout = os.environ.get("PROBE_LAYOUT", "star")
+    if layout != "star":
+        sub, nnz_c = workloads.assemble(wl, torch.from_numpy(w0["ei"]).to(dev), torch.from_numpy(w0["assign"]).to(dev), w0["n_clusters"], layout=layout)
     ptr = sub["ptr"].cpu().numpy()
     R, nnz = int(ptr[-1]), int(nnz_c.sum())
+    if "seg_start" in sub:   # the kernels' units: the stars
+        ptr = np.concatenate([np.nonzero(sub["seg_start"].cpu().numpy())[0], [R]]).astype(np.int64)
     H = 512
     X = torch.randn(R, H, device=dev)
     Y = torch.empty_like(X)
@@ -69,7 +74,7 @@ def main():
     # A/B bit of the LDS-window kernel: one tile per workgroup (round 1) instead of the pipelined form
     flagsets = {"": 0}
     if "ab" in variants:
-        pass
+        flagsets.update({"tiled": "tiled"})
         for k in list(graphs):
             if k[0] == "contig":
                 for nm in flagsets:
@@ -80,8 +85,10 @@ def main():
     for rnd in range(4):
         for k, g in graphs.items():
             fl = flagsets.get(k[0].partition(":")[2], 0)
-            res[k]["plain"].append(timeit(lambda: ops.spmm_graph(g, X, out=Y, epilogue=fl)))
-            res[k]["epi"].append(timeit(lambda: ops.spmm_graph(g, X, out=Y, bias=b, epilogue=fl | EPI_BIAS | EPI_ELU | EPI_DROPOUT, p=0.5, seed=7)))
+            cfg = ops.OpConfig(split_large_blocks=fl != "tiled")   # "tiled": large blocks cut into window-sized tiles (round 1)
+            fl = 0 if fl == "tiled" else fl
+            res[k]["plain"].append(timeit(lambda: ops.spmm_graph(g, X, out=Y, epilogue=fl, cfg=cfg)))
+            res[k]["epi"].append(timeit(lambda: ops.spmm_graph(g, X, out=Y, bias=b, epilogue=fl | EPI_BIAS | EPI_ELU | EPI_DROPOUT, p=0.5, seed=7, cfg=cfg)))
         copy.append(timeit(lambda: Y.copy_(X)))
     print(f"copy of {8 * H * R / 1e6:.1f} MB: {np.median(copy):.1f} us = {8 * H * R / np.median(copy) / 1e3:.0f} GB/s")
     for k, g in graphs.items():

@@ -9,7 +9,7 @@ import json
 import os
 import sys
 
-KEEP = ("spmm_tile_kernel", "spmm_gather_kernel", "gemm_nt_kernel", "gemm_atb_kernel", "epilogue_bwd_kernel", "segment_sum_kernel")
+KEEP = ("spmm_tile_kernel", "spmm_block_kernel", "spmm_gather_kernel", "gemm_nt_kernel", "gemm_atb_kernel", "epilogue_bwd_kernel", "segment_sum_kernel")
 
 
 def short(name):
