@@ -284,15 +284,20 @@ __global__ __launch_bounds__(kThreads, (B <= 4 ? 8 : 4)) void spmm_tile_kernel(
 // legal and are gathered too, so a connected subgraph with many centres is cut into one segment per centre (its star) once
 // the rows are laid out star by star (data.SubgraphBatch, layout="star").  H % 4 == 0 only (callers tile otherwise).
 constexpr int kBlkRows = 16;   // rows per piece (== the tile kernel's default window)
-constexpr int kBlkLong = 8;    // long rows carried per block: two per wave
+constexpr int kBlkLW = 1;      // long rows carried per wave
+constexpr int kBlkLong = 4 * kBlkLW;  // ... per block
 constexpr int kBlkMeta = 128;  // CSR entries of a piece staged in LDS (threads 0..127 fetch one each): a piece of 16 short rows
                                // holds ~50; with 256, on stars of ~50 rows, the staging itself was 8 % of the kernel's reads
 
-__global__ __launch_bounds__(kThreads, 6) void spmm_block_kernel(
+// XROW: operand row r of the pattern lives at X[xrow[r]] (a de-duplicated operand table, as in the tile kernel): the window
+// rows' table indices are fetched one piece ahead of the rows themselves, so the prefetch never waits on an index.
+template <bool XROW>
+__global__ __launch_bounds__(kThreads, kBlkLW == 1 ? 7 : 6) void spmm_block_kernel(
     const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col, const float *__restrict__ val,
     const float *__restrict__ X, int64_t ldx, float *__restrict__ Y, int64_t ldy, int32_t H,
     const fitgnn_block_t *__restrict__ blocks, int32_t n_blocks, const int32_t *__restrict__ long_rows, int32_t n_slabs,
-    const float *__restrict__ bias, uint32_t epi, float p_drop, uint64_t seed_arg, const uint8_t *__restrict__ mask) {
+    const float *__restrict__ bias, uint32_t epi, float p_drop, uint64_t seed_arg, const uint8_t *__restrict__ mask,
+    const int32_t *__restrict__ xrow) {
     using P = Pack<4>;
     using T = float4;
     const uint64_t seed = fitgnn::resolve_seed(seed_arg, epi);
@@ -301,16 +306,21 @@ __global__ __launch_bounds__(kThreads, 6) void spmm_block_kernel(
     __shared__ int32_t s_col[kBlkMeta];
     __shared__ float s_val[kBlkMeta];
     __shared__ int32_t s_long[kBlkLong];
+    // block -> (record position, slab) as in the tile kernel: position p runs on XCD p % 8 with both of its slabs; the host
+    // gives every XCD a contiguous range of the batch (records with row_begin == row_end pad the short ranges)
     const int bid = blockIdx.x;
-    const int slab = bid % n_slabs;
-    const int b = bid / n_slabs;
+    const int seq = bid >> 3;
+    const int slab = seq % n_slabs;
+    const int b = (seq / n_slabs) * 8 + (bid & 7);
     if (b >= n_blocks) return;
     const fitgnn_block_t blk = blocks[b];
+    if (blk.row_end <= blk.row_begin) return;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int col0 = slab * 256 + lane * 4;
     const bool live = col0 + 4 <= H;
     const float *Xs = X + (live ? col0 : max(H - 4, 0));
+    auto src = [&](int r) -> int64_t { return XROW ? (int64_t)xrow[r] : (int64_t)r; };  // operand row of pattern row / column r
     const int n_long = min(blk.n_long, kBlkLong);
     const float keep_scale = (epi & FITGNN_EPI_DROPOUT) ? 1.0f / (1.0f - p_drop) : 1.0f;
     const uint32_t thresh = fitgnn::dropout_threshold(p_drop);
@@ -320,11 +330,11 @@ __global__ __launch_bounds__(kThreads, 6) void spmm_block_kernel(
 
     // ---- the block's long rows: ids to LDS, their operand rows pinned, this wave's two accumulators and entry cursors ----
     if ((int)threadIdx.x < kBlkLong) s_long[threadIdx.x] = (int)threadIdx.x < n_long ? long_rows[blk.long_off + threadIdx.x] : -1;
-    int my_long[2], cur[2], end[2], pos[2], lc[2];
-    float lv[2];
-    T acc_long[2];
+    int my_long[kBlkLW], cur[kBlkLW], end[kBlkLW], pos[kBlkLW], lc[kBlkLW];
+    float lv[kBlkLW];
+    T acc_long[kBlkLW];
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
+    for (int q = 0; q < kBlkLW; ++q) {
         const int slot = wave + q * kWaves;
         my_long[q] = slot < n_long ? long_rows[blk.long_off + slot] : -1;
         my_long[q] = __builtin_amdgcn_readfirstlane(my_long[q]);
@@ -336,7 +346,7 @@ __global__ __launch_bounds__(kThreads, 6) void spmm_block_kernel(
         if (my_long[q] >= 0) {
             cur[q] = __builtin_amdgcn_readfirstlane(rowptr[my_long[q]]);
             end[q] = __builtin_amdgcn_readfirstlane(rowptr[my_long[q] + 1]);
-            s_win[(kBlkRows + slot) * 64 + lane] = *reinterpret_cast<const T *>(Xs + (int64_t)my_long[q] * ldx);
+            s_win[(kBlkRows + slot) * 64 + lane] = *reinterpret_cast<const T *>(Xs + src(my_long[q]) * ldx);
         }
     }
     __syncthreads();
@@ -348,13 +358,23 @@ __global__ __launch_bounds__(kThreads, 6) void spmm_block_kernel(
     T pv[4];
     int p_rp = 0, p_c = 0, p_E0 = 0, p_n = 0;
     float p_v = 0.f;
+    int xr_next = 0;  // XROW: lane j < 4 holds the table row of window row wave + 4 j of the NEXT piece to prefetch
+    auto fetch_indices = [&](int r0, int r1) {
+        if (XROW) {
+            const int r = r0 + wave + lane * kWaves;
+            xr_next = (lane < 4 && r < r1) ? xrow[r] : 0;
+        }
+    };
     auto prefetch = [&](int r0, int r1, int E0) {
+        const int xr = xr_next;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int r = r0 + wave + j * kWaves;
             pv[j] = P::zero();
-            if (r < r1) pv[j] = *reinterpret_cast<const T *>(Xs + (int64_t)r * ldx);
+            const int64_t sr = XROW ? (int64_t)__builtin_amdgcn_readlane(xr, j) : (int64_t)r;
+            if (r < r1) pv[j] = *reinterpret_cast<const T *>(Xs + sr * ldx);
         }
+        if (XROW) fetch_indices(r1, min(r1 + kBlkRows, blk.row_end));  // the piece after: its rows are requested next time round
         p_rp = 0;
         if ((int)threadIdx.x <= r1 - r0) p_rp = rowptr[r0 + threadIdx.x];
         // the slice's end is not known yet (it is rowptr[r1], in flight above): stage the next kBlkMeta entries of the block,
@@ -367,6 +387,7 @@ __global__ __launch_bounds__(kThreads, 6) void spmm_block_kernel(
         p_E0 = E0;
     };
     const int n_pieces = (blk.row_end - blk.row_begin + kBlkRows - 1) / kBlkRows;
+    fetch_indices(blk.row_begin, min(blk.row_begin + kBlkRows, blk.row_end));
     prefetch(blk.row_begin, min(blk.row_begin + kBlkRows, blk.row_end), blk.nnz_begin);
 
     // A long row's entries OUTSIDE the segment (a segment need not be a whole connected subgraph: the stars of a large
@@ -391,7 +412,7 @@ __global__ __launch_bounds__(kThreads, 6) void spmm_block_kernel(
                     const int kk = min(k + u, last);
                     const int c = __builtin_amdgcn_readlane(lc[q], kk);
                     w[u] = k + u <= last ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lv[q]), kk)) : 0.f;
-                    x[u] = *reinterpret_cast<const T *>(Xs + (int64_t)c * ldx);
+                    x[u] = *reinterpret_cast<const T *>(Xs + src(c) * ldx);
                 }
 #pragma unroll
                 for (int u = 0; u < 8; ++u) P::fma(acc_long[q], w[u], x[u]);
@@ -402,7 +423,7 @@ __global__ __launch_bounds__(kThreads, 6) void spmm_block_kernel(
         }
     };
 #pragma unroll
-    for (int q = 0; q < 2; ++q)
+    for (int q = 0; q < kBlkLW; ++q)
         if (my_long[q] >= 0) gather_long(q, blk.row_begin);
     for (int p = 0; p < n_pieces; ++p) {
         const int r0 = blk.row_begin + p * kBlkRows, r1 = min(r0 + kBlkRows, blk.row_end);
@@ -476,10 +497,10 @@ __global__ __launch_bounds__(kThreads, 6) void spmm_block_kernel(
                         x0 = s_win[c0 * 64 + lane]; x1 = s_win[c1 * 64 + lane];
                         x2 = s_win[c2 * 64 + lane]; x3 = s_win[c3 * 64 + lane];
                     } else {
-                        if (c0 >= 0) x0 = s_win[c0 * 64 + lane]; else x0 = *reinterpret_cast<const T *>(Xs + (int64_t)(-(c0 + 1)) * ldx);
-                        if (c1 >= 0) x1 = s_win[c1 * 64 + lane]; else x1 = *reinterpret_cast<const T *>(Xs + (int64_t)(-(c1 + 1)) * ldx);
-                        if (c2 >= 0) x2 = s_win[c2 * 64 + lane]; else x2 = *reinterpret_cast<const T *>(Xs + (int64_t)(-(c2 + 1)) * ldx);
-                        if (c3 >= 0) x3 = s_win[c3 * 64 + lane]; else x3 = *reinterpret_cast<const T *>(Xs + (int64_t)(-(c3 + 1)) * ldx);
+                        if (c0 >= 0) x0 = s_win[c0 * 64 + lane]; else x0 = *reinterpret_cast<const T *>(Xs + src(-(c0 + 1)) * ldx);
+                        if (c1 >= 0) x1 = s_win[c1 * 64 + lane]; else x1 = *reinterpret_cast<const T *>(Xs + src(-(c1 + 1)) * ldx);
+                        if (c2 >= 0) x2 = s_win[c2 * 64 + lane]; else x2 = *reinterpret_cast<const T *>(Xs + src(-(c2 + 1)) * ldx);
+                        if (c3 >= 0) x3 = s_win[c3 * 64 + lane]; else x3 = *reinterpret_cast<const T *>(Xs + src(-(c3 + 1)) * ldx);
                     }
                     P::fma(acc, w0, x0); P::fma(acc, w1, x1); P::fma(acc, w2, x2); P::fma(acc, w3, x3);
                 }
@@ -489,7 +510,7 @@ __global__ __launch_bounds__(kThreads, 6) void spmm_block_kernel(
 
         // ---- this wave's long rows: the entries whose operand rows sit in this piece (columns < r1), in CSR order ----
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
+        for (int q = 0; q < kBlkLW; ++q) {
             if (my_long[q] < 0) continue;  // wave-uniform
             while (cur[q] < end[q]) {
                 if (pos[q] == 64) {  // next 64 entries of the row into the lanes
@@ -522,7 +543,7 @@ __global__ __launch_bounds__(kThreads, 6) void spmm_block_kernel(
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // the window is overwritten by the next piece
     }
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
+    for (int q = 0; q < kBlkLW; ++q) {
         if (my_long[q] < 0) continue;
         gather_long(q, 0x7fffffff);
         if (live) finish_row<4>(acc_long[q], my_long[q], col0, H, Y, ldy, bv, epi, keep_scale, thresh, seed, mask);
@@ -770,7 +791,7 @@ extern "C" int fitgnn_spmm_csr_f32(const int32_t *rowptr, const int32_t *col, co
 extern "C" int fitgnn_spmm_csr_blocks_f32(const int32_t *rowptr, const int32_t *col, const float *val, const float *X,
                                           int64_t ldx, float *Y, int64_t ldy, int32_t n_rows, int32_t H,
                                           const fitgnn_block_t *blocks, int32_t n_blocks, const int32_t *long_rows,
-                                          const float *bias, uint32_t epilogue, float p_drop, uint64_t seed,
+                                          const int32_t *xrow, const float *bias, uint32_t epilogue, float p_drop, uint64_t seed,
                                           const uint8_t *mask, void *stream) {
     if (n_rows < 0 || H < 0 || n_blocks < 0) return FITGNN_E_BADARG;
     if (n_rows == 0 || H == 0 || n_blocks == 0) return 0;
@@ -781,7 +802,12 @@ extern "C" int fitgnn_spmm_csr_blocks_f32(const int32_t *rowptr, const int32_t *
     if ((H % 4) != 0 || (ldx % 4) != 0 || (ldy % 4) != 0) return FITGNN_E_BADARG;
     if ((((uintptr_t)X | (uintptr_t)Y) % 16) != 0) return FITGNN_E_ALIGN;
     const int n_slabs = (H + 255) / 256;
-    hipLaunchKernelGGL(spmm_block_kernel, dim3((unsigned)n_blocks * n_slabs), dim3(kThreads), 0, (hipStream_t)stream, rowptr, col, val, X,
-                       ldx, Y, ldy, H, blocks, n_blocks, long_rows, n_slabs, bias, epilogue, p_drop, seed, mask);
+    const dim3 grid((unsigned)((n_blocks + 7) / 8 * 8) * n_slabs);
+    if (xrow)
+        hipLaunchKernelGGL(spmm_block_kernel<true>, grid, dim3(kThreads), 0, (hipStream_t)stream, rowptr, col, val, X, ldx, Y, ldy, H, blocks,
+                           n_blocks, long_rows, n_slabs, bias, epilogue, p_drop, seed, mask, xrow);
+    else
+        hipLaunchKernelGGL(spmm_block_kernel<false>, grid, dim3(kThreads), 0, (hipStream_t)stream, rowptr, col, val, X, ldx, Y, ldy, H, blocks,
+                           n_blocks, long_rows, n_slabs, bias, epilogue, p_drop, seed, mask, xrow);
     return (int)hipGetLastError();
 }

@@ -19,16 +19,18 @@ TILE_DTYPE = np.dtype([("row_begin", np.int32), ("row_end", np.int32), ("win_beg
 TILE_INTS = 8  # sizeof(fitgnn_tile_t) / 4: the four fields above + nnz_begin, nnz_end, reserved[2]
 
 
-def arrange_tiles_for_xcds(tiles8, n_xcd=8):
+def arrange_tiles_for_xcds(tiles8, n_xcd=8, work=None):
     """Lay the tile table out for the kernel's block -> tile mapping (array position p runs on XCD p % 8):
     every XCD gets a CONTIGUOUS range of the batch (neighbouring tiles share L2 lines) holding an equal share of
     the work (rows written + operand rows staged), interleaved as out[j*8 + k] = range_k[j]; shorter ranges are
-    padded with empty tiles (row_begin == row_end), which the kernel skips."""
+    padded with empty tiles (row_begin == row_end), which the kernel skips.  Also used for fitgnn_block_t records (same
+    size, rows in the first two fields; work = rows)."""
     t = np.ascontiguousarray(tiles8, dtype=np.int32).reshape(-1, TILE_INTS)
     T = t.shape[0]
     if T == 0:
         return t
-    work = (t[:, 1] - t[:, 0]).astype(np.int64) + t[:, 3].astype(np.int64)
+    if work is None:
+        work = (t[:, 1] - t[:, 0]).astype(np.int64) + t[:, 3].astype(np.int64)
     cum = np.concatenate([[0], np.cumsum(work)])
     bounds = np.searchsorted(cum, np.linspace(0, cum[-1], n_xcd + 1), side="left")
     bounds[0], bounds[-1] = 0, T
@@ -162,9 +164,10 @@ def split_blocks(ptr, rowptr, cap, limit=None):
         off = np.cumsum(cnt) - cnt
         blocks[:, 4], blocks[:, 5] = off, cnt
         long_rows = lr.astype(np.int32)
-        # heaviest blocks first: the longest-running workgroups start early
-        order = np.argsort(-(r1 - r0), kind="stable")
-        blocks = blocks[order]
+        # row order, an equal share of the rows per XCD (position p runs on XCD p % 8): the stars of one subgraph run on one
+        # XCD at about the same time, so what they still gather from each other (leaf -- leaf edges across stars: 12 % of the
+        # entries of S-products) has a chance of being in that XCD's L2
+        blocks = arrange_tiles_for_xcds(blocks, work=(r1 - r0).astype(np.int64))
     return small, blocks, long_rows
 
 

@@ -390,10 +390,10 @@ def epilogue_bwd_raw(dOut, out, epilogue, p=0.0, seed=0, mask=None, want_db=True
     return dZ, db
 
 
-def spmm_blocks_raw(rowptr, col, val, blocks, long_rows, X, Y, bias=None, epilogue=0, p=0.0, seed=0, mask=None, cfg=DEFAULT):
+def spmm_blocks_raw(rowptr, col, val, blocks, long_rows, X, Y, bias=None, epilogue=0, p=0.0, seed=0, mask=None, cfg=DEFAULT, xrow=None):
     """The rows of the listed large diagonal blocks of Y = epilogue(A @ X) through fitgnn_spmm_csr_blocks_f32 (one workgroup
     walks a whole subgraph: every operand row read once)."""
-    _lib.require_cuda(rowptr, col, val, blocks, long_rows, X, Y, bias, mask)
+    _lib.require_cuda(rowptr, col, val, blocks, long_rows, X, Y, bias, mask, xrow)
     L = _lib.lib()
     seed, epilogue = _seed_arg(seed, epilogue)
     H = X.shape[1]
@@ -402,7 +402,7 @@ def spmm_blocks_raw(rowptr, col, val, blocks, long_rows, X, Y, bias=None, epilog
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         ev[0].record()
     rc = L.fitgnn_spmm_csr_blocks_f32(_lib.dptr(rowptr), _lib.dptr(col), _lib.dptr(val), _lib.dptr(X), X.stride(0), _lib.dptr(Y), Y.stride(0),
-                                      int(Y.shape[0]), H, _lib.dptr(blocks), int(blocks.shape[0]), _lib.dptr(long_rows), _lib.dptr(bias),
+                                      int(Y.shape[0]), H, _lib.dptr(blocks), int(blocks.shape[0]), _lib.dptr(long_rows), _lib.dptr(xrow), _lib.dptr(bias),
                                       epilogue, float(p), seed, _lib.dptr(mask), _lib.stream_ptr(X.device))
     if ev is not None:
         ev[1].record()
@@ -418,13 +418,14 @@ def spmm_graph(g, X, transposed=False, **kw):
     side = g.t if transposed else g.f
     epi = kw.pop("epilogue", 0) | (_lib.SPMM_GATHER if g.gather else 0)
     Xc = _f32c(X)
-    split = (side.blocks is not None and kw.get("xrow") is None and not (epi & _lib.SPMM_GATHER) and Xc.shape[1] % 4 == 0
-             and Xc.data_ptr() % 16 == 0 and kw.get("cfg", DEFAULT).split_large_blocks)
+    split = (side.blocks is not None and Xc.shape[1] % 4 == 0 and Xc.data_ptr() % 16 == 0 and kw.get("cfg", DEFAULT).split_large_blocks)
+    if split:
+        epi &= ~_lib.SPMM_GATHER   # the whole-subgraph kernel reads every operand row once: it supersedes the direct-gather variant
     if not split:
         return spmm_raw(side.rowptr, side.col, side.val, side.tiles, Xc, g.n, epilogue=epi, window_rows=g.window_rows,
                         lcol=side.lcol, win_cols=side.win_cols, **kw)
     out = kw.pop("out", None)
-    kw.pop("xrow", None)
+    xrow = kw.pop("xrow", None)
     cfg = kw.pop("cfg", DEFAULT)
     Y = out if out is not None else torch.empty((g.n, Xc.shape[1]), dtype=torch.float32, device=Xc.device)
     ev = None
@@ -433,11 +434,12 @@ def spmm_graph(g, X, transposed=False, **kw):
         ev[0].record()
     quiet = cfg if cfg.profile is None else cfg.replace(profile=None)
     if side.small_tiles.shape[0]:
-        spmm_raw(side.rowptr, side.col, side.val, side.small_tiles, Xc, g.n, epilogue=epi, window_rows=g.window_rows, out=Y, cfg=quiet, **kw)
-    spmm_blocks_raw(side.rowptr, side.col, side.val, side.blocks, side.long_rows, Xc, Y, epilogue=epi, cfg=quiet, **kw)
+        spmm_raw(side.rowptr, side.col, side.val, side.small_tiles, Xc, g.n, epilogue=epi, window_rows=g.window_rows, out=Y, cfg=quiet,
+                 xrow=xrow, **kw)
+    spmm_blocks_raw(side.rowptr, side.col, side.val, side.blocks, side.long_rows, Xc, Y, epilogue=epi, cfg=quiet, xrow=xrow, **kw)
     if ev is not None:
         ev[1].record()
-        cfg.profile.append((ev[0], ev[1], "tile"))
+        cfg.profile.append((ev[0], ev[1], "tile" if xrow is None else "table"))   # "table": layer 0 on the de-duplicated table
     return Y
 
 

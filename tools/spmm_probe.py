@@ -49,6 +49,17 @@ def main():
     sizes = np.diff(ptr)
     print(f"{wl}: rows {R} nnz' {nnz} ({nnz / R:.2f}/row) subgraphs {len(sizes)} rows/subgraph mean {sizes.mean():.1f} max {sizes.max()} "
           f"bytes/launch {bytes_spmm / 1e6:.1f} MB", flush=True)
+    if "stats" in variants:   # how much of the pattern leaves its segment (what the whole-subgraph kernel still has to gather)
+        e = sub["edge_index"]
+        seg_of = torch.from_numpy(np.repeat(np.arange(len(ptr) - 1), np.diff(ptr))).to(dev)
+        deg = torch.bincount(e[1], minlength=R) + 1
+        out = seg_of[e[0]] != seg_of[e[1]]
+        long_t = deg[e[1]] > 16
+        segsz = torch.from_numpy(np.diff(ptr)).to(dev)
+        big = segsz[seg_of[e[1]]] > 16
+        print(f"entries leaving their segment: {int(out.sum())} of {e.shape[1]} ({float(out.float().mean()):.3f}); in long rows {int((out & long_t).sum())}, "
+              f"in short rows {int((out & ~long_t).sum())}; in segments > 16 rows {int((out & big).sum())}; long rows {int((deg > 16).sum())}; "
+              f"rows in segments > 16 rows with > 4 long rows: {int(segsz[torch.bincount(seg_of[deg > 16], minlength=len(ptr) - 1) > 4].sum())}", flush=True)
     graphs = {}
     if "nohub" in variants:   # the same union with the entries of long rows (> 32 non-zeros: the hubs) removed: what their tails cost
         e = sub["edge_index"]
