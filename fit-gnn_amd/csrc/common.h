@@ -5,7 +5,7 @@
 
 namespace fitgnn {
 
-// Counter-based dropout: one splitmix64 per group of 4 consecutive elements (group g = (row*H + col) >> 2)
+// Counter-based dropout: one 64-bit hash per group of 4 consecutive elements (group g = (row*H + col) >> 2)
 // yields 4 x 16 uniform bits; element (g, sub) is kept iff its 16 bits >= floor(p * 65536).
 // Forward (spmm.hip) and backward (gcn_ops.hip) regenerate the same decisions; no mask is stored.
 // FITGNN_EPI_SEED_DEVICE (= 8): `seed` carries a device pointer to the seed
@@ -13,11 +13,19 @@ __device__ __forceinline__ uint64_t resolve_seed(uint64_t seed, uint32_t epi) {
     return ((epi & 8u) && (epi & 4u)) ? *reinterpret_cast<const uint64_t *>(seed) : seed;
 }
 
+// Two 32-bit murmur3 finalisers over (group, seed) instead of one splitmix64: 64-bit multiplies cost the vector ALU four
+// 32-bit ones each, and the hash sits in the epilogue of HBM-bound kernels (the forward SpMM, the epilogue-backward kernels, the
+// dH @ W GEMM) where it was most of a row's arithmetic.
+__host__ __device__ __forceinline__ uint32_t fmix32(uint32_t h) {
+    h ^= h >> 16; h *= 0x85EBCA6Bu;
+    h ^= h >> 13; h *= 0xC2B2AE35u;
+    return h ^ (h >> 16);
+}
 __host__ __device__ __forceinline__ uint64_t dropout_bits(uint64_t seed, uint64_t group) {
-    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (group + 1);
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    return z ^ (z >> 31);
+    const uint32_t g = (uint32_t)group * 0x9E3779B1u + (uint32_t)(group >> 32) * 0x85EBCA77u;
+    const uint32_t lo = fmix32(g ^ (uint32_t)seed);
+    const uint32_t hi = fmix32((g + 0x7F4A7C15u) ^ (uint32_t)(seed >> 32) ^ 0x68E31DA4u);
+    return ((uint64_t)hi << 32) | lo;
 }
 __host__ __device__ __forceinline__ uint32_t dropout_threshold(float p) { return (uint32_t)(p * 65536.0f); }
 __host__ __device__ __forceinline__ bool dropout_keep(uint64_t bits, int sub, uint32_t thresh) {
