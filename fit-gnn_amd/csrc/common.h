@@ -36,6 +36,22 @@ __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 
 }  // namespace fitgnn
 
+// Raise a kernel's dynamic-LDS limit ONCE per process and device (done: one bit per device ordinal).  hipFuncSetAttribute is a
+// host call into the runtime; issued before every launch it is a per-launch cost and a point where launches on different
+// streams meet.
+#include <atomic>
+inline int fitgnn_lds_limit_once(const void *kernel, int bytes, std::atomic<uint64_t> &done) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    const uint64_t bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return 0;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return (int)e;
+    done.fetch_or(bit, std::memory_order_release);
+    return 0;
+}
+
 #define FITGNN_RETURN_IF_HIP(expr)            \
     do {                                      \
         hipError_t _e = (expr);               \

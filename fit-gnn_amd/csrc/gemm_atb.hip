@@ -269,8 +269,8 @@ extern "C" int fitgnn_gemm_atb_f32(const float *a, int64_t lda, const float *b, 
     if (!a || !b || !out || !workspace) return FITGNN_E_BADARG;
     if ((((uintptr_t)a | (uintptr_t)b | (uintptr_t)out | (uintptr_t)workspace) % 16) != 0) return FITGNN_E_ALIGN;
     const Plan p = make_plan(R, M, N);
-    FITGNN_RETURN_IF_HIP(
-        hipFuncSetAttribute((const void *)gemm_atb_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
+    static std::atomic<uint64_t> lds_done{0};
+    if (const int rc = fitgnn_lds_limit_once((const void *)gemm_atb_kernel, kLdsBytes, lds_done)) return rc;
     hipLaunchKernelGGL(gemm_atb_kernel, dim3((unsigned)(p.ntile * p.nchunks)), dim3(kThreads), kLdsBytes,
                        (hipStream_t)stream, a, (long)lda, b, (long)ldb, (long)R, M, N, (long)p.r_main, p.chunk_rows, p.tiles_n, p.ntile,
                        (float *)workspace);

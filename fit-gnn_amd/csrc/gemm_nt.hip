@@ -359,7 +359,9 @@ int launch_nt(bool epi_on, bool b_is_image, const float *a, int64_t lda, const f
     const int groups = (tiles_m + 7) / 8;
     auto kern = b_is_image ? (epi_on ? gemm_nt_kernel<4, true, true> : gemm_nt_kernel<4, false, true>)
                            : (epi_on ? gemm_nt_kernel<4, true, false> : small ? gemm_nt_kernel<2, false, false> : gemm_nt_kernel<4, false, false>);
-    FITGNN_RETURN_IF_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    static std::atomic<uint64_t> lds_done[5];  // one per kernel variant
+    const int variant = b_is_image ? (epi_on ? 0 : 1) : (epi_on ? 2 : small ? 3 : 4);
+    if (const int rc = fitgnn_lds_limit_once((const void *)kern, lds_bytes, lds_done[variant])) return rc;
     hipLaunchKernelGGL(kern, dim3((unsigned)(groups * 8 * tiles_n)), dim3(small ? Geo<2>::kThreads : Geo<4>::kThreads), lds_bytes, (hipStream_t)stream, a,
                        (long)lda, b, (long)ldb, (long)R, N, K, tiles_m, tiles_n, c, (long)ldc, out, col_part, epi, p_drop, seed,
                        mask);

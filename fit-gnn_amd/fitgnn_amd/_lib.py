@@ -96,6 +96,11 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise FitgnnError(f"{LIB_PATH} not found: build the HIP extension first "
                               "(python -c 'import __graft_entry__ as g; g.build()'); there is no CPU fallback")
+        # torch first: its wheel carries its own HIP runtime, and the process must hold ONE -- the library's libamdhip64
+        # dependency then resolves to the copy torch has loaded.  Loaded the other way round (library first, e.g. build()
+        # followed by smoke() in one process) the two runtimes coexist and this library's sees no device (hipErrorNoDevice).
+        import torch  # noqa: F401
+
         L = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)
