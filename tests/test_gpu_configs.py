@@ -19,7 +19,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-CONFIGS = ["S-pubmed", "S-physics", "S-products"]
+CONFIGS = ["S-pubmed", "S-physics", "S-products"]   # node-level configurations; S-qm9 (graph level) below
 
 
 def rel(a, b):
@@ -156,3 +156,97 @@ def test_training_step_is_finite_moves_the_weights_and_reproduces(cfg):
     assert runs[0][0] == runs[1][0]
     for k in runs[0][1]:
         assert torch.equal(runs[0][1][k], runs[1][1][k]), k
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# BASELINE.json config 5: QM9 graph regression at its full size (S-qm9: 130 831 molecules of ~18 nodes)
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def qm9():
+    from fitgnn_amd import graph_data
+
+    n = 130_831
+    mol = graph_data.synthetic_molecules(n, seed=0)
+    gset = graph_data.GraphSet(mol, ratio=0.5, extra_node=True, device="cuda")
+    return dict(n=n, mol=mol, gset=gset)
+
+
+def test_qm9_sized_dataset_is_coarsened_and_assembled_whole(qm9):
+    """The whole dataset in one batched contraction (one wavefront per molecule) + pooling + subgraph assembly: every node is
+    the own node of exactly one cluster subgraph, every molecule keeps >= 1 cluster and about half its nodes, the
+    reference's row mask marks as many rows as there are nodes (utils.py:498-503)."""
+    mol, gset, n = qm9["mol"], qm9["gset"], qm9["n"]
+    N = int(mol["node_ptr"][-1])
+    assert gset.n_graphs == n and int(gset.gs_core.sum()) == N and int(gset.gs_mask.sum()) == N
+    per_graph = np.diff(gset.cluster_ptr)
+    nodes = np.diff(mol["node_ptr"])
+    assert per_graph.min() >= 1 and np.all(per_graph <= nodes)
+    assert abs(per_graph.sum() / N - 0.5) < 0.05, "r = 0.5 (main.py:370-377 passes 1 - coarsening_ratio)"
+    own = gset.gs_node[gset.gs_core]
+    assert int(torch.unique(own).numel()) == N
+
+
+def test_qm9_sampled_batches_match_the_literal_per_subgraph_loops(qm9):
+    """Regress_graph_gs on 128-graph loader batches taken from the start, the middle and the end of the training half
+    (run.py:513: batch_size 128), one block-diagonal pass each at hidden 512, against the oracle's literal restatement of
+    network.py:189-204 (a conv stack per subgraph, x[mask], mean pool per graph, lt1): outputs <= 1e-4, gradients <= 1e-3."""
+    import types
+
+    from fitgnn_amd import network, train
+    from oracle import gnn_oracle as gorc
+
+    mol, gset, n = qm9["mol"], qm9["gset"], qm9["n"]
+    args = argparse.Namespace(num_layers1=2, layer_name="GCNConv", num_features=11, hidden=512, num_classes=1, dropout=0.0)
+    torch.manual_seed(4)
+    model = network.Regress_graph_gs(args).cuda().train()
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    y_all = torch.from_numpy(mol["y"])
+    e_all = gset.gs_edge_index
+    half = n // 2
+    for g0 in (0, (half // 2) // 128 * 128, (half - 128) // 128 * 128):
+        b = train._cat_pieces([gset.batch(g0, g0 + 128, "gs")], "gs", types)   # the batch dict GraphTrainer feeds the model
+        model.zero_grad()
+        out = model(b, b["graph_of_masked"])
+        tgt = y_all[g0:g0 + 128].long()[:, 0].view(-1, 1).float().cuda()
+        loss = torch.nn.functional.l1_loss(out, tgt)
+        loss.backward()
+        # the same batch in the reference's layout: per graph, per cluster subgraph
+        set_gs = []
+        r_lo, r_hi = int(gset.gs_ptr[g0]), int(gset.gs_ptr[g0 + 128])
+        keep = (e_all[0] >= r_lo) & (e_all[0] < r_hi)
+        e = e_all[:, keep].cpu()
+        for g in range(g0, g0 + 128):
+            subs = []
+            for c in range(int(gset.cluster_ptr[g]), int(gset.cluster_ptr[g + 1])):
+                r0, r1 = int(gset.sub_ptr[c]), int(gset.sub_ptr[c + 1])
+                k = (e[0] >= r0) & (e[0] < r1)
+                subs.append(dict(x=gset.gs_x[r0:r1].cpu(), edge_index=e[:, k] - r0, mask=gset.gs_mask[r0:r1].cpu()))
+            set_gs.append(subs)
+        bt = torch.repeat_interleave(torch.arange(128), torch.from_numpy(np.diff(mol["node_ptr"][g0:g0 + 129])))
+        params = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        ref = gorc.regress_graph_gs_forward(params, set_gs, bt)
+        ref_loss = torch.nn.functional.l1_loss(ref, tgt.cpu())
+        ref_loss.backward()
+        assert rel(out.detach().cpu(), ref.detach()) < 1e-4, g0
+        assert abs(float(loss) - float(ref_loss)) <= 1e-4 * abs(float(ref_loss))
+        for k, p in model.named_parameters():
+            assert rel(p.grad.cpu(), params[k].grad) < 1e-3, (g0, k)
+
+
+def test_qm9_training_epoch_from_captured_steps(qm9):
+    """One Gs training epoch over the 65 415 training graphs (utils.py:33: half of the dataset), 512 steps of 128 graphs
+    replayed from hipGraphs: finite losses and moving weights (the reference never clears the gradients inside an epoch,
+    run.py:257,291 -- reproduced -- so the loss need not fall from one epoch to the next at this step count)."""
+    from fitgnn_amd import network, train
+
+    gset, n = qm9["gset"], qm9["n"]
+    args = argparse.Namespace(num_layers1=2, layer_name="GCNConv", num_features=11, hidden=512, num_classes=1)
+    torch.manual_seed(5)
+    model = network.Regress_graph_gs(args).cuda()
+    w0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    tr = train.GraphTrainer(model, gset, list(range(n // 2)), kind="gs", batch_size=128, lr=0.001, capture=True)
+    assert len(tr.batches) == (n // 2 + 127) // 128
+    l1 = float(tr.step())
+    l2 = float(tr.step())
+    assert np.isfinite(l1) and np.isfinite(l2)
+    assert any(not torch.equal(v, w0[k]) for k, v in model.state_dict().items())
