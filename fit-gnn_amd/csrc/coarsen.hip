@@ -80,10 +80,27 @@ __global__ __launch_bounds__(kCostWaves * 64) void variation_costs_kernel(CostGr
 // ------------------------------------------------------------------------------------------------
 // greedy selection: a single wavefront walks the candidates in (cost, insertion) order
 // ------------------------------------------------------------------------------------------------
+#ifdef FITGNN_GREEDY_STAMPS  // make EXTRA=-DFITGNN_GREEDY_STAMPS + tools/greedy_stamps.py: where the one wave's cycles go
+static __device__ unsigned long long g_greedy_dbg[16];
+// accumulated in registers and flushed once: a global read-modify-write per stamp would drain the prefetches it measures
+#define GSTAMP_DECL unsigned long long gdbg[16] = {0}
+#define GSTAMP(var) const unsigned long long var = __builtin_readcyclecounter()
+#define GACC(i, a, b) gdbg[i] += (b) - (a)
+#define GCNT(i) gdbg[i] += 1
+#define GSTAMP_FLUSH if ((threadIdx.x & 63) == 0) { for (int q = 0; q < 16; ++q) g_greedy_dbg[q] += gdbg[q]; }
+#else
+#define GSTAMP_DECL
+#define GSTAMP(var)
+#define GACC(i, a, b)
+#define GCNT(i)
+#define GSTAMP_FLUSH
+#endif
+
 struct HeapItem {
     double cost;
     int64_t seq;
     int32_t cand;
+    int32_t off, len;  // the set's extent in mem[]: a pop needs no look-up before it can fetch the members
     int32_t pad;
 };
 __device__ __forceinline__ bool item_less(const HeapItem &a, const HeapItem &b) {
@@ -92,138 +109,333 @@ __device__ __forceinline__ bool item_less(const HeapItem &a, const HeapItem &b) 
     return a.seq < b.seq;
 }
 
-constexpr int kHeapLds = 2048;      // single graph: top of the re-insertion heap lives in LDS (48 KiB), the rest in global
-constexpr int kHeapLdsBatch = 128;  // batched small components: 3 KiB per wave, 8 waves per CU
+constexpr int kHeapLds = 2048;      // single graph: the first slots of the re-insertion queue live in LDS (48 KiB), the rest in global
+constexpr int kStateLdsBytes = 80 * 1024;  // ... and the marked-node bitmap + block minima beside them when they fit (N <= 262 144)
+constexpr int kHeapLdsBatch = 128;  // batched small components: 4 KiB per wave
 
+// ---- lane-0 binary heap (batched small components): top in LDS, the rest in global ----
 template <int HEAP_LDS>
-struct Heap {
+struct BinHeap {
     HeapItem *lds;
     HeapItem *glob;
+    int n;  // uniform
     __device__ __forceinline__ HeapItem get(int i) const { return i < HEAP_LDS ? lds[i] : glob[i]; }
     __device__ __forceinline__ void put(int i, const HeapItem &v) { if (i < HEAP_LDS) lds[i] = v; else glob[i] = v; }
+    __device__ __forceinline__ int size() const { return n; }
+    __device__ inline void push(const HeapItem &it) {
+        if ((threadIdx.x & 63) == 0) {
+            int i = n;
+            while (i > 0) {
+                const int p = (i - 1) >> 1;
+                const HeapItem pv = get(p);
+                if (!item_less(it, pv)) break;
+                put(i, pv);
+                i = p;
+            }
+            put(i, it);
+        }
+        ++n;
+        FITGNN_WAVE_SYNC();
+    }
+    __device__ inline HeapItem extract_min() {
+        HeapItem top{};
+        --n;
+        if ((threadIdx.x & 63) == 0) {
+            top = get(0);
+            const HeapItem last = get(n);
+            int i = 0;
+            for (;;) {
+                const int l = 2 * i + 1, r = l + 1;
+                if (l >= n) break;
+                HeapItem cv = get(l);
+                int c = l;
+                if (r < n) {
+                    const HeapItem rv = get(r);
+                    if (item_less(rv, cv)) { cv = rv; c = r; }
+                }
+                if (!item_less(cv, last)) break;
+                put(i, cv);
+                i = c;
+            }
+            if (n > 0) put(i, last);
+        }
+        FITGNN_WAVE_SYNC();
+        top.cost = __shfl(top.cost, 0, 64);
+        top.seq = __shfl(top.seq, 0, 64);
+        top.cand = __shfl(top.cand, 0, 64);
+        top.off = __shfl(top.off, 0, 64);
+        top.len = __shfl(top.len, 0, 64);
+        return top;
+    }
 };
 
-template <class H>
-__device__ inline void heap_push(H &h, int &n, HeapItem it) {
-    int i = n++;
-    while (i > 0) {
-        const int p = (i - 1) >> 1;
-        const HeapItem pv = h.get(p);
-        if (!item_less(it, pv)) break;
-        h.put(i, pv);
-        i = p;
-    }
-    h.put(i, it);
+// ---- wave-parallel tournament (single graph) ----
+// A binary heap walked by one lane costs log2(n) DEPENDENT LDS round trips per operation (measured on S-pubmed, ~4 000
+// live items: 6 200 cycles per pop, 2 800 per push -- a third of the whole selection).  Here the live items sit densely
+// in slots [0, n), 64 slots form a block, and every block's minimum key is cached: a pop is (1) all lanes scan the block
+// minima, (2) all lanes read the winning block, (3) the last slot fills the hole and the block minimum is rebuilt from the
+// registers -- a fixed number of wave-wide steps whatever n is.  Keys order by (cost, seq) exactly like item_less: costs
+// are >= +0 (a Frobenius norm over a positive count), so their bit patterns order like the values.
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+    // row_shr 1,2,4,8: lane 15 of every 16-lane row holds the row's minimum; row_bcast 15 / 31 fold the rows into lane 63
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x111, 0xf, 0xf, false));
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x112, 0xf, 0xf, false));
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x114, 0xf, 0xf, false));
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x118, 0xf, 0xf, false));
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x142, 0xa, 0xf, false));
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x143, 0xc, 0xf, false));
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
-template <class H>
-__device__ inline HeapItem heap_pop(H &h, int &n) {
-    const HeapItem top = h.get(0);
-    const HeapItem last = h.get(--n);
-    int i = 0;
-    for (;;) {
-        const int l = 2 * i + 1, r = l + 1;
-        if (l >= n) break;
-        HeapItem cv = h.get(l);
-        int c = l;
-        if (r < n) {
-            const HeapItem rv = h.get(r);
-            if (item_less(rv, cv)) { cv = rv; c = r; }
+// lane holding the smallest (cost, seq) among the lanes with valid set; -1 when there is none.  All 64 lanes call it.
+__device__ __forceinline__ int wave_argmin(double cost, uint32_t seq, bool valid) {
+    const uint64_t bits = (uint64_t)__double_as_longlong(cost);
+    const uint32_t hi = (uint32_t)(bits >> 32), lo = (uint32_t)bits;
+    bool in = valid;
+    const uint32_t mh = wave_min_u32(in ? hi : 0xffffffffu);
+    in = in && hi == mh;
+    unsigned long long bal = __ballot(in);
+    if (bal == 0ull) return -1;
+    if (__popcll(bal) > 1) {  // wave-uniform; rare: the high words of two different costs seldom agree
+        const uint32_t ml = wave_min_u32(in ? lo : 0xffffffffu);
+        in = in && lo == ml;
+        bal = __ballot(in);
+        if (__popcll(bal) > 1) {
+            const uint32_t ms = wave_min_u32(in ? seq : 0xffffffffu);
+            in = in && seq == ms;
+            bal = __ballot(in);
         }
-        if (!item_less(cv, last)) break;
-        h.put(i, cv);
-        i = c;
     }
-    if (n > 0) h.put(i, last);
-    return top;
+    return __builtin_ctzll(bal);
+}
+__device__ __forceinline__ int32_t lane_bcast(int32_t v, int l) { return __builtin_amdgcn_readlane(v, l); }
+__device__ __forceinline__ uint32_t lane_bcast(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
+__device__ __forceinline__ double lane_bcast(double v, int l) {
+    const uint64_t b = (uint64_t)__double_as_longlong(v);
+    const uint32_t h = (uint32_t)__builtin_amdgcn_readlane((int)(b >> 32), l), w = (uint32_t)__builtin_amdgcn_readlane((int)b, l);
+    return __longlong_as_double((long long)(((uint64_t)h << 32) | w));
 }
 
+// LDS arrays are addressed through address-space-3 pointers: behind a plain pointer the compiler folds "slot in LDS ? a : b" into ONE
+// generic pointer and a flat load (vector-memory latency even for LDS, plus a pointer table in scratch)
+template <class T>
+using lds_ptr = __attribute__((address_space(3))) T *;
+template <class T>
+__device__ __forceinline__ lds_ptr<T> to_lds(T *p) { return (lds_ptr<T>)p; }
+
+template <int HEAP_LDS>
+struct TourSlots {  // slot arrays: the first HEAP_LDS slots in LDS, the rest (same index) in global
+    lds_ptr<double> l_cost; lds_ptr<uint32_t> l_seq; lds_ptr<int32_t> l_cand, l_off, l_len;
+    double *g_cost; uint32_t *g_seq; int32_t *g_cand, *g_off, *g_len;
+};
+struct BlockMinLds { lds_ptr<double> cost; lds_ptr<uint32_t> seq; };
+struct BlockMinGlobal { double *cost; uint32_t *seq; };
+template <int HEAP_LDS, class BlockMin>
+struct TourHeap {
+    static_assert(HEAP_LDS % 64 == 0, "blocks do not straddle the LDS / global split");
+    TourSlots<HEAP_LDS> a;
+    BlockMin b;        // per block of 64 slots: its minimum key (LDS when it fits, launcher)
+    int n;             // uniform
+    __device__ __forceinline__ int size() const { return n; }
+    __device__ __forceinline__ void read(int slot, double &c, uint32_t &s, int32_t &cd, int32_t &o, int32_t &l) const {
+        if (slot < HEAP_LDS) { c = a.l_cost[slot]; s = a.l_seq[slot]; cd = a.l_cand[slot]; o = a.l_off[slot]; l = a.l_len[slot]; }
+        else { c = a.g_cost[slot]; s = a.g_seq[slot]; cd = a.g_cand[slot]; o = a.g_off[slot]; l = a.g_len[slot]; }
+    }
+    __device__ __forceinline__ void write(int slot, double c, uint32_t s, int32_t cd, int32_t o, int32_t l) const {
+        if (slot < HEAP_LDS) { a.l_cost[slot] = c; a.l_seq[slot] = s; a.l_cand[slot] = cd; a.l_off[slot] = o; a.l_len[slot] = l; }
+        else { a.g_cost[slot] = c; a.g_seq[slot] = s; a.g_cand[slot] = cd; a.g_off[slot] = o; a.g_len[slot] = l; }
+    }
+    __device__ inline void push(const HeapItem &it) {
+        const int slot = n++;
+        if ((threadIdx.x & 63) == 0) {
+            write(slot, it.cost, (uint32_t)it.seq, it.cand, it.off, it.len);
+            const int j = slot >> 6;
+            bool lower = (slot & 63) == 0;
+            if (!lower) { const double bc = b.cost[j]; lower = it.cost < bc || (it.cost == bc && (uint32_t)it.seq < b.seq[j]); }
+            if (lower) { b.cost[j] = it.cost; b.seq[j] = (uint32_t)it.seq; }
+        }
+        FITGNN_WAVE_SYNC();
+    }
+    // minimum over the slots < n of block j, from this lane's key (kc, ks) of slot j*64 + lane; stored as the block's minimum
+    __device__ __forceinline__ void rebuild(int j, double kc, uint32_t ks) {
+        const int lane = threadIdx.x & 63;
+        const int l = wave_argmin(kc, ks, j * 64 + lane < n);
+        if (l >= 0) {
+            const double mc = lane_bcast(kc, l);
+            const uint32_t ms = lane_bcast(ks, l);
+            if (lane == 0) { b.cost[j] = mc; b.seq[j] = ms; }
+        }
+    }
+    __device__ inline HeapItem extract_min() {  // n > 0
+        const int lane = threadIdx.x & 63;
+        const int nb = (n + 63) >> 6;
+        // (1) the block holding the minimum
+        double c = 0.0;
+        uint32_t s = 0;
+        int jb = -1;
+        for (int j = lane; j < nb; j += 64) {
+            const double cj = b.cost[j];
+            const uint32_t sj = b.seq[j];
+            if (jb < 0 || cj < c || (cj == c && sj < s)) { c = cj; s = sj; jb = j; }
+        }
+        const int l1 = wave_argmin(c, s, jb >= 0);
+        jb = lane_bcast((int32_t)jb, l1);
+        // (2) the slot inside it
+        const int slot = jb * 64 + lane;
+        double kc = 0.0;
+        uint32_t ks = 0;
+        int32_t pc = 0, po = 0, pl = 0;
+        if (slot < n) read(slot, kc, ks, pc, po, pl);
+        const int l2 = wave_argmin(kc, ks, slot < n);
+        HeapItem out{lane_bcast(kc, l2), (int64_t)lane_bcast(ks, l2), lane_bcast(pc, l2), lane_bcast(po, l2), lane_bcast(pl, l2), 0};
+        const int p = jb * 64 + l2;
+        // (3) the last slot fills the hole
+        --n;
+        double lc = 0.0;
+        uint32_t ls = 0;
+        if (p != n) {
+            int32_t lcd, lo, ll;
+            read(n, lc, ls, lcd, lo, ll);  // same address in every lane
+            FITGNN_WAVE_SYNC();
+            if (lane == 0) write(p, lc, ls, lcd, lo, ll);
+            if (lane == l2) { kc = lc; ks = ls; }
+        }
+        rebuild(jb, kc, ks);
+        // the block the last slot left: its minimum changes only if the moved item was that minimum
+        const int jl = n >> 6;
+        if (p != n && jl != jb && (n & 63) != 0) {
+            if (__double_as_longlong(lc) == __double_as_longlong(b.cost[jl]) && ls == b.seq[jl]) {  // wave-uniform
+                const int sl = jl * 64 + lane;
+                double c2 = 0.0;
+                uint32_t s2 = 0;
+                if (sl < n) { if (sl < HEAP_LDS) { c2 = a.l_cost[sl]; s2 = a.l_seq[sl]; } else { c2 = a.g_cost[sl]; s2 = a.g_seq[sl]; } }
+                rebuild(jl, c2, s2);
+            }
+        }
+        FITGNN_WAVE_SYNC();
+        return out;
+    }
+};
+
+// Marked-node set of the selection: bytes in global memory (batched components: one wave each, node ranges of any size) or a
+// bitmap in LDS (single graph: 20 KiB for 165 000 nodes) -- the mark check and the prune then touch no global memory at all.
+struct MarksGlobal {
+    uint8_t *m;
+    __device__ __forceinline__ bool get(int32_t v) const { return m[v] != 0; }
+    __device__ __forceinline__ void set(int32_t v) const { m[v] = 1; }
+    // mark writes before later reads (waits for every outstanding access of the wave)
+    __device__ __forceinline__ void publish() const { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); }
+};
+struct MarksLds {
+    lds_ptr<uint32_t> w;
+    __device__ __forceinline__ bool get(int32_t v) const { return (w[v >> 5] >> (v & 31)) & 1u; }
+    __device__ __forceinline__ void set(int32_t v) const { __hip_atomic_fetch_or(&w[v >> 5], 1u << (v & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+    // the LDS pipeline is in order per wave: nothing to wait for, and the prefetches in flight stay in flight
+    __device__ __forceinline__ void publish() const { FITGNN_WAVE_SYNC(); }
+};
+
 // The greedy selection of contract_variation_linear (:604-650) over ONE connected component, run by one wavefront.
-// The component's candidates are order[head0 .. head1) (ascending (cost, node id)); node ids, set_off/mem/len/marked
+// The component's candidates are order[head0 .. head1) (ascending (cost, node id)); node ids, set_off/mem/len/marks
 // are those of the whole (possibly block-diagonal) graph.  Selected sets go to sel_mem[0 .. ) and their END
 // positions to sel_end[0 .. ) (both relative to the pointers passed in).  Returns through ns / pos / the residual
 // n_reduce.  Every iteration consumes one queue entry and re-insertions strictly shrink a set, so the loop is
 // bounded by max_iters = candidates + members + slack (an exit every lane reaches).
-#ifdef FITGNN_GREEDY_STAMPS
-__device__ unsigned long long g_greedy_dbg[8];  // cycles: pop, mark check, select, prune, recost, heap push; counts: pops, recosts
-#define FITGNN_STAMP(var) const unsigned long long var = __builtin_readcyclecounter()
-#define FITGNN_ACC(i, a, b) if ((threadIdx.x & 63) == 0) g_greedy_dbg[i] += (b) - (a)
-#else
-#define FITGNN_STAMP(var)
-#define FITGNN_ACC(i, a, b)
-#endif
-
-template <int HEAP_LDS>
-__device__ inline void greedy_component(const CostGraph &g, CostLds &lds, Heap<HEAP_LDS> heap, int32_t head0, int32_t head1,
+//
+// A pop is pointer chasing (list entry -> candidate -> its cost / extent -> its members -> their marks): five dependent
+// accesses, each an L2 round trip for the one wave that makes them.  The sorted initial family is known in advance, so it is
+// read through a three-stage software pipeline -- entry head + 2: id requested; head + 1: cost / extent requested; head:
+// complete, its first 64 members in the lanes -- and every request was issued at least one pop earlier; re-inserted sets
+// carry their extent in the heap item.  With the marks in LDS a pop from the list touches global memory only to prefetch.
+template <class Heap, class Marks>
+__device__ inline void greedy_component(const CostGraph &g, CostLds &lds, Heap heap, int32_t head0, int32_t head1,
                                         int64_t seq, const int32_t *__restrict__ set_off, int32_t *__restrict__ mem,
-                                        int32_t *__restrict__ len, uint8_t *__restrict__ marked,
+                                        int32_t *__restrict__ len, Marks marks,
                                         const int32_t *__restrict__ order, const double *__restrict__ cost0,
                                         int64_t &n_reduce, int64_t max_iters, int32_t *__restrict__ sel_end,
                                         int32_t *__restrict__ sel_mem, int32_t &ns, int32_t &pos) {
     const int lane = threadIdx.x & 63;
-    int hn = 0;          // heap size (uniform)
     int head = head0;    // next unread entry of the sorted initial family (uniform)
     ns = 0; pos = 0;
-    // the head of the sorted list is fetched one pop ahead (candidate, cost, set extent): the loads of the NEXT list
-    // entry are in flight while the current candidate is processed.  len[] of an unprocessed list entry is its initial
-    // length (only the candidate being processed is ever shrunk).
-    int32_t nx_cand = 0, nx_off = 0, nx_len = 0;
-    double nx_cost = 0.0;
-    if (head < head1) { nx_cand = order[head]; nx_cost = cost0[nx_cand]; nx_off = set_off[nx_cand]; nx_len = len[nx_cand]; }
+    GSTAMP_DECL;
+    // the smallest re-inserted set is held OUT of the heap, with its first 64 members already requested: popping it needs
+    // no look-up, and its successor is extracted (and its members requested) while this one is being processed
+    bool has_top = false;
+    HeapItem top{};
+    int32_t tm = -1;
+    // list pipeline (len[] of an unprocessed list entry is its initial length and its members are untouched: only the
+    // candidate being processed is ever shrunk)
+    int32_t c0 = 0, o0 = 0, l0 = 0, m0 = -1;  // entry head: candidate, extent, first 64 members (m0 per lane)
+    double k0 = 0.0;
+    int32_t c1 = 0, o1 = 0, l1 = 0;           // entry head + 1
+    double k1 = 0.0;
+    int32_t c2 = 0;                           // entry head + 2
+    auto entry = [&](int h) { return order[min(h, head1 - 1)]; };   // clamped: past the end the value is never used
+    if (head < head1) {
+        c0 = entry(head); c1 = entry(head + 1); c2 = entry(head + 2);
+        k0 = cost0[c0]; o0 = set_off[c0]; l0 = len[c0];
+        k1 = cost0[c1]; o1 = set_off[c1]; l1 = len[c1];
+        m0 = lane < l0 ? mem[o0 + lane] : -1;
+    }
     for (int64_t it = 0; it < max_iters; ++it) {
         if (n_reduce <= 0) break;
-        if (head >= head1 && hn == 0) break;
-        // ---- pop the minimum of {sorted initial list head, heap top}: SortedList.pop(0) ----
-        FITGNN_STAMP(t_a);
-        int32_t cand;
+        if (head >= head1 && !has_top) break;
+        // ---- pop the minimum of {sorted initial list head, smallest re-inserted set}: SortedList.pop(0) ----
+        GSTAMP(g0);
+        int32_t cand, mm;
         int off, nc;
-        bool from_list = hn == 0;
-        if (head < head1 && hn > 0) {
-            HeapItem li{nx_cost, (int64_t)nx_cand, nx_cand, 0};
-            const HeapItem top = heap.get(0);
+        bool from_list = !has_top;
+        if (head < head1 && has_top) {
+            HeapItem li{k0, (int64_t)c0, c0, 0, 0, 0};
             from_list = item_less(li, top);
         }
         if (from_list) {
-            cand = __builtin_amdgcn_readfirstlane(nx_cand);
-            off = __builtin_amdgcn_readfirstlane(nx_off);
-            nc = __builtin_amdgcn_readfirstlane(nx_len);
+            cand = __builtin_amdgcn_readfirstlane(c0);
+            off = __builtin_amdgcn_readfirstlane(o0);
+            nc = __builtin_amdgcn_readfirstlane(l0);
+            mm = m0;
             ++head;
-            if (head < head1) { nx_cand = order[head]; nx_cost = cost0[nx_cand]; nx_off = set_off[nx_cand]; nx_len = len[nx_cand]; }
+            if (head < head1) {  // advance the pipeline: every value used here was requested one pop ago or earlier
+                c0 = c1; k0 = k1; o0 = o1; l0 = l1;
+                m0 = lane < l0 ? mem[o0 + lane] : -1;
+                c1 = c2;
+                k1 = cost0[c1]; o1 = set_off[c1]; l1 = len[c1];
+                c2 = entry(head + 2);
+            }
         } else {
-            HeapItem top;
-            if (lane == 0) top = heap_pop(heap, hn); else --hn;
-            FITGNN_WAVE_SYNC();
-            cand = __builtin_amdgcn_readfirstlane(__shfl(top.cand, 0, 64));
-            off = __builtin_amdgcn_readfirstlane(set_off[cand]);
-            nc = __builtin_amdgcn_readfirstlane(len[cand]);
+            cand = top.cand; off = top.off; nc = top.len;
+            mm = tm;
+            has_top = heap.size() > 0;
+            if (has_top) {
+                top = heap.extract_min();
+                tm = lane < top.len ? mem[top.off + lane] : -1;
+            }
         }
         int32_t *S = mem + off;
-        FITGNN_STAMP(t_b);
-        FITGNN_ACC(0, t_a, t_b);
-        FITGNN_ACC(6, 0ull, 1ull);
+        GSTAMP(g1);
+        if (from_list) { GACC(0, g0, g1); GCNT(8); } else { GACC(1, g0, g1); GCNT(9); }
         // ---- any member marked? (coarsening_utils.py:620-622) ----
-        bool any = false;
-        for (int t0 = 0; t0 < nc; t0 += 64) {
+        bool any = __ballot(mm >= 0 && marks.get(mm)) != 0ull;
+        for (int t0 = 64; t0 < nc && !any; t0 += 64) {
             const int t = t0 + lane;
-            const bool mk = (t < nc) && marked[S[t]] != 0;
+            const bool mk = (t < nc) && marks.get(S[t]);
             any |= __ballot(mk) != 0ull;
         }
-        FITGNN_STAMP(t_c);
-        FITGNN_ACC(1, t_b, t_c);
+        GSTAMP(g2);
+        GACC(2, g1, g2);
         if (!any) {
             const int64_t gain = nc - 1;
             if (gain > n_reduce) continue;  // :625-626, would over-reduce: drop the set
             for (int t = lane; t < nc; t += 64) {
-                const int32_t v = S[t];
-                marked[v] = 1;
+                const int32_t v = t < 64 ? mm : S[t];
+                marks.set(v);
                 sel_mem[pos + t] = v;
             }
             pos += nc;
             if (lane == 0) sel_end[ns] = pos;
             ++ns;
             n_reduce -= gain;
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // marked[] writes before later reads
-            FITGNN_STAMP(t_d);
-            FITGNN_ACC(2, t_c, t_d);
+            marks.publish();
+            GSTAMP(g3);
+            GACC(3, g2, g3); GCNT(10);
         } else {
             // ---- drop marked members in place, keep order (:640) ----
             int m = 0;
@@ -231,47 +443,94 @@ __device__ inline void greedy_component(const CostGraph &g, CostLds &lds, Heap<H
                 const int t = t0 + lane;
                 int32_t v = 0;
                 bool keep = false;
-                if (t < nc) { v = S[t]; keep = marked[v] == 0; }
+                if (t < nc) { v = t0 == 0 ? mm : S[t]; keep = !marks.get(v); }
                 const unsigned long long bal = __ballot(keep);
                 const int before = __popcll(bal & ((1ull << lane) - 1ull));
                 FITGNN_WAVE_SYNC();  // all reads of this chunk done before the compacted writes (m <= t0)
-                if (keep) S[m + before] = v;
+                if (keep) {
+                    S[m + before] = v;
+                    if (m + before < fitgnn::kCostTile) lds.S[m + before] = v;  // staged for the re-cost
+                }
                 m += __popcll(bal);
             }
-            FITGNN_STAMP(t_e);
-            FITGNN_ACC(3, t_c, t_e);
+            GSTAMP(g4);
+            GACC(4, g2, g4); GCNT(11);
             if (m > 1) {
                 if (lane == 0) len[cand] = m;
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-                const double c = fitgnn::set_cost_wave(g, S, m, lds);  // :646 re-cost
-                FITGNN_STAMP(t_f);
-                FITGNN_ACC(4, t_e, t_f);
-                FITGNN_ACC(7, 0ull, 1ull);
-                if (lane == 0) heap_push(heap, hn, HeapItem{c, seq, cand, 0}); else ++hn;
+                double c;  // :646 re-cost
+                int32_t xm;  // the new set's first 64 members, per lane
+                if (m <= fitgnn::kCostTile) {
+                    FITGNN_WAVE_SYNC();
+                    c = fitgnn::set_cost_wave<true>(g, S, m, lds);
+                    xm = lane < m ? lds.S[lane] : -1;
+                } else {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // the compacted members are read back
+                    c = fitgnn::set_cost_wave<false>(g, S, m, lds);
+                    xm = S[lane];
+                }
+                GSTAMP(g5);
+                GACC(5, g4, g5); GCNT(12);
+                const HeapItem x{c, seq, cand, off, m, 0};
                 ++seq;
-                FITGNN_WAVE_SYNC();
-                FITGNN_STAMP(t_g);
-                FITGNN_ACC(5, t_f, t_g);
+                if (!has_top) {
+                    top = x; tm = xm; has_top = true;
+                } else if (item_less(x, top)) {
+                    heap.push(top);
+                    top = x; tm = xm;
+                } else {
+                    heap.push(x);
+                }
+                GSTAMP(g6);
+                GACC(6, g5, g6);
             }
         }
     }
+    GSTAMP_FLUSH;
+}
+
+// dynamic LDS of the single-graph kernel when the graph is small enough (launcher): marked-node bitmap, then the block minima
+__host__ __device__ inline size_t greedy_bitmap_words(int32_t N) { return ((size_t)N + 31) / 32; }
+__host__ __device__ inline size_t greedy_blocks(int32_t N) { return ((size_t)N + 63) / 64 + 1; }
+__host__ __device__ inline size_t greedy_dyn_lds_bytes(int32_t N) {
+    return ((greedy_bitmap_words(N) * 4 + 7) / 8) * 8 + greedy_blocks(N) * 12;
 }
 
 __global__ __launch_bounds__(64) void greedy_select_kernel(CostGraph g, int32_t N, const int32_t *__restrict__ set_off,
                                                            int32_t *__restrict__ mem, int32_t *__restrict__ len,
                                                            uint8_t *__restrict__ marked,
                                                            const int32_t *__restrict__ order,
-                                                           const double *__restrict__ cost0, HeapItem *__restrict__ heap_glob,
+                                                           const double *__restrict__ cost0, char *__restrict__ heap_glob,
                                                            int64_t n_reduce, int64_t max_iters,
                                                            int32_t *__restrict__ sel_off, int32_t *__restrict__ sel_mem,
-                                                           int32_t *__restrict__ sel_count) {
+                                                           int32_t *__restrict__ sel_count, int32_t state_in_lds) {
     __shared__ CostLds lds;
-    __shared__ HeapItem heap_lds[kHeapLds];
+    __shared__ double h_cost[kHeapLds];
+    __shared__ uint32_t h_seq[kHeapLds];
+    __shared__ int32_t h_cand[kHeapLds], h_off[kHeapLds], h_len[kHeapLds];
+    extern __shared__ double dyn_lds[];  // state_in_lds: [bitmap | block minima: cost, seq] (greedy_dyn_lds_bytes)
     if ((threadIdx.x & 63) == 0) sel_off[0] = 0;
     int32_t ns, pos;
+    // slots beyond kHeapLds and, for a graph too large for LDS, the block minima: carved from the heap workspace (32 B / node)
+    const size_t n = (size_t)N;
+    TourSlots<kHeapLds> slots{to_lds(h_cost), to_lds(h_seq), to_lds(h_cand), to_lds(h_off), to_lds(h_len),
+                              (double *)heap_glob, (uint32_t *)(heap_glob + 8 * n), (int32_t *)(heap_glob + 12 * n),
+                              (int32_t *)(heap_glob + 16 * n), (int32_t *)(heap_glob + 20 * n)};
     // re-inserted sets get seq = N, N+1, ... (initial family: seq = node id)
-    greedy_component<kHeapLds>(g, lds, Heap<kHeapLds>{heap_lds, heap_glob}, 0, N, (int64_t)N, set_off, mem, len, marked, order,
-                               cost0, n_reduce, max_iters, sel_off + 1, sel_mem, ns, pos);
+    if (state_in_lds) {
+        uint32_t *mark_bits = (uint32_t *)dyn_lds;
+        const size_t words = greedy_bitmap_words(N);
+        double *b_cost = dyn_lds + (words * 4 + 7) / 8;
+        uint32_t *b_seq = (uint32_t *)(b_cost + greedy_blocks(N));
+        for (int i = threadIdx.x; i < (int)words; i += 64) mark_bits[i] = 0u;
+        FITGNN_WAVE_SYNC();
+        greedy_component(g, lds, TourHeap<kHeapLds, BlockMinLds>{slots, BlockMinLds{to_lds(b_cost), to_lds(b_seq)}, 0}, 0, N, (int64_t)N,
+                         set_off, mem, len, MarksLds{to_lds(mark_bits)}, order, cost0, n_reduce, max_iters, sel_off + 1, sel_mem, ns, pos);
+    } else {
+        double *b_cost = (double *)(heap_glob + 24 * n);
+        uint32_t *b_seq = (uint32_t *)(b_cost + greedy_blocks(N));
+        greedy_component(g, lds, TourHeap<kHeapLds, BlockMinGlobal>{slots, BlockMinGlobal{b_cost, b_seq}, 0}, 0, N, (int64_t)N, set_off, mem,
+                         len, MarksGlobal{marked}, order, cost0, n_reduce, max_iters, sel_off + 1, sel_mem, ns, pos);
+    }
     if ((threadIdx.x & 63) == 0) { sel_count[0] = ns; sel_count[1] = pos; }
 }
 
@@ -299,8 +558,8 @@ __global__ __launch_bounds__(64) void greedy_select_batch_kernel(CostGraph g, in
     const int64_t max_iters = (int64_t)(e - b) + (int64_t)(set_off[e] - set_off[b]) + 8;
     int32_t ns = 0, pos = 0;
     if (e > b && n_reduce > 0)
-        greedy_component<kHeapLdsBatch>(g, lds, Heap<kHeapLdsBatch>{heap_lds, heap_glob + b}, b, e, (int64_t)N, set_off, mem, len,
-                                        marked, order, cost0, n_reduce, max_iters, stage_end + b, stage_mem + b, ns, pos);
+        greedy_component(g, lds, BinHeap<kHeapLdsBatch>{heap_lds, heap_glob + b, 0}, b, e, (int64_t)N, set_off, mem, len,
+                         MarksGlobal{marked}, order, cost0, n_reduce, max_iters, stage_end + b, stage_mem + b, ns, pos);
     if ((threadIdx.x & 63) == 0) { cnt_sets[c] = ns; cnt_mem[c] = pos; gain[c] = budget - n_reduce; }
 }
 
@@ -371,7 +630,7 @@ GreedyLayout greedy_layout(int32_t N, int64_t total_members) {
     L.keys_out = o; o += align_up(n * 8);
     L.ids_in = o; o += align_up(n * 4);
     L.order = o; o += align_up(n * 4);
-    L.heap = o; o += align_up(n * sizeof(HeapItem));
+    L.heap = o; o += align_up(n * sizeof(HeapItem) + 64);  // single graph: 24 B of slot arrays + 12/64 B of block minima per node
     size_t tmp = 0;
     (void)rocprim::radix_sort_pairs(nullptr, tmp, (uint64_t *)nullptr, (uint64_t *)nullptr, (int32_t *)nullptr,
                                     (int32_t *)nullptr, n, 0, 64, (hipStream_t)0);
@@ -469,11 +728,12 @@ extern "C" int fitgnn_variation_costs_batch_f64(const int32_t *rowptr, const int
 
 #ifdef FITGNN_GREEDY_STAMPS
 extern "C" int fitgnn_debug_greedy_counters(unsigned long long *out, int reset) {
-    hipDeviceSynchronize();
-    int rc = (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_greedy_dbg), sizeof(unsigned long long) * 8);
-    rc |= (int)hipMemcpyFromSymbol(out + 8, HIP_SYMBOL(g_cost_dbg), sizeof(unsigned long long) * 8);
-    if (reset) { unsigned long long z2[8] = {0}; rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(g_cost_dbg), z2, sizeof(z2)); }
-    if (reset) { unsigned long long z[8] = {0}; rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(g_greedy_dbg), z, sizeof(z)); }
+    int rc = (int)hipDeviceSynchronize();
+    rc |= (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_greedy_dbg), sizeof(unsigned long long) * 16);
+    if (reset) {
+        unsigned long long z[16] = {0};
+        rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(g_greedy_dbg), z, sizeof(z));
+    }
     return rc;
 }
 #endif
@@ -521,8 +781,13 @@ extern "C" int fitgnn_greedy_select(const int32_t *rowptr, const int32_t *col, c
                                                    (size_t)N, 0, 64, s));
     CostGraph g{rowptr, col, w, dw, A, K, lda, nullptr};
     const int64_t max_iters = (int64_t)N + (int64_t)total + 8;
-    hipLaunchKernelGGL(greedy_select_kernel, dim3(1), dim3(64), 0, s, g, N, set_off, mem, len, marked, order, cost0, heap,
-                       n_reduce, max_iters, sel_off, sel_mem, sel_count);
+    // marked-node bitmap and the queue's block minima in LDS while they fit beside the slots and the cost scratch
+    const size_t dyn_bytes = greedy_dyn_lds_bytes(N);
+    const int state_in_lds = dyn_bytes <= (size_t)kStateLdsBytes ? 1 : 0;
+    static std::atomic<uint64_t> lds_done{0};
+    if (const int rc = fitgnn_lds_limit_once((const void *)greedy_select_kernel, kStateLdsBytes, lds_done)) return rc;
+    hipLaunchKernelGGL(greedy_select_kernel, dim3(1), dim3(64), state_in_lds ? dyn_bytes : 0, s, g, N, set_off, mem, len, marked, order,
+                       cost0, (char *)heap, n_reduce, max_iters, sel_off, sel_mem, sel_count, state_in_lds);
     return (int)hipGetLastError();
 }
 

@@ -28,15 +28,6 @@
         __builtin_amdgcn_wave_barrier();                        \
     } while (0)
 
-#ifdef FITGNN_GREEDY_STAMPS
-static __device__ unsigned long long g_cost_dbg[8];
-#define CSTAMP(var) const unsigned long long var = __builtin_readcyclecounter()
-#define CACC(i, a, b) if ((threadIdx.x & 63) == 0) g_cost_dbg[i] += (b) - (a)
-#else
-#define CSTAMP(var)
-#define CACC(i, a, b)
-#endif
-
 namespace fitgnn {
 
 constexpr int kCostTile = 64;  // rows of S per LDS tile (one per lane)
@@ -79,15 +70,16 @@ __device__ __forceinline__ int lower_bound_i32(const int32_t *a, int n, int32_t 
 
 // All 64 lanes of the wave must call this with identical (g, S, nc).  Returns the cost in every lane.
 // S points to global memory (sorted ascending).  lds is this wave's private scratch.
+// STAGED: the caller has already put the members of a set of at most kCostTile nodes into lds.S (and synchronised the wave),
+// so nothing is read back from S -- the greedy selection re-costs a set it has just compacted in registers.
+template <bool STAGED = false>
 __device__ inline double set_cost_wave(const CostGraph &g, const int32_t *__restrict__ S, int nc, CostLds &lds) {
 #pragma clang fp contract(off)
     if (nc < 2) return INFINITY;
     const int lane = threadIdx.x & 63;
-    const int K = g.node_K ? __builtin_amdgcn_readfirstlane(g.node_K[S[0]]) : g.K;
+    const int K = g.node_K ? __builtin_amdgcn_readfirstlane(g.node_K[STAGED ? lds.S[0] : S[0]]) : g.K;
     const int KK = K * K;
     const bool small = nc <= kCostTile;  // whole set resident in LDS
-
-    CSTAMP(c0);
     // ---- pass 1: column means, sequential over members (tiles of 64 rows staged cooperatively) ----
     double msum = 0.0;
     int pre_e0 = 0, pre_deg = 0;   // small sets: the member's row extent and degree term ride along with the A gather
@@ -95,8 +87,8 @@ __device__ inline double set_cost_wave(const CostGraph &g, const int32_t *__rest
     for (int t0 = 0; t0 < nc; t0 += kCostTile) {
         const int rows = min(kCostTile, nc - t0);
         if (lane < rows) {
-            const int32_t u = S[t0 + lane];
-            lds.S[lane] = u;
+            int32_t u;
+            if (STAGED) u = lds.S[lane]; else { u = S[t0 + lane]; lds.S[lane] = u; }
             if (small) { pre_e0 = g.rowptr[u]; pre_deg = g.rowptr[u + 1] - pre_e0; pre_dw = g.dw[u]; }
         }
         FITGNN_WAVE_SYNC();
@@ -114,7 +106,6 @@ __device__ inline double set_cost_wave(const CostGraph &g, const int32_t *__rest
     }
     if (lane < K) lds.mean[lane] = msum / (double)nc;
     FITGNN_WAVE_SYNC();
-    CSTAMP(c1); CACC(0, c0, c1);
 
     // ---- pass 2: per tile, rows on lanes -> B, Y ; then entries on lanes -> M ----
     double m0 = 0.0, m1 = 0.0, m2 = 0.0, m3 = 0.0;
@@ -139,7 +130,6 @@ __device__ inline double set_cost_wave(const CostGraph &g, const int32_t *__rest
         // Fast path (whole set in one tile): all 64 lanes scan the members' adjacency lists TOGETHER -- one flattened
         // index space, independent loads -- and list the matches (position in S, weight) in LDS in (row, column)
         // order; each member's lane then folds ITS matches in that same order, so the arithmetic is the serial walk's.
-        CSTAMP(c2);
         bool listed = false;
         if (small) {
             const int e0 = pre_e0, deg = pre_deg;
@@ -272,7 +262,6 @@ __device__ inline double set_cost_wave(const CostGraph &g, const int32_t *__rest
                 if (l < K) { const double prod = d * lds.B[a * K + l]; lds.Y[a * K + l] = prod - T[l]; }
         }
         FITGNN_WAVE_SYNC();
-        CSTAMP(c3); CACC(1, c2, c3);
         // M[k][l] += B[a][k] * Y[a][l], a ascending
         {
             const int ka = ea / K, la = ea - ka * K;
@@ -289,7 +278,6 @@ __device__ inline double set_cost_wave(const CostGraph &g, const int32_t *__rest
         }
         FITGNN_WAVE_SYNC();
     }
-    CSTAMP(c4);
     // ---- Frobenius norm: canonical 64-lane tree ----
     double p = 0.0;
     if (ea < KK) p = m0 * m0;
@@ -303,7 +291,6 @@ __device__ inline double set_cost_wave(const CostGraph &g, const int32_t *__rest
     }
     p = __shfl(p, 0, 64);
     const double res = sqrt(p) / (double)(nc - 1);
-    CSTAMP(c5); CACC(3, c4, c5); CACC(4, c0, c5);
     return res;
 }
 
