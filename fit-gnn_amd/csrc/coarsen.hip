@@ -109,8 +109,8 @@ __device__ __forceinline__ bool item_less(const HeapItem &a, const HeapItem &b) 
     return a.seq < b.seq;
 }
 
-constexpr int kHeapLds = 2048;      // single graph: the first slots of the re-insertion queue live in LDS (48 KiB), the rest in global
-constexpr int kStateLdsBytes = 80 * 1024;  // ... and the marked-node bitmap + block minima beside them when they fit (N <= 262 144)
+constexpr int kHeapLds = 1024;      // single graph: the first slots of the re-insertion queue live in LDS (24 KiB), the rest in global
+constexpr int kStateLdsBytes = 64 * 1024;  // ... and the marked-node bitmap + block minima beside them when they fit (N <= 209 000)
 constexpr int kHeapLdsBatch = 128;  // batched small components: 4 KiB per wave
 
 // ---- lane-0 binary heap (batched small components): top in LDS, the rest in global ----
@@ -333,6 +333,81 @@ struct MarksLds {
     __device__ __forceinline__ void publish() const { FITGNN_WAVE_SYNC(); }
 };
 
+// ---- speculative re-costs (single graph) ----
+// 60 % of the selecting wave's time is the re-cost of sets it has just pruned, and 90 % of those are list entries meeting their
+// first marked member.  Which members a list entry will keep is almost always known a few pops early (marks only grow, and a
+// pop marks a handful of nodes out of thousands), so kSpecWaves helper waves of the same workgroup walk AHEAD of the list head:
+// entry p (p = helper id mod kSpecWaves) is pruned against the marks of that moment and, if something was dropped, costed with
+// the very routine the selecting wave would use; (p, kept count, cost) goes to the helper's ring in LDS.  The selecting wave
+// uses it only if the kept COUNT equals its own: the helper saw a subset of the marks, so it kept a superset of the members,
+// and equal counts mean equal sets -- the cost is then the one it would have computed, bit for bit.  A miss costs nothing
+// (it computes, as before); the selecting wave never waits for a helper, and helpers leave when it raises `done`.
+constexpr int kSpecWaves = 2;
+constexpr int kSpecRing = 64;    // ring entries per helper
+constexpr int kSpecAhead = 24;   // helpers work on entries less than this far past the list head
+struct SpecShared {
+    volatile int32_t head;                        // list entries below this index have been popped
+    volatile int32_t done;
+    volatile int32_t tag[kSpecWaves][kSpecRing];  // list index the entry describes (written last)
+    volatile int32_t cnt[kSpecWaves][kSpecRing];
+    volatile double cost[kSpecWaves][kSpecRing];
+};
+struct SpecNone {
+    __device__ __forceinline__ void publish_head(int) const {}
+    __device__ __forceinline__ bool lookup(int, int, double &) const { return false; }
+};
+struct SpecRing {
+    lds_ptr<SpecShared> sh;
+    __device__ __forceinline__ void publish_head(int head) const { if ((threadIdx.x & 63) == 0) sh->head = head; }
+    __device__ __forceinline__ bool lookup(int lp, int m, double &c) const {
+        const int w = lp % kSpecWaves, e = (lp / kSpecWaves) % kSpecRing;
+        if (sh->tag[w][e] != lp) return false;   // volatile: tag, then count and cost (the writer's order reversed)
+        if (sh->cnt[w][e] != m) return false;
+        c = sh->cost[w][e];
+        return true;
+    }
+};
+
+// Helper wave `w` (0-based) of the single-graph kernel; see above.  Reads mem / len of list entries that have not been popped
+// (immutable until then) and the marks; writes only its ring.
+template <class Marks>
+__device__ inline void greedy_speculate(const CostGraph &g, CostLds &lds, lds_ptr<SpecShared> sh, int w, int32_t n_list,
+                                        const int32_t *__restrict__ set_off, const int32_t *mem, const int32_t *len,
+                                        Marks marks, const int32_t *__restrict__ order) {
+    const int lane = threadIdx.x & 63;
+    for (int p = w; p < n_list; p += kSpecWaves) {
+        int h;
+        for (;;) {  // wait until the list head is near (or the selection is over)
+            if (sh->done) return;
+            h = sh->head;
+            if (p < h + kSpecAhead) break;
+            __builtin_amdgcn_s_sleep(8);
+        }
+        if (p <= h) continue;  // popped already, or being popped
+        const int32_t c = order[p];
+        const int off = __builtin_amdgcn_readfirstlane(set_off[c]);
+        const int nc = __builtin_amdgcn_readfirstlane(len[c]);
+        if (nc > fitgnn::kCostTile || nc < 3) continue;  // only sets the staged re-cost handles; a pair cannot be pruned to a set
+        const int32_t v = lane < nc ? mem[off + lane] : -1;
+        const bool keep = v >= 0 && !marks.get(v);
+        const unsigned long long bal = __ballot(keep);
+        const int m = __popcll(bal);
+        if (m == nc || m < 2) continue;  // nothing marked yet / the entry will be dropped
+        if (keep) lds.S[__popcll(bal & ((1ull << lane) - 1ull))] = v;
+        FITGNN_WAVE_SYNC();
+        const double cost = fitgnn::set_cost_wave<true>(g, nullptr, m, lds);
+        FITGNN_WAVE_SYNC();
+        // publish only if the entry is still unpopped: then every read above preceded the selecting wave's changes to it
+        if (sh->head > p) continue;
+        if (lane == 0) {
+            const int e = (p / kSpecWaves) % kSpecRing;
+            sh->cost[w][e] = cost;
+            sh->cnt[w][e] = m;
+            sh->tag[w][e] = p;
+        }
+    }
+}
+
 // The greedy selection of contract_variation_linear (:604-650) over ONE connected component, run by one wavefront.
 // The component's candidates are order[head0 .. head1) (ascending (cost, node id)); node ids, set_off/mem/len/marks
 // are those of the whole (possibly block-diagonal) graph.  Selected sets go to sel_mem[0 .. ) and their END
@@ -345,8 +420,8 @@ struct MarksLds {
 // read through a three-stage software pipeline -- entry head + 2: id requested; head + 1: cost / extent requested; head:
 // complete, its first 64 members in the lanes -- and every request was issued at least one pop earlier; re-inserted sets
 // carry their extent in the heap item.  With the marks in LDS a pop from the list touches global memory only to prefetch.
-template <class Heap, class Marks>
-__device__ inline void greedy_component(const CostGraph &g, CostLds &lds, Heap heap, int32_t head0, int32_t head1,
+template <class Heap, class Marks, class Spec>
+__device__ inline void greedy_component(const CostGraph &g, CostLds &lds, Heap heap, Spec spec, int32_t head0, int32_t head1,
                                         int64_t seq, const int32_t *__restrict__ set_off, int32_t *__restrict__ mem,
                                         int32_t *__restrict__ len, Marks marks,
                                         const int32_t *__restrict__ order, const double *__restrict__ cost0,
@@ -393,6 +468,7 @@ __device__ inline void greedy_component(const CostGraph &g, CostLds &lds, Heap h
             nc = __builtin_amdgcn_readfirstlane(l0);
             mm = m0;
             ++head;
+            spec.publish_head(head - head0);
             if (head < head1) {  // advance the pipeline: every value used here was requested one pop ago or earlier
                 c0 = c1; k0 = k1; o0 = o1; l0 = l1;
                 m0 = lane < l0 ? mem[o0 + lane] : -1;
@@ -461,7 +537,10 @@ __device__ inline void greedy_component(const CostGraph &g, CostLds &lds, Heap h
                 int32_t xm;  // the new set's first 64 members, per lane
                 if (m <= fitgnn::kCostTile) {
                     FITGNN_WAVE_SYNC();
-                    c = fitgnn::set_cost_wave<true>(g, S, m, lds);
+                    if (!(from_list && spec.lookup(head - 1 - head0, m, c))) c = fitgnn::set_cost_wave<true>(g, S, m, lds);
+#ifdef FITGNN_GREEDY_STAMPS
+                    else gdbg[15] += 1;
+#endif
                     xm = lane < m ? lds.S[lane] : -1;
                 } else {
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // the compacted members are read back
@@ -482,6 +561,10 @@ __device__ inline void greedy_component(const CostGraph &g, CostLds &lds, Heap h
                 }
                 GSTAMP(g6);
                 GACC(6, g5, g6);
+#ifdef FITGNN_GREEDY_STAMPS
+                if ((unsigned long long)heap.size() > gdbg[13]) gdbg[13] = heap.size();
+                if (from_list) gdbg[14] += 1;
+#endif
             }
         }
     }
@@ -495,20 +578,34 @@ __host__ __device__ inline size_t greedy_dyn_lds_bytes(int32_t N) {
     return ((greedy_bitmap_words(N) * 4 + 7) / 8) * 8 + greedy_blocks(N) * 12;
 }
 
-__global__ __launch_bounds__(64) void greedy_select_kernel(CostGraph g, int32_t N, const int32_t *__restrict__ set_off,
-                                                           int32_t *__restrict__ mem, int32_t *__restrict__ len,
-                                                           uint8_t *__restrict__ marked,
-                                                           const int32_t *__restrict__ order,
-                                                           const double *__restrict__ cost0, char *__restrict__ heap_glob,
-                                                           int64_t n_reduce, int64_t max_iters,
-                                                           int32_t *__restrict__ sel_off, int32_t *__restrict__ sel_mem,
-                                                           int32_t *__restrict__ sel_count, int32_t state_in_lds) {
-    __shared__ CostLds lds;
+__global__ __launch_bounds__(64 * (1 + kSpecWaves)) void greedy_select_kernel(
+    CostGraph g, int32_t N, const int32_t *__restrict__ set_off, int32_t *mem, int32_t *len, uint8_t *__restrict__ marked,
+    const int32_t *__restrict__ order, const double *__restrict__ cost0, char *__restrict__ heap_glob, int64_t n_reduce,
+    int64_t max_iters, int32_t *__restrict__ sel_off, int32_t *__restrict__ sel_mem, int32_t *__restrict__ sel_count,
+    int32_t state_in_lds) {
+    __shared__ CostLds lds[1 + kSpecWaves];
     __shared__ double h_cost[kHeapLds];
     __shared__ uint32_t h_seq[kHeapLds];
     __shared__ int32_t h_cand[kHeapLds], h_off[kHeapLds], h_len[kHeapLds];
+    __shared__ SpecShared spec_sh;
     extern __shared__ double dyn_lds[];  // state_in_lds: [bitmap | block minima: cost, seq] (greedy_dyn_lds_bytes)
-    if ((threadIdx.x & 63) == 0) sel_off[0] = 0;
+    const int wave = threadIdx.x >> 6;
+    // wave 0 selects; with the marks in LDS the other waves speculate ahead of it, otherwise they leave at once
+    uint32_t *mark_bits = (uint32_t *)dyn_lds;
+    const size_t words = greedy_bitmap_words(N);
+    if (state_in_lds) {
+        for (int i = threadIdx.x; i < (int)words; i += blockDim.x) mark_bits[i] = 0u;
+        for (int i = threadIdx.x; i < kSpecWaves * kSpecRing; i += blockDim.x) spec_sh.tag[i / kSpecRing][i % kSpecRing] = -1;
+        if (threadIdx.x == 0) { spec_sh.head = 0; spec_sh.done = 0; }
+        __syncthreads();  // the only workgroup barrier: nothing below waits for another wave
+        if (wave > 0) {
+            greedy_speculate(g, lds[wave], to_lds(&spec_sh), wave - 1, N, set_off, mem, len, MarksLds{to_lds(mark_bits)}, order);
+            return;
+        }
+    } else if (wave > 0) {
+        return;
+    }
+    if (threadIdx.x == 0) sel_off[0] = 0;
     int32_t ns, pos;
     // slots beyond kHeapLds and, for a graph too large for LDS, the block minima: carved from the heap workspace (32 B / node)
     const size_t n = (size_t)N;
@@ -517,21 +614,20 @@ __global__ __launch_bounds__(64) void greedy_select_kernel(CostGraph g, int32_t 
                               (int32_t *)(heap_glob + 16 * n), (int32_t *)(heap_glob + 20 * n)};
     // re-inserted sets get seq = N, N+1, ... (initial family: seq = node id)
     if (state_in_lds) {
-        uint32_t *mark_bits = (uint32_t *)dyn_lds;
-        const size_t words = greedy_bitmap_words(N);
         double *b_cost = dyn_lds + (words * 4 + 7) / 8;
         uint32_t *b_seq = (uint32_t *)(b_cost + greedy_blocks(N));
-        for (int i = threadIdx.x; i < (int)words; i += 64) mark_bits[i] = 0u;
-        FITGNN_WAVE_SYNC();
-        greedy_component(g, lds, TourHeap<kHeapLds, BlockMinLds>{slots, BlockMinLds{to_lds(b_cost), to_lds(b_seq)}, 0}, 0, N, (int64_t)N,
-                         set_off, mem, len, MarksLds{to_lds(mark_bits)}, order, cost0, n_reduce, max_iters, sel_off + 1, sel_mem, ns, pos);
+        greedy_component(g, lds[0], TourHeap<kHeapLds, BlockMinLds>{slots, BlockMinLds{to_lds(b_cost), to_lds(b_seq)}, 0},
+                         SpecRing{to_lds(&spec_sh)}, 0, N, (int64_t)N, set_off, mem, len, MarksLds{to_lds(mark_bits)}, order, cost0,
+                         n_reduce, max_iters, sel_off + 1, sel_mem, ns, pos);
+        if (threadIdx.x == 0) spec_sh.done = 1;
     } else {
         double *b_cost = (double *)(heap_glob + 24 * n);
         uint32_t *b_seq = (uint32_t *)(b_cost + greedy_blocks(N));
-        greedy_component(g, lds, TourHeap<kHeapLds, BlockMinGlobal>{slots, BlockMinGlobal{b_cost, b_seq}, 0}, 0, N, (int64_t)N, set_off, mem,
-                         len, MarksGlobal{marked}, order, cost0, n_reduce, max_iters, sel_off + 1, sel_mem, ns, pos);
+        greedy_component(g, lds[0], TourHeap<kHeapLds, BlockMinGlobal>{slots, BlockMinGlobal{b_cost, b_seq}, 0}, SpecNone{}, 0, N,
+                         (int64_t)N, set_off, mem, len, MarksGlobal{marked}, order, cost0, n_reduce, max_iters, sel_off + 1, sel_mem, ns,
+                         pos);
     }
-    if ((threadIdx.x & 63) == 0) { sel_count[0] = ns; sel_count[1] = pos; }
+    if (threadIdx.x == 0) { sel_count[0] = ns; sel_count[1] = pos; }
 }
 
 // One wavefront (= one 64-thread workgroup) per connected component of a block-diagonal graph whose components are
@@ -558,7 +654,7 @@ __global__ __launch_bounds__(64) void greedy_select_batch_kernel(CostGraph g, in
     const int64_t max_iters = (int64_t)(e - b) + (int64_t)(set_off[e] - set_off[b]) + 8;
     int32_t ns = 0, pos = 0;
     if (e > b && n_reduce > 0)
-        greedy_component(g, lds, BinHeap<kHeapLdsBatch>{heap_lds, heap_glob + b, 0}, b, e, (int64_t)N, set_off, mem, len,
+        greedy_component(g, lds, BinHeap<kHeapLdsBatch>{heap_lds, heap_glob + b, 0}, SpecNone{}, b, e, (int64_t)N, set_off, mem, len,
                          MarksGlobal{marked}, order, cost0, n_reduce, max_iters, stage_end + b, stage_mem + b, ns, pos);
     if ((threadIdx.x & 63) == 0) { cnt_sets[c] = ns; cnt_mem[c] = pos; gain[c] = budget - n_reduce; }
 }
@@ -786,7 +882,7 @@ extern "C" int fitgnn_greedy_select(const int32_t *rowptr, const int32_t *col, c
     const int state_in_lds = dyn_bytes <= (size_t)kStateLdsBytes ? 1 : 0;
     static std::atomic<uint64_t> lds_done{0};
     if (const int rc = fitgnn_lds_limit_once((const void *)greedy_select_kernel, kStateLdsBytes, lds_done)) return rc;
-    hipLaunchKernelGGL(greedy_select_kernel, dim3(1), dim3(64), state_in_lds ? dyn_bytes : 0, s, g, N, set_off, mem, len, marked, order,
+    hipLaunchKernelGGL(greedy_select_kernel, dim3(1), dim3(64 * (1 + kSpecWaves)), state_in_lds ? dyn_bytes : 0, s, g, N, set_off, mem, len, marked, order,
                        cost0, (char *)heap, n_reduce, max_iters, sel_off, sel_mem, sel_count, state_in_lds);
     return (int)hipGetLastError();
 }
