@@ -368,6 +368,74 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const float *__restri
     if (threadIdx.x == 0) out[0] = red[0];
 }
 
+// ------------------------------------------------------------------------------------------------
+// output head on selected rows: y[rows[i]] = out[rows[i]] Wl^T + bl
+// ------------------------------------------------------------------------------------------------
+// Only the rows that reach the loss (run.py:193-204 keeps out[mask]: a cluster's own train nodes, 2 % of an --extra_node union)
+// need the head's output, and a [rows x H] @ [H x C] product with C = 3..47 is a pass over `out`, not a GEMM.  Wl (padded to
+// H + 4 floats per class) stays in LDS for the block's lifetime; a wave stages kHeadRows gathered rows in LDS (coalesced) and
+// its lanes are (class, part): P = 64 / pow2(C) lanes share a class and take every P-th 16-byte chunk of h (a 16-lane read
+// group then covers consecutive chunks: no bank conflict; the row values are broadcasts), so a 3-class head walks 8 chunks
+// per lane, not 128.  Per (row, class): chunks in ascending order within a part, then the parts by a fixed xor tree.
+constexpr int kHeadRows = 4;
+__global__ __launch_bounds__(256) void head_rows_kernel(const float *__restrict__ out, long ldo, const int64_t *__restrict__ rows,
+                                                        int n_rows, const float *__restrict__ Wl, const float *__restrict__ bl, int C,
+                                                        int H, int P, float *__restrict__ y, long ldy) {
+    extern __shared__ __attribute__((aligned(16))) float head_lds[];
+    const int HP = H + 4;
+    float *w_lds = head_lds;                                              // [C][HP]
+    float *x_lds = head_lds + (size_t)C * HP + (threadIdx.x >> 6) * kHeadRows * H;  // this wave's [kHeadRows][H]
+    const int H4 = H >> 2;
+    for (int i = threadIdx.x; i < C * H4; i += blockDim.x) {
+        const int c = i / H4, h4 = i - c * H4;
+        *reinterpret_cast<float4 *>(w_lds + (size_t)c * HP + 4 * h4) = *reinterpret_cast<const float4 *>(Wl + (size_t)c * H + 4 * h4);
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n_groups = (n_rows + kHeadRows - 1) / kHeadRows;
+    const int per_pass = 64 / P;  // classes per pass over the lanes
+    for (int g = blockIdx.x * 4 + wave; g < n_groups; g += gridDim.x * 4) {
+        const int r0 = g * kHeadRows;
+        for (int i = lane; i < kHeadRows * H4; i += 64) {
+            const int r = i / H4, h4 = i - r * H4;
+            const long src = rows[min(r0 + r, n_rows - 1)];
+            *reinterpret_cast<float4 *>(x_lds + r * H + 4 * h4) = *reinterpret_cast<const float4 *>(out + src * ldo + 4 * h4);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (int c0 = 0; c0 < C; c0 += per_pass) {
+            const int c = c0 + lane / P, part = lane % P;
+            const bool live = c < C;
+            float acc[kHeadRows];
+#pragma unroll
+            for (int r = 0; r < kHeadRows; ++r) acc[r] = 0.f;
+            const float *wr = w_lds + (size_t)(live ? c : 0) * HP;
+            for (int h4 = part; h4 < H4; h4 += P) {
+                const float4 w = *reinterpret_cast<const float4 *>(wr + 4 * h4);
+#pragma unroll
+                for (int r = 0; r < kHeadRows; ++r) {
+                    const float4 x = *reinterpret_cast<const float4 *>(x_lds + r * H + 4 * h4);
+                    acc[r] = fmaf(x.x, w.x, acc[r]);
+                    acc[r] = fmaf(x.y, w.y, acc[r]);
+                    acc[r] = fmaf(x.z, w.z, acc[r]);
+                    acc[r] = fmaf(x.w, w.w, acc[r]);
+                }
+            }
+            for (int off = 1; off < P; off <<= 1) {  // lanes of one class are contiguous: xor stays inside the class
+#pragma unroll
+                for (int r = 0; r < kHeadRows; ++r) acc[r] += __shfl_xor(acc[r], off, 64);
+            }
+            if (live && part == 0) {
+                const float b = bl ? bl[c] : 0.f;
+#pragma unroll
+                for (int r = 0; r < kHeadRows; ++r)
+                    if (r0 + r < n_rows) y[rows[r0 + r] * ldy + c] = acc[r] + b;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();  // the staged rows are rewritten by the next group
+    }
+}
+
 }  // namespace
 
 extern "C" size_t fitgnn_softmax_nll_workspace_bytes(int32_t n) { return (size_t)((n > 0 ? n : 0) + 255) / 256 * sizeof(float) + 16; }
@@ -399,6 +467,30 @@ extern "C" int fitgnn_adam_step_f32(float *param, const float *grad, float *exp_
     hipLaunchKernelGGL(adam_flat_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, (float4 *)param, (const float4 *)grad,
                        (float4 *)exp_avg, (float4 *)exp_avg_sq, n4, lr, beta1, beta2, eps, weight_decay, step);
     hipLaunchKernelGGL(adam_step_advance_kernel, dim3(1), dim3(1), 0, s, step);
+    return (int)hipGetLastError();
+}
+
+extern "C" size_t fitgnn_head_rows_lds_bytes(int32_t H, int32_t C) {
+    if (H <= 0 || C <= 0) return 0;
+    return ((size_t)C * (H + 4) + (size_t)4 * kHeadRows * H) * sizeof(float);
+}
+
+extern "C" int fitgnn_head_rows_f32(const float *out, int64_t ldo, const int64_t *rows, int32_t n_rows, const float *Wl,
+                                    const float *bl, int32_t C, int32_t H, float *y, int64_t ldy, void *stream) {
+    if (n_rows < 0 || C < 1 || H < 4 || (H % 4) != 0 || ldo < H || (ldo % 4) != 0 || ldy < C) return FITGNN_E_BADARG;
+    if (n_rows == 0) return 0;
+    if (!out || !rows || !Wl || !y) return FITGNN_E_BADARG;
+    if ((((uintptr_t)out | (uintptr_t)Wl) % 16) != 0) return FITGNN_E_ALIGN;
+    const size_t lds = fitgnn_head_rows_lds_bytes(H, C);
+    if (lds > 160 * 1024) return FITGNN_E_BADARG;  // the head's weights do not fit LDS: the caller uses a GEMM
+    static std::atomic<uint64_t> lds_done{0};
+    if (const int rc = fitgnn_lds_limit_once((const void *)head_rows_kernel, 160 * 1024, lds_done)) return rc;
+    const int groups = (n_rows + kHeadRows - 1) / kHeadRows;
+    const int blocks = std::min((groups + 3) / 4, 256);
+    int P = 1;  // lanes per class: 64 / pow2(C), at most one per 16-byte chunk of h
+    while (P * 2 * C <= 64 && P * 2 <= H / 4) P *= 2;
+    hipLaunchKernelGGL(head_rows_kernel, dim3(blocks), dim3(256), lds, (hipStream_t)stream, out, (long)ldo, rows, n_rows, Wl, bl, C, H, P, y,
+                       (long)ldy);
     return (int)hipGetLastError();
 }
 

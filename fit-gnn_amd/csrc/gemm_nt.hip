@@ -20,6 +20,18 @@
 #include "common.h"
 #include "fitgnn_hip.h"
 
+// tools/microbench/gemm_probe.hip compiles this file with parts of the kernel removed (which of its streams bounds it)
+#ifdef PROBE_NO_MFMA
+#define PROBE_MFMA(x) asm volatile("" : "+v"(acc[i][jj]) : "v"(fa[i]), "v"(fb[jj]))
+#else
+#define PROBE_MFMA(x) x
+#endif
+#ifdef PROBE_NO_LDSREAD
+#define PROBE_FRAG(dst, src) asm volatile("" : "=v"(dst) : "v"(src))
+#else
+#define PROBE_FRAG(dst, src) dst = *reinterpret_cast<const bf16x8 *>(src)
+#endif
+
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -104,8 +116,12 @@ __global__ __launch_bounds__(128 * WMN, WMN == 2 ? 2 : 1) void gemm_nt_kernel(co
     // hand-placed loads and counted waits, as in gemm_atb.hip (`after`: fake dependence on the conversion of the
     // registers being refilled)
     auto load_row = [&](int k0, int i, uint32_t after) {
+#ifdef PROBE_NO_ALOAD  // every stage reads the same few rows: L2 hits instead of the HBM stream
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(g[i]) : "v"(voff[i] & 0xffffu), "s"(a + k0), "v"(after));
+#else
         const float *base = tile_src + k0;
         asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(g[i]) : "v"(voff[i]), "s"(base), "v"(after));
+#endif
     };
     // Outstanding vector-memory operations when g[i] is converted, oldest first: the rest of the stage held in g, (PRE) the 4
     // DMA instructions of this iteration, the i loads already refilled -- NG - 1 (+ 4) in every case.
@@ -161,28 +177,28 @@ __global__ __launch_bounds__(128 * WMN, WMN == 2 ? 2 : 1) void gemm_nt_kernel(co
         const unsigned char *pb = buf + kOperand + (JT * wn) * kBlk + rd_lane[ks];
         bf16x8 fa[2], fb[JT];
 #pragma unroll
-        for (int jj = 0; jj < JT; ++jj) fb[jj] = *reinterpret_cast<const bf16x8 *>(pb + jj * kBlk);
+        for (int jj = 0; jj < JT; ++jj) PROBE_FRAG(fb[jj], pb + jj * kBlk);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const bf16x8 *>(pa + kPart + i * kBlk);
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int jj = 0; jj < JT; ++jj)
-                acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[jj], acc[i][jj], 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const bf16x8 *>(pa + i * kBlk);
+        for (int i = 0; i < 2; ++i) PROBE_FRAG(fa[i], pa + kPart + i * kBlk);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int jj = 0; jj < JT; ++jj)
-                acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[jj], acc[i][jj], 0, 0, 0);
+                PROBE_MFMA(acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[jj], acc[i][jj], 0, 0, 0));
 #pragma unroll
-        for (int jj = 0; jj < JT; ++jj) fb[jj] = *reinterpret_cast<const bf16x8 *>(pb + kPart + jj * kBlk);
+        for (int i = 0; i < 2; ++i) PROBE_FRAG(fa[i], pa + i * kBlk);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int jj = 0; jj < JT; ++jj)
-                acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[jj], acc[i][jj], 0, 0, 0);
+                PROBE_MFMA(acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[jj], acc[i][jj], 0, 0, 0));
+#pragma unroll
+        for (int jj = 0; jj < JT; ++jj) PROBE_FRAG(fb[jj], pb + kPart + jj * kBlk);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int jj = 0; jj < JT; ++jj)
+                PROBE_MFMA(acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[jj], acc[i][jj], 0, 0, 0));
     };
 
     const int nstage = K / kStage;  // K % 32 == 0 (launcher)
@@ -223,7 +239,11 @@ __global__ __launch_bounds__(128 * WMN, WMN == 2 ? 2 : 1) void gemm_nt_kernel(co
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const long m = m0 + (r & 3) + 8 * (r >> 2);
+#ifdef PROBE_NO_STORE
+                    if (m < R && n < N && acc[i][jj][r] == 12345.678f) c[m * ldc + n] = acc[i][jj][r];
+#else
                     if (m < R && n < N) c[m * ldc + n] = acc[i][jj][r];
+#endif
                 }
             }
         }

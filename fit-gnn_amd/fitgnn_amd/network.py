@@ -105,7 +105,8 @@ class _Base(nn.Module):
         head run on len(rows) rows instead of all of them (same values on those rows: A (h W^T) = (A h) W^T).
         loss_rows (int64 index tensor, optional): the caller's promise that only these rows of the result reach its loss
         (run.py:193-204 keeps out[mask]), i.e. that the gradient it sends back is zero elsewhere; the head's weight and bias
-        gradients are then reduced over those rows alone.  Every row is still evaluated."""
+        gradients are then reduced over those rows alone, and the head itself is evaluated on those rows alone (the result is
+        zero on the others; the GCN layers still compute every row)."""
         L = self.num_layers
         if out_rows is not None:
             return self._embed_and_head_rows(x, edge_index, x_index, out_rows)

@@ -464,6 +464,26 @@ def epilogue_bwd_head_raw(dy, Wl, out, epilogue, p=0.0, seed=0, mask=None, want_
     return dZ, db, dWl
 
 
+def head_rows_supported(out, Wl):
+    H, C = out.shape[1], Wl.shape[0]
+    return (out.is_cuda and out.dtype == torch.float32 and Wl.dtype == torch.float32 and H % 4 == 0 and out.stride(1) == 1
+            and out.stride(0) % 4 == 0 and _lib.lib().fitgnn_head_rows_lds_bytes(H, C) <= 160 * 1024)
+
+
+def head_rows(out, rows, Wl, bl):
+    """y [R, C] with y[rows] = out[rows] @ Wl^T + bl and zeros elsewhere (fitgnn_head_rows_f32)."""
+    _lib.require_cuda(out, rows, Wl, bl)
+    R, H = out.shape
+    C = Wl.shape[0]
+    Wl = _f32c(Wl)
+    y = torch.zeros((R, C), dtype=torch.float32, device=out.device)
+    rows = rows if rows.dtype == torch.int64 else rows.long()
+    _lib.check(_lib.lib().fitgnn_head_rows_f32(_lib.dptr(out), out.stride(0), _lib.dptr(rows.contiguous()), rows.numel(), _lib.dptr(Wl),
+                                               _lib.dptr(None if bl is None else _f32c(bl)), C, H, _lib.dptr(y), C,
+                                               _lib.stream_ptr(out.device)), "fitgnn_head_rows_f32")
+    return y
+
+
 def segment_sum(seg_off, members, X, n_seg):
     """out[s] = sum of X[members[seg_off[s]:seg_off[s+1]]] (fitgnn_segment_sum_f32)."""
     _lib.require_cuda(seg_off, members, X)
@@ -659,7 +679,8 @@ class FusedGCNLayerHead(torch.autograd.Function):
     @staticmethod
     def forward(ctx, X, W, b, Wl, bl, g, p, training, seed, mask, link_in, cfg, loss_rows=None):
         """loss_rows (int64 index tensor, optional): the only rows of y that reach the loss -- the gradient dy the backward
-        receives is zero elsewhere, which lets the head's weight / bias gradients run over those rows alone."""
+        receives is zero elsewhere, which lets the head's weight / bias gradients run over those rows alone, and the head's
+        forward too: y is then zero on every other row."""
         X = _f32c(X)
         ctx.link_in, ctx.cfg, ctx.loss_rows = link_in, cfg, loss_rows
         Hm = mm_xwt(X, W, cfg)
@@ -668,9 +689,13 @@ class FusedGCNLayerHead(torch.autograd.Function):
         if drop:
             epi |= EPI_DROPOUT
         out = spmm_graph(g, Hm, bias=b, epilogue=epi, p=p if drop else 0.0, seed=seed, mask=mask if drop else None, cfg=cfg)
-        y = torch.mm(out, Wl.t())
-        if bl is not None:
-            y = y + bl
+        if loss_rows is not None and head_rows_supported(out, Wl):
+            # rows that never reach the loss are not evaluated (they read as zero): one pass over the kept rows
+            y = head_rows(out, loss_rows, Wl, bl)
+        else:
+            y = torch.mm(out, Wl.t())
+            if bl is not None:
+                y = y + bl
         ctx.save_for_backward(X, W, Wl, out, mask if drop else None)
         ctx.g, ctx.p, ctx.drop, ctx.seed, ctx.has_bias, ctx.has_bl = g, p, drop, seed, b is not None, bl is not None
         return y

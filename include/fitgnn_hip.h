@@ -181,6 +181,14 @@ int fitgnn_gemm_nt_epilogue_bwd_f32(const float *a, int64_t lda, const float *b,
                                     const float *out, float *dZ, uint32_t epilogue, float p_drop, uint64_t seed,
                                     const uint8_t *mask, float *db, void *work, size_t work_bytes, void *stream);
 
+/* The output head lt1 (network.py:34) on selected rows only: y[rows[i]][c] = sum_h out[rows[i]][h] * Wl[c][h] + bl[c]
+ * (bl may be NULL) for i < n_rows, accumulated in ascending h; the other rows of y are not touched.  For the train step, whose
+ * loss keeps out[mask] (run.py:193-204): one pass over the kept rows instead of a [R x H] @ [H x C] product over all of them.
+ * Wl [C x H] contiguous is held in LDS: fitgnn_head_rows_lds_bytes(H, C) must not exceed 160 KiB (else E_BADARG). */
+size_t fitgnn_head_rows_lds_bytes(int32_t H, int32_t C);
+int fitgnn_head_rows_f32(const float *out, int64_t ldo, const int64_t *rows, int32_t n_rows, const float *Wl, const float *bl,
+                         int32_t C, int32_t H, float *y, int64_t ldy, void *stream);
+
 /* out[c] = sum over rows of x[row][c] for a tall matrix with C <= 64 columns (row stride ldx), fixed order: the bias gradient
  * of the output head lt1 (network.py:34), grad_b = sum_rows grad_y.  torch's dim-0 reduction of such a matrix takes 19-50 us. */
 size_t fitgnn_colsum_narrow_workspace_bytes(int32_t n_rows, int32_t C);

@@ -453,6 +453,51 @@ def test_pruned_last_layer_equals_full_evaluation(mods):
     assert abs(lhs - rhs) < 1e-6 * (abs(lhs) + abs(rhs) + 1)
 
 
+@pytest.mark.parametrize("H,C,n_rows", [(512, 3, 1000), (512, 47, 5001), (64, 7, 13), (128, 60, 257), (512, 5, 1)])
+def test_head_on_selected_rows(mods, H, C, n_rows):
+    """fitgnn_head_rows_f32: the output head on the loss rows only equals out[rows] @ Wl^T + bl (fp32 tolerance: a different
+    summation order than the library's GEMM), leaves every other row of y zero, handles a ragged last group and a row stride."""
+    from fitgnn_amd import ops
+
+    torch.manual_seed(H + C)
+    R = 4 * n_rows + 3
+    base = torch.randn(R, H + 4, device="cuda")
+    out = base[:, :H]                                  # row stride H + 4
+    Wl, bl = torch.randn(C, H, device="cuda") / H ** 0.5, torch.randn(C, device="cuda")
+    rows = torch.randperm(R, device="cuda")[:n_rows].sort().values
+    assert ops.head_rows_supported(out, Wl)
+    y = ops.head_rows(out, rows, Wl, bl)
+    ref = (out.double() @ Wl.double().t() + bl.double()).float()
+    assert rel(y.index_select(0, rows), ref.index_select(0, rows)) < 2e-6
+    rest = torch.ones(R, dtype=torch.bool, device="cuda"); rest[rows] = False
+    assert float(y[rest].abs().max()) == 0.0
+    y0 = ops.head_rows(out, rows, Wl, None)
+    assert rel(y0.index_select(0, rows), (ref - bl).index_select(0, rows)) < 2e-6
+
+
+def test_loss_rows_hint_changes_nothing_the_loss_sees(mods):
+    """embed_and_head(loss_rows=...) -- head forward and its weight gradients over the loss rows alone -- gives the same
+    logits on those rows, the same loss and the same gradients as the full evaluation."""
+    network, fnn, gorc = mods
+    batch, _ = _subgraph_batches(seed=9)
+    args = argparse.Namespace(num_layers1=2, layer_name="GCNConv", num_features=24, hidden=64, num_classes=5)
+    torch.manual_seed(3)
+    m = network.Classify_node(args).cuda(); m.dropout_p = 0.0
+    m.train()
+    idx = batch.train_idx
+    grads = []
+    for hint in (None, idx):
+        m.zero_grad()
+        z = m.embed_and_head(batch.x, batch.edge_index, loss_rows=hint)
+        loss = torch.nn.functional.nll_loss(torch.log_softmax(z.index_select(0, idx), 1), batch.y.index_select(0, idx), reduction="sum")
+        loss.backward()
+        grads.append((z.detach().index_select(0, idx), float(loss), [p.grad.clone() for p in m.parameters()]))
+    (z0, l0, g0), (z1, l1, g1) = grads
+    assert rel(z1, z0) < 1e-5 and l1 == pytest.approx(l0, rel=1e-6)
+    for a, b in zip(g1, g0):
+        assert rel(a, b) < 2e-5
+
+
 def test_graph_trainer_reshuffle_option(mods):
     """GraphTrainer(reshuffle=True) re-draws the graph order every epoch (run.py:710 shuffle=True): batches change between
     epochs, every graph is still visited exactly once per epoch, and the loss keeps decreasing."""
