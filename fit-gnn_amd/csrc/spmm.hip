@@ -297,7 +297,7 @@ __global__ __launch_bounds__(kThreads, kBlkLW == 1 ? 7 : 6) void spmm_block_kern
     const float *__restrict__ X, int64_t ldx, float *__restrict__ Y, int64_t ldy, int32_t H,
     const fitgnn_block_t *__restrict__ blocks, int32_t n_blocks, const int32_t *__restrict__ long_rows, int32_t n_slabs,
     const float *__restrict__ bias, uint32_t epi, float p_drop, uint64_t seed_arg, const uint8_t *__restrict__ mask,
-    const int32_t *__restrict__ xrow) {
+    const int32_t *__restrict__ xrow, const int32_t *__restrict__ xcol) {
     using P = Pack<4>;
     using T = float4;
     const uint64_t seed = fitgnn::resolve_seed(seed_arg, epi);
@@ -321,6 +321,9 @@ __global__ __launch_bounds__(kThreads, kBlkLW == 1 ? 7 : 6) void spmm_block_kern
     const bool live = col0 + 4 <= H;
     const float *Xs = X + (live ? col0 : max(H - 4, 0));
     auto src = [&](int r) -> int64_t { return XROW ? (int64_t)xrow[r] : (int64_t)r; };  // operand row of pattern row / column r
+    // operand row of CSR entry e (pattern column c): with the table, xcol[e] = xrow[col[e]] is listed per entry (the caller
+    // builds it once per batch), so a gathered entry costs one dependent load, not two
+    auto ecol = [&](int e, int c) -> int { return (XROW && xcol) ? xcol[e] : (XROW ? xrow[c] : c); };
     const int n_long = min(blk.n_long, kBlkLong);
     const float keep_scale = (epi & FITGNN_EPI_DROPOUT) ? 1.0f / (1.0f - p_drop) : 1.0f;
     const uint32_t thresh = fitgnn::dropout_threshold(p_drop);
@@ -330,7 +333,7 @@ __global__ __launch_bounds__(kThreads, kBlkLW == 1 ? 7 : 6) void spmm_block_kern
 
     // ---- the block's long rows: ids to LDS, their operand rows pinned, this wave's two accumulators and entry cursors ----
     if ((int)threadIdx.x < kBlkLong) s_long[threadIdx.x] = (int)threadIdx.x < n_long ? long_rows[blk.long_off + threadIdx.x] : -1;
-    int my_long[kBlkLW], cur[kBlkLW], end[kBlkLW], pos[kBlkLW], lc[kBlkLW];
+    int my_long[kBlkLW], cur[kBlkLW], end[kBlkLW], pos[kBlkLW], lc[kBlkLW], lcx[kBlkLW];
     float lv[kBlkLW];
     T acc_long[kBlkLW];
 #pragma unroll
@@ -342,6 +345,7 @@ __global__ __launch_bounds__(kThreads, kBlkLW == 1 ? 7 : 6) void spmm_block_kern
         cur[q] = end[q] = 0;
         pos[q] = 64;  // "chunk exhausted": the first use loads entries [cur, cur + 64)
         lc[q] = 0x7fffffff;
+        lcx[q] = 0;
         lv[q] = 0.f;
         if (my_long[q] >= 0) {
             cur[q] = __builtin_amdgcn_readfirstlane(rowptr[my_long[q]]);
@@ -356,7 +360,7 @@ __global__ __launch_bounds__(kThreads, kBlkLW == 1 ? 7 : 6) void spmm_block_kern
 
     // ---- piece prefetch (registers): window rows wave, wave + 4, ...; row pointers; the piece's CSR slice ----
     T pv[4];
-    int p_rp = 0, p_c = 0, p_E0 = 0, p_n = 0;
+    int p_rp = 0, p_c = 0, p_cx = 0, p_E0 = 0;
     float p_v = 0.f;
     int xr_next = 0;  // XROW: lane j < 4 holds the table row of window row wave + 4 j of the NEXT piece to prefetch
     auto fetch_indices = [&](int r0, int r1) {
@@ -382,6 +386,7 @@ __global__ __launch_bounds__(kThreads, kBlkLW == 1 ? 7 : 6) void spmm_block_kern
         if ((int)threadIdx.x < kBlkMeta) {
             const int e = min(E0 + (int)threadIdx.x, blk.nnz_end - 1);
             p_c = col[e];
+            p_cx = (XROW && xcol) ? xcol[e] : p_c;
             p_v = val[e];
         }
         p_E0 = E0;
@@ -398,6 +403,7 @@ __global__ __launch_bounds__(kThreads, kBlkLW == 1 ? 7 : 6) void spmm_block_kern
             if (pos[q] == 64) {
                 const int e = cur[q] + lane;
                 lc[q] = e < end[q] ? col[e] : 0x7fffffff;
+                lcx[q] = (XROW && xcol && e < end[q]) ? xcol[e] : 0;
                 lv[q] = e < end[q] ? val[e] : 0.f;
                 pos[q] = 0;
             }
@@ -410,9 +416,9 @@ __global__ __launch_bounds__(kThreads, kBlkLW == 1 ? 7 : 6) void spmm_block_kern
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     const int kk = min(k + u, last);
-                    const int c = __builtin_amdgcn_readlane(lc[q], kk);
+                    const int64_t c = (XROW && xcol) ? (int64_t)__builtin_amdgcn_readlane(lcx[q], kk) : src(__builtin_amdgcn_readlane(lc[q], kk));
                     w[u] = k + u <= last ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lv[q]), kk)) : 0.f;
-                    x[u] = *reinterpret_cast<const T *>(Xs + src(c) * ldx);
+                    x[u] = *reinterpret_cast<const T *>(Xs + c * ldx);
                 }
 #pragma unroll
                 for (int u = 0; u < 8; ++u) P::fma(acc_long[q], w[u], x[u]);
@@ -439,7 +445,7 @@ __global__ __launch_bounds__(kThreads, kBlkLW == 1 ? 7 : 6) void spmm_block_kern
         if ((int)threadIdx.x < kBlkMeta) {   // entry -> LDS row (window slot, pinned row) or -(operand row + 1): resolved once, by the thread that stages it
             int sl = p_c - r0;
             if ((unsigned)sl >= (unsigned)rows) {
-                sl = -(p_c + 1);
+                sl = -(((XROW && !xcol) ? (int)xrow[p_c] : p_cx) + 1);   // a gathered entry: its operand row
 #pragma unroll
                 for (int i = 0; i < kBlkLong; ++i)
                     if (p_c == lid[i]) sl = kBlkRows + i;
@@ -477,7 +483,7 @@ __global__ __launch_bounds__(kThreads, kBlkLW == 1 ? 7 : 6) void spmm_block_kern
                         my_v = val[base + lane];
                         my_c = c - r0;
                         if ((unsigned)my_c >= (unsigned)rows) {
-                            my_c = -(c + 1);
+                            my_c = -(ecol(base + lane, c) + 1);
 #pragma unroll
                             for (int t = 0; t < kBlkLong; ++t)
                                 if (c == lid[t]) my_c = kBlkRows + t;
@@ -497,10 +503,10 @@ __global__ __launch_bounds__(kThreads, kBlkLW == 1 ? 7 : 6) void spmm_block_kern
                         x0 = s_win[c0 * 64 + lane]; x1 = s_win[c1 * 64 + lane];
                         x2 = s_win[c2 * 64 + lane]; x3 = s_win[c3 * 64 + lane];
                     } else {
-                        if (c0 >= 0) x0 = s_win[c0 * 64 + lane]; else x0 = *reinterpret_cast<const T *>(Xs + src(-(c0 + 1)) * ldx);
-                        if (c1 >= 0) x1 = s_win[c1 * 64 + lane]; else x1 = *reinterpret_cast<const T *>(Xs + src(-(c1 + 1)) * ldx);
-                        if (c2 >= 0) x2 = s_win[c2 * 64 + lane]; else x2 = *reinterpret_cast<const T *>(Xs + src(-(c2 + 1)) * ldx);
-                        if (c3 >= 0) x3 = s_win[c3 * 64 + lane]; else x3 = *reinterpret_cast<const T *>(Xs + src(-(c3 + 1)) * ldx);
+                        if (c0 >= 0) x0 = s_win[c0 * 64 + lane]; else x0 = *reinterpret_cast<const T *>(Xs + (int64_t)(-(c0 + 1)) * ldx);
+                        if (c1 >= 0) x1 = s_win[c1 * 64 + lane]; else x1 = *reinterpret_cast<const T *>(Xs + (int64_t)(-(c1 + 1)) * ldx);
+                        if (c2 >= 0) x2 = s_win[c2 * 64 + lane]; else x2 = *reinterpret_cast<const T *>(Xs + (int64_t)(-(c2 + 1)) * ldx);
+                        if (c3 >= 0) x3 = s_win[c3 * 64 + lane]; else x3 = *reinterpret_cast<const T *>(Xs + (int64_t)(-(c3 + 1)) * ldx);
                     }
                     P::fma(acc, w0, x0); P::fma(acc, w1, x1); P::fma(acc, w2, x2); P::fma(acc, w3, x3);
                 }
@@ -516,6 +522,7 @@ __global__ __launch_bounds__(kThreads, kBlkLW == 1 ? 7 : 6) void spmm_block_kern
                 if (pos[q] == 64) {  // next 64 entries of the row into the lanes
                     const int e = cur[q] + lane;
                     lc[q] = e < end[q] ? col[e] : 0x7fffffff;
+                    lcx[q] = (XROW && xcol && e < end[q]) ? xcol[e] : 0;
                     lv[q] = e < end[q] ? val[e] : 0.f;
                     pos[q] = 0;
                 }
@@ -791,9 +798,10 @@ extern "C" int fitgnn_spmm_csr_f32(const int32_t *rowptr, const int32_t *col, co
 extern "C" int fitgnn_spmm_csr_blocks_f32(const int32_t *rowptr, const int32_t *col, const float *val, const float *X,
                                           int64_t ldx, float *Y, int64_t ldy, int32_t n_rows, int32_t H,
                                           const fitgnn_block_t *blocks, int32_t n_blocks, const int32_t *long_rows,
-                                          const int32_t *xrow, const float *bias, uint32_t epilogue, float p_drop, uint64_t seed,
-                                          const uint8_t *mask, void *stream) {
+                                          const int32_t *xrow, const int32_t *xcol, const float *bias, uint32_t epilogue, float p_drop,
+                                          uint64_t seed, const uint8_t *mask, void *stream) {
     if (n_rows < 0 || H < 0 || n_blocks < 0) return FITGNN_E_BADARG;
+    if (xcol && !xrow) return FITGNN_E_BADARG;
     if (n_rows == 0 || H == 0 || n_blocks == 0) return 0;
     if (!rowptr || !col || !val || !X || !Y || !blocks) return FITGNN_E_BADARG;
     if ((epilogue & FITGNN_EPI_BIAS) && !bias) return FITGNN_E_BADARG;
@@ -805,9 +813,9 @@ extern "C" int fitgnn_spmm_csr_blocks_f32(const int32_t *rowptr, const int32_t *
     const dim3 grid((unsigned)((n_blocks + 7) / 8 * 8) * n_slabs);
     if (xrow)
         hipLaunchKernelGGL(spmm_block_kernel<true>, grid, dim3(kThreads), 0, (hipStream_t)stream, rowptr, col, val, X, ldx, Y, ldy, H, blocks,
-                           n_blocks, long_rows, n_slabs, bias, epilogue, p_drop, seed, mask, xrow);
+                           n_blocks, long_rows, n_slabs, bias, epilogue, p_drop, seed, mask, xrow, xcol);
     else
         hipLaunchKernelGGL(spmm_block_kernel<false>, grid, dim3(kThreads), 0, (hipStream_t)stream, rowptr, col, val, X, ldx, Y, ldy, H, blocks,
-                           n_blocks, long_rows, n_slabs, bias, epilogue, p_drop, seed, mask, xrow);
+                           n_blocks, long_rows, n_slabs, bias, epilogue, p_drop, seed, mask, xrow, xcol);
     return (int)hipGetLastError();
 }

@@ -186,10 +186,11 @@ class _Side:
     `tiles` covers every row.  `small_tiles` / `blocks` / `long_rows` (contiguous windows only) cover the rows once more, split
     by block size: tiles that pack the diagonal blocks of at most a window, and the larger blocks as fitgnn_block_t records
     for the whole-subgraph kernel (fitgnn_spmm_csr_blocks_f32), which reads each of their operand rows once."""
-    __slots__ = ("rowptr", "col", "val", "tiles", "lcol", "win_cols", "n_tiles", "small_tiles", "blocks", "long_rows")
+    __slots__ = ("rowptr", "col", "val", "tiles", "lcol", "win_cols", "n_tiles", "small_tiles", "blocks", "long_rows", "xcol")
 
     def __init__(self, rowptr, col):
         self.rowptr, self.col = rowptr, col
+        self.xcol = None   # (index data_ptr, index[col]): the operand-table row of every entry, cached by ops.spmm_graph
         self.val = self.tiles = self.lcol = self.win_cols = None
         self.small_tiles = self.blocks = self.long_rows = None
         self.n_tiles = 0

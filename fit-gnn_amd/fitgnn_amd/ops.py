@@ -390,10 +390,11 @@ def epilogue_bwd_raw(dOut, out, epilogue, p=0.0, seed=0, mask=None, want_db=True
     return dZ, db
 
 
-def spmm_blocks_raw(rowptr, col, val, blocks, long_rows, X, Y, bias=None, epilogue=0, p=0.0, seed=0, mask=None, cfg=DEFAULT, xrow=None):
+def spmm_blocks_raw(rowptr, col, val, blocks, long_rows, X, Y, bias=None, epilogue=0, p=0.0, seed=0, mask=None, cfg=DEFAULT, xrow=None,
+                    xcol=None):
     """The rows of the listed large diagonal blocks of Y = epilogue(A @ X) through fitgnn_spmm_csr_blocks_f32 (one workgroup
     walks a whole subgraph: every operand row read once)."""
-    _lib.require_cuda(rowptr, col, val, blocks, long_rows, X, Y, bias, mask, xrow)
+    _lib.require_cuda(rowptr, col, val, blocks, long_rows, X, Y, bias, mask, xrow, xcol)
     L = _lib.lib()
     seed, epilogue = _seed_arg(seed, epilogue)
     H = X.shape[1]
@@ -402,7 +403,8 @@ def spmm_blocks_raw(rowptr, col, val, blocks, long_rows, X, Y, bias=None, epilog
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         ev[0].record()
     rc = L.fitgnn_spmm_csr_blocks_f32(_lib.dptr(rowptr), _lib.dptr(col), _lib.dptr(val), _lib.dptr(X), X.stride(0), _lib.dptr(Y), Y.stride(0),
-                                      int(Y.shape[0]), H, _lib.dptr(blocks), int(blocks.shape[0]), _lib.dptr(long_rows), _lib.dptr(xrow), _lib.dptr(bias),
+                                      int(Y.shape[0]), H, _lib.dptr(blocks), int(blocks.shape[0]), _lib.dptr(long_rows), _lib.dptr(xrow),
+                                      _lib.dptr(xcol), _lib.dptr(bias),
                                       epilogue, float(p), seed, _lib.dptr(mask), _lib.stream_ptr(X.device))
     if ev is not None:
         ev[1].record()
@@ -436,7 +438,14 @@ def spmm_graph(g, X, transposed=False, **kw):
     if side.small_tiles.shape[0]:
         spmm_raw(side.rowptr, side.col, side.val, side.small_tiles, Xc, g.n, epilogue=epi, window_rows=g.window_rows, out=Y, cfg=quiet,
                  xrow=xrow, **kw)
-    spmm_blocks_raw(side.rowptr, side.col, side.val, side.blocks, side.long_rows, Xc, Y, epilogue=epi, cfg=quiet, xrow=xrow, **kw)
+    xcol = None
+    if xrow is not None:   # the table row of every CSR entry, listed once per (pattern side, index): see fitgnn_spmm_csr_blocks_f32
+        cached = getattr(side, "xcol", None)
+        if cached is None or cached[0] != xrow.data_ptr():
+            cached = (xrow.data_ptr(), xrow.index_select(0, side.col.long()).contiguous())
+            side.xcol = cached
+        xcol = cached[1]
+    spmm_blocks_raw(side.rowptr, side.col, side.val, side.blocks, side.long_rows, Xc, Y, epilogue=epi, cfg=quiet, xrow=xrow, xcol=xcol, **kw)
     if ev is not None:
         ev[1].record()
         cfg.profile.append((ev[0], ev[1], "tile" if xrow is None else "table"))   # "table": layer 0 on the de-duplicated table

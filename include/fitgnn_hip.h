@@ -86,11 +86,13 @@ typedef struct fitgnn_block {
  * semantics as fitgnn_spmm_csr_f32, same bits as that kernel on the same rows.  A batch is covered by ONE call of each:
  * fitgnn_spmm_csr_f32 over tiles that pack the small blocks, this one over the large blocks.  Requires H % 4 == 0, 16-byte
  * aligned rows (FITGNN_E_BADARG / FITGNN_E_ALIGN otherwise: tile those blocks instead).  xrow (may be NULL): row indirection into a
- * de-duplicated operand table, as in fitgnn_spmm_csr_f32. */
+ * de-duplicated operand table, as in fitgnn_spmm_csr_f32; xcol (may be NULL; needs xrow): xcol[e] = xrow[col[e]] for every CSR
+ * entry, built once per batch -- an entry whose operand row is gathered then costs one dependent load instead of two. */
 int fitgnn_spmm_csr_blocks_f32(const int32_t *rowptr, const int32_t *col, const float *val, const float *X, int64_t ldx,
                                float *Y, int64_t ldy, int32_t n_rows, int32_t H, const fitgnn_block_t *blocks,
-                               int32_t n_blocks, const int32_t *long_rows, const int32_t *xrow, const float *bias,
-                               uint32_t epilogue, float p_drop, uint64_t seed, const uint8_t *mask, void *stream);
+                               int32_t n_blocks, const int32_t *long_rows, const int32_t *xrow, const int32_t *xcol,
+                               const float *bias, uint32_t epilogue, float p_drop, uint64_t seed, const uint8_t *mask,
+                               void *stream);
 
 /* LDS window sizes of the SpMM kernel (rows of the dense operand staged per workgroup): the default used
  * when window_rows == 0, and the largest accepted value.  Tiles should be built with win_rows <= the
