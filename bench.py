@@ -270,6 +270,10 @@ def main():
     spmm_ms = float(np.mean(durs_ms)) if durs_ms else float("nan")
     achieved = bytes_spmm / (spmm_ms * 1e-3) / 1e9
     gather_ms = [a.elapsed_time(b) for a, b, kind in events if kind in ("gather", "table")]   # layer 0's forward on the table
+    # the last layer's backward SpMM: its operand dZ is zero outside the loss rows and is read in compact form through a row
+    # indirection (ops.OpConfig.compact_head_backward) -- every edge aggregated, but 17.6 GB instead of 34.0 GB algorithmic
+    # at S-products; it is NOT in the roofline average above
+    compact_ms = [a.elapsed_time(b) for a, b, kind in events if kind == "compact"]
     # the hand-written MFMA GEMM kernels of the step (secondary: the step's dominant kernel class by time, not by launch):
     # bf16 flops actually issued (three products per fp32 product) / mean HIP-event duration, against the dense bf16 peak
     by_kernel = {}
@@ -312,7 +316,7 @@ def main():
                    if split else "f32 everywhere (library fp32 MFMA products)",
                    "dense_gemm": ("hand-written kernels gemm_nt.hip (X@W^T, dH@W with the previous layer's epilogue backward fused) and "
                                   "gemm_atb.hip (dH^T@X, split-K with a fixed-order sum); layer 0's table zero-padded to K % 32 == 0; "
-                                  "library fp32 GEMM only for the few-column head") if split else "hipBLASLt fp32 MFMA",
+                                  "the few-column head on the loss rows by fitgnn_head_rows_f32 (no library GEMM in the step)") if split else "hipBLASLt fp32 MFMA",
                    "layer0_features": f"de-duplicated table ({info['nodes']} rows) + row indirection in the SpMM" if trainer.dedup
                    else "materialised union rows",
                    "rank0_union_rows": R, "rank0_nnz_prime": batch.nnz,
@@ -325,6 +329,7 @@ def main():
                      "algorithmic_bytes_per_launch": bytes_spmm, "avg_launch_us": spmm_ms * 1e3,
                      "launches_timed": len(durs_ms), "spmm_edges_per_s": batch.nnz / (spmm_ms * 1e-3),
                      "layer0_table_spmm_avg_launch_us": float(np.mean(gather_ms)) * 1e3 if gather_ms else None,
+                     "last_layer_backward_spmm_compact_operand_avg_launch_us": float(np.mean(compact_ms)) * 1e3 if compact_ms else None,
                      "copy_ceiling_GBps": copy_gbs, "frac_of_copy_ceiling": achieved / copy_gbs},
         "gemm_kernels": gemm_summary,
         "loss": loss_final,

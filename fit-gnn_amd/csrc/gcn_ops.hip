@@ -63,7 +63,10 @@ __global__ __launch_bounds__(256) void epilogue_bwd_kernel(const float *__restri
                                                            int32_t chunk_rows, uint32_t epi, float p_drop, uint64_t seed_arg,
                                                            const uint8_t *__restrict__ mask, float *__restrict__ partial,
                                                            const float *__restrict__ dy, const float *__restrict__ Wl,
-                                                           int32_t C, float *__restrict__ partialW) {
+                                                           int32_t C, float *__restrict__ partialW,
+                                                           const int64_t *__restrict__ sel) {
+    // sel (may be NULL): row i of dZ / of the sums is row sel[i] of every INPUT (dy, out, mask, the dropout hash) -- the
+    // compact form over the rows that reach the loss (fitgnn_epilogue_bwd_head_rows_f32)
     const uint64_t seed = fitgnn::resolve_seed(seed_arg, epi);
     constexpr int SLAB = 64 * VEC;
     __shared__ float red[4][SLAB];
@@ -105,7 +108,8 @@ __global__ __launch_bounds__(256) void epilogue_bwd_kernel(const float *__restri
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     const int row = min(row0 + 4 * u, r1 - 1);
-                    dyl[u] = lane < C ? dy[(int64_t)row * C + lane] : 0.f;
+                    const int64_t srow = sel ? sel[row] : (int64_t)row;
+                    dyl[u] = lane < C ? dy[srow * C + lane] : 0.f;
                 }
 #pragma unroll
                 for (int u = 0; u < U; ++u) nz[u] = __ballot((__float_as_uint(dyl[u]) & 0x7fffffffu) != 0u) != 0ull;  // wave-uniform
@@ -113,7 +117,7 @@ __global__ __launch_bounds__(256) void epilogue_bwd_kernel(const float *__restri
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int row = min(row0 + 4 * u, r1 - 1);  // clamped: rows past the chunk are loaded again, never used
-                const int64_t base = (int64_t)row * H + col0;
+                const int64_t base = (sel ? sel[row] : (int64_t)row) * H + col0;
                 if (HEAD && !nz[u]) {
 #pragma unroll
                     for (int i = 0; i < VEC; ++i) o[u][i] = 0.f;
@@ -135,12 +139,13 @@ __global__ __launch_bounds__(256) void epilogue_bwd_kernel(const float *__restri
             for (int u = 0; u < U; ++u) {
                 const int row = row0 + 4 * u;
                 if (row >= r1) break;  // wave-uniform
-                const int64_t base = (int64_t)row * H + col0;
+                const int64_t zbase = (int64_t)row * H + col0;                       // where the row of dZ goes
+                const int64_t base = (sel ? sel[row] : (int64_t)row) * H + col0;      // the row's inputs, its mask / dropout index
                 if (HEAD && !nz[u]) {  // dZ row = +0 (what 0 * dropout' * elu' gives); nothing to add to the sums
                     if (VEC == 4) {
-                        *reinterpret_cast<float4 *>(dZ + base) = make_float4(0.f, 0.f, 0.f, 0.f);
+                        *reinterpret_cast<float4 *>(dZ + zbase) = make_float4(0.f, 0.f, 0.f, 0.f);
                     } else {
-                        dZ[base] = 0.f;
+                        dZ[zbase] = 0.f;
                     }
                     continue;
                 }
@@ -179,9 +184,9 @@ __global__ __launch_bounds__(256) void epilogue_bwd_kernel(const float *__restri
                     sum[i] += d;
                 }
                 if (VEC == 4) {
-                    *reinterpret_cast<float4 *>(dZ + base) = make_float4(g[u][0], g[u][1 % VEC], g[u][2 % VEC], g[u][3 % VEC]);
+                    *reinterpret_cast<float4 *>(dZ + zbase) = make_float4(g[u][0], g[u][1 % VEC], g[u][2 % VEC], g[u][3 % VEC]);
                 } else {
-                    dZ[base] = g[u][0];
+                    dZ[zbase] = g[u][0];
                 }
             }
         }
@@ -566,7 +571,7 @@ bool head_supported(int32_t H, int32_t C, bool with_dWl) {
 
 int epilogue_bwd_launch(const float *dOut, const float *dy, const float *Wl, int32_t C, const float *out, float *dZ,
                         int32_t n_rows, int32_t H, uint32_t epilogue, float p_drop, uint64_t seed, const uint8_t *mask,
-                        float *db, float *dWl, void *work, size_t work_bytes, void *stream) {
+                        float *db, float *dWl, void *work, size_t work_bytes, void *stream, const int64_t *sel = nullptr) {
     if (n_rows < 0 || H < 0) return FITGNN_E_BADARG;
     if (n_rows == 0 || H == 0) return 0;
     const bool head = dOut == nullptr;
@@ -586,7 +591,7 @@ int epilogue_bwd_launch(const float *dOut, const float *dy, const float *Wl, int
     const dim3 grid(vec ? (H + 255) / 256 : (H + 63) / 64, chunks);
 #define FITGNN_LAUNCH_EB(V, HD, CWV)                                                                                     \
     hipLaunchKernelGGL((epilogue_bwd_kernel<V, HD, CWV>), grid, dim3(256), 0, s, dOut, out, dZ, n_rows, H, cr, epilogue,   \
-                       p_drop, seed, mask, partial, dy, Wl, C, partialW)
+                       p_drop, seed, mask, partial, dy, Wl, C, partialW, sel)
     if (!head) {
         if (vec) FITGNN_LAUNCH_EB(4, false, 0); else FITGNN_LAUNCH_EB(1, false, 0);
     } else if (!dWl) {
@@ -619,6 +624,15 @@ extern "C" int fitgnn_epilogue_bwd_head_supported(int32_t H, int32_t C, int32_t 
 extern "C" size_t fitgnn_epilogue_bwd_head_workspace_bytes(int32_t n_rows, int32_t H, int32_t C) {
     if (n_rows <= 0 || H <= 0 || C < 0) return 0;
     return fitgnn_epilogue_bwd_workspace_bytes(n_rows, H) * (size_t)(1 + C);
+}
+
+extern "C" int fitgnn_epilogue_bwd_head_rows_f32(const float *dy, const float *Wl, int32_t C, const float *out, const int64_t *rows,
+                                                 int32_t n_sel, float *dZc, int32_t H, uint32_t epilogue, float p_drop, uint64_t seed,
+                                                 const uint8_t *mask, float *db, float *dWl, void *work, size_t work_bytes,
+                                                 void *stream) {
+    if (n_sel > 0 && !rows) return FITGNN_E_BADARG;
+    return epilogue_bwd_launch(nullptr, dy, Wl, C, out, dZc, n_sel, H, epilogue, p_drop, seed, mask, db, dWl, work, work_bytes, stream,
+                               rows);
 }
 
 extern "C" int fitgnn_epilogue_bwd_head_f32(const float *dy, const float *Wl, int32_t C, const float *out, float *dZ,

@@ -292,7 +292,7 @@ constexpr int kBlkMeta = 128;  // CSR entries of a piece staged in LDS (threads 
 // XROW: operand row r of the pattern lives at X[xrow[r]] (a de-duplicated operand table, as in the tile kernel): the window
 // rows' table indices are fetched one piece ahead of the rows themselves, so the prefetch never waits on an index.
 template <bool XROW>
-__global__ __launch_bounds__(kThreads, kBlkLW == 1 ? 7 : 6) void spmm_block_kernel(
+__global__ __launch_bounds__(kThreads, XROW ? 6 : 7) void spmm_block_kernel(
     const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col, const float *__restrict__ val,
     const float *__restrict__ X, int64_t ldx, float *__restrict__ Y, int64_t ldy, int32_t H,
     const fitgnn_block_t *__restrict__ blocks, int32_t n_blocks, const int32_t *__restrict__ long_rows, int32_t n_slabs,

@@ -38,6 +38,8 @@ SIGNATURES = {
     "fitgnn_epilogue_bwd_head_workspace_bytes": (c_size, [c_i32, c_i32, c_i32]),
     "fitgnn_epilogue_bwd_head_f32": (ctypes.c_int, [ptr, ptr, c_i32, ptr, ptr, c_i32, c_i32, c_u32, c_f32, c_u64, ptr, ptr, ptr,
                                                    ptr, c_size, ptr]),
+    "fitgnn_epilogue_bwd_head_rows_f32": (ctypes.c_int, [ptr, ptr, c_i32, ptr, ptr, c_i32, ptr, c_i32, c_u32, c_f32, c_u64, ptr, ptr,
+                                                        ptr, ptr, c_size, ptr]),
     "fitgnn_spmm_epilogue_bwd_supported": (ctypes.c_int, [c_i32, c_i32, c_i32]),
     "fitgnn_spmm_epilogue_bwd_workspace_bytes": (c_size, [c_i32, c_i32, c_i32]),
     "fitgnn_spmm_epilogue_bwd_f32": (ctypes.c_int, [ptr, ptr, ptr, ptr, c_i32, c_i32, ptr, ptr, ptr, c_i32, ptr, ptr, c_i32, c_i32,

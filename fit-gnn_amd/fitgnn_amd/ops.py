@@ -32,22 +32,28 @@ class OpConfig:
     dedup_gather     layer 0 on a de-duplicated table through the direct-gather SpMM variant.
     split_large_blocks  diagonal blocks larger than the SpMM window through the whole-subgraph kernel (every operand row read
                      once) instead of window-sized tiles (A/B switch; identical bits).
+    compact_head_backward  with a loss_rows promise, the last layer's dZ (zero outside those rows) is produced compactly
+                     [len(loss_rows) + 1 x H] (last row zero) and the backward SpMM reads it through a row indirection: the
+                     [R x H] matrix that is 98 % zeros on an --extra_node union is neither written nor read.  Every edge is
+                     still aggregated (most with the zero row, which stays in cache).
     pad_table_min_k  static feature tables at least this wide whose width is not a multiple of 32 run layer 0's
                      products on a copy zero-padded once (real feature widths: 100, 500, 1 433, 8 415).
     profile / profile_gemm / profile_fused   None, or a list that collects HIP-event pairs around the SpMM / hand-written
                      GEMM / folded-backward launches (recorded on the stream the kernel is launched on).
     seed_bank        None, or a SeedBank supplying device-resident dropout seeds (steps captured in a hipGraph)."""
     __slots__ = ("gemm_precision", "atb_kernel", "nt_kernel", "nt_presplit", "fuse_dx_epilogue", "fold_backward",
-                 "dedup_gather", "pad_table_min_k", "split_large_blocks", "profile", "profile_gemm", "profile_fused", "seed_bank")
+                 "dedup_gather", "pad_table_min_k", "split_large_blocks", "compact_head_backward", "profile", "profile_gemm",
+                 "profile_fused", "seed_bank")
 
     def __init__(self, gemm_precision="high", atb_kernel=True, nt_kernel=True, nt_presplit=True, fuse_dx_epilogue=True,
-                 fold_backward=False, dedup_gather=True, pad_table_min_k=0, split_large_blocks=True, profile=None,
-                 profile_gemm=None, profile_fused=None, seed_bank=None):
+                 fold_backward=False, dedup_gather=True, pad_table_min_k=0, split_large_blocks=True, compact_head_backward=True,
+                 profile=None, profile_gemm=None, profile_fused=None, seed_bank=None):
         if gemm_precision not in ("high", "highest"):
             raise ValueError(f"gemm_precision {gemm_precision!r}: 'high' or 'highest'")
         self.gemm_precision, self.atb_kernel, self.nt_kernel, self.nt_presplit = gemm_precision, atb_kernel, nt_kernel, nt_presplit
         self.fuse_dx_epilogue, self.fold_backward, self.dedup_gather = fuse_dx_epilogue, fold_backward, dedup_gather
         self.pad_table_min_k, self.split_large_blocks = pad_table_min_k, split_large_blocks
+        self.compact_head_backward = compact_head_backward
         self.profile, self.profile_gemm, self.profile_fused, self.seed_bank = profile, profile_gemm, profile_fused, seed_bank
 
     def replace(self, **kw):
@@ -349,7 +355,7 @@ def _f32c(t):
 
 
 def spmm_raw(rowptr, col, val, tiles, X, n_rows, bias=None, epilogue=0, p=0.0, seed=0, mask=None, out=None, window_rows=0,
-             lcol=None, win_cols=None, xrow=None, cfg=DEFAULT):
+             lcol=None, win_cols=None, xrow=None, cfg=DEFAULT, profile_kind=None):
     """Y = epilogue(A @ X) through fitgnn_spmm_csr_f32.  X: [n_cols_of_A, H] f32 contiguous."""
     _lib.require_cuda(rowptr, col, val, tiles, X, bias, mask)
     L = _lib.lib()
@@ -367,7 +373,7 @@ def spmm_raw(rowptr, col, val, tiles, X, n_rows, bias=None, epilogue=0, p=0.0, s
                                _lib.stream_ptr(X.device))
     if ev is not None:
         ev[1].record()
-        cfg.profile.append((ev[0], ev[1], "gather" if (epilogue & _lib.SPMM_GATHER) else "tile"))
+        cfg.profile.append((ev[0], ev[1], profile_kind or ("gather" if (epilogue & _lib.SPMM_GATHER) else "tile")))
     _lib.check(rc, "fitgnn_spmm_csr_f32")
     return Y
 
@@ -429,6 +435,7 @@ def spmm_graph(g, X, transposed=False, **kw):
     out = kw.pop("out", None)
     xrow = kw.pop("xrow", None)
     cfg = kw.pop("cfg", DEFAULT)
+    kind = kw.pop("profile_kind", None)
     Y = out if out is not None else torch.empty((g.n, Xc.shape[1]), dtype=torch.float32, device=Xc.device)
     ev = None
     if cfg.profile is not None:   # ONE event pair around both launches: together they are the SpMM
@@ -448,7 +455,7 @@ def spmm_graph(g, X, transposed=False, **kw):
     spmm_blocks_raw(side.rowptr, side.col, side.val, side.blocks, side.long_rows, Xc, Y, epilogue=epi, cfg=quiet, xrow=xrow, xcol=xcol, **kw)
     if ev is not None:
         ev[1].record()
-        cfg.profile.append((ev[0], ev[1], "tile" if xrow is None else "table"))   # "table": layer 0 on the de-duplicated table
+        cfg.profile.append((ev[0], ev[1], kind or ("tile" if xrow is None else "table")))   # "table": layer 0 on the de-duplicated table
     return Y
 
 
@@ -471,6 +478,47 @@ def epilogue_bwd_head_raw(dy, Wl, out, epilogue, p=0.0, seed=0, mask=None, want_
                                         _lib.dptr(work), wb, _lib.stream_ptr(out.device))
     _lib.check(rc, "fitgnn_epilogue_bwd_head_f32")
     return dZ, db, dWl
+
+
+# zero rows appended to a compact operand: every row outside the selection reads one of them (r % ZERO_ROWS).  ONE zero row would be
+# 16 cache lines requested by all 256 CUs at once -- the L2 channels that hold them serialise (measured: the compact launch no
+# faster than the dense one); 256 rows (512 KB at H = 512) spread over every channel and still sit in L2.
+ZERO_ROWS = 256
+
+
+def epilogue_bwd_head_rows_raw(dy, Wl, out, rows, epilogue, p=0.0, seed=0, mask=None, want_db=True, want_dWl=True):
+    """epilogue_bwd_head_raw over the rows `rows` only, compact: dZc [len(rows) + ZERO_ROWS, H] whose last rows are zero (the
+    operand of every row outside `rows` in the backward SpMM), db, dWl (fitgnn_epilogue_bwd_head_rows_f32)."""
+    _lib.require_cuda(dy, Wl, out, mask, rows)
+    L = _lib.lib()
+    dy, Wl, out = _f32c(dy), _f32c(Wl), _f32c(out)
+    rows = (rows if rows.dtype == torch.int64 else rows.long()).contiguous()
+    n_sel, H = int(rows.numel()), out.shape[1]
+    C = Wl.shape[0]
+    seed, epilogue = _seed_arg(seed, epilogue)
+    dZc = torch.empty((n_sel + ZERO_ROWS, H), dtype=torch.float32, device=out.device)
+    dZc[n_sel:].zero_()
+    db = torch.empty(H, dtype=torch.float32, device=out.device) if want_db else None
+    dWl = torch.empty((C, H), dtype=torch.float32, device=out.device) if want_dWl else None
+    wb = int(L.fitgnn_epilogue_bwd_head_workspace_bytes(n_sel, H, C))
+    work = torch.empty(max(wb, 4), dtype=torch.uint8, device=out.device)
+    rc = L.fitgnn_epilogue_bwd_head_rows_f32(_lib.dptr(dy), _lib.dptr(Wl), C, _lib.dptr(out), _lib.dptr(rows), n_sel, _lib.dptr(dZc), H,
+                                             epilogue, float(p), seed, _lib.dptr(mask), _lib.dptr(db), _lib.dptr(dWl), _lib.dptr(work), wb,
+                                             _lib.stream_ptr(out.device))
+    _lib.check(rc, "fitgnn_epilogue_bwd_head_rows_f32")
+    return dZc, db, dWl
+
+
+def _compact_positions(g, rows):
+    """int32 [g.n]: position of row r in `rows`, len(rows) + r % ZERO_ROWS for the others (a zero row of a compact operand); cached on the graph
+    per index tensor (a trainer passes the same loss_rows every step)."""
+    cache = getattr(g, "_compact_pos", None)
+    if cache is None or cache[0] != rows.data_ptr() or cache[1] != int(rows.numel()):
+        pos = int(rows.numel()) + torch.arange(g.n, dtype=torch.int32, device=rows.device) % ZERO_ROWS
+        pos[rows.long()] = torch.arange(rows.numel(), dtype=torch.int32, device=rows.device)
+        cache = (rows.data_ptr(), int(rows.numel()), pos)
+        g._compact_pos = cache
+    return cache[2]
 
 
 def head_rows_supported(out, Wl):
@@ -557,6 +605,12 @@ def layer_backward(g, out, epi, p, seed, mask, want_db, dOut=None, dy=None, Wl=N
             cfg.profile_fused.append(ev)
         _lib.check(rc, "fitgnn_spmm_epilogue_bwd_f32")
         return dH, db, dWl
+    if head and loss_rows is not None and cfg.compact_head_backward and H % 4 == 0 and loss_rows.numel() > 0:
+        inside = want_dWl and bool(L.fitgnn_epilogue_bwd_head_supported(H, C, 1))
+        dZc, db, dWl = epilogue_bwd_head_rows_raw(dy, Wl, out, loss_rows, epi, p=p, seed=seed, mask=mask, want_db=want_db, want_dWl=inside)
+        if want_dWl and not inside:
+            dWl = mm_at_b(_f32c(dy).index_select(0, loss_rows), out.index_select(0, loss_rows), cfg)
+        return spmm_graph(g, dZc, transposed=True, cfg=cfg, xrow=_compact_positions(g, loss_rows), profile_kind="compact"), db, dWl
     if head:
         inside = want_dWl and bool(L.fitgnn_epilogue_bwd_head_supported(H, C, 1))
         dZ, db, dWl = epilogue_bwd_head_raw(dy, Wl, out, epi, p=p, seed=seed, mask=mask, want_db=want_db, want_dWl=inside)

@@ -240,6 +240,15 @@ int fitgnn_epilogue_bwd_head_f32(const float *dy, const float *Wl, int32_t C, co
                                  int32_t n_rows, int32_t H, uint32_t epilogue, float p_drop, uint64_t seed,
                                  const uint8_t *mask, float *db, float *dWl, void *work, size_t work_bytes, void *stream);
 
+/* The same over selected rows only, in compact form: for i < n_sel, row rows[i] of dy [R x C], out [R x H] and mask (and of
+ * the dropout hash) gives row i of dZc [n_sel x H]; db / dWl sum over those rows.  For a loss that keeps out[mask]
+ * (run.py:193-204) dy is zero on every other row, hence so is dZ there: the caller appends ONE zero row to dZc and hands the
+ * backward SpMM a row indirection (xrow[r] = i for r = rows[i], n_sel elsewhere) instead of a [R x H] matrix that is 98 % zeros.
+ * Workspace: fitgnn_epilogue_bwd_head_workspace_bytes(n_sel, H, C). */
+int fitgnn_epilogue_bwd_head_rows_f32(const float *dy, const float *Wl, int32_t C, const float *out, const int64_t *rows,
+                                      int32_t n_sel, float *dZc, int32_t H, uint32_t epilogue, float p_drop, uint64_t seed,
+                                      const uint8_t *mask, float *db, float *dWl, void *work, size_t work_bytes, void *stream);
+
 /* Backward SpMM with the epilogue backward folded in: dH = A^T dZ with dZ (above) formed while the operand rows are
  * staged, never written to memory; db / dWl reduced over tiles in a fixed order.  (rowptr, col, val, tiles) describe
  * the TRANSPOSED pattern; tiles must have contiguous windows that cover their own rows (fitgnn_amd.csr.make_tiles) and

@@ -496,6 +496,25 @@ def test_loss_rows_hint_changes_nothing_the_loss_sees(mods):
     assert rel(z1, z0) < 1e-5 and l1 == pytest.approx(l0, rel=1e-6)
     for a, b in zip(g1, g0):
         assert rel(a, b) < 2e-5
+    # the same with dropout on (an injected mask, so that both runs drop the same entries) and with the compact backward
+    # switched off: the compact dZ + row indirection is the dense dZ, row for row
+    from fitgnn_amd import ops
+    torch.manual_seed(5)
+    masks = [(torch.rand(batch.n_rows, 64, device="cuda") > 0.5).to(torch.uint8) for _ in range(2)]
+    m.dropout_p = 0.5
+    res = []
+    for compact in (True, False):
+        m.set_op_config(ops.OpConfig(compact_head_backward=compact))
+        m._inject_masks = masks
+        m.zero_grad()
+        z = m.embed_and_head(batch.x, batch.edge_index, loss_rows=idx)
+        loss = torch.nn.functional.nll_loss(torch.log_softmax(z.index_select(0, idx), 1), batch.y.index_select(0, idx), reduction="sum")
+        loss.backward()
+        res.append((float(loss), [p.grad.clone() for p in m.parameters()]))
+    m._inject_masks = None
+    assert res[0][0] == pytest.approx(res[1][0], rel=1e-6)
+    for a, b in zip(res[0][1], res[1][1]):
+        assert rel(a, b) < 2e-5
 
 
 def test_graph_trainer_reshuffle_option(mods):
