@@ -64,9 +64,10 @@ __global__ __launch_bounds__(256) void epilogue_bwd_kernel(const float *__restri
                                                            const uint8_t *__restrict__ mask, float *__restrict__ partial,
                                                            const float *__restrict__ dy, const float *__restrict__ Wl,
                                                            int32_t C, float *__restrict__ partialW,
-                                                           const int64_t *__restrict__ sel) {
-    // sel (may be NULL): row i of dZ / of the sums is row sel[i] of every INPUT (dy, out, mask, the dropout hash) -- the
-    // compact form over the rows that reach the loss (fitgnn_epilogue_bwd_head_rows_f32)
+                                                           const int64_t *__restrict__ sel, int32_t compact_in) {
+    // sel (may be NULL): row i of dZ / of the sums is ORIGINAL row sel[i] -- the compact form over the rows that reach the loss
+    // (fitgnn_epilogue_bwd_head_rows_f32).  The mask / dropout hash is always that row's; dy and out are indexed by it too
+    // unless compact_in (they are then compact themselves: row i)
     const uint64_t seed = fitgnn::resolve_seed(seed_arg, epi);
     constexpr int SLAB = 64 * VEC;
     __shared__ float red[4][SLAB];
@@ -108,7 +109,7 @@ __global__ __launch_bounds__(256) void epilogue_bwd_kernel(const float *__restri
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     const int row = min(row0 + 4 * u, r1 - 1);
-                    const int64_t srow = sel ? sel[row] : (int64_t)row;
+                    const int64_t srow = (sel && !compact_in) ? sel[row] : (int64_t)row;
                     dyl[u] = lane < C ? dy[srow * C + lane] : 0.f;
                 }
 #pragma unroll
@@ -117,7 +118,7 @@ __global__ __launch_bounds__(256) void epilogue_bwd_kernel(const float *__restri
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int row = min(row0 + 4 * u, r1 - 1);  // clamped: rows past the chunk are loaded again, never used
-                const int64_t base = (sel ? sel[row] : (int64_t)row) * H + col0;
+                const int64_t base = ((sel && !compact_in) ? sel[row] : (int64_t)row) * H + col0;
                 if (HEAD && !nz[u]) {
 #pragma unroll
                     for (int i = 0; i < VEC; ++i) o[u][i] = 0.f;
@@ -140,7 +141,7 @@ __global__ __launch_bounds__(256) void epilogue_bwd_kernel(const float *__restri
                 const int row = row0 + 4 * u;
                 if (row >= r1) break;  // wave-uniform
                 const int64_t zbase = (int64_t)row * H + col0;                       // where the row of dZ goes
-                const int64_t base = (sel ? sel[row] : (int64_t)row) * H + col0;      // the row's inputs, its mask / dropout index
+                const int64_t base = (sel ? sel[row] : (int64_t)row) * H + col0;      // the row's mask / dropout index
                 if (HEAD && !nz[u]) {  // dZ row = +0 (what 0 * dropout' * elu' gives); nothing to add to the sums
                     if (VEC == 4) {
                         *reinterpret_cast<float4 *>(dZ + zbase) = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -374,6 +375,43 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const float *__restri
 }
 
 // ------------------------------------------------------------------------------------------------
+// forward epilogue on compact rows: z[i] <- dropout(ELU(z[i] + b)) with the dropout pattern of ORIGINAL row rows[i]
+// ------------------------------------------------------------------------------------------------
+// The arithmetic of the SpMM kernels' store epilogue (spmm.hip finish_row), for a last layer evaluated on the loss rows only
+// (aggregate first, then the dense part on the rows that are kept): row i of the compact matrix is row rows[i] of the
+// union, and its dropout hash / mask entry is that row's.
+__global__ __launch_bounds__(256) void epilogue_fwd_rows_kernel(float *__restrict__ z, int64_t ldz, const int64_t *__restrict__ rows,
+                                                                int32_t n, int32_t H, const float *__restrict__ bias, uint32_t epi,
+                                                                float p_drop, uint64_t seed_arg, const uint8_t *__restrict__ mask) {
+    const uint64_t seed = fitgnn::resolve_seed(seed_arg, epi);
+    const float keep_scale = (epi & FITGNN_EPI_DROPOUT) ? 1.0f / (1.0f - p_drop) : 1.0f;
+    const uint32_t thresh = fitgnn::dropout_threshold(p_drop);
+    const int H4 = H >> 2;
+    const int64_t total = (int64_t)n * H4;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+        const int64_t i = t / H4;
+        const int col0 = (int)(t - i * H4) * 4;
+        const int64_t orow = rows ? rows[i] : i;
+        float4 v = *reinterpret_cast<float4 *>(z + i * ldz + col0);
+        float x[4] = {v.x, v.y, v.z, v.w};
+        const uint64_t idx0 = (uint64_t)orow * (uint64_t)H + (uint64_t)col0;
+        uint64_t bits = 0;
+        if ((epi & FITGNN_EPI_DROPOUT) && !mask) bits = fitgnn::dropout_bits(seed, idx0 >> 2);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float y = x[e] + ((epi & FITGNN_EPI_BIAS) ? bias[col0 + e] : 0.f);
+            if (epi & FITGNN_EPI_ELU) y = y > 0.f ? y : __expf(y) - 1.0f;
+            if (epi & FITGNN_EPI_DROPOUT) {
+                const bool keep = mask ? (mask[idx0 + e] != 0) : fitgnn::dropout_keep(bits, (int)((idx0 + e) & 3), thresh);
+                y = keep ? y * keep_scale : 0.f;
+            }
+            x[e] = y;
+        }
+        *reinterpret_cast<float4 *>(z + i * ldz + col0) = make_float4(x[0], x[1], x[2], x[3]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // output head on selected rows: y[rows[i]] = out[rows[i]] Wl^T + bl
 // ------------------------------------------------------------------------------------------------
 // Only the rows that reach the loss (run.py:193-204 keeps out[mask]: a cluster's own train nodes, 2 % of an --extra_node union)
@@ -385,7 +423,7 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const float *__restri
 constexpr int kHeadRows = 4;
 __global__ __launch_bounds__(256) void head_rows_kernel(const float *__restrict__ out, long ldo, const int64_t *__restrict__ rows,
                                                         int n_rows, const float *__restrict__ Wl, const float *__restrict__ bl, int C,
-                                                        int H, int P, float *__restrict__ y, long ldy) {
+                                                        int H, int P, float *__restrict__ y, long ldy, int out_compact) {
     extern __shared__ __attribute__((aligned(16))) float head_lds[];
     const int HP = H + 4;
     float *w_lds = head_lds;                                              // [C][HP]
@@ -403,7 +441,8 @@ __global__ __launch_bounds__(256) void head_rows_kernel(const float *__restrict_
         const int r0 = g * kHeadRows;
         for (int i = lane; i < kHeadRows * H4; i += 64) {
             const int r = i / H4, h4 = i - r * H4;
-            const long src = rows[min(r0 + r, n_rows - 1)];
+            const int ri = min(r0 + r, n_rows - 1);
+            const long src = out_compact ? (long)ri : (long)rows[ri];   // out_compact: row i of `out` IS the i-th selected row
             *reinterpret_cast<float4 *>(x_lds + r * H + 4 * h4) = *reinterpret_cast<const float4 *>(out + src * ldo + 4 * h4);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -481,7 +520,7 @@ extern "C" size_t fitgnn_head_rows_lds_bytes(int32_t H, int32_t C) {
 }
 
 extern "C" int fitgnn_head_rows_f32(const float *out, int64_t ldo, const int64_t *rows, int32_t n_rows, const float *Wl,
-                                    const float *bl, int32_t C, int32_t H, float *y, int64_t ldy, void *stream) {
+                                    const float *bl, int32_t C, int32_t H, float *y, int64_t ldy, int32_t out_compact, void *stream) {
     if (n_rows < 0 || C < 1 || H < 4 || (H % 4) != 0 || ldo < H || (ldo % 4) != 0 || ldy < C) return FITGNN_E_BADARG;
     if (n_rows == 0) return 0;
     if (!out || !rows || !Wl || !y) return FITGNN_E_BADARG;
@@ -495,7 +534,7 @@ extern "C" int fitgnn_head_rows_f32(const float *out, int64_t ldo, const int64_t
     int P = 1;  // lanes per class: 64 / pow2(C), at most one per 16-byte chunk of h
     while (P * 2 * C <= 64 && P * 2 <= H / 4) P *= 2;
     hipLaunchKernelGGL(head_rows_kernel, dim3(blocks), dim3(256), lds, (hipStream_t)stream, out, (long)ldo, rows, n_rows, Wl, bl, C, H, P, y,
-                       (long)ldy);
+                       (long)ldy, (int)out_compact);
     return (int)hipGetLastError();
 }
 
@@ -571,7 +610,8 @@ bool head_supported(int32_t H, int32_t C, bool with_dWl) {
 
 int epilogue_bwd_launch(const float *dOut, const float *dy, const float *Wl, int32_t C, const float *out, float *dZ,
                         int32_t n_rows, int32_t H, uint32_t epilogue, float p_drop, uint64_t seed, const uint8_t *mask,
-                        float *db, float *dWl, void *work, size_t work_bytes, void *stream, const int64_t *sel = nullptr) {
+                        float *db, float *dWl, void *work, size_t work_bytes, void *stream, const int64_t *sel = nullptr,
+                        int32_t compact_in = 0) {
     if (n_rows < 0 || H < 0) return FITGNN_E_BADARG;
     if (n_rows == 0 || H == 0) return 0;
     const bool head = dOut == nullptr;
@@ -591,7 +631,7 @@ int epilogue_bwd_launch(const float *dOut, const float *dy, const float *Wl, int
     const dim3 grid(vec ? (H + 255) / 256 : (H + 63) / 64, chunks);
 #define FITGNN_LAUNCH_EB(V, HD, CWV)                                                                                     \
     hipLaunchKernelGGL((epilogue_bwd_kernel<V, HD, CWV>), grid, dim3(256), 0, s, dOut, out, dZ, n_rows, H, cr, epilogue,   \
-                       p_drop, seed, mask, partial, dy, Wl, C, partialW, sel)
+                       p_drop, seed, mask, partial, dy, Wl, C, partialW, sel, compact_in)
     if (!head) {
         if (vec) FITGNN_LAUNCH_EB(4, false, 0); else FITGNN_LAUNCH_EB(1, false, 0);
     } else if (!dWl) {
@@ -627,12 +667,27 @@ extern "C" size_t fitgnn_epilogue_bwd_head_workspace_bytes(int32_t n_rows, int32
 }
 
 extern "C" int fitgnn_epilogue_bwd_head_rows_f32(const float *dy, const float *Wl, int32_t C, const float *out, const int64_t *rows,
-                                                 int32_t n_sel, float *dZc, int32_t H, uint32_t epilogue, float p_drop, uint64_t seed,
-                                                 const uint8_t *mask, float *db, float *dWl, void *work, size_t work_bytes,
-                                                 void *stream) {
+                                                 int32_t n_sel, int32_t inputs_compact, float *dZc, int32_t H, uint32_t epilogue,
+                                                 float p_drop, uint64_t seed, const uint8_t *mask, float *db, float *dWl, void *work,
+                                                 size_t work_bytes, void *stream) {
     if (n_sel > 0 && !rows) return FITGNN_E_BADARG;
     return epilogue_bwd_launch(nullptr, dy, Wl, C, out, dZc, n_sel, H, epilogue, p_drop, seed, mask, db, dWl, work, work_bytes, stream,
-                               rows);
+                               rows, inputs_compact ? 1 : 0);
+}
+
+extern "C" int fitgnn_epilogue_fwd_rows_f32(float *z, int64_t ldz, const int64_t *rows, int32_t n, int32_t H, const float *bias,
+                                            uint32_t epilogue, float p_drop, uint64_t seed, const uint8_t *mask, void *stream) {
+    if (n < 0 || H < 4 || (H % 4) != 0 || ldz < H || (ldz % 4) != 0) return FITGNN_E_BADARG;
+    if (n == 0) return 0;
+    if (!z) return FITGNN_E_BADARG;
+    if ((epilogue & FITGNN_EPI_BIAS) && !bias) return FITGNN_E_BADARG;
+    if ((epilogue & FITGNN_EPI_DROPOUT) && !(p_drop >= 0.f && p_drop < 1.f)) return FITGNN_E_BADARG;
+    if (((uintptr_t)z % 16) != 0) return FITGNN_E_ALIGN;
+    const int64_t total = (int64_t)n * (H / 4);
+    const int blocks = (int)std::min<int64_t>((total + 255) / 256, 256 * 16);
+    hipLaunchKernelGGL(epilogue_fwd_rows_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, z, ldz, rows, n, H, bias, epilogue, p_drop,
+                       seed, mask);
+    return (int)hipGetLastError();
 }
 
 extern "C" int fitgnn_epilogue_bwd_head_f32(const float *dy, const float *Wl, int32_t C, const float *out, float *dZ,

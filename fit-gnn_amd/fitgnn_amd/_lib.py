@@ -38,8 +38,8 @@ SIGNATURES = {
     "fitgnn_epilogue_bwd_head_workspace_bytes": (c_size, [c_i32, c_i32, c_i32]),
     "fitgnn_epilogue_bwd_head_f32": (ctypes.c_int, [ptr, ptr, c_i32, ptr, ptr, c_i32, c_i32, c_u32, c_f32, c_u64, ptr, ptr, ptr,
                                                    ptr, c_size, ptr]),
-    "fitgnn_epilogue_bwd_head_rows_f32": (ctypes.c_int, [ptr, ptr, c_i32, ptr, ptr, c_i32, ptr, c_i32, c_u32, c_f32, c_u64, ptr, ptr,
-                                                        ptr, ptr, c_size, ptr]),
+    "fitgnn_epilogue_bwd_head_rows_f32": (ctypes.c_int, [ptr, ptr, c_i32, ptr, ptr, c_i32, c_i32, ptr, c_i32, c_u32, c_f32, c_u64, ptr,
+                                                        ptr, ptr, ptr, c_size, ptr]),
     "fitgnn_spmm_epilogue_bwd_supported": (ctypes.c_int, [c_i32, c_i32, c_i32]),
     "fitgnn_spmm_epilogue_bwd_workspace_bytes": (c_size, [c_i32, c_i32, c_i32]),
     "fitgnn_spmm_epilogue_bwd_f32": (ctypes.c_int, [ptr, ptr, ptr, ptr, c_i32, c_i32, ptr, ptr, ptr, c_i32, ptr, ptr, c_i32, c_i32,
@@ -63,7 +63,8 @@ SIGNATURES = {
                                                        ctypes.c_uint64, ptr, ptr, ptr, c_size, ptr]),
     "fitgnn_colsum_partials_f32": (ctypes.c_int, [ptr, c_i32, c_i32, ptr, ptr]),
     "fitgnn_head_rows_lds_bytes": (c_size, [c_i32, c_i32]),
-    "fitgnn_head_rows_f32": (ctypes.c_int, [ptr, c_i64, ptr, c_i32, ptr, ptr, c_i32, c_i32, ptr, c_i64, ptr]),
+    "fitgnn_head_rows_f32": (ctypes.c_int, [ptr, c_i64, ptr, c_i32, ptr, ptr, c_i32, c_i32, ptr, c_i64, c_i32, ptr]),
+    "fitgnn_epilogue_fwd_rows_f32": (ctypes.c_int, [ptr, c_i64, ptr, c_i32, c_i32, ptr, c_u32, c_f32, c_u64, ptr, ptr]),
     "fitgnn_colsum_narrow_workspace_bytes": (c_size, [c_i32, c_i32]),
     "fitgnn_colsum_narrow_f32": (ctypes.c_int, [ptr, c_i64, c_i32, c_i32, ptr, ptr, c_size, ptr]),
     "fitgnn_spmm_narrow_f32": (ctypes.c_int, [ptr, ptr, ptr, ptr, ptr, c_i32, c_i32, c_f32, ptr, c_f32, ptr, c_f32, ptr]),

@@ -32,6 +32,9 @@ class OpConfig:
     dedup_gather     layer 0 on a de-duplicated table through the direct-gather SpMM variant.
     split_large_blocks  diagonal blocks larger than the SpMM window through the whole-subgraph kernel (every operand row read
                      once) instead of window-sized tiles (A/B switch; identical bits).
+    last_layer_on_loss_rows  with a loss_rows promise, the last GCN layer runs aggregate-first -- A_hat h over EVERY row and edge, then
+                     the dense part (x W^T, bias, ELU, dropout, the head, and in the backward both weight-side products) on the
+                     loss rows alone: (A h) W^T = A (h W^T), and rows outside the loss feed nothing (FusedGCNLastLayerRows).
     compact_head_backward  with a loss_rows promise, the last layer's dZ (zero outside those rows) is produced compactly
                      [len(loss_rows) + 1 x H] (last row zero) and the backward SpMM reads it through a row indirection: the
                      [R x H] matrix that is 98 % zeros on an --extra_node union is neither written nor read.  Every edge is
@@ -42,18 +45,18 @@ class OpConfig:
                      GEMM / folded-backward launches (recorded on the stream the kernel is launched on).
     seed_bank        None, or a SeedBank supplying device-resident dropout seeds (steps captured in a hipGraph)."""
     __slots__ = ("gemm_precision", "atb_kernel", "nt_kernel", "nt_presplit", "fuse_dx_epilogue", "fold_backward",
-                 "dedup_gather", "pad_table_min_k", "split_large_blocks", "compact_head_backward", "profile", "profile_gemm",
+                 "dedup_gather", "pad_table_min_k", "split_large_blocks", "compact_head_backward", "last_layer_on_loss_rows", "profile", "profile_gemm",
                  "profile_fused", "seed_bank")
 
     def __init__(self, gemm_precision="high", atb_kernel=True, nt_kernel=True, nt_presplit=True, fuse_dx_epilogue=True,
                  fold_backward=False, dedup_gather=True, pad_table_min_k=0, split_large_blocks=True, compact_head_backward=True,
-                 profile=None, profile_gemm=None, profile_fused=None, seed_bank=None):
+                 last_layer_on_loss_rows=True, profile=None, profile_gemm=None, profile_fused=None, seed_bank=None):
         if gemm_precision not in ("high", "highest"):
             raise ValueError(f"gemm_precision {gemm_precision!r}: 'high' or 'highest'")
         self.gemm_precision, self.atb_kernel, self.nt_kernel, self.nt_presplit = gemm_precision, atb_kernel, nt_kernel, nt_presplit
         self.fuse_dx_epilogue, self.fold_backward, self.dedup_gather = fuse_dx_epilogue, fold_backward, dedup_gather
         self.pad_table_min_k, self.split_large_blocks = pad_table_min_k, split_large_blocks
-        self.compact_head_backward = compact_head_backward
+        self.compact_head_backward, self.last_layer_on_loss_rows = compact_head_backward, last_layer_on_loss_rows
         self.profile, self.profile_gemm, self.profile_fused, self.seed_bank = profile, profile_gemm, profile_fused, seed_bank
 
     def replace(self, **kw):
@@ -486,9 +489,11 @@ def epilogue_bwd_head_raw(dy, Wl, out, epilogue, p=0.0, seed=0, mask=None, want_
 ZERO_ROWS = 256
 
 
-def epilogue_bwd_head_rows_raw(dy, Wl, out, rows, epilogue, p=0.0, seed=0, mask=None, want_db=True, want_dWl=True):
-    """epilogue_bwd_head_raw over the rows `rows` only, compact: dZc [len(rows) + ZERO_ROWS, H] whose last rows are zero (the
-    operand of every row outside `rows` in the backward SpMM), db, dWl (fitgnn_epilogue_bwd_head_rows_f32)."""
+def epilogue_bwd_head_rows_raw(dy, Wl, out, rows, epilogue, p=0.0, seed=0, mask=None, want_db=True, want_dWl=True, inputs_compact=False,
+                               zero_rows=ZERO_ROWS):
+    """epilogue_bwd_head_raw over the rows `rows` only, compact: dZc [len(rows) + zero_rows, H] whose last rows are zero (the
+    operand of every row outside `rows` in a backward SpMM), db, dWl (fitgnn_epilogue_bwd_head_rows_f32).  inputs_compact: dy and
+    out hold those rows only (row i = original row rows[i])."""
     _lib.require_cuda(dy, Wl, out, mask, rows)
     L = _lib.lib()
     dy, Wl, out = _f32c(dy), _f32c(Wl), _f32c(out)
@@ -496,17 +501,29 @@ def epilogue_bwd_head_rows_raw(dy, Wl, out, rows, epilogue, p=0.0, seed=0, mask=
     n_sel, H = int(rows.numel()), out.shape[1]
     C = Wl.shape[0]
     seed, epilogue = _seed_arg(seed, epilogue)
-    dZc = torch.empty((n_sel + ZERO_ROWS, H), dtype=torch.float32, device=out.device)
-    dZc[n_sel:].zero_()
+    dZc = torch.empty((n_sel + zero_rows, H), dtype=torch.float32, device=out.device)
+    if zero_rows:
+        dZc[n_sel:].zero_()
     db = torch.empty(H, dtype=torch.float32, device=out.device) if want_db else None
     dWl = torch.empty((C, H), dtype=torch.float32, device=out.device) if want_dWl else None
     wb = int(L.fitgnn_epilogue_bwd_head_workspace_bytes(n_sel, H, C))
     work = torch.empty(max(wb, 4), dtype=torch.uint8, device=out.device)
-    rc = L.fitgnn_epilogue_bwd_head_rows_f32(_lib.dptr(dy), _lib.dptr(Wl), C, _lib.dptr(out), _lib.dptr(rows), n_sel, _lib.dptr(dZc), H,
-                                             epilogue, float(p), seed, _lib.dptr(mask), _lib.dptr(db), _lib.dptr(dWl), _lib.dptr(work), wb,
-                                             _lib.stream_ptr(out.device))
+    rc = L.fitgnn_epilogue_bwd_head_rows_f32(_lib.dptr(dy), _lib.dptr(Wl), C, _lib.dptr(out), _lib.dptr(rows), n_sel, 1 if inputs_compact else 0,
+                                             _lib.dptr(dZc), H, epilogue, float(p), seed, _lib.dptr(mask), _lib.dptr(db), _lib.dptr(dWl),
+                                             _lib.dptr(work), wb, _lib.stream_ptr(out.device))
     _lib.check(rc, "fitgnn_epilogue_bwd_head_rows_f32")
     return dZc, db, dWl
+
+
+def epilogue_fwd_rows_(z, rows, bias, epilogue, p=0.0, seed=0, mask=None):
+    """In place: z[i] = dropout(ELU(z[i] + bias)) with the dropout pattern of original row rows[i] (fitgnn_epilogue_fwd_rows_f32)."""
+    _lib.require_cuda(z, rows, bias, mask)
+    seed, epilogue = _seed_arg(seed, epilogue)
+    rows = (rows if rows.dtype == torch.int64 else rows.long()).contiguous()
+    _lib.check(_lib.lib().fitgnn_epilogue_fwd_rows_f32(_lib.dptr(z), z.stride(0), _lib.dptr(rows), z.shape[0], z.shape[1],
+                                                       _lib.dptr(None if bias is None else _f32c(bias)), epilogue, float(p), seed,
+                                                       _lib.dptr(mask), _lib.stream_ptr(z.device)), "fitgnn_epilogue_fwd_rows_f32")
+    return z
 
 
 def _compact_positions(g, rows):
@@ -527,16 +544,18 @@ def head_rows_supported(out, Wl):
             and out.stride(0) % 4 == 0 and _lib.lib().fitgnn_head_rows_lds_bytes(H, C) <= 160 * 1024)
 
 
-def head_rows(out, rows, Wl, bl):
-    """y [R, C] with y[rows] = out[rows] @ Wl^T + bl and zeros elsewhere (fitgnn_head_rows_f32)."""
+def head_rows(out, rows, Wl, bl, n_total=None):
+    """y [R, C] with y[rows] = out[rows] @ Wl^T + bl and zeros elsewhere (fitgnn_head_rows_f32).  n_total: `out` holds the selected
+    rows only (row i = original row rows[i]) and R = n_total."""
     _lib.require_cuda(out, rows, Wl, bl)
-    R, H = out.shape
+    compact = n_total is not None
+    R, H = (int(n_total) if compact else out.shape[0]), out.shape[1]
     C = Wl.shape[0]
     Wl = _f32c(Wl)
     y = torch.zeros((R, C), dtype=torch.float32, device=out.device)
     rows = rows if rows.dtype == torch.int64 else rows.long()
     _lib.check(_lib.lib().fitgnn_head_rows_f32(_lib.dptr(out), out.stride(0), _lib.dptr(rows.contiguous()), rows.numel(), _lib.dptr(Wl),
-                                               _lib.dptr(None if bl is None else _f32c(bl)), C, H, _lib.dptr(y), C,
+                                               _lib.dptr(None if bl is None else _f32c(bl)), C, H, _lib.dptr(y), C, 1 if compact else 0,
                                                _lib.stream_ptr(out.device)), "fitgnn_head_rows_f32")
     return y
 
@@ -779,6 +798,62 @@ class FusedGCNLayerHead(torch.autograd.Function):
         dW = mm_at_b(dH, X, cfg) if ctx.needs_input_grad[1] else None
         dX = _dx_through_link(cfg, ctx.link_in, dH, W, X) if ctx.needs_input_grad[0] else None
         return dX, dW, (db if ctx.has_bias else None), dWl, dbl, None, None, None, None, None, None, None, None
+
+
+class FusedGCNLastLayerRows(torch.autograd.Function):
+    """FusedGCNLayerHead when only `rows` of the result reach the loss (run.py:193-204 keeps out[mask]; with --extra_node 2 % of a
+    union's rows), evaluated aggregate-first:
+        AH = A_hat X                              every row, every edge (the SpMM of the layer)
+        out[rows] = dropout(ELU(AH[rows] W^T + b)) ; y[rows] = out[rows] Wl^T + bl ; y = 0 elsewhere
+    (A X) W^T = A (X W^T) (network.py:31: GCNConv applies the Linear first; same values up to fp32 rounding), and a row outside
+    `rows` feeds nothing downstream, so the dense part -- the layer's GEMM, its epilogue, the head and, in the backward,
+        dW = dZ^T AH[rows],  dAH[rows] = dZ W   (dZ is zero outside `rows`: both products run over len(rows) rows)
+    -- touches len(rows) rows instead of all of them; dX = A_hat^T dAH reads dAH in compact form through a row indirection
+    (every edge aggregated, as in layer_backward's compact path)."""
+
+    @staticmethod
+    def forward(ctx, X, W, b, Wl, bl, g, p, training, seed, mask, rows, cfg):
+        X = _f32c(X)
+        rows = rows if rows.dtype == torch.int64 else rows.long()
+        AH = spmm_graph(g, X, cfg=cfg)                                   # [R, K]
+        AHc = AH.index_select(0, rows)                                   # [n, K]
+        del AH
+        outc = mm_xwt(AHc, W, cfg)                                       # [n, H]
+        if not outc.is_contiguous():
+            outc = outc.contiguous()
+        epi = EPI_ELU | (EPI_BIAS if b is not None else 0)
+        drop = bool(training) and p > 0.0
+        if drop:
+            epi |= EPI_DROPOUT
+        epilogue_fwd_rows_(outc, rows, b, epi, p=p if drop else 0.0, seed=seed, mask=mask if drop else None)
+        y = head_rows(outc, rows, Wl, bl, n_total=g.n)
+        ctx.save_for_backward(W, Wl, AHc, outc, rows, mask if drop else None)
+        ctx.g, ctx.p, ctx.drop, ctx.seed, ctx.has_bias, ctx.has_bl, ctx.cfg = g, p, drop, seed, b is not None, bl is not None, cfg
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        W, Wl, AHc, outc, rows, mask = ctx.saved_tensors
+        g, cfg = ctx.g, ctx.cfg
+        L = _lib.lib()
+        H, C = outc.shape[1], Wl.shape[0]
+        dy_c = _f32c(dy).index_select(0, rows)                           # [n, C]
+        epi = EPI_ELU | (EPI_DROPOUT if ctx.drop else 0)
+        inside = ctx.needs_input_grad[3] and bool(L.fitgnn_epilogue_bwd_head_supported(H, C, 1))
+        dZc, db, dWl = epilogue_bwd_head_rows_raw(dy_c, Wl, outc, rows, epi, p=ctx.p if ctx.drop else 0.0, seed=ctx.seed, mask=mask,
+                                                  want_db=ctx.has_bias, want_dWl=inside, inputs_compact=True, zero_rows=0)
+        if ctx.needs_input_grad[3] and not inside:
+            dWl = mm_at_b(dy_c, outc, cfg)
+        dbl = colsum_narrow(dy_c) if ctx.has_bl and ctx.needs_input_grad[4] else None
+        dW = mm_at_b(dZc, AHc, cfg) if ctx.needs_input_grad[1] else None  # [H, K]
+        dX = None
+        if ctx.needs_input_grad[0]:
+            n, K = AHc.shape
+            dAH = torch.empty((n + ZERO_ROWS, K), dtype=torch.float32, device=dZc.device)
+            dAH[n:].zero_()
+            dAH[:n] = mm_by_transposed(dZc, W, cfg)                      # dZ @ W on the loss rows
+            dX = spmm_graph(g, dAH, transposed=True, cfg=cfg, xrow=_compact_positions(g, rows), profile_kind="compact")
+        return dX, dW, (db if ctx.has_bias else None), dWl, dbl, None, None, None, None, None, None, None
 
 
 class FusedGCNLayerDedup(torch.autograd.Function):

@@ -186,10 +186,11 @@ int fitgnn_gemm_nt_epilogue_bwd_f32(const float *a, int64_t lda, const float *b,
 /* The output head lt1 (network.py:34) on selected rows only: y[rows[i]][c] = sum_h out[rows[i]][h] * Wl[c][h] + bl[c]
  * (bl may be NULL) for i < n_rows, accumulated in ascending h; the other rows of y are not touched.  For the train step, whose
  * loss keeps out[mask] (run.py:193-204): one pass over the kept rows instead of a [R x H] @ [H x C] product over all of them.
- * Wl [C x H] contiguous is held in LDS: fitgnn_head_rows_lds_bytes(H, C) must not exceed 160 KiB (else E_BADARG). */
+ * Wl [C x H] contiguous is held in LDS: fitgnn_head_rows_lds_bytes(H, C) must not exceed 160 KiB (else E_BADARG).
+ * out_compact != 0: `out` holds the selected rows only (row i of out is row rows[i] of y). */
 size_t fitgnn_head_rows_lds_bytes(int32_t H, int32_t C);
 int fitgnn_head_rows_f32(const float *out, int64_t ldo, const int64_t *rows, int32_t n_rows, const float *Wl, const float *bl,
-                         int32_t C, int32_t H, float *y, int64_t ldy, void *stream);
+                         int32_t C, int32_t H, float *y, int64_t ldy, int32_t out_compact, void *stream);
 
 /* out[c] = sum over rows of x[row][c] for a tall matrix with C <= 64 columns (row stride ldx), fixed order: the bias gradient
  * of the output head lt1 (network.py:34), grad_b = sum_rows grad_y.  torch's dim-0 reduction of such a matrix takes 19-50 us. */
@@ -240,14 +241,22 @@ int fitgnn_epilogue_bwd_head_f32(const float *dy, const float *Wl, int32_t C, co
                                  int32_t n_rows, int32_t H, uint32_t epilogue, float p_drop, uint64_t seed,
                                  const uint8_t *mask, float *db, float *dWl, void *work, size_t work_bytes, void *stream);
 
-/* The same over selected rows only, in compact form: for i < n_sel, row rows[i] of dy [R x C], out [R x H] and mask (and of
- * the dropout hash) gives row i of dZc [n_sel x H]; db / dWl sum over those rows.  For a loss that keeps out[mask]
- * (run.py:193-204) dy is zero on every other row, hence so is dZ there: the caller appends ONE zero row to dZc and hands the
- * backward SpMM a row indirection (xrow[r] = i for r = rows[i], n_sel elsewhere) instead of a [R x H] matrix that is 98 % zeros.
+/* The same over selected rows only, in compact form: for i < n_sel, ORIGINAL row rows[i] gives row i of dZc [n_sel x H]; db / dWl
+ * sum over those rows.  The mask entry / dropout hash of row i is that of row rows[i].  inputs_compact == 0: dy [R x C] and
+ * out [R x H] are the full matrices, read at row rows[i]; != 0: they are compact themselves ([n_sel x C], [n_sel x H], row i).
+ * For a loss that keeps out[mask] (run.py:193-204) dy is zero on every other row, hence so is dZ there: the caller appends zero
+ * rows to dZc and hands the backward SpMM a row indirection instead of a [R x H] matrix that is 98 % zeros.
  * Workspace: fitgnn_epilogue_bwd_head_workspace_bytes(n_sel, H, C). */
 int fitgnn_epilogue_bwd_head_rows_f32(const float *dy, const float *Wl, int32_t C, const float *out, const int64_t *rows,
-                                      int32_t n_sel, float *dZc, int32_t H, uint32_t epilogue, float p_drop, uint64_t seed,
-                                      const uint8_t *mask, float *db, float *dWl, void *work, size_t work_bytes, void *stream);
+                                      int32_t n_sel, int32_t inputs_compact, float *dZc, int32_t H, uint32_t epilogue, float p_drop,
+                                      uint64_t seed, const uint8_t *mask, float *db, float *dWl, void *work, size_t work_bytes,
+                                      void *stream);
+
+/* z[i] <- dropout(ELU(z[i] + bias)) for the n rows of a compact matrix z (row stride ldz), row i standing for ORIGINAL row
+ * rows[i] (rows == NULL: i) whose dropout hash / mask entry it takes: the store epilogue of fitgnn_spmm_csr_f32 (same flags,
+ * same arithmetic) for a layer whose dense part is evaluated on selected rows only.  H % 4 == 0, z 16-byte aligned. */
+int fitgnn_epilogue_fwd_rows_f32(float *z, int64_t ldz, const int64_t *rows, int32_t n, int32_t H, const float *bias,
+                                 uint32_t epilogue, float p_drop, uint64_t seed, const uint8_t *mask, void *stream);
 
 /* Backward SpMM with the epilogue backward folded in: dH = A^T dZ with dZ (above) formed while the operand rows are
  * staged, never written to memory; db / dWl reduced over tiles in a fixed order.  (rowptr, col, val, tiles) describe
