@@ -45,6 +45,7 @@ def parse_args():
     ap.add_argument("--hidden", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fp32", action="store_true", help="skip the plain-fp32 re-timing of the step")
+    ap.add_argument("--no-all-rows", action="store_true", help="skip the re-timing with every dense operation over all union rows")
     ap.add_argument("--fold", action="store_true", help="A/B: epilogue backward folded into the transposed SpMM (slower, see DESIGN.md)")
     ap.add_argument("--prune-unused-rows", action="store_true",
                     help="NOT the headline configuration: last layer only on the clusters' own nodes (the extra nodes' outputs "
@@ -199,12 +200,15 @@ def main():
     info["t_batch_csr_s"] = round(time.time() - t5, 2)
     del sub
 
-    def make_trainer(precision, profile=False):
+    def make_trainer(precision, profile=False, loss_rows_only=True):
         margs = argparse.Namespace(num_layers1=2, layer_name="GCNConv", num_features=F, hidden=H, num_classes=C)
         torch.manual_seed(2)  # weight seed; identical on every rank
         model = network.Classify_node(margs).to(device)
         sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
-        cfg = ops.OpConfig(gemm_precision=precision, fold_backward=args.fold, dedup_gather=not args.no_dedup_gather)
+        # loss_rows_only=False: the last layer transform-first with every dense operation over all union rows (the shape of the
+        # reference's step); True (default): aggregate-first, the dense part on the rows that reach the loss -- see DESIGN §0
+        cfg = ops.OpConfig(gemm_precision=precision, fold_backward=args.fold, dedup_gather=not args.no_dedup_gather,
+                           last_layer_on_loss_rows=loss_rows_only, compact_head_backward=loss_rows_only)
         tr = train.GDTrainer(model, batch, lr=0.01, weight_decay=5e-4, dedup=not args.no_dedup,
                              prune_unused_rows=args.prune_unused_rows, op_config=cfg)
         return tr, sd
@@ -260,6 +264,14 @@ def main():
         del tr32
     else:
         loss_final = float(loss)
+    # the same step with the last layer transform-first and every dense operation over all union rows
+    all_rows = None
+    if not args.no_all_rows:
+        tra, _ = make_trainer(args.gemm_precision, loss_rows_only=False)
+        ka = max(3, min(args.steps, 10))
+        dta, loss_a = timed(tra, ka, 2)
+        all_rows = dict(ms_per_step=dta / ka * 1e3, value=edges_per_step_total * ka / dta, steps=ka, loss=float(loss_a))
+        del tra
 
     # SpMM roofline: algorithmic bytes of one launch / mean HIP-event duration of the launches in the timed region
     # (the launches of the LDS-window kernel only: layer 0's forward on the de-duplicated table runs the direct-gather
@@ -307,8 +319,15 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "ms_per_step_fp32": None if fp32 is None else fp32["ms_per_step"],
         "value_fp32": None if fp32 is None else fp32["value"],
+        "ms_per_step_dense_on_all_rows": None if all_rows is None else all_rows["ms_per_step"],
+        "value_dense_on_all_rows": None if all_rows is None else all_rows["value"],
         "config": {"workload": f"{args.workload}: variation_neighborhoods r={r}, extra-node subgraphs, ONE block-diagonal union "
                                f"sharded over the ranks by whole subgraphs, 2-layer GCN hidden {H}, GD step + Adam",
+                   "last_layer": ("aggregate-first: A_hat h over every row and edge, then x W^T / bias / ELU / dropout / head and the backward's "
+                                  "weight-side products on the rows that reach the loss (every cluster's own nodes: "
+                                  f"{int(batch.train_idx.numel())} of {batch.n_rows} union rows); all four SpMMs of the step run over all "
+                                  "nnz' edges; ms_per_step_dense_on_all_rows = the same step transform-first with every dense operation "
+                                  "over all rows"),
                    "parallelism": f"dp{world}", "backend": backend, "ranks_in_group": world if world == 1 else torch.distributed.get_world_size(),
                    "precision": ("f32 storage and accumulation; SpMM, epilogues, loss, Adam in f32; the tall dense products as a "
                                  "3 x bf16 split (hi.hi + hi.lo + lo.hi) on the bf16 MFMA pipe, measured 4-5e-6 relative error vs "

@@ -50,26 +50,86 @@ template <> struct Pack<1> {
     static __device__ __forceinline__ void set(T &a, int, float f) { a = f; }
 };
 
-template <int VEC>
+// The epilogue applied as a row leaves the kernel.  Forward (default): + bias, ELU, dropout.  FITGNN_EPI_BACKWARD: the row is a
+// GRADIENT w.r.t. a fused layer output  o = dropout(ELU(z))  and what is stored is the gradient w.r.t. z,
+//   dZ = keep ? d / (1 - p) * (e > 0 ? 1 : e + 1) : 0,   e = o * (1 - p)
+// (the arithmetic of epilogue_bwd_kernel, gcn_ops.hip; `prev` = o, same dropout hash), with the lane's column sums kept in cs
+// for the bias gradient: a backward SpMM whose result feeds the previous layer never writes the un-transformed gradient.
+struct RowEpilogue {
+    uint32_t epi;
+    float keep_scale, unscale;
+    uint32_t thresh;
+    uint64_t seed;
+    const uint8_t *mask;
+    const float *prev;
+};
+// BWD_OK == false compiles the backward mode out (the whole-subgraph kernel's forward instantiations sit at their register limit)
+template <int VEC, bool BWD_OK = true>
 __device__ __forceinline__ void finish_row(typename Pack<VEC>::T acc, int row, int col0, int H, float *__restrict__ Y,
-                                           int64_t ldy, const float (&bv)[VEC], uint32_t epi, float keep_scale,
-                                           uint32_t thresh, uint64_t seed, const uint8_t *__restrict__ mask) {
+                                           int64_t ldy, const float (&bv)[VEC], const RowEpilogue &E, float (&cs)[VEC],
+                                           const typename Pack<VEC>::T &o) {
+    // o: the row's slice of E.prev, requested by the caller BEFORE it aggregated the row (prev_row): the load rides under the row's
+    // gathers instead of standing between the last FMA and the store
     using P = Pack<VEC>;
     using T = typename P::T;
+    const uint32_t epi = E.epi;
     uint64_t bits = 0;
     const uint64_t idx0 = (uint64_t)row * (uint64_t)H + (uint64_t)col0;
-    if ((epi & FITGNN_EPI_DROPOUT) && !mask) bits = fitgnn::dropout_bits(seed, idx0 >> 2);
+    if ((epi & FITGNN_EPI_DROPOUT) && !E.mask) bits = fitgnn::dropout_bits(E.seed, idx0 >> 2);
+    if (BWD_OK && (epi & FITGNN_EPI_BACKWARD)) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            float d = P::get(acc, i);
+            if (epi & FITGNN_EPI_DROPOUT) {
+                const bool keep = E.mask ? (E.mask[idx0 + i] != 0) : fitgnn::dropout_keep(bits, (int)((idx0 + i) & 3), E.thresh);
+                d = keep ? d * E.keep_scale : 0.f;
+            }
+            if (epi & FITGNN_EPI_ELU) {
+                const float e = P::get(o, i) * E.unscale;
+                d = e > 0.f ? d : d * (e + 1.0f);
+            }
+            P::set(acc, i, d);
+            cs[i] += d;
+        }
+        *reinterpret_cast<T *>(Y + (int64_t)row * ldy + col0) = acc;
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
         float z = P::get(acc, i) + bv[i];
         if (epi & FITGNN_EPI_ELU) z = z > 0.f ? z : __expf(z) - 1.0f;
         if (epi & FITGNN_EPI_DROPOUT) {
-            const bool keep = mask ? (mask[idx0 + i] != 0) : fitgnn::dropout_keep(bits, (int)((idx0 + i) & 3), thresh);
-            z = keep ? z * keep_scale : 0.f;
+            const bool keep = E.mask ? (E.mask[idx0 + i] != 0) : fitgnn::dropout_keep(bits, (int)((idx0 + i) & 3), E.thresh);
+            z = keep ? z * E.keep_scale : 0.f;
         }
         P::set(acc, i, z);
     }
     *reinterpret_cast<T *>(Y + (int64_t)row * ldy + col0) = acc;
+}
+
+template <int VEC, bool BWD_OK = true>
+__device__ __forceinline__ typename Pack<VEC>::T prev_row(const RowEpilogue &E, int row, int col0, int H, bool live) {
+    using T = typename Pack<VEC>::T;
+    if (BWD_OK && (E.epi & FITGNN_EPI_BACKWARD) && live) return *reinterpret_cast<const T *>(E.prev + (uint64_t)row * (uint64_t)H + (uint64_t)col0);
+    return Pack<VEC>::zero();
+}
+
+// Column sums of the rows a workgroup stored (backward epilogue): lanes own columns, the 4 waves are added in a fixed order
+// through LDS (`red`: 4 x 64 x VEC floats, free at this point) into col_part[part * H + column].
+template <int VEC>
+__device__ __forceinline__ void write_col_part(float *red, const float (&cs)[VEC], float *__restrict__ col_part, int64_t part, int H,
+                                               int col0, bool live) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) red[(wave * 64 + lane) * VEC + i] = cs[i];
+    __syncthreads();
+    if (wave == 0 && live) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i)
+            col_part[part * H + col0 + i] = ((red[(0 * 64 + lane) * VEC + i] + red[(1 * 64 + lane) * VEC + i]) + red[(2 * 64 + lane) * VEC + i]) +
+                                            red[(3 * 64 + lane) * VEC + i];
+    }
 }
 
 // B = window rows each wave keeps in flight per pass; MPR = staged CSR entries per window row (8 B each).
@@ -78,12 +138,15 @@ __device__ __forceinline__ void finish_row(typename Pack<VEC>::T acc, int row, i
 // PLAIN: contiguous windows and no row indirection (lcol == win_cols == xrow == NULL), the hidden layers' production case:
 // the column -> operand-row translation folds to an addition and the row loop carries no per-entry scalar branches.
 template <int VEC, int B, int MPR, bool PLAIN>
-__global__ __launch_bounds__(kThreads, (B <= 4 ? 8 : 4)) void spmm_tile_kernel(
+__global__ __launch_bounds__(kThreads, (B <= 4 ? (PLAIN ? 8 : 7) : 4)) void spmm_tile_kernel(
     const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col, const float *__restrict__ val,
     const float *__restrict__ X, int64_t ldx, float *__restrict__ Y, int64_t ldy, int32_t H,
     const fitgnn_tile_t *__restrict__ tiles, int32_t n_tiles, int32_t tiles_per_xcd, int32_t n_slabs, int32_t lds_rows,
     const int32_t *__restrict__ lcol_arg, const int32_t *__restrict__ win_cols_arg, const int32_t *__restrict__ xrow_arg,
-    const float *__restrict__ bias, uint32_t epi, float p_drop, uint64_t seed_arg, const uint8_t *__restrict__ mask) {
+    const float *__restrict__ bias, uint32_t epi, float p_drop, uint64_t seed_arg, const uint8_t *__restrict__ mask,
+    const float *__restrict__ prev, float *__restrict__ col_part, int32_t zero_from_arg) {
+    // zero_from (with xrow): operand rows >= zero_from are rows of zeros and are not loaded (see spmm_block_kernel)
+    const int zero_from = PLAIN ? -1 : zero_from_arg;
     const int32_t *__restrict__ lcol = PLAIN ? nullptr : lcol_arg;
     const int32_t *__restrict__ win_cols = PLAIN ? nullptr : win_cols_arg;
     const int32_t *__restrict__ xrow = PLAIN ? nullptr : xrow_arg;
@@ -150,7 +213,7 @@ __global__ __launch_bounds__(kThreads, (B <= 4 ? 8 : 4)) void spmm_tile_kernel(
                 const int rr = min(r, max(win_rows - 1, 0));
                 const int src = indirect ? __builtin_amdgcn_readlane(wcv, min(p0 + j, 63)) : win_begin + rr;
                 v[j] = P::zero();
-                if (r < win_rows) v[j] = *reinterpret_cast<const T *>(Xs + (int64_t)src * ldx);
+                if (r < win_rows && !(zero_from >= 0 && xrow && src >= zero_from)) v[j] = *reinterpret_cast<const T *>(Xs + (int64_t)src * ldx);
             }
             if (p0 == 0) {  // first pass: put the CSR slice in flight behind the window loads
                 if ((int)threadIdx.x <= rp_rows) rpv = rowptr[tile.row_begin + threadIdx.x];
@@ -182,6 +245,10 @@ __global__ __launch_bounds__(kThreads, (B <= 4 ? 8 : 4)) void spmm_tile_kernel(
 
     const float keep_scale = (epi & FITGNN_EPI_DROPOUT) ? 1.0f / (1.0f - p_drop) : 1.0f;
     const uint32_t thresh = fitgnn::dropout_threshold(p_drop);
+    const RowEpilogue rowepi{epi, keep_scale, (epi & FITGNN_EPI_DROPOUT) ? 1.0f - p_drop : 1.0f, thresh, seed, mask, prev};
+    float cs[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) cs[i] = 0.f;
     float bv[VEC];
 #pragma unroll
     for (int i = 0; i < VEC; ++i) bv[i] = ((epi & FITGNN_EPI_BIAS) && live) ? bias[col0 + i] : 0.f;
@@ -193,7 +260,13 @@ __global__ __launch_bounds__(kThreads, (B <= 4 ? 8 : 4)) void spmm_tile_kernel(
         return listed ? win_cols[win_begin + c] : win_begin + c;      // staged slot beyond a clamped LDS window
     };
     auto xsrc = [&](int g) -> int64_t { return xrow ? xrow[g] : g; };
+    auto gather = [&](int g) -> T {   // operand row of pattern column g, from memory -- unless it is one of the zero rows
+        const int64_t sr = xsrc(g);
+        if (zero_from >= 0 && xrow && sr >= zero_from) return P::zero();
+        return *reinterpret_cast<const T *>(Xs + sr * ldx);
+    };
     for (int row = tile.row_begin + wave; row < tile.row_end; row += kWaves) {
+        const T o_prev = prev_row<VEC>(rowepi, row, col0, H, live);
         const int lr = row - tile.row_begin;
         int e0, e1;
         if (lr < rp_rows) { e0 = s_rp[lr]; e1 = s_rp[lr + 1]; } else { e0 = rowptr[row]; e1 = rowptr[row + 1]; }
@@ -221,7 +294,7 @@ __global__ __launch_bounds__(kThreads, (B <= 4 ? 8 : 4)) void spmm_tile_kernel(
                     for (int u = 0; u < 8; ++u) {
                         const int c = __builtin_amdgcn_readlane(my_c, k + u) - slot_off;
                         w[u] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_v), k + u));
-                        x[u] = *reinterpret_cast<const T *>(Xs + xsrc(gcol(c)) * ldx);
+                        x[u] = gather(gcol(c));
                     }
 #pragma unroll
                     for (int u = 0; u < 8; ++u) P::fma(acc, w[u], x[u]);
@@ -249,16 +322,18 @@ __global__ __launch_bounds__(kThreads, (B <= 4 ? 8 : 4)) void spmm_tile_kernel(
                     x2 = lds[c2 * 64 + lane]; x3 = lds[c3 * 64 + lane];
                 } else {
                     const int g0 = gcol(c0), g1 = gcol(c1), g2 = gcol(c2), g3 = gcol(c3);
-                    if (in0) x0 = lds[c0 * 64 + lane]; else x0 = *reinterpret_cast<const T *>(Xs + xsrc(g0) * ldx);
-                    if (in1) x1 = lds[c1 * 64 + lane]; else x1 = *reinterpret_cast<const T *>(Xs + xsrc(g1) * ldx);
-                    if (in2) x2 = lds[c2 * 64 + lane]; else x2 = *reinterpret_cast<const T *>(Xs + xsrc(g2) * ldx);
-                    if (in3) x3 = lds[c3 * 64 + lane]; else x3 = *reinterpret_cast<const T *>(Xs + xsrc(g3) * ldx);
+                    if (in0) x0 = lds[c0 * 64 + lane]; else x0 = gather(g0);
+                    if (in1) x1 = lds[c1 * 64 + lane]; else x1 = gather(g1);
+                    if (in2) x2 = lds[c2 * 64 + lane]; else x2 = gather(g2);
+                    if (in3) x3 = lds[c3 * 64 + lane]; else x3 = gather(g3);
                 }
                 P::fma(acc, w0, x0); P::fma(acc, w1, x1); P::fma(acc, w2, x2); P::fma(acc, w3, x3);
             }
         }
-        if (live) finish_row<VEC>(acc, row, col0, H, Y, ldy, bv, epi, keep_scale, thresh, seed, mask);
+        if (live) finish_row<VEC>(acc, row, col0, H, Y, ldy, bv, rowepi, cs, o_prev);
     }
+    if ((epi & FITGNN_EPI_BACKWARD) && col_part)   // wave-uniform, every wave of the workgroup gets here
+        write_col_part<VEC>(reinterpret_cast<float *>(lds_raw), cs, col_part, t, H, col0, live);
 }
 
 
@@ -291,17 +366,23 @@ constexpr int kBlkMeta = 128;  // CSR entries of a piece staged in LDS (threads 
 
 // XROW: operand row r of the pattern lives at X[xrow[r]] (a de-duplicated operand table, as in the tile kernel): the window
 // rows' table indices are fetched one piece ahead of the rows themselves, so the prefetch never waits on an index.
-template <bool XROW>
-__global__ __launch_bounds__(kThreads, XROW ? 6 : 7) void spmm_block_kernel(
+template <bool XROW, bool BWD>
+__global__ __launch_bounds__(kThreads, (XROW && BWD) ? 5 : (XROW || BWD) ? 6 : 7) void spmm_block_kernel(
     const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col, const float *__restrict__ val,
     const float *__restrict__ X, int64_t ldx, float *__restrict__ Y, int64_t ldy, int32_t H,
     const fitgnn_block_t *__restrict__ blocks, int32_t n_blocks, const int32_t *__restrict__ long_rows, int32_t n_slabs,
     const float *__restrict__ bias, uint32_t epi, float p_drop, uint64_t seed_arg, const uint8_t *__restrict__ mask,
-    const int32_t *__restrict__ xrow, const int32_t *__restrict__ xcol) {
+    const int32_t *__restrict__ xrow, const int32_t *__restrict__ xcol, const float *__restrict__ prev, float *__restrict__ col_part,
+    int32_t zero_from) {
+    // zero_from (XROW): operand rows >= zero_from are rows of zeros (the tail of a compact operand, ops.ZERO_ROWS): they are not
+    // loaded -- as window rows they are staged as zeros, as gathered entries they read the LDS slot kZeroSlot -- so an operand
+    // that is zero on most rows costs LDS reads and FMAs, not a memory round trip per gathered entry (measured on the compact
+    // backward of S-products: the kernel was latency-bound on those gathers at 2.6 TB/s of stores; a plain fill reaches 6.8)
     using P = Pack<4>;
     using T = float4;
+    constexpr int kZeroSlot = kBlkRows + kBlkLong;
     const uint64_t seed = fitgnn::resolve_seed(seed_arg, epi);
-    __shared__ T s_win[(kBlkRows + kBlkLong) * 64];  // piece window, then the pinned rows
+    __shared__ T s_win[(kBlkRows + kBlkLong + 1) * 64];  // piece window, then the pinned rows, then one row of zeros
     __shared__ int32_t s_rp[kBlkRows + 4];
     __shared__ int32_t s_col[kBlkMeta];
     __shared__ float s_val[kBlkMeta];
@@ -327,12 +408,20 @@ __global__ __launch_bounds__(kThreads, XROW ? 6 : 7) void spmm_block_kernel(
     const int n_long = min(blk.n_long, kBlkLong);
     const float keep_scale = (epi & FITGNN_EPI_DROPOUT) ? 1.0f / (1.0f - p_drop) : 1.0f;
     const uint32_t thresh = fitgnn::dropout_threshold(p_drop);
+    const RowEpilogue rowepi{BWD ? epi : (epi & ~FITGNN_EPI_BACKWARD), keep_scale, (epi & FITGNN_EPI_DROPOUT) ? 1.0f - p_drop : 1.0f, thresh,
+                             seed, mask, BWD ? prev : nullptr};
+    float cs[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) cs[i] = 0.f;
     float bv[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) bv[i] = ((epi & FITGNN_EPI_BIAS) && live) ? bias[col0 + i] : 0.f;
 
     // ---- the block's long rows: ids to LDS, their operand rows pinned, this wave's two accumulators and entry cursors ----
     if ((int)threadIdx.x < kBlkLong) s_long[threadIdx.x] = (int)threadIdx.x < n_long ? long_rows[blk.long_off + threadIdx.x] : -1;
+    if (XROW && (int)threadIdx.x < 64) s_win[kZeroSlot * 64 + threadIdx.x] = P::zero();
+    const bool has_zero = XROW && zero_from >= 0;
+    auto is_zero_row = [&](int64_t opr) { return has_zero && opr >= (int64_t)zero_from; };
     int my_long[kBlkLW], cur[kBlkLW], end[kBlkLW], pos[kBlkLW], lc[kBlkLW], lcx[kBlkLW];
     float lv[kBlkLW];
     T acc_long[kBlkLW];
@@ -350,7 +439,8 @@ __global__ __launch_bounds__(kThreads, XROW ? 6 : 7) void spmm_block_kernel(
         if (my_long[q] >= 0) {
             cur[q] = __builtin_amdgcn_readfirstlane(rowptr[my_long[q]]);
             end[q] = __builtin_amdgcn_readfirstlane(rowptr[my_long[q] + 1]);
-            s_win[(kBlkRows + slot) * 64 + lane] = *reinterpret_cast<const T *>(Xs + src(my_long[q]) * ldx);
+            const int64_t lr_src = src(my_long[q]);
+            s_win[(kBlkRows + slot) * 64 + lane] = is_zero_row(lr_src) ? P::zero() : *reinterpret_cast<const T *>(Xs + lr_src * ldx);
         }
     }
     __syncthreads();
@@ -376,7 +466,7 @@ __global__ __launch_bounds__(kThreads, XROW ? 6 : 7) void spmm_block_kernel(
             const int r = r0 + wave + j * kWaves;
             pv[j] = P::zero();
             const int64_t sr = XROW ? (int64_t)__builtin_amdgcn_readlane(xr, j) : (int64_t)r;
-            if (r < r1) pv[j] = *reinterpret_cast<const T *>(Xs + sr * ldx);
+            if (r < r1 && !is_zero_row(sr)) pv[j] = *reinterpret_cast<const T *>(Xs + sr * ldx);   // wave-uniform
         }
         if (XROW) fetch_indices(r1, min(r1 + kBlkRows, blk.row_end));  // the piece after: its rows are requested next time round
         p_rp = 0;
@@ -418,7 +508,7 @@ __global__ __launch_bounds__(kThreads, XROW ? 6 : 7) void spmm_block_kernel(
                     const int kk = min(k + u, last);
                     const int64_t c = (XROW && xcol) ? (int64_t)__builtin_amdgcn_readlane(lcx[q], kk) : src(__builtin_amdgcn_readlane(lc[q], kk));
                     w[u] = k + u <= last ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lv[q]), kk)) : 0.f;
-                    x[u] = *reinterpret_cast<const T *>(Xs + c * ldx);
+                    x[u] = is_zero_row(c) ? P::zero() : *reinterpret_cast<const T *>(Xs + c * ldx);   // wave-uniform
                 }
 #pragma unroll
                 for (int u = 0; u < 8; ++u) P::fma(acc_long[q], w[u], x[u]);
@@ -445,7 +535,8 @@ __global__ __launch_bounds__(kThreads, XROW ? 6 : 7) void spmm_block_kernel(
         if ((int)threadIdx.x < kBlkMeta) {   // entry -> LDS row (window slot, pinned row) or -(operand row + 1): resolved once, by the thread that stages it
             int sl = p_c - r0;
             if ((unsigned)sl >= (unsigned)rows) {
-                sl = -(((XROW && !xcol) ? (int)xrow[p_c] : p_cx) + 1);   // a gathered entry: its operand row
+                const int opr = (XROW && !xcol) ? (int)xrow[p_c] : p_cx;   // a gathered entry: its operand row
+                sl = is_zero_row(opr) ? kZeroSlot : -(opr + 1);
 #pragma unroll
                 for (int i = 0; i < kBlkLong; ++i)
                     if (p_c == lid[i]) sl = kBlkRows + i;
@@ -467,6 +558,7 @@ __global__ __launch_bounds__(kThreads, XROW ? 6 : 7) void spmm_block_kernel(
 #pragma unroll
             for (int i = 0; i < kBlkLong; ++i) is_long |= (row == lid[i]);
             if (is_long) continue;  // wave-uniform
+            const T o_prev = prev_row<4, BWD>(rowepi, row, col0, H, live);
             const int lr = row - r0;
             const int e0 = __builtin_amdgcn_readfirstlane(s_rp[lr]);
             const int e1 = __builtin_amdgcn_readfirstlane(s_rp[lr + 1]);
@@ -483,7 +575,8 @@ __global__ __launch_bounds__(kThreads, XROW ? 6 : 7) void spmm_block_kernel(
                         my_v = val[base + lane];
                         my_c = c - r0;
                         if ((unsigned)my_c >= (unsigned)rows) {
-                            my_c = -(ecol(base + lane, c) + 1);
+                            const int opr = ecol(base + lane, c);
+                            my_c = is_zero_row(opr) ? kZeroSlot : -(opr + 1);
 #pragma unroll
                             for (int t = 0; t < kBlkLong; ++t)
                                 if (c == lid[t]) my_c = kBlkRows + t;
@@ -511,7 +604,7 @@ __global__ __launch_bounds__(kThreads, XROW ? 6 : 7) void spmm_block_kernel(
                     P::fma(acc, w0, x0); P::fma(acc, w1, x1); P::fma(acc, w2, x2); P::fma(acc, w3, x3);
                 }
             }
-            if (live) finish_row<4>(acc, row, col0, H, Y, ldy, bv, epi, keep_scale, thresh, seed, mask);
+            if (live) finish_row<4, BWD>(acc, row, col0, H, Y, ldy, bv, rowepi, cs, o_prev);
         }
 
         // ---- this wave's long rows: the entries whose operand rows sit in this piece (columns < r1), in CSR order ----
@@ -552,9 +645,11 @@ __global__ __launch_bounds__(kThreads, XROW ? 6 : 7) void spmm_block_kernel(
 #pragma unroll
     for (int q = 0; q < kBlkLW; ++q) {
         if (my_long[q] < 0) continue;
+        const T o_prev = prev_row<4, BWD>(rowepi, my_long[q], col0, H, live);
         gather_long(q, 0x7fffffff);
-        if (live) finish_row<4>(acc_long[q], my_long[q], col0, H, Y, ldy, bv, epi, keep_scale, thresh, seed, mask);
+        if (live) finish_row<4, BWD>(acc_long[q], my_long[q], col0, H, Y, ldy, bv, rowepi, cs, o_prev);
     }
+    if (BWD && col_part) write_col_part<4>(reinterpret_cast<float *>(s_win), cs, col_part, b, H, col0, live);
 }
 
 // Direct-gather variant for very sparse batches (few non-zeros per row, e.g. PubMed-like subgraphs with
@@ -639,6 +734,10 @@ __global__ __launch_bounds__(kThreads) void spmm_gather_kernel(
     const bool live = col0 + VEC <= H;
     const float keep_scale = (epi & FITGNN_EPI_DROPOUT) ? 1.0f / (1.0f - p_drop) : 1.0f;
     const uint32_t thresh = fitgnn::dropout_threshold(p_drop);
+    const RowEpilogue rowepi{epi & ~FITGNN_EPI_BACKWARD, keep_scale, 1.0f, thresh, seed, mask, nullptr};  // forward epilogues only (launcher)
+    float cs[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) cs[i] = 0.f;
     // lanes past the last column (only when H is not a multiple of the slab) load from the last valid
     // column group instead of being branched around: keeps every load unconditional (static vmcnt counts)
     const float *Xs = X + (live ? col0 : max(H - VEC, 0));
@@ -670,14 +769,14 @@ __global__ __launch_bounds__(kThreads) void spmm_gather_kernel(
         for (; i + 1 < nrows; i += 2) {
             issue_row<VEC>(qb, i + 1, rp_v, E0, my_c, my_v, Xs, ldx, live);
             const T a0 = consume_row<VEC>(qa, my_c, my_v, Xs, ldx, live);
-            if (live) finish_row<VEC>(a0, r_lo + i, col0, H, Y, ldy, bv, epi, keep_scale, thresh, seed, mask);
+            if (live) finish_row<VEC>(a0, r_lo + i, col0, H, Y, ldy, bv, rowepi, cs, P::zero());
             issue_row<VEC>(qa, min(i + 2, nrows - 1), rp_v, E0, my_c, my_v, Xs, ldx, live);
             const T a1 = consume_row<VEC>(qb, my_c, my_v, Xs, ldx, live);
-            if (live) finish_row<VEC>(a1, r_lo + i + 1, col0, H, Y, ldy, bv, epi, keep_scale, thresh, seed, mask);
+            if (live) finish_row<VEC>(a1, r_lo + i + 1, col0, H, Y, ldy, bv, rowepi, cs, P::zero());
         }
         if (i < nrows) {
             const T a0 = consume_row<VEC>(qa, my_c, my_v, Xs, ldx, live);
-            if (live) finish_row<VEC>(a0, r_lo + i, col0, H, Y, ldy, bv, epi, keep_scale, thresh, seed, mask);
+            if (live) finish_row<VEC>(a0, r_lo + i, col0, H, Y, ldy, bv, rowepi, cs, P::zero());
         }
         return;
     }
@@ -716,7 +815,7 @@ __global__ __launch_bounds__(kThreads) void spmm_gather_kernel(
                 P::fma(acc, w, x);
             }
         }
-        if (live) finish_row<VEC>(acc, row, col0, H, Y, ldy, bv, epi, keep_scale, thresh, seed, mask);
+        if (live) finish_row<VEC>(acc, row, col0, H, Y, ldy, bv, rowepi, cs, P::zero());
     }
 }
 
@@ -728,7 +827,8 @@ template <int VEC, int B, int MPR, bool PLAIN>
 int launch_tile(const int32_t *rowptr, const int32_t *col, const float *val, const float *X, int64_t ldx, float *Y,
                 int64_t ldy, int32_t H, const fitgnn_tile_t *tiles, int32_t n_tiles, const int32_t *lcol,
                 const int32_t *win_cols, const int32_t *xrow, int32_t lds_rows, int n_slabs, int tiles_per_xcd,
-                const float *bias, uint32_t epi, float p_drop, uint64_t seed, const uint8_t *mask, hipStream_t s) {
+                const float *bias, uint32_t epi, float p_drop, uint64_t seed, const uint8_t *mask, const float *prev, float *col_part,
+                int32_t zero_from, hipStream_t s) {
     constexpr int SLAB = 64 * VEC;
     const size_t lds_bytes = lds_bytes_for(lds_rows, SLAB, MPR);
     if (lds_bytes > 64 * 1024) {
@@ -738,7 +838,7 @@ int launch_tile(const int32_t *rowptr, const int32_t *col, const float *val, con
     }
     dim3 grid(tiles_per_xcd * 8 * n_slabs);
     hipLaunchKernelGGL((spmm_tile_kernel<VEC, B, MPR, PLAIN>), grid, dim3(kThreads), lds_bytes, s, rowptr, col, val, X, ldx, Y, ldy,
-                       H, tiles, n_tiles, tiles_per_xcd, n_slabs, lds_rows, lcol, win_cols, xrow, bias, epi, p_drop, seed, mask);
+                       H, tiles, n_tiles, tiles_per_xcd, n_slabs, lds_rows, lcol, win_cols, xrow, bias, epi, p_drop, seed, mask, prev, col_part, zero_from);
     return (int)hipGetLastError();
 }
 
@@ -746,7 +846,7 @@ template <int VEC>
 int launch(const int32_t *rowptr, const int32_t *col, const float *val, const float *X, int64_t ldx, float *Y,
            int64_t ldy, int32_t H, const fitgnn_tile_t *tiles, int32_t n_tiles, const int32_t *lcol, const int32_t *win_cols,
            const int32_t *xrow, int32_t window_rows, const float *bias, uint32_t epi, float p_drop, uint64_t seed, const uint8_t *mask,
-           hipStream_t s) {
+           const float *prev, float *col_part, int32_t zero_from, hipStream_t s) {
     constexpr int SLAB = 64 * VEC;
     const int n_slabs = (H + SLAB - 1) / SLAB;
     const int tiles_per_xcd = (n_tiles + 7) / 8;
@@ -759,12 +859,12 @@ int launch(const int32_t *rowptr, const int32_t *col, const float *val, const fl
     const int lds_rows = window_rows > 0 ? std::min(window_rows, kMaxWindowRows) : kDefaultWindowRows;
     if (lds_rows <= kSmallWindowRows && !lcol && !win_cols && !xrow)
         return launch_tile<VEC, 4, 16, true>(rowptr, col, val, X, ldx, Y, ldy, H, tiles, n_tiles, lcol, win_cols, xrow, lds_rows, n_slabs,
-                                             tiles_per_xcd, bias, epi, p_drop, seed, mask, s);
+                                             tiles_per_xcd, bias, epi, p_drop, seed, mask, prev, col_part, zero_from, s);
     if (lds_rows <= kSmallWindowRows)
         return launch_tile<VEC, 4, 16, false>(rowptr, col, val, X, ldx, Y, ldy, H, tiles, n_tiles, lcol, win_cols, xrow, lds_rows, n_slabs,
-                                       tiles_per_xcd, bias, epi, p_drop, seed, mask, s);
+                                       tiles_per_xcd, bias, epi, p_drop, seed, mask, prev, col_part, zero_from, s);
     return launch_tile<VEC, 8, 32, false>(rowptr, col, val, X, ldx, Y, ldy, H, tiles, n_tiles, lcol, win_cols, xrow, lds_rows, n_slabs,
-                                   tiles_per_xcd, bias, epi, p_drop, seed, mask, s);
+                                   tiles_per_xcd, bias, epi, p_drop, seed, mask, prev, col_part, zero_from, s);
 }
 
 }  // namespace
@@ -776,12 +876,14 @@ extern "C" int fitgnn_spmm_max_window_rows(int32_t H) {
     return kMaxWindowRows;
 }
 
-extern "C" int fitgnn_spmm_csr_f32(const int32_t *rowptr, const int32_t *col, const float *val, const float *X,
-                                   int64_t ldx, float *Y, int64_t ldy, int32_t n_rows, int32_t H,
-                                   const fitgnn_tile_t *tiles, int32_t n_tiles, const int32_t *lcol,
-                                   const int32_t *win_cols, const int32_t *xrow, int32_t window_rows, const float *bias,
-                                   uint32_t epilogue, float p_drop, uint64_t seed, const uint8_t *mask, void *stream) {
+namespace {
+int spmm_csr_impl(const int32_t *rowptr, const int32_t *col, const float *val, const float *X, int64_t ldx, float *Y, int64_t ldy,
+                  int32_t n_rows, int32_t H, const fitgnn_tile_t *tiles, int32_t n_tiles, const int32_t *lcol, const int32_t *win_cols,
+                  const int32_t *xrow, int32_t window_rows, const float *bias, uint32_t epilogue, float p_drop, uint64_t seed,
+                  const uint8_t *mask, const float *prev, float *col_part, int32_t zero_from, void *stream) {
     if (n_rows < 0 || H < 0 || n_tiles < 0 || window_rows < 0) return FITGNN_E_BADARG;
+    if (!xrow) zero_from = -1;
+    if (zero_from >= 0) epilogue &= ~FITGNN_SPMM_GATHER;  // the direct-gather variant knows no zero rows
     if (n_rows == 0 || H == 0 || n_tiles == 0) return 0;
     // col/val may be NULL only for a matrix without non-zeros (they are then never dereferenced)
     if (!rowptr || !X || !Y || !tiles) return FITGNN_E_BADARG;
@@ -789,17 +891,20 @@ extern "C" int fitgnn_spmm_csr_f32(const int32_t *rowptr, const int32_t *col, co
     if ((epilogue & FITGNN_EPI_DROPOUT) && !(p_drop >= 0.f && p_drop < 1.f)) return FITGNN_E_BADARG;
     if (ldx < H || ldy < H) return FITGNN_E_BADARG;
     if ((lcol == nullptr) != (win_cols == nullptr) && lcol == nullptr) return FITGNN_E_BADARG;  // win_cols needs lcol
+    if (epilogue & FITGNN_EPI_BACKWARD) {  // prev is indexed like a contiguous [n_rows x H] matrix; not for the direct-gather variant
+        if (!prev || (epilogue & (FITGNN_SPMM_GATHER | FITGNN_EPI_BIAS)) || ((uintptr_t)prev % 16) != 0 || (H % 4) != 0) return FITGNN_E_BADARG;
+    }
     hipStream_t s = (hipStream_t)stream;
     const bool vec = (H % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) && (((uintptr_t)X | (uintptr_t)Y) % 16 == 0);
-    if (vec) return launch<4>(rowptr, col, val, X, ldx, Y, ldy, H, tiles, n_tiles, lcol, win_cols, xrow, window_rows, bias, epilogue, p_drop, seed, mask, s);
-    return launch<1>(rowptr, col, val, X, ldx, Y, ldy, H, tiles, n_tiles, lcol, win_cols, xrow, window_rows, bias, epilogue, p_drop, seed, mask, s);
+    if ((epilogue & FITGNN_EPI_BACKWARD) && !vec) return FITGNN_E_ALIGN;
+    if (vec) return launch<4>(rowptr, col, val, X, ldx, Y, ldy, H, tiles, n_tiles, lcol, win_cols, xrow, window_rows, bias, epilogue, p_drop, seed, mask, prev, col_part, zero_from, s);
+    return launch<1>(rowptr, col, val, X, ldx, Y, ldy, H, tiles, n_tiles, lcol, win_cols, xrow, window_rows, bias, epilogue, p_drop, seed, mask, prev, col_part, zero_from, s);
 }
 
-extern "C" int fitgnn_spmm_csr_blocks_f32(const int32_t *rowptr, const int32_t *col, const float *val, const float *X,
-                                          int64_t ldx, float *Y, int64_t ldy, int32_t n_rows, int32_t H,
-                                          const fitgnn_block_t *blocks, int32_t n_blocks, const int32_t *long_rows,
-                                          const int32_t *xrow, const int32_t *xcol, const float *bias, uint32_t epilogue, float p_drop,
-                                          uint64_t seed, const uint8_t *mask, void *stream) {
+int spmm_blocks_impl(const int32_t *rowptr, const int32_t *col, const float *val, const float *X, int64_t ldx, float *Y, int64_t ldy,
+                     int32_t n_rows, int32_t H, const fitgnn_block_t *blocks, int32_t n_blocks, const int32_t *long_rows,
+                     const int32_t *xrow, const int32_t *xcol, const float *bias, uint32_t epilogue, float p_drop, uint64_t seed,
+                     const uint8_t *mask, const float *prev, float *col_part, int32_t zero_from, void *stream) {
     if (n_rows < 0 || H < 0 || n_blocks < 0) return FITGNN_E_BADARG;
     if (xcol && !xrow) return FITGNN_E_BADARG;
     if (n_rows == 0 || H == 0 || n_blocks == 0) return 0;
@@ -809,13 +914,55 @@ extern "C" int fitgnn_spmm_csr_blocks_f32(const int32_t *rowptr, const int32_t *
     if (ldx < H || ldy < H) return FITGNN_E_BADARG;
     if ((H % 4) != 0 || (ldx % 4) != 0 || (ldy % 4) != 0) return FITGNN_E_BADARG;
     if ((((uintptr_t)X | (uintptr_t)Y) % 16) != 0) return FITGNN_E_ALIGN;
+    if ((epilogue & FITGNN_EPI_BACKWARD) && (!prev || (epilogue & FITGNN_EPI_BIAS) || ((uintptr_t)prev % 16) != 0)) return FITGNN_E_BADARG;
     const int n_slabs = (H + 255) / 256;
     const dim3 grid((unsigned)((n_blocks + 7) / 8 * 8) * n_slabs);
-    if (xrow)
-        hipLaunchKernelGGL(spmm_block_kernel<true>, grid, dim3(kThreads), 0, (hipStream_t)stream, rowptr, col, val, X, ldx, Y, ldy, H, blocks,
-                           n_blocks, long_rows, n_slabs, bias, epilogue, p_drop, seed, mask, xrow, xcol);
-    else
-        hipLaunchKernelGGL(spmm_block_kernel<false>, grid, dim3(kThreads), 0, (hipStream_t)stream, rowptr, col, val, X, ldx, Y, ldy, H, blocks,
-                           n_blocks, long_rows, n_slabs, bias, epilogue, p_drop, seed, mask, xrow, xcol);
+#define FITGNN_LAUNCH_BLK(XR, BW)                                                                                                    \
+    hipLaunchKernelGGL((spmm_block_kernel<XR, BW>), grid, dim3(kThreads), 0, (hipStream_t)stream, rowptr, col, val, X, ldx, Y, ldy, H, \
+                       blocks, n_blocks, long_rows, n_slabs, bias, epilogue, p_drop, seed, mask, xrow, xcol, prev, col_part, zero_from)
+    const bool bwd = (epilogue & FITGNN_EPI_BACKWARD) != 0;
+    if (xrow) { if (bwd) FITGNN_LAUNCH_BLK(true, true); else FITGNN_LAUNCH_BLK(true, false); }
+    else { if (bwd) FITGNN_LAUNCH_BLK(false, true); else FITGNN_LAUNCH_BLK(false, false); }
+#undef FITGNN_LAUNCH_BLK
     return (int)hipGetLastError();
+}
+}  // namespace
+
+extern "C" int fitgnn_spmm_csr_f32(const int32_t *rowptr, const int32_t *col, const float *val, const float *X,
+                                   int64_t ldx, float *Y, int64_t ldy, int32_t n_rows, int32_t H,
+                                   const fitgnn_tile_t *tiles, int32_t n_tiles, const int32_t *lcol,
+                                   const int32_t *win_cols, const int32_t *xrow, int32_t xrow_zero_from, int32_t window_rows,
+                                   const float *bias, uint32_t epilogue, float p_drop, uint64_t seed, const uint8_t *mask, void *stream) {
+    if (epilogue & FITGNN_EPI_BACKWARD) return FITGNN_E_BADARG;  // fitgnn_spmm_csr_dz_f32
+    return spmm_csr_impl(rowptr, col, val, X, ldx, Y, ldy, n_rows, H, tiles, n_tiles, lcol, win_cols, xrow, window_rows, bias, epilogue,
+                         p_drop, seed, mask, nullptr, nullptr, xrow_zero_from, stream);
+}
+
+extern "C" int fitgnn_spmm_csr_blocks_f32(const int32_t *rowptr, const int32_t *col, const float *val, const float *X,
+                                          int64_t ldx, float *Y, int64_t ldy, int32_t n_rows, int32_t H,
+                                          const fitgnn_block_t *blocks, int32_t n_blocks, const int32_t *long_rows,
+                                          const int32_t *xrow, const int32_t *xcol, int32_t xrow_zero_from, const float *bias,
+                                          uint32_t epilogue, float p_drop, uint64_t seed, const uint8_t *mask, void *stream) {
+    if (epilogue & FITGNN_EPI_BACKWARD) return FITGNN_E_BADARG;  // fitgnn_spmm_csr_blocks_dz_f32
+    return spmm_blocks_impl(rowptr, col, val, X, ldx, Y, ldy, n_rows, H, blocks, n_blocks, long_rows, xrow, xcol, bias, epilogue, p_drop, seed,
+                            mask, nullptr, nullptr, xrow ? xrow_zero_from : -1, stream);
+}
+
+// The same products as the input gradient of a fused layer: Y = (A @ X) * dropout' * ELU'(prev), see finish_row.
+extern "C" int fitgnn_spmm_csr_dz_f32(const int32_t *rowptr, const int32_t *col, const float *val, const float *X, int64_t ldx,
+                                      float *Y, int64_t ldy, int32_t n_rows, int32_t H, const fitgnn_tile_t *tiles, int32_t n_tiles,
+                                      const int32_t *lcol, const int32_t *win_cols, const int32_t *xrow, int32_t xrow_zero_from,
+                                      int32_t window_rows, const float *prev, uint32_t epilogue, float p_drop, uint64_t seed,
+                                      const uint8_t *mask, float *col_part, void *stream) {
+    return spmm_csr_impl(rowptr, col, val, X, ldx, Y, ldy, n_rows, H, tiles, n_tiles, lcol, win_cols, xrow, window_rows, nullptr,
+                         (epilogue & ~FITGNN_SPMM_GATHER) | FITGNN_EPI_BACKWARD, p_drop, seed, mask, prev, col_part, xrow_zero_from, stream);
+}
+
+extern "C" int fitgnn_spmm_csr_blocks_dz_f32(const int32_t *rowptr, const int32_t *col, const float *val, const float *X, int64_t ldx,
+                                             float *Y, int64_t ldy, int32_t n_rows, int32_t H, const fitgnn_block_t *blocks,
+                                             int32_t n_blocks, const int32_t *long_rows, const int32_t *xrow, const int32_t *xcol,
+                                             int32_t xrow_zero_from, const float *prev, uint32_t epilogue, float p_drop, uint64_t seed,
+                                             const uint8_t *mask, float *col_part, void *stream) {
+    return spmm_blocks_impl(rowptr, col, val, X, ldx, Y, ldy, n_rows, H, blocks, n_blocks, long_rows, xrow, xcol, nullptr,
+                            epilogue | FITGNN_EPI_BACKWARD, p_drop, seed, mask, prev, col_part, xrow ? xrow_zero_from : -1, stream);
 }

@@ -146,9 +146,10 @@ class _Base(nn.Module):
         seed = ops.next_seed(cfg) if (self.training and self.dropout_p > 0 and mask is None) else 0
         if (loss_rows is not None and cfg.last_layer_on_loss_rows and loss_rows.numel() > 0 and x.shape[1] % 4 == 0
                 and last.lin.weight.shape[0] % 4 == 0 and ops.head_rows_supported(x.new_empty((1, last.lin.weight.shape[0])), self.lt1.weight)):
-            # aggregate first, then the dense part on the loss rows only; the previous layer applies its own epilogue backward
+            # aggregate first, then the dense part on the loss rows only; the previous layer's epilogue backward rides on the
+            # backward SpMM's store (link)
             return ops.FusedGCNLastLayerRows.apply(x, last.lin.weight, last.bias, self.lt1.weight, self.lt1.bias, g,
-                                                   float(self.dropout_p), bool(self.training), seed, mask, loss_rows, cfg)
+                                                   float(self.dropout_p), bool(self.training), seed, mask, loss_rows, cfg, link)
         return ops.FusedGCNLayerHead.apply(x, last.lin.weight, last.bias, self.lt1.weight, self.lt1.bias, g,
                                            float(self.dropout_p), bool(self.training), seed, mask, link, cfg, loss_rows)
 

@@ -358,7 +358,7 @@ def _f32c(t):
 
 
 def spmm_raw(rowptr, col, val, tiles, X, n_rows, bias=None, epilogue=0, p=0.0, seed=0, mask=None, out=None, window_rows=0,
-             lcol=None, win_cols=None, xrow=None, cfg=DEFAULT, profile_kind=None):
+             lcol=None, win_cols=None, xrow=None, cfg=DEFAULT, profile_kind=None, zero_from=-1):
     """Y = epilogue(A @ X) through fitgnn_spmm_csr_f32.  X: [n_cols_of_A, H] f32 contiguous."""
     _lib.require_cuda(rowptr, col, val, tiles, X, bias, mask)
     L = _lib.lib()
@@ -372,7 +372,8 @@ def spmm_raw(rowptr, col, val, tiles, X, n_rows, bias=None, epilogue=0, p=0.0, s
         ev[0].record()
     rc = L.fitgnn_spmm_csr_f32(_lib.dptr(rowptr), _lib.dptr(col), _lib.dptr(val), _lib.dptr(X), X.stride(0) if X.numel() else H,
                                _lib.dptr(Y), Y.stride(0) if Y.numel() else H, n_rows, H, _lib.dptr(tiles), int(tiles.shape[0]),
-                               _lib.dptr(lcol), _lib.dptr(win_cols), _lib.dptr(xrow), int(window_rows), _lib.dptr(bias), epilogue, float(p), seed, _lib.dptr(mask),
+                               _lib.dptr(lcol), _lib.dptr(win_cols), _lib.dptr(xrow), int(zero_from), int(window_rows), _lib.dptr(bias), epilogue, float(p),
+                               seed, _lib.dptr(mask),
                                _lib.stream_ptr(X.device))
     if ev is not None:
         ev[1].record()
@@ -400,7 +401,7 @@ def epilogue_bwd_raw(dOut, out, epilogue, p=0.0, seed=0, mask=None, want_db=True
 
 
 def spmm_blocks_raw(rowptr, col, val, blocks, long_rows, X, Y, bias=None, epilogue=0, p=0.0, seed=0, mask=None, cfg=DEFAULT, xrow=None,
-                    xcol=None):
+                    xcol=None, zero_from=-1):
     """The rows of the listed large diagonal blocks of Y = epilogue(A @ X) through fitgnn_spmm_csr_blocks_f32 (one workgroup
     walks a whole subgraph: every operand row read once)."""
     _lib.require_cuda(rowptr, col, val, blocks, long_rows, X, Y, bias, mask, xrow, xcol)
@@ -413,7 +414,7 @@ def spmm_blocks_raw(rowptr, col, val, blocks, long_rows, X, Y, bias=None, epilog
         ev[0].record()
     rc = L.fitgnn_spmm_csr_blocks_f32(_lib.dptr(rowptr), _lib.dptr(col), _lib.dptr(val), _lib.dptr(X), X.stride(0), _lib.dptr(Y), Y.stride(0),
                                       int(Y.shape[0]), H, _lib.dptr(blocks), int(blocks.shape[0]), _lib.dptr(long_rows), _lib.dptr(xrow),
-                                      _lib.dptr(xcol), _lib.dptr(bias),
+                                      _lib.dptr(xcol), int(zero_from), _lib.dptr(bias),
                                       epilogue, float(p), seed, _lib.dptr(mask), _lib.stream_ptr(X.device))
     if ev is not None:
         ev[1].record()
@@ -439,6 +440,7 @@ def spmm_graph(g, X, transposed=False, **kw):
     xrow = kw.pop("xrow", None)
     cfg = kw.pop("cfg", DEFAULT)
     kind = kw.pop("profile_kind", None)
+    zero_from = kw.pop("zero_from", -1)
     Y = out if out is not None else torch.empty((g.n, Xc.shape[1]), dtype=torch.float32, device=Xc.device)
     ev = None
     if cfg.profile is not None:   # ONE event pair around both launches: together they are the SpMM
@@ -447,7 +449,7 @@ def spmm_graph(g, X, transposed=False, **kw):
     quiet = cfg if cfg.profile is None else cfg.replace(profile=None)
     if side.small_tiles.shape[0]:
         spmm_raw(side.rowptr, side.col, side.val, side.small_tiles, Xc, g.n, epilogue=epi, window_rows=g.window_rows, out=Y, cfg=quiet,
-                 xrow=xrow, **kw)
+                 xrow=xrow, zero_from=zero_from, **kw)
     xcol = None
     if xrow is not None:   # the table row of every CSR entry, listed once per (pattern side, index): see fitgnn_spmm_csr_blocks_f32
         cached = getattr(side, "xcol", None)
@@ -455,11 +457,63 @@ def spmm_graph(g, X, transposed=False, **kw):
             cached = (xrow.data_ptr(), xrow.index_select(0, side.col.long()).contiguous())
             side.xcol = cached
         xcol = cached[1]
-    spmm_blocks_raw(side.rowptr, side.col, side.val, side.blocks, side.long_rows, Xc, Y, epilogue=epi, cfg=quiet, xrow=xrow, xcol=xcol, **kw)
+    spmm_blocks_raw(side.rowptr, side.col, side.val, side.blocks, side.long_rows, Xc, Y, epilogue=epi, cfg=quiet, xrow=xrow, xcol=xcol,
+                    zero_from=zero_from, **kw)
     if ev is not None:
         ev[1].record()
         cfg.profile.append((ev[0], ev[1], kind or ("tile" if xrow is None else "table")))   # "table": layer 0 on the de-duplicated table
     return Y
+
+
+def spmm_graph_dz(g, X, prev, epilogue, p=0.0, seed=0, mask=None, want_db=True, transposed=True, xrow=None, cfg=DEFAULT, profile_kind=None,
+                  zero_from=-1):
+    """(dZ, db): dZ = (A @ X) * dropout' * ELU'(prev), the input gradient of the fused layer whose forward output is `prev`
+    (fitgnn_spmm_csr_dz_f32 / fitgnn_spmm_csr_blocks_dz_f32: the derivative is applied as the rows are stored), db = column
+    sums of dZ.  `epilogue`, p, seed, mask: the FORWARD's (ELU / dropout flags).  The direct-gather variant is not used here."""
+    side = g.t if transposed else g.f
+    Xc, prev = _f32c(X), _f32c(prev)
+    _lib.require_cuda(Xc, prev, mask, xrow)
+    L = _lib.lib()
+    H = Xc.shape[1]
+    dev = Xc.device
+    seed_v, epi_v = _seed_arg(seed, epilogue & ~_lib.SPMM_GATHER)
+    split = side.blocks is not None and cfg.split_large_blocks
+    tiles = side.small_tiles if split else side.tiles
+    n_tiles = int(tiles.shape[0])
+    n_blocks = int(side.blocks.shape[0]) if split else 0
+    Y = torch.empty((g.n, H), dtype=torch.float32, device=dev)
+    part = torch.zeros((n_tiles + n_blocks, H), dtype=torch.float32, device=dev) if want_db else None
+    st = _lib.stream_ptr(dev)
+    ev = None
+    if cfg.profile is not None:
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
+    if n_tiles:
+        _lib.check(L.fitgnn_spmm_csr_dz_f32(_lib.dptr(side.rowptr), _lib.dptr(side.col), _lib.dptr(side.val), _lib.dptr(Xc), Xc.stride(0),
+                                            _lib.dptr(Y), Y.stride(0), g.n, H, _lib.dptr(tiles), n_tiles,
+                                            _lib.dptr(None if split else side.lcol), _lib.dptr(None if split else side.win_cols),
+                                            _lib.dptr(xrow), int(zero_from), int(g.window_rows), _lib.dptr(prev), epi_v, float(p), seed_v,
+                                            _lib.dptr(mask), _lib.dptr(part), st), "fitgnn_spmm_csr_dz_f32")
+    if n_blocks:
+        xcol = None
+        if xrow is not None:
+            cached = side.xcol
+            if cached is None or cached[0] != xrow.data_ptr():
+                cached = (xrow.data_ptr(), xrow.index_select(0, side.col.long()).contiguous())
+                side.xcol = cached
+            xcol = cached[1]
+        _lib.check(L.fitgnn_spmm_csr_blocks_dz_f32(_lib.dptr(side.rowptr), _lib.dptr(side.col), _lib.dptr(side.val), _lib.dptr(Xc), Xc.stride(0),
+                                                   _lib.dptr(Y), Y.stride(0), g.n, H, _lib.dptr(side.blocks), n_blocks, _lib.dptr(side.long_rows),
+                                                   _lib.dptr(xrow), _lib.dptr(xcol), int(zero_from), _lib.dptr(prev), epi_v, float(p), seed_v, _lib.dptr(mask),
+                                                   _lib.dptr(None if part is None else part[n_tiles:]), st), "fitgnn_spmm_csr_blocks_dz_f32")
+    if ev is not None:
+        ev[1].record()
+        cfg.profile.append((ev[0], ev[1], profile_kind or "dz"))
+    db = None
+    if want_db:
+        db = torch.empty(H, dtype=torch.float32, device=dev)
+        _lib.check(L.fitgnn_colsum_partials_f32(_lib.dptr(part), n_tiles + n_blocks, H, _lib.dptr(db), st), "fitgnn_colsum_partials_f32")
+    return Y, db
 
 
 def epilogue_bwd_head_raw(dy, Wl, out, epilogue, p=0.0, seed=0, mask=None, want_db=True, want_dWl=True):
@@ -629,7 +683,8 @@ def layer_backward(g, out, epi, p, seed, mask, want_db, dOut=None, dy=None, Wl=N
         dZc, db, dWl = epilogue_bwd_head_rows_raw(dy, Wl, out, loss_rows, epi, p=p, seed=seed, mask=mask, want_db=want_db, want_dWl=inside)
         if want_dWl and not inside:
             dWl = mm_at_b(_f32c(dy).index_select(0, loss_rows), out.index_select(0, loss_rows), cfg)
-        return spmm_graph(g, dZc, transposed=True, cfg=cfg, xrow=_compact_positions(g, loss_rows), profile_kind="compact"), db, dWl
+        return spmm_graph(g, dZc, transposed=True, cfg=cfg, xrow=_compact_positions(g, loss_rows), profile_kind="compact",
+                          zero_from=int(loss_rows.numel())), db, dWl
     if head:
         inside = want_dWl and bool(L.fitgnn_epilogue_bwd_head_supported(H, C, 1))
         dZ, db, dWl = epilogue_bwd_head_raw(dy, Wl, out, epi, p=p, seed=seed, mask=mask, want_db=want_db, want_dWl=inside)
@@ -812,9 +867,10 @@ class FusedGCNLastLayerRows(torch.autograd.Function):
     (every edge aggregated, as in layer_backward's compact path)."""
 
     @staticmethod
-    def forward(ctx, X, W, b, Wl, bl, g, p, training, seed, mask, rows, cfg):
+    def forward(ctx, X, W, b, Wl, bl, g, p, training, seed, mask, rows, cfg, link_in=None):
         X = _f32c(X)
         rows = rows if rows.dtype == torch.int64 else rows.long()
+        ctx.link_in = link_in
         AH = spmm_graph(g, X, cfg=cfg)                                   # [R, K]
         AHc = AH.index_select(0, rows)                                   # [n, K]
         del AH
@@ -827,13 +883,15 @@ class FusedGCNLastLayerRows(torch.autograd.Function):
             epi |= EPI_DROPOUT
         epilogue_fwd_rows_(outc, rows, b, epi, p=p if drop else 0.0, seed=seed, mask=mask if drop else None)
         y = head_rows(outc, rows, Wl, bl, n_total=g.n)
-        ctx.save_for_backward(W, Wl, AHc, outc, rows, mask if drop else None)
+        # X (the previous layer's output) is kept only when that layer's epilogue backward is applied here, in the SpMM's store
+        keep_x = link_in is not None and cfg.fuse_dx_epilogue and X.shape[1] % 4 == 0
+        ctx.save_for_backward(W, Wl, AHc, outc, rows, mask if drop else None, X if keep_x else None)
         ctx.g, ctx.p, ctx.drop, ctx.seed, ctx.has_bias, ctx.has_bl, ctx.cfg = g, p, drop, seed, b is not None, bl is not None, cfg
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        W, Wl, AHc, outc, rows, mask = ctx.saved_tensors
+        W, Wl, AHc, outc, rows, mask, Xprev = ctx.saved_tensors
         g, cfg = ctx.g, ctx.cfg
         L = _lib.lib()
         H, C = outc.shape[1], Wl.shape[0]
@@ -852,8 +910,15 @@ class FusedGCNLastLayerRows(torch.autograd.Function):
             dAH = torch.empty((n + ZERO_ROWS, K), dtype=torch.float32, device=dZc.device)
             dAH[n:].zero_()
             dAH[:n] = mm_by_transposed(dZc, W, cfg)                      # dZ @ W on the loss rows
-            dX = spmm_graph(g, dAH, transposed=True, cfg=cfg, xrow=_compact_positions(g, rows), profile_kind="compact")
-        return dX, dW, (db if ctx.has_bias else None), dWl, dbl, None, None, None, None, None, None, None
+            link = ctx.link_in
+            if Xprev is not None:
+                # the producing layer's ELU' / dropout' applied as the rows are stored: what travels back on this edge is its dZ
+                dX, db_prev = spmm_graph_dz(g, dAH, Xprev, link.epi, p=link.p, seed=link.seed, mask=link.mask, want_db=link.want_db,
+                                            xrow=_compact_positions(g, rows), cfg=cfg, profile_kind="compact", zero_from=n)
+                link.fused, link.db = True, db_prev
+            else:
+                dX = spmm_graph(g, dAH, transposed=True, cfg=cfg, xrow=_compact_positions(g, rows), profile_kind="compact", zero_from=n)
+        return dX, dW, (db if ctx.has_bias else None), dWl, dbl, None, None, None, None, None, None, None, None
 
 
 class FusedGCNLayerDedup(torch.autograd.Function):

@@ -87,12 +87,31 @@ typedef struct fitgnn_block {
  * fitgnn_spmm_csr_f32 over tiles that pack the small blocks, this one over the large blocks.  Requires H % 4 == 0, 16-byte
  * aligned rows (FITGNN_E_BADARG / FITGNN_E_ALIGN otherwise: tile those blocks instead).  xrow (may be NULL): row indirection into a
  * de-duplicated operand table, as in fitgnn_spmm_csr_f32; xcol (may be NULL; needs xrow): xcol[e] = xrow[col[e]] for every CSR
- * entry, built once per batch -- an entry whose operand row is gathered then costs one dependent load instead of two. */
+ * entry, built once per batch -- an entry whose operand row is gathered then costs one dependent load instead of two.
+ * xrow_zero_from (with xrow; -1: none): operand rows with index >= xrow_zero_from are rows of zeros (the tail of a compact operand):
+ * they are not loaded (window rows staged as zeros, gathered entries served from an LDS row of zeros) -- same result. */
 int fitgnn_spmm_csr_blocks_f32(const int32_t *rowptr, const int32_t *col, const float *val, const float *X, int64_t ldx,
                                float *Y, int64_t ldy, int32_t n_rows, int32_t H, const fitgnn_block_t *blocks,
                                int32_t n_blocks, const int32_t *long_rows, const int32_t *xrow, const int32_t *xcol,
-                               const float *bias, uint32_t epilogue, float p_drop, uint64_t seed, const uint8_t *mask,
-                               void *stream);
+                               int32_t xrow_zero_from, const float *bias, uint32_t epilogue, float p_drop, uint64_t seed,
+                               const uint8_t *mask, void *stream);
+
+/* The same two products as the input gradient of a fused layer output  prev = dropout(ELU(z))  (network.py:32-33): what is stored is
+ *   Y[row] = keep ? (A @ X)[row] / (1 - p) * (e > 0 ? 1 : e + 1) : 0,   e = prev[row] * (1 - p)
+ * -- fitgnn_epilogue_bwd_f32's arithmetic with the forward's flags (FITGNN_EPI_ELU and/or FITGNN_EPI_DROPOUT), seed and mask --
+ * so that a backward SpMM whose result is the gradient w.r.t. the previous layer's output writes that layer's dZ directly and the
+ * un-transformed gradient is never written and re-read.  prev: contiguous [n_rows x H], 16-byte aligned; H % 4 == 0.
+ * col_part (may be NULL): [n_tiles (resp. n_blocks) x H], ZEROED by the caller; row t receives the column sums of the rows tile /
+ * block t stored, in a fixed order -- sum them (fitgnn_colsum_partials_f32) for the bias gradient. */
+int fitgnn_spmm_csr_dz_f32(const int32_t *rowptr, const int32_t *col, const float *val, const float *X, int64_t ldx, float *Y,
+                           int64_t ldy, int32_t n_rows, int32_t H, const fitgnn_tile_t *tiles, int32_t n_tiles, const int32_t *lcol,
+                           const int32_t *win_cols, const int32_t *xrow, int32_t xrow_zero_from, int32_t window_rows, const float *prev,
+                           uint32_t epilogue, float p_drop, uint64_t seed, const uint8_t *mask, float *col_part, void *stream);
+int fitgnn_spmm_csr_blocks_dz_f32(const int32_t *rowptr, const int32_t *col, const float *val, const float *X, int64_t ldx, float *Y,
+                                  int64_t ldy, int32_t n_rows, int32_t H, const fitgnn_block_t *blocks, int32_t n_blocks,
+                                  const int32_t *long_rows, const int32_t *xrow, const int32_t *xcol, int32_t xrow_zero_from,
+                                  const float *prev, uint32_t epilogue, float p_drop, uint64_t seed, const uint8_t *mask,
+                                  float *col_part, void *stream);
 
 /* LDS window sizes of the SpMM kernel (rows of the dense operand staged per workgroup): the default used
  * when window_rows == 0, and the largest accepted value.  Tiles should be built with win_rows <= the
@@ -114,6 +133,8 @@ int fitgnn_gcn_norm_csr_f32(const int32_t *rowptr, const int32_t *col, const flo
 /* the `seed` argument is a DEVICE pointer to the uint64 seed (read by the kernel), not the seed itself: a step
  * captured in a hipGraph keeps drawing fresh dropout patterns, its seeds are advanced by a kernel of the graph */
 #define FITGNN_EPI_SEED_DEVICE 8u
+/* internal to the *_dz_* entry points below (the store epilogue is the DERIVATIVE of ELU / dropout); rejected elsewhere */
+#define FITGNN_EPI_BACKWARD 0x10u
 /* kernel-variant hint carried in the same word: skip the LDS window, gather operand rows straight from
  * L2/HBM -- faster when rows hold only a few non-zeros (identical results) */
 #define FITGNN_SPMM_GATHER 0x100u
@@ -125,7 +146,8 @@ int fitgnn_gcn_norm_csr_f32(const int32_t *rowptr, const int32_t *col, const flo
  * window and `col` is used as is.
  * xrow (may be NULL): operand row r of the pattern is read from X[xrow[r]] instead of X[r] -- lets the many union rows
  * that are copies of one original node (extra nodes of the subgraphs, utils.py:235-239) share a single row of a
- * de-duplicated operand table.
+ * de-duplicated operand table.  xrow_zero_from (with xrow; -1: none): table rows with index >= xrow_zero_from are rows of zeros
+ * (the tail of a compact operand) and are not loaded; the direct-gather variant is then not used.
  * window_rows: LDS rows per workgroup (0 = default); see fitgnn_spmm_default_window_rows().
  * Dropout: element (row,h) is kept iff mask[row*H+h] != 0 when `mask` is given, else iff 16 bits of a
  * counter-based hash of (seed, (row*H+h)/4) are >= floor(p*65536); kept values are scaled by 1/(1-p).  16-byte aligned X/Y rows (H%4==0 and
@@ -133,8 +155,8 @@ int fitgnn_gcn_norm_csr_f32(const int32_t *rowptr, const int32_t *col, const flo
 int fitgnn_spmm_csr_f32(const int32_t *rowptr, const int32_t *col, const float *val, const float *X, int64_t ldx,
                         float *Y, int64_t ldy, int32_t n_rows, int32_t H, const fitgnn_tile_t *tiles,
                         int32_t n_tiles, const int32_t *lcol, const int32_t *win_cols, const int32_t *xrow,
-                        int32_t window_rows, const float *bias, uint32_t epilogue, float p_drop, uint64_t seed,
-                        const uint8_t *mask, void *stream);
+                        int32_t xrow_zero_from, int32_t window_rows, const float *bias, uint32_t epilogue, float p_drop,
+                        uint64_t seed, const uint8_t *mask, void *stream);
 
 /* out[s] = sum of X[members[m]] for m in [seg_off[s], seg_off[s+1]) in that order (f32, fixed order: reproducible).
  * The adjoint of the row indirection above: gradients of duplicated union rows summed back per original node. */

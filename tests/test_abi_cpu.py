@@ -46,8 +46,10 @@ def test_error_strings_and_size_queries():
 
 def test_bad_arguments_are_rejected_without_touching_the_gpu():
     L = _lib.lib()
-    assert L.fitgnn_spmm_csr_f32(None, None, None, None, 4, None, 4, -1, 4, None, 0, None, None, None, 0, None, 0, 0.0, 0, None, None) == -1
-    assert L.fitgnn_spmm_csr_f32(None, None, None, None, 4, None, 4, 0, 4, None, 0, None, None, None, 0, None, 0, 0.0, 0, None, None) == 0
+    assert L.fitgnn_spmm_csr_f32(None, None, None, None, 4, None, 4, -1, 4, None, 0, None, None, None, -1, 0, None, 0, 0.0, 0, None, None) == -1
+    assert L.fitgnn_spmm_csr_f32(None, None, None, None, 4, None, 4, 0, 4, None, 0, None, None, None, -1, 0, None, 0, 0.0, 0, None, None) == 0
+    # the backward-epilogue flag belongs to the *_dz_* entry points only
+    assert L.fitgnn_spmm_csr_f32(None, None, None, None, 4, None, 4, 8, 4, None, 1, None, None, None, -1, 0, None, 0x10, 0.0, 0, None, None) == -1
     assert L.fitgnn_variation_costs_f64(None, None, None, None, None, 17, 17, None, None, None, 1, None, None) == -1
     assert L.fitgnn_variation_costs_f64(None, None, None, None, None, 10, 10, None, None, None, 0, None, None) == 0
     assert L.fitgnn_pool_rows_f32(None, None, 5, 0, None, 4, 4, None, 4, None, None, 0, None) == 0

@@ -280,6 +280,39 @@ def test_whole_subgraph_kernel_gives_the_tile_kernel_bits(mods, H, sizes, centre
             assert torch.equal(ops.spmm_graph(gg, Xt, xrow=xrow, cfg=cfg), want)
 
 
+@pytest.mark.parametrize("H", [512, 64])
+@pytest.mark.parametrize("use_mask", [False, True])
+def test_backward_spmm_with_the_previous_layers_epilogue_in_its_store(mods, H, use_mask):
+    """spmm_graph_dz (the derivative of dropout(ELU(.)) applied as the SpMM stores its rows, column sums per workgroup) ==
+    the SpMM followed by the epilogue-backward kernel, bit for bit for dZ and to fp32 summation order for db; tiles only, the
+    whole-subgraph kernel + tiles, with a compact operand behind a row indirection."""
+    _lib, csr, ops, orc, gorc = mods
+    from fitgnn_amd._lib import EPI_DROPOUT, EPI_ELU
+
+    sizes = [100, 7, 17, 300, 3, 3, 64, 33, 2, 1000, 5, 5, 40]
+    ei, n = star_blocks(sizes, 2, seed=H)
+    ptr = np.concatenate([[0], np.cumsum(sizes)])
+    torch.manual_seed(H)
+    prev = torch.randn(n, H).cuda() * (torch.rand(n, H).cuda() > 0.3)        # a forward output: zeros where dropout hit
+    mask = (torch.rand(n, H).cuda() > 0.5).to(torch.uint8) if use_mask else None
+    flags, p, seed = EPI_ELU | EPI_DROPOUT, 0.5, 77
+    for g in (csr.CSRGraph(ei.cuda(), n, mode="gcn", ptr=ptr), csr.CSRGraph(ei.cuda(), n, mode="gcn", ptr=ptr, block_limit=4096)):
+        X = torch.randn(n, H).cuda()
+        plain = ops.spmm_graph(g, X, transposed=True)
+        want, want_db = ops.epilogue_bwd_raw(plain, prev, flags, p=p, seed=seed, mask=mask, want_db=True)
+        got, got_db = ops.spmm_graph_dz(g, X, prev, flags, p=p, seed=seed, mask=mask, want_db=True)
+        assert torch.equal(got, want)
+        assert rel_err(got_db.cpu(), want_db.cpu()) < 1e-5
+        # compact operand: a third of the rows carry values, the others read a zero row
+        rows = torch.randperm(n).cuda()[: n // 3].sort().values
+        Xc = torch.cat([torch.randn(rows.numel(), H).cuda(), torch.zeros(ops.ZERO_ROWS, H).cuda()])
+        pos = ops._compact_positions(g, rows)
+        dense = torch.zeros(n, H).cuda(); dense[rows] = Xc[: rows.numel()]
+        want2, _ = ops.epilogue_bwd_raw(ops.spmm_graph(g, dense, transposed=True), prev, flags, p=p, seed=seed, mask=mask, want_db=False)
+        got2, none = ops.spmm_graph_dz(g, Xc, prev, flags, p=p, seed=seed, mask=mask, want_db=False, xrow=pos)
+        assert none is None and torch.equal(got2, want2)
+
+
 @pytest.mark.parametrize("H,C,with_dWl", [(512, 3, True), (512, 47, False), (64, 7, True)])
 def test_head_backward_skips_rows_without_gradient_bit_for_bit(mods, H, C, with_dWl):
     """Rows whose head gradient dy is all zero (nodes outside the loss: most rows of an --extra_node subgraph) are written
