@@ -258,8 +258,8 @@ def main():
     if not args.no_fp32 and args.gemm_precision == "high":
         loss_final = float(loss)
         tr32, _ = make_trainer("highest")
-        k32 = max(3, min(args.steps, 10))
-        dt32, _ = timed(tr32, k32, 2)
+        k32 = max(3, min(args.steps, 50))
+        dt32, _ = timed(tr32, k32, max(2, min(args.warmup, 10)))
         fp32 = dict(ms_per_step=dt32 / k32 * 1e3, value=edges_per_step_total * k32 / dt32, steps=k32)
         del tr32
     else:
@@ -268,8 +268,8 @@ def main():
     all_rows = None
     if not args.no_all_rows:
         tra, _ = make_trainer(args.gemm_precision, loss_rows_only=False)
-        ka = max(3, min(args.steps, 10))
-        dta, loss_a = timed(tra, ka, 2)
+        ka = max(3, min(args.steps, 50))
+        dta, loss_a = timed(tra, ka, max(2, min(args.warmup, 10)))
         all_rows = dict(ms_per_step=dta / ka * 1e3, value=edges_per_step_total * ka / dta, steps=ka, loss=float(loss_a))
         del tra
 

@@ -367,7 +367,7 @@ constexpr int kBlkMeta = 128;  // CSR entries of a piece staged in LDS (threads 
 // XROW: operand row r of the pattern lives at X[xrow[r]] (a de-duplicated operand table, as in the tile kernel): the window
 // rows' table indices are fetched one piece ahead of the rows themselves, so the prefetch never waits on an index.
 template <bool XROW, bool BWD>
-__global__ __launch_bounds__(kThreads, (XROW && BWD) ? 5 : (XROW || BWD) ? 6 : 7) void spmm_block_kernel(
+__global__ __launch_bounds__(kThreads, BWD ? 4 : XROW ? 6 : 7) void spmm_block_kernel(
     const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col, const float *__restrict__ val,
     const float *__restrict__ X, int64_t ldx, float *__restrict__ Y, int64_t ldy, int32_t H,
     const fitgnn_block_t *__restrict__ blocks, int32_t n_blocks, const int32_t *__restrict__ long_rows, int32_t n_slabs,
@@ -553,12 +553,23 @@ __global__ __launch_bounds__(kThreads, (XROW && BWD) ? 5 : (XROW || BWD) ? 6 : 7
         if (p + 1 < n_pieces) prefetch(r1, min(r1 + kBlkRows, blk.row_end), E1);
 
         // ---- short rows of the piece ----
-        for (int row = r0 + wave; row < r1; row += kWaves) {
+        // backward epilogue: the `prev` slices of ALL this wave's rows of the piece are requested up front -- one at a time, at the
+        // top of each row, every row of the wave waited out a memory round trip of its own (the aggregation itself runs from LDS)
+        T o_pre[kBlkRows / kWaves];
+#pragma unroll
+        for (int j = 0; j < kBlkRows / kWaves; ++j) {
+            const int row = r0 + wave + j * kWaves;
+            o_pre[j] = prev_row<4, BWD>(rowepi, min(row, r1 - 1), col0, H, live);
+        }
+#pragma unroll
+        for (int j = 0; j < kBlkRows / kWaves; ++j) {
+            const int row = r0 + wave + j * kWaves;
+            if (row >= r1) break;  // wave-uniform
             bool is_long = false;
 #pragma unroll
             for (int i = 0; i < kBlkLong; ++i) is_long |= (row == lid[i]);
             if (is_long) continue;  // wave-uniform
-            const T o_prev = prev_row<4, BWD>(rowepi, row, col0, H, live);
+            const T o_prev = o_pre[j];
             const int lr = row - r0;
             const int e0 = __builtin_amdgcn_readfirstlane(s_rp[lr]);
             const int e1 = __builtin_amdgcn_readfirstlane(s_rp[lr + 1]);
