@@ -454,6 +454,7 @@ __global__ __launch_bounds__(256) void head_rows_kernel(const float *__restrict_
 #pragma unroll
             for (int r = 0; r < kHeadRows; ++r) acc[r] = 0.f;
             const float *wr = w_lds + (size_t)(live ? c : 0) * HP;
+#pragma unroll 4   // the loop is a chain of LDS round trips otherwise: four iterations' reads in flight
             for (int h4 = part; h4 < H4; h4 += P) {
                 const float4 w = *reinterpret_cast<const float4 *>(wr + 4 * h4);
 #pragma unroll

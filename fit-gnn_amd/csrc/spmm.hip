@@ -417,37 +417,8 @@ __global__ __launch_bounds__(kThreads, BWD ? 4 : XROW ? 6 : 7) void spmm_block_k
 #pragma unroll
     for (int i = 0; i < 4; ++i) bv[i] = ((epi & FITGNN_EPI_BIAS) && live) ? bias[col0 + i] : 0.f;
 
-    // ---- the block's long rows: ids to LDS, their operand rows pinned, this wave's two accumulators and entry cursors ----
-    if ((int)threadIdx.x < kBlkLong) s_long[threadIdx.x] = (int)threadIdx.x < n_long ? long_rows[blk.long_off + threadIdx.x] : -1;
-    if (XROW && (int)threadIdx.x < 64) s_win[kZeroSlot * 64 + threadIdx.x] = P::zero();
     const bool has_zero = XROW && zero_from >= 0;
     auto is_zero_row = [&](int64_t opr) { return has_zero && opr >= (int64_t)zero_from; };
-    int my_long[kBlkLW], cur[kBlkLW], end[kBlkLW], pos[kBlkLW], lc[kBlkLW], lcx[kBlkLW];
-    float lv[kBlkLW];
-    T acc_long[kBlkLW];
-#pragma unroll
-    for (int q = 0; q < kBlkLW; ++q) {
-        const int slot = wave + q * kWaves;
-        my_long[q] = slot < n_long ? long_rows[blk.long_off + slot] : -1;
-        my_long[q] = __builtin_amdgcn_readfirstlane(my_long[q]);
-        acc_long[q] = P::zero();
-        cur[q] = end[q] = 0;
-        pos[q] = 64;  // "chunk exhausted": the first use loads entries [cur, cur + 64)
-        lc[q] = 0x7fffffff;
-        lcx[q] = 0;
-        lv[q] = 0.f;
-        if (my_long[q] >= 0) {
-            cur[q] = __builtin_amdgcn_readfirstlane(rowptr[my_long[q]]);
-            end[q] = __builtin_amdgcn_readfirstlane(rowptr[my_long[q] + 1]);
-            const int64_t lr_src = src(my_long[q]);
-            s_win[(kBlkRows + slot) * 64 + lane] = is_zero_row(lr_src) ? P::zero() : *reinterpret_cast<const T *>(Xs + lr_src * ldx);
-        }
-    }
-    __syncthreads();
-    int lid[kBlkLong];  // the long-row ids, wave-uniform
-#pragma unroll
-    for (int i = 0; i < kBlkLong; ++i) lid[i] = __builtin_amdgcn_readfirstlane(s_long[i]);
-
     // ---- piece prefetch (registers): window rows wave, wave + 4, ...; row pointers; the piece's CSR slice ----
     T pv[4];
     int p_rp = 0, p_c = 0, p_cx = 0, p_E0 = 0;
@@ -481,9 +452,44 @@ __global__ __launch_bounds__(kThreads, BWD ? 4 : XROW ? 6 : 7) void spmm_block_k
         }
         p_E0 = E0;
     };
-    const int n_pieces = (blk.row_end - blk.row_begin + kBlkRows - 1) / kBlkRows;
-    fetch_indices(blk.row_begin, min(blk.row_begin + kBlkRows, blk.row_end));
+    // ---- the block's long rows: ids to LDS, their operand rows pinned, this wave's two accumulators and entry cursors ----
+    fetch_indices(blk.row_begin, min(blk.row_begin + kBlkRows, blk.row_end));   // (table row ids of the first piece)
+    if ((int)threadIdx.x < kBlkLong) s_long[threadIdx.x] = (int)threadIdx.x < n_long ? long_rows[blk.long_off + threadIdx.x] : -1;
+    if (XROW && (int)threadIdx.x < 64) s_win[kZeroSlot * 64 + threadIdx.x] = P::zero();
+    int my_long[kBlkLW], cur[kBlkLW], end[kBlkLW], pos[kBlkLW], lc[kBlkLW], lcx[kBlkLW];
+    float lv[kBlkLW];
+    T acc_long[kBlkLW];
+#pragma unroll
+    for (int q = 0; q < kBlkLW; ++q) {
+        const int slot = wave + q * kWaves;
+        my_long[q] = slot < n_long ? long_rows[blk.long_off + slot] : -1;
+        my_long[q] = __builtin_amdgcn_readfirstlane(my_long[q]);
+        acc_long[q] = P::zero();
+        cur[q] = end[q] = 0;
+        pos[q] = 64;  // "chunk exhausted": the first use loads entries [cur, cur + 64)
+        lc[q] = 0x7fffffff;
+        lcx[q] = 0;
+        lv[q] = 0.f;
+    }
+    // the first piece is requested HERE, between the two dependent levels of the long-row set-up (ids above, their row pointers /
+    // operand rows below): issued after it, a workgroup's start was six dependent memory round trips long, now four
     prefetch(blk.row_begin, min(blk.row_begin + kBlkRows, blk.row_end), blk.nnz_begin);
+#pragma unroll
+    for (int q = 0; q < kBlkLW; ++q) {
+        const int slot = wave + q * kWaves;
+        if (my_long[q] >= 0) {
+            cur[q] = __builtin_amdgcn_readfirstlane(rowptr[my_long[q]]);
+            end[q] = __builtin_amdgcn_readfirstlane(rowptr[my_long[q] + 1]);
+            const int64_t lr_src = src(my_long[q]);
+            s_win[(kBlkRows + slot) * 64 + lane] = is_zero_row(lr_src) ? P::zero() : *reinterpret_cast<const T *>(Xs + lr_src * ldx);
+        }
+    }
+    __syncthreads();
+    int lid[kBlkLong];  // the long-row ids, wave-uniform
+#pragma unroll
+    for (int i = 0; i < kBlkLong; ++i) lid[i] = __builtin_amdgcn_readfirstlane(s_long[i]);
+
+    const int n_pieces = (blk.row_end - blk.row_begin + kBlkRows - 1) / kBlkRows;
 
     // A long row's entries OUTSIDE the segment (a segment need not be a whole connected subgraph: the stars of a large
     // cluster are segments of their own, and their centres reference each other) are gathered, eight in flight, before

@@ -511,8 +511,19 @@ def spmm_graph_dz(g, X, prev, epilogue, p=0.0, seed=0, mask=None, want_db=True, 
         cfg.profile.append((ev[0], ev[1], profile_kind or "dz"))
     db = None
     if want_db:
-        db = torch.empty(H, dtype=torch.float32, device=dev)
-        _lib.check(L.fitgnn_colsum_partials_f32(_lib.dptr(part), n_tiles + n_blocks, H, _lib.dptr(db), st), "fitgnn_colsum_partials_f32")
+        n_part = n_tiles + n_blocks
+        if n_part > 8192:
+            # one partial row per star: 166 000 at S-products.  colsum_partials' grid is H / 16 workgroups (0.4 ms for them); fold
+            # contiguous runs of rows first (torch's reduction: deterministic for a fixed shape), then the fixed-order kernel
+            G = 1024
+            per = n_part // G
+            head = part[: G * per].view(G, per, H).sum(1)
+            part2 = torch.cat([head, part[G * per:]]) if n_part > G * per else head
+            db = torch.empty(H, dtype=torch.float32, device=dev)
+            _lib.check(L.fitgnn_colsum_partials_f32(_lib.dptr(part2), int(part2.shape[0]), H, _lib.dptr(db), st), "fitgnn_colsum_partials_f32")
+        else:
+            db = torch.empty(H, dtype=torch.float32, device=dev)
+            _lib.check(L.fitgnn_colsum_partials_f32(_lib.dptr(part), n_part, H, _lib.dptr(db), st), "fitgnn_colsum_partials_f32")
     return Y, db
 
 
