@@ -239,7 +239,8 @@ class CSRGraph:
         device = edge_index.device
         self.device, self.n, self.mode = device, int(num_nodes), mode
         self.planned, self.gather, self.split_large, self.block_limit = planned, gather, split_large, block_limit
-        self.split_min_rows = 1_000_000   # x 2 KiB rows = 2 GB at hidden 512: far beyond the 256-MiB Infinity Cache
+        self.split_min_rows = 600_000   # x 2 KiB rows = 1.2 GB at hidden 512: far beyond the 256-MiB Infinity Cache (an eighth of the
+                                        # S-products union, one rank of 8, is 1.03 M rows and must take the same kernels as the whole)
         # tiles from make_tiles: contiguous windows covering their own rows -> the folded backward kernel applies
         self.fold_ok = (not planned) and (not gather)
         src, dst = edge_index[0].to(torch.int64), edge_index[1].to(torch.int64)

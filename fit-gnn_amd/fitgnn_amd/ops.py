@@ -240,6 +240,18 @@ def gemm_nt_epilogue_bwd(a, b, out, epilogue, p=0.0, seed=0, mask=None, want_db=
     return dZ, db
 
 
+def head_weight_grad_rows(dy_c, out_c, cfg=DEFAULT):
+    """dWl = dy_c^T @ out_c for a head too wide for the epilogue kernel's registers (ogbn-products: 47 classes): the class
+    columns zero-padded to 64 so that the split-K kernel takes it (the library's batched product was the last library GEMM
+    of the step)."""
+    C = dy_c.shape[1]
+    if dy_c.is_cuda and C < 64 and cfg.atb_kernel and cfg.gemm_precision == "high" and dy_c.shape[0] >= 256 and _atb_ok(out_c):
+        pad = torch.zeros((dy_c.shape[0], 64), dtype=torch.float32, device=dy_c.device)
+        pad[:, :C] = dy_c
+        return gemm_atb(pad, out_c, cfg)[:C].contiguous()
+    return mm_at_b(dy_c, out_c, cfg)
+
+
 def mm_at_b(a, b, cfg=DEFAULT):
     """a^T @ b for tall operands a [R, M], b [R, N] (the weight-gradient product dH^T @ X, reduction over all R
     rows): the hand-written split-K kernel where it applies.  Otherwise the library: hipBLASLt serves this huge-K /
@@ -693,7 +705,7 @@ def layer_backward(g, out, epi, p, seed, mask, want_db, dOut=None, dy=None, Wl=N
         inside = want_dWl and bool(L.fitgnn_epilogue_bwd_head_supported(H, C, 1))
         dZc, db, dWl = epilogue_bwd_head_rows_raw(dy, Wl, out, loss_rows, epi, p=p, seed=seed, mask=mask, want_db=want_db, want_dWl=inside)
         if want_dWl and not inside:
-            dWl = mm_at_b(_f32c(dy).index_select(0, loss_rows), out.index_select(0, loss_rows), cfg)
+            dWl = head_weight_grad_rows(_f32c(dy).index_select(0, loss_rows), out.index_select(0, loss_rows), cfg)
         return spmm_graph(g, dZc, transposed=True, cfg=cfg, xrow=_compact_positions(g, loss_rows), profile_kind="compact",
                           zero_from=int(loss_rows.numel())), db, dWl
     if head:
@@ -912,7 +924,7 @@ class FusedGCNLastLayerRows(torch.autograd.Function):
         dZc, db, dWl = epilogue_bwd_head_rows_raw(dy_c, Wl, outc, rows, epi, p=ctx.p if ctx.drop else 0.0, seed=ctx.seed, mask=mask,
                                                   want_db=ctx.has_bias, want_dWl=inside, inputs_compact=True, zero_rows=0)
         if ctx.needs_input_grad[3] and not inside:
-            dWl = mm_at_b(dy_c, outc, cfg)
+            dWl = head_weight_grad_rows(dy_c, outc, cfg)
         dbl = colsum_narrow(dy_c) if ctx.has_bl and ctx.needs_input_grad[4] else None
         dW = mm_at_b(dZc, AHc, cfg) if ctx.needs_input_grad[1] else None  # [H, K]
         dX = None
