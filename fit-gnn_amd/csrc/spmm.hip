@@ -91,6 +91,9 @@ __device__ __forceinline__ void finish_row(typename Pack<VEC>::T acc, int row, i
             P::set(acc, i, d);
             cs[i] += d;
         }
+#ifdef FITGNN_SPMM_NOSTORE
+        if (cs[0] == 12345.678f)
+#endif
         *reinterpret_cast<T *>(Y + (int64_t)row * ldy + col0) = acc;
         return;
     }
@@ -104,6 +107,9 @@ __device__ __forceinline__ void finish_row(typename Pack<VEC>::T acc, int row, i
         }
         P::set(acc, i, z);
     }
+#ifdef FITGNN_SPMM_NOSTORE
+    if (P::get(acc, 0) == 12345.678f)
+#endif
     *reinterpret_cast<T *>(Y + (int64_t)row * ldy + col0) = acc;
 }
 
@@ -358,6 +364,14 @@ __global__ __launch_bounds__(kThreads, (B <= 4 ? (PLAIN ? 8 : 7) : 4)) void spmm
 // gathered from L2 / HBM as in the tile kernel.  A "block" is any run of consecutive rows (a SEGMENT): columns outside it are
 // legal and are gathered too, so a connected subgraph with many centres is cut into one segment per centre (its star) once
 // the rows are laid out star by star (data.SubgraphBatch, layout="star").  H % 4 == 0 only (callers tile otherwise).
+#ifdef FITGNN_SPMM_STAMPS  // make EXTRA=-DFITGNN_SPMM_STAMPS + tools/spmm_stamps.py: where a workgroup of the whole-subgraph kernel spends its cycles
+static __device__ unsigned long long *g_spmm_dbg;   // [workgroups x 8], set by fitgnn_debug_spmm_buffer: plain stores, no atomics
+#define SSTAMP(var) const unsigned long long var = __builtin_readcyclecounter()
+#define SACC(i, a, b) sdbg[i] += (b) - (a)
+#else
+#define SSTAMP(var)
+#define SACC(i, a, b)
+#endif
 constexpr int kBlkRows = 16;   // rows per piece (== the tile kernel's default window)
 constexpr int kBlkLW = 1;      // long rows carried per wave
 constexpr int kBlkLong = 4 * kBlkLW;  // ... per block
@@ -394,6 +408,10 @@ __global__ __launch_bounds__(kThreads, BWD ? 4 : XROW ? 6 : 7) void spmm_block_k
     const int slab = seq % n_slabs;
     const int b = (seq / n_slabs) * 8 + (bid & 7);
     if (b >= n_blocks) return;
+#ifdef FITGNN_SPMM_STAMPS
+    unsigned long long sdbg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    SSTAMP(s_begin);
     const fitgnn_block_t blk = blocks[b];
     if (blk.row_end <= blk.row_begin) return;
     const int lane = threadIdx.x & 63;
@@ -421,6 +439,7 @@ __global__ __launch_bounds__(kThreads, BWD ? 4 : XROW ? 6 : 7) void spmm_block_k
     auto is_zero_row = [&](int64_t opr) { return has_zero && opr >= (int64_t)zero_from; };
     // ---- piece prefetch (registers): window rows wave, wave + 4, ...; row pointers; the piece's CSR slice ----
     T pv[4];
+    T o_nx[kBlkRows / kWaves];   // BWD: the `prev` slices of this wave's rows of the piece being prefetched
     int p_rp = 0, p_c = 0, p_cx = 0, p_E0 = 0;
     float p_v = 0.f;
     int xr_next = 0;  // XROW: lane j < 4 holds the table row of window row wave + 4 j of the NEXT piece to prefetch
@@ -440,6 +459,10 @@ __global__ __launch_bounds__(kThreads, BWD ? 4 : XROW ? 6 : 7) void spmm_block_k
             if (r < r1 && !is_zero_row(sr)) pv[j] = *reinterpret_cast<const T *>(Xs + sr * ldx);   // wave-uniform
         }
         if (XROW) fetch_indices(r1, min(r1 + kBlkRows, blk.row_end));  // the piece after: its rows are requested next time round
+        if (BWD) {
+#pragma unroll
+            for (int j = 0; j < kBlkRows / kWaves; ++j) o_nx[j] = prev_row<4, BWD>(rowepi, min(r0 + wave + j * kWaves, r1 - 1), col0, H, live);
+        }
         p_rp = 0;
         if ((int)threadIdx.x <= r1 - r0) p_rp = rowptr[r0 + threadIdx.x];
         // the slice's end is not known yet (it is rowptr[r1], in flight above): stage the next kBlkMeta entries of the block,
@@ -527,10 +550,16 @@ __global__ __launch_bounds__(kThreads, BWD ? 4 : XROW ? 6 : 7) void spmm_block_k
 #pragma unroll
     for (int q = 0; q < kBlkLW; ++q)
         if (my_long[q] >= 0) gather_long(q, blk.row_begin);
+    SSTAMP(s_loop);
+    SACC(0, s_begin, s_loop);
     for (int p = 0; p < n_pieces; ++p) {
+        SSTAMP(s_p0);
         const int r0 = blk.row_begin + p * kBlkRows, r1 = min(r0 + kBlkRows, blk.row_end);
         const int rows = r1 - r0;
         // ---- publish the prefetched piece ----
+        T o_pre[kBlkRows / kWaves];
+#pragma unroll
+        for (int j = 0; j < kBlkRows / kWaves; ++j) o_pre[j] = o_nx[j];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int r = wave + j * kWaves;
@@ -554,19 +583,17 @@ __global__ __launch_bounds__(kThreads, BWD ? 4 : XROW ? 6 : 7) void spmm_block_k
         // for the acknowledgement of this piece's row stores.  The hand-off only involves LDS: lgkmcnt(0) covers this wave's
         // ds_writes (above) / ds_reads (at the end of the piece).
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        SSTAMP(s_p1);
+        SACC(1, s_p0, s_p1);
         const int E1 = __builtin_amdgcn_readfirstlane(s_rp[rows]);
         const int n_meta = min(E1 - E0, kBlkMeta);
         if (p + 1 < n_pieces) prefetch(r1, min(r1 + kBlkRows, blk.row_end), E1);
 
         // ---- short rows of the piece ----
-        // backward epilogue: the `prev` slices of ALL this wave's rows of the piece are requested up front -- one at a time, at the
-        // top of each row, every row of the wave waited out a memory round trip of its own (the aggregation itself runs from LDS)
-        T o_pre[kBlkRows / kWaves];
-#pragma unroll
-        for (int j = 0; j < kBlkRows / kWaves; ++j) {
-            const int row = r0 + wave + j * kWaves;
-            o_pre[j] = prev_row<4, BWD>(rowepi, min(row, r1 - 1), col0, H, live);
-        }
+        // backward epilogue: the `prev` slices of ALL this wave's rows of a piece travel with the piece's prefetch, one piece ahead --
+        // one at a time, at the top of each row, every row of the wave waited out a memory round trip of its own (the
+        // aggregation itself runs from LDS)
+        // (o_pre: taken from the prefetch at the top of the piece, see below)
 #pragma unroll
         for (int j = 0; j < kBlkRows / kWaves; ++j) {
             const int row = r0 + wave + j * kWaves;
@@ -624,6 +651,8 @@ __global__ __launch_bounds__(kThreads, BWD ? 4 : XROW ? 6 : 7) void spmm_block_k
             if (live) finish_row<4, BWD>(acc, row, col0, H, Y, ldy, bv, rowepi, cs, o_prev);
         }
 
+        SSTAMP(s_p2);
+        SACC(2, s_p1, s_p2);
         // ---- this wave's long rows: the entries whose operand rows sit in this piece (columns < r1), in CSR order ----
 #pragma unroll
         for (int q = 0; q < kBlkLW; ++q) {
@@ -657,8 +686,13 @@ __global__ __launch_bounds__(kThreads, BWD ? 4 : XROW ? 6 : 7) void spmm_block_k
                 if (pos[q] < 64) break;  // the rest of the chunk belongs to later pieces
             }
         }
+        SSTAMP(s_p3);
+        SACC(3, s_p2, s_p3);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // the window is overwritten by the next piece
+        SSTAMP(s_p4);
+        SACC(4, s_p3, s_p4);
     }
+    SSTAMP(s_tail);
 #pragma unroll
     for (int q = 0; q < kBlkLW; ++q) {
         if (my_long[q] < 0) continue;
@@ -667,6 +701,17 @@ __global__ __launch_bounds__(kThreads, BWD ? 4 : XROW ? 6 : 7) void spmm_block_k
         if (live) finish_row<4, BWD>(acc_long[q], my_long[q], col0, H, Y, ldy, bv, rowepi, cs, o_prev);
     }
     if (BWD && col_part) write_col_part<4>(reinterpret_cast<float *>(s_win), cs, col_part, b, H, col0, live);
+#ifdef FITGNN_SPMM_STAMPS
+    {
+        SSTAMP(s_end);
+        SACC(5, s_tail, s_end);
+        sdbg[6] = s_end - s_begin;
+        sdbg[7] = (unsigned long long)n_pieces;
+        if (threadIdx.x == 0 && g_spmm_dbg) {
+            for (int i = 0; i < 8; ++i) g_spmm_dbg[(size_t)blockIdx.x * 8 + i] = sdbg[i];
+        }
+    }
+#endif
 }
 
 // Direct-gather variant for very sparse batches (few non-zeros per row, e.g. PubMed-like subgraphs with
@@ -983,3 +1028,9 @@ extern "C" int fitgnn_spmm_csr_blocks_dz_f32(const int32_t *rowptr, const int32_
     return spmm_blocks_impl(rowptr, col, val, X, ldx, Y, ldy, n_rows, H, blocks, n_blocks, long_rows, xrow, xcol, nullptr,
                             epilogue | FITGNN_EPI_BACKWARD, p_drop, seed, mask, prev, col_part, xrow ? xrow_zero_from : -1, stream);
 }
+
+#ifdef FITGNN_SPMM_STAMPS
+extern "C" int fitgnn_debug_spmm_buffer(unsigned long long *device_buf) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_spmm_dbg), &device_buf, sizeof(device_buf));
+}
+#endif
