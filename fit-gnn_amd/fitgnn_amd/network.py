@@ -97,7 +97,7 @@ class _Base(nn.Module):
                 link = None
         return x
 
-    def embed_and_head(self, x, edge_index, x_index=None, out_rows=None, loss_rows=None):
+    def embed_and_head(self, x, edge_index, x_index=None, out_rows=None, loss_rows=None, compact_logits=False):
         """embed() followed by lt1; on the GPU the last GCN layer and the head form one autograd node.
         x_index (ops.RowIndex, optional): x is a de-duplicated table and union row r is table row x_index.index[r].
         out_rows (csr.RowSubset, optional): return the head's output on those rows only.  The last layer is then
@@ -106,7 +106,9 @@ class _Base(nn.Module):
         loss_rows (int64 index tensor, optional): the caller's promise that only these rows of the result reach its loss
         (run.py:193-204 keeps out[mask]), i.e. that the gradient it sends back is zero elsewhere; the head's weight and bias
         gradients are then reduced over those rows alone, and the head itself is evaluated on those rows alone (the result is
-        zero on the others; the GCN layers still compute every row)."""
+        zero on the others; the GCN layers still compute every row).
+        compact_logits (with loss_rows): the caller accepts the result as [len(loss_rows), C] (the logits of those rows, in their
+        order) when the last layer runs on the loss rows -- check the returned shape: other paths return all rows."""
         L = self.num_layers
         if out_rows is not None:
             return self._embed_and_head_rows(x, edge_index, x_index, out_rows)
@@ -149,7 +151,8 @@ class _Base(nn.Module):
             # aggregate first, then the dense part on the loss rows only; the previous layer's epilogue backward rides on the
             # backward SpMM's store (link)
             return ops.FusedGCNLastLayerRows.apply(x, last.lin.weight, last.bias, self.lt1.weight, self.lt1.bias, g,
-                                                   float(self.dropout_p), bool(self.training), seed, mask, loss_rows, cfg, link)
+                                                   float(self.dropout_p), bool(self.training), seed, mask, loss_rows, cfg, link,
+                                                   bool(compact_logits))
         return ops.FusedGCNLayerHead.apply(x, last.lin.weight, last.bias, self.lt1.weight, self.lt1.bias, g,
                                            float(self.dropout_p), bool(self.training), seed, mask, link, cfg, loss_rows)
 

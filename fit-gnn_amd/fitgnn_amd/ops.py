@@ -878,6 +878,15 @@ class FusedGCNLayerHead(torch.autograd.Function):
         return dX, dW, (db if ctx.has_bias else None), dWl, dbl, None, None, None, None, None, None, None, None
 
 
+def _arange_rows(g, n, device):
+    """int64 [n] = 0..n-1, cached on the graph (row ids of a compact matrix)."""
+    cache = getattr(g, "_arange_rows", None)
+    if cache is None or cache.numel() != n or cache.device != device:
+        cache = torch.arange(n, dtype=torch.int64, device=device)
+        g._arange_rows = cache
+    return cache
+
+
 class FusedGCNLastLayerRows(torch.autograd.Function):
     """FusedGCNLayerHead when only `rows` of the result reach the loss (run.py:193-204 keeps out[mask]; with --extra_node 2 % of a
     union's rows), evaluated aggregate-first:
@@ -890,10 +899,12 @@ class FusedGCNLastLayerRows(torch.autograd.Function):
     (every edge aggregated, as in layer_backward's compact path)."""
 
     @staticmethod
-    def forward(ctx, X, W, b, Wl, bl, g, p, training, seed, mask, rows, cfg, link_in=None):
+    def forward(ctx, X, W, b, Wl, bl, g, p, training, seed, mask, rows, cfg, link_in=None, compact_out=False):
+        """compact_out: return the logits of the kept rows only, [len(rows), C] in the order of `rows`, instead of an [R, C] matrix
+        that is zero elsewhere (the caller's loss then runs on them directly: no [R, C] logits, no [R, C] gradient)."""
         X = _f32c(X)
         rows = rows if rows.dtype == torch.int64 else rows.long()
-        ctx.link_in = link_in
+        ctx.link_in, ctx.compact_out = link_in, bool(compact_out)
         AH = spmm_graph(g, X, cfg=cfg)                                   # [R, K]
         AHc = AH.index_select(0, rows)                                   # [n, K]
         del AH
@@ -905,7 +916,10 @@ class FusedGCNLastLayerRows(torch.autograd.Function):
         if drop:
             epi |= EPI_DROPOUT
         epilogue_fwd_rows_(outc, rows, b, epi, p=p if drop else 0.0, seed=seed, mask=mask if drop else None)
-        y = head_rows(outc, rows, Wl, bl, n_total=g.n)
+        if compact_out:
+            y = head_rows(outc, _arange_rows(g, rows.numel(), rows.device), Wl, bl, n_total=rows.numel())
+        else:
+            y = head_rows(outc, rows, Wl, bl, n_total=g.n)
         # X (the previous layer's output) is kept only when that layer's epilogue backward is applied here, in the SpMM's store
         keep_x = link_in is not None and cfg.fuse_dx_epilogue and X.shape[1] % 4 == 0
         ctx.save_for_backward(W, Wl, AHc, outc, rows, mask if drop else None, X if keep_x else None)
@@ -918,7 +932,7 @@ class FusedGCNLastLayerRows(torch.autograd.Function):
         g, cfg = ctx.g, ctx.cfg
         L = _lib.lib()
         H, C = outc.shape[1], Wl.shape[0]
-        dy_c = _f32c(dy).index_select(0, rows)                           # [n, C]
+        dy_c = _f32c(dy) if ctx.compact_out else _f32c(dy).index_select(0, rows)   # [n, C]
         epi = EPI_ELU | (EPI_DROPOUT if ctx.drop else 0)
         inside = ctx.needs_input_grad[3] and bool(L.fitgnn_epilogue_bwd_head_supported(H, C, 1))
         dZc, db, dWl = epilogue_bwd_head_rows_raw(dy_c, Wl, outc, rows, epi, p=ctx.p if ctx.drop else 0.0, seed=ctx.seed, mask=mask,
@@ -941,7 +955,7 @@ class FusedGCNLastLayerRows(torch.autograd.Function):
                 link.fused, link.db = True, db_prev
             else:
                 dX = spmm_graph(g, dAH, transposed=True, cfg=cfg, xrow=_compact_positions(g, rows), profile_kind="compact", zero_from=n)
-        return dX, dW, (db if ctx.has_bias else None), dWl, dbl, None, None, None, None, None, None, None, None
+        return dX, dW, (db if ctx.has_bias else None), dWl, dbl, None, None, None, None, None, None, None, None, None
 
 
 class FusedGCNLayerDedup(torch.autograd.Function):

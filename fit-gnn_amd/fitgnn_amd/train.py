@@ -118,6 +118,7 @@ class GDTrainer:
         from . import network as _net
         self.fused_loss = (task == "node_cls" and isinstance(model, _net.Classify_node) and next(model.parameters()).is_cuda)
         self._y_train = batch.y.index_select(0, batch.train_idx) if self.fused_loss else None
+        self._train_arange = None
         if prune_unused_rows and self.fused_loss and batch.graph is not None:
             from .csr import RowSubset
             core_rows = torch.nonzero(batch.core).flatten()
@@ -185,9 +186,14 @@ class GDTrainer:
                      else m.embed_and_head(b.x, b.edge_index, out_rows=self.sub))
                 loss = SoftmaxNLL.apply(z, self._train_pos, self._y_train, scale)
             else:
-                z = (m.embed_and_head(b.x_table, b.edge_index, b.row_index, loss_rows=b.train_idx) if self.dedup
-                     else m.embed_and_head(b.x, b.edge_index, loss_rows=b.train_idx))
-                loss = SoftmaxNLL.apply(z, b.train_idx, self._y_train, scale)
+                z = (m.embed_and_head(b.x_table, b.edge_index, b.row_index, loss_rows=b.train_idx, compact_logits=True) if self.dedup
+                     else m.embed_and_head(b.x, b.edge_index, loss_rows=b.train_idx, compact_logits=True))
+                if z.shape[0] == b.train_idx.numel() and z.shape[0] != b.n_rows:   # the logits of the train rows only, in their order
+                    if self._train_arange is None:
+                        self._train_arange = torch.arange(z.shape[0], dtype=torch.int64, device=z.device)
+                    loss = SoftmaxNLL.apply(z, self._train_arange, self._y_train, scale)
+                else:
+                    loss = SoftmaxNLL.apply(z, b.train_idx, self._y_train, scale)
             return self._backward_and_step(loss)
         out = m(b.x_table, b.edge_index, x_index=b.row_index) if self.dedup else m(b.x, b.edge_index)
         sel = out.index_select(0, b.train_idx)

@@ -514,6 +514,19 @@ def test_loss_rows_hint_changes_nothing_the_loss_sees(mods):
                 assert rel(a, b) < 2e-4, (name, p_drop)
     m._inject_masks = None
     m.set_op_config(ops.DEFAULT)
+    # compact_logits: the same logits as a [len(rows), C] matrix in the order of loss_rows, and the same gradients through it
+    m.dropout_p = 0.0
+    m.zero_grad()
+    zc = m.embed_and_head(batch.x, batch.edge_index, loss_rows=idx, compact_logits=True)
+    assert zc.shape == (idx.numel(), 5)
+    torch.nn.functional.nll_loss(torch.log_softmax(zc, 1), batch.y.index_select(0, idx), reduction="sum").backward()
+    gc = [p.grad.clone() for p in m.parameters()]
+    m.zero_grad()
+    zf = m.embed_and_head(batch.x, batch.edge_index, loss_rows=idx)
+    torch.nn.functional.nll_loss(torch.log_softmax(zf.index_select(0, idx), 1), batch.y.index_select(0, idx), reduction="sum").backward()
+    assert torch.equal(zc, zf.index_select(0, idx))
+    for a, b in zip(gc, [p.grad for p in m.parameters()]):
+        assert rel(a, b) < 1e-6
 
 
 def test_forward_epilogue_on_compact_rows_is_the_spmm_epilogue(mods):
