@@ -64,10 +64,14 @@ struct RowEpilogue {
     const float *prev;
 };
 // BWD_OK == false compiles the backward mode out (the whole-subgraph kernel's forward instantiations sit at their register limit)
-template <int VEC, bool BWD_OK = true>
+template <int VEC, bool BWD_OK = true, bool NOEPI = false>
 __device__ __forceinline__ void finish_row(typename Pack<VEC>::T acc, int row, int col0, int H, float *__restrict__ Y,
                                            int64_t ldy, const float (&bv)[VEC], const RowEpilogue &E, float (&cs)[VEC],
                                            const typename Pack<VEC>::T &o) {
+    if (NOEPI) {  // a plain product (the launcher saw epilogue == 0): nothing but the store
+        *reinterpret_cast<typename Pack<VEC>::T *>(Y + (int64_t)row * ldy + col0) = acc;
+        return;
+    }
     // o: the row's slice of E.prev, requested by the caller BEFORE it aggregated the row (prev_row): the load rides under the row's
     // gathers instead of standing between the last FMA and the store
     using P = Pack<VEC>;
@@ -143,7 +147,7 @@ __device__ __forceinline__ void write_col_part(float *red, const float (&cs)[VEC
 // what hides the fetch -> compute -> store-acknowledge latency chain of a tile (~8 us under load) at HBM rate.
 // PLAIN: contiguous windows and no row indirection (lcol == win_cols == xrow == NULL), the hidden layers' production case:
 // the column -> operand-row translation folds to an addition and the row loop carries no per-entry scalar branches.
-template <int VEC, int B, int MPR, bool PLAIN>
+template <int VEC, int B, int MPR, bool PLAIN, bool NOEPI = false>
 __global__ __launch_bounds__(kThreads, (B <= 4 ? (PLAIN ? 8 : 7) : 4)) void spmm_tile_kernel(
     const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col, const float *__restrict__ val,
     const float *__restrict__ X, int64_t ldx, float *__restrict__ Y, int64_t ldy, int32_t H,
@@ -336,9 +340,9 @@ __global__ __launch_bounds__(kThreads, (B <= 4 ? (PLAIN ? 8 : 7) : 4)) void spmm
                 P::fma(acc, w0, x0); P::fma(acc, w1, x1); P::fma(acc, w2, x2); P::fma(acc, w3, x3);
             }
         }
-        if (live) finish_row<VEC>(acc, row, col0, H, Y, ldy, bv, rowepi, cs, o_prev);
+        if (live) finish_row<VEC, true, NOEPI>(acc, row, col0, H, Y, ldy, bv, rowepi, cs, o_prev);
     }
-    if ((epi & FITGNN_EPI_BACKWARD) && col_part)   // wave-uniform, every wave of the workgroup gets here
+    if (!NOEPI && (epi & FITGNN_EPI_BACKWARD) && col_part)   // wave-uniform, every wave of the workgroup gets here
         write_col_part<VEC>(reinterpret_cast<float *>(lds_raw), cs, col_part, t, H, col0, live);
 }
 
@@ -380,7 +384,7 @@ constexpr int kBlkMeta = 128;  // CSR entries of a piece staged in LDS (threads 
 
 // XROW: operand row r of the pattern lives at X[xrow[r]] (a de-duplicated operand table, as in the tile kernel): the window
 // rows' table indices are fetched one piece ahead of the rows themselves, so the prefetch never waits on an index.
-template <bool XROW, bool BWD>
+template <bool XROW, bool BWD, bool NOEPI = false>
 __global__ __launch_bounds__(kThreads, BWD ? 4 : XROW ? 6 : 7) void spmm_block_kernel(
     const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col, const float *__restrict__ val,
     const float *__restrict__ X, int64_t ldx, float *__restrict__ Y, int64_t ldy, int32_t H,
@@ -648,7 +652,7 @@ __global__ __launch_bounds__(kThreads, BWD ? 4 : XROW ? 6 : 7) void spmm_block_k
                     P::fma(acc, w0, x0); P::fma(acc, w1, x1); P::fma(acc, w2, x2); P::fma(acc, w3, x3);
                 }
             }
-            if (live) finish_row<4, BWD>(acc, row, col0, H, Y, ldy, bv, rowepi, cs, o_prev);
+            if (live) finish_row<4, BWD, NOEPI>(acc, row, col0, H, Y, ldy, bv, rowepi, cs, o_prev);
         }
 
         SSTAMP(s_p2);
@@ -698,7 +702,7 @@ __global__ __launch_bounds__(kThreads, BWD ? 4 : XROW ? 6 : 7) void spmm_block_k
         if (my_long[q] < 0) continue;
         const T o_prev = prev_row<4, BWD>(rowepi, my_long[q], col0, H, live);
         gather_long(q, 0x7fffffff);
-        if (live) finish_row<4, BWD>(acc_long[q], my_long[q], col0, H, Y, ldy, bv, rowepi, cs, o_prev);
+        if (live) finish_row<4, BWD, NOEPI>(acc_long[q], my_long[q], col0, H, Y, ldy, bv, rowepi, cs, o_prev);
     }
     if (BWD && col_part) write_col_part<4>(reinterpret_cast<float *>(s_win), cs, col_part, b, H, col0, live);
 #ifdef FITGNN_SPMM_STAMPS
@@ -885,7 +889,7 @@ inline size_t lds_bytes_for(int lds_rows, int slab_floats, int mpr) {
     return (size_t)lds_rows * slab_floats * 4 + (size_t)((lds_rows + 1 + 3) / 4 * 4) * 4 + (size_t)lds_rows * mpr * 8;
 }
 
-template <int VEC, int B, int MPR, bool PLAIN>
+template <int VEC, int B, int MPR, bool PLAIN, bool NOEPI = false>
 int launch_tile(const int32_t *rowptr, const int32_t *col, const float *val, const float *X, int64_t ldx, float *Y,
                 int64_t ldy, int32_t H, const fitgnn_tile_t *tiles, int32_t n_tiles, const int32_t *lcol,
                 const int32_t *win_cols, const int32_t *xrow, int32_t lds_rows, int n_slabs, int tiles_per_xcd,
@@ -894,12 +898,12 @@ int launch_tile(const int32_t *rowptr, const int32_t *col, const float *val, con
     constexpr int SLAB = 64 * VEC;
     const size_t lds_bytes = lds_bytes_for(lds_rows, SLAB, MPR);
     if (lds_bytes > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void *)spmm_tile_kernel<VEC, B, MPR, PLAIN>,
+        hipError_t e = hipFuncSetAttribute((const void *)spmm_tile_kernel<VEC, B, MPR, PLAIN, NOEPI>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return (int)e;
     }
     dim3 grid(tiles_per_xcd * 8 * n_slabs);
-    hipLaunchKernelGGL((spmm_tile_kernel<VEC, B, MPR, PLAIN>), grid, dim3(kThreads), lds_bytes, s, rowptr, col, val, X, ldx, Y, ldy,
+    hipLaunchKernelGGL((spmm_tile_kernel<VEC, B, MPR, PLAIN, NOEPI>), grid, dim3(kThreads), lds_bytes, s, rowptr, col, val, X, ldx, Y, ldy,
                        H, tiles, n_tiles, tiles_per_xcd, n_slabs, lds_rows, lcol, win_cols, xrow, bias, epi, p_drop, seed, mask, prev, col_part, zero_from);
     return (int)hipGetLastError();
 }
@@ -919,6 +923,11 @@ int launch(const int32_t *rowptr, const int32_t *col, const float *val, const fl
         return (int)hipGetLastError();
     }
     const int lds_rows = window_rows > 0 ? std::min(window_rows, kMaxWindowRows) : kDefaultWindowRows;
+    // a plain product (no epilogue flag): the instantiation whose rows leave with a bare store
+    if (lds_rows <= kSmallWindowRows && !lcol && !win_cols && !xrow &&
+        (epi & (FITGNN_EPI_BIAS | FITGNN_EPI_ELU | FITGNN_EPI_DROPOUT | FITGNN_EPI_BACKWARD)) == 0)
+        return launch_tile<VEC, 4, 16, true, true>(rowptr, col, val, X, ldx, Y, ldy, H, tiles, n_tiles, lcol, win_cols, xrow, lds_rows, n_slabs,
+                                                   tiles_per_xcd, bias, epi, p_drop, seed, mask, prev, col_part, zero_from, s);
     if (lds_rows <= kSmallWindowRows && !lcol && !win_cols && !xrow)
         return launch_tile<VEC, 4, 16, true>(rowptr, col, val, X, ldx, Y, ldy, H, tiles, n_tiles, lcol, win_cols, xrow, lds_rows, n_slabs,
                                              tiles_per_xcd, bias, epi, p_drop, seed, mask, prev, col_part, zero_from, s);
@@ -983,8 +992,13 @@ int spmm_blocks_impl(const int32_t *rowptr, const int32_t *col, const float *val
     hipLaunchKernelGGL((spmm_block_kernel<XR, BW>), grid, dim3(kThreads), 0, (hipStream_t)stream, rowptr, col, val, X, ldx, Y, ldy, H, \
                        blocks, n_blocks, long_rows, n_slabs, bias, epilogue, p_drop, seed, mask, xrow, xcol, prev, col_part, zero_from)
     const bool bwd = (epilogue & FITGNN_EPI_BACKWARD) != 0;
+    const bool noepi = (epilogue & (FITGNN_EPI_BIAS | FITGNN_EPI_ELU | FITGNN_EPI_DROPOUT | FITGNN_EPI_BACKWARD)) == 0;
     if (xrow) { if (bwd) FITGNN_LAUNCH_BLK(true, true); else FITGNN_LAUNCH_BLK(true, false); }
-    else { if (bwd) FITGNN_LAUNCH_BLK(false, true); else FITGNN_LAUNCH_BLK(false, false); }
+    else if (bwd) FITGNN_LAUNCH_BLK(false, true);
+    else if (noepi) hipLaunchKernelGGL((spmm_block_kernel<false, false, true>), grid, dim3(kThreads), 0, (hipStream_t)stream, rowptr, col, val, X, ldx, Y,
+                                       ldy, H, blocks, n_blocks, long_rows, n_slabs, bias, epilogue, p_drop, seed, mask, xrow, xcol, prev, col_part,
+                                       zero_from);
+    else FITGNN_LAUNCH_BLK(false, false);
 #undef FITGNN_LAUNCH_BLK
     return (int)hipGetLastError();
 }
