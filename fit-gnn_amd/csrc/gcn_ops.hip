@@ -236,8 +236,10 @@ __global__ __launch_bounds__(kColsumPhases * kColsumCols) void colsum_partials_k
     const int cl = threadIdx.x % kColsumCols, ph = threadIdx.x / kColsumCols;
     const int h = blockIdx.x * kColsumCols + cl;
     float s = 0.f;
-    if (h < H)
+    if (h < H) {
+#pragma unroll 8   // eight loads in flight, added in the same order
         for (int c = ph; c < n_chunks; c += kColsumPhases) s += partial[(int64_t)c * H + h];
+    }
     red[ph][cl] = s;
     __syncthreads();
     for (int w = kColsumPhases / 2; w >= 1; w >>= 1) {
