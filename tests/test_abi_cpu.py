@@ -50,6 +50,16 @@ def test_bad_arguments_are_rejected_without_touching_the_gpu():
     assert L.fitgnn_spmm_csr_f32(None, None, None, None, 4, None, 4, 0, 4, None, 0, None, None, None, -1, 0, None, 0, 0.0, 0, None, None) == 0
     # the backward-epilogue flag belongs to the *_dz_* entry points only
     assert L.fitgnn_spmm_csr_f32(None, None, None, None, 4, None, 4, 8, 4, None, 1, None, None, None, -1, 0, None, 0x10, 0.0, 0, None, None) == -1
+    # the loss-row entry points: argument errors before any GPU work
+    assert L.fitgnn_head_rows_f32(None, 512, None, -1, None, None, 3, 512, None, 3, 0, None) == -1       # negative row count
+    assert L.fitgnn_head_rows_f32(None, 510, None, 4, None, None, 3, 510, None, 3, 0, None) == -1        # H % 4 != 0
+    assert L.fitgnn_head_rows_f32(None, 512, None, 0, None, None, 3, 512, None, 3, 0, None) == 0         # nothing to do
+    assert L.fitgnn_head_rows_lds_bytes(512, 47) == (47 * 516 + 4 * 4 * 512) * 4
+    assert L.fitgnn_epilogue_fwd_rows_f32(None, 512, None, 5, 510, None, 0, 0.0, 0, None, None) == -1   # H % 4 != 0
+    assert L.fitgnn_epilogue_fwd_rows_f32(None, 512, None, 0, 512, None, 0, 0.0, 0, None, None) == 0
+    assert L.fitgnn_epilogue_bwd_head_rows_f32(None, None, 3, None, None, 4, 0, None, 512, 0, 0.0, 0, None, None, None, None, 0, None) == -1
+    assert L.fitgnn_spmm_csr_dz_f32(None, None, None, None, 4, None, 4, -1, 4, None, 0, None, None, None, -1, 0, None, 0, 0.0, 0, None, None, None) == -1
+    assert L.fitgnn_spmm_csr_blocks_dz_f32(None, None, None, None, 4, None, 4, 8, 4, None, 1, None, None, None, -1, None, 0, 0.0, 0, None, None, None) == -1
     assert L.fitgnn_variation_costs_f64(None, None, None, None, None, 17, 17, None, None, None, 1, None, None) == -1
     assert L.fitgnn_variation_costs_f64(None, None, None, None, None, 10, 10, None, None, None, 0, None, None) == 0
     assert L.fitgnn_pool_rows_f32(None, None, 5, 0, None, 4, 4, None, 4, None, None, 0, None) == 0
