@@ -896,7 +896,10 @@ int launch_tile(const int32_t *rowptr, const int32_t *col, const float *val, con
                 const float *bias, uint32_t epi, float p_drop, uint64_t seed, const uint8_t *mask, const float *prev, float *col_part,
                 int32_t zero_from, hipStream_t s) {
     constexpr int SLAB = 64 * VEC;
-    const size_t lds_bytes = lds_bytes_for(lds_rows, SLAB, MPR);
+    size_t lds_bytes = lds_bytes_for(lds_rows, SLAB, MPR);
+    // the backward epilogue's column sums pass through LDS once more (write_col_part: kWaves x 64 x VEC floats): a window of
+    // fewer than four rows would be smaller than that scratch
+    if (epi & FITGNN_EPI_BACKWARD) lds_bytes = std::max(lds_bytes, (size_t)kWaves * 64 * VEC * sizeof(float));
     if (lds_bytes > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *)spmm_tile_kernel<VEC, B, MPR, PLAIN, NOEPI>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);

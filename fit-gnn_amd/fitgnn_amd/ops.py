@@ -435,6 +435,24 @@ def spmm_blocks_raw(rowptr, col, val, blocks, long_rows, X, Y, bias=None, epilog
     return Y
 
 
+def _same_index(entry, t):
+    """A cache entry (tensor, version, ...) was built from index tensor `t` as it is now.  The entry HOLDS the tensor it was built
+    from, so that storage cannot be freed and handed to another tensor while the entry lives (a raw address alone can be recycled
+    by the caching allocator); an in-place edit of `t` (or of any alias) moves its version counter."""
+    return (entry is not None and entry[0].data_ptr() == t.data_ptr() and entry[0].numel() == t.numel() and entry[0].dtype == t.dtype
+            and entry[1] == t._version)
+
+
+def _entry_rows(side, xrow):
+    """int32 [nnz]: the operand-table row of every CSR entry of `side` under the row indirection `xrow` (xrow[col[e]]), listed once
+    per (pattern side, index tensor): see fitgnn_spmm_csr_blocks_f32."""
+    cached = getattr(side, "xcol", None)
+    if not _same_index(cached, xrow):
+        cached = (xrow, xrow._version, xrow.index_select(0, side.col.long()).contiguous())
+        side.xcol = cached
+    return cached[2]
+
+
 def spmm_graph(g, X, transposed=False, **kw):
     """SpMM with a CSRGraph (forward or transposed pattern), using its planned tiles and kernel variant.  A batch with
     diagonal blocks larger than the window is covered by two launches on the same stream: the tile kernel over the small
@@ -464,11 +482,7 @@ def spmm_graph(g, X, transposed=False, **kw):
                  xrow=xrow, zero_from=zero_from, **kw)
     xcol = None
     if xrow is not None:   # the table row of every CSR entry, listed once per (pattern side, index): see fitgnn_spmm_csr_blocks_f32
-        cached = getattr(side, "xcol", None)
-        if cached is None or cached[0] != xrow.data_ptr():
-            cached = (xrow.data_ptr(), xrow.index_select(0, side.col.long()).contiguous())
-            side.xcol = cached
-        xcol = cached[1]
+        xcol = _entry_rows(side, xrow)
     spmm_blocks_raw(side.rowptr, side.col, side.val, side.blocks, side.long_rows, Xc, Y, epilogue=epi, cfg=quiet, xrow=xrow, xcol=xcol,
                     zero_from=zero_from, **kw)
     if ev is not None:
@@ -509,11 +523,7 @@ def spmm_graph_dz(g, X, prev, epilogue, p=0.0, seed=0, mask=None, want_db=True, 
     if n_blocks:
         xcol = None
         if xrow is not None:
-            cached = side.xcol
-            if cached is None or cached[0] != xrow.data_ptr():
-                cached = (xrow.data_ptr(), xrow.index_select(0, side.col.long()).contiguous())
-                side.xcol = cached
-            xcol = cached[1]
+            xcol = _entry_rows(side, xrow)
         _lib.check(L.fitgnn_spmm_csr_blocks_dz_f32(_lib.dptr(side.rowptr), _lib.dptr(side.col), _lib.dptr(side.val), _lib.dptr(Xc), Xc.stride(0),
                                                    _lib.dptr(Y), Y.stride(0), g.n, H, _lib.dptr(side.blocks), n_blocks, _lib.dptr(side.long_rows),
                                                    _lib.dptr(xrow), _lib.dptr(xcol), int(zero_from), _lib.dptr(prev), epi_v, float(p), seed_v, _lib.dptr(mask),
@@ -607,10 +617,10 @@ def _compact_positions(g, rows):
     """int32 [g.n]: position of row r in `rows`, len(rows) + r % ZERO_ROWS for the others (a zero row of a compact operand); cached on the graph
     per index tensor (a trainer passes the same loss_rows every step)."""
     cache = getattr(g, "_compact_pos", None)
-    if cache is None or cache[0] != rows.data_ptr() or cache[1] != int(rows.numel()):
+    if not _same_index(cache, rows):
         pos = int(rows.numel()) + torch.arange(g.n, dtype=torch.int32, device=rows.device) % ZERO_ROWS
         pos[rows.long()] = torch.arange(rows.numel(), dtype=torch.int32, device=rows.device)
-        cache = (rows.data_ptr(), int(rows.numel()), pos)
+        cache = (rows, rows._version, pos)
         g._compact_pos = cache
     return cache[2]
 
@@ -951,7 +961,7 @@ class FusedGCNLastLayerRows(torch.autograd.Function):
             if Xprev is not None:
                 # the producing layer's ELU' / dropout' applied as the rows are stored: what travels back on this edge is its dZ
                 dX, db_prev = spmm_graph_dz(g, dAH, Xprev, link.epi, p=link.p, seed=link.seed, mask=link.mask, want_db=link.want_db,
-                                            xrow=_compact_positions(g, rows), cfg=cfg, profile_kind="compact", zero_from=n)
+                                            xrow=_compact_positions(g, rows), cfg=cfg, profile_kind="compact_dz", zero_from=n)
                 link.fused, link.db = True, db_prev
             else:
                 dX = spmm_graph(g, dAH, transposed=True, cfg=cfg, xrow=_compact_positions(g, rows), profile_kind="compact", zero_from=n)

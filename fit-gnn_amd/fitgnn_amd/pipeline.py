@@ -19,7 +19,7 @@ import torch
 import torch.nn.functional as F
 
 from . import coarsening, data as fdata, network
-from .train import GDTrainer, MBTrainer
+from .train import GDTrainer, MBTrainer, broadcast_parameters
 
 SYNTHETIC_SHAPES = {  # name: (N, E, F, classes)   dataset_info.csv:4-7
     "synthetic-cora": (2708, 5278, 1433, 7),
@@ -348,6 +348,8 @@ def node_classification(args, path, data, co, device="cuda", log=print):
             torch.manual_seed(args.seed + run)
         model = network.Classify_node(args).to(device)
         model.reset_parameters()
+        if world > 1:   # the replicated Gc phase and the all-reduced Gs phase both assume ONE set of weights
+            broadcast_parameters(model)
         opt = torch.optim.Adam(model.parameters(), lr=args.lr, weight_decay=args.weight_decay)
         if args.exp_setup in ("Gc_train_2_Gs_infer", "Gc_train_2_Gs_train"):
             best = float("inf")

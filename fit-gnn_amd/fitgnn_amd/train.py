@@ -89,6 +89,25 @@ class FlatAdam:
                 self.step_count.fill_(float(e["step"]))
 
 
+def broadcast_parameters(model, process_group=None, flat=None):
+    """Data parallel: make rank 0's weights (and buffers) everyone's.  The replicated optimiser step keeps the replicas identical
+    only if they START identical, and nothing else guarantees that: an unseeded run (--seed defaults to None, main.py:64 as in the
+    reference) draws different initial weights on every rank.  flat: a FlatAdam whose flat parameter buffer the model's
+    parameters are views of (one broadcast instead of one per tensor).  No-op without an initialised group of > 1 ranks."""
+    dist = torch.distributed
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(process_group) <= 1:
+        return
+    src = dist.get_global_rank(process_group, 0) if process_group is not None else 0
+    with torch.no_grad():
+        if flat is not None:
+            dist.broadcast(flat.P, src, group=process_group)
+        else:
+            for p in model.parameters():
+                dist.broadcast(p.data, src, group=process_group)
+        for b in model.buffers():
+            dist.broadcast(b.data, src, group=process_group)
+
+
 class GDTrainer:
     def __init__(self, model, batch, lr=0.01, weight_decay=5e-4, reduction="mean", process_group=None, dedup=True,
                  task="node_cls", prune_unused_rows=False, op_config=None):
@@ -115,6 +134,8 @@ class GDTrainer:
         self.pg = process_group
         self.dist = process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()
                                                   and torch.distributed.get_world_size() > 1)
+        if self.dist:   # replicas must start from ONE set of weights (whatever seeds the ranks drew theirs from)
+            broadcast_parameters(model, process_group, flat=self.opt if isinstance(self.opt, FlatAdam) else None)
         from . import network as _net
         self.fused_loss = (task == "node_cls" and isinstance(model, _net.Classify_node) and next(model.parameters()).is_cuda)
         self._y_train = batch.y.index_select(0, batch.train_idx) if self.fused_loss else None

@@ -195,6 +195,14 @@ def main(argv=None):
     args = build_parser().parse_args(argv)
     args = arg_correction(args)
     rank, world = init_distributed(args)
+    if world > 1 and args.seed is None:
+        # unseeded (the default, as in the reference): every rank would draw its own weights, splits and dropout seeds, while the
+        # data-parallel step assumes ONE run replicated -- rank 0 draws the run's seed and every rank uses it
+        box = [int(np.random.SeedSequence().generate_state(1)[0] % (2 ** 31))]
+        torch.distributed.broadcast_object_list(box, src=0)
+        args.seed = box[0]
+        if rank == 0:
+            print(f"data parallel run without --seed: rank 0 drew seed {args.seed} for every rank")
     if args.seed is not None:
         np.random.seed(args.seed)
         torch.manual_seed(args.seed)

@@ -85,6 +85,50 @@ def test_two_rank_step_equals_single_process():
         assert np.array_equal(res[0][2][k], res[1][2][k]), f"ranks diverged on {k}"
 
 
+def _unseeded_worker(rank, world, port, out_q):
+    sys.path.insert(0, os.path.join(ROOT, "fit-gnn_amd"))
+    from fitgnn_amd import train
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
+    x, y = _data()
+    lo, hi = (0, 25) if rank == 0 else (25, 60)
+    torch.manual_seed(100 + 17 * rank)   # what an unseeded launch amounts to: every rank draws its own initial weights
+    model = TinyModel(8, 3)
+    w_own = {k: v.numpy().copy() for k, v in model.state_dict().items()}
+    tr = train.GDTrainer(model, Shard(x[lo:hi], y[lo:hi], torch.arange(0, hi - lo, 2)), lr=0.01, weight_decay=5e-4)
+    w_start = {k: v.numpy().copy() for k, v in model.state_dict().items()}
+    for _ in range(3):
+        tr.step()
+    out_q.put((rank, w_own, w_start, {k: v.numpy().copy() for k, v in model.state_dict().items()}))
+    torch.distributed.destroy_process_group()
+
+
+def test_ranks_that_drew_different_weights_train_one_model():
+    """--seed defaults to None (main.py:64, as in the reference): each rank then initialises its model from its own generator
+    state.  GDTrainer broadcasts rank 0's weights before the first step, so the replicas start -- and, stepping on one
+    all-reduced gradient, stay -- identical."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_unseeded_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (_, own0, start0, end0), (_, own1, start1, end1) = res
+    assert any(not np.array_equal(own0[k], own1[k]) for k in own0), "the ranks were meant to draw different weights"
+    for k in start0:
+        assert np.array_equal(start0[k], own0[k]), f"rank 0 keeps its own {k}"
+        assert np.array_equal(start1[k], own0[k]), f"rank 1 starts from rank 0's {k}"
+        assert np.array_equal(end0[k], end1[k]), f"ranks diverged on {k}"
+        assert not np.array_equal(end0[k], start0[k]), f"{k} did not move"
+
+
 def test_shard_clusters_balances_nnz():
     sys.path.insert(0, os.path.join(ROOT, "fit-gnn_amd"))
     from fitgnn_amd.data import shard_clusters

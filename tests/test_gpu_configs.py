@@ -1,5 +1,7 @@
-"""GPU tier: BASELINE.json's configurations at their full sizes through the path bench.py times (GDTrainer: de-duplicated
-layer-0 table with the direct-gather SpMM, linked epilogues, fused head, fused loss, hidden 512).
+"""GPU tier: BASELINE.json's configurations at their full sizes through the path bench.py times -- GDTrainer.step's own call
+(train.py:189: de-duplicated layer-0 table, embed_and_head(loss_rows=train_idx, compact_logits=True) -> aggregate-first last
+layer on the loss rows, compact dZ, fused-derivative backward SpMM, fused loss; hidden 512); _fast_path asserts through the
+launch log that those launches ran.
 
 The oracle cannot run the whole union (8.2 M rows at S-products), so each configuration is checked in two links:
   1. sampled loader slices -- a few of the reference's 128-subgraph loader batches (run.py:336) cut out of the union
@@ -48,16 +50,40 @@ def _model(name, seed=2, dropout=0.5):
     return network.Classify_node(args).cuda()
 
 
-def _fast_path(model, batch, scale):
-    """Eval-mode forward + fused loss + backward exactly as GDTrainer.step issues them (dedup table, fused head)."""
+def _fast_path(model, batch, scale, masks=None):
+    """Forward + fused loss + backward EXACTLY as GDTrainer.step issues them (train.py:189): the de-duplicated layer-0 table, then
+    embed_and_head(..., loss_rows=batch.train_idx, compact_logits=True) under the default OpConfig -> ops.FusedGCNLastLayerRows
+    (aggregate-first last layer, head_rows_kernel on the loss rows, compact dZ, the backward SpMM with layer 0's ELU' / dropout'
+    in its store), the fused softmax + NLL on the compact logits.  masks=None: eval mode (dropout off); a list of two uint8
+    [rows, hidden] masks: training mode with those dropout patterns injected (the oracle takes the same ones).
+    Returns (compact logits [len(train_idx), C] in the order of train_idx, loss, gradients, launch kinds seen by cfg.profile);
+    asserts that the timed path really ran: compact logits, a 'compact_dz' backward launch and a 'table' / 'gather' layer-0
+    launch -- a silent fall-back to the all-rows form fails here."""
+    from fitgnn_amd import ops
     from fitgnn_amd.ops import SoftmaxNLL
 
-    model.eval()
+    cfg = ops.OpConfig(profile=[])            # the default switches (what GDTrainer runs under) + the launch log
+    model.set_op_config(cfg)
+    if masks is None:
+        model.eval()
+        model._inject_masks = None
+    else:
+        model.train()
+        model._inject_masks = masks
     model.zero_grad()
-    z = model.embed_and_head(batch.x_table, batch.edge_index, batch.row_index)
-    loss = SoftmaxNLL.apply(z, batch.train_idx, batch.y.index_select(0, batch.train_idx), scale)
+    idx = batch.train_idx
+    z = model.embed_and_head(batch.x_table, batch.edge_index, batch.row_index, loss_rows=idx, compact_logits=True)
+    assert z.shape[0] == idx.numel() and z.shape[0] != batch.n_rows, "the last layer did not run on the loss rows"
+    ar = torch.arange(z.shape[0], dtype=torch.int64, device=z.device)
+    loss = SoftmaxNLL.apply(z, ar, batch.y.index_select(0, idx), scale)
     loss.backward()
-    return z.detach(), float(loss), {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+    torch.cuda.synchronize()
+    kinds = [k for _, _, k in cfg.profile]
+    assert "compact_dz" in kinds, kinds       # the last layer's backward SpMM: compact operand + fused derivative
+    assert any(k in ("table", "gather") for k in kinds), kinds   # layer 0 on the de-duplicated table
+    model._inject_masks = None
+    model.set_op_config(ops.DEFAULT)
+    return z.detach(), float(loss), {k: p.grad.detach().clone() for k, p in model.named_parameters()}, kinds
 
 
 def test_partition_properties(cfg):
@@ -78,6 +104,9 @@ def test_partition_properties(cfg):
 
 
 def test_sampled_loader_slices_match_the_oracle_and_the_full_union(cfg):
+    """The step bench.py times (GDTrainer.step's call: see _fast_path) against the oracle, at hidden 512 and the configuration's
+    class count: compact logits == the oracle's log-probabilities on the train rows (<= 1e-4), loss, every gradient (<= 1e-3),
+    in eval mode on four loader slices and in training mode (injected dropout masks) on one."""
     from fitgnn_amd import data, workloads
     from oracle import gnn_oracle as gorc
 
@@ -87,26 +116,42 @@ def test_sampled_loader_slices_match_the_oracle_and_the_full_union(cfg):
     sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
     full = workloads.batch_from_subgraphs(name, sub, cfg["dev"], cfg["X"], cfg["y"])
     scale = 1.0 / float(full.train_idx.numel())
-    z_full, loss_full, g_full = _fast_path(model, full, scale)
+    z_full, loss_full, g_full, kinds_full = _fast_path(model, full, scale)
     assert np.isfinite(loss_full)
+    if name == "S-products":   # the union whose stars go to the whole-subgraph kernel: all four launches of the step ran
+        assert full.graph.f.blocks is not None and kinds_full.count("tile") == 2, kinds_full
+    full_idx = full.train_idx
     n_batches = (n_c + 127) // 128
     picks = sorted({0, n_batches // 3, (2 * n_batches) // 3, n_batches - 1})
     ptr = sub["ptr"].cpu().numpy()
     for b in picks:
         clusters = np.arange(b * 128, min((b + 1) * 128, n_c))
         part = workloads.batch_from_subgraphs(name, data.select_clusters(sub, clusters), cfg["dev"], cfg["X"], cfg["y"])
-        z, loss, g = _fast_path(model, part, scale)
+        z, loss, g, _ = _fast_path(model, part, scale)
         r0, r1 = int(ptr[clusters[0]]), int(ptr[clusters[-1] + 1])
         assert part.n_rows == r1 - r0
-        # link 2: the full union's rows of this slice == the slice run
-        assert rel(z_full[r0:r1].cpu(), z.cpu()) < 2e-5, (name, b)
+        # link 2: the full union's logits of this slice's train rows == the slice run
+        lo, hi = (int(v) for v in torch.searchsorted(full_idx, torch.tensor([r0, r1], device=full_idx.device)))
+        assert hi - lo == z.shape[0] and torch.equal(full_idx[lo:hi] - r0, part.train_idx)
+        assert rel(z_full[lo:hi].cpu(), z.cpu()) < 2e-5, (name, b)
         # link 1: the slice run == the oracle
+        tm = part.train_mask.cpu()
         o_ref, l_ref, g_ref = gorc.classify_node_fwd_bwd(sd, part.x.cpu(), part.edge_index.cpu(), part.y.cpu(), num_layers=2,
-                                                         train_mask=part.train_mask.cpu(), loss_scale=scale)
-        assert rel(torch.log_softmax(z, 1).cpu(), o_ref) < 1e-4, (name, b)   # Classify_node's output (network.py:35)
+                                                         train_mask=tm, loss_scale=scale)
+        assert rel(torch.log_softmax(z, 1).cpu(), o_ref[tm]) < 1e-4, (name, b)   # Classify_node's output (network.py:35) on out[mask] (run.py:193-204)
         assert abs(loss - float(l_ref)) <= 1e-4 * abs(float(l_ref)), (name, b, loss, float(l_ref))
         for k in g:
             assert rel(g[k].cpu(), g_ref[k]) < 1e-3, (name, b, k)
+        if b == picks[1]:   # the same slice in TRAINING mode: dropout patterns injected on both sides
+            torch.manual_seed(17 + b)
+            masks = [(torch.rand(part.n_rows, 512, device=cfg["dev"]) > 0.5).to(torch.uint8) for _ in range(2)]
+            zt, losst, gt, kinds = _fast_path(model, part, scale, masks=masks)
+            o_ref, l_ref, g_ref = gorc.classify_node_fwd_bwd(sd, part.x.cpu(), part.edge_index.cpu(), part.y.cpu(), num_layers=2,
+                                                             train_mask=tm, masks=[m.cpu() for m in masks], loss_scale=scale)
+            assert rel(torch.log_softmax(zt, 1).cpu(), o_ref[tm]) < 1e-4, (name, b, "train")
+            assert abs(losst - float(l_ref)) <= 1e-4 * abs(float(l_ref)), (name, b, losst, float(l_ref))
+            for k in gt:
+                assert rel(gt[k].cpu(), g_ref[k]) < 1e-3, (name, b, k, "train")
         del part
 
 
@@ -119,7 +164,7 @@ def test_gradient_is_additive_over_shards(cfg):
     model = _model(name)
     full = workloads.batch_from_subgraphs(name, sub, cfg["dev"], cfg["X"], cfg["y"])
     scale = 1.0 / float(full.train_idx.numel())
-    _, loss_full, g_full = _fast_path(model, full, scale)
+    _, loss_full, g_full, _ = _fast_path(model, full, scale)
     del full
     world = 3
     owner = data.shard_clusters(None, cfg["nnz_c"], world)
@@ -128,7 +173,7 @@ def test_gradient_is_additive_over_shards(cfg):
     acc, loss_sum = None, 0.0
     for k in range(world):
         part = workloads.batch_from_subgraphs(name, data.select_clusters(sub, np.nonzero(owner == k)[0]), cfg["dev"], cfg["X"], cfg["y"])
-        _, loss, g = _fast_path(model, part, scale)
+        _, loss, g, _ = _fast_path(model, part, scale)
         loss_sum += loss
         acc = g if acc is None else {n: acc[n] + g[n] for n in g}
         del part
@@ -235,17 +280,34 @@ def test_qm9_sampled_batches_match_the_literal_per_subgraph_loops(qm9):
 
 def test_qm9_training_epoch_from_captured_steps(qm9):
     """One Gs training epoch over the 65 415 training graphs (utils.py:33: half of the dataset), 512 steps of 128 graphs
-    replayed from hipGraphs: finite losses and moving weights (the reference never clears the gradients inside an epoch,
+    replayed from hipGraphs, against the SAME epoch run eagerly from the same weights (dropout off, so that the two do not
+    depend on how their dropout seeds are drawn): the reported epoch loss and the weights after the epoch agree; then a second
+    captured epoch with dropout on: finite loss, weights keep moving (the reference never clears the gradients inside an epoch,
     run.py:257,291 -- reproduced -- so the loss need not fall from one epoch to the next at this step count)."""
     from fitgnn_amd import network, train
 
     gset, n = qm9["gset"], qm9["n"]
+    graphs = list(range(n // 2))
+    runs = {}
+    for capture in (True, False):
+        args = argparse.Namespace(num_layers1=2, layer_name="GCNConv", num_features=11, hidden=512, num_classes=1, dropout=0.0)
+        torch.manual_seed(5)
+        model = network.Regress_graph_gs(args).cuda()
+        tr = train.GraphTrainer(model, gset, graphs, kind="gs", batch_size=128, lr=0.001, capture=capture)
+        assert len(tr.batches) == (n // 2 + 127) // 128
+        loss = float(tr.step())
+        runs[capture] = (loss, {k: v.detach().clone() for k, v in model.state_dict().items()})
+    l_cap, w_cap = runs[True]
+    l_eag, w_eag = runs[False]
+    assert np.isfinite(l_cap) and abs(l_cap - l_eag) <= 1e-4 * abs(l_eag), (l_cap, l_eag)
+    for k in w_cap:
+        assert rel(w_cap[k], w_eag[k]) < 1e-3, k
+    # dropout on (device-resident seeds advanced inside the captured steps)
     args = argparse.Namespace(num_layers1=2, layer_name="GCNConv", num_features=11, hidden=512, num_classes=1)
     torch.manual_seed(5)
     model = network.Regress_graph_gs(args).cuda()
     w0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
-    tr = train.GraphTrainer(model, gset, list(range(n // 2)), kind="gs", batch_size=128, lr=0.001, capture=True)
-    assert len(tr.batches) == (n // 2 + 127) // 128
+    tr = train.GraphTrainer(model, gset, graphs, kind="gs", batch_size=128, lr=0.001, capture=True)
     l1 = float(tr.step())
     l2 = float(tr.step())
     assert np.isfinite(l1) and np.isfinite(l2)
