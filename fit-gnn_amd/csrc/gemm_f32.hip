@@ -1,0 +1,309 @@
+// gemm_f32.hip -- the dense products of a layer in the REFERENCE's arithmetic: fp32 operands, fp32 products, fp32 accumulation
+// (gfx950 only).
+//
+// GCNConv's Linear (network.py:13-31 through torch_geometric: h = x W^T, no bias) and its backward (grad_x = grad_h W,
+// grad_W = grad_h^T x; run.py:207 `loss.backward()`) are fp32 GEMMs in the reference.  gemm_nt.hip / gemm_atb.hip compute them as
+// three bf16 products of a two-term split (4-5e-6 relative error against fp64: inside north_star's 1e-4 on logits, but narrower than
+// the reference's own arithmetic).  This file is the fp32-faithful form on the matrix cores: v_mfma_f32_32x32x2_f32 multiplies fp32
+// operands exactly and accumulates in fp32 (MI355X_MICROARCH.md: "exact f32, == fmaf chain"; 64 FLOP/clk/SIMD, 157 TFLOP/s dense
+// peak = 1/16 of the bf16 rate), so the result differs from an fp64 product only by fp32 accumulation rounding (measured ~1e-7).
+//
+// ONE kernel serves the three products of a Linear; an operand is either "k-minor" (k contiguous in memory: x [rows x K], W [N x K])
+// or "k-major" (k is the row index: the tall operands of grad_W = dH^T x, and W read as W^T in grad_x = dH W):
+//     forward      c[i][j] = sum_k x[i][k] W[j][k]        A k-minor, B k-minor
+//     grad_x       c[i][j] = sum_k dH[i][k] W[k][j]       A k-minor, B k-major (no transposed copy of W)
+//     grad_W       c[i][j] = sum_r dH[r][i] x[r][j]       A k-major, B k-major, split over the rows r (fixed-order sum: reproducible)
+// Mapping: a workgroup of WM x WN waves owns a (64 WM) x (128 WN) output tile, each wave 2 x 4 MFMA blocks of 32 x 32 (128
+// accumulator registers).  K runs in stages of 32: both operand slabs are staged HBM -> registers -> LDS with 16-byte accesses,
+// double-buffered, one barrier per stage, the next stage's global loads in flight under the current stage's 256 MFMAs per wave.
+// LDS images: k-minor [row][32 k] with a row pitch of 36 dwords (a lane's ds_read_b128 brings the 4 k of four consecutive MFMA steps;
+// pitch 36 keeps the 16-lane read groups on distinct banks), k-major [k][row] as in memory (one ds_read_b32 per MFMA step, lanes on
+// consecutive banks).  The kernel is bound by the fp32 matrix pipe (64 cycles per MFMA and SIMD against 6 LDS reads per 32 MFMAs);
+// operand traffic is (TI + TJ) x 4 bytes per 2 TI TJ flops = 64 flop/byte at 256 x 256, 2.4 TB/s at the fp32 MFMA peak.
+#include <algorithm>
+
+#include "common.h"
+#include "fitgnn_hip.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kBK = 32;     // k per stage
+constexpr int kPitch = 36;  // dwords per row of a k-minor LDS image
+
+template <int WM, int WN, bool AKM, bool BKM>
+struct Geo {
+    static constexpr int TI = 64 * WM, TJ = 128 * WN, THREADS = 64 * WM * WN;
+    static constexpr int A_DW = AKM ? kBK * TI : TI * kPitch;
+    static constexpr int B_DW = BKM ? kBK * TJ : TJ * kPitch;
+    static constexpr int STAGE_DW = A_DW + B_DW;
+    static constexpr int LDS_BYTES = 2 * STAGE_DW * 4;
+    static constexpr int NA = TI * 8 / THREADS, NB = TJ * 8 / THREADS;   // float4 per thread and stage
+    static_assert(LDS_BYTES <= 160 * 1024, "tile does not fit the CU's LDS");
+    static_assert(TI * 8 % THREADS == 0 && TJ * 8 % THREADS == 0, "stage not divisible over the threads");
+};
+
+// One operand slab of a stage, global -> registers.  T rows (k-minor) or T columns (k-major) starting at t0; rows / columns past
+// `lim` are clamped to the last valid ones (they only feed outputs that are never stored), k past `klim` reads as zero.
+template <bool KM, int T, int NV, int THREADS>
+__device__ __forceinline__ void load_slab(float4 (&r)[NV], const float *__restrict__ P, long ld, long t0, long lim, long k0, long klim) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int p = 0; p < NV; ++p) {
+        const int v = tid + p * THREADS;
+        if (!KM) {
+            const int row = v >> 3, k4 = v & 7;
+            long i = t0 + row;
+            i = i < lim ? i : lim - 1;
+            const long k = k0 + 4 * k4;
+            r[p] = k < klim ? *reinterpret_cast<const float4 *>(P + i * ld + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+        } else {
+            constexpr int Q = T / 4;
+            const int kr = v / Q, c4 = v % Q;
+            long i = t0 + 4 * c4;
+            i = i + 4 <= lim ? i : lim - 4;
+            const long k = k0 + kr;
+            r[p] = k < klim ? *reinterpret_cast<const float4 *>(P + k * ld + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+}
+
+template <bool KM, int T, int NV, int THREADS>
+__device__ __forceinline__ void store_slab(const float4 (&r)[NV], float *lds) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int p = 0; p < NV; ++p) {
+        const int v = tid + p * THREADS;
+        if (!KM) {
+            const int row = v >> 3, k4 = v & 7;
+            *reinterpret_cast<float4 *>(lds + row * kPitch + 4 * k4) = r[p];
+        } else {
+            constexpr int Q = T / 4;
+            const int kr = v / Q, c4 = v % Q;
+            *reinterpret_cast<float4 *>(lds + kr * T + 4 * c4) = r[p];
+        }
+    }
+}
+
+// The operand values of block row/column `o` (32 wide) for the four MFMA steps of k-octet kk: lane l holds index o + l % 32 and
+// k = 8 kk + 4 (l / 32) + step.
+template <bool KM, int T>
+__device__ __forceinline__ void frag(float (&f)[4], const float *lds, int o, int kk, int lane) {
+    if (!KM) {
+        const float4 v = *reinterpret_cast<const float4 *>(lds + (o + (lane & 31)) * kPitch + 8 * kk + 4 * (lane >> 5));
+        f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
+    } else {
+        const float *p = lds + (8 * kk + 4 * (lane >> 5)) * T + o + (lane & 31);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) f[s] = p[s * T];
+    }
+}
+
+// nchunks > 1: split over k.  Workgroup (chunk, tile) reduces k in [chunk * chunk_k, +chunk_k) and stores its tile into
+// partial[chunk] (an [I x J] matrix each); sum_chunks_kernel adds them in a fixed order.
+template <int WM, int WN, bool AKM, bool BKM>
+__global__ __launch_bounds__(64 * WM * WN, 1) void gemm_f32_kernel(const float *__restrict__ A, long lda, const float *__restrict__ B, long ldb,
+                                                                   long I, int J, long K, float *__restrict__ C, long ldc, int tiles_i,
+                                                                   int tiles_j, int nchunks, long chunk_k) {
+    using G = Geo<WM, WN, AKM, BKM>;
+    extern __shared__ __attribute__((aligned(16))) float lds_f[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    // block -> (chunk, tile): blocks are dealt round-robin over the 8 XCDs, so give the workgroups that share an operand slab
+    // consecutive slots of ONE XCD (its L2 serves the second read): without a k split the J tiles of a row tile, with one the
+    // tiles of a chunk
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    int ti, tj, chunk = 0;
+    if (nchunks > 1) {
+        const int ntile = tiles_i * tiles_j;
+        const int tile = slot % ntile;
+        chunk = xcd + 8 * (slot / ntile);
+        ti = tile / tiles_j, tj = tile % tiles_j;
+        if (chunk >= nchunks) return;
+    } else {
+        tj = slot % tiles_j;
+        ti = xcd + 8 * (slot / tiles_j);
+        if (ti >= tiles_i) return;
+    }
+    const long i0 = (long)ti * G::TI, j0 = (long)tj * G::TJ;
+    const long k_begin = (long)chunk * chunk_k;
+    const long k_end = nchunks > 1 ? (k_begin + chunk_k < K ? k_begin + chunk_k : K) : K;
+    const int nstage = k_end > k_begin ? (int)((k_end - k_begin + kBK - 1) / kBK) : 0;
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    float4 ra[G::NA], rb[G::NB];
+    if (nstage > 0) {
+        load_slab<AKM, G::TI, G::NA, G::THREADS>(ra, A, lda, i0, I, k_begin, k_end);
+        load_slab<BKM, G::TJ, G::NB, G::THREADS>(rb, B, ldb, j0, (long)J, k_begin, k_end);
+        store_slab<AKM, G::TI, G::NA, G::THREADS>(ra, lds_f);
+        store_slab<BKM, G::TJ, G::NB, G::THREADS>(rb, lds_f + G::A_DW);
+    }
+    __syncthreads();
+    for (int s = 0; s < nstage; ++s) {
+        const float *sa = lds_f + (s & 1) * G::STAGE_DW;
+        const float *sb = sa + G::A_DW;
+        const bool more = s + 1 < nstage;   // workgroup-uniform
+        if (more) {
+            const long k0 = k_begin + (long)(s + 1) * kBK;
+            load_slab<AKM, G::TI, G::NA, G::THREADS>(ra, A, lda, i0, I, k0, k_end);
+            load_slab<BKM, G::TJ, G::NB, G::THREADS>(rb, B, ldb, j0, (long)J, k0, k_end);
+        }
+#pragma unroll
+        for (int kk = 0; kk < kBK / 8; ++kk) {
+            float fa[2][4], fb[4][4];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) frag<AKM, G::TI>(fa[i], sa, wm * 64 + i * 32, kk, lane);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) frag<BKM, G::TJ>(fb[j], sb, wn * 128 + j * 32, kk, lane);
+#pragma unroll
+            for (int st = 0; st < 4; ++st)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][st], fb[j][st], acc[i][j], 0, 0, 0);
+        }
+        if (more) {
+            float *na = lds_f + ((s + 1) & 1) * G::STAGE_DW;
+            store_slab<AKM, G::TI, G::NA, G::THREADS>(ra, na);
+            store_slab<BKM, G::TJ, G::NB, G::THREADS>(rb, na + G::A_DW);
+        }
+        __syncthreads();
+    }
+
+    // C/D layout of the 32 x 32 MFMA: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+    float *out = nchunks > 1 ? C + (long)chunk * I * J : C;
+    const long ldo = nchunks > 1 ? (long)J : ldc;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const long col = j0 + wn * 128 + j * 32 + (lane & 31);
+            const long row0 = i0 + wm * 64 + i * 32 + 4 * (lane >> 5);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long row = row0 + (r & 3) + 8 * (r >> 2);
+                if (row < I && col < J) out[row * ldo + col] = acc[i][j][r];
+            }
+        }
+    }
+}
+
+// out = sum over chunks of partial[chunk] in a fixed order (nchunks a multiple of 8: eight loads in flight per lane)
+__global__ __launch_bounds__(256) void sum_chunks_kernel(const float *__restrict__ partial, int nchunks, long IJ, float *__restrict__ out, int J,
+                                                         long ldc) {
+    const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= IJ) return;
+    float part[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) part[u] = 0.f;
+    for (int c = 0; c < nchunks; c += 8) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) part[u] += partial[(long)(c + u) * IJ + q];
+    }
+    float acc = part[0];
+#pragma unroll
+    for (int u = 1; u < 8; ++u) acc += part[u];
+    out[(q / J) * ldc + (q % J)] = acc;
+}
+
+struct Plan {
+    int wm, wn;          // wave grid of the tile
+    int tiles_i, tiles_j, nchunks;
+    long chunk_k;
+};
+
+Plan make_plan(long I, int J, long K, bool akm, bool bkm) {
+    Plan p;
+    // tile shapes: 256 x 256 by default; a short I (the head's weight gradient: 64 padded class rows) takes 64 x 512, a narrow J
+    // (layer 0's weight gradient on a 100-column table) 256 x 128
+    if (I <= 64 && akm && bkm) { p.wm = 1; p.wn = 4; }
+    else if (J <= 128) { p.wm = 4; p.wn = 1; }
+    else { p.wm = 4; p.wn = 2; }
+    const int TI = 64 * p.wm, TJ = 128 * p.wn;
+    p.tiles_i = (int)((I + TI - 1) / TI);
+    p.tiles_j = (J + TJ - 1) / TJ;
+    p.nchunks = 1;
+    p.chunk_k = K;
+    const long ntile = (long)p.tiles_i * p.tiles_j;
+    if (ntile < 128 && K >= 64 * kBK) {   // too few tiles for 256 CUs and a long reduction: split k
+        long want = (256 + ntile - 1) / ntile;
+        const long most = K / (4 * kBK);   // at least four stages per chunk
+        if (want > most) want = most;
+        p.nchunks = (int)((want + 7) / 8 * 8);
+        const long per = (K + p.nchunks - 1) / p.nchunks;
+        p.chunk_k = (per + kBK - 1) / kBK * kBK;
+    }
+    return p;
+}
+
+template <int WM, int WN, bool AKM, bool BKM>
+int launch(const Plan &p, const float *a, long lda, const float *b, long ldb, long I, int J, long K, float *c, long ldc, hipStream_t s) {
+    using G = Geo<WM, WN, AKM, BKM>;
+    static std::atomic<uint64_t> lds_done{0};
+    if (const int rc = fitgnn_lds_limit_once((const void *)gemm_f32_kernel<WM, WN, AKM, BKM>, G::LDS_BYTES, lds_done)) return rc;
+    unsigned grid;
+    if (p.nchunks > 1) grid = (unsigned)(p.tiles_i * p.tiles_j * p.nchunks);
+    else grid = (unsigned)((p.tiles_i + 7) / 8 * 8 * p.tiles_j);
+    hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, AKM, BKM>), dim3(grid), dim3(G::THREADS), G::LDS_BYTES, s, a, lda, b, ldb, I, J, K, c, ldc,
+                       p.tiles_i, p.tiles_j, p.nchunks, p.chunk_k);
+    return (int)hipGetLastError();
+}
+
+template <bool AKM, bool BKM>
+int launch_shape(const Plan &p, const float *a, long lda, const float *b, long ldb, long I, int J, long K, float *c, long ldc, hipStream_t s) {
+    if constexpr (AKM && BKM) {   // make_plan picks the 64 x 512 tile for this pair only (its k-minor LDS image would not fit)
+        if (p.wm == 1) return launch<1, 4, AKM, BKM>(p, a, lda, b, ldb, I, J, K, c, ldc, s);
+    }
+    if (p.wn == 1) return launch<4, 1, AKM, BKM>(p, a, lda, b, ldb, I, J, K, c, ldc, s);
+    return launch<4, 2, AKM, BKM>(p, a, lda, b, ldb, I, J, K, c, ldc, s);
+}
+
+}  // namespace
+
+extern "C" size_t fitgnn_gemm_exact_workspace_bytes(int64_t I, int32_t J, int64_t K, int32_t a_kmajor, int32_t b_kmajor) {
+    if (I <= 0 || J <= 0 || K <= 0) return 0;
+    const Plan p = make_plan((long)I, J, (long)K, a_kmajor != 0, b_kmajor != 0);
+    return p.nchunks > 1 ? (size_t)p.nchunks * (size_t)I * (size_t)J * sizeof(float) : 0;
+}
+
+extern "C" int fitgnn_gemm_exact_f32(const float *a, int64_t lda, int32_t a_kmajor, const float *b, int64_t ldb, int32_t b_kmajor,
+                                     int64_t I, int32_t J, int64_t K, float *c, int64_t ldc, void *workspace, void *stream) {
+    if (I <= 0 || J <= 0 || K <= 0 || ldc < J) return FITGNN_E_BADARG;
+    if (!a || !b || !c) return FITGNN_E_BADARG;
+    // 16-byte accesses along the contiguous dimension of each operand
+    const int64_t a_inner = a_kmajor ? I : K, b_inner = b_kmajor ? (int64_t)J : K;
+    if (a_inner < 4 || b_inner < 4 || (a_inner % 4) != 0 || (b_inner % 4) != 0 || lda < a_inner || ldb < b_inner || (lda % 4) != 0 ||
+        (ldb % 4) != 0)
+        return FITGNN_E_BADARG;
+    if ((((uintptr_t)a | (uintptr_t)b) % 16) != 0) return FITGNN_E_ALIGN;
+    if (a_kmajor && !b_kmajor) return FITGNN_E_BADARG;   // no caller: (k-major, k-minor) is the transpose of (k-minor, k-major)
+    const Plan p = make_plan((long)I, J, (long)K, a_kmajor != 0, b_kmajor != 0);
+    hipStream_t s = (hipStream_t)stream;
+    float *dst = c;
+    long ldd = (long)ldc;
+    if (p.nchunks > 1) {
+        if (!workspace || ((uintptr_t)workspace % 16) != 0) return FITGNN_E_BADARG;
+        dst = (float *)workspace;
+    }
+    int rc;
+    if (a_kmajor) rc = launch_shape<true, true>(p, a, (long)lda, b, (long)ldb, (long)I, J, (long)K, dst, ldd, s);
+    else if (b_kmajor) rc = launch_shape<false, true>(p, a, (long)lda, b, (long)ldb, (long)I, J, (long)K, dst, ldd, s);
+    else rc = launch_shape<false, false>(p, a, (long)lda, b, (long)ldb, (long)I, J, (long)K, dst, ldd, s);
+    if (rc) return rc;
+    if (p.nchunks > 1) {
+        const long IJ = (long)I * J;
+        hipLaunchKernelGGL(sum_chunks_kernel, dim3((unsigned)((IJ + 255) / 256)), dim3(256), 0, s, (const float *)workspace, p.nchunks, IJ, c, J,
+                           (long)ldc);
+        return (int)hipGetLastError();
+    }
+    return 0;
+}
