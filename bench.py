@@ -17,9 +17,11 @@ nnz'), every rank steps on its shard, one flat RCCL gradient all-reduce per step
 under torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE in the environment) or plainly as `python bench.py --gpus N`:
 the parent then spawns N fresh children itself BEFORE it touches torch or the GPU and relays rank 0's line.
 
-Prints ONE JSON line (rank 0): the metric, `roofline` for the SpMM kernel (HIP events around its launches inside the
-timed region), `ms_per_step_fp32` (the same step with the dense products in plain fp32 instead of the 3 x bf16 split),
-and at N=1 `cpu_baseline` (the torch-CPU oracle of the same step + the C oracle of the contraction, on this host).
+Prints ONE JSON line (rank 0): the metric (dense products in the reference's fp32 arithmetic: csrc/gemm_f32.hip), `roofline` for
+the SpMM kernel over ALL FOUR launches of the step (HIP events around each launch inside the timed region; per-launch entries
+with their own compulsory bytes), `ms_per_step_bf16x3` (the same step with the dense products as a 3 x bf16 split: secondary),
+at N>1 `allreduce_ms` and the ranks' nnz', and at N=1 `cpu_baseline` (the torch-CPU oracle of the same step + the C oracle of the
+contraction, on this host).
 """
 import argparse
 import json
@@ -43,8 +45,10 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--workload", default="S-products", choices=sorted(DEFAULT_STEPS))
     ap.add_argument("--hidden", type=int, default=512)
+    ap.add_argument("--dropout", type=float, default=0.5, help="F.dropout's p (network.py:33: the default 0.5); 0 makes the step "
+                    "deterministic across shardings (the dropout hash is keyed on a rank's own row numbers)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-fp32", action="store_true", help="skip the plain-fp32 re-timing of the step")
+    ap.add_argument("--no-bf16x3", action="store_true", help="skip the re-timing of the step with the dense products as a 3 x bf16 split")
     ap.add_argument("--no-all-rows", action="store_true", help="skip the re-timing with every dense operation over all union rows")
     ap.add_argument("--fold", action="store_true", help="A/B: epilogue backward folded into the transposed SpMM (slower, see DESIGN.md)")
     ap.add_argument("--prune-unused-rows", action="store_true",
@@ -56,9 +60,10 @@ def parse_args():
     ap.add_argument("--no-dedup-gather", action="store_true",
                     help="A/B: layer 0 on the de-duplicated table through the LDS-window SpMM (row indirection) instead of the "
                          "direct-gather variant")
-    ap.add_argument("--gemm-precision", default="high", choices=["high", "highest"],
-                    help="dense GEMM policy of the timed region (ops.OpConfig.gemm_precision): high = fp32 via 3 x bf16 split "
-                         "(rel err ~5e-6), highest = plain fp32 MFMA everywhere")
+    ap.add_argument("--gemm-precision", default="exact", choices=["exact", "high", "highest"],
+                    help="dense GEMM policy of the timed region (ops.OpConfig.gemm_precision): exact = the reference's arithmetic, "
+                         "fp32 products and accumulation on the fp32 MFMA (csrc/gemm_f32.hip); high = 3 x bf16 split (rel err ~5e-6); "
+                         "highest = the library's fp32 kernels")
     ap.add_argument("--spectral", default="device", choices=["device", "arpack"],
                     help="spectral prelude of the contraction (not timed): thick-restart Lanczos on the GPU, or ARPACK on the host")
     args = ap.parse_args()
@@ -184,24 +189,40 @@ def main():
     n_clusters = int(head[1])
     info["clusters"] = n_clusters
 
-    # ---- subgraphs of every cluster (device), this rank's shard, the block-diagonal batch ----------------------------
+    # ---- this rank's subgraphs (device), the block-diagonal batch ---------------------------------------------------------
+    # world > 1: the partition is sharded BEFORE anything is assembled (LPT over a weight every rank computes from the graph and
+    # the partition: workloads.shard_before_assembly), and a rank assembles its own clusters only
     t4 = time.time()
-    sub, nnz_c = workloads.assemble(args.workload, ei_d, assign_d, n_clusters)
+    mine = None
+    if world > 1:
+        owner = workloads.shard_before_assembly(args.workload, ei_d, assign_d, n_clusters, world)
+        mine = np.nonzero(owner == rank)[0]
+    sub, nnz_c = workloads.assemble(args.workload, ei_d, assign_d, n_clusters, clusters=mine)
     torch.cuda.synchronize()
     t5 = time.time()
-    info.update(union_rows=int(sub["ptr"][-1]), nnz_prime=int(nnz_c.sum()), t_assemble_s=round(t5 - t4, 2))
+    mine_sizes = torch.tensor([float(sub["ptr"][-1]), float(nnz_c.sum())], device=device, dtype=torch.float64)
     if world > 1:
-        owner = data.shard_clusters(None, nnz_c, world)         # LPT over nnz' (SURVEY §8e); same on every rank
-        sub = data.select_clusters(sub, np.nonzero(owner == rank)[0])
-        info["shard_nnz_prime"] = [int(nnz_c[owner == k].sum()) for k in range(world)]
+        per_rank = [torch.zeros_like(mine_sizes) for _ in range(world)]
+        if backend == "gloo":
+            host = [t.cpu() for t in per_rank]
+            torch.distributed.all_gather(host, mine_sizes.cpu())
+            per_rank = host
+        else:
+            torch.distributed.all_gather(per_rank, mine_sizes)
+        info["shard_union_rows"] = [int(t[0]) for t in per_rank]
+        info["shard_nnz_prime"] = [int(t[1]) for t in per_rank]
+        info.update(union_rows=sum(info["shard_union_rows"]), nnz_prime=sum(info["shard_nnz_prime"]))
+    else:
+        info.update(union_rows=int(mine_sizes[0]), nnz_prime=int(mine_sizes[1]))
+    info["t_assemble_s"] = round(t5 - t4, 2)
     del ei_d
     batch = workloads.batch_from_subgraphs(args.workload, sub, device)
     torch.cuda.synchronize()
     info["t_batch_csr_s"] = round(time.time() - t5, 2)
     del sub
 
-    def make_trainer(precision, profile=False, loss_rows_only=True):
-        margs = argparse.Namespace(num_layers1=2, layer_name="GCNConv", num_features=F, hidden=H, num_classes=C)
+    def make_trainer(precision, loss_rows_only=True):
+        margs = argparse.Namespace(num_layers1=2, layer_name="GCNConv", num_features=F, hidden=H, num_classes=C, dropout=args.dropout)
         torch.manual_seed(2)  # weight seed; identical on every rank
         model = network.Classify_node(margs).to(device)
         sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
@@ -218,14 +239,19 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    def timed(tr, steps, warmup, events=None):
+    def timed(tr, steps, warmup, per_step_events=None):
         for _ in range(warmup):
             tr.step()
         barrier()
         t0 = time.perf_counter()
         for i in range(steps):
-            # HIP-event pairs around the SpMM launches of every 4th step of the timed region (each marker costs ~1 us)
-            tr.cfg.profile = events if (events is not None and i % 4 == 0) else None
+            # HIP-event pairs around the SpMM launches of every 4th step of the timed region (each marker costs ~1 us); recorded
+            # on the stream the kernels are launched on (ops.spmm_*: torch's current stream = the one handed to the C ABI)
+            if per_step_events is not None and i % 4 == 0:
+                tr.cfg.profile = []
+                per_step_events.append(tr.cfg.profile)
+            else:
+                tr.cfg.profile = None
             loss = tr.step()
         tr.cfg.profile = None
         barrier()
@@ -235,8 +261,16 @@ def main():
         return float(dt.item()), loss
 
     trainer, sd0 = make_trainer(args.gemm_precision)
-    events = []
-    dt, loss = timed(trainer, args.steps, args.warmup, events)
+    step_events = []
+    if world > 1:
+        trainer.comm_events = []
+    dt, loss = timed(trainer, args.steps, args.warmup, step_events)
+    loss_final = float(loss)
+    comm_ms = None
+    if world > 1 and trainer.comm_events:
+        torch.cuda.synchronize()
+        comm_ms = float(np.mean([a.elapsed_time(b) for a, b in trainer.comm_events[args.warmup:]]))
+    trainer.comm_events = None
     # a few more steps, outside the timed region, with events around the hand-written GEMM launches (secondary figures:
     # their markers would cost the headline 1 %)
     trainer.cfg.profile_gemm = []
@@ -253,50 +287,74 @@ def main():
         torch.distributed.all_reduce(edges)
     edges_per_step_total = float(edges.item())
 
-    # the same step with every dense product in plain fp32 (library MFMA fp32 kernels): what the 3 x bf16 split buys
-    fp32 = None
-    if not args.no_fp32 and args.gemm_precision == "high":
-        loss_final = float(loss)
-        tr32, _ = make_trainer("highest")
-        k32 = max(3, min(args.steps, 50))
-        dt32, _ = timed(tr32, k32, max(2, min(args.warmup, 10)))
-        fp32 = dict(ms_per_step=dt32 / k32 * 1e3, value=edges_per_step_total * k32 / dt32, steps=k32)
-        del tr32
-    else:
-        loss_final = float(loss)
-    # the same step with the last layer transform-first and every dense operation over all union rows
-    all_rows = None
-    if not args.no_all_rows:
-        tra, _ = make_trainer(args.gemm_precision, loss_rows_only=False)
-        ka = max(3, min(args.steps, 50))
-        dta, loss_a = timed(tra, ka, max(2, min(args.warmup, 10)))
-        all_rows = dict(ms_per_step=dta / ka * 1e3, value=edges_per_step_total * ka / dta, steps=ka, loss=float(loss_a))
-        del tra
+    def retime(precision, **kw):
+        tr2, _ = make_trainer(precision, **kw)
+        k2 = max(3, min(args.steps, 50))
+        dt2, loss2 = timed(tr2, k2, max(2, min(args.warmup, 10)))
+        return dict(ms_per_step=dt2 / k2 * 1e3, value=edges_per_step_total * k2 / dt2, steps=k2, loss=float(loss2))
 
-    # SpMM roofline: algorithmic bytes of one launch / mean HIP-event duration of the launches in the timed region
-    # (the launches of the LDS-window kernel only: layer 0's forward on the de-duplicated table runs the direct-gather
-    # variant, whose operand is a table that stays in L2 / MALL, not an [R x H] matrix)
-    R = batch.n_rows
-    bytes_spmm = 4 * H * R + 4 * H * R + 8 * batch.nnz + 4 * (R + 1)
-    durs_ms = [a.elapsed_time(b) for a, b, kind in events if kind == "tile"]
-    spmm_ms = float(np.mean(durs_ms)) if durs_ms else float("nan")
-    achieved = bytes_spmm / (spmm_ms * 1e-3) / 1e9
-    gather_ms = [a.elapsed_time(b) for a, b, kind in events if kind in ("gather", "table")]   # layer 0's forward on the table
-    # the last layer's backward SpMM: its operand dZ is zero outside the loss rows and is read in compact form through a row
-    # indirection (ops.OpConfig.compact_head_backward) -- every edge aggregated, but 17.6 GB instead of 34.0 GB algorithmic
-    # at S-products; it is NOT in the roofline average above
-    compact_ms = [a.elapsed_time(b) for a, b, kind in events if kind == "compact"]
-    # the hand-written MFMA GEMM kernels of the step (secondary: the step's dominant kernel class by time, not by launch):
-    # bf16 flops actually issued (three products per fp32 product) / mean HIP-event duration, against the dense bf16 peak
+    # secondary: the same step with the dense products as a 3 x bf16 split (narrower than the reference's fp32: never the headline)
+    bf16x3 = retime("high") if (not args.no_bf16x3 and args.gemm_precision == "exact") else None
+    # the same step with the last layer transform-first and every dense operation over all union rows
+    all_rows = retime(args.gemm_precision, loss_rows_only=False) if not args.no_all_rows else None
+
+    # ---- SpMM roofline, ALL launches of the step -------------------------------------------------------------------------------
+    # one fp32 CSR SpMM moves 4H R (read X) + 4H R (write Y) + 8 nnz' + 4 (R + 1) bytes; `achieved` = that figure for
+    # the step's SpMM launches / the sum of their mean HIP-event durations in the timed region (step-weighted: every launch counts
+    # with its own time).  Next to it each launch's OWN compulsory bytes: layer 0's forward reads a de-duplicated table instead of
+    # an [R x H] operand, the last layer's backward reads a compact operand and `prev` and lists a table row per CSR entry.
+    R, nnz = batch.n_rows, batch.nnz
+    n_loss, n_table = int(batch.train_idx.numel()), int(batch.x_table.shape[0]) if batch.x_table is not None else R
+    bytes_spmm = 4 * H * R + 4 * H * R + 8 * nnz + 4 * (R + 1)
+    csr_bytes = 8 * nnz + 4 * (R + 1)
+    names = ["layer0_forward", "layer1_forward", "layer1_backward", "layer0_backward"]
+    what = {"table": "operand = the de-duplicated table through a row indirection, bias / ELU / dropout in the store",
+            "gather": "direct-gather variant on the de-duplicated table, bias / ELU / dropout in the store",
+            "tile": "plain product (operand [R x H], bare store)",
+            "compact_dz": "compact operand (loss rows + zero rows) through a row indirection, layer 0's ELU' / dropout' in the store, bias-gradient column sums",
+            "compact": "compact operand (loss rows + zero rows) through a row indirection", "dz": "previous layer's ELU' / dropout' in the store"}
+    own_bytes = {"table": 4 * H * R + 4 * H * n_table + csr_bytes + 4 * R + 4 * nnz,
+                 "gather": 4 * H * R + 4 * H * n_table + csr_bytes + 4 * nnz,
+                 "tile": bytes_spmm,
+                 "compact_dz": 2 * 4 * H * R + 4 * H * n_loss + csr_bytes + 4 * R + 4 * nnz,
+                 "compact": 4 * H * R + 4 * H * n_loss + csr_bytes + 4 * R + 4 * nnz,
+                 "dz": 3 * 4 * H * R + csr_bytes}
+    launches, n_per_step = [], None
+    full_steps = [ev for ev in step_events if len(ev) == 4]
+    if full_steps and trainer.sub is None:
+        for pos in range(4):
+            kind = full_steps[0][pos][2]
+            ms = float(np.mean([ev[pos][0].elapsed_time(ev[pos][1]) for ev in full_steps]))
+            launches.append({"launch": names[pos], "kind": kind, "what": what.get(kind, kind), "avg_us": ms * 1e3,
+                             "launches_timed": len(full_steps), "algorithmic_bytes": bytes_spmm,
+                             "frac": bytes_spmm / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                             "own_compulsory_bytes": own_bytes.get(kind), "frac_own": (own_bytes[kind] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS)
+                             if kind in own_bytes else None})
+        sum_ms = sum(l["avg_us"] for l in launches) * 1e-3
+        achieved = 4 * bytes_spmm / (sum_ms * 1e-3) / 1e9
+        best = max(launches, key=lambda l: l["frac"])
+        covers = "all four SpMM launches of the step, step-weighted (4 x the §8(d) bytes / the sum of the four mean launch times)"
+    else:   # A/B configurations whose step has another launch list: every recorded SpMM launch, formula bytes each
+        durs = [a.elapsed_time(b) for ev in step_events for a, b, _ in ev]
+        sum_ms = float(np.sum(durs)) if durs else float("nan")
+        achieved = len(durs) * bytes_spmm / (sum_ms * 1e-3) / 1e9
+        best = None
+        covers = "every SpMM launch recorded in the timed region"
+    # the hand-written MFMA GEMM kernels of the step (secondary): flops issued / mean HIP-event duration against the dense peak of
+    # the pipe they run on (fp32 MFMA 157.3 TFLOP/s for the exact policy; bf16 2 500 for the split, three products per fp32 product)
+    exact = args.gemm_precision == "exact"
+    peak_tf = 157.3 if exact else 2500.0
     by_kernel = {}
     for a_ev, b_ev, name, flops in gemm_events:
         by_kernel.setdefault(name, []).append((a_ev.elapsed_time(b_ev), flops))
     gemm_summary = {name: {"launches_timed": len(v), "avg_launch_us": float(np.mean([d for d, _ in v])) * 1e3,
-                           "bound": "mfma", "unit": "TFLOP/s (bf16, 3 products per fp32 product)",
+                           "bound": "mfma", "unit": "TFLOP/s (fp32 MFMA)" if name.startswith("gemm_f32") else "TFLOP/s (bf16, 3 products per fp32 product)",
                            "achieved": float(np.sum([f for _, f in v]) / (np.sum([d for d, _ in v]) * 1e-3) / 1e12),
-                           "peak": 2500.0,
-                           "frac": float(np.sum([f for _, f in v]) / (np.sum([d for d, _ in v]) * 1e-3) / 1e12 / 2500.0)}
+                           "peak": 157.3 if name.startswith("gemm_f32") else 2500.0,
+                           "frac": float(np.sum([f for _, f in v]) / (np.sum([d for d, _ in v]) * 1e-3) / 1e12 /
+                                         (157.3 if name.startswith("gemm_f32") else 2500.0))}
                     for name, v in by_kernel.items()}
+    gemm_ms_per_step = float(np.sum([d for v in by_kernel.values() for d, _ in v]) / max(min(args.steps, 5), 1))
     # device-to-device copy ceiling of this GPU, same process, after the timed region (read + write bytes / time)
     src = torch.empty(256 << 20, dtype=torch.float32, device=device)
     dst = torch.empty_like(src)
@@ -310,32 +368,40 @@ def main():
     copy_gbs = 10 * 2 * src.numel() * 4 / (c0.elapsed_time(c1) * 1e-3) / 1e9
     del src, dst
 
-    split = args.gemm_precision == "high"
+    precision_text = {
+        "exact": ("f32 everywhere: SpMM, epilogues, loss, Adam in f32; every dense product of the step in the reference's arithmetic -- fp32 "
+                  "operands, exact fp32 products, fp32 accumulation on v_mfma_f32_32x32x2_f32 (hand-written csrc/gemm_f32.hip; measured "
+                  "<= 3e-7 of the largest entry against fp64 = fp32 accumulation rounding, the library's own fp32 GEMM error); "
+                  "ms_per_step_bf16x3 / value_bf16x3 = the same step with those products as a 3 x bf16 split (4-5e-6: secondary)"),
+        "high": ("f32 storage and accumulation; the tall dense products as a 3 x bf16 split (hi.hi + hi.lo + lo.hi) on the bf16 MFMA pipe, "
+                 "measured 4-5e-6 relative error vs fp64 (narrower than the reference's fp32)"),
+        "highest": "f32 everywhere (library fp32 MFMA products)"}[args.gemm_precision]
+    dense_text = {
+        "exact": ("hand-written fp32-MFMA kernel csrc/gemm_f32.hip for x W^T, dH W (W read in place) and the split-k dH^T x with a "
+                  "fixed-order sum; the few-column head on the loss rows by fitgnn_head_rows_f32; no library GEMM in the step"),
+        "high": ("hand-written kernels gemm_nt.hip (X@W^T, dH@W with the previous layer's epilogue backward fused) and gemm_atb.hip "
+                 "(dH^T@X, split-K with a fixed-order sum); layer 0's table zero-padded to K % 32 == 0; the few-column head on the loss "
+                 "rows by fitgnn_head_rows_f32 (no library GEMM in the step)"),
+        "highest": "hipBLASLt fp32 MFMA"}[args.gemm_precision]
     out = {
         "metric": "edges aggregated/sec (GCN fwd+bwd) on coarsened subgraphs",
         "value": edges_per_step_total * args.steps / dt, "unit": "edges/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "ms_per_step_fp32": None if fp32 is None else fp32["ms_per_step"],
-        "value_fp32": None if fp32 is None else fp32["value"],
+        "ms_per_step_bf16x3": None if bf16x3 is None else bf16x3["ms_per_step"],
+        "value_bf16x3": None if bf16x3 is None else bf16x3["value"],
         "ms_per_step_dense_on_all_rows": None if all_rows is None else all_rows["ms_per_step"],
         "value_dense_on_all_rows": None if all_rows is None else all_rows["value"],
         "config": {"workload": f"{args.workload}: variation_neighborhoods r={r}, extra-node subgraphs, ONE block-diagonal union "
                                f"sharded over the ranks by whole subgraphs, 2-layer GCN hidden {H}, GD step + Adam",
                    "last_layer": ("aggregate-first: A_hat h over every row and edge, then x W^T / bias / ELU / dropout / head and the backward's "
                                   "weight-side products on the rows that reach the loss (every cluster's own nodes: "
-                                  f"{int(batch.train_idx.numel())} of {batch.n_rows} union rows); all four SpMMs of the step run over all "
+                                  f"{n_loss} of {batch.n_rows} union rows); all four SpMMs of the step run over all "
                                   "nnz' edges; ms_per_step_dense_on_all_rows = the same step transform-first with every dense operation "
                                   "over all rows"),
                    "parallelism": f"dp{world}", "backend": backend, "ranks_in_group": world if world == 1 else torch.distributed.get_world_size(),
-                   "precision": ("f32 storage and accumulation; SpMM, epilogues, loss, Adam in f32; the tall dense products as a "
-                                 "3 x bf16 split (hi.hi + hi.lo + lo.hi) on the bf16 MFMA pipe, measured 4-5e-6 relative error vs "
-                                 "fp64 (north_star tolerance 1e-4); ms_per_step_fp32 = the same step with plain fp32 MFMA library products")
-                   if split else "f32 everywhere (library fp32 MFMA products)",
-                   "dense_gemm": ("hand-written kernels gemm_nt.hip (X@W^T, dH@W with the previous layer's epilogue backward fused) and "
-                                  "gemm_atb.hip (dH^T@X, split-K with a fixed-order sum); layer 0's table zero-padded to K % 32 == 0; "
-                                  "the few-column head on the loss rows by fitgnn_head_rows_f32 (no library GEMM in the step)") if split else "hipBLASLt fp32 MFMA",
+                   "precision": precision_text, "dense_gemm": dense_text, "dropout_p": args.dropout,
                    "layer0_features": f"de-duplicated table ({info['nodes']} rows) + row indirection in the SpMM" if trainer.dedup
                    else "materialised union rows",
                    "rank0_union_rows": R, "rank0_nnz_prime": batch.nnz,
@@ -345,14 +411,18 @@ def main():
                                 "spmm_tile_kernel (CSR SpMM, LDS row windows, H=%d, f32)") % H, "bound": "hbm", "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": None,   # PMC bytes cannot be read inside the run: profiles/ holds the rocprofv3 --pmc passes of this command
-                     "algorithmic_bytes_per_launch": bytes_spmm, "avg_launch_us": spmm_ms * 1e3,
-                     "launches_timed": len(durs_ms), "spmm_edges_per_s": batch.nnz / (spmm_ms * 1e-3),
-                     "layer0_table_spmm_avg_launch_us": float(np.mean(gather_ms)) * 1e3 if gather_ms else None,
-                     "last_layer_backward_spmm_compact_operand_avg_launch_us": float(np.mean(compact_ms)) * 1e3 if compact_ms else None,
+                     "covers": covers,
+                     "algorithmic_bytes_per_launch": bytes_spmm, "spmm_ms_per_step": sum_ms if launches else None,
+                     "launches": launches,
+                     "best_launch": None if best is None else {"launch": best["launch"], "frac": best["frac"], "avg_us": best["avg_us"]},
+                     "spmm_edges_per_s": (4 * nnz / (sum_ms * 1e-3)) if launches else None,
                      "copy_ceiling_GBps": copy_gbs, "frac_of_copy_ceiling": achieved / copy_gbs},
-        "gemm_kernels": gemm_summary,
+        "gemm_kernels": gemm_summary, "gemm_ms_per_step": gemm_ms_per_step,
         "loss": loss_final,
     }
+    if world > 1:
+        out["allreduce_ms"] = comm_ms   # rank 0: compute-stream time per step inside GDTrainer._reduce_grads (the exposed part)
+        out["allreduce_bytes"] = int(trainer.flat.buf.numel()) * 4
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(batch, sd0, 2)
         out["cpu_baseline"]["cpu_model"] = cpu_model()

@@ -59,6 +59,8 @@ SIGNATURES = {
     "fitgnn_gemm_atb_workspace_bytes": (c_size, [c_i64, c_i32, c_i32]),
     "fitgnn_gemm_atb_f32": (ctypes.c_int, [ptr, c_i64, ptr, c_i64, c_i64, c_i32, c_i32, ptr, ptr, ptr]),
     "fitgnn_gemm_nt_f32": (ctypes.c_int, [ptr, c_i64, ptr, c_i64, c_i64, c_i32, c_i32, ptr, c_i64, ptr]),
+    "fitgnn_gemm_exact_workspace_bytes": (c_size, [c_i64, c_i32, c_i64, c_i32, c_i32]),
+    "fitgnn_gemm_exact_f32": (ctypes.c_int, [ptr, c_i64, c_i32, ptr, c_i64, c_i32, c_i64, c_i32, c_i64, ptr, c_i64, ptr, ptr]),
     "fitgnn_gemm_nt_presplit_bytes": (c_size, [c_i32, c_i32]),
     "fitgnn_gemm_nt_presplit_f32": (ctypes.c_int, [ptr, c_i64, c_i64, c_i32, c_i32, c_i32, ptr, ptr]),
     "fitgnn_gemm_nt_pre_f32": (ctypes.c_int, [ptr, c_i64, ptr, c_i64, c_i32, c_i32, ptr, c_i64, ptr]),

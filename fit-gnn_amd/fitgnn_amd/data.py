@@ -110,7 +110,30 @@ def assemble_subgraphs(edge_index, num_nodes, assign, n_clusters, extra_node=Tru
     return dict(ptr=ptr, node_id=mem_n, core=core, edge_index=np.stack([e_src, e_dst]))
 
 
-def assemble_subgraphs_torch(edge_index, num_nodes, assign, n_clusters, extra_node=True, chunk_rows=1 << 20, layout="sorted"):
+def cluster_weights_torch(edge_index, num_nodes, assign, n_clusters, extra_node=True):
+    """A cheap stand-in for nnz' per cluster subgraph, from the partition alone (no assembly): rows (own + distinct extra nodes) +
+    directed edges with both ends among the own nodes + both directions of every (own node, extra node) edge.  What it leaves
+    out are the edges BETWEEN extra nodes of a subgraph (~10 % of nnz' on S-products), so it is a lower bound that ranks
+    clusters like nnz' does: data-parallel ranks shard on it BEFORE assembling (every rank computes the same numbers from the
+    graph and the partition it already holds) and then assemble only their own clusters.  int64 numpy [n_clusters]."""
+    dev = edge_index.device
+    src, dst = edge_index[0].long(), edge_index[1].long()
+    assign = torch.as_tensor(assign, device=dev).long()
+    N, n = int(num_nodes), int(n_clusters)
+    w = torch.bincount(assign, minlength=n)                                  # own nodes
+    cs, cd = assign[src], assign[dst]
+    inner = cs == cd
+    w = w + torch.bincount(cs[inner], minlength=n)                           # own -- own, both directions are listed
+    if extra_node:
+        cut = ~inner
+        w = w + 2 * torch.bincount(cs[cut], minlength=n)                     # own -> extra and back
+        pairs = torch.unique(cs[cut] * N + dst[cut])                         # distinct (cluster, extra node)
+        w = w + torch.bincount(pairs // N, minlength=n)
+    return w.cpu().numpy()
+
+
+def assemble_subgraphs_torch(edge_index, num_nodes, assign, n_clusters, extra_node=True, chunk_rows=1 << 20, layout="sorted",
+                             clusters=None):
     """assemble_subgraphs with torch tensor ops on the device of `edge_index` (the reference's
     neighbour() scans all E edges per node, utils.py:52-56; here: one sort of the membership keys, one CSR gather and a
     binary search per (member, neighbour) pair, in chunks of `chunk_rows` members to bound memory).
@@ -123,14 +146,28 @@ def assemble_subgraphs_torch(edge_index, num_nodes, assign, n_clusters, extra_no
                 centres: every extra node is there because it neighbours one); laid out like this each star is a run of
                 consecutive rows that references little outside itself, which is what the whole-subgraph SpMM kernel wants
                 (csrc/spmm.hip: every operand row read once).  The dict then also carries `seg_start` (bool per row: first
-                row of a star)."""
+                row of a star).
+    clusters (ascending cluster ids, optional): assemble ONLY these clusters' subgraphs -- the result is what
+      select_clusters(assemble_subgraphs_torch(...), clusters) returns (clusters renumbered 0..len-1 in that order) without ever
+      building the others: a data-parallel rank's shard."""
     dev = edge_index.device
     src, dst = edge_index[0].long(), edge_index[1].long()
     assign = torch.as_tensor(assign, device=dev).long()
     N, n = int(num_nodes), int(n_clusters)
-    pc, pn = [assign], [torch.arange(N, device=dev)]
+    nodes = torch.arange(N, device=dev)
+    if clusters is not None:
+        # renumber: selected cluster -> its rank in `clusters`, every other cluster -> -1; edges and nodes that start in an
+        # unselected cluster take no part in the membership list
+        sel = torch.as_tensor(np.asarray(clusters, dtype=np.int64), device=dev)
+        new_id = torch.full((n,), -1, dtype=torch.int64, device=dev)
+        new_id[sel] = torch.arange(int(sel.numel()), device=dev)
+        assign = new_id[assign]
+        n = int(sel.numel())
+        nodes = nodes[assign >= 0]
+    pc, pn = [assign[nodes]], [nodes]
     if extra_node:
-        cut = assign[src] != assign[dst]
+        # cut edges that START in a (selected) cluster; the full edge list stays: an extra node's own adjacency is needed below
+        cut = (assign[src] >= 0) & (assign[src] != assign[dst])
         pc.append(assign[src[cut]])
         pn.append(dst[cut])
     key = torch.unique(torch.cat(pc) * N + torch.cat(pn))            # sorted by (cluster, node)

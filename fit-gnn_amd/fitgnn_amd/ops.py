@@ -20,6 +20,10 @@ class OpConfig:
     trainers / streams / devices in one process never see each other's settings (re-entrant).
 
     gemm_precision   dense GEMM policy (BASELINE.json north_star: MFMA for the dense weight GEMMs).
+                     "exact" (default): the reference's arithmetic -- fp32 operands, exact fp32 products, fp32 accumulation -- on
+                     v_mfma_f32_32x32x2_f32 through the hand-written kernel csrc/gemm_f32.hip (x @ W^T, dH @ W and the split-k
+                     dH^T @ x; ~1e-7 against fp64, the rounding of fp32 accumulation alone).  Operands whose rows cannot be read
+                     with 16-byte loads (a column count that is not a multiple of 4: a 3-class head) run as fp32 library products.
                      "high": the tall fp32 products of a Linear as three bf16 products (hi.hi + hi.lo + lo.hi of the
                      two-term split of each operand) on the bf16 MFMA pipe with fp32 accumulation -- measured 4-5e-6
                      relative error vs fp64 -- through the hand-written kernels csrc/gemm_nt.hip (x @ W^T, dH @ W) and
@@ -48,11 +52,11 @@ class OpConfig:
                  "dedup_gather", "pad_table_min_k", "split_large_blocks", "compact_head_backward", "last_layer_on_loss_rows", "profile", "profile_gemm",
                  "profile_fused", "seed_bank")
 
-    def __init__(self, gemm_precision="high", atb_kernel=True, nt_kernel=True, nt_presplit=True, fuse_dx_epilogue=True,
+    def __init__(self, gemm_precision="exact", atb_kernel=True, nt_kernel=True, nt_presplit=True, fuse_dx_epilogue=True,
                  fold_backward=False, dedup_gather=True, pad_table_min_k=0, split_large_blocks=True, compact_head_backward=True,
                  last_layer_on_loss_rows=True, profile=None, profile_gemm=None, profile_fused=None, seed_bank=None):
-        if gemm_precision not in ("high", "highest"):
-            raise ValueError(f"gemm_precision {gemm_precision!r}: 'high' or 'highest'")
+        if gemm_precision not in ("exact", "high", "highest"):
+            raise ValueError(f"gemm_precision {gemm_precision!r}: 'exact', 'high' or 'highest'")
         self.gemm_precision, self.atb_kernel, self.nt_kernel, self.nt_presplit = gemm_precision, atb_kernel, nt_kernel, nt_presplit
         self.fuse_dx_epilogue, self.fold_backward, self.dedup_gather = fuse_dx_epilogue, fold_backward, dedup_gather
         self.pad_table_min_k, self.split_large_blocks = pad_table_min_k, split_large_blocks
@@ -74,6 +78,51 @@ def mm(a, b):
     return torch.mm(a, b)
 
 
+def _rows_16b(t):
+    """A 2-D fp32 device matrix whose rows csrc/gemm_f32.hip can read with 16-byte loads."""
+    return (t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 and t.shape[0] >= 1 and t.shape[1] >= 4 and t.shape[1] % 4 == 0
+            and t.stride(1) == 1 and t.stride(0) % 4 == 0 and t.stride(0) >= t.shape[1] and t.data_ptr() % 16 == 0)
+
+
+def _exact(cfg, a, b):
+    return cfg.gemm_precision == "exact" and _rows_16b(a) and _rows_16b(b)
+
+
+def gemm_exact(a, b, form, cfg=DEFAULT):
+    """One product of a Linear in exact fp32 on the fp32 MFMA (fitgnn_gemm_exact_f32, csrc/gemm_f32.hip):
+        form "nt": a [I, K] @ b [J, K]^T   (forward x W^T)
+             "nn": a [I, K] @ b [K, J]     (grad_x = dH W: W is read as it lies, no transposed copy)
+             "tn": a [K, I]^T @ b [K, J]   (grad_W = dH^T x: reduction over the rows, split over k with a fixed-order sum)."""
+    L = _lib.lib()
+    if form == "nt":
+        (I, K), J, akm, bkm = a.shape, b.shape[0], 0, 0
+        assert b.shape[1] == K
+    elif form == "nn":
+        (I, K), J, akm, bkm = a.shape, b.shape[1], 0, 1
+        assert b.shape[0] == K
+    elif form == "tn":
+        (K, I), J, akm, bkm = a.shape, b.shape[1], 1, 1
+        assert b.shape[0] == K
+    else:
+        raise ValueError(form)
+    out = torch.empty((I, J), dtype=torch.float32, device=a.device)
+    wb = int(L.fitgnn_gemm_exact_workspace_bytes(I, J, K, akm, bkm))
+    ws = torch.empty(wb // 4, dtype=torch.float32, device=a.device) if wb else None
+    ev = _gemm_events(cfg, "gemm_f32_kernel[%s]" % form, 2.0 * I * J * K)
+    rc = L.fitgnn_gemm_exact_f32(_lib.dptr(a), a.stride(0), akm, _lib.dptr(b), b.stride(0), bkm, I, J, K, _lib.dptr(out), J,
+                                 _lib.dptr(ws), _lib.stream_ptr(a.device))
+    _gemm_done(cfg, ev)
+    _lib.check(rc, "fitgnn_gemm_exact_f32")
+    return out
+
+
+def padded_weight(W, Kp):
+    """W [N, K] zero-padded to [N, Kp] columns (the partner of padded_table for a feature width that is not a multiple of 4)."""
+    Wp = torch.zeros((W.shape[0], Kp), dtype=torch.float32, device=W.device)
+    Wp[:, : W.shape[1]] = W
+    return Wp
+
+
 def _full_grid(R, N):
     return ((R + 255) // 256) * ((N + 255) // 256) >= 128
 
@@ -92,6 +141,8 @@ def _nt_ok(a, b, cfg):
 
 def mm_xwt(x, W, cfg=DEFAULT):
     """x [R, K] @ W [N, K]^T (a Linear's forward) under the GEMM policy."""
+    if _exact(cfg, x, W):
+        return gemm_exact(x, W, "nt", cfg)
     if _nt_ok(x, W, cfg):
         return gemm_nt(x, W, cfg)
     return mm(x, W.t())
@@ -109,6 +160,8 @@ def mm_by_transposed(a, W, cfg=DEFAULT):
     """a @ W for a square-ish weight W [out, in]: the library's kernel for a row-major right operand (NN) takes 201 us on
     the S-pubmed union, the one for a transposed right operand (the forward's x @ W^T form) 160 us -- materialise W^T
     (1 MB) and use the latter.  Bit-identical result."""
+    if _exact(cfg, a, W):
+        return gemm_exact(a, W, "nn", cfg)
     if a.is_cuda and W.dim() == 2 and W.shape[0] >= 64 and W.shape[1] >= 64:
         Wt = _wt_operand(a, W, cfg)
         if _nt_ok(a, Wt, cfg):
@@ -245,6 +298,13 @@ def head_weight_grad_rows(dy_c, out_c, cfg=DEFAULT):
     columns zero-padded to 64 so that the split-K kernel takes it (the library's batched product was the last library GEMM
     of the step)."""
     C = dy_c.shape[1]
+    if cfg.gemm_precision == "exact" and dy_c.is_cuda and _rows_16b(out_c):
+        Cp = (C + 3) // 4 * 4
+        if Cp != C or not _rows_16b(dy_c):   # class columns zero-padded to a multiple of 4 (16-byte rows)
+            pad = torch.zeros((dy_c.shape[0], Cp), dtype=torch.float32, device=dy_c.device)
+            pad[:, :C] = dy_c
+            dy_c = pad
+        return gemm_exact(dy_c, out_c, "tn", cfg)[:C].contiguous()
     if dy_c.is_cuda and C < 64 and cfg.atb_kernel and cfg.gemm_precision == "high" and dy_c.shape[0] >= 256 and _atb_ok(out_c):
         pad = torch.zeros((dy_c.shape[0], 64), dtype=torch.float32, device=dy_c.device)
         pad[:, :C] = dy_c
@@ -259,6 +319,8 @@ def mm_at_b(a, b, cfg=DEFAULT):
     a sum of the partial products it takes 394 us -- split-K by hand.  The partials are summed in a fixed order:
     reproducible."""
     R = a.shape[0]
+    if _exact(cfg, a, b):
+        return gemm_exact(a, b, "tn", cfg)
     if (cfg.gemm_precision == "high" and cfg.atb_kernel and R >= 256 and min(a.shape[1], b.shape[1]) >= 64 and _atb_ok(a)
             and _atb_ok(b)):  # narrower operands would leave most of a 256 x 256 tile multiplying padding
         return gemm_atb(a, b, cfg)
@@ -979,7 +1041,15 @@ class FusedGCNLayerDedup(torch.autograd.Function):
         Xt = _f32c(Xt)
         ctx.link_out, ctx.cfg = link_out, cfg
         ctx.wide = _padded_table_path(Xt, W, cfg)
-        Ht = gemm_nt_padded_k(padded_table(Xt), W, cfg) if ctx.wide else mm_xwt(Xt, W, cfg)  # [N0, H]
+        # exact fp32 on a feature width that is not a multiple of 4 (1 433, 8 415): rows of Xt / W are not 16-byte aligned --
+        # both products run against the zero-padded copy of the static table (and a zero-padded W: a copy of the weight per call)
+        ctx.exact_pad = (cfg.gemm_precision == "exact" and Xt.is_cuda and Xt.shape[1] % 4 != 0 and not Xt.requires_grad
+                         and W.shape[0] % 4 == 0)
+        if ctx.exact_pad:
+            Xp = padded_table(Xt)
+            Ht = gemm_exact(Xp, padded_weight(W, Xp.shape[1]), "nt", cfg)
+        else:
+            Ht = gemm_nt_padded_k(padded_table(Xt), W, cfg) if ctx.wide else mm_xwt(Xt, W, cfg)  # [N0, H]
         epi = EPI_ELU | (EPI_BIAS if b is not None else 0)
         drop = bool(training) and p > 0.0
         if drop:
@@ -1002,7 +1072,9 @@ class FusedGCNLayerDedup(torch.autograd.Function):
         cfg = ctx.cfg
         dH, db = _producer_backward(cfg, ctx.link_out, g, out, epi, ctx.p if ctx.drop else 0.0, ctx.seed, mask, ctx.has_bias, dOut)  # [R, H]
         dHt = segment_sum(ridx.seg_off, ridx.members, dH, ridx.n_table)  # [N0, H] per original node
-        if ctx.wide and ctx.needs_input_grad[1]:
+        if ctx.exact_pad and ctx.needs_input_grad[1]:
+            dW = gemm_exact(_f32c(dHt), padded_table(Xt), "tn", cfg)[:, : Xt.shape[1]]
+        elif ctx.wide and ctx.needs_input_grad[1]:
             dW = gemm_atb(_f32c(dHt), padded_table(Xt), cfg)[:, : Xt.shape[1]]   # [H, F'] on the padded table, F' - F zero columns dropped
         else:
             dW = mm_at_b(dHt, Xt, cfg) if ctx.needs_input_grad[1] else None

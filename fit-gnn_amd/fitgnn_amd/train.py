@@ -157,6 +157,7 @@ class GDTrainer:
         # backward kernels, the first layer's part afterwards.  xGMI is point-to-point: two latency-bound ~1 MB calls, no
         # finer bucketing.
         self._work, self._split = None, 0
+        self.comm_events = None
         if self.dist:
             first = [p for n, p in model.named_parameters() if n.startswith("conv.0.")]
             ids = {id(p) for p in first}
@@ -173,7 +174,19 @@ class GDTrainer:
             self._work = torch.distributed.all_reduce(self.flat.buf[self._split:], group=self.pg, async_op=True)
 
     def _reduce_grads(self):
-        """Finish the gradient all-reduce: the early bucket was launched from the hook, the first layer's follows here."""
+        """Finish the gradient all-reduce: the early bucket was launched from the hook, the first layer's follows here.
+        comm_events (a list, or None): HIP-event pairs around this call on the compute stream -- the part of the all-reduce the
+        step actually waits for (the early bucket runs on the collective's own stream under the first layer's backward)."""
+        ev = None
+        if self.comm_events is not None and self.flat.buf.is_cuda:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+        self._reduce_grads_now()
+        if ev is not None:
+            ev[1].record()
+            self.comm_events.append(ev)
+
+    def _reduce_grads_now(self):
         if self._split and self._work is not None:
             torch.distributed.all_reduce(self.flat.buf[:self._split], group=self.pg)
             self._work.wait()

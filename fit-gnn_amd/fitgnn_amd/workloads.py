@@ -63,12 +63,21 @@ def features_and_labels(name):
     return X, y
 
 
-def assemble(name, ei_d, assign_d, n_clusters, layout="star"):
+def assemble(name, ei_d, assign_d, n_clusters, layout="star", clusters=None):
     """All cluster subgraphs of the partition (device tensors) and their nnz'.  layout: the row order inside a subgraph
-    (data.assemble_subgraphs_torch): star by star by default, which is what the train path uses."""
+    (data.assemble_subgraphs_torch): star by star by default, which is what the train path uses.  clusters: only these
+    clusters' subgraphs (a data-parallel rank's shard: see shard_before_assembly)."""
     N = SHAPES[name][0]
-    sub = data.assemble_subgraphs_torch(ei_d, N, assign_d, n_clusters, extra_node=True, layout=layout)
+    sub = data.assemble_subgraphs_torch(ei_d, N, assign_d, n_clusters, extra_node=True, layout=layout, clusters=clusters)
     return sub, data.cluster_nnz(sub)
+
+
+def shard_before_assembly(name, ei_d, assign_d, n_clusters, world):
+    """owner[c] = rank of cluster c (whole subgraphs, LPT), decided BEFORE any subgraph exists from
+    data.cluster_weights_torch -- computed by every rank from the graph and the partition it already holds, so every rank gets
+    the same answer and then assembles its own clusters only."""
+    N = SHAPES[name][0]
+    return data.shard_clusters(None, data.cluster_weights_torch(ei_d, N, assign_d, n_clusters, extra_node=True), world)
 
 
 def batch_from_subgraphs(name, sub, device, X=None, y=None):

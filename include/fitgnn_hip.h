@@ -185,6 +185,20 @@ int fitgnn_gemm_atb_f32(const float *a, int64_t lda, const float *b, int64_t ldb
 int fitgnn_gemm_nt_f32(const float *a, int64_t lda, const float *b, int64_t ldb, int64_t R, int32_t N, int32_t K,
                        float *c, int64_t ldc, void *stream);
 
+/* The same three products of a Linear in the REFERENCE's own arithmetic -- fp32 operands, exact fp32 products, fp32 accumulation
+ * (PyG's Linear inside GCNConv, network.py:13-31, is an fp32 GEMM) -- on v_mfma_f32_32x32x2_f32 (csrc/gemm_f32.hip):
+ *     c[i][j] = sum_k A(i,k) * B(j,k),  c [I x J] row-major with row stride ldc,
+ *     A(i,k) = a[i * lda + k] (a_kmajor == 0: k contiguous) or a[k * lda + i] (a_kmajor != 0: k is the row index); B likewise.
+ * forward h = x W^T: (0, 0);  grad_x = grad_h W: (0, 1) with b = W (no transposed copy);  grad_W = grad_h^T x: (1, 1) with
+ * a = grad_h, b = x and K = the number of rows.  (1, 0) is E_BADARG (swap the operands and transpose the result).
+ * A long reduction into few output tiles is split over k: the partial tiles go to `workspace`
+ * (fitgnn_gemm_exact_workspace_bytes; 0 = none needed, workspace may then be NULL) and are added in a fixed order -- reproducible,
+ * no atomics.  The contiguous extent of each operand (K if k-minor, I or J if k-major), lda and ldb are multiples of 4; a and b
+ * are 16-byte aligned; any I, J, K otherwise (ragged tiles are masked, k beyond K reads as zero). */
+size_t fitgnn_gemm_exact_workspace_bytes(int64_t I, int32_t J, int64_t K, int32_t a_kmajor, int32_t b_kmajor);
+int fitgnn_gemm_exact_f32(const float *a, int64_t lda, int32_t a_kmajor, const float *b, int64_t ldb, int32_t b_kmajor,
+                          int64_t I, int32_t J, int64_t K, float *c, int64_t ldc, void *workspace, void *stream);
+
 /* Pre-split b operand for the tall-GEMM kernels: b [N x K] given by element strides (b[n * stride_n + k * stride_k]; so
  * b = W^T needs no transposed copy) is converted ONCE per call into bf16 hi/lo fragments laid out as the kernel's LDS image,
  * per (256-column tile, 32-wide k stage); b has K_valid <= K columns, the image is zero from there to K (a multiple of 32:

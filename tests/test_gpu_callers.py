@@ -187,3 +187,32 @@ def test_cli_data_parallel_run_equals_the_single_process_run(tmp_path):
     ra = (one / "results" / "synthetic-cora.csv").read_text().splitlines()
     rb = (two / "results" / "synthetic-cora.csv").read_text().splitlines()
     assert len(ra) == len(rb) == 2, "rank 0 alone writes the results row"
+
+
+def test_bench_two_ranks_report_the_single_rank_loss(tmp_path):
+    """bench.py's data-parallel path end to end, as the driver launches it: `python bench.py --gpus 2` spawns its two ranks itself
+    (a parent that never touches the GPU; gloo over this one GPU = a rehearsal of the RCCL path, same code): rank 0 coarsens and
+    broadcasts the partition, every rank shards it BEFORE assembling and builds its own clusters only, steps on its shard, one
+    gradient all-reduce per step -- the global loss after two steps equals the one-rank run's (dropout off: its hash is keyed on
+    a rank's own row numbers), and the line carries the ranks' nnz' and the all-reduce time."""
+    import json
+
+    bench = os.path.join(ROOT, "bench.py")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", FITGNN_BENCH_BACKEND="gloo")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    common = ["--workload", "S-pubmed", "--steps", "2", "--warmup", "0", "--dropout", "0", "--no-cpu-baseline", "--no-bf16x3", "--no-all-rows"]
+    lines = {}
+    for n in (1, 2):
+        res = subprocess.run([sys.executable, bench, "--gpus", str(n)] + common, env=env, cwd=tmp_path, check=True, timeout=900,
+                             stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+        lines[n] = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
+    one, two = lines[1], lines[2]
+    assert two["n_gpus"] == 2 and two["config"]["parallelism"] == "dp2"
+    assert abs(two["loss"] - one["loss"]) <= 1e-5 * abs(one["loss"]), (one["loss"], two["loss"])
+    shards = two["config"]["shard_nnz_prime"]
+    assert len(shards) == 2 and sum(shards) == one["config"]["nnz_prime"] == two["config"]["nnz_prime"]
+    assert max(shards) <= 1.05 * min(shards)
+    assert two["allreduce_ms"] is not None and two["allreduce_ms"] > 0
+    assert len(one["roofline"]["launches"]) == 4 and [l["launch"] for l in one["roofline"]["launches"]] == [
+        "layer0_forward", "layer1_forward", "layer1_backward", "layer0_backward"]

@@ -602,7 +602,7 @@ def test_dx_gemm_with_the_previous_layers_epilogue(mods, layers, dedup, inject):
     grads = {}
     for fuse in (True, False):
         ops.gemm_nt_epilogue_bwd = counting
-        model.set_op_config(ops.OpConfig(fuse_dx_epilogue=fuse))   # per-model switch: no process-wide state
+        model.set_op_config(ops.OpConfig(gemm_precision="high", fuse_dx_epilogue=fuse))   # per-model switch: no process-wide state
         try:
             model.zero_grad()
             if inject:
@@ -693,7 +693,7 @@ def test_wide_unaligned_feature_table_runs_on_the_gemm_kernels(mods):
     ridx = ops.RowIndex(idx.cuda(), N0)
     res = {}
     for wide in (True, False):
-        model.set_op_config(ops.OpConfig(pad_table_min_k=0 if wide else 10 ** 9))
+        model.set_op_config(ops.OpConfig(gemm_precision="high", pad_table_min_k=0 if wide else 10 ** 9))
         model.zero_grad()
         out = model(Xt, ei.cuda(), x_index=ridx)
         torch.nn.functional.nll_loss(out, y).backward()
@@ -703,3 +703,69 @@ def test_wide_unaligned_feature_table_runs_on_the_gemm_kernels(mods):
     for k in res[True][1]:
         assert res[True][1][k].shape == res[False][1][k].shape
         assert rel(res[True][1][k].cpu(), res[False][1][k].cpu()) < 1e-4, k
+
+
+def test_feature_width_that_is_not_a_multiple_of_four_under_the_exact_policy(mods):
+    """Cora's 1 433 features (8 415 at Physics): rows of the table and of W0 are not 16-byte aligned, so under the default exact-fp32
+    policy layer 0's two products run against the zero-padded table and a zero-padded copy of W0 (ops.FusedGCNLayerDedup):
+    outputs and gradients equal the fp32 library products' (both are fp32 GEMMs: agreement to accumulation-order rounding)."""
+    network, fnn, gorc = mods
+    from fitgnn_amd import ops
+
+    N0, F, H, n = 3000, 1433, 128, 5000
+    ei, n = graph(n=n, m=15000, seed=52)
+    torch.manual_seed(9)
+    idx = torch.randint(0, N0, (n,)); idx[:N0] = torch.arange(N0)
+    Xt = torch.rand(N0, F).cuda()
+    args = argparse.Namespace(num_layers1=2, layer_name="GCNConv", num_features=F, hidden=H, num_classes=7)
+    model = network.Classify_node(args).cuda().train()
+    model._inject_masks = [(torch.rand(n, H) > 0.5).to(torch.uint8).cuda() for _ in range(2)]
+    y = torch.randint(0, 7, (n,)).cuda()
+    ridx = ops.RowIndex(idx.cuda(), N0)
+    res = {}
+    for prec in ("exact", "highest"):
+        log = []
+        model.set_op_config(ops.OpConfig(gemm_precision=prec, profile_gemm=log))
+        model.zero_grad()
+        out = model(Xt, ei.cuda(), x_index=ridx)
+        torch.nn.functional.nll_loss(out, y).backward()
+        res[prec] = (out.detach().clone(), {k: p.grad.clone() for k, p in model.named_parameters()}, [e[2] for e in log])
+    model.set_op_config(ops.DEFAULT)
+    assert "gemm_f32_kernel[nt]" in res["exact"][2] and "gemm_f32_kernel[tn]" in res["exact"][2] and not res["highest"][2]
+    assert getattr(Xt, "_fitgnn_pad")[1].shape == (N0, 1440)
+    assert rel(res["exact"][0].cpu(), res["highest"][0].cpu()) < 2e-6
+    for k in res["exact"][1]:
+        assert res["exact"][1][k].shape == res["highest"][1][k].shape
+        assert rel(res["exact"][1][k].cpu(), res["highest"][1][k].cpu()) < 2e-5, k
+
+
+def test_row_index_caches_follow_the_index_tensor_not_its_address(mods):
+    """embed_and_head(loss_rows=...) caches the compact-operand positions (and the per-entry table rows) on the graph.  The cache
+    entry holds the index tensor it was built from and its version: a caller that rewrites its loss_rows IN PLACE (same
+    address, same length) gets positions for the new rows, not the stale ones -- gradients equal the un-hinted evaluation's."""
+    network, fnn, gorc = mods
+    batch, _ = _subgraph_batches(seed=9)
+    args = argparse.Namespace(num_layers1=2, layer_name="GCNConv", num_features=24, hidden=64, num_classes=5)
+    torch.manual_seed(3)
+    m = network.Classify_node(args).cuda()
+    m.eval()
+    core = torch.nonzero(batch.core).flatten()
+    k = int(core.numel()) // 2
+    first, second = core[:k].clone(), core[-k:].clone()
+    assert not torch.equal(first, second)
+
+    def grads(rows, hint):
+        m.zero_grad()
+        z = m.embed_and_head(batch.x, batch.edge_index, loss_rows=rows if hint else None, compact_logits=hint)
+        zs = z if (hint and z.shape[0] == rows.numel()) else z.index_select(0, rows)
+        torch.nn.functional.nll_loss(torch.log_softmax(zs, 1), batch.y.index_select(0, rows), reduction="sum").backward()
+        return [p.grad.clone() for p in m.parameters()]
+
+    rows = first.clone()
+    g_first = grads(rows, True)
+    rows.copy_(second)                       # same tensor, same address, new selection
+    g_second = grads(rows, True)
+    for a, b in zip(g_second, grads(second, False)):
+        assert rel(a, b) < 2e-4
+    for a, b in zip(g_first, grads(first, False)):
+        assert rel(a, b) < 2e-4

@@ -448,20 +448,96 @@ def test_weight_gradient_gemm_matches_f64(mods, R, M, N):
     assert float((got - ref).abs().max() / ref.abs().max()) < 2e-5
 
 
-def test_weight_gradient_gemm_is_the_default_path(mods):
+def test_weight_gradient_gemm_is_the_split_policys_path(mods):
     _lib, csr, ops, orc, gorc = mods
+    HIGH = ops.OpConfig(gemm_precision="high")   # the 3 x bf16 policy (the default is the exact fp32 kernel, tested below)
     a = torch.randn(3000, 64).cuda()
     b = torch.randn(3000, 96).cuda()   # operands narrower than 64 columns stay on the library path (mostly padding in a tile)
-    assert ops.DEFAULT.atb_kernel
-    assert torch.equal(ops.mm_at_b(a, b), ops.gemm_atb(a, b))
+    assert HIGH.atb_kernel
+    assert torch.equal(ops.mm_at_b(a, b, HIGH), ops.gemm_atb(a, b))
     ref = a.double().t() @ b.double()
-    assert float((ops.mm_at_b(a, b) - ref).abs().max() / ref.abs().max()) < 2e-5
+    assert float((ops.mm_at_b(a, b, HIGH) - ref).abs().max() / ref.abs().max()) < 2e-5
     # exact zeros and signed values survive the hi/lo split
     z = torch.zeros(512, 8).cuda()
     assert float(ops.gemm_atb(z, b[:512]).abs().max()) == 0.0
     narrow = torch.randn(3000, 8).cuda()
     ref = narrow.double().t() @ b.double()
-    assert float((ops.mm_at_b(narrow, b) - ref).abs().max() / ref.abs().max()) < 2e-5
+    assert float((ops.mm_at_b(narrow, b, HIGH) - ref).abs().max() / ref.abs().max()) < 2e-5
+
+
+# The DEFAULT policy: the three products of a Linear in exact fp32 on v_mfma_f32_32x32x2_f32 (csrc/gemm_f32.hip).  Shapes: the
+# configurations' own (hidden 512; feature widths 100 and 500; 47 / 48 class columns; the S-pubmed / S-products row counts cut
+# down), rows around the 256 / 64-row tiles, k around the 32-wide stage and the chunking of the split-k form, strided operands.
+EXACT_SHAPES = {
+    "nt": [(90549, 512, 512), (20000, 512, 100), (4097, 260, 96), (1024, 512, 32), (257, 64, 64), (5, 4, 36), (19717, 500, 512),
+           (300, 128, 500), (1, 4, 4)],
+    "nn": [(90549, 512, 512), (4097, 96, 260), (257, 64, 64), (19717, 512, 500), (5, 36, 4), (1000, 100, 512)],
+    "tn": [(90549, 512, 512), (19717, 512, 500), (165000, 48, 512), (40000, 512, 100), (4097, 260, 36), (1000, 64, 128), (256, 512, 4),
+           (33, 8, 4), (31, 8, 8), (2048, 4, 4), (1, 4, 4), (2047, 64, 512)],
+}
+
+
+@pytest.mark.parametrize("form,dims", [(f, d) for f, ds in EXACT_SHAPES.items() for d in ds])
+def test_exact_fp32_gemm_matches_f64(mods, form, dims):
+    """fitgnn_gemm_exact_f32 against an fp64 product: the error is that of fp32 accumulation alone -- at most a few 1e-7 of the
+    largest entry, no worse than the library's own fp32 GEMM on the same operands -- and the result is bit-reproducible."""
+    _lib, csr, ops, orc, gorc = mods
+    g = torch.Generator().manual_seed(sum(dims) + len(form))
+    if form == "nt":      # (I, J, K): a [I, K] @ b [J, K]^T
+        I, J, K = dims
+        a, b = torch.randn(I, K, generator=g).cuda(), torch.randn(J, K, generator=g).cuda()
+        ref = lambda x, y: x.double() @ y.double().t()      # noqa: E731
+        lib = lambda x, y: x @ y.t()                        # noqa: E731
+    elif form == "nn":    # (I, K, J): a [I, K] @ b [K, J]
+        I, K, J = dims
+        a, b = torch.randn(I, K, generator=g).cuda(), torch.randn(K, J, generator=g).cuda()
+        ref = lambda x, y: x.double() @ y.double()          # noqa: E731
+        lib = lambda x, y: x @ y                            # noqa: E731
+    else:                 # (K, I, J): a [K, I]^T @ b [K, J]
+        K, I, J = dims
+        a, b = torch.randn(K, I, generator=g).cuda(), torch.randn(K, J, generator=g).cuda()
+        ref = lambda x, y: x.double().t() @ y.double()      # noqa: E731
+        lib = lambda x, y: x.t() @ y                        # noqa: E731
+    want = ref(a, b)
+    got = ops.gemm_exact(a, b, form)
+    assert got.shape == want.shape
+    err = float((got - want).abs().max() / want.abs().max())
+    err_lib = float((lib(a, b) - want).abs().max() / want.abs().max())
+    assert err < 1e-6 and err <= 4 * err_lib + 1e-7, (form, dims, err, err_lib)
+    assert torch.equal(got, ops.gemm_exact(a, b, form)), "fixed-order sums: bit-reproducible"
+    # strided operands: column windows of wider matrices (row stride > extent)
+    wa = torch.randn(a.shape[0], a.shape[1] + 8, generator=g).cuda()
+    wb = torch.randn(b.shape[0], b.shape[1] + 4, generator=g).cuda()
+    va, vb = wa[:, 4:4 + a.shape[1]], wb[:, : b.shape[1]]
+    want = ref(va, vb)
+    assert float((ops.gemm_exact(va, vb, form) - want).abs().max() / want.abs().max()) < 1e-6
+    # exact zeros survive
+    assert float(ops.gemm_exact(torch.zeros_like(a), b, form).abs().max()) == 0.0
+
+
+def test_exact_fp32_gemm_is_the_default_policy_and_differentiates(mods):
+    _lib, csr, ops, orc, gorc = mods
+    assert ops.DEFAULT.gemm_precision == "exact"
+    x = torch.randn(2048, 128, device="cuda", requires_grad=True)
+    W = torch.randn(96, 128, device="cuda", requires_grad=True)
+    y = ops.Linear.apply(x, W, ops.DEFAULT)
+    assert torch.equal(y, ops.gemm_exact(x.detach(), W.detach(), "nt"))
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    assert torch.equal(x.grad, ops.gemm_exact(gy, W.detach(), "nn"))
+    assert torch.equal(W.grad, ops.gemm_exact(gy, x.detach(), "tn"))
+    xd, Wd = x.detach().double(), W.detach().double()
+    assert float((x.grad - gy.double() @ Wd).abs().max()) < 1e-6 * float((gy.double() @ Wd).abs().max())
+    assert float((W.grad - gy.double().t() @ xd).abs().max()) < 1e-6 * float((gy.double().t() @ xd).abs().max())
+    # rows that cannot be read with 16-byte loads (3 class columns) run as fp32 library products
+    n3, xs = torch.randn(2048, 3).cuda(), x.detach()
+    ref = n3.double().t() @ xs.double()
+    assert float((ops.mm_at_b(n3, xs) - ref).abs().max() / ref.abs().max()) < 1e-6
+    # argument errors of the C entry point, before any GPU work
+    L = _lib.lib()
+    assert L.fitgnn_gemm_exact_f32(None, 4, 0, None, 4, 0, 8, 8, 8, None, 8, None, None) == -1          # NULL operands
+    a = torch.randn(8, 6).cuda()
+    assert L.fitgnn_gemm_exact_f32(_lib.dptr(a), 6, 0, _lib.dptr(a), 6, 0, 8, 8, 6, _lib.dptr(a), 8, None, None) == -1   # K % 4 != 0
 
 
 # h = x W^T and dX = dH W (csrc/gemm_nt.hip): row counts around the 256-row tile, ragged N, K = 32..512, strided operands
@@ -483,12 +559,13 @@ def test_linear_gemm_matches_f64(mods, R, N, K):
     assert float((ops.gemm_nt(va, vb) - ref).abs().max() / ref.abs().max()) < 2e-5
 
 
-def test_linear_gemm_is_the_default_path_and_differentiates(mods):
+def test_linear_gemm_is_the_split_policys_path_and_differentiates(mods):
     _lib, csr, ops, orc, gorc = mods
-    assert ops.DEFAULT.nt_kernel
+    HIGH = ops.OpConfig(gemm_precision="high")
+    assert HIGH.nt_kernel
     x = torch.randn(2048, 128, device="cuda", requires_grad=True)
     W = torch.randn(96, 128, device="cuda", requires_grad=True)
-    y = ops.Linear.apply(x, W, ops.DEFAULT)
+    y = ops.Linear.apply(x, W, HIGH)
     assert torch.equal(y, ops.gemm_nt(x.detach(), W.detach()))
     gy = torch.randn_like(y)
     y.backward(gy)

@@ -1,5 +1,6 @@
 """CPU tier: host-side index plumbing (CSR build, block detection, tile packing, graph object)."""
 import numpy as np
+import pytest
 import scipy.sparse as sp
 import torch
 
@@ -393,6 +394,41 @@ def test_select_clusters_and_sharding_partition_the_union():
             assert np.array_equal(ea, eo)
         total_edges += a["edge_index"].shape[1]
     assert total_edges == sub["edge_index"].shape[1]
+
+
+@pytest.mark.parametrize("layout", ["sorted", "star"])
+def test_a_rank_assembles_only_its_own_clusters(layout):
+    """Data parallel set-up (bench.py): the partition is sharded BEFORE any subgraph exists, on a weight every rank
+    computes from the graph and the partition (data.cluster_weights_torch: a lower bound of nnz' that leaves out the edges
+    between extra nodes), and assemble_subgraphs_torch(clusters=mine) builds the rank's subgraphs alone -- the same dict as
+    cutting them out of the whole union (data.select_clusters), without ever building the others."""
+    from fitgnn_amd import data
+
+    ei = data.synthetic_graph(3000, 9000, seed=3)
+    rng = np.random.default_rng(0)
+    assign = rng.integers(0, 400, size=3000)
+    assign[:400] = np.arange(400)
+    e, a = torch.from_numpy(ei), torch.from_numpy(assign)
+    full = data.assemble_subgraphs_torch(e, 3000, a, 400, layout=layout)
+    nnz = data.cluster_nnz(full)
+    w = data.cluster_weights_torch(e, 3000, a, 400)
+    assert np.all(w <= nnz) and np.all(w >= 0.5 * nnz), "a lower bound that tracks nnz'"
+    owner = data.shard_clusters(None, w, 3)
+    load = np.bincount(owner, weights=nnz, minlength=3)
+    assert load.max() <= 1.1 * load.min(), "shards balanced in the real nnz' too"
+    rows = 0
+    for r in range(3):
+        mine = np.nonzero(owner == r)[0]
+        want = data.select_clusters(full, mine)
+        got = data.assemble_subgraphs_torch(e, 3000, a, 400, layout=layout, clusters=mine)
+        assert set(want) == set(got)
+        for k in want:
+            if k == "edge_index":   # the same edge set (the enumeration order follows the member rows either way)
+                assert torch.equal(want[k], got[k])
+            else:
+                assert torch.equal(want[k], got[k]), k
+        rows += int(got["ptr"][-1])
+    assert rows == int(full["ptr"][-1])
 
 
 def test_star_layout_is_a_row_permutation_of_the_sorted_layout():
