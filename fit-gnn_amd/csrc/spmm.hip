@@ -718,6 +718,112 @@ __global__ __launch_bounds__(kThreads, BWD ? 4 : XROW ? 6 : 7) void spmm_block_k
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Row-streaming kernel for a COMPACT operand (fitgnn_spmm_rows_compact_f32 / _dz_f32).
+//
+// The last layer's backward SpMM, dX = A_hat^T dAH, reads an operand that is zero outside the rows that reach the loss
+// (run.py:193-204 keeps out[mask]: with --extra_node 2 % of a union's rows): dAH is handed over in compact form -- [n_sel + zero
+// rows, H] behind a row indirection, xcol[e] = the operand row of CSR entry e, rows >= zero_from are zero -- and what the launch
+// really moves is its OUTPUT (4H R bytes written) and, with the previous layer's derivative in the store, `prev` (4H R read): a
+// stream.  The whole-subgraph kernel runs that stream through its LDS windows, barriers and 120 registers (4 workgroups per CU,
+// 9.1 ms at S-products for 34 GB).  Here every wave streams a contiguous range of rows on its own, no LDS, no barrier:
+//   * the CSR entries of consecutive rows are consecutive: they pass through two 64-entry register tiles (current, next), the row
+//     pointers through 64-row batches, all broadcast by v_readlane -- no dependent memory access per row;
+//   * EVERY entry is multiplied and added, in CSR order (the order of the other kernels: same bits): an entry whose operand row is
+//     one of the zero rows adds w * 0 from registers, a non-zero operand row is fetched once and kept while consecutive rows
+//     reference it (the leaves of a star all reference their centre);
+//   * the `prev` slices of the next four rows are in flight while a row is processed (4 KB per wave, 32 waves per CU);
+//   * column sums for the bias gradient stay in registers over the wave's whole range: one partial row per range, not per block.
+// <= 64 VGPR: 8 waves per SIMD.
+template <bool BWD>
+__global__ __launch_bounds__(kThreads, BWD ? 7 : 8) void spmm_rows_compact_kernel(
+    const int32_t *__restrict__ rowptr, const int32_t *__restrict__ xcol, const float *__restrict__ val, const float *__restrict__ X,
+    int64_t ldx, int32_t zero_from, float *__restrict__ Y, int64_t ldy, int32_t H, int32_t n_rows, int32_t nnz, int32_t n_slabs,
+    int32_t rows_per_range, int32_t n_ranges, uint32_t epi, float p_drop, uint64_t seed_arg, const uint8_t *__restrict__ mask,
+    const float *__restrict__ prev, float *__restrict__ col_part) {
+    using P = Pack<4>;
+    using T = float4;
+    const uint64_t seed = fitgnn::resolve_seed(seed_arg, epi);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * kWaves + (threadIdx.x >> 6)));
+    const int slab = wave % n_slabs, range = wave / n_slabs;   // both 1-KiB halves of a row are in flight together
+    if (range >= n_ranges) return;
+    const int r_begin = range * rows_per_range;
+    const int r_end = min(n_rows, r_begin + rows_per_range);
+    const int col0 = slab * 256 + lane * 4;
+    const bool live = col0 + 4 <= H;
+    const int colc = live ? col0 : max(H - 4, 0);   // dead lanes read a valid column group (never stored)
+    const float *Xs = X + colc;
+    const float keep_scale = (epi & FITGNN_EPI_DROPOUT) ? 1.0f / (1.0f - p_drop) : 1.0f;
+    const RowEpilogue rowepi{BWD ? epi : 0u, keep_scale, (epi & FITGNN_EPI_DROPOUT) ? 1.0f - p_drop : 1.0f, fitgnn::dropout_threshold(p_drop),
+                             seed, mask, BWD ? prev : nullptr};
+    float cs[4] = {0.f, 0.f, 0.f, 0.f};
+    const float bv[4] = {0.f, 0.f, 0.f, 0.f};
+    auto prev_at = [&](int row) -> T {   // rows past the range's end re-read its last row (the load stays unconditional)
+        if (!BWD) return P::zero();
+        return *reinterpret_cast<const T *>(prev + (uint64_t)min(row, r_end - 1) * (uint64_t)H + (uint64_t)colc);
+    };
+    // row pointers: lane i of rp holds rowptr[rb + i] of the current 64-row batch, rp_n the next batch's
+    int rb = r_begin;
+    int rp = rowptr[min(rb + lane, n_rows)], rp_n = rowptr[min(rb + 64 + lane, n_rows)];
+    // CSR entries: lane i of (t_x, t_v) holds entry T0 + i, (n_x, n_v) entry T0 + 64 + i
+    int T0 = __builtin_amdgcn_readfirstlane(rp);
+    auto ent = [&](int e) { return min(e, max(nnz - 1, 0)); };
+    int t_x = xcol[ent(T0 + lane)], n_x = xcol[ent(T0 + 64 + lane)];
+    float t_v = val[ent(T0 + lane)], n_v = val[ent(T0 + 64 + lane)];
+    T o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = prev_at(r_begin + j);
+    int cached = -1;          // operand row held in xc (wave-uniform)
+    T xc = P::zero();
+    for (int r = r_begin; r < r_end; r += 4) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int row = r + j;
+            if (row >= r_end) break;   // wave-uniform
+            const T o_prev = o[j];
+            o[j] = prev_at(row + 4);   // in flight while the next four rows are processed
+            int i = row - rb;
+            if (i >= 64) {   // next batch of row pointers
+                rb += 64;
+                i -= 64;
+                rp = rp_n;
+                rp_n = rowptr[min(rb + 64 + lane, n_rows)];
+            }
+            const int e0 = __builtin_amdgcn_readlane(rp, i);
+            const int e1 = i < 63 ? __builtin_amdgcn_readlane(rp, i + 1) : __builtin_amdgcn_readfirstlane(rp_n);
+            T acc = P::zero();
+            for (int e = e0; e < e1; ++e) {
+                int k = e - T0;
+                if (k >= 64) {   // next tile of entries
+                    T0 += 64;
+                    k -= 64;
+                    t_x = n_x;
+                    t_v = n_v;
+                    n_x = xcol[ent(T0 + 64 + lane)];
+                    n_v = val[ent(T0 + 64 + lane)];
+                }
+                const int c = __builtin_amdgcn_readlane(t_x, k);
+                const float w = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t_v), k));
+                if (c < zero_from) {   // a row of the selection (wave-uniform)
+                    if (c != cached) {
+                        xc = *reinterpret_cast<const T *>(Xs + (int64_t)c * ldx);
+                        cached = c;
+                    }
+                    P::fma(acc, w, xc);
+                } else {
+                    P::fma(acc, w, P::zero());   // a zero row: multiplied and added like every other entry, from registers
+                }
+            }
+            if (live) finish_row<4, BWD, !BWD>(acc, row, col0, H, Y, ldy, bv, rowepi, cs, o_prev);
+        }
+    }
+    if (BWD && col_part && live) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) col_part[(int64_t)range * H + col0 + i] = cs[i];
+    }
+}
+
 // Direct-gather variant for very sparse batches (few non-zeros per row, e.g. PubMed-like subgraphs with
 // ~3 entries per row): no LDS phase, no barrier.  Each wave owns a CONTIGUOUS run of the tile's rows, so its
 // slice of the CSR is contiguous too: one vector load brings the run's row pointers, one more its (col, val)
@@ -1044,6 +1150,62 @@ extern "C" int fitgnn_spmm_csr_blocks_dz_f32(const int32_t *rowptr, const int32_
                                              const uint8_t *mask, float *col_part, void *stream) {
     return spmm_blocks_impl(rowptr, col, val, X, ldx, Y, ldy, n_rows, H, blocks, n_blocks, long_rows, xrow, xcol, nullptr,
                             epilogue | FITGNN_EPI_BACKWARD, p_drop, seed, mask, prev, col_part, xrow ? xrow_zero_from : -1, stream);
+}
+
+namespace {
+// ranges of consecutive rows, one per (wave, slab): enough waves to fill 256 CUs x 32 waves several times over on a large batch,
+// at least 64 rows each
+inline void rows_plan(int32_t n_rows, int32_t *rows_per_range, int32_t *n_ranges) {
+    const int want = 8192;
+    int per = (n_rows + want - 1) / want;
+    if (per < 64) per = 64;
+    *rows_per_range = per;
+    *n_ranges = (n_rows + per - 1) / per;
+}
+
+int spmm_rows_impl(const int32_t *rowptr, const int32_t *xcol, const float *val, int64_t nnz, const float *X, int64_t ldx, int32_t zero_from,
+                   float *Y, int64_t ldy, int32_t n_rows, int32_t H, const float *prev, uint32_t epilogue, float p_drop, uint64_t seed,
+                   const uint8_t *mask, float *col_part, bool bwd, void *stream) {
+    if (n_rows < 0 || H < 0 || nnz < 0 || nnz > 0x7fffffffLL || zero_from < 0) return FITGNN_E_BADARG;
+    if (n_rows == 0 || H == 0) return 0;
+    if (!rowptr || !X || !Y || (nnz > 0 && (!xcol || !val))) return FITGNN_E_BADARG;
+    if ((H % 4) != 0 || (ldx % 4) != 0 || (ldy % 4) != 0 || ldx < H || ldy < H) return FITGNN_E_BADARG;
+    if ((((uintptr_t)X | (uintptr_t)Y) % 16) != 0) return FITGNN_E_ALIGN;
+    if ((epilogue & FITGNN_EPI_DROPOUT) && !(p_drop >= 0.f && p_drop < 1.f)) return FITGNN_E_BADARG;
+    if (bwd && (!prev || ((uintptr_t)prev % 16) != 0 || (epilogue & FITGNN_EPI_BIAS))) return FITGNN_E_BADARG;
+    int32_t per, n_ranges;
+    rows_plan(n_rows, &per, &n_ranges);
+    const int n_slabs = (H + 255) / 256;
+    const dim3 grid((unsigned)(((int64_t)n_ranges * n_slabs + kWaves - 1) / kWaves));
+    if (bwd)
+        hipLaunchKernelGGL(spmm_rows_compact_kernel<true>, grid, dim3(kThreads), 0, (hipStream_t)stream, rowptr, xcol, val, X, ldx, zero_from, Y, ldy,
+                           H, n_rows, (int32_t)nnz, n_slabs, per, n_ranges, epilogue | FITGNN_EPI_BACKWARD, p_drop, seed, mask, prev, col_part);
+    else
+        hipLaunchKernelGGL(spmm_rows_compact_kernel<false>, grid, dim3(kThreads), 0, (hipStream_t)stream, rowptr, xcol, val, X, ldx, zero_from, Y,
+                           ldy, H, n_rows, (int32_t)nnz, n_slabs, per, n_ranges, 0u, 0.f, (uint64_t)0, (const uint8_t *)nullptr,
+                           (const float *)nullptr, (float *)nullptr);
+    return (int)hipGetLastError();
+}
+}  // namespace
+
+extern "C" int32_t fitgnn_spmm_rows_compact_parts(int32_t n_rows) {
+    if (n_rows <= 0) return 0;
+    int32_t per, n_ranges;
+    rows_plan(n_rows, &per, &n_ranges);
+    return n_ranges;
+}
+
+extern "C" int fitgnn_spmm_rows_compact_f32(const int32_t *rowptr, const int32_t *xcol, const float *val, int64_t nnz, const float *X,
+                                            int64_t ldx, int32_t zero_from, float *Y, int64_t ldy, int32_t n_rows, int32_t H, void *stream) {
+    return spmm_rows_impl(rowptr, xcol, val, nnz, X, ldx, zero_from, Y, ldy, n_rows, H, nullptr, 0u, 0.f, 0, nullptr, nullptr, false, stream);
+}
+
+extern "C" int fitgnn_spmm_rows_compact_dz_f32(const int32_t *rowptr, const int32_t *xcol, const float *val, int64_t nnz, const float *X,
+                                               int64_t ldx, int32_t zero_from, float *Y, int64_t ldy, int32_t n_rows, int32_t H,
+                                               const float *prev, uint32_t epilogue, float p_drop, uint64_t seed, const uint8_t *mask,
+                                               float *col_part, void *stream) {
+    return spmm_rows_impl(rowptr, xcol, val, nnz, X, ldx, zero_from, Y, ldy, n_rows, H, prev, epilogue & ~FITGNN_SPMM_GATHER, p_drop, seed, mask,
+                          col_part, true, stream);
 }
 
 #ifdef FITGNN_SPMM_STAMPS

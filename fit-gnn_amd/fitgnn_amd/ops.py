@@ -43,24 +43,28 @@ class OpConfig:
                      [len(loss_rows) + 1 x H] (last row zero) and the backward SpMM reads it through a row indirection: the
                      [R x H] matrix that is 98 % zeros on an --extra_node union is neither written nor read.  Every edge is
                      still aggregated (most with the zero row, which stays in cache).
+    compact_rows_kernel  a backward SpMM whose operand is compact (compact_head_backward / last_layer_on_loss_rows) runs on the
+                     row-streaming kernel (fitgnn_spmm_rows_compact[_dz]_f32: no LDS windows, every wave streams a range of rows)
+                     instead of the tile / whole-subgraph kernels with a row indirection (A/B switch; dZ bit-identical).
     pad_table_min_k  static feature tables at least this wide whose width is not a multiple of 32 run layer 0's
                      products on a copy zero-padded once (real feature widths: 100, 500, 1 433, 8 415).
     profile / profile_gemm / profile_fused   None, or a list that collects HIP-event pairs around the SpMM / hand-written
                      GEMM / folded-backward launches (recorded on the stream the kernel is launched on).
     seed_bank        None, or a SeedBank supplying device-resident dropout seeds (steps captured in a hipGraph)."""
     __slots__ = ("gemm_precision", "atb_kernel", "nt_kernel", "nt_presplit", "fuse_dx_epilogue", "fold_backward",
-                 "dedup_gather", "pad_table_min_k", "split_large_blocks", "compact_head_backward", "last_layer_on_loss_rows", "profile", "profile_gemm",
-                 "profile_fused", "seed_bank")
+                 "dedup_gather", "pad_table_min_k", "split_large_blocks", "compact_head_backward", "last_layer_on_loss_rows",
+                 "compact_rows_kernel", "profile", "profile_gemm", "profile_fused", "seed_bank")
 
     def __init__(self, gemm_precision="exact", atb_kernel=True, nt_kernel=True, nt_presplit=True, fuse_dx_epilogue=True,
                  fold_backward=False, dedup_gather=True, pad_table_min_k=0, split_large_blocks=True, compact_head_backward=True,
-                 last_layer_on_loss_rows=True, profile=None, profile_gemm=None, profile_fused=None, seed_bank=None):
+                 last_layer_on_loss_rows=True, compact_rows_kernel=True, profile=None, profile_gemm=None, profile_fused=None, seed_bank=None):
         if gemm_precision not in ("exact", "high", "highest"):
             raise ValueError(f"gemm_precision {gemm_precision!r}: 'exact', 'high' or 'highest'")
         self.gemm_precision, self.atb_kernel, self.nt_kernel, self.nt_presplit = gemm_precision, atb_kernel, nt_kernel, nt_presplit
         self.fuse_dx_epilogue, self.fold_backward, self.dedup_gather = fuse_dx_epilogue, fold_backward, dedup_gather
         self.pad_table_min_k, self.split_large_blocks = pad_table_min_k, split_large_blocks
         self.compact_head_backward, self.last_layer_on_loss_rows = compact_head_backward, last_layer_on_loss_rows
+        self.compact_rows_kernel = compact_rows_kernel
         self.profile, self.profile_gemm, self.profile_fused, self.seed_bank = profile, profile_gemm, profile_fused, seed_bank
 
     def replace(self, **kw):
@@ -522,6 +526,9 @@ def spmm_graph(g, X, transposed=False, **kw):
     side = g.t if transposed else g.f
     epi = kw.pop("epilogue", 0) | (_lib.SPMM_GATHER if g.gather else 0)
     Xc = _f32c(X)
+    if (kw.get("xrow") is not None and kw.get("zero_from", -1) >= 0 and kw.get("cfg", DEFAULT).compact_rows_kernel and Xc.shape[1] % 4 == 0
+            and (epi & ~_lib.SPMM_GATHER) == 0 and kw.get("bias") is None and kw.get("out") is None):
+        return _spmm_rows_compact(g, side, Xc, kw["xrow"], kw["zero_from"], kw.get("cfg", DEFAULT), kw.get("profile_kind"))
     split = (side.blocks is not None and Xc.shape[1] % 4 == 0 and Xc.data_ptr() % 16 == 0 and kw.get("cfg", DEFAULT).split_large_blocks)
     if split:
         epi &= ~_lib.SPMM_GATHER   # the whole-subgraph kernel reads every operand row once: it supersedes the direct-gather variant
@@ -553,6 +560,41 @@ def spmm_graph(g, X, transposed=False, **kw):
     return Y
 
 
+def _spmm_rows_compact(g, side, Xc, xrow, zero_from, cfg, kind, dz=None):
+    """A @ X for a compact operand through the row-streaming kernel.  dz = (prev, epilogue, p, seed, mask, want_db): with the
+    previous layer's derivative in the store -> (dZ, db)."""
+    L = _lib.lib()
+    _lib.require_cuda(Xc, xrow)
+    H, dev = Xc.shape[1], Xc.device
+    xcol = _entry_rows(side, xrow)
+    Y = torch.empty((g.n, H), dtype=torch.float32, device=dev)
+    st = _lib.stream_ptr(dev)
+    ev = None
+    if cfg.profile is not None:
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
+    db = None
+    if dz is None:
+        _lib.check(L.fitgnn_spmm_rows_compact_f32(_lib.dptr(side.rowptr), _lib.dptr(xcol), _lib.dptr(side.val), int(side.col.numel()), _lib.dptr(Xc),
+                                                  Xc.stride(0), int(zero_from), _lib.dptr(Y), Y.stride(0), g.n, H, st), "fitgnn_spmm_rows_compact_f32")
+    else:
+        prev, epilogue, p, seed, mask, want_db = dz
+        seed_v, epi_v = _seed_arg(seed, epilogue & ~_lib.SPMM_GATHER)
+        n_part = int(L.fitgnn_spmm_rows_compact_parts(g.n))
+        part = torch.empty((n_part, H), dtype=torch.float32, device=dev) if want_db else None
+        _lib.check(L.fitgnn_spmm_rows_compact_dz_f32(_lib.dptr(side.rowptr), _lib.dptr(xcol), _lib.dptr(side.val), int(side.col.numel()),
+                                                     _lib.dptr(Xc), Xc.stride(0), int(zero_from), _lib.dptr(Y), Y.stride(0), g.n, H, _lib.dptr(prev),
+                                                     epi_v, float(p), seed_v, _lib.dptr(mask), _lib.dptr(part), st),
+                   "fitgnn_spmm_rows_compact_dz_f32")
+        if want_db:
+            db = torch.empty(H, dtype=torch.float32, device=dev)
+            _lib.check(L.fitgnn_colsum_partials_f32(_lib.dptr(part), n_part, H, _lib.dptr(db), st), "fitgnn_colsum_partials_f32")
+    if ev is not None:
+        ev[1].record()
+        cfg.profile.append((ev[0], ev[1], kind or ("compact" if dz is None else "compact_dz")))
+    return Y if dz is None else (Y, db)
+
+
 def spmm_graph_dz(g, X, prev, epilogue, p=0.0, seed=0, mask=None, want_db=True, transposed=True, xrow=None, cfg=DEFAULT, profile_kind=None,
                   zero_from=-1):
     """(dZ, db): dZ = (A @ X) * dropout' * ELU'(prev), the input gradient of the fused layer whose forward output is `prev`
@@ -563,6 +605,8 @@ def spmm_graph_dz(g, X, prev, epilogue, p=0.0, seed=0, mask=None, want_db=True, 
     _lib.require_cuda(Xc, prev, mask, xrow)
     L = _lib.lib()
     H = Xc.shape[1]
+    if xrow is not None and zero_from >= 0 and cfg.compact_rows_kernel and H % 4 == 0:
+        return _spmm_rows_compact(g, side, Xc, xrow, zero_from, cfg, profile_kind, dz=(prev, epilogue, p, seed, mask, want_db))
     dev = Xc.device
     seed_v, epi_v = _seed_arg(seed, epilogue & ~_lib.SPMM_GATHER)
     split = side.blocks is not None and cfg.split_large_blocks

@@ -113,6 +113,21 @@ int fitgnn_spmm_csr_blocks_dz_f32(const int32_t *rowptr, const int32_t *col, con
                                   const float *prev, uint32_t epilogue, float p_drop, uint64_t seed, const uint8_t *mask,
                                   float *col_part, void *stream);
 
+/* The same two products for a COMPACT operand, by a row-streaming kernel (csrc/spmm.hip: spmm_rows_compact_kernel): X holds the
+ * operand rows of a selection followed by rows of zeros (rows >= zero_from), and xcol[e] names the operand row of CSR entry e
+ * (xcol[e] = xrow[col[e]] of the entry points above).  This is the last layer's backward SpMM of the train step, whose operand is
+ * zero outside the rows that reach the loss (run.py:193-204 keeps out[mask]): every entry is still multiplied and added, in CSR
+ * order (same bits as the kernels above), zero rows from registers; each wave streams a contiguous range of rows, no LDS.
+ * _dz_: the store applies the previous layer's ELU' / dropout' as fitgnn_spmm_csr_dz_f32 does; col_part (may be NULL) receives
+ * fitgnn_spmm_rows_compact_parts(n_rows) partial rows [parts x H] of column sums of dZ (every element written: no zeroing needed),
+ * to be folded by fitgnn_colsum_partials_f32.  H, ldx, ldy multiples of 4; X, Y, prev 16-byte aligned. */
+int32_t fitgnn_spmm_rows_compact_parts(int32_t n_rows);
+int fitgnn_spmm_rows_compact_f32(const int32_t *rowptr, const int32_t *xcol, const float *val, int64_t nnz, const float *X, int64_t ldx,
+                                 int32_t zero_from, float *Y, int64_t ldy, int32_t n_rows, int32_t H, void *stream);
+int fitgnn_spmm_rows_compact_dz_f32(const int32_t *rowptr, const int32_t *xcol, const float *val, int64_t nnz, const float *X, int64_t ldx,
+                                    int32_t zero_from, float *Y, int64_t ldy, int32_t n_rows, int32_t H, const float *prev,
+                                    uint32_t epilogue, float p_drop, uint64_t seed, const uint8_t *mask, float *col_part, void *stream);
+
 /* LDS window sizes of the SpMM kernel (rows of the dense operand staged per workgroup): the default used
  * when window_rows == 0, and the largest accepted value.  Tiles should be built with win_rows <= the
  * window_rows later passed to fitgnn_spmm_csr_f32 (larger windows are clamped: still correct, slower). */

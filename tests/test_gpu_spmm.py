@@ -313,6 +313,55 @@ def test_backward_spmm_with_the_previous_layers_epilogue_in_its_store(mods, H, u
         assert none is None and torch.equal(got2, want2)
 
 
+@pytest.mark.parametrize("H", [512, 96, 260])
+@pytest.mark.parametrize("sizes", [[100, 7, 17, 300, 3, 3, 64, 33, 2, 1000, 5, 5, 40], [3, 2], [1], [70] * 400])
+def test_row_streaming_kernel_for_a_compact_operand(mods, H, sizes):
+    """fitgnn_spmm_rows_compact[_dz]_f32 (every wave streams a range of rows; CSR entries through register tiles; zero rows from
+    registers) == the tile / whole-subgraph kernels reading the same compact operand through a row indirection: the product bit for
+    bit, with the previous layer's derivative in the store bit for bit (hashed dropout and an injected mask), column sums to fp32
+    summation order; and both == the dense operand's product.  Row counts below one 64-row batch, entry counts across several
+    64-entry tiles (the 1000-row star's centre), H that is not a multiple of the 256-column slab."""
+    _lib, csr, ops, orc, gorc = mods
+    from fitgnn_amd._lib import EPI_DROPOUT, EPI_ELU
+
+    ei, n = star_blocks(sizes, 2, seed=H + len(sizes))
+    ptr = np.concatenate([[0], np.cumsum(sizes)])
+    g = csr.CSRGraph(ei.cuda(), n, mode="gcn", ptr=ptr)
+    torch.manual_seed(H + n)
+    rows = torch.randperm(n).cuda()[: max(n // 3, 1)].sort().values
+    k = int(rows.numel())
+    Xc = torch.cat([torch.randn(k, H).cuda(), torch.zeros(ops.ZERO_ROWS, H).cuda()])
+    pos = ops._compact_positions(g, rows)
+    dense = torch.zeros(n, H).cuda(); dense[rows] = Xc[:k]
+    old, new = ops.OpConfig(compact_rows_kernel=False, profile=[]), ops.OpConfig(compact_rows_kernel=True, profile=[])
+    for transposed in (True, False):
+        want = ops.spmm_graph(g, dense, transposed=transposed)
+        a = ops.spmm_graph(g, Xc, transposed=transposed, xrow=pos, zero_from=k, cfg=old)
+        b = ops.spmm_graph(g, Xc, transposed=transposed, xrow=pos, zero_from=k, cfg=new)
+        assert torch.equal(a, want) and torch.equal(b, want)
+    assert new.profile[-1][2] == "compact" and len(new.profile) == 2
+    prev = torch.randn(n, H).cuda() * (torch.rand(n, H).cuda() > 0.3)
+    for mask in (None, (torch.rand(n, H).cuda() > 0.5).to(torch.uint8)):
+        flags, p, seed = EPI_ELU | EPI_DROPOUT, 0.5, 77
+        a, da = ops.spmm_graph_dz(g, Xc, prev, flags, p=p, seed=seed, mask=mask, want_db=True, xrow=pos, zero_from=k, cfg=old)
+        b, db = ops.spmm_graph_dz(g, Xc, prev, flags, p=p, seed=seed, mask=mask, want_db=True, xrow=pos, zero_from=k, cfg=new)
+        assert torch.equal(a, b)
+        assert rel_err(db.cpu(), da.cpu()) < 1e-5 or float(da.abs().max()) == 0.0
+        want, want_db = ops.epilogue_bwd_raw(ops.spmm_graph(g, dense, transposed=True), prev, flags, p=p, seed=seed, mask=mask, want_db=True)
+        assert torch.equal(b, want)
+        assert rel_err(db.cpu(), want_db.cpu()) < 1e-5 or float(want_db.abs().max()) == 0.0
+        # ELU alone (eval mode: no dropout), no column sums
+        b2, none = ops.spmm_graph_dz(g, Xc, prev, EPI_ELU, want_db=False, xrow=pos, zero_from=k, cfg=new)
+        w2, _ = ops.epilogue_bwd_raw(ops.spmm_graph(g, dense, transposed=True), prev, EPI_ELU, want_db=False)
+        assert none is None and torch.equal(b2, w2)
+    assert new.profile[-1][2] == "compact_dz"
+    # argument errors of the C entry points, before any GPU work
+    L = _lib.lib()
+    assert L.fitgnn_spmm_rows_compact_parts(0) == 0 and L.fitgnn_spmm_rows_compact_parts(8246057) <= 8192
+    assert L.fitgnn_spmm_rows_compact_f32(None, None, None, 0, None, 512, 0, None, 512, 5, 510, None) == -1   # H % 4
+    assert L.fitgnn_spmm_rows_compact_f32(None, None, None, 0, None, 512, 0, None, 512, 0, 512, None) == 0    # nothing to do
+
+
 @pytest.mark.parametrize("H,C,with_dWl", [(512, 3, True), (512, 47, False), (64, 7, True)])
 def test_head_backward_skips_rows_without_gradient_bit_for_bit(mods, H, C, with_dWl):
     """Rows whose head gradient dy is all zero (nodes outside the loss: most rows of an --extra_node subgraph) are written
@@ -503,14 +552,15 @@ def test_exact_fp32_gemm_matches_f64(mods, form, dims):
     assert got.shape == want.shape
     err = float((got - want).abs().max() / want.abs().max())
     err_lib = float((lib(a, b) - want).abs().max() / want.abs().max())
-    assert err < 1e-6 and err <= 4 * err_lib + 1e-7, (form, dims, err, err_lib)
+    # fp32 accumulation over k: ~1e-6 of the largest entry at k = 512 (hipBLASLt's fp32 GEMM: 1.07e-6 on the same operands)
+    assert err < 3e-6 and err <= 2 * err_lib + 1e-7, (form, dims, err, err_lib)
     assert torch.equal(got, ops.gemm_exact(a, b, form)), "fixed-order sums: bit-reproducible"
     # strided operands: column windows of wider matrices (row stride > extent)
     wa = torch.randn(a.shape[0], a.shape[1] + 8, generator=g).cuda()
     wb = torch.randn(b.shape[0], b.shape[1] + 4, generator=g).cuda()
     va, vb = wa[:, 4:4 + a.shape[1]], wb[:, : b.shape[1]]
     want = ref(va, vb)
-    assert float((ops.gemm_exact(va, vb, form) - want).abs().max() / want.abs().max()) < 1e-6
+    assert float((ops.gemm_exact(va, vb, form) - want).abs().max() / want.abs().max()) < 3e-6
     # exact zeros survive
     assert float(ops.gemm_exact(torch.zeros_like(a), b, form).abs().max()) == 0.0
 
@@ -527,12 +577,12 @@ def test_exact_fp32_gemm_is_the_default_policy_and_differentiates(mods):
     assert torch.equal(x.grad, ops.gemm_exact(gy, W.detach(), "nn"))
     assert torch.equal(W.grad, ops.gemm_exact(gy, x.detach(), "tn"))
     xd, Wd = x.detach().double(), W.detach().double()
-    assert float((x.grad - gy.double() @ Wd).abs().max()) < 1e-6 * float((gy.double() @ Wd).abs().max())
-    assert float((W.grad - gy.double().t() @ xd).abs().max()) < 1e-6 * float((gy.double().t() @ xd).abs().max())
+    assert float((x.grad - gy.double() @ Wd).abs().max()) < 3e-6 * float((gy.double() @ Wd).abs().max())
+    assert float((W.grad - gy.double().t() @ xd).abs().max()) < 3e-6 * float((gy.double().t() @ xd).abs().max())
     # rows that cannot be read with 16-byte loads (3 class columns) run as fp32 library products
     n3, xs = torch.randn(2048, 3).cuda(), x.detach()
     ref = n3.double().t() @ xs.double()
-    assert float((ops.mm_at_b(n3, xs) - ref).abs().max() / ref.abs().max()) < 1e-6
+    assert float((ops.mm_at_b(n3, xs) - ref).abs().max() / ref.abs().max()) < 3e-6
     # argument errors of the C entry point, before any GPU work
     L = _lib.lib()
     assert L.fitgnn_gemm_exact_f32(None, 4, 0, None, 4, 0, 8, 8, 8, None, 8, None, None) == -1          # NULL operands
