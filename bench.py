@@ -60,6 +60,8 @@ def parse_args():
     ap.add_argument("--no-dedup-gather", action="store_true",
                     help="A/B: layer 0 on the de-duplicated table through the LDS-window SpMM (row indirection) instead of the "
                          "direct-gather variant")
+    ap.add_argument("--no-stream-kernel", action="store_true", help="A/B: the whole-subgraph kernel (LDS windows) instead of the segment-streaming one")
+    ap.add_argument("--no-compact-rows", action="store_true", help="A/B: the compact backward operand through the tile / whole-subgraph kernels")
     ap.add_argument("--gemm-precision", default="exact", choices=["exact", "high", "highest"],
                     help="dense GEMM policy of the timed region (ops.OpConfig.gemm_precision): exact = the reference's arithmetic, "
                          "fp32 products and accumulation on the fp32 MFMA (csrc/gemm_f32.hip); high = 3 x bf16 split (rel err ~5e-6); "
@@ -229,7 +231,8 @@ def main():
         # loss_rows_only=False: the last layer transform-first with every dense operation over all union rows (the shape of the
         # reference's step); True (default): aggregate-first, the dense part on the rows that reach the loss -- see DESIGN §0
         cfg = ops.OpConfig(gemm_precision=precision, fold_backward=args.fold, dedup_gather=not args.no_dedup_gather,
-                           last_layer_on_loss_rows=loss_rows_only, compact_head_backward=loss_rows_only)
+                           last_layer_on_loss_rows=loss_rows_only, compact_head_backward=loss_rows_only,
+                           stream_kernel=not args.no_stream_kernel, compact_rows_kernel=not args.no_compact_rows)
         tr = train.GDTrainer(model, batch, lr=0.01, weight_decay=5e-4, dedup=not args.no_dedup,
                              prune_unused_rows=args.prune_unused_rows, op_config=cfg)
         return tr, sd

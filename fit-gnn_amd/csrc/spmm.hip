@@ -64,18 +64,14 @@ struct RowEpilogue {
     const float *prev;
 };
 // BWD_OK == false compiles the backward mode out (the whole-subgraph kernel's forward instantiations sit at their register limit)
+// epilogue_value: the row's slice as it leaves the kernel (see RowEpilogue); finish_row: + the store.
+// o: the row's slice of E.prev, requested by the caller BEFORE it aggregated the row (prev_row): the load rides under the row's
+// gathers instead of standing between the last FMA and the store
 template <int VEC, bool BWD_OK = true, bool NOEPI = false>
-__device__ __forceinline__ void finish_row(typename Pack<VEC>::T acc, int row, int col0, int H, float *__restrict__ Y,
-                                           int64_t ldy, const float (&bv)[VEC], const RowEpilogue &E, float (&cs)[VEC],
-                                           const typename Pack<VEC>::T &o) {
-    if (NOEPI) {  // a plain product (the launcher saw epilogue == 0): nothing but the store
-        *reinterpret_cast<typename Pack<VEC>::T *>(Y + (int64_t)row * ldy + col0) = acc;
-        return;
-    }
-    // o: the row's slice of E.prev, requested by the caller BEFORE it aggregated the row (prev_row): the load rides under the row's
-    // gathers instead of standing between the last FMA and the store
+__device__ __forceinline__ typename Pack<VEC>::T epilogue_value(typename Pack<VEC>::T acc, int row, int col0, int H, const float (&bv)[VEC],
+                                                                const RowEpilogue &E, float (&cs)[VEC], const typename Pack<VEC>::T &o) {
+    if (NOEPI) return acc;  // a plain product (the launcher saw epilogue == 0)
     using P = Pack<VEC>;
-    using T = typename P::T;
     const uint32_t epi = E.epi;
     uint64_t bits = 0;
     const uint64_t idx0 = (uint64_t)row * (uint64_t)H + (uint64_t)col0;
@@ -95,11 +91,7 @@ __device__ __forceinline__ void finish_row(typename Pack<VEC>::T acc, int row, i
             P::set(acc, i, d);
             cs[i] += d;
         }
-#ifdef FITGNN_SPMM_NOSTORE
-        if (cs[0] == 12345.678f)
-#endif
-        *reinterpret_cast<T *>(Y + (int64_t)row * ldy + col0) = acc;
-        return;
+        return acc;
     }
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
@@ -111,11 +103,39 @@ __device__ __forceinline__ void finish_row(typename Pack<VEC>::T acc, int row, i
         }
         P::set(acc, i, z);
     }
-#ifdef FITGNN_SPMM_NOSTORE
-    if (P::get(acc, 0) == 12345.678f)
-#endif
-    *reinterpret_cast<T *>(Y + (int64_t)row * ldy + col0) = acc;
+    return acc;
 }
+
+template <int VEC, bool BWD_OK = true, bool NOEPI = false>
+__device__ __forceinline__ void finish_row(typename Pack<VEC>::T acc, int row, int col0, int H, float *__restrict__ Y,
+                                           int64_t ldy, const float (&bv)[VEC], const RowEpilogue &E, float (&cs)[VEC],
+                                           const typename Pack<VEC>::T &o) {
+    using T = typename Pack<VEC>::T;
+    const T out = epilogue_value<VEC, BWD_OK, NOEPI>(acc, row, col0, H, bv, E, cs, o);
+#ifdef FITGNN_SPMM_NOSTORE
+    if (Pack<VEC>::get(out, 0) == 12345.678f)
+#endif
+    *reinterpret_cast<T *>(Y + (int64_t)row * ldy + col0) = out;
+}
+
+// Vector-memory accesses whose completion the kernel counts BY HAND (the row-streaming kernels below).  hipcc's waitcnt insertion
+// cannot count across their loops with conditional loads and falls back to s_waitcnt vmcnt(0) before every use -- which waits for
+// the prefetch issued one instruction earlier, i.e. turns a four-row prefetch ring into one memory round trip per row (measured:
+// 49 of 62 waits were vmcnt(0)).  As inline asm the accesses are invisible to that pass; the kernels place s_waitcnt vmcnt(N)
+// themselves (vmcnt retires in issue order, loads and stores together: "at most N outstanding" completes everything older than
+// the N youngest).  `sbase` must be wave-uniform (an SGPR pair), voff a byte offset per lane.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void vm_load4(f32x4 &d, const float *sbase, uint32_t voff) {
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(d) : "v"(voff), "s"(sbase) : "memory");
+}
+__device__ __forceinline__ void vm_load1(int &d, const void *sbase, uint32_t voff) {
+    asm volatile("global_load_dword %0, %1, %2" : "=v"(d) : "v"(voff), "s"(sbase) : "memory");
+}
+__device__ __forceinline__ void vm_store4(float *sbase, uint32_t voff, f32x4 v) {
+    asm volatile("global_store_dwordx4 %0, %1, %2" : : "v"(voff), "v"(v), "s"(sbase) : "memory");
+}
+__device__ __forceinline__ float4 as_float4(f32x4 v) { return make_float4(v[0], v[1], v[2], v[3]); }
+__device__ __forceinline__ f32x4 as_f32x4(float4 v) { f32x4 r = {v.x, v.y, v.z, v.w}; return r; }
 
 template <int VEC, bool BWD_OK = true>
 __device__ __forceinline__ typename Pack<VEC>::T prev_row(const RowEpilogue &E, int row, int col0, int H, bool live) {
@@ -753,71 +773,329 @@ __global__ __launch_bounds__(kThreads, BWD ? 7 : 8) void spmm_rows_compact_kerne
     const int col0 = slab * 256 + lane * 4;
     const bool live = col0 + 4 <= H;
     const int colc = live ? col0 : max(H - 4, 0);   // dead lanes read a valid column group (never stored)
-    const float *Xs = X + colc;
+    const uint32_t cbytes = (uint32_t)colc * 4u;
     const float keep_scale = (epi & FITGNN_EPI_DROPOUT) ? 1.0f / (1.0f - p_drop) : 1.0f;
     const RowEpilogue rowepi{BWD ? epi : 0u, keep_scale, (epi & FITGNN_EPI_DROPOUT) ? 1.0f - p_drop : 1.0f, fitgnn::dropout_threshold(p_drop),
                              seed, mask, BWD ? prev : nullptr};
     float cs[4] = {0.f, 0.f, 0.f, 0.f};
     const float bv[4] = {0.f, 0.f, 0.f, 0.f};
-    auto prev_at = [&](int row) -> T {   // rows past the range's end re-read its last row (the load stays unconditional)
-        if (!BWD) return P::zero();
-        return *reinterpret_cast<const T *>(prev + (uint64_t)min(row, r_end - 1) * (uint64_t)H + (uint64_t)colc);
+    // Every vector-memory access of the row loop is issued through vm_load* / vm_store4 and waited for by count.  Per row, in this
+    // order: [wait] one `prev` load (BWD; row + 4), the occasional batch / tile / operand-row loads, one store.  So when row r starts,
+    // the 2 x 3 + 1 accesses of rows r-3 .. r-1 and the store of r-4 are younger than the load of prev[r] (issued as row r-4
+    // started): s_waitcnt vmcnt(7) completes it and everything older -- conditional loads in between only make the wait safer.
+    auto prev_issue = [&](f32x4 &d, int row) {   // rows past the range's end re-read its last row (one load per row, always)
+        vm_load4(d, prev + (uint64_t)min(row, r_end - 1) * (uint64_t)H, cbytes);
     };
     // row pointers: lane i of rp holds rowptr[rb + i] of the current 64-row batch, rp_n the next batch's
     int rb = r_begin;
-    int rp = rowptr[min(rb + lane, n_rows)], rp_n = rowptr[min(rb + 64 + lane, n_rows)];
+    int rp, rp_n;
+    vm_load1(rp, rowptr, (uint32_t)min(rb + lane, n_rows) * 4u);
+    vm_load1(rp_n, rowptr, (uint32_t)min(rb + 64 + lane, n_rows) * 4u);
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(rp), "+v"(rp_n));
     // CSR entries: lane i of (t_x, t_v) holds entry T0 + i, (n_x, n_v) entry T0 + 64 + i
     int T0 = __builtin_amdgcn_readfirstlane(rp);
-    auto ent = [&](int e) { return min(e, max(nnz - 1, 0)); };
-    int t_x = xcol[ent(T0 + lane)], n_x = xcol[ent(T0 + 64 + lane)];
-    float t_v = val[ent(T0 + lane)], n_v = val[ent(T0 + 64 + lane)];
-    T o[4];
+    const int last_e = max(nnz - 1, 0);
+    int t_x, n_x, t_vi, n_vi;   // values as raw bits
+    auto tile_issue = [&](int &dx, int &dv, int e0) {
+        const uint32_t off = (uint32_t)min(e0 + lane, last_e) * 4u;
+        vm_load1(dx, xcol, off);
+        vm_load1(dv, val, off);
+    };
+    tile_issue(t_x, t_vi, T0);
+    tile_issue(n_x, n_vi, T0 + 64);
+    int tile_row = r_begin - 8;   // the row during which the `next` tile was last requested
+    f32x4 o[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    if (BWD) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) o[j] = prev_at(r_begin + j);
+        for (int j = 0; j < 4; ++j) prev_issue(o[j], r_begin + j);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(t_x), "+v"(t_vi), "+v"(n_x), "+v"(n_vi), "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3]));
     int cached = -1;          // operand row held in xc (wave-uniform)
-    T xc = P::zero();
+    f32x4 xc = {0.f, 0.f, 0.f, 0.f};
     for (int r = r_begin; r < r_end; r += 4) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int row = r + j;
             if (row >= r_end) break;   // wave-uniform
-            const T o_prev = o[j];
-            o[j] = prev_at(row + 4);   // in flight while the next four rows are processed
+            T o_prev = P::zero();
+            if (BWD) {
+                asm volatile("s_waitcnt vmcnt(7)" : "+v"(o[j]), "+v"(rp_n), "+v"(n_x), "+v"(n_vi));
+                o_prev = as_float4(o[j]);
+                prev_issue(o[j], row + 4);   // in flight while the next four rows are processed
+            } else {
+                asm volatile("s_waitcnt vmcnt(3)" : "+v"(rp_n), "+v"(n_x), "+v"(n_vi));   // no ring: one store per row
+            }
             int i = row - rb;
-            if (i >= 64) {   // next batch of row pointers
+            if (i >= 64) {   // next batch of row pointers (requested 64 rows ago)
                 rb += 64;
                 i -= 64;
                 rp = rp_n;
-                rp_n = rowptr[min(rb + 64 + lane, n_rows)];
+                vm_load1(rp_n, rowptr, (uint32_t)min(rb + 64 + lane, n_rows) * 4u);
             }
             const int e0 = __builtin_amdgcn_readlane(rp, i);
-            const int e1 = i < 63 ? __builtin_amdgcn_readlane(rp, i + 1) : __builtin_amdgcn_readfirstlane(rp_n);
+            int e1;
+            if (i < 63) e1 = __builtin_amdgcn_readlane(rp, i + 1);
+            else {   // the first pointer of the next batch: requested at least a row ago, but possibly younger than this row's wait
+                if (row - rb < 5 + 63) asm volatile("s_waitcnt vmcnt(0)" : "+v"(rp_n));
+                e1 = __builtin_amdgcn_readfirstlane(rp_n);
+            }
             T acc = P::zero();
             for (int e = e0; e < e1; ++e) {
                 int k = e - T0;
                 if (k >= 64) {   // next tile of entries
+                    // requested during row tile_row: complete by this row's wait only if that lies five rows back
+                    if (row - tile_row < 5) asm volatile("s_waitcnt vmcnt(0)" : "+v"(n_x), "+v"(n_vi));
                     T0 += 64;
                     k -= 64;
                     t_x = n_x;
-                    t_v = n_v;
-                    n_x = xcol[ent(T0 + 64 + lane)];
-                    n_v = val[ent(T0 + 64 + lane)];
+                    t_vi = n_vi;
+                    tile_issue(n_x, n_vi, T0 + 64);
+                    tile_row = row;
                 }
                 const int c = __builtin_amdgcn_readlane(t_x, k);
-                const float w = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t_v), k));
+                const float w = __int_as_float(__builtin_amdgcn_readlane(t_vi, k));
                 if (c < zero_from) {   // a row of the selection (wave-uniform)
                     if (c != cached) {
-                        xc = *reinterpret_cast<const T *>(Xs + (int64_t)c * ldx);
+                        vm_load4(xc, X + (int64_t)c * ldx, cbytes);
+                        asm volatile("s_waitcnt vmcnt(0)" : "+v"(xc));
                         cached = c;
                     }
-                    P::fma(acc, w, xc);
+                    P::fma(acc, w, as_float4(xc));
                 } else {
                     P::fma(acc, w, P::zero());   // a zero row: multiplied and added like every other entry, from registers
                 }
             }
-            if (live) finish_row<4, BWD, !BWD>(acc, row, col0, H, Y, ldy, bv, rowepi, cs, o_prev);
+            const T out = epilogue_value<4, BWD, !BWD>(acc, row, col0, H, bv, rowepi, cs, o_prev);
+            if (live) vm_store4(Y + (int64_t)row * ldy, (uint32_t)col0 * 4u, as_f32x4(out));
         }
     }
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3]), "+v"(rp_n), "+v"(n_x), "+v"(n_vi) : : "memory");
+    if (BWD && col_part && live) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) col_part[(int64_t)range * H + col0 + i] = cs[i];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Segment-streaming kernel (fitgnn_spmm_csr_stream_f32 / _dz_f32): the whole-subgraph kernel's algorithm, one WAVE per run of
+// segments instead of one workgroup per segment -- no LDS, no barrier.
+//
+// A segment is a run of consecutive rows whose FIRST row is its hub: in the star-by-star layout of an --extra_node union
+// (data.assemble_subgraphs_torch, layout="star") an own node of the cluster followed by the extra nodes that are there because they
+// neighbour it (utils.py:235-239).  A wave streams the rows of its segments in order; the operand row of a row passes through
+// the wave's registers exactly once and serves, while it is there,
+//   * the row's own entry (self loop),
+//   * the hub's entry for that row: the hub's accumulator is carried across the segment and takes its entries in CSR order as the
+//     rows stream by (columns inside a segment are its rows, ascending) -- the order of the one-row-at-a-time kernels: same bits;
+// a row's entry for its hub reads the hub's operand row kept in registers; everything else (edges between extra nodes, the other
+// own nodes of the cluster) is gathered from L2 / HBM, four of a row's entries in flight.  So every operand row is read from HBM
+// once by the wave that owns it and every output row is written once, as in the whole-subgraph kernel -- without its LDS windows,
+// two barriers per 16-row piece and 79-120 registers: the waves are independent, 5-6 per SIMD, each with the operand rows (and, in
+// the backward form, the `prev` slices) of the next four rows in flight.  Row pointers, segment starts, the row indirection and
+// the CSR entries pass through register batches / tiles broadcast by v_readlane: no dependent memory access per row.
+// XROW: operand row r lives at X[xrow[r]] (layer 0 on the de-duplicated table), xcol[e] = xrow[col[e]] per entry.
+template <bool XROW, bool BWD, bool NOEPI>
+__global__ __launch_bounds__(kThreads, BWD ? 4 : (NOEPI && !XROW) ? 6 : 5) void spmm_stream_kernel(
+    const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col, const float *__restrict__ val, const float *__restrict__ X,
+    int64_t ldx, float *__restrict__ Y, int64_t ldy, int32_t H, int32_t n_rows, int32_t nnz, const int32_t *__restrict__ seg_ptr,
+    int32_t n_seg, const int32_t *__restrict__ range_seg, int32_t n_ranges, int32_t n_slabs, const float *__restrict__ bias, uint32_t epi,
+    float p_drop, uint64_t seed_arg, const uint8_t *__restrict__ mask, const int32_t *__restrict__ xrow, const int32_t *__restrict__ xcol,
+    const float *__restrict__ prev, float *__restrict__ col_part) {
+    using P = Pack<4>;
+    using T = float4;
+    const uint64_t seed = fitgnn::resolve_seed(seed_arg, epi);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * kWaves + (threadIdx.x >> 6)));
+    const int slab = wave % n_slabs, range = wave / n_slabs;   // both 1-KiB halves of a row are in flight together
+    if (range >= n_ranges) return;
+    const int s_begin = range_seg[range], s_end = range_seg[range + 1];
+    const int r_begin = seg_ptr[s_begin], r_end = seg_ptr[s_end];
+    const int col0 = slab * 256 + lane * 4;
+    const bool live = col0 + 4 <= H;
+    const int colc = live ? col0 : max(H - 4, 0);   // dead lanes read a valid column group (never stored)
+    const float *Xs = X + colc;
+    const float keep_scale = (epi & FITGNN_EPI_DROPOUT) ? 1.0f / (1.0f - p_drop) : 1.0f;
+    const RowEpilogue rowepi{BWD ? epi : (epi & ~FITGNN_EPI_BACKWARD), keep_scale, (epi & FITGNN_EPI_DROPOUT) ? 1.0f - p_drop : 1.0f,
+                             fitgnn::dropout_threshold(p_drop), seed, mask, BWD ? prev : nullptr};
+    float cs[4] = {0.f, 0.f, 0.f, 0.f};
+    float bv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bv[i] = (!NOEPI && (epi & FITGNN_EPI_BIAS) && live) ? bias[col0 + i] : 0.f;
+    if (r_begin >= r_end) {
+        if (BWD && col_part && live) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) col_part[(int64_t)range * H + col0 + i] = 0.f;
+        }
+        return;
+    }
+    auto ent = [&](int e) { return min(e, nnz - 1); };   // nnz >= n_rows >= 1 here (every row has its self loop or is empty: clamp anyway)
+    // ---- register batches: row pointers (and the row indirection) of 64 rows, the starts of 64 segments ----
+    int rb = r_begin;
+    int rp = rowptr[min(rb + lane, n_rows)], rp_n = rowptr[min(rb + 64 + lane, n_rows)];
+    int xr = 0, xr_n = 0;
+    if (XROW) { xr = xrow[min(rb + lane, n_rows - 1)]; xr_n = xrow[min(rb + 64 + lane, n_rows - 1)]; }
+    int sb = s_begin + 1;   // sg lane i = start of segment sb + i (the first segment starts at r_begin)
+    int sg = seg_ptr[min(sb + lane, n_seg)];
+    int si = 0;
+    int next_seg = __builtin_amdgcn_readfirstlane(sg);   // = seg_ptr[s_begin + 1]
+    auto src_of = [&](int row) -> int64_t {   // operand row of union row `row` (rb <= row < rb + 128)
+        if (!XROW) return (int64_t)row;
+        const int i = row - rb;
+        return (int64_t)(i < 64 ? __builtin_amdgcn_readlane(xr, i) : __builtin_amdgcn_readlane(xr_n, i - 64));
+    };
+    auto row_at = [&](int row) -> T { return *reinterpret_cast<const T *>(Xs + src_of(min(row, r_end - 1)) * ldx); };
+    auto prev_at = [&](int row) -> T {
+        if (!BWD) return P::zero();
+        return *reinterpret_cast<const T *>(prev + (uint64_t)min(row, r_end - 1) * (uint64_t)H + (uint64_t)colc);
+    };
+    // ---- CSR entries of the leaf rows: two 64-entry register tiles (current, next) over the sequential entry stream ----
+    int T0 = __builtin_amdgcn_readfirstlane(rp);
+    int t_c, t_x = 0, n_c, n_x = 0;
+    float t_v, n_v;
+    auto load_tiles = [&]() {
+        t_c = col[ent(T0 + lane)]; t_v = val[ent(T0 + lane)];
+        n_c = col[ent(T0 + 64 + lane)]; n_v = val[ent(T0 + 64 + lane)];
+        if (XROW) { t_x = xcol[ent(T0 + lane)]; n_x = xcol[ent(T0 + 64 + lane)]; }
+    };
+    load_tiles();
+    // ---- the hub: its operand row, its accumulator, a 64-entry tile of ITS entries and the cursor into them ----
+    int hub = -1, h1 = 0, cur = 0, HB = 0;
+    int h_c = 0, h_x = 0;
+    float h_v = 0.f;
+    T xhub = P::zero(), acc_h = P::zero(), o_hub = P::zero();
+    auto hub_tile = [&]() {   // entries [HB, HB + 64) of the hub's row
+        const int e = HB + lane;
+        h_c = e < h1 ? col[e] : 0x7fffffff;
+        h_v = e < h1 ? val[e] : 0.f;
+        if (XROW) h_x = e < h1 ? xcol[e] : 0;
+    };
+    // hub entries whose column is < bound and that lie OUTSIDE the streamed rows (other segments): gathered, four in flight
+    auto hub_gather = [&](int bound) {
+        while (cur < h1) {
+            if (cur - HB >= 64) { HB = cur; hub_tile(); }
+            const int k0 = cur - HB;
+            const unsigned long long in = __ballot(h_c < bound) >> k0;
+            const int n_in = in == 0 ? 0 : (int)__builtin_popcountll(in);
+            for (int k = k0; k < k0 + n_in; k += 4) {
+                const int last = k0 + n_in - 1;
+                T x[4];
+                float w[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int kk = min(k + u, last);
+                    const int64_t c = XROW ? (int64_t)__builtin_amdgcn_readlane(h_x, kk) : (int64_t)__builtin_amdgcn_readlane(h_c, kk);
+                    w[u] = k + u <= last ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(h_v), kk)) : 0.f;
+                    x[u] = *reinterpret_cast<const T *>(Xs + c * ldx);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) P::fma(acc_h, w[u], x[u]);
+            }
+            cur += n_in;
+            if (k0 + n_in < 64) break;   // the rest of the tile is >= bound
+        }
+    };
+    auto finish_hub = [&]() {
+        if (hub < 0) return;
+        hub_gather(0x7fffffff);
+        if (live) finish_row<4, BWD, NOEPI>(acc_h, hub, col0, H, Y, ldy, bv, rowepi, cs, o_hub);
+    };
+    T xq[4], oq[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { xq[j] = row_at(r_begin + j); oq[j] = prev_at(r_begin + j); }
+    for (int r = r_begin; r < r_end; r += 4) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int row = r + j;
+            if (row >= r_end) break;   // wave-uniform
+            if (row - rb >= 64) {      // next batch of row pointers / row indirection
+                rb += 64;
+                rp = rp_n;
+                rp_n = rowptr[min(rb + 64 + lane, n_rows)];
+                if (XROW) { xr = xr_n; xr_n = xrow[min(rb + 64 + lane, n_rows - 1)]; }
+            }
+            const T x = xq[j];
+            const T o_prev = oq[j];
+            xq[j] = row_at(row + 4);   // in flight while the next four rows are processed
+            oq[j] = prev_at(row + 4);
+            const int i = row - rb;
+            const int e0 = __builtin_amdgcn_readlane(rp, i);
+            const int e1 = i < 63 ? __builtin_amdgcn_readlane(rp, i + 1) : __builtin_amdgcn_readfirstlane(rp_n);
+            if (row == r_begin || row == next_seg) {   // ---- a segment starts: this row is its hub ----
+                finish_hub();
+                if (row != r_begin) {
+                    if (++si >= 64) { sb += 64; si = 0; sg = seg_ptr[min(sb + lane, n_seg)]; }
+                    next_seg = __builtin_amdgcn_readlane(sg, si);
+                }
+                hub = row;
+                xhub = x;
+                o_hub = o_prev;
+                acc_h = P::zero();
+                cur = e0;
+                h1 = e1;
+                HB = e0;
+                hub_tile();
+                hub_gather(row);   // entries left of the hub (other segments), then its own entry
+                if (cur < h1) {
+                    if (cur - HB >= 64) { HB = cur; hub_tile(); }
+                    if (__builtin_amdgcn_readlane(h_c, cur - HB) == row) {
+                        P::fma(acc_h, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(h_v), cur - HB)), x);
+                        ++cur;
+                    }
+                }
+                continue;
+            }
+            // ---- a row of the hub's segment ----
+            T acc = P::zero();
+            for (int base = e0; base < e1; base += 4) {
+                int k = base - T0;
+                if (k + 3 >= 128) {          // far beyond the tiles (the hub's entries were skipped): re-base
+                    T0 = base;
+                    k = 0;
+                    load_tiles();
+                } else if (k >= 64) {        // next tile
+                    T0 += 64;
+                    k -= 64;
+                    t_c = n_c; t_v = n_v; t_x = n_x;
+                    n_c = col[ent(T0 + 64 + lane)]; n_v = val[ent(T0 + 64 + lane)];
+                    if (XROW) n_x = xcol[ent(T0 + 64 + lane)];
+                }
+                const int cnt = min(4, e1 - base);
+                T v[4];
+                float w[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int ku = k + min(u, cnt - 1);   // a last group of 1-3 entries is padded with its last entry at weight 0
+                    int c, cx;
+                    float wv;
+                    if (ku < 64) {
+                        c = __builtin_amdgcn_readlane(t_c, ku);
+                        wv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t_v), ku));
+                        cx = XROW ? __builtin_amdgcn_readlane(t_x, ku) : c;
+                    } else {
+                        c = __builtin_amdgcn_readlane(n_c, ku - 64);
+                        wv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(n_v), ku - 64));
+                        cx = XROW ? __builtin_amdgcn_readlane(n_x, ku - 64) : c;
+                    }
+                    w[u] = u < cnt ? wv : 0.f;
+                    if (c == row) v[u] = x;                 // wave-uniform
+                    else if (c == hub) v[u] = xhub;
+                    else v[u] = *reinterpret_cast<const T *>(Xs + (int64_t)cx * ldx);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) P::fma(acc, w[u], v[u]);
+            }
+            if (live) finish_row<4, BWD, NOEPI>(acc, row, col0, H, Y, ldy, bv, rowepi, cs, o_prev);
+            // the hub's entry for this row, if it has one (its entries inside the segment are consumed in row order)
+            if (cur < h1) {
+                if (cur - HB >= 64) { HB = cur; hub_tile(); }
+                if (__builtin_amdgcn_readlane(h_c, cur - HB) == row) {
+                    P::fma(acc_h, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(h_v), cur - HB)), x);
+                    ++cur;
+                }
+            }
+        }
+    }
+    finish_hub();
     if (BWD && col_part && live) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) col_part[(int64_t)range * H + col0 + i] = cs[i];
@@ -1187,6 +1465,55 @@ int spmm_rows_impl(const int32_t *rowptr, const int32_t *xcol, const float *val,
     return (int)hipGetLastError();
 }
 }  // namespace
+
+namespace {
+int spmm_stream_impl(const int32_t *rowptr, const int32_t *col, const float *val, int64_t nnz, const float *X, int64_t ldx, float *Y,
+                     int64_t ldy, int32_t n_rows, int32_t H, const int32_t *seg_ptr, int32_t n_seg, const int32_t *range_seg, int32_t n_ranges,
+                     const int32_t *xrow, const int32_t *xcol, const float *bias, uint32_t epilogue, float p_drop, uint64_t seed,
+                     const uint8_t *mask, const float *prev, float *col_part, void *stream) {
+    if (n_rows < 0 || H < 0 || nnz < 0 || nnz > 0x7fffffffLL || n_seg < 0 || n_ranges < 0) return FITGNN_E_BADARG;
+    if ((xrow == nullptr) != (xcol == nullptr)) return FITGNN_E_BADARG;
+    if (n_rows == 0 || H == 0 || n_ranges == 0) return 0;
+    if (!rowptr || !col || !val || nnz == 0 || !X || !Y || !seg_ptr || !range_seg || n_seg == 0) return FITGNN_E_BADARG;
+    if ((epilogue & FITGNN_EPI_BIAS) && !bias) return FITGNN_E_BADARG;
+    if ((epilogue & FITGNN_EPI_DROPOUT) && !(p_drop >= 0.f && p_drop < 1.f)) return FITGNN_E_BADARG;
+    if ((H % 4) != 0 || (ldx % 4) != 0 || (ldy % 4) != 0 || ldx < H || ldy < H) return FITGNN_E_BADARG;
+    if ((((uintptr_t)X | (uintptr_t)Y) % 16) != 0) return FITGNN_E_ALIGN;
+    const bool bwd = (epilogue & FITGNN_EPI_BACKWARD) != 0;
+    if (bwd && (!prev || (epilogue & FITGNN_EPI_BIAS) || ((uintptr_t)prev % 16) != 0)) return FITGNN_E_BADARG;
+    const bool noepi = (epilogue & (FITGNN_EPI_BIAS | FITGNN_EPI_ELU | FITGNN_EPI_DROPOUT | FITGNN_EPI_BACKWARD)) == 0;
+    const int n_slabs = (H + 255) / 256;
+    const dim3 grid((unsigned)(((int64_t)n_ranges * n_slabs + kWaves - 1) / kWaves));
+#define FITGNN_LAUNCH_STREAM(XR, BW, NE)                                                                                                  \
+    hipLaunchKernelGGL((spmm_stream_kernel<XR, BW, NE>), grid, dim3(kThreads), 0, (hipStream_t)stream, rowptr, col, val, X, ldx, Y, ldy, H, \
+                       n_rows, (int32_t)nnz, seg_ptr, n_seg, range_seg, n_ranges, n_slabs, bias, epilogue, p_drop, seed, mask, xrow, xcol, prev,  \
+                       col_part)
+    if (xrow) { if (bwd) FITGNN_LAUNCH_STREAM(true, true, false); else if (noepi) FITGNN_LAUNCH_STREAM(true, false, true); else FITGNN_LAUNCH_STREAM(true, false, false); }
+    else if (bwd) FITGNN_LAUNCH_STREAM(false, true, false);
+    else if (noepi) FITGNN_LAUNCH_STREAM(false, false, true);
+    else FITGNN_LAUNCH_STREAM(false, false, false);
+#undef FITGNN_LAUNCH_STREAM
+    return (int)hipGetLastError();
+}
+}  // namespace
+
+extern "C" int fitgnn_spmm_csr_stream_f32(const int32_t *rowptr, const int32_t *col, const float *val, int64_t nnz, const float *X, int64_t ldx,
+                                          float *Y, int64_t ldy, int32_t n_rows, int32_t H, const int32_t *seg_ptr, int32_t n_seg,
+                                          const int32_t *range_seg, int32_t n_ranges, const int32_t *xrow, const int32_t *xcol,
+                                          const float *bias, uint32_t epilogue, float p_drop, uint64_t seed, const uint8_t *mask, void *stream) {
+    if (epilogue & FITGNN_EPI_BACKWARD) return FITGNN_E_BADARG;  // fitgnn_spmm_csr_stream_dz_f32
+    return spmm_stream_impl(rowptr, col, val, nnz, X, ldx, Y, ldy, n_rows, H, seg_ptr, n_seg, range_seg, n_ranges, xrow, xcol, bias,
+                            epilogue & ~FITGNN_SPMM_GATHER, p_drop, seed, mask, nullptr, nullptr, stream);
+}
+
+extern "C" int fitgnn_spmm_csr_stream_dz_f32(const int32_t *rowptr, const int32_t *col, const float *val, int64_t nnz, const float *X,
+                                             int64_t ldx, float *Y, int64_t ldy, int32_t n_rows, int32_t H, const int32_t *seg_ptr,
+                                             int32_t n_seg, const int32_t *range_seg, int32_t n_ranges, const int32_t *xrow,
+                                             const int32_t *xcol, const float *prev, uint32_t epilogue, float p_drop, uint64_t seed,
+                                             const uint8_t *mask, float *col_part, void *stream) {
+    return spmm_stream_impl(rowptr, col, val, nnz, X, ldx, Y, ldy, n_rows, H, seg_ptr, n_seg, range_seg, n_ranges, xrow, xcol, nullptr,
+                            (epilogue & ~FITGNN_SPMM_GATHER) | FITGNN_EPI_BACKWARD, p_drop, seed, mask, prev, col_part, stream);
+}
 
 extern "C" int32_t fitgnn_spmm_rows_compact_parts(int32_t n_rows) {
     if (n_rows <= 0) return 0;

@@ -120,6 +120,23 @@ BLOCK_INTS = 8     # sizeof(fitgnn_block_t) / 4
 LONG_ROW = 16      # rows with more non-zeros are a block's "long rows" (spmm.hip kLongRow)
 
 
+def stream_ranges(ptr, n_rows, device, want=8192, min_rows=64):
+    """(seg_ptr int32 [n_seg + 1], range_seg int32 [n_ranges + 1]) for fitgnn_spmm_csr_stream_f32: the segments `ptr` (row
+    boundaries, ptr[0] = 0, ptr[-1] = n_rows) and, for each of ~`want` waves per column slab, its run of WHOLE segments with about
+    the same number of rows (at least min_rows): a wave streams its rows in order, so equal rows = equal bytes."""
+    ptr = np.asarray(ptr, dtype=np.int64)
+    if len(ptr) < 2 or ptr[0] != 0 or ptr[-1] != n_rows:
+        raise ValueError("segment boundaries must run from 0 to n_rows")
+    ptr = np.unique(ptr)   # empty segments carry no rows
+    n_seg = len(ptr) - 1
+    n_ranges = int(max(1, min(want, n_rows // max(min_rows, 1), n_seg)))
+    targets = (np.arange(n_ranges + 1, dtype=np.int64) * n_rows) // n_ranges
+    rs = np.searchsorted(ptr, targets, side="left")
+    rs[0], rs[-1] = 0, n_seg
+    rs = np.maximum.accumulate(rs)
+    return (torch.from_numpy(ptr.astype(np.int32)).to(device), torch.from_numpy(rs.astype(np.int32)).to(device))
+
+
 def split_blocks(ptr, rowptr, cap, limit=None):
     """Diagonal blocks of cap < rows <= limit -> fitgnn_block_t records + their long rows (the whole-subgraph kernel: one
     workgroup per block and column slab walks it in cap-row pieces); everything else -> tiles (consecutive blocks packed,
@@ -256,6 +273,7 @@ class CSRGraph:
         rowptr_t, col_t, self._perm_t = _csr_from_coo(col.to(torch.int64), rows_f, self.n)
         self.f, self.t = _Side(rowptr, col), _Side(rowptr_t, col_t)
         self.dinv = None
+        self.seg = self.range_seg = None   # fitgnn_spmm_csr_stream_f32: segment starts, segments per wave (set with the blocks)
         self._ptr, self._lds_rows = ptr, lds_rows
         self.window_rows = 0
         if device.type == "cuda":
@@ -323,6 +341,8 @@ class CSRGraph:
                     side.small_tiles = tiles_to_device(small, side.rowptr) if len(small) else torch.zeros((0, TILE_INTS), dtype=torch.int32, device=dev)
                     side.blocks = torch.from_numpy(blocks).to(dev)
                     side.long_rows = torch.from_numpy(long_rows if len(long_rows) else np.zeros(1, dtype=np.int32)).to(dev)
+                    if self.seg is None:   # the segment-streaming kernel's view of the same runs (both sides share it)
+                        self.seg, self.range_seg = stream_ranges(ptr_np, self.n, dev)
         return self
 
 

@@ -46,6 +46,9 @@ class OpConfig:
     compact_rows_kernel  a backward SpMM whose operand is compact (compact_head_backward / last_layer_on_loss_rows) runs on the
                      row-streaming kernel (fitgnn_spmm_rows_compact[_dz]_f32: no LDS windows, every wave streams a range of rows)
                      instead of the tile / whole-subgraph kernels with a row indirection (A/B switch; dZ bit-identical).
+    stream_kernel    a batch whose runs go to the whole-subgraph kernel (split_large_blocks) runs on the segment-streaming kernel instead
+                     (fitgnn_spmm_csr_stream[_dz]_f32: the same algorithm with one wave per run of segments, no LDS; one launch covers
+                     every row; same bits).  A/B switch.
     pad_table_min_k  static feature tables at least this wide whose width is not a multiple of 32 run layer 0's
                      products on a copy zero-padded once (real feature widths: 100, 500, 1 433, 8 415).
     profile / profile_gemm / profile_fused   None, or a list that collects HIP-event pairs around the SpMM / hand-written
@@ -53,18 +56,18 @@ class OpConfig:
     seed_bank        None, or a SeedBank supplying device-resident dropout seeds (steps captured in a hipGraph)."""
     __slots__ = ("gemm_precision", "atb_kernel", "nt_kernel", "nt_presplit", "fuse_dx_epilogue", "fold_backward",
                  "dedup_gather", "pad_table_min_k", "split_large_blocks", "compact_head_backward", "last_layer_on_loss_rows",
-                 "compact_rows_kernel", "profile", "profile_gemm", "profile_fused", "seed_bank")
+                 "compact_rows_kernel", "stream_kernel", "profile", "profile_gemm", "profile_fused", "seed_bank")
 
     def __init__(self, gemm_precision="exact", atb_kernel=True, nt_kernel=True, nt_presplit=True, fuse_dx_epilogue=True,
                  fold_backward=False, dedup_gather=True, pad_table_min_k=0, split_large_blocks=True, compact_head_backward=True,
-                 last_layer_on_loss_rows=True, compact_rows_kernel=True, profile=None, profile_gemm=None, profile_fused=None, seed_bank=None):
+                 last_layer_on_loss_rows=True, compact_rows_kernel=True, stream_kernel=True, profile=None, profile_gemm=None, profile_fused=None, seed_bank=None):
         if gemm_precision not in ("exact", "high", "highest"):
             raise ValueError(f"gemm_precision {gemm_precision!r}: 'exact', 'high' or 'highest'")
         self.gemm_precision, self.atb_kernel, self.nt_kernel, self.nt_presplit = gemm_precision, atb_kernel, nt_kernel, nt_presplit
         self.fuse_dx_epilogue, self.fold_backward, self.dedup_gather = fuse_dx_epilogue, fold_backward, dedup_gather
         self.pad_table_min_k, self.split_large_blocks = pad_table_min_k, split_large_blocks
         self.compact_head_backward, self.last_layer_on_loss_rows = compact_head_backward, last_layer_on_loss_rows
-        self.compact_rows_kernel = compact_rows_kernel
+        self.compact_rows_kernel, self.stream_kernel = compact_rows_kernel, stream_kernel
         self.profile, self.profile_gemm, self.profile_fused, self.seed_bank = profile, profile_gemm, profile_fused, seed_bank
 
     def replace(self, **kw):
@@ -530,6 +533,11 @@ def spmm_graph(g, X, transposed=False, **kw):
             and (epi & ~_lib.SPMM_GATHER) == 0 and kw.get("bias") is None and kw.get("out") is None):
         return _spmm_rows_compact(g, side, Xc, kw["xrow"], kw["zero_from"], kw.get("cfg", DEFAULT), kw.get("profile_kind"))
     split = (side.blocks is not None and Xc.shape[1] % 4 == 0 and Xc.data_ptr() % 16 == 0 and kw.get("cfg", DEFAULT).split_large_blocks)
+    if (split and kw.get("cfg", DEFAULT).stream_kernel and g.seg is not None and kw.get("zero_from", -1) < 0 and kw.get("out") is None
+            and Xc.stride(0) % 4 == 0):
+        cfg = kw.get("cfg", DEFAULT)
+        return _spmm_stream(g, side, Xc, kw.get("xrow"), cfg, kw.get("profile_kind"), bias=kw.get("bias"), epilogue=epi & ~_lib.SPMM_GATHER,
+                            p=kw.get("p", 0.0), seed=kw.get("seed", 0), mask=kw.get("mask"))
     if split:
         epi &= ~_lib.SPMM_GATHER   # the whole-subgraph kernel reads every operand row once: it supersedes the direct-gather variant
     if not split:
@@ -558,6 +566,43 @@ def spmm_graph(g, X, transposed=False, **kw):
         ev[1].record()
         cfg.profile.append((ev[0], ev[1], kind or ("tile" if xrow is None else "table")))   # "table": layer 0 on the de-duplicated table
     return Y
+
+
+def _spmm_stream(g, side, Xc, xrow, cfg, kind, bias=None, epilogue=0, p=0.0, seed=0, mask=None, dz=None):
+    """epilogue(A @ X) over EVERY row of a segmented batch through the segment-streaming kernel.  dz = (prev, want_db): the
+    epilogue flags / p / seed / mask are the previous layer's forward ones and the store applies its derivative -> (dZ, db)."""
+    L = _lib.lib()
+    _lib.require_cuda(Xc, xrow, bias, mask)
+    H, dev = Xc.shape[1], Xc.device
+    xcol = _entry_rows(side, xrow) if xrow is not None else None
+    Y = torch.empty((g.n, H), dtype=torch.float32, device=dev)
+    st = _lib.stream_ptr(dev)
+    n_seg, n_ranges = int(g.seg.numel()) - 1, int(g.range_seg.numel()) - 1
+    seed_v, epi_v = _seed_arg(seed, epilogue)
+    ev = None
+    if cfg.profile is not None:
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
+    db = None
+    if dz is None:
+        _lib.check(L.fitgnn_spmm_csr_stream_f32(_lib.dptr(side.rowptr), _lib.dptr(side.col), _lib.dptr(side.val), int(side.col.numel()),
+                                                _lib.dptr(Xc), Xc.stride(0), _lib.dptr(Y), Y.stride(0), g.n, H, _lib.dptr(g.seg), n_seg,
+                                                _lib.dptr(g.range_seg), n_ranges, _lib.dptr(xrow), _lib.dptr(xcol), _lib.dptr(bias), epi_v,
+                                                float(p), seed_v, _lib.dptr(mask), st), "fitgnn_spmm_csr_stream_f32")
+    else:
+        prev, want_db = dz
+        part = torch.empty((n_ranges, H), dtype=torch.float32, device=dev) if want_db else None
+        _lib.check(L.fitgnn_spmm_csr_stream_dz_f32(_lib.dptr(side.rowptr), _lib.dptr(side.col), _lib.dptr(side.val), int(side.col.numel()),
+                                                   _lib.dptr(Xc), Xc.stride(0), _lib.dptr(Y), Y.stride(0), g.n, H, _lib.dptr(g.seg), n_seg,
+                                                   _lib.dptr(g.range_seg), n_ranges, _lib.dptr(xrow), _lib.dptr(xcol), _lib.dptr(prev), epi_v,
+                                                   float(p), seed_v, _lib.dptr(mask), _lib.dptr(part), st), "fitgnn_spmm_csr_stream_dz_f32")
+        if want_db:
+            db = torch.empty(H, dtype=torch.float32, device=dev)
+            _lib.check(L.fitgnn_colsum_partials_f32(_lib.dptr(part), n_ranges, H, _lib.dptr(db), st), "fitgnn_colsum_partials_f32")
+    if ev is not None:
+        ev[1].record()
+        cfg.profile.append((ev[0], ev[1], kind or ("dz" if dz is not None else ("tile" if xrow is None else "table"))))
+    return Y if dz is None else (Y, db)
 
 
 def _spmm_rows_compact(g, side, Xc, xrow, zero_from, cfg, kind, dz=None):
@@ -607,6 +652,10 @@ def spmm_graph_dz(g, X, prev, epilogue, p=0.0, seed=0, mask=None, want_db=True, 
     H = Xc.shape[1]
     if xrow is not None and zero_from >= 0 and cfg.compact_rows_kernel and H % 4 == 0:
         return _spmm_rows_compact(g, side, Xc, xrow, zero_from, cfg, profile_kind, dz=(prev, epilogue, p, seed, mask, want_db))
+    if (side.blocks is not None and cfg.split_large_blocks and cfg.stream_kernel and g.seg is not None and zero_from < 0 and H % 4 == 0
+            and Xc.stride(0) % 4 == 0):
+        return _spmm_stream(g, side, Xc, xrow, cfg, profile_kind, epilogue=epilogue & ~_lib.SPMM_GATHER, p=p, seed=seed, mask=mask,
+                            dz=(prev, want_db))
     dev = Xc.device
     seed_v, epi_v = _seed_arg(seed, epilogue & ~_lib.SPMM_GATHER)
     split = side.blocks is not None and cfg.split_large_blocks

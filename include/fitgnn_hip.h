@@ -113,6 +113,24 @@ int fitgnn_spmm_csr_blocks_dz_f32(const int32_t *rowptr, const int32_t *col, con
                                   const float *prev, uint32_t epilogue, float p_drop, uint64_t seed, const uint8_t *mask,
                                   float *col_part, void *stream);
 
+/* The same products by the segment-streaming kernel (csrc/spmm.hip: spmm_stream_kernel): the whole-subgraph kernel's algorithm
+ * with one WAVE per run of segments and no LDS.  seg_ptr [n_seg + 1] (ascending, seg_ptr[0] = 0, seg_ptr[n_seg] = n_rows) cuts the
+ * rows into segments whose FIRST row is the hub (star-by-star layout of an --extra_node union: an own node followed by the extra
+ * nodes it brought in, utils.py:235-239); range_seg [n_ranges + 1] (ascending segment indices, range_seg[0] = 0,
+ * range_seg[n_ranges] = n_seg) gives every wave its run of whole segments.  A row's operand row is read once, by the wave that
+ * streams it; the hub's accumulator is carried across its segment in CSR order (same bits as fitgnn_spmm_csr_f32).  xrow / xcol
+ * (both or neither): operand row of union row r is X[xrow[r]], of CSR entry e X[xcol[e]] (= xrow[col[e]]).  _dz_: the store
+ * applies the previous layer's ELU' / dropout' (as fitgnn_spmm_csr_dz_f32); col_part (may be NULL) receives one partial row of
+ * column sums of dZ per range, [n_ranges x H], every element written.  H, ldx, ldy multiples of 4; X, Y, prev 16-byte aligned. */
+int fitgnn_spmm_csr_stream_f32(const int32_t *rowptr, const int32_t *col, const float *val, int64_t nnz, const float *X, int64_t ldx,
+                               float *Y, int64_t ldy, int32_t n_rows, int32_t H, const int32_t *seg_ptr, int32_t n_seg,
+                               const int32_t *range_seg, int32_t n_ranges, const int32_t *xrow, const int32_t *xcol, const float *bias,
+                               uint32_t epilogue, float p_drop, uint64_t seed, const uint8_t *mask, void *stream);
+int fitgnn_spmm_csr_stream_dz_f32(const int32_t *rowptr, const int32_t *col, const float *val, int64_t nnz, const float *X, int64_t ldx,
+                                  float *Y, int64_t ldy, int32_t n_rows, int32_t H, const int32_t *seg_ptr, int32_t n_seg,
+                                  const int32_t *range_seg, int32_t n_ranges, const int32_t *xrow, const int32_t *xcol, const float *prev,
+                                  uint32_t epilogue, float p_drop, uint64_t seed, const uint8_t *mask, float *col_part, void *stream);
+
 /* The same two products for a COMPACT operand, by a row-streaming kernel (csrc/spmm.hip: spmm_rows_compact_kernel): X holds the
  * operand rows of a selection followed by rows of zeros (rows >= zero_from), and xcol[e] names the operand row of CSR entry e
  * (xcol[e] = xrow[col[e]] of the entry points above).  This is the last layer's backward SpMM of the train step, whose operand is

@@ -263,11 +263,16 @@ def test_whole_subgraph_kernel_gives_the_tile_kernel_bits(mods, H, sizes, centre
     X = torch.randn(n, H).cuda()
     b = torch.randn(H).cuda()
     off = ops.OpConfig(split_large_blocks=False)
+    # the two kernels that read every operand row once: the whole-subgraph kernel (one workgroup per run, LDS windows) and the
+    # segment-streaming kernel (one wave per run of segments, no LDS; the default)
+    blk, stream = ops.OpConfig(stream_kernel=False), ops.OpConfig(stream_kernel=True, profile=[])
     for transposed in (False, True):
         for kw in (dict(), dict(bias=b, epilogue=EPI_BIAS | EPI_ELU | EPI_DROPOUT, p=0.5, seed=123)):
             tiled = ops.spmm_graph(g, X, transposed=transposed, cfg=off, **kw)
             for gg in (g, g64):
-                assert torch.equal(ops.spmm_graph(gg, X, transposed=transposed, **kw), tiled)
+                for cfg in (blk, stream):
+                    assert torch.equal(ops.spmm_graph(gg, X, transposed=transposed, cfg=cfg, **kw), tiled)
+    assert g64.seg is not None and len(stream.profile) >= 4   # one event pair per streamed launch
     ref = torch.from_numpy(orc.spmm_csr_f32(g.rowptr.cpu().numpy(), g.col.cpu().numpy(), g.val.cpu().numpy(), X.cpu().numpy()))
     assert rel_err(ops.spmm_graph(g, X).cpu(), ref) < RTOL
     # row indirection into a de-duplicated operand table (layer 0): pattern row / column r reads Xt[xrow[r]]
@@ -276,8 +281,10 @@ def test_whole_subgraph_kernel_gives_the_tile_kernel_bits(mods, H, sizes, centre
     Xt = torch.randn(N0, H).cuda()
     want = ops.spmm_graph(g64, Xt[xrow.long()].contiguous(), cfg=off)
     for gg in (g, g64):
-        for cfg in (ops.DEFAULT, off):
+        for cfg in (ops.DEFAULT, blk, off):
             assert torch.equal(ops.spmm_graph(gg, Xt, xrow=xrow, cfg=cfg), want)
+            assert torch.equal(ops.spmm_graph(gg, Xt, xrow=xrow, cfg=cfg, bias=b, epilogue=EPI_BIAS | EPI_ELU | EPI_DROPOUT, p=0.5, seed=5),
+                               ops.spmm_graph(g64, Xt[xrow.long()].contiguous(), cfg=off, bias=b, epilogue=EPI_BIAS | EPI_ELU | EPI_DROPOUT, p=0.5, seed=5))
 
 
 @pytest.mark.parametrize("H", [512, 64])
