@@ -118,25 +118,6 @@ __device__ __forceinline__ void finish_row(typename Pack<VEC>::T acc, int row, i
     *reinterpret_cast<T *>(Y + (int64_t)row * ldy + col0) = out;
 }
 
-// Vector-memory accesses whose completion the kernel counts BY HAND (the row-streaming kernels below).  hipcc's waitcnt insertion
-// cannot count across their loops with conditional loads and falls back to s_waitcnt vmcnt(0) before every use -- which waits for
-// the prefetch issued one instruction earlier, i.e. turns a four-row prefetch ring into one memory round trip per row (measured:
-// 49 of 62 waits were vmcnt(0)).  As inline asm the accesses are invisible to that pass; the kernels place s_waitcnt vmcnt(N)
-// themselves (vmcnt retires in issue order, loads and stores together: "at most N outstanding" completes everything older than
-// the N youngest).  `sbase` must be wave-uniform (an SGPR pair), voff a byte offset per lane.
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void vm_load4(f32x4 &d, const float *sbase, uint32_t voff) {
-    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(d) : "v"(voff), "s"(sbase) : "memory");
-}
-__device__ __forceinline__ void vm_load1(int &d, const void *sbase, uint32_t voff) {
-    asm volatile("global_load_dword %0, %1, %2" : "=v"(d) : "v"(voff), "s"(sbase) : "memory");
-}
-__device__ __forceinline__ void vm_store4(float *sbase, uint32_t voff, f32x4 v) {
-    asm volatile("global_store_dwordx4 %0, %1, %2" : : "v"(voff), "v"(v), "s"(sbase) : "memory");
-}
-__device__ __forceinline__ float4 as_float4(f32x4 v) { return make_float4(v[0], v[1], v[2], v[3]); }
-__device__ __forceinline__ f32x4 as_f32x4(float4 v) { f32x4 r = {v.x, v.y, v.z, v.w}; return r; }
-
 template <int VEC, bool BWD_OK = true>
 __device__ __forceinline__ typename Pack<VEC>::T prev_row(const RowEpilogue &E, int row, int col0, int H, bool live) {
     using T = typename Pack<VEC>::T;
@@ -752,7 +733,8 @@ __global__ __launch_bounds__(kThreads, BWD ? 4 : XROW ? 6 : 7) void spmm_block_k
 //   * EVERY entry is multiplied and added, in CSR order (the order of the other kernels: same bits): an entry whose operand row is
 //     one of the zero rows adds w * 0 from registers, a non-zero operand row is fetched once and kept while consecutive rows
 //     reference it (the leaves of a star all reference their centre);
-//   * the `prev` slices of the next four rows are in flight while a row is processed (4 KB per wave, 32 waves per CU);
+//   * the `prev` slices of four rows at a time are requested together, ahead of their rows' arithmetic (4 KB per wave in flight,
+//     28 waves per CU);
 //   * column sums for the bias gradient stay in registers over the wave's whole range: one partial row per range, not per block.
 // <= 64 VGPR: 8 waves per SIMD.
 template <bool BWD>
@@ -773,103 +755,73 @@ __global__ __launch_bounds__(kThreads, BWD ? 7 : 8) void spmm_rows_compact_kerne
     const int col0 = slab * 256 + lane * 4;
     const bool live = col0 + 4 <= H;
     const int colc = live ? col0 : max(H - 4, 0);   // dead lanes read a valid column group (never stored)
-    const uint32_t cbytes = (uint32_t)colc * 4u;
+    const float *Xs = X + colc;
     const float keep_scale = (epi & FITGNN_EPI_DROPOUT) ? 1.0f / (1.0f - p_drop) : 1.0f;
     const RowEpilogue rowepi{BWD ? epi : 0u, keep_scale, (epi & FITGNN_EPI_DROPOUT) ? 1.0f - p_drop : 1.0f, fitgnn::dropout_threshold(p_drop),
                              seed, mask, BWD ? prev : nullptr};
     float cs[4] = {0.f, 0.f, 0.f, 0.f};
     const float bv[4] = {0.f, 0.f, 0.f, 0.f};
-    // Every vector-memory access of the row loop is issued through vm_load* / vm_store4 and waited for by count.  Per row, in this
-    // order: [wait] one `prev` load (BWD; row + 4), the occasional batch / tile / operand-row loads, one store.  So when row r starts,
-    // the 2 x 3 + 1 accesses of rows r-3 .. r-1 and the store of r-4 are younger than the load of prev[r] (issued as row r-4
-    // started): s_waitcnt vmcnt(7) completes it and everything older -- conditional loads in between only make the wait safer.
-    auto prev_issue = [&](f32x4 &d, int row) {   // rows past the range's end re-read its last row (one load per row, always)
-        vm_load4(d, prev + (uint64_t)min(row, r_end - 1) * (uint64_t)H, cbytes);
+    auto prev_at = [&](int row) -> T {   // rows past the range's end re-read its last row (the load stays unconditional)
+        if (!BWD) return P::zero();
+        return *reinterpret_cast<const T *>(prev + (uint64_t)min(row, r_end - 1) * (uint64_t)H + (uint64_t)colc);
     };
     // row pointers: lane i of rp holds rowptr[rb + i] of the current 64-row batch, rp_n the next batch's
     int rb = r_begin;
-    int rp, rp_n;
-    vm_load1(rp, rowptr, (uint32_t)min(rb + lane, n_rows) * 4u);
-    vm_load1(rp_n, rowptr, (uint32_t)min(rb + 64 + lane, n_rows) * 4u);
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(rp), "+v"(rp_n));
+    int rp = rowptr[min(rb + lane, n_rows)], rp_n = rowptr[min(rb + 64 + lane, n_rows)];
     // CSR entries: lane i of (t_x, t_v) holds entry T0 + i, (n_x, n_v) entry T0 + 64 + i
     int T0 = __builtin_amdgcn_readfirstlane(rp);
-    const int last_e = max(nnz - 1, 0);
-    int t_x, n_x, t_vi, n_vi;   // values as raw bits
-    auto tile_issue = [&](int &dx, int &dv, int e0) {
-        const uint32_t off = (uint32_t)min(e0 + lane, last_e) * 4u;
-        vm_load1(dx, xcol, off);
-        vm_load1(dv, val, off);
-    };
-    tile_issue(t_x, t_vi, T0);
-    tile_issue(n_x, n_vi, T0 + 64);
-    int tile_row = r_begin - 8;   // the row during which the `next` tile was last requested
-    f32x4 o[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-    if (BWD) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) prev_issue(o[j], r_begin + j);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(t_x), "+v"(t_vi), "+v"(n_x), "+v"(n_vi), "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3]));
+    auto ent = [&](int e) { return min(e, max(nnz - 1, 0)); };
+    int t_x = xcol[ent(T0 + lane)], n_x = xcol[ent(T0 + 64 + lane)];
+    float t_v = val[ent(T0 + lane)], n_v = val[ent(T0 + 64 + lane)];
     int cached = -1;          // operand row held in xc (wave-uniform)
-    f32x4 xc = {0.f, 0.f, 0.f, 0.f};
+    T xc = P::zero();
     for (int r = r_begin; r < r_end; r += 4) {
+        // The `prev` slices of the group's four rows are requested TOGETHER, ahead of the first row's arithmetic: hipcc waits with
+        // s_waitcnt vmcnt(0) before the first use of a loaded register whenever a loop lies between request and use (it cannot
+        // count across the entry loop), so a request made one row ahead is waited for at once -- one memory round trip per row.
+        // Requested as a group the four loads share one round trip (4 KB per wave in flight, 28 waves per CU).
+        T o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = prev_at(r + j);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int row = r + j;
             if (row >= r_end) break;   // wave-uniform
-            T o_prev = P::zero();
-            if (BWD) {
-                asm volatile("s_waitcnt vmcnt(7)" : "+v"(o[j]), "+v"(rp_n), "+v"(n_x), "+v"(n_vi));
-                o_prev = as_float4(o[j]);
-                prev_issue(o[j], row + 4);   // in flight while the next four rows are processed
-            } else {
-                asm volatile("s_waitcnt vmcnt(3)" : "+v"(rp_n), "+v"(n_x), "+v"(n_vi));   // no ring: one store per row
-            }
             int i = row - rb;
-            if (i >= 64) {   // next batch of row pointers (requested 64 rows ago)
+            if (i >= 64) {   // next batch of row pointers
                 rb += 64;
                 i -= 64;
                 rp = rp_n;
-                vm_load1(rp_n, rowptr, (uint32_t)min(rb + 64 + lane, n_rows) * 4u);
+                rp_n = rowptr[min(rb + 64 + lane, n_rows)];
             }
             const int e0 = __builtin_amdgcn_readlane(rp, i);
-            int e1;
-            if (i < 63) e1 = __builtin_amdgcn_readlane(rp, i + 1);
-            else {   // the first pointer of the next batch: requested at least a row ago, but possibly younger than this row's wait
-                if (row - rb < 5 + 63) asm volatile("s_waitcnt vmcnt(0)" : "+v"(rp_n));
-                e1 = __builtin_amdgcn_readfirstlane(rp_n);
-            }
+            const int e1 = i < 63 ? __builtin_amdgcn_readlane(rp, i + 1) : __builtin_amdgcn_readfirstlane(rp_n);
             T acc = P::zero();
             for (int e = e0; e < e1; ++e) {
                 int k = e - T0;
                 if (k >= 64) {   // next tile of entries
-                    // requested during row tile_row: complete by this row's wait only if that lies five rows back
-                    if (row - tile_row < 5) asm volatile("s_waitcnt vmcnt(0)" : "+v"(n_x), "+v"(n_vi));
                     T0 += 64;
                     k -= 64;
                     t_x = n_x;
-                    t_vi = n_vi;
-                    tile_issue(n_x, n_vi, T0 + 64);
-                    tile_row = row;
+                    t_v = n_v;
+                    n_x = xcol[ent(T0 + 64 + lane)];
+                    n_v = val[ent(T0 + 64 + lane)];
                 }
                 const int c = __builtin_amdgcn_readlane(t_x, k);
-                const float w = __int_as_float(__builtin_amdgcn_readlane(t_vi, k));
+                const float w = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t_v), k));
                 if (c < zero_from) {   // a row of the selection (wave-uniform)
                     if (c != cached) {
-                        vm_load4(xc, X + (int64_t)c * ldx, cbytes);
-                        asm volatile("s_waitcnt vmcnt(0)" : "+v"(xc));
+                        xc = *reinterpret_cast<const T *>(Xs + (int64_t)c * ldx);
                         cached = c;
                     }
-                    P::fma(acc, w, as_float4(xc));
+                    P::fma(acc, w, xc);
                 } else {
                     P::fma(acc, w, P::zero());   // a zero row: multiplied and added like every other entry, from registers
                 }
             }
-            const T out = epilogue_value<4, BWD, !BWD>(acc, row, col0, H, bv, rowepi, cs, o_prev);
-            if (live) vm_store4(Y + (int64_t)row * ldy, (uint32_t)col0 * 4u, as_f32x4(out));
+            if (live) finish_row<4, BWD, !BWD>(acc, row, col0, H, Y, ldy, bv, rowepi, cs, o[j]);
         }
     }
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3]), "+v"(rp_n), "+v"(n_x), "+v"(n_vi) : : "memory");
     if (BWD && col_part && live) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) col_part[(int64_t)range * H + col0 + i] = cs[i];
@@ -890,8 +842,8 @@ __global__ __launch_bounds__(kThreads, BWD ? 7 : 8) void spmm_rows_compact_kerne
 // a row's entry for its hub reads the hub's operand row kept in registers; everything else (edges between extra nodes, the other
 // own nodes of the cluster) is gathered from L2 / HBM, four of a row's entries in flight.  So every operand row is read from HBM
 // once by the wave that owns it and every output row is written once, as in the whole-subgraph kernel -- without its LDS windows,
-// two barriers per 16-row piece and 79-120 registers: the waves are independent, 5-6 per SIMD, each with the operand rows (and, in
-// the backward form, the `prev` slices) of the next four rows in flight.  Row pointers, segment starts, the row indirection and
+// two barriers per 16-row piece and 79-120 registers: the waves are independent, 4-6 per SIMD, each requesting the operand rows (and,
+// in the backward form, the `prev` slices) of four rows at a time.  Row pointers, segment starts, the row indirection and
 // the CSR entries pass through register batches / tiles broadcast by v_readlane: no dependent memory access per row.
 // XROW: operand row r lives at X[xrow[r]] (layer 0 on the de-duplicated table), xcol[e] = xrow[col[e]] per entry.
 template <bool XROW, bool BWD, bool NOEPI>
@@ -928,7 +880,7 @@ __global__ __launch_bounds__(kThreads, BWD ? 4 : (NOEPI && !XROW) ? 6 : 5) void 
         }
         return;
     }
-    auto ent = [&](int e) { return min(e, nnz - 1); };   // nnz >= n_rows >= 1 here (every row has its self loop or is empty: clamp anyway)
+    auto ent = [&](int e) { return min(e, nnz - 1); };   // nnz >= 1 (checked by the launcher)
     // ---- register batches: row pointers (and the row indirection) of 64 rows, the starts of 64 segments ----
     int rb = r_begin;
     int rp = rowptr[min(rb + lane, n_rows)], rp_n = rowptr[min(rb + 64 + lane, n_rows)];
@@ -994,32 +946,43 @@ __global__ __launch_bounds__(kThreads, BWD ? 4 : (NOEPI && !XROW) ? 6 : 5) void 
             if (k0 + n_in < 64) break;   // the rest of the tile is >= bound
         }
     };
+    auto hub_take = [&](int row, const T &x) {   // the hub's entry for `row`, if it is the next one
+        if (cur < h1) {
+            if (cur - HB >= 64) { HB = cur; hub_tile(); }
+            if (__builtin_amdgcn_readlane(h_c, cur - HB) == row) {
+                P::fma(acc_h, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(h_v), cur - HB)), x);
+                ++cur;
+            }
+        }
+    };
     auto finish_hub = [&]() {
         if (hub < 0) return;
         hub_gather(0x7fffffff);
         if (live) finish_row<4, BWD, NOEPI>(acc_h, hub, col0, H, Y, ldy, bv, rowepi, cs, o_hub);
     };
-    T xq[4], oq[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { xq[j] = row_at(r_begin + j); oq[j] = prev_at(r_begin + j); }
     for (int r = r_begin; r < r_end; r += 4) {
+        if (r - rb >= 64) {          // next batch of row pointers / row indirection; a group may reach three rows into the batch after
+            rb += 64;
+            rp = rp_n;
+            rp_n = rowptr[min(rb + 64 + lane, n_rows)];
+            if (XROW) { xr = xr_n; xr_n = xrow[min(rb + 64 + lane, n_rows - 1)]; }
+        }
+        // The operand rows (and `prev` slices) of the group's four rows are requested TOGETHER, ahead of the first row's arithmetic:
+        // hipcc waits with s_waitcnt vmcnt(0) before the first use of a loaded register whenever a loop lies between request and
+        // use, so a request made one row ahead would be waited for at once (one memory round trip per row); as a group the loads
+        // share one round trip -- 4 KB (8 KB with `prev`) per wave in flight, 16-24 waves per CU.
+        T xq[4], oq[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { xq[j] = row_at(r + j); oq[j] = prev_at(r + j); }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int row = r + j;
             if (row >= r_end) break;   // wave-uniform
-            if (row - rb >= 64) {      // next batch of row pointers / row indirection
-                rb += 64;
-                rp = rp_n;
-                rp_n = rowptr[min(rb + 64 + lane, n_rows)];
-                if (XROW) { xr = xr_n; xr_n = xrow[min(rb + 64 + lane, n_rows - 1)]; }
-            }
             const T x = xq[j];
             const T o_prev = oq[j];
-            xq[j] = row_at(row + 4);   // in flight while the next four rows are processed
-            oq[j] = prev_at(row + 4);
-            const int i = row - rb;
-            const int e0 = __builtin_amdgcn_readlane(rp, i);
-            const int e1 = i < 63 ? __builtin_amdgcn_readlane(rp, i + 1) : __builtin_amdgcn_readfirstlane(rp_n);
+            const int i = row - rb;   // 0 .. 66
+            const int e0 = i < 64 ? __builtin_amdgcn_readlane(rp, i) : __builtin_amdgcn_readlane(rp_n, i - 64);
+            const int e1 = i < 63 ? __builtin_amdgcn_readlane(rp, i + 1) : __builtin_amdgcn_readlane(rp_n, i - 63);
             if (row == r_begin || row == next_seg) {   // ---- a segment starts: this row is its hub ----
                 finish_hub();
                 if (row != r_begin) {
@@ -1035,13 +998,7 @@ __global__ __launch_bounds__(kThreads, BWD ? 4 : (NOEPI && !XROW) ? 6 : 5) void 
                 HB = e0;
                 hub_tile();
                 hub_gather(row);   // entries left of the hub (other segments), then its own entry
-                if (cur < h1) {
-                    if (cur - HB >= 64) { HB = cur; hub_tile(); }
-                    if (__builtin_amdgcn_readlane(h_c, cur - HB) == row) {
-                        P::fma(acc_h, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(h_v), cur - HB)), x);
-                        ++cur;
-                    }
-                }
+                hub_take(row, x);
                 continue;
             }
             // ---- a row of the hub's segment ----
@@ -1085,14 +1042,7 @@ __global__ __launch_bounds__(kThreads, BWD ? 4 : (NOEPI && !XROW) ? 6 : 5) void 
                 for (int u = 0; u < 4; ++u) P::fma(acc, w[u], v[u]);
             }
             if (live) finish_row<4, BWD, NOEPI>(acc, row, col0, H, Y, ldy, bv, rowepi, cs, o_prev);
-            // the hub's entry for this row, if it has one (its entries inside the segment are consumed in row order)
-            if (cur < h1) {
-                if (cur - HB >= 64) { HB = cur; hub_tile(); }
-                if (__builtin_amdgcn_readlane(h_c, cur - HB) == row) {
-                    P::fma(acc_h, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(h_v), cur - HB)), x);
-                    ++cur;
-                }
-            }
+            hub_take(row, x);   // the hub's entry for this row (its entries inside the segment are consumed in row order)
         }
     }
     finish_hub();
