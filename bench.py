@@ -60,7 +60,7 @@ def parse_args():
     ap.add_argument("--no-dedup-gather", action="store_true",
                     help="A/B: layer 0 on the de-duplicated table through the LDS-window SpMM (row indirection) instead of the "
                          "direct-gather variant")
-    ap.add_argument("--no-stream-kernel", action="store_true", help="A/B: the whole-subgraph kernel (LDS windows) instead of the segment-streaming one")
+    ap.add_argument("--stream-kernel", action="store_true", help="A/B: the segment-streaming kernel (one wave per run of segments, no LDS) instead of the whole-subgraph kernel")
     ap.add_argument("--no-compact-rows", action="store_true", help="A/B: the compact backward operand through the tile / whole-subgraph kernels")
     ap.add_argument("--gemm-precision", default="exact", choices=["exact", "high", "highest"],
                     help="dense GEMM policy of the timed region (ops.OpConfig.gemm_precision): exact = the reference's arithmetic, "
@@ -232,7 +232,7 @@ def main():
         # reference's step); True (default): aggregate-first, the dense part on the rows that reach the loss -- see DESIGN §0
         cfg = ops.OpConfig(gemm_precision=precision, fold_backward=args.fold, dedup_gather=not args.no_dedup_gather,
                            last_layer_on_loss_rows=loss_rows_only, compact_head_backward=loss_rows_only,
-                           stream_kernel=not args.no_stream_kernel, compact_rows_kernel=not args.no_compact_rows)
+                           stream_kernel=args.stream_kernel, compact_rows_kernel=not args.no_compact_rows)
         tr = train.GDTrainer(model, batch, lr=0.01, weight_decay=5e-4, dedup=not args.no_dedup,
                              prune_unused_rows=args.prune_unused_rows, op_config=cfg)
         return tr, sd

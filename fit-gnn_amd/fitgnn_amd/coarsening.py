@@ -109,34 +109,47 @@ def lanczos_smallest(L, K, device="cuda", tol=1e-5, m=None, max_restarts=300, se
     """The K smallest eigenpairs of the graph Laplacian L on the device: thick-restart Lanczos with full (two-pass)
     reorthogonalisation in float64 on T = 2 max(diag L) I - L, the shifted operator the reference hands to ARPACK
     (coarsening_utils.py:83-90), same relative tolerance.  SURVEY §8 f4: 42 % of the reference's coarsening time is this
-    solve.  Returns (lk ascending, Uk) as NumPy arrays, the (lk, Uk) coarsen() accepts."""
+    solve.  One Lanczos step = five launches of csrc/lanczos.hip over a column-major basis (the CSR product, three projection
+    passes, the normalisation; fixed-order sums: reproducible); the projected m x m eigenproblem and the basis rotation of a
+    restart are small dense library calls.  Returns (lk ascending, Uk) as NumPy arrays, the (lk, Uk) coarsen() accepts."""
+    Lh = _lib.lib()
     dev = torch.device(device)
+    if dev.type != "cuda":
+        raise _lib.FitgnnError("lanczos_smallest runs on the MI355X (spectral='host' is the reference's ARPACK call)")
     Lc = sp.csr_matrix(L).astype(np.float64)
     N = Lc.shape[0]
     offset = 2.0 * float(Lc.diagonal().max())
     T = (offset * sp.eye(N, format="csr") - Lc).tocsr()
-    Td = torch.sparse_csr_tensor(torch.from_numpy(T.indptr.astype(np.int64)).to(dev), torch.from_numpy(T.indices.astype(np.int64)).to(dev),
-                                 torch.from_numpy(T.data).to(dev), size=(N, N))
+    T.sort_indices()
+    rowptr = torch.from_numpy(T.indptr.astype(np.int32)).to(dev)
+    col = torch.from_numpy(T.indices.astype(np.int32)).to(dev)
+    val = torch.from_numpy(T.data.astype(np.float64)).to(dev)
     m = int(m or min(N - 1, max(4 * K + 20, 60)))
+    if m + 1 > 128:
+        raise ValueError("lanczos_smallest: at most 127 basis vectors (fitgnn_lanczos_project_f64)")
     K = min(K, m - 1)
+    st = _lib.stream_ptr(dev)
     gen = torch.Generator(device="cpu").manual_seed(seed)
-    V = torch.zeros(N, m + 1, dtype=torch.float64, device=dev)
+    V = torch.zeros(m + 1, N, dtype=torch.float64, device=dev)        # basis vector c = V[c] (contiguous)
     v = torch.randn(N, generator=gen, dtype=torch.float64).to(dev)
-    V[:, 0] = v / v.norm()
+    V[0] = v / v.norm()
     H = torch.zeros(m + 1, m, dtype=torch.float64, device=dev)
+    w = torch.empty(N, dtype=torch.float64, device=dev)
+    parts = int(Lh.fitgnn_lanczos_parts(N))
+    pa, pb, pc = (torch.empty(parts * (m + 1), dtype=torch.float64, device=dev) for _ in range(3))
+    nrm = torch.empty(parts, dtype=torch.float64, device=dev)
     j0 = 0
     for _ in range(max_restarts):
         for j in range(j0, m):
-            w = (Td @ V[:, j:j + 1]).squeeze(1)
-            Vj = V[:, :j + 1]
-            h = Vj.T @ w
-            w = w - Vj @ h
-            h2 = Vj.T @ w
-            w = w - Vj @ h2
-            H[:j + 1, j] = h + h2
-            beta = w.norm()
-            H[j + 1, j] = beta
-            V[:, j + 1] = w / beta.clamp(min=1e-300)
+            _lib.check(Lh.fitgnn_lanczos_spmv_f64(_lib.dptr(rowptr), _lib.dptr(col), _lib.dptr(val), _lib.dptr(V[j]), _lib.dptr(w), N, st),
+                       "fitgnn_lanczos_spmv_f64")
+            # h = V^T w;  w -= V h, h2 = V^T w;  w -= V h2, |w|^2;  v_{j+1} = w / |w|, H[:, j] = h + h2
+            _lib.check(Lh.fitgnn_lanczos_project_f64(_lib.dptr(V), N, j + 1, _lib.dptr(w), N, None, _lib.dptr(pa), None, st), "lanczos_project")
+            _lib.check(Lh.fitgnn_lanczos_project_f64(_lib.dptr(V), N, j + 1, _lib.dptr(w), N, _lib.dptr(pa), _lib.dptr(pb), None, st), "lanczos_project")
+            _lib.check(Lh.fitgnn_lanczos_project_f64(_lib.dptr(V), N, j + 1, _lib.dptr(w), N, _lib.dptr(pb), _lib.dptr(pc), _lib.dptr(nrm), st),
+                       "lanczos_project")
+            _lib.check(Lh.fitgnn_lanczos_finish_f64(_lib.dptr(V), N, j, _lib.dptr(w), N, _lib.dptr(nrm), _lib.dptr(pa), _lib.dptr(pb), _lib.dptr(H), m,
+                                                    st), "fitgnn_lanczos_finish_f64")
         Hm = (H[:m, :m] + H[:m, :m].T) / 2
         theta, S = torch.linalg.eigh(Hm)
         order = torch.argsort(theta, descending=True)
@@ -147,14 +160,14 @@ def lanczos_smallest(L, K, device="cuda", tol=1e-5, m=None, max_restarts=300, se
         keep = order[:min(K + 5, m - 2)]
         nk = int(keep.numel())
         Vn = torch.zeros_like(V)
-        Vn[:, :nk] = V[:, :m] @ S[:, keep]
-        Vn[:, nk] = V[:, m]
+        Vn[:nk] = S[:, keep].T.contiguous() @ V[:m]
+        Vn[nk] = V[m]
         Hn = torch.zeros_like(H)
         Hn[:nk, :nk] = torch.diag(theta[keep])
         Hn[nk, :nk] = H[m, m - 1] * S[m - 1, keep]
         V, H, j0 = Vn, Hn, nk
     lk = (offset - theta[idx]).cpu().numpy()
-    Uk = (V[:, :m] @ S[:, idx]).cpu().numpy()
+    Uk = (S[:, idx].T.contiguous() @ V[:m]).T.contiguous().cpu().numpy()
     o = np.argsort(lk)
     return lk[o], np.ascontiguousarray(Uk[:, o])
 

@@ -48,7 +48,9 @@ class OpConfig:
                      instead of the tile / whole-subgraph kernels with a row indirection (A/B switch; dZ bit-identical).
     stream_kernel    a batch whose runs go to the whole-subgraph kernel (split_large_blocks) runs on the segment-streaming kernel instead
                      (fitgnn_spmm_csr_stream[_dz]_f32: the same algorithm with one wave per run of segments, no LDS; one launch covers
-                     every row; same bits).  A/B switch.
+                     every row; same bits).  Off: measured slower than the whole-subgraph kernel on S-products (7.6-7.9 vs 6.3-6.7 ms
+                     per plain launch): hipcc's s_waitcnt vmcnt(0) in front of every first use keeps a wave to one memory
+                     round trip per group of rows.
     pad_table_min_k  static feature tables at least this wide whose width is not a multiple of 32 run layer 0's
                      products on a copy zero-padded once (real feature widths: 100, 500, 1 433, 8 415).
     profile / profile_gemm / profile_fused   None, or a list that collects HIP-event pairs around the SpMM / hand-written
@@ -60,7 +62,7 @@ class OpConfig:
 
     def __init__(self, gemm_precision="exact", atb_kernel=True, nt_kernel=True, nt_presplit=True, fuse_dx_epilogue=True,
                  fold_backward=False, dedup_gather=True, pad_table_min_k=0, split_large_blocks=True, compact_head_backward=True,
-                 last_layer_on_loss_rows=True, compact_rows_kernel=True, stream_kernel=True, profile=None, profile_gemm=None, profile_fused=None, seed_bank=None):
+                 last_layer_on_loss_rows=True, compact_rows_kernel=True, stream_kernel=False, profile=None, profile_gemm=None, profile_fused=None, seed_bank=None):
         if gemm_precision not in ("exact", "high", "highest"):
             raise ValueError(f"gemm_precision {gemm_precision!r}: 'exact', 'high' or 'highest'")
         self.gemm_precision, self.atb_kernel, self.nt_kernel, self.nt_presplit = gemm_precision, atb_kernel, nt_kernel, nt_presplit

@@ -281,7 +281,7 @@ def test_whole_subgraph_kernel_gives_the_tile_kernel_bits(mods, H, sizes, centre
     Xt = torch.randn(N0, H).cuda()
     want = ops.spmm_graph(g64, Xt[xrow.long()].contiguous(), cfg=off)
     for gg in (g, g64):
-        for cfg in (ops.DEFAULT, blk, off):
+        for cfg in (ops.DEFAULT, blk, stream, off):
             assert torch.equal(ops.spmm_graph(gg, Xt, xrow=xrow, cfg=cfg), want)
             assert torch.equal(ops.spmm_graph(gg, Xt, xrow=xrow, cfg=cfg, bias=b, epilogue=EPI_BIAS | EPI_ELU | EPI_DROPOUT, p=0.5, seed=5),
                                ops.spmm_graph(g64, Xt[xrow.long()].contiguous(), cfg=off, bias=b, epilogue=EPI_BIAS | EPI_ELU | EPI_DROPOUT, p=0.5, seed=5))
@@ -307,9 +307,10 @@ def test_backward_spmm_with_the_previous_layers_epilogue_in_its_store(mods, H, u
         X = torch.randn(n, H).cuda()
         plain = ops.spmm_graph(g, X, transposed=True)
         want, want_db = ops.epilogue_bwd_raw(plain, prev, flags, p=p, seed=seed, mask=mask, want_db=True)
-        got, got_db = ops.spmm_graph_dz(g, X, prev, flags, p=p, seed=seed, mask=mask, want_db=True)
-        assert torch.equal(got, want)
-        assert rel_err(got_db.cpu(), want_db.cpu()) < 1e-5
+        for cfg in (ops.DEFAULT, ops.OpConfig(stream_kernel=True)):   # whole-subgraph kernel / segment-streaming kernel (where the graph is split)
+            got, got_db = ops.spmm_graph_dz(g, X, prev, flags, p=p, seed=seed, mask=mask, want_db=True, cfg=cfg)
+            assert torch.equal(got, want)
+            assert rel_err(got_db.cpu(), want_db.cpu()) < 1e-5
         # compact operand: a third of the rows carry values, the others read a zero row
         rows = torch.randperm(n).cuda()[: n // 3].sort().values
         Xc = torch.cat([torch.randn(rows.numel(), H).cuda(), torch.zeros(ops.ZERO_ROWS, H).cuda()])

@@ -469,3 +469,25 @@ def test_star_layout_is_a_row_permutation_of_the_sorted_layout():
     # a shard keeps the star marks of its rows
     sh = select_clusters(b, np.arange(0, n, 3))
     assert int(sh["seg_start"].sum()) == int(sh["core"].sum())
+
+
+def test_stream_ranges_cover_whole_segments():
+    """csr.stream_ranges: the segment-streaming SpMM kernel's work list -- every range is a run of WHOLE segments, the ranges
+    partition the segments in order, carry about equal row counts, and empty segments vanish."""
+    from fitgnn_amd.csr import stream_ranges
+
+    rng = np.random.default_rng(5)
+    sizes = np.concatenate([rng.integers(1, 120, size=5000), [0, 0, 900, 1, 0]])
+    ptr = np.concatenate([[0], np.cumsum(sizes)])
+    n = int(ptr[-1])
+    seg, rs = (t.numpy() for t in stream_ranges(ptr, n, "cpu", want=64, min_rows=64))
+    assert seg[0] == 0 and seg[-1] == n and np.all(np.diff(seg) > 0)
+    assert set(seg.tolist()) == set(ptr.tolist())
+    assert rs[0] == 0 and rs[-1] == len(seg) - 1 and np.all(np.diff(rs) >= 0) and len(rs) == 65
+    rows = np.diff(seg[rs])
+    assert rows.sum() == n and rows.max() <= n / 64 + 900
+    # fewer rows than ranges asked for: one range per 64 rows at most, never more ranges than segments
+    seg, rs = stream_ranges(np.array([0, 3, 10]), 10, "cpu")
+    assert rs.tolist() == [0, 2]
+    with pytest.raises(ValueError):
+        stream_ranges(np.array([0, 3]), 10, "cpu")
