@@ -179,6 +179,9 @@ def main():
         info.update(wl["timings"])
         ei_d, assign_d = torch.from_numpy(wl["ei"]).to(device), torch.from_numpy(wl["assign"]).to(device)
         head = torch.tensor([wl["ei"].shape[1], wl["n_clusters"]], dtype=torch.int64, device=device)
+        # a fingerprint of the partition (the spectral prelude and the contraction are deterministic: every run of this workload
+        # must print the same one)
+        info["partition_fingerprint"] = int((wl["assign"].astype(np.int64) * (np.arange(N, dtype=np.int64) % 65521 + 1)).sum() % (2 ** 61 - 1))
         del wl
     else:
         head = torch.zeros(2, dtype=torch.int64, device=device)

@@ -211,6 +211,7 @@ def test_bench_two_ranks_report_the_single_rank_loss(tmp_path):
         lines[n] = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
     one, two = lines[1], lines[2]
     assert two["n_gpus"] == 2 and two["config"]["parallelism"] == "dp2"
+    assert one["config"]["partition_fingerprint"] == two["config"]["partition_fingerprint"], "the two runs coarsened to different partitions"
     assert abs(two["loss"] - one["loss"]) <= 1e-5 * abs(one["loss"]), (one["loss"], two["loss"])
     shards = two["config"]["shard_nnz_prime"]
     assert len(shards) == 2 and sum(shards) == one["config"]["nnz_prime"] == two["config"]["nnz_prime"]
