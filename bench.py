@@ -272,6 +272,11 @@ def main():
         trainer.comm_events = []
     dt, loss = timed(trainer, args.steps, args.warmup, step_events)
     loss_final = float(loss)
+    if world > 1:   # every rank's share of the last timed step's loss (they add up to `loss`)
+        share = trainer.local_loss.detach().to(torch.float64).view(1)
+        shares = [torch.zeros(1, dtype=torch.float64) for _ in range(world)] if backend == "gloo" else [torch.zeros_like(share) for _ in range(world)]
+        torch.distributed.all_gather(shares, share.cpu() if backend == "gloo" else share)
+        info["loss_shares"] = [float(t) for t in shares]
     comm_ms = None
     if world > 1 and trainer.comm_events:
         torch.cuda.synchronize()

@@ -19,7 +19,6 @@
 #include <stdint.h>
 
 #include <algorithm>
-#include <cstdlib>
 
 #include "common.h"
 #include "fitgnn_hip.h"
@@ -386,8 +385,8 @@ constexpr int kBlkMeta = 128;  // CSR entries of a piece staged in LDS (threads 
 
 // XROW: operand row r of the pattern lives at X[xrow[r]] (a de-duplicated operand table, as in the tile kernel): the window
 // rows' table indices are fetched one piece ahead of the rows themselves, so the prefetch never waits on an index.
-template <bool XROW, bool BWD, bool NOEPI = false, int WGS = 0>
-__global__ __launch_bounds__(kThreads, WGS ? WGS : BWD ? 4 : XROW ? 6 : 7) void spmm_block_kernel(
+template <bool XROW, bool BWD, bool NOEPI = false>
+__global__ __launch_bounds__(kThreads, BWD ? 4 : XROW ? 6 : 7) void spmm_block_kernel(
     const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col, const float *__restrict__ val,
     const float *__restrict__ X, int64_t ldx, float *__restrict__ Y, int64_t ldy, int32_t H,
     const fitgnn_block_t *__restrict__ blocks, int32_t n_blocks, const int32_t *__restrict__ long_rows, int32_t n_slabs,
@@ -1331,12 +1330,7 @@ int spmm_blocks_impl(const int32_t *rowptr, const int32_t *col, const float *val
                        blocks, n_blocks, long_rows, n_slabs, bias, epilogue, p_drop, seed, mask, xrow, xcol, prev, col_part, zero_from)
     const bool bwd = (epilogue & FITGNN_EPI_BACKWARD) != 0;
     const bool noepi = (epilogue & (FITGNN_EPI_BIAS | FITGNN_EPI_ELU | FITGNN_EPI_DROPOUT | FITGNN_EPI_BACKWARD)) == 0;
-    // FITGNN_BLK_OCC7 (experiment): the forward instantiation on an operand table at 72 registers (7 workgroups per CU, 11 spilled)
-    static const bool occ7 = getenv("FITGNN_BLK_OCC7") != nullptr;
-    if (xrow && !bwd && occ7)
-        hipLaunchKernelGGL((spmm_block_kernel<true, false, false, 7>), grid, dim3(kThreads), 0, (hipStream_t)stream, rowptr, col, val, X, ldx, Y, ldy, H,
-                           blocks, n_blocks, long_rows, n_slabs, bias, epilogue, p_drop, seed, mask, xrow, xcol, prev, col_part, zero_from);
-    else if (xrow) { if (bwd) FITGNN_LAUNCH_BLK(true, true); else FITGNN_LAUNCH_BLK(true, false); }
+    if (xrow) { if (bwd) FITGNN_LAUNCH_BLK(true, true); else FITGNN_LAUNCH_BLK(true, false); }
     else if (bwd) FITGNN_LAUNCH_BLK(false, true);
     else if (noepi) hipLaunchKernelGGL((spmm_block_kernel<false, false, true>), grid, dim3(kThreads), 0, (hipStream_t)stream, rowptr, col, val, X, ldx, Y,
                                        ldy, H, blocks, n_blocks, long_rows, n_slabs, bias, epilogue, p_drop, seed, mask, xrow, xcol, prev, col_part,

@@ -197,6 +197,7 @@ class GDTrainer:
     def _backward_and_step(self, loss):
         """loss = this rank's share (its sum-loss x 1 / global count): backward, gradient all-reduce with the loss riding in
         the buffer's tail slot, replicated Adam.  Returns the GLOBAL loss (the sum of the ranks' shares)."""
+        self.local_loss = loss.detach()   # this rank's share of the step's loss (the whole loss without data parallelism)
         if self.dist:
             self.flat.tail[:1].copy_(loss.detach().view(1))   # before backward: the late bucket leaves from a backward hook
         loss.backward()
