@@ -163,7 +163,11 @@ def main():
     info = dict(nodes=N, undirected_edges=E, features=F, classes=C)
 
     def bcast(t):
-        """Broadcast a device tensor from rank 0 (through the host under gloo)."""
+        """Broadcast a device tensor from rank 0 (through the host under gloo).  The buffer is made contiguous first: the collective
+        ships memory, not indices, and the receiving ranks' buffers are row-major (synthetic_graph's edge array is a column-indexed
+        NumPy view whose strides torch keeps: shipped as it lay, rank 1 received the edge list scrambled -- found in round 3 through
+        the per-rank fingerprints below)."""
+        t = t.contiguous()
         if backend == "gloo":
             h = t.cpu()
             torch.distributed.broadcast(h, 0)
@@ -177,7 +181,8 @@ def main():
         wl = workloads.coarsen_workload(args.workload, device, spectral=args.spectral)
         coarsen_inputs = (wl["W"], wl["Uk"], wl["lk"], wl["r"])
         info.update(wl["timings"])
-        ei_d, assign_d = torch.from_numpy(wl["ei"]).to(device), torch.from_numpy(wl["assign"]).to(device)
+        ei_d = torch.from_numpy(np.ascontiguousarray(wl["ei"])).to(device)
+        assign_d = torch.from_numpy(np.ascontiguousarray(wl["assign"])).to(device)
         head = torch.tensor([wl["ei"].shape[1], wl["n_clusters"]], dtype=torch.int64, device=device)
         # a fingerprint of the partition (the spectral prelude and the contraction are deterministic: every run of this workload
         # must print the same one)
@@ -202,10 +207,17 @@ def main():
     if world > 1:
         owner = workloads.shard_before_assembly(args.workload, ei_d, assign_d, n_clusters, world)
         mine = np.nonzero(owner == rank)[0]
+        info["owner_fingerprint"] = int((owner * (np.arange(len(owner)) % 65521 + 1)).sum())   # the same on every rank, every run
     sub, nnz_c = workloads.assemble(args.workload, ei_d, assign_d, n_clusters, clusters=mine)
     torch.cuda.synchronize()
     t5 = time.time()
-    mine_sizes = torch.tensor([float(sub["ptr"][-1]), float(nnz_c.sum())], device=device, dtype=torch.float64)
+    # [rows, nnz'] of this rank's shard + fingerprints of what it was built from (graph, partition, ownership): position-weighted
+    # sums, so a permuted copy does not pass
+    pos_e = torch.arange(ei_d.shape[1], device=device) % 1009 + 1
+    mine_sizes = torch.tensor([float(sub["ptr"][-1]), float(nnz_c.sum()),
+                               float(((ei_d[0] * 31 + ei_d[1] * 17) * pos_e).sum() % 1000003),
+                               float((assign_d * (torch.arange(N, device=device) % 1009 + 1)).sum() % 1000003),
+                               float(info.get("owner_fingerprint", 0)), float(sub["core"].sum())], device=device, dtype=torch.float64)
     if world > 1:
         per_rank = [torch.zeros_like(mine_sizes) for _ in range(world)]
         if backend == "gloo":
@@ -214,6 +226,11 @@ def main():
             per_rank = host
         else:
             torch.distributed.all_gather(per_rank, mine_sizes)
+        for k in (2, 3, 4):   # every rank must have built its shard from the same graph, partition and ownership
+            if len({float(t[k]) for t in per_rank}) != 1:
+                raise RuntimeError(f"ranks disagree on their inputs (fingerprint {k}): {[float(t[k]) for t in per_rank]}")
+        if int(sum(float(t[5]) for t in per_rank)) != N:
+            raise RuntimeError("the shards' own nodes do not add up to the graph's nodes")
         info["shard_union_rows"] = [int(t[0]) for t in per_rank]
         info["shard_nnz_prime"] = [int(t[1]) for t in per_rank]
         info.update(union_rows=sum(info["shard_union_rows"]), nnz_prime=sum(info["shard_nnz_prime"]))

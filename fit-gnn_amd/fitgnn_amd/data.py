@@ -50,7 +50,7 @@ def synthetic_graph(N, E, seed=0):
         und = np.stack([keys // N, keys % N], axis=1)
         ei = np.concatenate([und.T, und.T[::-1]], axis=1)
         order = np.lexsort((ei[1], ei[0]))
-        return ei[:, order]
+        return np.ascontiguousarray(ei[:, order])   # (a column-indexed view is not row-major: collectives ship memory as it lies)
     und = {(min(a, b), max(a, b)) for a, b in zip(src, dst)}
     while len(und) < E:
         need = E - len(und)
@@ -64,7 +64,7 @@ def synthetic_graph(N, E, seed=0):
     und = np.array(sorted(und), dtype=np.int64)[:E]
     ei = np.concatenate([und.T, und.T[::-1]], axis=1)
     order = np.lexsort((ei[1], ei[0]))
-    return ei[:, order]
+    return np.ascontiguousarray(ei[:, order])
 
 
 def assemble_subgraphs(edge_index, num_nodes, assign, n_clusters, extra_node=True):

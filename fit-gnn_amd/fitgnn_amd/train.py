@@ -103,7 +103,12 @@ def broadcast_parameters(model, process_group=None, flat=None):
             dist.broadcast(flat.P, src, group=process_group)
         else:
             for p in model.parameters():
-                dist.broadcast(p.data, src, group=process_group)
+                if p.data.is_contiguous():
+                    dist.broadcast(p.data, src, group=process_group)
+                else:   # a collective ships memory as it lies: go through a row-major copy
+                    c = p.data.contiguous()
+                    dist.broadcast(c, src, group=process_group)
+                    p.data.copy_(c)
         for b in model.buffers():
             dist.broadcast(b.data, src, group=process_group)
 

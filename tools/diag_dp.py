@@ -39,6 +39,7 @@ for k in range(2):
     same = {key: bool(torch.equal(a[key], b[key])) for key in a}
     la, ca, za = loss_of(a, 1.0 / N)
     lb, cb, zb = loss_of(b, 1.0 / N)
+    print("rank", k, "clusters", len(mine), "owner crc", int((owner * (np.arange(len(owner)) % 65521 + 1)).sum()), "rows", int(a["ptr"][-1]), "nnz'", int(data.cluster_nnz(a).sum()))
     print("rank", k, "dict equal:", same, "loss a", la, "loss b", lb, "counts", ca, cb, "logits equal", bool(torch.equal(za, zb)))
     tot_a += la; tot_b += lb
 print("sum of shares: assembled alone", tot_a, " cut from the union", tot_b, " full", lf)
