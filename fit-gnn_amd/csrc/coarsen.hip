@@ -408,6 +408,33 @@ __device__ inline void greedy_speculate(const CostGraph &g, CostLds &lds, lds_pt
     }
 }
 
+// ---- the match lists of re-inserted sets, kept between their re-costs (variation_cost.h: HitIO) ----
+// Only the selecting wave reads or writes them.  hc_off / hc_n [N]: pool offset (-1: no list) and current length (-1: not valid) of
+// the list of the set that grew out of candidate `cand`.
+struct HitCacheNone {
+    __device__ __forceinline__ fitgnn::HitIO *begin(fitgnn::HitIO &, int32_t, bool) { return nullptr; }
+    __device__ __forceinline__ void end(fitgnn::HitIO *, int32_t) {}
+};
+struct HitCacheGlobal {
+    int32_t *hc_off, *hc_n;
+    uint16_t *pool_ab;
+    double *pool_w;
+    int64_t pool_cap;
+    int64_t bump;
+    __device__ __forceinline__ fitgnn::HitIO *begin(fitgnn::HitIO &io, int32_t cand, bool remap_ok) {
+        const int32_t off = __builtin_amdgcn_readfirstlane(hc_off[cand]);
+        const int32_t n = __builtin_amdgcn_readfirstlane(hc_n[cand]);
+        io.pool_ab = pool_ab; io.pool_w = pool_w; io.bump = &bump; io.pool_cap = pool_cap;
+        io.off = off;
+        io.n = remap_ok ? n : -1;   // the translation table covers sets of at most 64 members
+        io.use_remap = true;
+        return &io;
+    }
+    __device__ __forceinline__ void end(fitgnn::HitIO *io, int32_t cand) {
+        if ((threadIdx.x & 63) == 0) { hc_off[cand] = (int32_t)io->off; hc_n[cand] = io->n; }
+    }
+};
+
 // The greedy selection of contract_variation_linear (:604-650) over ONE connected component, run by one wavefront.
 // The component's candidates are order[head0 .. head1) (ascending (cost, node id)); node ids, set_off/mem/len/marks
 // are those of the whole (possibly block-diagonal) graph.  Selected sets go to sel_mem[0 .. ) and their END
@@ -420,13 +447,13 @@ __device__ inline void greedy_speculate(const CostGraph &g, CostLds &lds, lds_pt
 // read through a three-stage software pipeline -- entry head + 2: id requested; head + 1: cost / extent requested; head:
 // complete, its first 64 members in the lanes -- and every request was issued at least one pop earlier; re-inserted sets
 // carry their extent in the heap item.  With the marks in LDS a pop from the list touches global memory only to prefetch.
-template <class Heap, class Marks, class Spec>
+template <class Heap, class Marks, class Spec, class Cache = HitCacheNone>
 __device__ inline void greedy_component(const CostGraph &g, CostLds &lds, Heap heap, Spec spec, int32_t head0, int32_t head1,
                                         int64_t seq, const int32_t *__restrict__ set_off, int32_t *__restrict__ mem,
                                         int32_t *__restrict__ len, Marks marks,
                                         const int32_t *__restrict__ order, const double *__restrict__ cost0,
                                         int64_t &n_reduce, int64_t max_iters, int32_t *__restrict__ sel_end,
-                                        int32_t *__restrict__ sel_mem, int32_t &ns, int32_t &pos) {
+                                        int32_t *__restrict__ sel_mem, int32_t &ns, int32_t &pos, Cache cache = Cache{}) {
     const int lane = threadIdx.x & 63;
     int head = head0;    // next unread entry of the sorted initial family (uniform)
     ns = 0; pos = 0;
@@ -527,6 +554,7 @@ __device__ inline void greedy_component(const CostGraph &g, CostLds &lds, Heap h
                     S[m + before] = v;
                     if (m + before < fitgnn::kCostTile) lds.S[m + before] = v;  // staged for the re-cost
                 }
+                if (t0 == 0 && t < nc) lds.remap[lane] = keep ? (uint8_t)before : (uint8_t)255;  // old position -> new (sets of <= 64)
                 m += __popcll(bal);
             }
             GSTAMP(g4);
@@ -537,7 +565,12 @@ __device__ inline void greedy_component(const CostGraph &g, CostLds &lds, Heap h
                 int32_t xm;  // the new set's first 64 members, per lane
                 if (m <= fitgnn::kCostTile) {
                     FITGNN_WAVE_SYNC();
-                    if (!(from_list && spec.lookup(head - 1 - head0, m, c))) c = fitgnn::set_cost_wave<true>(g, S, m, lds);
+                    if (!(from_list && spec.lookup(head - 1 - head0, m, c))) {
+                        fitgnn::HitIO io;
+                        fitgnn::HitIO *iop = cache.begin(io, cand, nc <= fitgnn::kCostTile);
+                        c = fitgnn::set_cost_wave<true>(g, S, m, lds, iop);
+                        if (iop) cache.end(iop, cand);
+                    }
 #ifdef FITGNN_GREEDY_STAMPS
                     else gdbg[15] += 1;
 #endif
@@ -582,7 +615,7 @@ __global__ __launch_bounds__(64 * (1 + kSpecWaves)) void greedy_select_kernel(
     CostGraph g, int32_t N, const int32_t *__restrict__ set_off, int32_t *mem, int32_t *len, uint8_t *__restrict__ marked,
     const int32_t *__restrict__ order, const double *__restrict__ cost0, char *__restrict__ heap_glob, int64_t n_reduce,
     int64_t max_iters, int32_t *__restrict__ sel_off, int32_t *__restrict__ sel_mem, int32_t *__restrict__ sel_count,
-    int32_t state_in_lds) {
+    int32_t state_in_lds, int32_t *hc_off, int32_t *hc_n, uint16_t *hc_ab, double *hc_w, int64_t hc_cap) {
     __shared__ CostLds lds[1 + kSpecWaves];
     __shared__ double h_cost[kHeapLds];
     __shared__ uint32_t h_seq[kHeapLds];
@@ -618,14 +651,14 @@ __global__ __launch_bounds__(64 * (1 + kSpecWaves)) void greedy_select_kernel(
         uint32_t *b_seq = (uint32_t *)(b_cost + greedy_blocks(N));
         greedy_component(g, lds[0], TourHeap<kHeapLds, BlockMinLds>{slots, BlockMinLds{to_lds(b_cost), to_lds(b_seq)}, 0},
                          SpecRing{to_lds(&spec_sh)}, 0, N, (int64_t)N, set_off, mem, len, MarksLds{to_lds(mark_bits)}, order, cost0,
-                         n_reduce, max_iters, sel_off + 1, sel_mem, ns, pos);
+                         n_reduce, max_iters, sel_off + 1, sel_mem, ns, pos, HitCacheGlobal{hc_off, hc_n, hc_ab, hc_w, hc_cap, 0});
         if (threadIdx.x == 0) spec_sh.done = 1;
     } else {
         double *b_cost = (double *)(heap_glob + 24 * n);
         uint32_t *b_seq = (uint32_t *)(b_cost + greedy_blocks(N));
         greedy_component(g, lds[0], TourHeap<kHeapLds, BlockMinGlobal>{slots, BlockMinGlobal{b_cost, b_seq}, 0}, SpecNone{}, 0, N,
                          (int64_t)N, set_off, mem, len, MarksGlobal{marked}, order, cost0, n_reduce, max_iters, sel_off + 1, sel_mem, ns,
-                         pos);
+                         pos, HitCacheGlobal{hc_off, hc_n, hc_ab, hc_w, hc_cap, 0});
     }
     if (threadIdx.x == 0) { sel_count[0] = ns; sel_count[1] = pos; }
 }
@@ -713,7 +746,7 @@ __global__ void len_init_kernel(const int32_t *__restrict__ set_off, int32_t N, 
 }
 
 struct GreedyLayout {
-    size_t mem, len, marked, keys_in, keys_out, ids_in, order, heap, sort_tmp, sort_tmp_bytes, total;
+    size_t mem, len, marked, keys_in, keys_out, ids_in, order, heap, sort_tmp, sort_tmp_bytes, hc_off, hc_n, hc_ab, hc_w, hc_cap, total;
 };
 GreedyLayout greedy_layout(int32_t N, int64_t total_members) {
     GreedyLayout L{};
@@ -732,6 +765,12 @@ GreedyLayout greedy_layout(int32_t N, int64_t total_members) {
                                     (int32_t *)nullptr, n, 0, 64, (hipStream_t)0);
     L.sort_tmp_bytes = tmp;
     L.sort_tmp = o; o += align_up(tmp);
+    // match lists of re-inserted sets (HitCacheGlobal): two ints per node + a pool of one entry per family member
+    L.hc_off = o; o += align_up(n * 4);
+    L.hc_n = o; o += align_up(n * 4);
+    L.hc_cap = tm;
+    L.hc_ab = o; o += align_up(tm * 2);
+    L.hc_w = o; o += align_up(tm * 8);
     L.total = o;
     return L;
 }
@@ -869,6 +908,8 @@ extern "C" int fitgnn_greedy_select(const int32_t *rowptr, const int32_t *col, c
     HeapItem *heap = (HeapItem *)(base + L.heap);
     FITGNN_RETURN_IF_HIP(hipMemcpyAsync(mem, set_mem, (size_t)total * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
     FITGNN_RETURN_IF_HIP(hipMemsetAsync(marked, 0, (size_t)N, s));
+    FITGNN_RETURN_IF_HIP(hipMemsetAsync(base + L.hc_off, 0xff, (size_t)N * 4, s));   // -1: no list
+    FITGNN_RETURN_IF_HIP(hipMemsetAsync(base + L.hc_n, 0xff, (size_t)N * 4, s));
     hipLaunchKernelGGL(len_init_kernel, blocks_for(N), dim3(256), 0, s, set_off, N, len);
     hipLaunchKernelGGL(cost_keys_kernel, blocks_for(N), dim3(256), 0, s, cost0, N, keys_in, ids_in);
     // stable LSD radix sort on the cost bits: ties keep ascending node id == SortedList's stable build
@@ -883,7 +924,8 @@ extern "C" int fitgnn_greedy_select(const int32_t *rowptr, const int32_t *col, c
     static std::atomic<uint64_t> lds_done{0};
     if (const int rc = fitgnn_lds_limit_once((const void *)greedy_select_kernel, kStateLdsBytes, lds_done)) return rc;
     hipLaunchKernelGGL(greedy_select_kernel, dim3(1), dim3(64 * (1 + kSpecWaves)), state_in_lds ? dyn_bytes : 0, s, g, N, set_off, mem, len, marked, order,
-                       cost0, (char *)heap, n_reduce, max_iters, sel_off, sel_mem, sel_count, state_in_lds);
+                       cost0, (char *)heap, n_reduce, max_iters, sel_off, sel_mem, sel_count, state_in_lds, (int32_t *)(base + L.hc_off),
+                       (int32_t *)(base + L.hc_n), (uint16_t *)(base + L.hc_ab), (double *)(base + L.hc_w), (int64_t)L.hc_cap);
     return (int)hipGetLastError();
 }
 

@@ -44,6 +44,22 @@ struct CostLds {  // per-wave LDS scratch
     int32_t re0[kCostTile];         // rowptr of every member
     int32_t cnt[kCostTile];         // matches per member row
     uint8_t hit_b[kHitCap];         // position in S of every match
+    uint8_t hit_a[kHitCap];         // ... and the member row it belongs to (what a cached list is filtered by)
+    uint8_t remap[kCostTile];       // greedy selection: position of an old member in the pruned set, 255 = dropped
+};
+
+// A set's list of matches (W_S in (row, column) order) can be kept between two costings of the same, shrinking set: the greedy
+// selection re-costs a re-inserted set every time a member of it is marked, and the matches of the pruned set are the old ones
+// minus those that touch a dropped member -- no adjacency list has to be scanned again (a 50-member set of degree-50 nodes: 2 500
+// entries, ten rounds of dependent look-ups, 45 us; 91 % of the S-products selection).  Same list, same order: same arithmetic.
+struct HitIO {
+    uint16_t *pool_ab;   // (row << 8) | column per match, positions at the time of storing
+    double *pool_w;      // weights (only used for a weighted graph)
+    int64_t *bump;       // next free pool entry (owned by the one selecting wave)
+    int64_t pool_cap;
+    int64_t off;         // this set's list: pool offset (-1: none yet), in: number of stored matches (-1: none, scan)
+    int32_t n;           // out: number of matches now stored (-1: the list did not fit / was not built)
+    bool use_remap;      // the stored positions are to be translated through lds.remap
 };
 
 struct CostGraph {
@@ -73,7 +89,7 @@ __device__ __forceinline__ int lower_bound_i32(const int32_t *a, int n, int32_t 
 // STAGED: the caller has already put the members of a set of at most kCostTile nodes into lds.S (and synchronised the wave),
 // so nothing is read back from S -- the greedy selection re-costs a set it has just compacted in registers.
 template <bool STAGED = false>
-__device__ inline double set_cost_wave(const CostGraph &g, const int32_t *__restrict__ S, int nc, CostLds &lds) {
+__device__ inline double set_cost_wave(const CostGraph &g, const int32_t *__restrict__ S, int nc, CostLds &lds, HitIO *io = nullptr) {
 #pragma clang fp contract(off)
     if (nc < 2) return INFINITY;
     const int lane = threadIdx.x & 63;
@@ -131,7 +147,35 @@ __device__ inline double set_cost_wave(const CostGraph &g, const int32_t *__rest
         // index space, independent loads -- and list the matches (position in S, weight) in LDS in (row, column)
         // order; each member's lane then folds ITS matches in that same order, so the arithmetic is the serial walk's.
         bool listed = false;
-        if (small) {
+        int nh_listed = 0;
+        if (small && io && io->off >= 0 && io->n >= 0) {
+            // ---- the stored list of this set, minus the matches that touch a dropped member ----
+            lds.cnt[lane] = 0;
+            FITGNN_WAVE_SYNC();
+            int nh = 0;
+            for (int base = 0; base < io->n; base += 64) {
+                const int i = base + lane;
+                const bool valid = i < io->n;
+                const uint32_t ab = valid ? io->pool_ab[io->off + i] : 0u;
+                const double wv = (valid && g.w) ? io->pool_w[io->off + i] : 1.0;
+                int a = (int)(ab >> 8), b = (int)(ab & 255u);
+                if (io->use_remap) { a = lds.remap[a]; b = lds.remap[b]; }
+                const bool hit = valid && a != 255 && b != 255;
+                const unsigned long long bal = __ballot(hit);
+                if (hit) {
+                    const int at = nh + __popcll(bal & ((1ull << lane) - 1ull));
+                    lds.hit_a[at] = (uint8_t)a;
+                    lds.hit_b[at] = (uint8_t)b;
+                    lds.hit_w[at] = wv;
+                    atomicAdd(&lds.cnt[a], 1);
+                }
+                nh += __popcll(bal);
+            }
+            listed = true;
+            nh_listed = nh;
+            FITGNN_WAVE_SYNC();
+        }
+        if (small && !listed) {
             const int e0 = pre_e0, deg = pre_deg;
             int incl = deg;
 #pragma unroll
@@ -178,6 +222,7 @@ __device__ inline double set_cost_wave(const CostGraph &g, const int32_t *__rest
                     if (nh + nb > kHitCap) { listed = false; break; }  // wave-uniform
                     if (hit) {
                         const int at = nh + __popcll(bal & ((1ull << lane) - 1ull));
+                        lds.hit_a[at] = (uint8_t)a4[q];
                         lds.hit_b[at] = (uint8_t)b;
                         lds.hit_w[at] = w4[q];
                         atomicAdd(&lds.cnt[a4[q]], 1);
@@ -185,7 +230,23 @@ __device__ inline double set_cost_wave(const CostGraph &g, const int32_t *__rest
                     nh += nb;
                 }
             }
+            nh_listed = nh;
             FITGNN_WAVE_SYNC();
+        }
+        if (small) {
+            if (io) {   // keep the list for the set's next costing (in place when it was read from the pool: it only shrinks)
+                io->n = -1;
+                if (listed) {
+                    if (io->off < 0 && *io->bump + nh_listed <= io->pool_cap) { io->off = *io->bump; *io->bump += nh_listed; }
+                    if (io->off >= 0) {
+                        for (int i = lane; i < nh_listed; i += 64) {
+                            io->pool_ab[io->off + i] = (uint16_t)(((uint32_t)lds.hit_a[i] << 8) | (uint32_t)lds.hit_b[i]);
+                            if (g.w) io->pool_w[io->off + i] = lds.hit_w[i];
+                        }
+                        io->n = nh_listed;
+                    }
+                }
+            }
             if (listed) {
                 const int cn = lane < rows ? lds.cnt[lane] : 0;
                 int hincl = cn;
