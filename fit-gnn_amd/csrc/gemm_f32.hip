@@ -21,6 +21,7 @@
 // consecutive banks).  The kernel is bound by the fp32 matrix pipe (64 cycles per MFMA and SIMD against 6 LDS reads per 32 MFMAs);
 // operand traffic is (TI + TJ) x 4 bytes per 2 TI TJ flops = 64 flop/byte at 256 x 256, 2.4 TB/s at the fp32 MFMA peak.
 #include <algorithm>
+#include <cmath>
 
 #include "common.h"
 #include "fitgnn_hip.h"
@@ -197,7 +198,7 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void gemm_f32_kernel(const float *
     }
 }
 
-// out = sum over chunks of partial[chunk] in a fixed order (nchunks a multiple of 8: eight loads in flight per lane)
+// out = sum over chunks of partial[chunk] in a fixed order (eight running sums: eight loads in flight per lane)
 __global__ __launch_bounds__(256) void sum_chunks_kernel(const float *__restrict__ partial, int nchunks, long IJ, float *__restrict__ out, int J,
                                                          long ldc) {
     const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -205,10 +206,14 @@ __global__ __launch_bounds__(256) void sum_chunks_kernel(const float *__restrict
     float part[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) part[u] = 0.f;
-    for (int c = 0; c < nchunks; c += 8) {
+    int c = 0;
+    for (; c + 8 <= nchunks; c += 8) {
 #pragma unroll
         for (int u = 0; u < 8; ++u) part[u] += partial[(long)(c + u) * IJ + q];
     }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+        if (c + u < nchunks) part[u] += partial[(long)(c + u) * IJ + q];
     float acc = part[0];
 #pragma unroll
     for (int u = 1; u < 8; ++u) acc += part[u];
@@ -233,14 +238,22 @@ Plan make_plan(long I, int J, long K, bool akm, bool bkm) {
     p.tiles_j = (J + TJ - 1) / TJ;
     p.nchunks = 1;
     p.chunk_k = K;
-    const long ntile = (long)p.tiles_i * p.tiles_j;
-    if (ntile < 128 && K >= 64 * kBK) {   // too few tiles for 256 CUs and a long reduction: split k
-        long want = (256 + ntile - 1) / ntile;
-        const long most = K / (4 * kBK);   // at least four stages per chunk
-        if (want > most) want = most;
-        p.nchunks = (int)((want + 7) / 8 * 8);
+    // Split over k where that shortens the launch.  One workgroup per CU (LDS), 256 CUs: a launch takes ceil(workgroups / 256)
+    // rounds of one tile's time each, so 270 full-k tiles (S-physics' layer 0: 34 493 rows) take two rounds with the second one
+    // 5 % full, and 66 tiles leave 190 CUs idle.  c chunks make the tiles c times shorter at the price of c + 1 passes over an
+    // [I x J] partial matrix; the model below -- fp32 MFMA at ~0.45 TFLOP/s per CU as measured, partials at 3 TB/s -- picks c.
+    const double ntile = (double)p.tiles_i * p.tiles_j;
+    const double t_tile = 2.0 * TI * TJ * (double)K / 0.45e12;
+    const long most = K / (4 * kBK);   // at least four stages per chunk
+    double best = ceil(ntile / 256.0) * t_tile;
+    for (long c = 2; c <= most && c <= 256; ++c) {
+        const double t = ceil(ntile * (double)c / 256.0) * t_tile / (double)c + (double)(c + 1) * (double)I * (double)J * 4.0 / 3.0e12 + 4e-6;
+        if (t < 0.92 * best) { best = t; p.nchunks = (int)c; }
+    }
+    if (p.nchunks > 1) {
         const long per = (K + p.nchunks - 1) / p.nchunks;
         p.chunk_k = (per + kBK - 1) / kBK * kBK;
+        p.nchunks = (int)((K + p.chunk_k - 1) / p.chunk_k);   // chunks that hold at least one stage
     }
     return p;
 }
@@ -251,7 +264,7 @@ int launch(const Plan &p, const float *a, long lda, const float *b, long ldb, lo
     static std::atomic<uint64_t> lds_done{0};
     if (const int rc = fitgnn_lds_limit_once((const void *)gemm_f32_kernel<WM, WN, AKM, BKM>, G::LDS_BYTES, lds_done)) return rc;
     unsigned grid;
-    if (p.nchunks > 1) grid = (unsigned)(p.tiles_i * p.tiles_j * p.nchunks);
+    if (p.nchunks > 1) grid = (unsigned)(p.tiles_i * p.tiles_j * ((p.nchunks + 7) / 8 * 8));   // chunk = xcd + 8 * (slot / tiles)
     else grid = (unsigned)((p.tiles_i + 7) / 8 * 8 * p.tiles_j);
     hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, AKM, BKM>), dim3(grid), dim3(G::THREADS), G::LDS_BYTES, s, a, lda, b, ldb, I, J, K, c, ldc,
                        p.tiles_i, p.tiles_j, p.nchunks, p.chunk_k);

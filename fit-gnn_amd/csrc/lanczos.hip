@@ -28,11 +28,12 @@ __device__ __forceinline__ double wave_sum(double v) {   // fixed butterfly: eve
     return v;
 }
 
-// y = A x for a CSR matrix in f64; 8 lanes share a row (a Laplacian row of the S-products graph holds ~51 entries, PubMed's ~5),
-// their partial sums are added in a fixed order.
+// y = alpha (A x) + beta x for a CSR matrix in f64 (alpha = -1, beta = 2 max(dw), A = L: the shifted operator T = beta I - L the
+// reference hands to ARPACK, coarsening_utils.py:83-88, without building it); 8 lanes share a row (a Laplacian row of the S-products
+// graph holds ~51 entries, PubMed's ~5), their partial sums are added in a fixed order.
 __global__ __launch_bounds__(kThreads) void lanczos_spmv_kernel(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
                                                                const double *__restrict__ val, const double *__restrict__ x,
-                                                               double *__restrict__ y, int n) {
+                                                               double *__restrict__ y, int n, double alpha, double beta) {
     const int g = (blockIdx.x * kThreads + threadIdx.x) >> 3, l = threadIdx.x & 7;
     double s = 0.0;
     if (g < n) {
@@ -42,7 +43,7 @@ __global__ __launch_bounds__(kThreads) void lanczos_spmv_kernel(const int32_t *_
     s += __shfl_xor(s, 1, 64);
     s += __shfl_xor(s, 2, 64);
     s += __shfl_xor(s, 4, 64);
-    if (g < n && l == 0) y[g] = s;
+    if (g < n && l == 0) y[g] = alpha * s + beta * x[g];
 }
 
 // One projection pass over the rows [b * rows_per_block, ...) of workgroup b:
@@ -140,13 +141,13 @@ inline int project_blocks(int n) {
 extern "C" int32_t fitgnn_lanczos_parts(int32_t n) { return n <= 0 ? 0 : project_blocks(n); }
 
 extern "C" int fitgnn_lanczos_spmv_f64(const int32_t *rowptr, const int32_t *col, const double *val, const double *x, double *y, int32_t n,
-                                       void *stream) {
+                                       double alpha, double beta, void *stream) {
     if (n < 0) return FITGNN_E_BADARG;
     if (n == 0) return 0;
     if (!rowptr || !x || !y) return FITGNN_E_BADARG;
     const int64_t threads = (int64_t)n * 8;
     hipLaunchKernelGGL(lanczos_spmv_kernel, dim3((unsigned)((threads + kThreads - 1) / kThreads)), dim3(kThreads), 0, (hipStream_t)stream, rowptr,
-                       col, val, x, y, n);
+                       col, val, x, y, n, alpha, beta);
     return (int)hipGetLastError();
 }
 

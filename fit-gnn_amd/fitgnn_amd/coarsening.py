@@ -116,14 +116,14 @@ def lanczos_smallest(L, K, device="cuda", tol=1e-5, m=None, max_restarts=300, se
     dev = torch.device(device)
     if dev.type != "cuda":
         raise _lib.FitgnnError("lanczos_smallest runs on the MI355X (spectral='host' is the reference's ARPACK call)")
-    Lc = sp.csr_matrix(L).astype(np.float64)
+    # L is symmetric: a CSC matrix's arrays ARE the CSR arrays of the same matrix (Graph.L is CSC) -- no conversion, no T on the host:
+    # the device product computes y = offset x - L x
+    Lc = L if sp.isspmatrix_csc(L) or sp.isspmatrix_csr(L) else sp.csr_matrix(L)
     N = Lc.shape[0]
     offset = 2.0 * float(Lc.diagonal().max())
-    T = (offset * sp.eye(N, format="csr") - Lc).tocsr()
-    T.sort_indices()
-    rowptr = torch.from_numpy(T.indptr.astype(np.int32)).to(dev)
-    col = torch.from_numpy(T.indices.astype(np.int32)).to(dev)
-    val = torch.from_numpy(T.data.astype(np.float64)).to(dev)
+    rowptr = torch.from_numpy(np.ascontiguousarray(Lc.indptr, dtype=np.int32)).to(dev)
+    col = torch.from_numpy(np.ascontiguousarray(Lc.indices, dtype=np.int32)).to(dev)
+    val = torch.from_numpy(np.ascontiguousarray(Lc.data, dtype=np.float64)).to(dev)
     m = int(m or min(N - 1, max(4 * K + 20, 60)))
     if m + 1 > 128:
         raise ValueError("lanczos_smallest: at most 127 basis vectors (fitgnn_lanczos_project_f64)")
@@ -141,8 +141,8 @@ def lanczos_smallest(L, K, device="cuda", tol=1e-5, m=None, max_restarts=300, se
     j0 = 0
     for _ in range(max_restarts):
         for j in range(j0, m):
-            _lib.check(Lh.fitgnn_lanczos_spmv_f64(_lib.dptr(rowptr), _lib.dptr(col), _lib.dptr(val), _lib.dptr(V[j]), _lib.dptr(w), N, st),
-                       "fitgnn_lanczos_spmv_f64")
+            _lib.check(Lh.fitgnn_lanczos_spmv_f64(_lib.dptr(rowptr), _lib.dptr(col), _lib.dptr(val), _lib.dptr(V[j]), _lib.dptr(w), N, -1.0, offset,
+                                                  st), "fitgnn_lanczos_spmv_f64")
             # h = V^T w;  w -= V h, h2 = V^T w;  w -= V h2, |w|^2;  v_{j+1} = w / |w|, H[:, j] = h + h2
             _lib.check(Lh.fitgnn_lanczos_project_f64(_lib.dptr(V), N, j + 1, _lib.dptr(w), N, None, _lib.dptr(pa), None, st), "lanczos_project")
             _lib.check(Lh.fitgnn_lanczos_project_f64(_lib.dptr(V), N, j + 1, _lib.dptr(w), N, _lib.dptr(pa), _lib.dptr(pb), None, st), "lanczos_project")

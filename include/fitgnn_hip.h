@@ -116,7 +116,8 @@ int fitgnn_spmm_csr_blocks_dz_f32(const int32_t *rowptr, const int32_t *col, con
 /* One step of the thick-restart Lanczos iteration of the spectral prelude (coarsening_utils.py:83-90 hands T = 2 max(dw) I - L to
  * ARPACK; fitgnn_amd.coarsening.lanczos_smallest iterates on the device), float64, over a COLUMN-major basis
  * V [m + 1][ldv] (basis vector c = V + c * ldv, ldv >= n):
- *   fitgnn_lanczos_spmv_f64     y = A x for a CSR matrix (int32 indices, f64 values);
+ *   fitgnn_lanczos_spmv_f64     y = alpha (A x) + beta x for a CSR matrix (int32 indices, f64 values): with A = L, alpha = -1,
+ *                               beta = 2 max(dw) the reference's shifted operator, never built;
  *   fitgnn_lanczos_project_f64  h = the fixed-order sum of the previous pass's partial rows part_in [parts x ncol] (part_in NULL: no
  *                               subtraction);  w -= sum_{c < ncol} V[c] h[c];  part_out[b][c] = this workgroup's share of V[c] . w,
  *                               norm_out[b] (may be NULL) its share of w . w;  parts = fitgnn_lanczos_parts(n);  ncol <= 128;
@@ -125,7 +126,8 @@ int fitgnn_spmm_csr_blocks_dz_f32(const int32_t *rowptr, const int32_t *col, con
  *                               H[j + 1][j] = beta;  H row-major with row stride ldh.
  * No atomics: every sum runs in a fixed order, the iteration is reproducible. */
 int32_t fitgnn_lanczos_parts(int32_t n);
-int fitgnn_lanczos_spmv_f64(const int32_t *rowptr, const int32_t *col, const double *val, const double *x, double *y, int32_t n, void *stream);
+int fitgnn_lanczos_spmv_f64(const int32_t *rowptr, const int32_t *col, const double *val, const double *x, double *y, int32_t n,
+                            double alpha, double beta, void *stream);
 int fitgnn_lanczos_project_f64(const double *V, int64_t ldv, int32_t ncol, double *w, int32_t n, const double *part_in, double *part_out,
                                double *norm_out, void *stream);
 int fitgnn_lanczos_finish_f64(double *V, int64_t ldv, int32_t j, const double *w, int32_t n, const double *norm_part, const double *part_a,

@@ -19,7 +19,7 @@ for (n, e, r) in [(19717, 44324, 0.5), (60000, 600000, 0.5), (5000, 30000, 0.7)]
     dw = np.ascontiguousarray(Gr.dw)
     ref = orc.variation_costs(rowptr, col, ww, dw, A, off[:-1].copy(), np.diff(off).astype(np.int32), mem)
     so, sm, _ = orc.greedy_select(rowptr, col, ww, dw, A, off, mem, ref, int(np.floor(r * n)))
-    for rep in range(40):
+    for rep in range(int(os.environ.get("STRESS_REPS", "40"))):
         res = co.contract_level(Gr, A, r, keep_debug=True)
         if not (np.array_equal(res.sel_off, so) and np.array_equal(res.sel_mem, sm)):
             bad += 1
