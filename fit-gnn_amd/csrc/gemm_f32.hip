@@ -22,6 +22,7 @@
 // operand traffic is (TI + TJ) x 4 bytes per 2 TI TJ flops = 64 flop/byte at 256 x 256, 2.4 TB/s at the fp32 MFMA peak.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 #include "common.h"
 #include "fitgnn_hip.h"
@@ -249,6 +250,10 @@ Plan make_plan(long I, int J, long K, bool akm, bool bkm) {
     for (long c = 2; c <= most && c <= 256; ++c) {
         const double t = ceil(ntile * (double)c / 256.0) * t_tile / (double)c + (double)(c + 1) * (double)I * (double)J * 4.0 / 3.0e12 + 4e-6;
         if (t < 0.92 * best) { best = t; p.nchunks = (int)c; }
+    }
+    if (const char *force = getenv("FITGNN_GEMM_CHUNKS")) {   // experiments: a fixed chunk count (clamped to what K allows)
+        const long c = atol(force);
+        p.nchunks = (int)(c < 1 ? 1 : (c > most && most >= 1 ? most : c));
     }
     if (p.nchunks > 1) {
         const long per = (K + p.nchunks - 1) / p.nchunks;
