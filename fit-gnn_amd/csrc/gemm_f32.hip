@@ -246,19 +246,20 @@ Plan make_plan(long I, int J, long K, bool akm, bool bkm) {
     const double ntile = (double)p.tiles_i * p.tiles_j;
     const double t_tile = 2.0 * TI * TJ * (double)K / 0.45e12;
     const long most = K / (4 * kBK);   // at least four stages per chunk
+    // chunk counts are multiples of 8: a tile's chunks sit on consecutive block ids = one per XCD (block -> (chunk, tile) below), so
+    // any other count leaves XCDs idle (measured: 2 chunks of the 34 493 x 8 448 product took 10.0 ms against 4.6 unsplit, 8: 2.8)
     double best = ceil(ntile / 256.0) * t_tile;
-    for (long c = 2; c <= most && c <= 256; ++c) {
+    for (long c = 8; c <= most && c <= 256; c += 8) {
         const double t = ceil(ntile * (double)c / 256.0) * t_tile / (double)c + (double)(c + 1) * (double)I * (double)J * 4.0 / 3.0e12 + 4e-6;
         if (t < 0.92 * best) { best = t; p.nchunks = (int)c; }
     }
     if (const char *force = getenv("FITGNN_GEMM_CHUNKS")) {   // experiments: a fixed chunk count (clamped to what K allows)
         const long c = atol(force);
-        p.nchunks = (int)(c < 1 ? 1 : (c > most && most >= 1 ? most : c));
+        p.nchunks = (int)(c <= 1 ? 1 : (c + 7) / 8 * 8);
     }
     if (p.nchunks > 1) {
         const long per = (K + p.nchunks - 1) / p.nchunks;
-        p.chunk_k = (per + kBK - 1) / kBK * kBK;
-        p.nchunks = (int)((K + p.chunk_k - 1) / p.chunk_k);   // chunks that hold at least one stage
+        p.chunk_k = (per + kBK - 1) / kBK * kBK;   // (a last chunk may come out empty: it stores zeros)
     }
     return p;
 }
