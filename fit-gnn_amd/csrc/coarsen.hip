@@ -568,6 +568,9 @@ __device__ inline void greedy_component(const CostGraph &g, CostLds &lds, Heap h
                     if (!(from_list && spec.lookup(head - 1 - head0, m, c))) {
                         fitgnn::HitIO io;
                         fitgnn::HitIO *iop = cache.begin(io, cand, nc <= fitgnn::kCostTile);
+#ifdef FITGNN_GREEDY_STAMPS
+                        if (iop && iop->off >= 0 && iop->n >= 0) gdbg[7] += 1;   // re-costs answered from the set's stored match list
+#endif
                         c = fitgnn::set_cost_wave<true>(g, S, m, lds, iop);
                         if (iop) cache.end(iop, cand);
                     }

@@ -321,6 +321,25 @@ def test_backward_spmm_with_the_previous_layers_epilogue_in_its_store(mods, H, u
         assert none is None and torch.equal(got2, want2)
 
 
+def test_backward_epilogue_with_a_window_smaller_than_its_column_sum_scratch(mods):
+    """The tile kernel's backward epilogue folds its column sums through LDS (4 waves x 64 lanes x 4 floats = 4 KiB); a window
+    of 2 or 3 rows allocates less than that for the window itself: the launcher keeps the allocation at the scratch's
+    size, and dZ / db equal the default window's."""
+    _lib, csr, ops, orc, gorc = mods
+    from fitgnn_amd._lib import EPI_DROPOUT, EPI_ELU
+
+    ei, n = block_graph([5, 3, 9, 2, 7, 30, 4] * 8, seed=3, p=0.4)
+    torch.manual_seed(1)
+    X, prev = torch.randn(n, 64).cuda(), torch.randn(n, 64).cuda()
+    ref_g = csr.CSRGraph(ei.cuda(), n, mode="gcn")
+    want, want_db = ops.spmm_graph_dz(ref_g, X, prev, EPI_ELU | EPI_DROPOUT, p=0.5, seed=9, want_db=True)
+    for rows in (2, 3):
+        g = csr.CSRGraph(ei.cuda(), n, mode="gcn", lds_rows=rows)
+        got, got_db = ops.spmm_graph_dz(g, X, prev, EPI_ELU | EPI_DROPOUT, p=0.5, seed=9, want_db=True)
+        assert torch.equal(got, want)
+        assert rel_err(got_db.cpu(), want_db.cpu()) < 1e-5
+
+
 @pytest.mark.parametrize("H", [512, 96, 260])
 @pytest.mark.parametrize("sizes", [[100, 7, 17, 300, 3, 3, 64, 33, 2, 1000, 5, 5, 40], [3, 2], [1], [70] * 400])
 def test_row_streaming_kernel_for_a_compact_operand(mods, H, sizes):

@@ -32,4 +32,4 @@ names = ["pop from list", "pop from heap", "mark check", "select", "prune", "re-
 cnts = [v[8], v[9], v[8] + v[9], v[10], v[11], v[12], v[12]]
 for n, cyc, c in zip(names, v[0:7], cnts):
     print(f"  {n:14s} {100.0*cyc/max(tot,1):5.1f} %  n={c:7d}  cycles/op={cyc/max(c,1):8.1f}")
-print(f"  max queue size {v[13]}, re-costs of list entries {v[14]} of {v[12]}, answered by a helper wave {v[15]}")
+print(f"  max queue size {v[13]}, re-costs of list entries {v[14]} of {v[12]}, answered by a helper wave {v[15]}, from a stored match list {v[7]}")
