@@ -351,19 +351,24 @@ struct SpecShared {
     volatile int32_t tag[kSpecWaves][kSpecRing];  // list index the entry describes (written last)
     volatile int32_t cnt[kSpecWaves][kSpecRing];
     volatile double cost[kSpecWaves][kSpecRing];
+    volatile int32_t hoff[kSpecWaves][kSpecRing];   // the helper's stored match list of the pruned set (pool offset, length; -1: none)
+    volatile int32_t hn[kSpecWaves][kSpecRing];
 };
 struct SpecNone {
     __device__ __forceinline__ void publish_head(int) const {}
-    __device__ __forceinline__ bool lookup(int, int, double &) const { return false; }
+    __device__ __forceinline__ bool lookup(int, int, double &, int32_t &, int32_t &) const { return false; }
 };
 struct SpecRing {
     lds_ptr<SpecShared> sh;
     __device__ __forceinline__ void publish_head(int head) const { if ((threadIdx.x & 63) == 0) sh->head = head; }
-    __device__ __forceinline__ bool lookup(int lp, int m, double &c) const {
+    __device__ __forceinline__ bool lookup(int lp, int m, double &c, int32_t &hoff, int32_t &hn) const {
         const int w = lp % kSpecWaves, e = (lp / kSpecWaves) % kSpecRing;
         if (sh->tag[w][e] != lp) return false;   // volatile: tag, then count and cost (the writer's order reversed)
         if (sh->cnt[w][e] != m) return false;
         c = sh->cost[w][e];
+        hoff = sh->hoff[w][e];
+        hn = sh->hn[w][e];
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   // the helper's pool entries (same CU) before any later read of them
         return true;
     }
 };
@@ -373,8 +378,10 @@ struct SpecRing {
 template <class Marks>
 __device__ inline void greedy_speculate(const CostGraph &g, CostLds &lds, lds_ptr<SpecShared> sh, int w, int32_t n_list,
                                         const int32_t *__restrict__ set_off, const int32_t *mem, const int32_t *len,
-                                        Marks marks, const int32_t *__restrict__ order) {
+                                        Marks marks, const int32_t *__restrict__ order, uint16_t *pool_ab, double *pool_w,
+                                        int64_t pool_begin, int64_t pool_end) {
     const int lane = threadIdx.x & 63;
+    int64_t bump = pool_begin;   // this helper's own region of the match-list pool
     for (int p = w; p < n_list; p += kSpecWaves) {
         int h;
         for (;;) {  // wait until the list head is near (or the selection is over)
@@ -395,14 +402,20 @@ __device__ inline void greedy_speculate(const CostGraph &g, CostLds &lds, lds_pt
         if (m == nc || m < 2) continue;  // nothing marked yet / the entry will be dropped
         if (keep) lds.S[__popcll(bal & ((1ull << lane) - 1ull))] = v;
         FITGNN_WAVE_SYNC();
-        const double cost = fitgnn::set_cost_wave<true>(g, nullptr, m, lds);
+        // the pruned set's match list goes to the pool with its cost: if the selecting wave takes the cost (equal sets), the set's
+        // next re-cost filters that list instead of scanning adjacency lists again
+        fitgnn::HitIO io{pool_ab, pool_w, &bump, pool_end, -1, -1, false};
+        const double cost = fitgnn::set_cost_wave<true>(g, nullptr, m, lds, pool_ab ? &io : nullptr);
         FITGNN_WAVE_SYNC();
         // publish only if the entry is still unpopped: then every read above preceded the selecting wave's changes to it
         if (sh->head > p) continue;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the list's entries before the ring entry that names them
         if (lane == 0) {
             const int e = (p / kSpecWaves) % kSpecRing;
             sh->cost[w][e] = cost;
             sh->cnt[w][e] = m;
+            sh->hoff[w][e] = (int32_t)io.off;
+            sh->hn[w][e] = io.n;
             sh->tag[w][e] = p;
         }
     }
@@ -414,6 +427,7 @@ __device__ inline void greedy_speculate(const CostGraph &g, CostLds &lds, lds_pt
 struct HitCacheNone {
     __device__ __forceinline__ fitgnn::HitIO *begin(fitgnn::HitIO &, int32_t, bool) { return nullptr; }
     __device__ __forceinline__ void end(fitgnn::HitIO *, int32_t) {}
+    __device__ __forceinline__ void adopt(int32_t, int32_t, int32_t) {}
 };
 struct HitCacheGlobal {
     int32_t *hc_off, *hc_n;
@@ -432,6 +446,10 @@ struct HitCacheGlobal {
     }
     __device__ __forceinline__ void end(fitgnn::HitIO *io, int32_t cand) {
         if ((threadIdx.x & 63) == 0) { hc_off[cand] = (int32_t)io->off; hc_n[cand] = io->n; }
+    }
+    // a helper wave costed this very set and stored its list (SpecRing::lookup)
+    __device__ __forceinline__ void adopt(int32_t cand, int32_t off, int32_t n) {
+        if ((threadIdx.x & 63) == 0) { hc_off[cand] = off; hc_n[cand] = off >= 0 ? n : -1; }
     }
 };
 
@@ -565,7 +583,13 @@ __device__ inline void greedy_component(const CostGraph &g, CostLds &lds, Heap h
                 int32_t xm;  // the new set's first 64 members, per lane
                 if (m <= fitgnn::kCostTile) {
                     FITGNN_WAVE_SYNC();
-                    if (!(from_list && spec.lookup(head - 1 - head0, m, c))) {
+                    int32_t h_off = -1, h_n = -1;
+                    if (from_list && spec.lookup(head - 1 - head0, m, c, h_off, h_n)) {
+                        cache.adopt(cand, h_off, h_n);
+#ifdef FITGNN_GREEDY_STAMPS
+                        gdbg[15] += 1;
+#endif
+                    } else {
                         fitgnn::HitIO io;
                         fitgnn::HitIO *iop = cache.begin(io, cand, nc <= fitgnn::kCostTile);
 #ifdef FITGNN_GREEDY_STAMPS
@@ -574,9 +598,6 @@ __device__ inline void greedy_component(const CostGraph &g, CostLds &lds, Heap h
                         c = fitgnn::set_cost_wave<true>(g, S, m, lds, iop);
                         if (iop) cache.end(iop, cand);
                     }
-#ifdef FITGNN_GREEDY_STAMPS
-                    else gdbg[15] += 1;
-#endif
                     xm = lane < m ? lds.S[lane] : -1;
                 } else {
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // the compacted members are read back
@@ -635,7 +656,10 @@ __global__ __launch_bounds__(64 * (1 + kSpecWaves)) void greedy_select_kernel(
         if (threadIdx.x == 0) { spec_sh.head = 0; spec_sh.done = 0; }
         __syncthreads();  // the only workgroup barrier: nothing below waits for another wave
         if (wave > 0) {
-            greedy_speculate(g, lds[wave], to_lds(&spec_sh), wave - 1, N, set_off, mem, len, MarksLds{to_lds(mark_bits)}, order);
+            // the match-list pool: first half the selecting wave's, the second half split between the helpers
+            const int64_t half = hc_cap / 2, per = (hc_cap - half) / kSpecWaves;
+            greedy_speculate(g, lds[wave], to_lds(&spec_sh), wave - 1, N, set_off, mem, len, MarksLds{to_lds(mark_bits)}, order, hc_ab, hc_w,
+                             half + (wave - 1) * per, half + wave * per);
             return;
         }
     } else if (wave > 0) {
@@ -654,7 +678,7 @@ __global__ __launch_bounds__(64 * (1 + kSpecWaves)) void greedy_select_kernel(
         uint32_t *b_seq = (uint32_t *)(b_cost + greedy_blocks(N));
         greedy_component(g, lds[0], TourHeap<kHeapLds, BlockMinLds>{slots, BlockMinLds{to_lds(b_cost), to_lds(b_seq)}, 0},
                          SpecRing{to_lds(&spec_sh)}, 0, N, (int64_t)N, set_off, mem, len, MarksLds{to_lds(mark_bits)}, order, cost0,
-                         n_reduce, max_iters, sel_off + 1, sel_mem, ns, pos, HitCacheGlobal{hc_off, hc_n, hc_ab, hc_w, hc_cap, 0});
+                         n_reduce, max_iters, sel_off + 1, sel_mem, ns, pos, HitCacheGlobal{hc_off, hc_n, hc_ab, hc_w, hc_cap / 2, 0});
         if (threadIdx.x == 0) spec_sh.done = 1;
     } else {
         double *b_cost = (double *)(heap_glob + 24 * n);
