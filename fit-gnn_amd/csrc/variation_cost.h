@@ -108,9 +108,20 @@ __device__ inline double set_cost_wave(const CostGraph &g, const int32_t *__rest
             if (small) { pre_e0 = g.rowptr[u]; pre_deg = g.rowptr[u + 1] - pre_e0; pre_dw = g.dw[u]; }
         }
         FITGNN_WAVE_SYNC();
-        for (int i = lane; i < rows * K; i += 64) {
-            const int a = i / K, k = i - a * K;
-            lds.B[i] = g.A[(int64_t)lds.S[a] * g.lda + k];
+        {   // the tile's rows of A: every load requested before the first is stored (one memory round trip, not one per 64 entries)
+            constexpr int kIters = kCostTile * FITGNN_MAX_K / 64;
+            double av[kIters];
+#pragma unroll
+            for (int q = 0; q < kIters; ++q) {
+                const int i = lane + 64 * q;
+                av[q] = 0.0;
+                if (i < rows * K) { const int a = i / K, k = i - a * K; av[q] = g.A[(int64_t)lds.S[a] * g.lda + k]; }
+            }
+#pragma unroll
+            for (int q = 0; q < kIters; ++q) {
+                const int i = lane + 64 * q;
+                if (i < rows * K) lds.B[i] = av[q];
+            }
         }
         FITGNN_WAVE_SYNC();
         if (lane < K) {
@@ -153,11 +164,23 @@ __device__ inline double set_cost_wave(const CostGraph &g, const int32_t *__rest
             lds.cnt[lane] = 0;
             FITGNN_WAVE_SYNC();
             int nh = 0;
-            for (int base = 0; base < io->n; base += 64) {
+            constexpr int kChunks = kHitCap / 64;
+            uint32_t ab_q[kChunks];
+            double w_q[kChunks];
+#pragma unroll
+            for (int q = 0; q < kChunks; ++q) {   // the whole list requested at once
+                const int i = q * 64 + lane;
+                ab_q[q] = i < io->n ? io->pool_ab[io->off + i] : 0u;
+                w_q[q] = (i < io->n && g.w) ? io->pool_w[io->off + i] : 1.0;
+            }
+#pragma unroll
+            for (int q = 0; q < kChunks; ++q) {
+                const int base = q * 64;
+                if (base >= io->n) break;   // wave-uniform
                 const int i = base + lane;
                 const bool valid = i < io->n;
-                const uint32_t ab = valid ? io->pool_ab[io->off + i] : 0u;
-                const double wv = (valid && g.w) ? io->pool_w[io->off + i] : 1.0;
+                const uint32_t ab = ab_q[q];
+                const double wv = w_q[q];
                 int a = (int)(ab >> 8), b = (int)(ab & 255u);
                 if (io->use_remap) { a = lds.remap[a]; b = lds.remap[b]; }
                 const bool hit = valid && a != 255 && b != 255;
