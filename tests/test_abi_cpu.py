@@ -107,3 +107,35 @@ def test_fused_gemm_epilogue_entry_points():
     assert L.fitgnn_gemm_nt_presplit_bytes(512, 48) == 0                  # K % 32 != 0: not supported
     assert L.fitgnn_gemm_nt_presplit_f32(None, 1, 1, 8, 64, 64, None, None) == -1
     assert L.fitgnn_gemm_nt_presplit_f32(None, 1, 1, 8, 64, 65, None, None) == -1   # K_valid > K
+
+
+def test_round3_entry_points_check_their_arguments_without_a_gpu():
+    """fitgnn_gemm_exact_f32, the row- / segment-streaming SpMMs and the Lanczos step: argument errors are reported before any GPU
+    work, size queries are host-only."""
+    L = _lib.lib()
+    # exact fp32 GEMM: k split only where it shortens the launch, in multiples of 8 chunks
+    assert L.fitgnn_gemm_exact_workspace_bytes(165000, 512, 512, 0, 0) == 0                        # 1 290 tiles: no split
+    assert L.fitgnn_gemm_exact_workspace_bytes(512, 512, 165000, 1, 1) == 64 * 512 * 512 * 4       # 4 tiles: 64 chunks
+    wb = L.fitgnn_gemm_exact_workspace_bytes(34493, 512, 8448, 0, 0)                               # 270 tiles of a long k: split
+    assert wb > 0 and (wb // (34493 * 512 * 4)) % 8 == 0
+    assert L.fitgnn_gemm_exact_workspace_bytes(0, 8, 8, 0, 0) == 0
+    assert L.fitgnn_gemm_exact_f32(None, 8, 0, None, 8, 0, 8, 8, 8, None, 8, None, None) == -1      # NULL operands
+    assert L.fitgnn_gemm_exact_f32(None, 8, 1, None, 8, 0, 8, 8, 8, None, 8, None, None) == -1      # (k-major, k-minor): not a form
+    assert L.fitgnn_gemm_exact_f32(None, 8, 0, None, 8, 0, 0, 8, 8, None, 8, None, None) == -1      # I = 0
+    # compact-operand row streaming
+    assert L.fitgnn_spmm_rows_compact_parts(1) == 1 and L.fitgnn_spmm_rows_compact_parts(64 * 8192 + 1) <= 8192
+    assert L.fitgnn_spmm_rows_compact_dz_f32(None, None, None, 0, None, 512, 0, None, 512, 4, 512, None, 0, 0.0, 0, None, None, None) == -1
+    assert L.fitgnn_spmm_rows_compact_f32(None, None, None, 0, None, 512, -1, None, 512, 4, 512, None) == -1   # zero_from < 0
+    # segment streaming: xrow and xcol come together
+    assert L.fitgnn_spmm_csr_stream_f32(None, None, None, 0, None, 512, None, 512, 0, 512, None, 0, None, 0, None, None, None, 0, 0.0, 0,
+                                        None, None) == 0                                            # nothing to do
+    assert L.fitgnn_spmm_csr_stream_f32(None, None, None, 5, None, 512, None, 512, 4, 512, None, 1, None, 1, None, None, None, 0, 0.0, 0,
+                                        None, None) == -1                                           # NULL arrays
+    assert L.fitgnn_spmm_csr_stream_dz_f32(None, None, None, 5, None, 512, None, 512, 4, 510, None, 1, None, 1, None, None, None, 0, 0.0, 0,
+                                           None, None, None) == -1
+    # Lanczos step
+    assert L.fitgnn_lanczos_parts(0) == 0 and L.fitgnn_lanczos_parts(165000) == (165000 + 511) // 512
+    assert L.fitgnn_lanczos_spmv_f64(None, None, None, None, None, 0, -1.0, 2.0, None) == 0
+    assert L.fitgnn_lanczos_spmv_f64(None, None, None, None, None, 5, -1.0, 2.0, None) == -1
+    assert L.fitgnn_lanczos_project_f64(None, 10, 200, None, 10, None, None, None, None) == -1      # more than 128 basis vectors
+    assert L.fitgnn_lanczos_finish_f64(None, 4, 0, None, 10, None, None, None, None, 1, None) == -1  # ldv < n
