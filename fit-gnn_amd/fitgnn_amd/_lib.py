@@ -34,8 +34,10 @@ SIGNATURES = {
                                                      ptr, ptr, c_i32, ptr, c_u32, c_f32, c_u64, ptr, ptr, ptr]),
     "fitgnn_lanczos_parts": (c_i32, [c_i32]),
     "fitgnn_lanczos_spmv_f64": (ctypes.c_int, [ptr, ptr, ptr, ptr, ptr, c_i32, ctypes.c_double, ctypes.c_double, ptr]),
-    "fitgnn_lanczos_project_f64": (ctypes.c_int, [ptr, c_i64, c_i32, ptr, c_i32, ptr, ptr, ptr, ptr]),
+    "fitgnn_lanczos_project_f64": (ctypes.c_int, [ptr, c_i64, c_i32, ptr, c_i32, ptr, ptr, ptr]),
+    "fitgnn_lanczos_reduce_f64": (ctypes.c_int, [ptr, c_i32, c_i32, ptr, ptr]),
     "fitgnn_lanczos_finish_f64": (ctypes.c_int, [ptr, c_i64, c_i32, ptr, c_i32, ptr, ptr, ptr, ptr, c_i32, ptr]),
+    "fitgnn_lanczos_rotate_f64": (ctypes.c_int, [ptr, c_i64, c_i32, ptr, c_i32, ptr, c_i64, c_i32, ptr]),
     "fitgnn_spmm_csr_stream_f32": (ctypes.c_int, [ptr, ptr, ptr, c_i64, ptr, c_i64, ptr, c_i64, c_i32, c_i32, ptr, c_i32, ptr, c_i32, ptr, ptr,
                                                   ptr, c_u32, c_f32, c_u64, ptr, ptr]),
     "fitgnn_spmm_csr_stream_dz_f32": (ctypes.c_int, [ptr, ptr, ptr, c_i64, ptr, c_i64, ptr, c_i64, c_i32, c_i32, ptr, c_i32, ptr, c_i32, ptr, ptr,

@@ -131,43 +131,58 @@ def lanczos_smallest(L, K, device="cuda", tol=1e-5, m=None, max_restarts=300, se
     st = _lib.stream_ptr(dev)
     gen = torch.Generator(device="cpu").manual_seed(seed)
     V = torch.zeros(m + 1, N, dtype=torch.float64, device=dev)        # basis vector c = V[c] (contiguous)
+    V2 = torch.zeros_like(V)                                           # the rotated basis of a restart
     v = torch.randn(N, generator=gen, dtype=torch.float64).to(dev)
     V[0] = v / v.norm()
     H = torch.zeros(m + 1, m, dtype=torch.float64, device=dev)
     w = torch.empty(N, dtype=torch.float64, device=dev)
     parts = int(Lh.fitgnn_lanczos_parts(N))
-    pa, pb, pc = (torch.empty(parts * (m + 1), dtype=torch.float64, device=dev) for _ in range(3))
-    nrm = torch.empty(parts, dtype=torch.float64, device=dev)
+    part = torch.empty(parts * (m + 2), dtype=torch.float64, device=dev)
+    ha, hb, hc = (torch.empty(m + 2, dtype=torch.float64, device=dev) for _ in range(3))
+
+    def project(ncol, h_in, h_out):
+        _lib.check(Lh.fitgnn_lanczos_project_f64(_lib.dptr(V), N, ncol, _lib.dptr(w), N, _lib.dptr(h_in), _lib.dptr(part), st), "lanczos_project")
+        _lib.check(Lh.fitgnn_lanczos_reduce_f64(_lib.dptr(part), parts, ncol + 1, _lib.dptr(h_out), st), "lanczos_reduce")
+
+    def rotate(src, Smat, dst):
+        """dst[c] = sum_j Smat[j, c] src[j] (Smat: host array [m, nk], nk <= 16)."""
+        Sd = torch.from_numpy(np.ascontiguousarray(Smat, dtype=np.float64)).to(dev)
+        _lib.check(Lh.fitgnn_lanczos_rotate_f64(_lib.dptr(src), N, int(Smat.shape[0]), _lib.dptr(Sd), int(Smat.shape[1]), _lib.dptr(dst), N, N, st),
+                   "lanczos_rotate")
+
     j0 = 0
     for _ in range(max_restarts):
         for j in range(j0, m):
             _lib.check(Lh.fitgnn_lanczos_spmv_f64(_lib.dptr(rowptr), _lib.dptr(col), _lib.dptr(val), _lib.dptr(V[j]), _lib.dptr(w), N, -1.0, offset,
                                                   st), "fitgnn_lanczos_spmv_f64")
             # h = V^T w;  w -= V h, h2 = V^T w;  w -= V h2, |w|^2;  v_{j+1} = w / |w|, H[:, j] = h + h2
-            _lib.check(Lh.fitgnn_lanczos_project_f64(_lib.dptr(V), N, j + 1, _lib.dptr(w), N, None, _lib.dptr(pa), None, st), "lanczos_project")
-            _lib.check(Lh.fitgnn_lanczos_project_f64(_lib.dptr(V), N, j + 1, _lib.dptr(w), N, _lib.dptr(pa), _lib.dptr(pb), None, st), "lanczos_project")
-            _lib.check(Lh.fitgnn_lanczos_project_f64(_lib.dptr(V), N, j + 1, _lib.dptr(w), N, _lib.dptr(pb), _lib.dptr(pc), _lib.dptr(nrm), st),
-                       "lanczos_project")
-            _lib.check(Lh.fitgnn_lanczos_finish_f64(_lib.dptr(V), N, j, _lib.dptr(w), N, _lib.dptr(nrm), _lib.dptr(pa), _lib.dptr(pb), _lib.dptr(H), m,
+            project(j + 1, None, ha)
+            project(j + 1, ha, hb)
+            project(j + 1, hb, hc)
+            _lib.check(Lh.fitgnn_lanczos_finish_f64(_lib.dptr(V), N, j, _lib.dptr(w), N, _lib.dptr(ha), _lib.dptr(hb), _lib.dptr(hc), _lib.dptr(H), m,
                                                     st), "fitgnn_lanczos_finish_f64")
-        Hm = (H[:m, :m] + H[:m, :m].T) / 2
-        theta, S = torch.linalg.eigh(Hm)
-        order = torch.argsort(theta, descending=True)
+        # the projected m x m eigenproblem on the host (60 x 60: LAPACK takes less than the launch of a device solver)
+        Hh = H.cpu().numpy()
+        Hm = (Hh[:m, :m] + Hh[:m, :m].T) / 2
+        theta, S = np.linalg.eigh(Hm)
+        order = np.argsort(-theta, kind="stable")
         idx = order[:K]
-        resid = (H[m, m - 1] * S[m - 1, idx]).abs()
-        if float(resid.max()) <= tol * float(theta.abs().max()):
+        resid = np.abs(Hh[m, m - 1] * S[m - 1, idx])
+        if float(resid.max()) <= tol * float(np.abs(theta).max()):
             break
-        keep = order[:min(K + 5, m - 2)]
-        nk = int(keep.numel())
-        Vn = torch.zeros_like(V)
-        Vn[:nk] = S[:, keep].T.contiguous() @ V[:m]
-        Vn[nk] = V[m]
-        Hn = torch.zeros_like(H)
-        Hn[:nk, :nk] = torch.diag(theta[keep])
-        Hn[nk, :nk] = H[m, m - 1] * S[m - 1, keep]
-        V, H, j0 = Vn, Hn, nk
-    lk = (offset - theta[idx]).cpu().numpy()
-    Uk = (S[:, idx].T.contiguous() @ V[:m]).T.contiguous().cpu().numpy()
+        keep = order[:min(K + 5, m - 2, 16)]
+        nk = int(keep.size)
+        rotate(V, S[:, keep], V2)                 # V2[:nk] = the kept Ritz vectors
+        V2[nk].copy_(V[m])
+        Hn = np.zeros_like(Hh)
+        Hn[:nk, :nk] = np.diag(theta[keep])
+        Hn[nk, :nk] = Hh[m, m - 1] * S[m - 1, keep]
+        V, V2 = V2, V
+        H.copy_(torch.from_numpy(Hn))
+        j0 = nk
+    lk = offset - theta[idx]
+    rotate(V, S[:, idx], V2)
+    Uk = V2[:K].T.contiguous().cpu().numpy()
     o = np.argsort(lk)
     return lk[o], np.ascontiguousarray(Uk[:, o])
 

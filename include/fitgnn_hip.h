@@ -118,20 +118,24 @@ int fitgnn_spmm_csr_blocks_dz_f32(const int32_t *rowptr, const int32_t *col, con
  * V [m + 1][ldv] (basis vector c = V + c * ldv, ldv >= n):
  *   fitgnn_lanczos_spmv_f64     y = alpha (A x) + beta x for a CSR matrix (int32 indices, f64 values): with A = L, alpha = -1,
  *                               beta = 2 max(dw) the reference's shifted operator, never built;
- *   fitgnn_lanczos_project_f64  h = the fixed-order sum of the previous pass's partial rows part_in [parts x ncol] (part_in NULL: no
- *                               subtraction);  w -= sum_{c < ncol} V[c] h[c];  part_out[b][c] = this workgroup's share of V[c] . w,
- *                               norm_out[b] (may be NULL) its share of w . w;  parts = fitgnn_lanczos_parts(n);  ncol <= 128;
- *   fitgnn_lanczos_finish_f64   beta = sqrt(sum norm_part);  V[j + 1] = w / max(beta, 1e-300);  H[c][j] = sum part_a[.][c] +
- *                               sum part_b[.][c] for c <= j (the coefficients of the two orthogonalisation passes),
- *                               H[j + 1][j] = beta;  H row-major with row stride ldh.
+ *   fitgnn_lanczos_project_f64  w -= sum_{c < ncol} V[c] h_in[c] (h_in NULL: no subtraction);  part_out[b][c] = workgroup b's share of
+ *                               V[c] . w for c < ncol and, in column ncol, of w . w (row stride ncol + 1);
+ *                               fitgnn_lanczos_parts(n) workgroups;  ncol <= 128;
+ *   fitgnn_lanczos_reduce_f64   out[c] = sum over the n_part partial rows of part[.][c], c < ncol1 (= ncol + 1), in a fixed order;
+ *   fitgnn_lanczos_finish_f64   beta = sqrt(hc[j + 1]);  V[j + 1] = w / max(beta, 1e-300);  H[c][j] = ha[c] + hb[c] for c <= j (the
+ *                               coefficients of the two orthogonalisation passes), H[j + 1][j] = beta;  H row-major, row stride ldh;
+ *   fitgnn_lanczos_rotate_f64   out[c] = sum_{j < m} S[j * nk + c] V[j], c < nk <= 16 (a restart's Ritz vectors), out row stride ldo.
  * No atomics: every sum runs in a fixed order, the iteration is reproducible. */
 int32_t fitgnn_lanczos_parts(int32_t n);
 int fitgnn_lanczos_spmv_f64(const int32_t *rowptr, const int32_t *col, const double *val, const double *x, double *y, int32_t n,
                             double alpha, double beta, void *stream);
-int fitgnn_lanczos_project_f64(const double *V, int64_t ldv, int32_t ncol, double *w, int32_t n, const double *part_in, double *part_out,
-                               double *norm_out, void *stream);
-int fitgnn_lanczos_finish_f64(double *V, int64_t ldv, int32_t j, const double *w, int32_t n, const double *norm_part, const double *part_a,
-                              const double *part_b, double *H, int32_t ldh, void *stream);
+int fitgnn_lanczos_project_f64(const double *V, int64_t ldv, int32_t ncol, double *w, int32_t n, const double *h_in, double *part_out,
+                               void *stream);
+int fitgnn_lanczos_reduce_f64(const double *part, int32_t n_part, int32_t ncol1, double *out, void *stream);
+int fitgnn_lanczos_finish_f64(double *V, int64_t ldv, int32_t j, const double *w, int32_t n, const double *ha, const double *hb,
+                              const double *hc, double *H, int32_t ldh, void *stream);
+int fitgnn_lanczos_rotate_f64(const double *V, int64_t ldv, int32_t m, const double *S, int32_t nk, double *out, int64_t ldo, int32_t n,
+                              void *stream);
 
 /* The same products by the segment-streaming kernel (csrc/spmm.hip: spmm_stream_kernel): the whole-subgraph kernel's algorithm
  * with one WAVE per run of segments and no LDS.  seg_ptr [n_seg + 1] (ascending, seg_ptr[0] = 0, seg_ptr[n_seg] = n_rows) cuts the

@@ -137,5 +137,7 @@ def test_round3_entry_points_check_their_arguments_without_a_gpu():
     assert L.fitgnn_lanczos_parts(0) == 0 and L.fitgnn_lanczos_parts(165000) == (165000 + 511) // 512
     assert L.fitgnn_lanczos_spmv_f64(None, None, None, None, None, 0, -1.0, 2.0, None) == 0
     assert L.fitgnn_lanczos_spmv_f64(None, None, None, None, None, 5, -1.0, 2.0, None) == -1
-    assert L.fitgnn_lanczos_project_f64(None, 10, 200, None, 10, None, None, None, None) == -1      # more than 128 basis vectors
+    assert L.fitgnn_lanczos_project_f64(None, 10, 200, None, 10, None, None, None) == -1            # more than 128 basis vectors
+    assert L.fitgnn_lanczos_reduce_f64(None, 4, 200, None, None) == -1
+    assert L.fitgnn_lanczos_rotate_f64(None, 10, 60, None, 17, None, 10, 10, None) == -1            # more than 16 rotated columns
     assert L.fitgnn_lanczos_finish_f64(None, 4, 0, None, 10, None, None, None, None, 1, None) == -1  # ldv < n
