@@ -353,10 +353,17 @@ struct SpecShared {
     volatile double cost[kSpecWaves][kSpecRing];
     volatile int32_t hoff[kSpecWaves][kSpecRing];   // the helper's stored match list of the pruned set (pool offset, length; -1: none)
     volatile int32_t hn[kSpecWaves][kSpecRing];
+    // the re-insertion queue's held-out minimum, published by the selecting wave for the last helper to prune and cost ahead of
+    // its pop (job_seq written last), and that helper's answer (res_seq written last)
+    volatile int32_t job_seq, job_cand, job_off, job_len;
+    volatile int32_t res_seq, res_cnt, res_hoff, res_hn;
+    volatile double res_cost;
 };
 struct SpecNone {
     __device__ __forceinline__ void publish_head(int) const {}
     __device__ __forceinline__ bool lookup(int, int, double &, int32_t &, int32_t &) const { return false; }
+    __device__ __forceinline__ void publish_top(int, int32_t, int32_t, int32_t) const {}
+    __device__ __forceinline__ bool lookup_top(int, int, double &, int32_t &, int32_t &) const { return false; }
 };
 struct SpecRing {
     lds_ptr<SpecShared> sh;
@@ -371,6 +378,21 @@ struct SpecRing {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   // the helper's pool entries (same CU) before any later read of them
         return true;
     }
+    // the queue's new held-out minimum: its members and stored list are final until it is popped (only the set being processed
+    // is ever changed), so a helper may prune and cost it now
+    __device__ __forceinline__ void publish_top(int seq, int32_t cand, int32_t off, int32_t len) const {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // this wave's writes to the set's members / list table first
+        if ((threadIdx.x & 63) == 0) { sh->job_cand = cand; sh->job_off = off; sh->job_len = len; sh->job_seq = seq; }
+    }
+    __device__ __forceinline__ bool lookup_top(int seq, int m, double &c, int32_t &hoff, int32_t &hn) const {
+        if (sh->res_seq != seq) return false;
+        if (sh->res_cnt != m) return false;
+        c = sh->res_cost;
+        hoff = sh->res_hoff;
+        hn = sh->res_hn;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        return true;
+    }
 };
 
 // Helper wave `w` (0-based) of the single-graph kernel; see above.  Reads mem / len of list entries that have not been popped
@@ -379,13 +401,53 @@ template <class Marks>
 __device__ inline void greedy_speculate(const CostGraph &g, CostLds &lds, lds_ptr<SpecShared> sh, int w, int32_t n_list,
                                         const int32_t *__restrict__ set_off, const int32_t *mem, const int32_t *len,
                                         Marks marks, const int32_t *__restrict__ order, uint16_t *pool_ab, double *pool_w,
-                                        int64_t pool_begin, int64_t pool_end) {
+                                        int64_t pool_begin, int64_t pool_end, const int32_t *hc_off, const int32_t *hc_n) {
     const int lane = threadIdx.x & 63;
     int64_t bump = pool_begin;   // this helper's own region of the match-list pool
+    int last_job = 0;
+    // The last helper also serves the queue: whenever the selecting wave publishes a new held-out minimum it prunes that set
+    // against the marks of the moment and costs it from the set's stored match list -- the selecting wave is busy with the pop
+    // before, and when it gets to this set its own prune keeps the same members unless that pop marked one of them (equal counts
+    // = equal sets, as for the list entries).  The filtered list goes to a fresh region of this helper's pool.
+    auto serve_queue = [&]() {
+        if (w != kSpecWaves - 1 || !hc_off) return;
+        const int js = sh->job_seq;
+        if (js == last_job) return;
+        last_job = js;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        const int32_t cand = sh->job_cand;
+        const int off = sh->job_off, nc = sh->job_len;
+        if (sh->job_seq != js) return;            // overwritten while being read: the next poll takes the newer job
+        if (nc > fitgnn::kCostTile || nc < 3) return;
+        const int32_t v = lane < nc ? mem[off + lane] : -1;
+        const bool keep = v >= 0 && !marks.get(v);
+        const unsigned long long bal = __ballot(keep);
+        const int m = __popcll(bal);
+        if (m == nc || m < 2) return;             // nothing marked (no re-cost will be needed) / the set will be dropped
+        const int before = __popcll(bal & ((1ull << lane) - 1ull));
+        if (keep) lds.S[before] = v;
+        if (lane < nc) lds.remap[lane] = keep ? (uint8_t)before : (uint8_t)255;
+        FITGNN_WAVE_SYNC();
+        const int32_t s_off = __builtin_amdgcn_readfirstlane(hc_off[cand]), s_n = __builtin_amdgcn_readfirstlane(hc_n[cand]);
+        fitgnn::HitIO io{true, pool_ab, pool_w, bump, pool_end, (int64_t)s_off, s_n, true, true};
+        const double cost = fitgnn::set_cost_wave<true>(g, nullptr, m, lds, io);
+        bump = io.bump;
+        FITGNN_WAVE_SYNC();
+        if (sh->job_seq != js) return;            // the minimum changed meanwhile: nobody will ask for this answer
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) {
+            sh->res_cost = cost;
+            sh->res_cnt = m;
+            sh->res_hoff = (int32_t)io.off;
+            sh->res_hn = io.n;
+            sh->res_seq = js;
+        }
+    };
     for (int p = w; p < n_list; p += kSpecWaves) {
         int h;
         for (;;) {  // wait until the list head is near (or the selection is over)
             if (sh->done) return;
+            serve_queue();
             h = sh->head;
             if (p < h + kSpecAhead) break;
             __builtin_amdgcn_s_sleep(8);
@@ -404,8 +466,9 @@ __device__ inline void greedy_speculate(const CostGraph &g, CostLds &lds, lds_pt
         FITGNN_WAVE_SYNC();
         // the pruned set's match list goes to the pool with its cost: if the selecting wave takes the cost (equal sets), the set's
         // next re-cost filters that list instead of scanning adjacency lists again
-        fitgnn::HitIO io{pool_ab, pool_w, &bump, pool_end, -1, -1, false};
-        const double cost = fitgnn::set_cost_wave<true>(g, nullptr, m, lds, pool_ab ? &io : nullptr);
+        fitgnn::HitIO io{pool_ab != nullptr, pool_ab, pool_w, bump, pool_end, -1, -1, false, false};
+        const double cost = fitgnn::set_cost_wave<true>(g, nullptr, m, lds, io);
+        bump = io.bump;
         FITGNN_WAVE_SYNC();
         // publish only if the entry is still unpopped: then every read above preceded the selecting wave's changes to it
         if (sh->head > p) continue;
@@ -419,14 +482,18 @@ __device__ inline void greedy_speculate(const CostGraph &g, CostLds &lds, lds_pt
             sh->tag[w][e] = p;
         }
     }
+    while (!sh->done) {   // the list is exhausted: the queue still pops
+        serve_queue();
+        __builtin_amdgcn_s_sleep(8);
+    }
 }
 
 // ---- the match lists of re-inserted sets, kept between their re-costs (variation_cost.h: HitIO) ----
 // Only the selecting wave reads or writes them.  hc_off / hc_n [N]: pool offset (-1: no list) and current length (-1: not valid) of
 // the list of the set that grew out of candidate `cand`.
 struct HitCacheNone {
-    __device__ __forceinline__ fitgnn::HitIO *begin(fitgnn::HitIO &, int32_t, bool) { return nullptr; }
-    __device__ __forceinline__ void end(fitgnn::HitIO *, int32_t) {}
+    __device__ __forceinline__ void begin(fitgnn::HitIO &io, int32_t, bool) { io.active = false; }
+    __device__ __forceinline__ void end(const fitgnn::HitIO &, int32_t) {}
     __device__ __forceinline__ void adopt(int32_t, int32_t, int32_t) {}
 };
 struct HitCacheGlobal {
@@ -435,17 +502,19 @@ struct HitCacheGlobal {
     double *pool_w;
     int64_t pool_cap;
     int64_t bump;
-    __device__ __forceinline__ fitgnn::HitIO *begin(fitgnn::HitIO &io, int32_t cand, bool remap_ok) {
+    __device__ __forceinline__ void begin(fitgnn::HitIO &io, int32_t cand, bool remap_ok) {
         const int32_t off = __builtin_amdgcn_readfirstlane(hc_off[cand]);
         const int32_t n = __builtin_amdgcn_readfirstlane(hc_n[cand]);
-        io.pool_ab = pool_ab; io.pool_w = pool_w; io.bump = &bump; io.pool_cap = pool_cap;
+        io.active = true;
+        io.pool_ab = pool_ab; io.pool_w = pool_w; io.bump = bump; io.pool_cap = pool_cap;
         io.off = off;
         io.n = remap_ok ? n : -1;   // the translation table covers sets of at most 64 members
         io.use_remap = true;
-        return &io;
+        io.fresh_out = false;
     }
-    __device__ __forceinline__ void end(fitgnn::HitIO *io, int32_t cand) {
-        if ((threadIdx.x & 63) == 0) { hc_off[cand] = (int32_t)io->off; hc_n[cand] = io->n; }
+    __device__ __forceinline__ void end(const fitgnn::HitIO &io, int32_t cand) {
+        bump = io.bump;
+        if ((threadIdx.x & 63) == 0) { hc_off[cand] = (int32_t)io.off; hc_n[cand] = io.n; }
     }
     // a helper wave costed this very set and stored its list (SpecRing::lookup)
     __device__ __forceinline__ void adopt(int32_t cand, int32_t off, int32_t n) {
@@ -481,6 +550,7 @@ __device__ inline void greedy_component(const CostGraph &g, CostLds &lds, Heap h
     bool has_top = false;
     HeapItem top{};
     int32_t tm = -1;
+    int top_job = 0, cur_job = 0;   // the held-out minimum's number with the helper that costs it ahead of its pop (Spec)
     // list pipeline (len[] of an unprocessed list entry is its initial length and its members are untouched: only the
     // candidate being processed is ever shrunk)
     int32_t c0 = 0, o0 = 0, l0 = 0, m0 = -1;  // entry head: candidate, extent, first 64 members (m0 per lane)
@@ -524,10 +594,12 @@ __device__ inline void greedy_component(const CostGraph &g, CostLds &lds, Heap h
         } else {
             cand = top.cand; off = top.off; nc = top.len;
             mm = tm;
+            cur_job = top_job;
             has_top = heap.size() > 0;
             if (has_top) {
                 top = heap.extract_min();
                 tm = lane < top.len ? mem[top.off + lane] : -1;
+                spec.publish_top(++top_job, top.cand, top.off, top.len);
             }
         }
         int32_t *S = mem + off;
@@ -584,19 +656,20 @@ __device__ inline void greedy_component(const CostGraph &g, CostLds &lds, Heap h
                 if (m <= fitgnn::kCostTile) {
                     FITGNN_WAVE_SYNC();
                     int32_t h_off = -1, h_n = -1;
-                    if (from_list && spec.lookup(head - 1 - head0, m, c, h_off, h_n)) {
+                    if (from_list ? spec.lookup(head - 1 - head0, m, c, h_off, h_n)
+                                  : (nc <= fitgnn::kCostTile && spec.lookup_top(cur_job, m, c, h_off, h_n))) {
                         cache.adopt(cand, h_off, h_n);
 #ifdef FITGNN_GREEDY_STAMPS
-                        gdbg[15] += 1;
+                        gdbg[from_list ? 15 : 6] += 1;   // slot 6's time is not kept any more: answered queue re-costs
 #endif
                     } else {
-                        fitgnn::HitIO io;
-                        fitgnn::HitIO *iop = cache.begin(io, cand, nc <= fitgnn::kCostTile);
+                        fitgnn::HitIO io{};
+                        cache.begin(io, cand, nc <= fitgnn::kCostTile);
 #ifdef FITGNN_GREEDY_STAMPS
-                        if (iop && iop->off >= 0 && iop->n >= 0) gdbg[7] += 1;   // re-costs answered from the set's stored match list
+                        if (io.active && io.off >= 0 && io.n >= 0) gdbg[7] += 1;   // re-costs answered from the set's stored match list
 #endif
-                        c = fitgnn::set_cost_wave<true>(g, S, m, lds, iop);
-                        if (iop) cache.end(iop, cand);
+                        c = fitgnn::set_cost_wave<true>(g, S, m, lds, io);
+                        cache.end(io, cand);
                     }
                     xm = lane < m ? lds.S[lane] : -1;
                 } else {
@@ -610,14 +683,14 @@ __device__ inline void greedy_component(const CostGraph &g, CostLds &lds, Heap h
                 ++seq;
                 if (!has_top) {
                     top = x; tm = xm; has_top = true;
+                    spec.publish_top(++top_job, cand, off, m);
                 } else if (item_less(x, top)) {
                     heap.push(top);
                     top = x; tm = xm;
+                    spec.publish_top(++top_job, cand, off, m);
                 } else {
                     heap.push(x);
                 }
-                GSTAMP(g6);
-                GACC(6, g5, g6);
 #ifdef FITGNN_GREEDY_STAMPS
                 if ((unsigned long long)heap.size() > gdbg[13]) gdbg[13] = heap.size();
                 if (from_list) gdbg[14] += 1;
@@ -653,13 +726,13 @@ __global__ __launch_bounds__(64 * (1 + kSpecWaves)) void greedy_select_kernel(
     if (state_in_lds) {
         for (int i = threadIdx.x; i < (int)words; i += blockDim.x) mark_bits[i] = 0u;
         for (int i = threadIdx.x; i < kSpecWaves * kSpecRing; i += blockDim.x) spec_sh.tag[i / kSpecRing][i % kSpecRing] = -1;
-        if (threadIdx.x == 0) { spec_sh.head = 0; spec_sh.done = 0; }
+        if (threadIdx.x == 0) { spec_sh.head = 0; spec_sh.done = 0; spec_sh.job_seq = 0; spec_sh.res_seq = 0; }
         __syncthreads();  // the only workgroup barrier: nothing below waits for another wave
         if (wave > 0) {
             // the match-list pool: first half the selecting wave's, the second half split between the helpers
             const int64_t half = hc_cap / 2, per = (hc_cap - half) / kSpecWaves;
             greedy_speculate(g, lds[wave], to_lds(&spec_sh), wave - 1, N, set_off, mem, len, MarksLds{to_lds(mark_bits)}, order, hc_ab, hc_w,
-                             half + (wave - 1) * per, half + wave * per);
+                             half + (wave - 1) * per, half + wave * per, hc_off, hc_n);
             return;
         }
     } else if (wave > 0) {
@@ -895,6 +968,15 @@ extern "C" int fitgnn_debug_greedy_counters(unsigned long long *out, int reset) 
     if (reset) {
         unsigned long long z[16] = {0};
         rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(g_greedy_dbg), z, sizeof(z));
+    }
+    return rc;
+}
+extern "C" int fitgnn_debug_cost_counters(unsigned long long *out, int reset) {
+    int rc = (int)hipDeviceSynchronize();
+    rc |= (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(fitgnn::g_cost_dbg), sizeof(unsigned long long) * 12);
+    if (reset) {
+        unsigned long long z[12] = {0};
+        rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(fitgnn::g_cost_dbg), z, sizeof(z));
     }
     return rc;
 }

@@ -1083,12 +1083,15 @@ class FusedGCNLastLayerRows(torch.autograd.Function):
         if drop:
             epi |= EPI_DROPOUT
         epilogue_fwd_rows_(outc, rows, b, epi, p=p if drop else 0.0, seed=seed, mask=mask if drop else None)
-        if compact_out and _exact(cfg, outc, Wl):
+        if _exact(cfg, outc, Wl):
             # the head on the kept rows as one more exact-fp32 product: [n, H] @ [C, H]^T on the fp32 MFMA (a 256 x 128 tile of which C
-            # columns are stored: 0.2 ms at S-products against 0.68 ms for head_rows_kernel's LDS-resident weights), bias added after
+            # columns are stored: 0.2 ms at S-products against 0.68 ms for head_rows_kernel's LDS-resident weights), bias added after;
+            # the [R, C] form is the same values scattered into zeros
             y = gemm_exact(outc, Wl, "nt", cfg)
             if bl is not None:
                 y = y + bl
+            if not compact_out:
+                y = torch.zeros((g.n, y.shape[1]), dtype=torch.float32, device=y.device).index_copy_(0, rows, y)
         elif compact_out:
             y = head_rows(outc, _arange_rows(g, rows.numel(), rows.device), Wl, bl, n_total=rows.numel())
         else:

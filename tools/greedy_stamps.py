@@ -17,19 +17,35 @@ G = coarsening.Graph(W)
 lk, Uk = coarsening.lanczos_smallest(G.L, 10, seed=0)
 A = coarsening._spectral_level1(G, 10, Uk.copy(), lk.copy())
 L = _lib.lib()
+if not hasattr(L, "fitgnn_debug_greedy_counters"):   # a library without the counters: the plain time only
+    coarsening.contract_level(G, A, r); torch.cuda.synchronize()
+    for _ in range(3):
+        t0 = time.time()
+        coarsening.contract_level(G, A, r); torch.cuda.synchronize()
+        print(f"{name}: contract_level {(time.time() - t0)*1e3:.1f} ms (no counters in this build)")
+    sys.exit(0)
 L.fitgnn_debug_greedy_counters.argtypes = [ctypes.c_void_p, ctypes.c_int]
 buf = (ctypes.c_ulonglong * 16)()
 coarsening.contract_level(G, A, r); torch.cuda.synchronize()
 L.fitgnn_debug_greedy_counters(buf, 1)
+L.fitgnn_debug_cost_counters.argtypes = [ctypes.c_void_p, ctypes.c_int]
+cb = (ctypes.c_ulonglong * 12)()
+L.fitgnn_debug_cost_counters(cb, 1)
 t0 = time.time()
 coarsening.contract_level(G, A, r); torch.cuda.synchronize()
 dt = time.time() - t0
 L.fitgnn_debug_greedy_counters(buf, 1)
 v = list(buf)
-tot = sum(v[0:7])
+tot = sum(v[0:6])
 print(f"{name}: contract_level {dt*1e3:.1f} ms; stamped cycles {tot}")
-names = ["pop from list", "pop from heap", "mark check", "select", "prune", "re-cost", "heap push"]
-cnts = [v[8], v[9], v[8] + v[9], v[10], v[11], v[12], v[12]]
-for n, cyc, c in zip(names, v[0:7], cnts):
+names = ["pop from list", "pop from heap", "mark check", "select", "prune", "re-cost + push"]
+cnts = [v[8], v[9], v[8] + v[9], v[10], v[11], v[12]]
+for n, cyc, c in zip(names, v[0:6], cnts):
     print(f"  {n:14s} {100.0*cyc/max(tot,1):5.1f} %  n={c:7d}  cycles/op={cyc/max(c,1):8.1f}")
-print(f"  max queue size {v[13]}, re-costs of list entries {v[14]} of {v[12]}, answered by a helper wave {v[15]}, from a stored match list {v[7]}")
+print(f"  max queue size {v[13]}, re-costs of list entries {v[14]} of {v[12]}, answered by a helper wave {v[15]}; queue re-costs answered by the helper {v[6]}; from a stored match list {v[7]}")
+L.fitgnn_debug_cost_counters(cb, 1)
+c = list(cb)
+ct = sum(c[0:9])
+print(f"  re-costs on the selecting wave: {ct} cycles; members {c[10]}, matches {c[11]}, stored matches read {c[9]}")
+for n, cyc in zip(["gather A rows", "column means", "centre", "stored list arrives", "filter stored list / scan adjacency", "export + fold rows (T, Y)", "M accumulate", "norm", "filter: first chunk"], c[0:9]):
+    print(f"    {n:28s} {100.0*cyc/max(ct,1):5.1f} %")
