@@ -81,13 +81,13 @@ __global__ __launch_bounds__(kCostWaves * 64) void variation_costs_kernel(CostGr
 // greedy selection: a single wavefront walks the candidates in (cost, insertion) order
 // ------------------------------------------------------------------------------------------------
 #ifdef FITGNN_GREEDY_STAMPS  // make EXTRA=-DFITGNN_GREEDY_STAMPS + tools/greedy_stamps.py: where the one wave's cycles go
-static __device__ unsigned long long g_greedy_dbg[16];
+static __device__ unsigned long long g_greedy_dbg[24];
 // accumulated in registers and flushed once: a global read-modify-write per stamp would drain the prefetches it measures
-#define GSTAMP_DECL unsigned long long gdbg[16] = {0}
+#define GSTAMP_DECL unsigned long long gdbg[24] = {0}
 #define GSTAMP(var) const unsigned long long var = __builtin_readcyclecounter()
 #define GACC(i, a, b) gdbg[i] += (b) - (a)
 #define GCNT(i) gdbg[i] += 1
-#define GSTAMP_FLUSH if ((threadIdx.x & 63) == 0) { for (int q = 0; q < 16; ++q) g_greedy_dbg[q] += gdbg[q]; }
+#define GSTAMP_FLUSH if ((threadIdx.x & 63) == 0) { for (int q = 0; q < 24; ++q) g_greedy_dbg[q] += gdbg[q]; }
 #else
 #define GSTAMP_DECL
 #define GSTAMP(var)
@@ -337,46 +337,60 @@ struct MarksLds {
 // 60 % of the selecting wave's time is the re-cost of sets it has just pruned, and 90 % of those are list entries meeting their
 // first marked member.  Which members a list entry will keep is almost always known a few pops early (marks only grow, and a
 // pop marks a handful of nodes out of thousands), so kSpecWaves helper waves of the same workgroup walk AHEAD of the list head:
-// entry p (p = helper id mod kSpecWaves) is pruned against the marks of that moment and, if something was dropped, costed with
-// the very routine the selecting wave would use; (p, kept count, cost) goes to the helper's ring in LDS.  The selecting wave
+// the next unclaimed entry p (a counter in LDS: whichever helper is free takes it) is pruned against the marks of that moment
+// and, if something was dropped, costed with the very routine the selecting wave would use; (p, kept count, cost) goes to a
+// ring in LDS.  The selecting wave
 // uses it only if the kept COUNT equals its own: the helper saw a subset of the marks, so it kept a superset of the members,
 // and equal counts mean equal sets -- the cost is then the one it would have computed, bit for bit.  A miss costs nothing
 // (it computes, as before); the selecting wave never waits for a helper, and helpers leave when it raises `done`.
 constexpr int kSpecWaves = 2;
-constexpr int kSpecRing = 64;    // ring entries per helper
+constexpr int kSpecRing = 64;    // ring entries (entry p in slot p mod kSpecRing; > kSpecAhead + kSpecWaves, so a slot is only reused once its entry is popped)
 constexpr int kSpecAhead = 24;   // helpers work on entries less than this far past the list head
 struct SpecShared {
     volatile int32_t head;                        // list entries below this index have been popped
     volatile int32_t done;
-    volatile int32_t tag[kSpecWaves][kSpecRing];  // list index the entry describes (written last)
-    volatile int32_t cnt[kSpecWaves][kSpecRing];
-    volatile double cost[kSpecWaves][kSpecRing];
-    volatile int32_t hoff[kSpecWaves][kSpecRing];   // the helper's stored match list of the pruned set (pool offset, length; -1: none)
-    volatile int32_t hn[kSpecWaves][kSpecRing];
+    volatile int32_t next;                        // first list entry no helper has claimed
+    volatile int32_t tag[kSpecRing];  // list index the entry describes (written last)
+    volatile int32_t cnt[kSpecRing];
+    volatile double cost[kSpecRing];
+    volatile int32_t hoff[kSpecRing];   // the helper's stored match list of the pruned set (pool offset, length; -1: none)
+    volatile int32_t hn[kSpecRing];
+    volatile unsigned long long keep[kSpecRing];   // which of the entry's members the helper kept (bit = position)
     // the re-insertion queue's held-out minimum, published by the selecting wave for the last helper to prune and cost ahead of
     // its pop (job_seq written last), and that helper's answer (res_seq written last)
     volatile int32_t job_seq, job_cand, job_off, job_len;
     volatile int32_t res_seq, res_cnt, res_hoff, res_hn;
     volatile double res_cost;
 };
+// what a helper has for a set the selecting wave has just pruned to m members
+enum SpecAnswer { kSpecNothing = 0, kSpecCost = 1, kSpecList = 2 };
 struct SpecNone {
     __device__ __forceinline__ void publish_head(int) const {}
-    __device__ __forceinline__ bool lookup(int, int, double &, int32_t &, int32_t &) const { return false; }
+    __device__ __forceinline__ int lookup(int, int, double &, int32_t &, int32_t &, unsigned long long &) const { return kSpecNothing; }
     __device__ __forceinline__ void publish_top(int, int32_t, int32_t, int32_t) const {}
-    __device__ __forceinline__ bool lookup_top(int, int, double &, int32_t &, int32_t &) const { return false; }
+    __device__ __forceinline__ int lookup_top(int, int, double &, int32_t &, int32_t &) const { return kSpecNothing; }
 };
 struct SpecRing {
     lds_ptr<SpecShared> sh;
     __device__ __forceinline__ void publish_head(int head) const { if ((threadIdx.x & 63) == 0) sh->head = head; }
-    __device__ __forceinline__ bool lookup(int lp, int m, double &c, int32_t &hoff, int32_t &hn) const {
-        const int w = lp % kSpecWaves, e = (lp / kSpecWaves) % kSpecRing;
-        if (sh->tag[w][e] != lp) return false;   // volatile: tag, then count and cost (the writer's order reversed)
-        if (sh->cnt[w][e] != m) return false;
-        c = sh->cost[w][e];
-        hoff = sh->hoff[w][e];
-        hn = sh->hn[w][e];
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   // the helper's pool entries (same CU) before any later read of them
-        return true;
+    // kSpecCost: the helper pruned the entry to the same m members (marks only grow: equal counts = equal sets) -- its cost and its
+    // stored match list are this set's.  kSpecList: it kept more (a member was marked after it looked): the cost is of no use, but
+    // its match list is that of a superset, which the caller filters (keep = the members it kept) instead of scanning adjacency lists.
+    __device__ __forceinline__ int lookup(int lp, int m, double &c, int32_t &hoff, int32_t &hn, unsigned long long &keep) const {
+        const int e = lp % kSpecRing;
+        if (sh->tag[e] != lp) return kSpecNothing;   // volatile: tag, then the rest (the writer's order reversed)
+        const int cnt = sh->cnt[e];
+        hoff = sh->hoff[e];
+        hn = sh->hn[e];
+        if (cnt == m) {
+            c = sh->cost[e];
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   // the helper's pool entries (same CU) before any later read of them
+            return kSpecCost;
+        }
+        if (cnt < m || hoff < 0 || hn < 0) return kSpecNothing;
+        keep = sh->keep[e];
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        return kSpecList;
     }
     // the queue's new held-out minimum: its members and stored list are final until it is popped (only the set being processed
     // is ever changed), so a helper may prune and cost it now
@@ -384,14 +398,15 @@ struct SpecRing {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // this wave's writes to the set's members / list table first
         if ((threadIdx.x & 63) == 0) { sh->job_cand = cand; sh->job_off = off; sh->job_len = len; sh->job_seq = seq; }
     }
-    __device__ __forceinline__ bool lookup_top(int seq, int m, double &c, int32_t &hoff, int32_t &hn) const {
-        if (sh->res_seq != seq) return false;
-        if (sh->res_cnt != m) return false;
+    // (a queue set has its own stored list: a helper's list of a superset of it is of no use)
+    __device__ __forceinline__ int lookup_top(int seq, int m, double &c, int32_t &hoff, int32_t &hn) const {
+        if (sh->res_seq != seq) return kSpecNothing;
+        if (sh->res_cnt != m) return kSpecNothing;
         c = sh->res_cost;
         hoff = sh->res_hoff;
         hn = sh->res_hn;
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        return true;
+        return kSpecCost;
     }
 };
 
@@ -443,16 +458,17 @@ __device__ inline void greedy_speculate(const CostGraph &g, CostLds &lds, lds_pt
             sh->res_seq = js;
         }
     };
-    for (int p = w; p < n_list; p += kSpecWaves) {
-        int h;
-        for (;;) {  // wait until the list head is near (or the selection is over)
-            if (sh->done) return;
-            serve_queue();
-            h = sh->head;
-            if (p < h + kSpecAhead) break;
-            __builtin_amdgcn_s_sleep(8);
-        }
-        if (p <= h) continue;  // popped already, or being popped
+    for (;;) {
+        if (sh->done) return;
+        serve_queue();
+        // claim the next list entry once it is inside the window (when the list is used up the queue still pops: keep serving it)
+        const int h = sh->head;
+        if (sh->next >= n_list || sh->next >= h + kSpecAhead) { __builtin_amdgcn_s_sleep(8); continue; }
+        int p = 0;
+        if (lane == 0) p = atomicAdd((int *)&sh->next, 1);
+        p = __builtin_amdgcn_readfirstlane(p);
+        if (p >= n_list) continue;
+        if (p <= sh->head) continue;  // popped already, or being popped
         const int32_t c = order[p];
         const int off = __builtin_amdgcn_readfirstlane(set_off[c]);
         const int nc = __builtin_amdgcn_readfirstlane(len[c]);
@@ -474,17 +490,14 @@ __device__ inline void greedy_speculate(const CostGraph &g, CostLds &lds, lds_pt
         if (sh->head > p) continue;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the list's entries before the ring entry that names them
         if (lane == 0) {
-            const int e = (p / kSpecWaves) % kSpecRing;
-            sh->cost[w][e] = cost;
-            sh->cnt[w][e] = m;
-            sh->hoff[w][e] = (int32_t)io.off;
-            sh->hn[w][e] = io.n;
-            sh->tag[w][e] = p;
+            const int e = p % kSpecRing;
+            sh->cost[e] = cost;
+            sh->cnt[e] = m;
+            sh->hoff[e] = (int32_t)io.off;
+            sh->hn[e] = io.n;
+            sh->keep[e] = bal;
+            sh->tag[e] = p;
         }
-    }
-    while (!sh->done) {   // the list is exhausted: the queue still pops
-        serve_queue();
-        __builtin_amdgcn_s_sleep(8);
     }
 }
 
@@ -493,6 +506,7 @@ __device__ inline void greedy_speculate(const CostGraph &g, CostLds &lds, lds_pt
 // the list of the set that grew out of candidate `cand`.
 struct HitCacheNone {
     __device__ __forceinline__ void begin(fitgnn::HitIO &io, int32_t, bool) { io.active = false; }
+    __device__ __forceinline__ void begin_from(fitgnn::HitIO &io, int32_t, int32_t) { io.active = false; }
     __device__ __forceinline__ void end(const fitgnn::HitIO &, int32_t) {}
     __device__ __forceinline__ void adopt(int32_t, int32_t, int32_t) {}
 };
@@ -509,6 +523,15 @@ struct HitCacheGlobal {
         io.pool_ab = pool_ab; io.pool_w = pool_w; io.bump = bump; io.pool_cap = pool_cap;
         io.off = off;
         io.n = remap_ok ? n : -1;   // the translation table covers sets of at most 64 members
+        io.use_remap = true;
+        io.fresh_out = false;
+    }
+    // a helper's list of a superset of the set (its region of the pool is never reused: the filtered list replaces it in place)
+    __device__ __forceinline__ void begin_from(fitgnn::HitIO &io, int32_t off, int32_t n) {
+        io.active = true;
+        io.pool_ab = pool_ab; io.pool_w = pool_w; io.bump = bump; io.pool_cap = pool_cap;
+        io.off = off;
+        io.n = n;
         io.use_remap = true;
         io.fresh_out = false;
     }
@@ -656,17 +679,36 @@ __device__ inline void greedy_component(const CostGraph &g, CostLds &lds, Heap h
                 if (m <= fitgnn::kCostTile) {
                     FITGNN_WAVE_SYNC();
                     int32_t h_off = -1, h_n = -1;
-                    if (from_list ? spec.lookup(head - 1 - head0, m, c, h_off, h_n)
-                                  : (nc <= fitgnn::kCostTile && spec.lookup_top(cur_job, m, c, h_off, h_n))) {
+                    unsigned long long h_keep = 0ull;
+                    const int ans = from_list ? spec.lookup(head - 1 - head0, m, c, h_off, h_n, h_keep)
+                                              : (nc <= fitgnn::kCostTile ? spec.lookup_top(cur_job, m, c, h_off, h_n) : (int)kSpecNothing);
+                    if (ans == kSpecCost) {
                         cache.adopt(cand, h_off, h_n);
 #ifdef FITGNN_GREEDY_STAMPS
-                        gdbg[from_list ? 15 : 6] += 1;   // slot 6's time is not kept any more: answered queue re-costs
+                        gdbg[from_list ? 15 : 6] += 1;
 #endif
                     } else {
                         fitgnn::HitIO io{};
-                        cache.begin(io, cand, nc <= fitgnn::kCostTile);
+                        if (ans == kSpecList) {
+                            // the helper numbered the members it kept 0, 1, ...: its position -> the position after this prune
+                            const bool in_h = lane < nc && ((h_keep >> lane) & 1ull) != 0ull;
+                            const uint8_t to = in_h ? lds.remap[lane] : (uint8_t)255;
+                            const int ph = __popcll(h_keep & ((1ull << lane) - 1ull));
+                            FITGNN_WAVE_SYNC();
+                            if (in_h) lds.remap[ph] = to;
+                            FITGNN_WAVE_SYNC();
+                            cache.begin_from(io, h_off, h_n);
 #ifdef FITGNN_GREEDY_STAMPS
-                        if (io.active && io.off >= 0 && io.n >= 0) gdbg[7] += 1;   // re-costs answered from the set's stored match list
+                            gdbg[16] += 1;
+#endif
+                        } else {
+                            cache.begin(io, cand, nc <= fitgnn::kCostTile);
+#ifdef FITGNN_GREEDY_STAMPS
+                            if (!(io.active && io.off >= 0 && io.n >= 0)) gdbg[from_list ? 18 : 19] += 1;   // adjacency lists scanned by the selecting wave
+#endif
+                        }
+#ifdef FITGNN_GREEDY_STAMPS
+                        if (io.active && io.off >= 0 && io.n >= 0) gdbg[7] += 1;   // re-costs answered from a stored match list
 #endif
                         c = fitgnn::set_cost_wave<true>(g, S, m, lds, io);
                         cache.end(io, cand);
@@ -725,8 +767,8 @@ __global__ __launch_bounds__(64 * (1 + kSpecWaves)) void greedy_select_kernel(
     const size_t words = greedy_bitmap_words(N);
     if (state_in_lds) {
         for (int i = threadIdx.x; i < (int)words; i += blockDim.x) mark_bits[i] = 0u;
-        for (int i = threadIdx.x; i < kSpecWaves * kSpecRing; i += blockDim.x) spec_sh.tag[i / kSpecRing][i % kSpecRing] = -1;
-        if (threadIdx.x == 0) { spec_sh.head = 0; spec_sh.done = 0; spec_sh.job_seq = 0; spec_sh.res_seq = 0; }
+        for (int i = threadIdx.x; i < kSpecRing; i += blockDim.x) spec_sh.tag[i] = -1;
+        if (threadIdx.x == 0) { spec_sh.head = 0; spec_sh.done = 0; spec_sh.next = 0; spec_sh.job_seq = 0; spec_sh.res_seq = 0; }
         __syncthreads();  // the only workgroup barrier: nothing below waits for another wave
         if (wave > 0) {
             // the match-list pool: first half the selecting wave's, the second half split between the helpers
@@ -964,9 +1006,9 @@ extern "C" int fitgnn_variation_costs_batch_f64(const int32_t *rowptr, const int
 #ifdef FITGNN_GREEDY_STAMPS
 extern "C" int fitgnn_debug_greedy_counters(unsigned long long *out, int reset) {
     int rc = (int)hipDeviceSynchronize();
-    rc |= (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_greedy_dbg), sizeof(unsigned long long) * 16);
+    rc |= (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_greedy_dbg), sizeof(unsigned long long) * 24);
     if (reset) {
-        unsigned long long z[16] = {0};
+        unsigned long long z[24] = {0};
         rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(g_greedy_dbg), z, sizeof(z));
     }
     return rc;

@@ -145,6 +145,7 @@ __device__ inline double set_cost_wave_k(const CostGraph &g, const int32_t *__re
         if (lane < K) {
             int a = 0;
             if (t0 == 0) { msum = lds.B[lane]; a = 1; }
+#pragma unroll 8   // eight rows' LDS reads in flight; the additions stay in row order
             for (; a < rows; ++a) msum = msum + lds.B[a * K + lane];
         }
         FITGNN_WAVE_SYNC();

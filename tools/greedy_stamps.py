@@ -25,7 +25,7 @@ if not hasattr(L, "fitgnn_debug_greedy_counters"):   # a library without the cou
         print(f"{name}: contract_level {(time.time() - t0)*1e3:.1f} ms (no counters in this build)")
     sys.exit(0)
 L.fitgnn_debug_greedy_counters.argtypes = [ctypes.c_void_p, ctypes.c_int]
-buf = (ctypes.c_ulonglong * 16)()
+buf = (ctypes.c_ulonglong * 24)()
 coarsening.contract_level(G, A, r); torch.cuda.synchronize()
 L.fitgnn_debug_greedy_counters(buf, 1)
 L.fitgnn_debug_cost_counters.argtypes = [ctypes.c_void_p, ctypes.c_int]
@@ -43,6 +43,7 @@ cnts = [v[8], v[9], v[8] + v[9], v[10], v[11], v[12]]
 for n, cyc, c in zip(names, v[0:6], cnts):
     print(f"  {n:14s} {100.0*cyc/max(tot,1):5.1f} %  n={c:7d}  cycles/op={cyc/max(c,1):8.1f}")
 print(f"  max queue size {v[13]}, re-costs of list entries {v[14]} of {v[12]}, answered by a helper wave {v[15]}; queue re-costs answered by the helper {v[6]}; from a stored match list {v[7]}")
+print(f"  a helper's list of a superset filtered for {v[16]} list entries; adjacency lists scanned by the selecting wave: list entries {v[18]}, queue sets {v[19]}")
 L.fitgnn_debug_cost_counters(cb, 1)
 c = list(cb)
 ct = sum(c[0:9])
