@@ -51,6 +51,10 @@ class OpConfig:
                      every row; same bits).  Off: measured slower than the whole-subgraph kernel on S-products (7.6-7.9 vs 6.3-6.7 ms
                      per plain launch): hipcc's s_waitcnt vmcnt(0) in front of every first use keeps a wave to one memory
                      round trip per group of rows.
+    two_hop_backward the layer below a last layer evaluated on the loss rows receives A_hat^T dZ straight from that layer's backward
+                     (fitgnn_spmm_two_hop_dz_f32: dZ = (A_hat^T dAH) . ELU'/dropout' is used from registers and never written) instead
+                     of dZ followed by its own plain SpMM: the 8 H R bytes of writing and re-reading dZ are not moved (same bits
+                     for the gradient rows; the bias gradient's partial sums are grouped differently).  Needs a segmented batch.
     pad_table_min_k  static feature tables at least this wide whose width is not a multiple of 32 run layer 0's
                      products on a copy zero-padded once (real feature widths: 100, 500, 1 433, 8 415).
     profile / profile_gemm / profile_fused   None, or a list that collects HIP-event pairs around the SpMM / hand-written
@@ -58,18 +62,18 @@ class OpConfig:
     seed_bank        None, or a SeedBank supplying device-resident dropout seeds (steps captured in a hipGraph)."""
     __slots__ = ("gemm_precision", "atb_kernel", "nt_kernel", "nt_presplit", "fuse_dx_epilogue", "fold_backward",
                  "dedup_gather", "pad_table_min_k", "split_large_blocks", "compact_head_backward", "last_layer_on_loss_rows",
-                 "compact_rows_kernel", "stream_kernel", "profile", "profile_gemm", "profile_fused", "seed_bank")
+                 "compact_rows_kernel", "stream_kernel", "two_hop_backward", "profile", "profile_gemm", "profile_fused", "seed_bank")
 
     def __init__(self, gemm_precision="exact", atb_kernel=True, nt_kernel=True, nt_presplit=True, fuse_dx_epilogue=True,
                  fold_backward=False, dedup_gather=True, pad_table_min_k=0, split_large_blocks=True, compact_head_backward=True,
-                 last_layer_on_loss_rows=True, compact_rows_kernel=True, stream_kernel=False, profile=None, profile_gemm=None, profile_fused=None, seed_bank=None):
+                 last_layer_on_loss_rows=True, compact_rows_kernel=True, stream_kernel=False, two_hop_backward=False, profile=None, profile_gemm=None, profile_fused=None, seed_bank=None):
         if gemm_precision not in ("exact", "high", "highest"):
             raise ValueError(f"gemm_precision {gemm_precision!r}: 'exact', 'high' or 'highest'")
         self.gemm_precision, self.atb_kernel, self.nt_kernel, self.nt_presplit = gemm_precision, atb_kernel, nt_kernel, nt_presplit
         self.fuse_dx_epilogue, self.fold_backward, self.dedup_gather = fuse_dx_epilogue, fold_backward, dedup_gather
         self.pad_table_min_k, self.split_large_blocks = pad_table_min_k, split_large_blocks
         self.compact_head_backward, self.last_layer_on_loss_rows = compact_head_backward, last_layer_on_loss_rows
-        self.compact_rows_kernel, self.stream_kernel = compact_rows_kernel, stream_kernel
+        self.compact_rows_kernel, self.stream_kernel, self.two_hop_backward = compact_rows_kernel, stream_kernel, two_hop_backward
         self.profile, self.profile_gemm, self.profile_fused, self.seed_bank = profile, profile_gemm, profile_fused, seed_bank
 
     def replace(self, **kw):
@@ -642,6 +646,80 @@ def _spmm_rows_compact(g, side, Xc, xrow, zero_from, cfg, kind, dz=None):
     return Y if dz is None else (Y, db)
 
 
+def two_hop_supported(g, link, Xc, prev, cfg):
+    """The two-hop backward applies: the producer ran on this very graph, the batch is segmented, shapes are vectorisable."""
+    return (cfg.two_hop_backward and link is not None and link.g is g and g.seg is not None and Xc.shape[1] % 4 == 0
+            and prev.is_contiguous() and prev.shape[1] == Xc.shape[1])
+
+
+NO_ROW = 0x7fffffff
+
+
+def _two_hop_index(g, rows, pos):
+    """(zcol int32 [nnz], zt_rows int64 [n_sel + n_ref]) for fitgnn_spmm_two_hop_dz_f32 on the transposed pattern, cached on the graph
+    per index tensor.  zt_rows: the rows whose dZ goes to the side table -- the loss rows, then every row that some OTHER row has an
+    entry for, unless that other row is the hub of the row's own segment (it takes the value from the stream).  zcol[e]: the table
+    row of entry e's column (loss rows: their compact position, which is also their operand row), NO_ROW where none is needed."""
+    cache = getattr(g, "_two_hop", None)
+    if not _same_index(cache, rows):
+        side, dev, R, n_sel = g.t, rows.device, g.n, int(rows.numel())
+        col = side.col.long()
+        counts = (side.rowptr[1:] - side.rowptr[:-1]).long()
+        ar = torch.arange(R, device=dev)
+        row_e = torch.repeat_interleave(ar, counts)
+        seg = g.seg.long()
+        seg_of = torch.searchsorted(seg, ar, right=True) - 1          # segment of every row
+        is_hub = seg[seg_of] == ar
+        pc = pos.long().index_select(0, col)
+        taken = is_hub.index_select(0, row_e) & (seg_of.index_select(0, col) == seg_of.index_select(0, row_e))
+        need = (col != row_e) & ~taken & (pc >= n_sel)
+        del taken, row_e
+        ref = torch.unique(col[need])
+        pos2 = torch.full((R,), NO_ROW, dtype=torch.int64, device=dev)
+        pos2[ref] = n_sel + torch.arange(ref.numel(), device=dev)
+        zcol = torch.where(pc < n_sel, pc, torch.where(need, pos2.index_select(0, col), torch.full_like(pc, NO_ROW))).to(torch.int32).contiguous()
+        zt_rows = torch.cat([rows.long(), ref]).contiguous()
+        cache = (rows, rows._version, zcol, zt_rows)
+        g._two_hop = cache
+    return cache[2], cache[3]
+
+
+def spmm_two_hop_dz(g, Xc, prev, rows, pos, link, cfg=DEFAULT, profile_kind=None):
+    """(A_hat^T dZ, db) with dZ = (A_hat^T Xc) . ELU'/dropout'(prev) never stored as a whole (fitgnn_spmm_two_hop_dz_f32).  Xc: the
+    compact operand [len(rows) + ZERO_ROWS, H]; pos = _compact_positions(g, rows); link: the producing layer's forward epilogue."""
+    L = _lib.lib()
+    side = g.t
+    Xc, prev = _f32c(Xc), _f32c(prev)
+    _lib.require_cuda(Xc, prev, rows, pos, link.mask)
+    H, dev = Xc.shape[1], Xc.device
+    n_sel = int(rows.numel())
+    zcol, zt_rows = _two_hop_index(g, rows, pos)
+    n_zt = int(zt_rows.numel())
+    Y = torch.empty((g.n, H), dtype=torch.float32, device=dev)
+    ZT = torch.empty((max(n_zt, 1), H), dtype=torch.float32, device=dev)
+    n_seg, n_ranges = int(g.seg.numel()) - 1, int(g.range_seg.numel()) - 1
+    part = torch.empty((n_ranges, H), dtype=torch.float32, device=dev) if link.want_db else None
+    seed_v, epi_v = _seed_arg(link.seed, link.epi)
+    st = _lib.stream_ptr(dev)
+    ev = None
+    if cfg.profile is not None:
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
+    _lib.check(L.fitgnn_spmm_two_hop_dz_f32(_lib.dptr(side.rowptr), _lib.dptr(side.col), _lib.dptr(side.val), int(side.col.numel()), _lib.dptr(zcol),
+                                            _lib.dptr(pos), _lib.dptr(Xc), Xc.stride(0), n_sel, _lib.dptr(zt_rows), n_zt, _lib.dptr(prev),
+                                            _lib.dptr(Y), Y.stride(0), g.n, H, _lib.dptr(g.seg), n_seg, _lib.dptr(g.range_seg), n_ranges, epi_v,
+                                            float(link.p), seed_v, _lib.dptr(link.mask), _lib.dptr(ZT), ZT.stride(0), _lib.dptr(part), st),
+               "fitgnn_spmm_two_hop_dz_f32")
+    db = None
+    if link.want_db:
+        db = torch.empty(H, dtype=torch.float32, device=dev)
+        _lib.check(L.fitgnn_colsum_partials_f32(_lib.dptr(part), n_ranges, H, _lib.dptr(db), st), "fitgnn_colsum_partials_f32")
+    if ev is not None:
+        ev[1].record()
+        cfg.profile.append((ev[0], ev[1], profile_kind or "two_hop"))
+    return Y, db
+
+
 def spmm_graph_dz(g, X, prev, epilogue, p=0.0, seed=0, mask=None, want_db=True, transposed=True, xrow=None, cfg=DEFAULT, profile_kind=None,
                   zero_from=-1):
     """(dZ, db): dZ = (A @ X) * dropout' * ELU'(prev), the input gradient of the fused layer whose forward output is `prev`
@@ -929,15 +1007,18 @@ class EpilogueLink:
     dZ = epilogue'(dOut) in place of dOut, with the bias gradient, and marks the link; the producer's backward skips its
     own epilogue-backward kernel.  Only for strictly sequential stacks (network.py:29-33): `out` must have no other
     consumer, since what travels through autograd on this edge is no longer the plain gradient."""
-    __slots__ = ("epi", "p", "seed", "mask", "want_db", "fused", "db")
+    __slots__ = ("epi", "p", "seed", "mask", "want_db", "fused", "db", "g", "aggregated")
 
     def __init__(self):
         self.epi, self.p, self.seed, self.mask, self.want_db, self.fused, self.db = 0, 0.0, 0, None, False, False, None
+        self.g, self.aggregated = None, False
 
-    def record(self, drop, p, seed, mask, want_db):
+    def record(self, drop, p, seed, mask, want_db, g=None):
+        """g: the producer's graph.  A consumer on the SAME graph may go one step further than dZ and hand back A_hat^T dZ (the
+        producer's own backward SpMM), marking `aggregated` (ops.FusedGCNLastLayerRows, OpConfig.two_hop_backward)."""
         self.epi = EPI_ELU | (EPI_DROPOUT if drop else 0)
         self.p, self.seed, self.mask, self.want_db = (p if drop else 0.0), seed, (mask if drop else None), bool(want_db)
-        self.fused, self.db = False, None
+        self.fused, self.db, self.g, self.aggregated = False, None, g, False
 
 
 def _dx_through_link(cfg, link, dH, W, X):
@@ -958,7 +1039,10 @@ def _dx_through_link(cfg, link, dH, W, X):
 def _producer_backward(cfg, link, g, out, epi, p, seed, mask, has_bias, dOut):
     """(dH, db) of a fused layer: through the link when its consumer already applied the epilogue's derivative."""
     if link is not None and link.fused:
-        db, link.fused, link.db = link.db, False, None
+        db, aggregated = link.db, link.aggregated
+        link.fused, link.db, link.aggregated = False, None, False
+        if aggregated:   # the consumer's backward already ran this layer's SpMM over dZ (two-hop)
+            return _f32c(dOut), db
         return spmm_graph(g, _f32c(dOut), transposed=True, cfg=cfg), db
     dH, db, _ = layer_backward(g, out, epi, p, seed, mask, has_bias, dOut=dOut, cfg=cfg)
     return dH, db
@@ -981,7 +1065,7 @@ class FusedGCNLayer(torch.autograd.Function):
         ctx.g, ctx.p, ctx.drop, ctx.seed, ctx.has_bias, ctx.cfg = g, p, drop, seed, b is not None, cfg
         ctx.link_in, ctx.link_out = link_in, link_out
         if link_out is not None:
-            link_out.record(drop, p, seed, mask, b is not None)
+            link_out.record(drop, p, seed, mask, b is not None, g=g)
         return out
 
     @staticmethod
@@ -1124,7 +1208,11 @@ class FusedGCNLastLayerRows(torch.autograd.Function):
             dAH[n:].zero_()
             dAH[:n] = mm_by_transposed(dZc, W, cfg)                      # dZ @ W on the loss rows
             link = ctx.link_in
-            if Xprev is not None:
+            if Xprev is not None and two_hop_supported(g, link, dAH, Xprev, cfg):
+                # ... and the producing layer's own backward SpMM over that dZ in the same pass: what travels back is A_hat^T dZ
+                dX, db_prev = spmm_two_hop_dz(g, dAH, Xprev, rows, _compact_positions(g, rows), link, cfg=cfg)
+                link.fused, link.db, link.aggregated = True, db_prev, True
+            elif Xprev is not None:
                 # the producing layer's ELU' / dropout' applied as the rows are stored: what travels back on this edge is its dZ
                 dX, db_prev = spmm_graph_dz(g, dAH, Xprev, link.epi, p=link.p, seed=link.seed, mask=link.mask, want_db=link.want_db,
                                             xrow=_compact_positions(g, rows), cfg=cfg, profile_kind="compact_dz", zero_from=n)
@@ -1165,7 +1253,7 @@ class FusedGCNLayerDedup(torch.autograd.Function):
         ctx.save_for_backward(Xt, W, out, mask if drop else None)
         ctx.g, ctx.ridx, ctx.p, ctx.drop, ctx.seed, ctx.has_bias = g, ridx, p, drop, seed, b is not None
         if link_out is not None:
-            link_out.record(drop, p, seed, mask, b is not None)
+            link_out.record(drop, p, seed, mask, b is not None, g=g)
         return out
 
     @staticmethod

@@ -170,6 +170,29 @@ int fitgnn_spmm_rows_compact_dz_f32(const int32_t *rowptr, const int32_t *xcol, 
                                     int32_t zero_from, float *Y, int64_t ldy, int32_t n_rows, int32_t H, const float *prev,
                                     uint32_t epilogue, float p_drop, uint64_t seed, const uint8_t *mask, float *col_part, void *stream);
 
+/* Two backward products in one pass (csrc/spmm.hip: spmm_two_hop_kernel), for the layer right below a last GCN layer that was
+ * evaluated on the loss rows (network.py:29-33: h = dropout(ELU(conv(x))) feeding the last GCNConv; run.py:193-204 keeps out[mask]):
+ *     dZ = (A^T Xc) (.) ELU' / dropout' (prev)         fitgnn_spmm_rows_compact_dz_f32's product, NOT stored as a whole
+ *     Y  = A^T dZ                                      fitgnn_spmm_csr_f32's plain product over it
+ * rowptr / col / val: the CSR of A^T; Xc: the compact operand ([zero_from + zero rows] x H; rows >= zero_from are zero); xrow
+ * [n_rows]: compact position of every row (loss row number i -> i, any other row -> some position >= zero_from); prev: the layer's
+ * forward output [n_rows x H] (contiguous); epilogue / p_drop / seed / mask: the FORWARD's ELU / dropout flags (no FITGNN_EPI_BIAS).
+ * seg_ptr / range_seg as for fitgnn_spmm_csr_stream_f32 (segments whose first row is their hub).
+ * ZT: workspace [n_zt x H] (row stride ldz): a first launch fills it with dZ of the rows zt_rows[0 .. n_zt) (int64) -- the
+ * zero_from loss rows in compact order, then every row that another row has an entry for, other than the hub of the row's own
+ * segment (which takes dZ of its segment's rows as they stream by).  zcol [nnz]: per entry the ZT row of its column -- a value
+ * < zero_from is also the column's operand row in Xc -- or 0x7fffffff where none is needed (the row's own entry, a hub's entry
+ * inside its segment whose column is not a loss row).  col_part (may be NULL): [n_ranges x H], one partial row of column sums of dZ
+ * per range, every element written.
+ * Every entry of A^T enters both products in CSR order: Y has the bits of the two separate launches; what is saved is writing and
+ * re-reading dZ for the rows outside ZT (all but the loss rows and the rows seen from outside their star).
+ * H, ldx, ldy, ldz multiples of 4; Xc, Y, prev, ZT 16-byte aligned. */
+int fitgnn_spmm_two_hop_dz_f32(const int32_t *rowptr, const int32_t *col, const float *val, int64_t nnz, const int32_t *zcol,
+                               const int32_t *xrow, const float *Xc, int64_t ldx, int32_t zero_from, const int64_t *zt_rows, int32_t n_zt,
+                               const float *prev, float *Y, int64_t ldy, int32_t n_rows, int32_t H, const int32_t *seg_ptr, int32_t n_seg,
+                               const int32_t *range_seg, int32_t n_ranges, uint32_t epilogue, float p_drop, uint64_t seed,
+                               const uint8_t *mask, float *ZT, int64_t ldz, float *col_part, void *stream);
+
 /* LDS window sizes of the SpMM kernel (rows of the dense operand staged per workgroup): the default used
  * when window_rows == 0, and the largest accepted value.  Tiles should be built with win_rows <= the
  * window_rows later passed to fitgnn_spmm_csr_f32 (larger windows are clamped: still correct, slower). */
