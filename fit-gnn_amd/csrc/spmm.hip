@@ -385,14 +385,23 @@ constexpr int kBlkMeta = 128;  // CSR entries of a piece staged in LDS (threads 
 
 // XROW: operand row r of the pattern lives at X[xrow[r]] (a de-duplicated operand table, as in the tile kernel): the window
 // rows' table indices are fetched one piece ahead of the rows themselves, so the prefetch never waits on an index.
-template <bool XROW, bool BWD, bool NOEPI = false>
-__global__ __launch_bounds__(kThreads, BWD ? 4 : XROW ? 6 : 7) void spmm_block_kernel(
+// TWO (with XROW, NOEPI): the two-hop backward, fitgnn_spmm_two_hop_dz_f32.  The operand of the product is dZ of the layer below,
+// which is not stored: X is the side table ZT (dZ of the rows that have to be readable from anywhere), xrow[r] >= 0 names row r's
+// place in it and xcol[e] that of entry e's column; a row with xrow[r] < 0 is a "simple" one -- at most one of its columns is a loss
+// row -- and its dZ is made as the row is staged into the window: the prefetch brings its `prev` slice and the compact operand row
+// Xc[row_p[r]] of that column, and dZ = (row_w[r] * Xc row) . ELU' / dropout' (prev) goes to LDS in place of an operand row.  From
+// there on the kernel is the plain product.  The column sums of dZ (every row of a block passes through a window once) leave as
+// in the backward form.
+template <bool XROW, bool BWD, bool NOEPI = false, bool TWO = false>
+__global__ __launch_bounds__(kThreads, BWD ? 4 : TWO ? 5 : XROW ? 6 : 7) void spmm_block_kernel(
     const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col, const float *__restrict__ val,
     const float *__restrict__ X, int64_t ldx, float *__restrict__ Y, int64_t ldy, int32_t H,
     const fitgnn_block_t *__restrict__ blocks, int32_t n_blocks, const int32_t *__restrict__ long_rows, int32_t n_slabs,
     const float *__restrict__ bias, uint32_t epi, float p_drop, uint64_t seed_arg, const uint8_t *__restrict__ mask,
     const int32_t *__restrict__ xrow, const int32_t *__restrict__ xcol, const float *__restrict__ prev, float *__restrict__ col_part,
-    int32_t zero_from) {
+    int32_t zero_from, const float *__restrict__ Xc2 = nullptr, int64_t ldxc = 0, const int32_t *__restrict__ row_p = nullptr,
+    const float *__restrict__ row_w = nullptr, int32_t xc_zero_from = 0) {
+    static_assert(!TWO || (XROW && !BWD && NOEPI), "the two-hop form is a plain product over a table");
     // zero_from (XROW): operand rows >= zero_from are rows of zeros (the tail of a compact operand, ops.ZERO_ROWS): they are not
     // loaded -- as window rows they are staged as zeros, as gathered entries they read the LDS slot kZeroSlot -- so an operand
     // that is zero on most rows costs LDS reads and FMAs, not a memory round trip per gathered entry (measured on the compact
@@ -431,8 +440,9 @@ __global__ __launch_bounds__(kThreads, BWD ? 4 : XROW ? 6 : 7) void spmm_block_k
     const int n_long = min(blk.n_long, kBlkLong);
     const float keep_scale = (epi & FITGNN_EPI_DROPOUT) ? 1.0f / (1.0f - p_drop) : 1.0f;
     const uint32_t thresh = fitgnn::dropout_threshold(p_drop);
-    const RowEpilogue rowepi{BWD ? epi : (epi & ~FITGNN_EPI_BACKWARD), keep_scale, (epi & FITGNN_EPI_DROPOUT) ? 1.0f - p_drop : 1.0f, thresh,
-                             seed, mask, BWD ? prev : nullptr};
+    const RowEpilogue rowepi{(BWD || TWO) ? (epi | FITGNN_EPI_BACKWARD) : (epi & ~FITGNN_EPI_BACKWARD), keep_scale,
+                             (epi & FITGNN_EPI_DROPOUT) ? 1.0f - p_drop : 1.0f, thresh, seed, mask, (BWD || TWO) ? prev : nullptr};
+    const int colc2 = live ? col0 : max(H - 4, 0);
     float cs[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) cs[i] = 0.f;
@@ -448,20 +458,42 @@ __global__ __launch_bounds__(kThreads, BWD ? 4 : XROW ? 6 : 7) void spmm_block_k
     int p_rp = 0, p_c = 0, p_cx = 0, p_E0 = 0;
     float p_v = 0.f;
     int xr_next = 0;  // XROW: lane j < 4 holds the table row of window row wave + 4 j of the NEXT piece to prefetch
+    int xp_next = 0, xw_next = 0;   // TWO: ... and the compact operand row / weight of a simple row's one loss column
+    int xr_pub = 0, xw_pub = 0, xp_pub = 0;   // TWO: the same for the piece whose rows are in pv (published at the top of the piece loop)
+    T hv = P::zero();               // TWO: the compact operand row of the prefetched simple rows' loss column -- ONE per wave and piece, that of
+    int hv_pos = 0x7fffffff;        //      the first such row (the leaves of a star share their centre); a row with another one loads it late
     auto fetch_indices = [&](int r0, int r1) {
         if (XROW) {
             const int r = r0 + wave + lane * kWaves;
             xr_next = (lane < 4 && r < r1) ? xrow[r] : 0;
+            if (TWO) {
+                xp_next = (lane < 4 && r < r1) ? row_p[r] : 0x7fffffff;
+                xw_next = (lane < 4 && r < r1) ? __float_as_int(row_w[r]) : 0;
+            }
         }
     };
     auto prefetch = [&](int r0, int r1, int E0) {
         const int xr = xr_next;
+        if (TWO) { xr_pub = xr; xw_pub = xw_next; xp_pub = xp_next; hv_pos = 0x7fffffff; }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int r = r0 + wave + j * kWaves;
             pv[j] = P::zero();
             const int64_t sr = XROW ? (int64_t)__builtin_amdgcn_readlane(xr, j) : (int64_t)r;
-            if (r < r1 && !is_zero_row(sr)) pv[j] = *reinterpret_cast<const T *>(Xs + sr * ldx);   // wave-uniform
+            if (TWO) {
+                // one unconditional row load (the table row, or the row's `prev` slice) and the operand row of a simple row's loss column
+                const int rr = min(r, r1 - 1);
+                const float *rowp = sr >= 0 ? Xs + sr * ldx : prev + (uint64_t)rr * (uint64_t)H + (uint64_t)colc2;
+                const int pp = __builtin_amdgcn_readlane(xp_next, j);
+                const T a = *reinterpret_cast<const T *>(rowp);
+                pv[j] = r < r1 ? a : P::zero();
+                if (r < r1 && sr < 0 && pp < xc_zero_from && hv_pos == 0x7fffffff) {   // wave-uniform
+                    hv_pos = pp;
+                    hv = *reinterpret_cast<const T *>(Xc2 + (int64_t)pp * ldxc + colc2);
+                }
+            } else if (r < r1 && !is_zero_row(sr)) {
+                pv[j] = *reinterpret_cast<const T *>(Xs + sr * ldx);   // wave-uniform
+            }
         }
         if (XROW) fetch_indices(r1, min(r1 + kBlkRows, blk.row_end));  // the piece after: its rows are requested next time round
         if (BWD) {
@@ -568,7 +600,24 @@ __global__ __launch_bounds__(kThreads, BWD ? 4 : XROW ? 6 : 7) void spmm_block_k
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int r = wave + j * kWaves;
-            if (r < rows) s_win[r * 64 + lane] = pv[j];
+            if (r < rows) {
+                T v = pv[j];
+                if (TWO) {
+                    if (__builtin_amdgcn_readlane(xr_pub, j) < 0) {   // a simple row: pv is its `prev` slice
+                        T u = P::zero();
+                        const int pp = __builtin_amdgcn_readlane(xp_pub, j);
+                        T h = P::zero();
+                        if (pp == hv_pos) h = hv;
+                        else if (pp < xc_zero_from) h = *reinterpret_cast<const T *>(Xc2 + (int64_t)pp * ldxc + colc2);
+                        P::fma(u, __int_as_float(__builtin_amdgcn_readlane(xw_pub, j)), h);
+                        v = epilogue_value<4, true, false>(u, r0 + r, col0, H, bv, rowepi, cs, pv[j]);
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) cs[q] += P::get(v, q);
+                    }
+                }
+                s_win[r * 64 + lane] = v;
+            }
         }
         if ((int)threadIdx.x <= rows) s_rp[threadIdx.x] = p_rp;
         const int E0 = p_E0;
@@ -705,7 +754,7 @@ __global__ __launch_bounds__(kThreads, BWD ? 4 : XROW ? 6 : 7) void spmm_block_k
         gather_long(q, 0x7fffffff);
         if (live) finish_row<4, BWD, NOEPI>(acc_long[q], my_long[q], col0, H, Y, ldy, bv, rowepi, cs, o_prev);
     }
-    if (BWD && col_part) write_col_part<4>(reinterpret_cast<float *>(s_win), cs, col_part, b, H, col0, live);
+    if ((BWD || TWO) && col_part) write_col_part<4>(reinterpret_cast<float *>(s_win), cs, col_part, b, H, col0, live);
 #ifdef FITGNN_SPMM_STAMPS
     {
         SSTAMP(s_end);
@@ -1053,7 +1102,7 @@ __global__ __launch_bounds__(kThreads, BWD ? 4 : (NOEPI && !XROW) ? 6 : 5) void 
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Two-hop backward (fitgnn_spmm_two_hop_dz_f32): the last GCN layer's input gradient and the layer below's aggregation in ONE pass.
+// Two-hop backward, side table (fitgnn_two_hop_rows_f32; the product itself is spmm_block_kernel<.., TWO>).
 //
 // network.py:29-33 stacks  h = dropout(ELU(A_hat (x W0^T) + b0))  under the last GCNConv; with the last layer evaluated
 // aggregate-first on the rows that reach the loss (ops.FusedGCNLastLayerRows) its backward hands over dAH, zero outside those rows
@@ -1061,310 +1110,13 @@ __global__ __launch_bounds__(kThreads, BWD ? 4 : (NOEPI && !XROW) ? 6 : 5) void 
 //     dZ = (A_hat^T dAH) (.) ELU' / dropout' (h)          [R, H]   (fitgnn_spmm_rows_compact_dz_f32: reads h, writes dZ)
 //     G  = A_hat^T dZ                                     [R, H]   (a plain SpMM: reads dZ, writes G)
 // -- dZ itself is needed by nothing else (its column sums are the bias gradient).  Written and re-read it costs 8 H R bytes, as
-// much as the two compulsory streams (h in, G out) together.  Here dZ of a row lives in registers while the row streams by:
-//   * z(r) = dZ[r] is computed from the row's `prev` slice and the compact operand rows it references (the leaves of a star
-//     reference their centre: that row is cached);
-//   * G[r] = sum_e a_e z(col e) takes z(r) from registers and z of any OTHER row from the side table ZT -- dZ of the n_sel loss rows
-//     and of the rows that some other row references without being its segment's hub (edges between extra nodes, extra nodes seen
-//     by a second own node), computed by a first launch (two_hop_rows_kernel) over just those rows and cached like the operand row;
-//   * the hub's G takes z(r) of its segment's rows as they stream by, in CSR order (the segment-streaming kernel's carried
-//     accumulator): those entries need no table.
-// zcol[e] says which: < zero_from -- the column is loss row number zcol[e] (operand row Xc[zcol], dZ row ZT[zcol]); < kNoRow -- a
-// row of zeros in the operand, dZ row ZT[zcol]; kNoRow -- the entry is the row's own or one the hub takes from the stream.
-// Every entry of A_hat^T is used in both products, in CSR order: G has the bits of the two separate launches.  The column sums of
-// dZ leave as one partial row per range of segments.  (A first version recomputed dZ of a referenced row on the spot -- row
-// pointer, entries, operand rows, `prev` slice: four dependent round trips -- and ran no faster than the two launches: in a union
-// whose large subgraphs hold 1 600 extra nodes a quarter of the rows has such an entry.)
+// much as the two compulsory streams (h in, G out) together.  The whole-subgraph kernel makes dZ of a row as it stages the row
+// into its LDS window; only the rows it has to read from elsewhere -- the loss rows, rows seen from another piece or block -- are
+// computed beforehand, into the side table ZT, by the kernel below.
+// (A first, segment-streaming form -- dZ in registers, one wave per run of segments -- was bit-exact too but instruction-bound:
+// 560 instructions per 1-KiB row slice, 3.5 G VALU per launch, 10.9 ms + the table against 13.5 ms for the two launches.)
 constexpr int32_t kNoRow = 0x7fffffff;
-__global__ __launch_bounds__(kThreads, 4) void spmm_two_hop_kernel(
-    const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col, const float *__restrict__ val, const int32_t *__restrict__ zcol,
-    const int32_t *__restrict__ xrow, const float *__restrict__ Xc, int64_t ldx, const float *__restrict__ ZT, int64_t ldz, int32_t zero_from,
-    const float *__restrict__ prev, float *__restrict__ Y, int64_t ldy, int32_t H, int32_t n_rows, int32_t nnz,
-    const int32_t *__restrict__ seg_ptr, int32_t n_seg, const int32_t *__restrict__ range_seg, int32_t n_ranges, int32_t n_slabs, uint32_t epi,
-    float p_drop, uint64_t seed_arg, const uint8_t *__restrict__ mask, float *__restrict__ col_part) {
-    using P = Pack<4>;
-    using T = float4;
-    const uint64_t seed = fitgnn::resolve_seed(seed_arg, epi);
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * kWaves + (threadIdx.x >> 6)));
-    const int slab = wave % n_slabs, range = wave / n_slabs;
-    if (range >= n_ranges) return;
-    const int s_begin = range_seg[range], s_end = range_seg[range + 1];
-    const int r_begin = seg_ptr[s_begin], r_end = seg_ptr[s_end];
-    const int col0 = slab * 256 + lane * 4;
-    const bool live = col0 + 4 <= H;
-    const int colc = live ? col0 : max(H - 4, 0);   // dead lanes read a valid column group (never stored)
-    const float *Xs = Xc + colc, *Zs = ZT + colc;
-    const float keep_scale = (epi & FITGNN_EPI_DROPOUT) ? 1.0f / (1.0f - p_drop) : 1.0f;
-    const RowEpilogue rowepi{epi | FITGNN_EPI_BACKWARD, keep_scale, (epi & FITGNN_EPI_DROPOUT) ? 1.0f - p_drop : 1.0f,
-                             fitgnn::dropout_threshold(p_drop), seed, mask, prev};
-    float cs[4] = {0.f, 0.f, 0.f, 0.f};
-    const float bv[4] = {0.f, 0.f, 0.f, 0.f};
-    if (r_begin >= r_end) {
-        if (col_part && live) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) col_part[(int64_t)range * H + col0 + i] = 0.f;
-        }
-        return;
-    }
-    auto ent = [&](int e) { return min(max(e, 0), nnz - 1); };   // nnz >= 1 (checked by the launcher)
-    // ---- register batches: row pointers and compact positions of 64 rows, the starts of 64 segments ----
-    int rb = r_begin;
-    int rp = rowptr[min(rb + lane, n_rows)], rp_n = rowptr[min(rb + 64 + lane, n_rows)];
-    int xr = xrow[min(rb + lane, n_rows - 1)], xr_n = xrow[min(rb + 64 + lane, n_rows - 1)];
-    int sb = s_begin + 1;
-    int sg = seg_ptr[min(sb + lane, n_seg)];
-    int si = 0;
-    int next_seg = __builtin_amdgcn_readfirstlane(sg);
-    auto pos_of = [&](int row) -> int {   // compact position of union row `row` (rb <= row < rb + 128)
-        const int i = row - rb;
-        return i < 64 ? __builtin_amdgcn_readlane(xr, i) : __builtin_amdgcn_readlane(xr_n, i - 64);
-    };
-    auto prev_at = [&](int row) -> T { return *reinterpret_cast<const T *>(prev + (uint64_t)min(row, r_end - 1) * (uint64_t)H + (uint64_t)colc); };
-    // ---- CSR entries of the streamed (non-hub) rows: two 64-entry register tiles over the sequential entry stream ----
-    int T0 = __builtin_amdgcn_readfirstlane(rp);
-    int t_c, t_x, n_c, n_x;
-    float t_v, n_v;
-    auto load_tiles = [&]() {
-        t_c = col[ent(T0 + lane)]; t_v = val[ent(T0 + lane)]; t_x = zcol[ent(T0 + lane)];
-        n_c = col[ent(T0 + 64 + lane)]; n_v = val[ent(T0 + 64 + lane)]; n_x = zcol[ent(T0 + 64 + lane)];
-    };
-    load_tiles();
-    auto entry = [&](int e, int &c, int &x, float &w) {   // entry e through the tiles (outside them: re-base)
-        int k = e - T0;
-        if (k < 0 || k >= 128) {
-            T0 = e;
-            k = 0;
-            load_tiles();
-        }
-        if (k < 64) {
-            c = __builtin_amdgcn_readlane(t_c, k);
-            x = __builtin_amdgcn_readlane(t_x, k);
-            w = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t_v), k));
-        } else {
-            c = __builtin_amdgcn_readlane(n_c, k - 64);
-            x = __builtin_amdgcn_readlane(n_x, k - 64);
-            w = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(n_v), k - 64));
-        }
-    };
-    auto advance_to = [&](int e0) {   // called once per row, before its entries: slide the tiles forward when e0 left the first one
-        const int k = e0 - T0;
-        if (k >= 64 && k < 128) {
-            T0 += 64;
-            t_c = n_c; t_v = n_v; t_x = n_x;
-            n_c = col[ent(T0 + 64 + lane)]; n_v = val[ent(T0 + 64 + lane)]; n_x = zcol[ent(T0 + 64 + lane)];
-        }
-    };
-    // ---- the cached table row: dZ of one row and, when it is a loss row, its operand (dAH) row ----
-    int cpos = -1;
-    T xc = P::zero(), zc = P::zero();
-    auto fetch = [&](int pos) {
-        if (pos != cpos) {
-            zc = *reinterpret_cast<const T *>(Zs + (int64_t)pos * ldz);
-            xc = pos < zero_from ? *reinterpret_cast<const T *>(Xs + (int64_t)pos * ldx) : P::zero();
-            cpos = pos;
-        }
-    };
-    // ---- the hub: its G accumulator, a 64-entry tile of ITS entries and the cursor into them ----
-    int hub = -1, h1 = 0, cur = 0, HB = 0;
-    int h_c = 0, h_x = 0;
-    float h_v = 0.f;
-    T acc_h = P::zero();
-    auto hub_tile = [&]() {
-        const int e = HB + lane;
-        h_c = e < h1 ? col[e] : 0x7fffffff;
-        h_v = e < h1 ? val[e] : 0.f;
-        h_x = e < h1 ? zcol[e] : kNoRow;
-    };
-    auto hub_gather = [&](int bound) {   // hub entries with column < bound that lie outside the streamed rows: four in flight
-        while (cur < h1) {
-            if (cur - HB >= 64) { HB = cur; hub_tile(); }
-            const int k0 = cur - HB;
-            const unsigned long long in = __ballot(h_c < bound) >> k0;
-            const int n_in = in == 0 ? 0 : (int)__builtin_popcountll(in);
-            for (int k = k0; k < k0 + n_in; k += 4) {
-                const int last = k0 + n_in - 1;
-                T v[4];
-                float w[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int kk = min(k + u, last);
-                    const int x = __builtin_amdgcn_readlane(h_x, kk);
-                    w[u] = k + u <= last ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(h_v), kk)) : 0.f;
-                    v[u] = x != kNoRow ? *reinterpret_cast<const T *>(Zs + (int64_t)x * ldz) : P::zero();
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) P::fma(acc_h, w[u], v[u]);
-            }
-            cur += n_in;
-            if (k0 + n_in < 64) break;   // the rest of the tile is >= bound
-        }
-    };
-    auto hub_take = [&](int row, const T &z) {   // the hub's entry for `row`, if it is the next one
-        if (cur < h1) {
-            if (cur - HB >= 64) { HB = cur; hub_tile(); }
-            if (__builtin_amdgcn_readlane(h_c, cur - HB) == row) {
-                P::fma(acc_h, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(h_v), cur - HB)), z);
-                ++cur;
-            }
-        }
-    };
-    auto finish_hub = [&]() {
-        if (hub < 0) return;
-        hub_gather(0x7fffffff);
-        if (live) *reinterpret_cast<T *>(Y + (int64_t)hub * ldy + col0) = acc_h;
-    };
-    auto bounds = [&](int row, int &e0, int &e1) {
-        const int i = row - rb;   // 0 .. 66
-        e0 = i < 64 ? __builtin_amdgcn_readlane(rp, i) : __builtin_amdgcn_readlane(rp_n, i - 64);
-        e1 = i < 63 ? __builtin_amdgcn_readlane(rp, i + 1) : __builtin_amdgcn_readlane(rp_n, i - 63);
-    };
-    for (int r = r_begin; r < r_end; r += 4) {
-        if (r - rb >= 64) {
-            rb += 64;
-            rp = rp_n;
-            rp_n = rowptr[min(rb + 64 + lane, n_rows)];
-            xr = xr_n;
-            xr_n = xrow[min(rb + 64 + lane, n_rows - 1)];
-        }
-        // A group of four rows in four steps, so that no row waits for a memory round trip of its own (hipcc waits for every
-        // outstanding load before the first use of a loaded register: requests made together share one round trip):
-        //   A. request the four `prev` slices and the table rows of the group's first loss row;
-        //   B. z of the four rows (the operand row a leaf references is its hub's: cached);
-        //   C. request, per row, the table row of its first entry that is neither its own nor the cached one (an edge between two
-        //      extra nodes: one row in four of a large subgraph has one) -- four gathers in flight instead of one after the other;
-        //   D. G of the four rows in CSR order, the hub taking z of each row as it passes.
-        T oq[4], zr[4], gq[4];
-        int gx[4];
-        T lq_x = P::zero(), lq_z = P::zero();
-        int lq_pos = -1;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            oq[j] = prev_at(r + j);
-            const int pj = pos_of(min(r + j, r_end - 1));
-            if (pj < zero_from && lq_pos < 0) {   // wave-uniform
-                lq_pos = pj;
-                lq_x = *reinterpret_cast<const T *>(Xs + (int64_t)pj * ldx);
-                lq_z = *reinterpret_cast<const T *>(Zs + (int64_t)pj * ldz);
-            }
-        }
-        {   // the group's entries are read through the tiles without sliding them: slide once, here
-            int e0, e1;
-            bounds(r, e0, e1);
-            advance_to(e0);
-        }
-        // ---- B: z of the group's rows ----
-        // (the group may cross segment starts: steps B and C must know which rows are hubs without moving the state step D moves)
-        auto start_after = [&](int k) { return k < 64 ? __builtin_amdgcn_readlane(sg, k) : seg_ptr[min(sb + k, n_seg)]; };
-        int seg_cursor = next_seg, lsi = si;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int row = r + j;
-            zr[j] = P::zero();
-            if (row >= r_end) break;   // wave-uniform
-            int e0, e1;
-            bounds(row, e0, e1);
-            const int pr = pos_of(row);
-            const bool is_hub = row == r_begin || row == seg_cursor;
-            if (is_hub && row != r_begin) seg_cursor = start_after(++lsi);   // the start after this one, for the rest of the group
-            if (pr < zero_from) {            // a loss row: its dZ was computed by the first launch
-                if (pr == lq_pos) { xc = lq_x; zc = lq_z; cpos = pr; } else fetch(pr);
-                zr[j] = zc;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) cs[q] += P::get(zr[j], q);
-            } else {
-                T u = P::zero();
-                if (is_hub) {                // (a hub that is not a loss row: its entries do not pass through the stream tiles)
-                    for (int e = e0; e < e1; ++e) {
-                        const int x = zcol[e];
-                        const float w = val[e];
-                        if (x < zero_from) { fetch(x); P::fma(u, w, xc); } else P::fma(u, w, P::zero());
-                    }
-                } else {
-                    for (int e = e0; e < e1; ++e) {
-                        int c, x;
-                        float w;
-                        entry(e, c, x, w);
-                        if (x < zero_from) { fetch(x); P::fma(u, w, xc); } else P::fma(u, w, P::zero());
-                    }
-                }
-                zr[j] = epilogue_value<4, true, false>(u, row, col0, H, bv, rowepi, cs, oq[j]);
-            }
-        }
-        // ---- C: the first foreign table row of every non-hub row ----
-        seg_cursor = next_seg;
-        lsi = si;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int row = r + j;
-            gx[j] = kNoRow;
-            gq[j] = P::zero();
-            if (row >= r_end) break;   // wave-uniform
-            const bool is_hub = row == r_begin || row == seg_cursor;
-            if (is_hub) {
-                if (row != r_begin) seg_cursor = start_after(++lsi);
-                continue;
-            }
-            int e0, e1;
-            bounds(row, e0, e1);
-            for (int e = e0; e < e1; ++e) {
-                int c, x;
-                float w;
-                entry(e, c, x, w);
-                if (c != row && x != cpos && x != kNoRow) {
-                    gx[j] = x;
-                    gq[j] = *reinterpret_cast<const T *>(Zs + (int64_t)x * ldz);
-                    break;
-                }
-            }
-        }
-        // ---- D: G of the group's rows ----
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int row = r + j;
-            if (row >= r_end) break;   // wave-uniform
-            int e0, e1;
-            bounds(row, e0, e1);
-            const T z = zr[j];
-            if (row == r_begin || row == next_seg) {   // ---- a segment starts: this row is its hub ----
-                finish_hub();
-                if (row != r_begin) {
-                    if (++si >= 64) { sb += 64; si = 0; sg = seg_ptr[min(sb + lane, n_seg)]; }
-                    next_seg = __builtin_amdgcn_readlane(sg, si);
-                }
-                hub = row;
-                acc_h = P::zero();
-                cur = e0;
-                h1 = e1;
-                HB = e0;
-                hub_tile();
-                hub_gather(row);   // entries left of the hub (other segments), then its own entry
-                hub_take(row, z);
-                continue;
-            }
-            T acc = P::zero();
-            for (int e = e0; e < e1; ++e) {
-                int c, x;
-                float w;
-                entry(e, c, x, w);
-                if (c == row) P::fma(acc, w, z);
-                else if (x == kNoRow) P::fma(acc, w, P::zero());   // (not produced by the index: no table row, nothing to read)
-                else if (x == gx[j]) P::fma(acc, w, gq[j]);
-                else if (x == cpos) P::fma(acc, w, zc);
-                else P::fma(acc, w, *reinterpret_cast<const T *>(Zs + (int64_t)x * ldz));   // a second foreign row, or the cache moved on
-            }
-            if (live) *reinterpret_cast<T *>(Y + (int64_t)row * ldy + col0) = acc;
-            hub_take(row, z);
-        }
-    }
-    finish_hub();
-    if (col_part && live) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) col_part[(int64_t)range * H + col0 + i] = cs[i];
-    }
-}
-
-// ZT[i] = dZ[rows[i]] for the n_zt table rows (see spmm_two_hop_kernel): one wave per (row, slab); the row's entries are taken 64 at
+// ZT[i] = dZ[rows[i]] for the n_zt table rows: one wave per (row, slab); the row's entries are taken 64 at
 // a time and only those whose operand row is not a zero row are visited (a centre's entries are mostly its leaves), in CSR order.
 __global__ __launch_bounds__(kThreads) void two_hop_rows_kernel(
     const int32_t *__restrict__ rowptr, const int32_t *__restrict__ zcol, const float *__restrict__ val, const float *__restrict__ Xc, int64_t ldx,
@@ -1839,31 +1591,43 @@ extern "C" int fitgnn_spmm_rows_compact_dz_f32(const int32_t *rowptr, const int3
                           col_part, true, stream);
 }
 
-extern "C" int fitgnn_spmm_two_hop_dz_f32(const int32_t *rowptr, const int32_t *col, const float *val, int64_t nnz, const int32_t *zcol,
-                                          const int32_t *xrow, const float *Xc, int64_t ldx, int32_t zero_from, const int64_t *zt_rows,
-                                          int32_t n_zt, const float *prev, float *Y, int64_t ldy, int32_t n_rows, int32_t H,
-                                          const int32_t *seg_ptr, int32_t n_seg, const int32_t *range_seg, int32_t n_ranges, uint32_t epilogue,
-                                          float p_drop, uint64_t seed, const uint8_t *mask, float *ZT, int64_t ldz, float *col_part,
-                                          void *stream) {
-    if (n_rows < 0 || H < 0 || nnz < 0 || nnz > 0x7fffffffLL || n_seg < 0 || n_ranges < 0 || n_zt < 0 || zero_from < 0) return FITGNN_E_BADARG;
-    if (n_rows == 0 || H == 0 || n_ranges == 0) return 0;
-    if (!rowptr || !col || !val || !zcol || !xrow || nnz == 0 || !Xc || !Y || !prev || !seg_ptr || !range_seg || n_seg == 0) return FITGNN_E_BADARG;
-    if (n_zt < zero_from) return FITGNN_E_BADARG;   // table rows 0 .. zero_from - 1 are the loss rows
-    if (n_zt > 0 && (!zt_rows || !ZT)) return FITGNN_E_BADARG;
+extern "C" int fitgnn_two_hop_rows_f32(const int32_t *rowptr, const int32_t *zcol, const float *val, const float *Xc, int64_t ldx, int32_t zero_from,
+                                      const int64_t *zt_rows, int32_t n_zt, const float *prev, int32_t H, uint32_t epilogue, float p_drop,
+                                      uint64_t seed, const uint8_t *mask, float *ZT, int64_t ldz, void *stream) {
+    if (H < 0 || n_zt < 0 || zero_from < 0) return FITGNN_E_BADARG;
+    if (n_zt == 0 || H == 0) return 0;
+    if (!rowptr || !zcol || !val || !Xc || !zt_rows || !prev || !ZT) return FITGNN_E_BADARG;
+    epilogue &= ~(uint32_t)FITGNN_SPMM_GATHER;
+    if (epilogue & (FITGNN_EPI_BIAS | FITGNN_EPI_BACKWARD)) return FITGNN_E_BADARG;   // the FORWARD's ELU / dropout flags
+    if ((epilogue & FITGNN_EPI_DROPOUT) && !(p_drop >= 0.f && p_drop < 1.f)) return FITGNN_E_BADARG;
+    if ((H % 4) != 0 || (ldx % 4) != 0 || (ldz % 4) != 0 || ldx < H || ldz < H) return FITGNN_E_BADARG;
+    if ((((uintptr_t)Xc | (uintptr_t)prev | (uintptr_t)ZT) % 16) != 0) return FITGNN_E_ALIGN;
+    const int n_slabs = (H + 255) / 256;
+    const dim3 grid0((unsigned)(((int64_t)n_zt * n_slabs + kWaves - 1) / kWaves));
+    hipLaunchKernelGGL(two_hop_rows_kernel, grid0, dim3(kThreads), 0, (hipStream_t)stream, rowptr, zcol, val, Xc, ldx, zero_from, zt_rows, n_zt, prev, H,
+                       n_slabs, epilogue, p_drop, seed, mask, ZT, ldz);
+    return (int)hipGetLastError();
+}
+
+extern "C" int fitgnn_spmm_two_hop_blocks_f32(const int32_t *rowptr, const int32_t *col, const float *val, const float *ZT, int64_t ldz, float *Y,
+                                              int64_t ldy, int32_t n_rows, int32_t H, const fitgnn_block_t *blocks, int32_t n_blocks,
+                                              const int32_t *long_rows, const int32_t *zrow, const int32_t *zcol, const float *prev,
+                                              const float *Xc, int64_t ldx, int32_t zero_from, const int32_t *row_p, const float *row_w,
+                                              uint32_t epilogue, float p_drop, uint64_t seed, const uint8_t *mask, float *col_part,
+                                              void *stream) {
+    if (n_rows < 0 || H < 0 || n_blocks < 0 || zero_from < 0) return FITGNN_E_BADARG;
+    if (n_rows == 0 || H == 0 || n_blocks == 0) return 0;
+    if (!rowptr || !col || !val || !ZT || !Y || !blocks || !zrow || !zcol || !prev || !Xc || !row_p || !row_w) return FITGNN_E_BADARG;
     epilogue &= ~(uint32_t)FITGNN_SPMM_GATHER;
     if (epilogue & (FITGNN_EPI_BIAS | FITGNN_EPI_BACKWARD)) return FITGNN_E_BADARG;   // the FORWARD's ELU / dropout flags
     if ((epilogue & FITGNN_EPI_DROPOUT) && !(p_drop >= 0.f && p_drop < 1.f)) return FITGNN_E_BADARG;
     if ((H % 4) != 0 || (ldx % 4) != 0 || (ldy % 4) != 0 || (ldz % 4) != 0 || ldx < H || ldy < H || ldz < H) return FITGNN_E_BADARG;
     if ((((uintptr_t)Xc | (uintptr_t)Y | (uintptr_t)prev | (uintptr_t)ZT) % 16) != 0) return FITGNN_E_ALIGN;
     const int n_slabs = (H + 255) / 256;
-    if (n_zt > 0) {
-        const dim3 grid0((unsigned)(((int64_t)n_zt * n_slabs + kWaves - 1) / kWaves));
-        hipLaunchKernelGGL(two_hop_rows_kernel, grid0, dim3(kThreads), 0, (hipStream_t)stream, rowptr, zcol, val, Xc, ldx, zero_from, zt_rows, n_zt, prev,
-                           H, n_slabs, epilogue, p_drop, seed, mask, ZT, ldz);
-    }
-    const dim3 grid((unsigned)(((int64_t)n_ranges * n_slabs + kWaves - 1) / kWaves));
-    hipLaunchKernelGGL(spmm_two_hop_kernel, grid, dim3(kThreads), 0, (hipStream_t)stream, rowptr, col, val, zcol, xrow, Xc, ldx, ZT, ldz, zero_from,
-                       prev, Y, ldy, H, n_rows, (int32_t)nnz, seg_ptr, n_seg, range_seg, n_ranges, n_slabs, epilogue, p_drop, seed, mask, col_part);
+    const dim3 grid((unsigned)((n_blocks + 7) / 8 * 8) * n_slabs);
+    hipLaunchKernelGGL((spmm_block_kernel<true, false, true, true>), grid, dim3(kThreads), 0, (hipStream_t)stream, rowptr, col, val, ZT, ldz, Y, ldy, H,
+                       blocks, n_blocks, long_rows, n_slabs, (const float *)nullptr, epilogue, p_drop, seed, mask, zrow, zcol, prev, col_part, -1, Xc,
+                       ldx, row_p, row_w, zero_from);
     return (int)hipGetLastError();
 }
 

@@ -46,8 +46,9 @@ SIGNATURES = {
     "fitgnn_spmm_rows_compact_f32": (ctypes.c_int, [ptr, ptr, ptr, c_i64, ptr, c_i64, c_i32, ptr, c_i64, c_i32, c_i32, ptr]),
     "fitgnn_spmm_rows_compact_dz_f32": (ctypes.c_int, [ptr, ptr, ptr, c_i64, ptr, c_i64, c_i32, ptr, c_i64, c_i32, c_i32, ptr, c_u32, c_f32,
                                                        c_u64, ptr, ptr, ptr]),
-    "fitgnn_spmm_two_hop_dz_f32": (ctypes.c_int, [ptr, ptr, ptr, c_i64, ptr, ptr, ptr, c_i64, c_i32, ptr, c_i32, ptr, ptr, c_i64, c_i32, c_i32,
-                                                  ptr, c_i32, ptr, c_i32, c_u32, c_f32, c_u64, ptr, ptr, c_i64, ptr, ptr]),
+    "fitgnn_two_hop_rows_f32": (ctypes.c_int, [ptr, ptr, ptr, ptr, c_i64, c_i32, ptr, c_i32, ptr, c_i32, c_u32, c_f32, c_u64, ptr, ptr, c_i64, ptr]),
+    "fitgnn_spmm_two_hop_blocks_f32": (ctypes.c_int, [ptr, ptr, ptr, ptr, c_i64, ptr, c_i64, c_i32, c_i32, ptr, c_i32, ptr, ptr, ptr, ptr, ptr, c_i64,
+                                                      c_i32, ptr, ptr, c_u32, c_f32, c_u64, ptr, ptr, ptr]),
     "fitgnn_segment_sum_f32": (ctypes.c_int, [ptr, ptr, c_i32, ptr, c_i64, c_i32, ptr, c_i64, ptr]),
     "fitgnn_plan_tiles_host": (ctypes.c_int, [ptr, ptr, c_i32, c_i32, ptr, c_i32, c_i32, c_i32, ptr, ptr, ptr, ptr, ptr]),
     "fitgnn_epilogue_bwd_workspace_bytes": (c_size, [c_i32, c_i32]),

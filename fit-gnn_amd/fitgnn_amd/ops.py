@@ -52,9 +52,10 @@ class OpConfig:
                      per plain launch): hipcc's s_waitcnt vmcnt(0) in front of every first use keeps a wave to one memory
                      round trip per group of rows.
     two_hop_backward the layer below a last layer evaluated on the loss rows receives A_hat^T dZ straight from that layer's backward
-                     (fitgnn_spmm_two_hop_dz_f32: dZ = (A_hat^T dAH) . ELU'/dropout' is used from registers and never written) instead
-                     of dZ followed by its own plain SpMM: the 8 H R bytes of writing and re-reading dZ are not moved (same bits
-                     for the gradient rows; the bias gradient's partial sums are grouped differently).  Needs a segmented batch.
+                     (fitgnn_spmm_two_hop_blocks_f32: dZ = (A_hat^T dAH) . ELU'/dropout' is made in the whole-subgraph kernel's LDS
+                     windows and never written as a whole) instead of dZ followed by its own plain SpMM: most of the 8 H R bytes of
+                     writing and re-reading dZ are not moved (same bits for the gradient rows; the bias gradient's partial sums are
+                     grouped differently).  Needs a batch that runs on the whole-subgraph kernel (split_large_blocks).
     pad_table_min_k  static feature tables at least this wide whose width is not a multiple of 32 run layer 0's
                      products on a copy zero-padded once (real feature widths: 100, 500, 1 433, 8 415).
     profile / profile_gemm / profile_fused   None, or a list that collects HIP-event pairs around the SpMM / hand-written
@@ -66,7 +67,7 @@ class OpConfig:
 
     def __init__(self, gemm_precision="exact", atb_kernel=True, nt_kernel=True, nt_presplit=True, fuse_dx_epilogue=True,
                  fold_backward=False, dedup_gather=True, pad_table_min_k=0, split_large_blocks=True, compact_head_backward=True,
-                 last_layer_on_loss_rows=True, compact_rows_kernel=True, stream_kernel=False, two_hop_backward=False, profile=None, profile_gemm=None, profile_fused=None, seed_bank=None):
+                 last_layer_on_loss_rows=True, compact_rows_kernel=True, stream_kernel=False, two_hop_backward=True, profile=None, profile_gemm=None, profile_fused=None, seed_bank=None):
         if gemm_precision not in ("exact", "high", "highest"):
             raise ValueError(f"gemm_precision {gemm_precision!r}: 'exact', 'high' or 'highest'")
         self.gemm_precision, self.atb_kernel, self.nt_kernel, self.nt_presplit = gemm_precision, atb_kernel, nt_kernel, nt_presplit
@@ -647,77 +648,133 @@ def _spmm_rows_compact(g, side, Xc, xrow, zero_from, cfg, kind, dz=None):
 
 
 def two_hop_supported(g, link, Xc, prev, cfg):
-    """The two-hop backward applies: the producer ran on this very graph, the batch is segmented, shapes are vectorisable."""
-    return (cfg.two_hop_backward and link is not None and link.g is g and g.seg is not None and Xc.shape[1] % 4 == 0
-            and prev.is_contiguous() and prev.shape[1] == Xc.shape[1])
+    """The two-hop backward applies: the producer ran on this very graph, the batch runs on the whole-subgraph kernel, shapes are
+    vectorisable."""
+    return (cfg.two_hop_backward and link is not None and link.g is g and Xc.shape[1] % 4 == 0 and prev.is_contiguous()
+            and prev.shape[1] == Xc.shape[1] and g.t.blocks is not None and cfg.split_large_blocks)
 
 
 NO_ROW = 0x7fffffff
 
 
-def _two_hop_index(g, rows, pos):
-    """(zcol int32 [nnz], zt_rows int64 [n_sel + n_ref]) for fitgnn_spmm_two_hop_dz_f32 on the transposed pattern, cached on the graph
-    per index tensor.  zt_rows: the rows whose dZ goes to the side table -- the loss rows, then every row that some OTHER row has an
-    entry for, unless that other row is the hub of the row's own segment (it takes the value from the stream).  zcol[e]: the table
-    row of entry e's column (loss rows: their compact position, which is also their operand row), NO_ROW where none is needed."""
-    cache = getattr(g, "_two_hop", None)
+BLOCK_PIECE_ROWS = 16   # csrc/spmm.hip kBlkRows: rows of a whole-subgraph block staged in LDS together
+BLOCK_CARRIED = 4       # kBlkLong: long rows of a block whose operand rows stay pinned in LDS
+
+
+def _two_hop_block_index(g, rows, pos):
+    """Index of fitgnn_spmm_two_hop_blocks_f32 on the transposed pattern, cached on the graph per index tensor.  The whole-subgraph
+    kernel serves an entry (r, c) from LDS when r and c lie in the same 16-row piece of the same block, when c is one of the block's
+    carried long rows, or when r is one (it takes its columns piece by piece); every other entry reads the column's dZ from the
+    side table ZT.  In ZT: the loss rows (first, in compact order), every column read that way, the carried long rows (pinned from
+    the table), the rows outside the blocks (the tile kernel reads them through a row indirection) and the rows with two or more
+    loss columns (their dZ is not one product).  All remaining rows are "simple": dZ = (row_w * Xc[row_p]) . ELU'/dropout'(prev).
+    Returns a dict: zcol int32 [nnz], zrow int32 [R] (-1: simple), zt_rows int64 [n_zt], row_p int32 [R], row_w f32 [R],
+    tile_zt int64 (table rows of the rows outside the blocks)."""
+    cache = getattr(g, "_two_hop_blk", None)
     if not _same_index(cache, rows):
         side, dev, R, n_sel = g.t, rows.device, g.n, int(rows.numel())
         col = side.col.long()
         counts = (side.rowptr[1:] - side.rowptr[:-1]).long()
         ar = torch.arange(R, device=dev)
         row_e = torch.repeat_interleave(ar, counts)
-        seg = g.seg.long()
-        seg_of = torch.searchsorted(seg, ar, right=True) - 1          # segment of every row
-        is_hub = seg[seg_of] == ar
+        blk = side.blocks.long()
+        rb, cnt = blk[:, 0], blk[:, 1] - blk[:, 0]
+        nb = int(blk.shape[0])
+        in_rows = torch.repeat_interleave(rb, cnt) + (torch.arange(int(cnt.sum()), device=dev) - torch.repeat_interleave(torch.cumsum(cnt, 0) - cnt, cnt))
+        block_of = torch.full((R,), -1, dtype=torch.int64, device=dev)
+        block_of[in_rows] = torch.repeat_interleave(torch.arange(nb, device=dev), cnt)
+        piece_of = torch.zeros(R, dtype=torch.int64, device=dev)
+        piece_of[in_rows] = (in_rows - torch.repeat_interleave(rb, cnt)) // BLOCK_PIECE_ROWS
+        carried = torch.zeros(R, dtype=torch.bool, device=dev)
+        long_rows = side.long_rows.long()
+        for k in range(BLOCK_CARRIED):
+            sel = blk[:, 5] > k
+            if bool(sel.any()):
+                carried[long_rows[blk[sel, 4] + k]] = True
         pc = pos.long().index_select(0, col)
-        taken = is_hub.index_select(0, row_e) & (seg_of.index_select(0, col) == seg_of.index_select(0, row_e))
-        need = (col != row_e) & ~taken & (pc >= n_sel)
-        del taken, row_e
-        ref = torch.unique(col[need])
-        pos2 = torch.full((R,), NO_ROW, dtype=torch.int64, device=dev)
-        pos2[ref] = n_sel + torch.arange(ref.numel(), device=dev)
-        zcol = torch.where(pc < n_sel, pc, torch.where(need, pos2.index_select(0, col), torch.full_like(pc, NO_ROW))).to(torch.int32).contiguous()
-        zt_rows = torch.cat([rows.long(), ref]).contiguous()
-        cache = (rows, rows._version, zcol, zt_rows)
-        g._two_hop = cache
-    return cache[2], cache[3]
+        loss_e = pc < n_sel
+        b_r, b_c = block_of.index_select(0, row_e), block_of.index_select(0, col)
+        served = (b_r >= 0) & (b_r == b_c) & ((piece_of.index_select(0, row_e) == piece_of.index_select(0, col)) | carried.index_select(0, col)
+                                              | carried.index_select(0, row_e))
+        n_loss_cols = torch.zeros(R, dtype=torch.int64, device=dev).index_add_(0, row_e, loss_e.long())
+        in_zt = (block_of < 0) | carried | (n_loss_cols >= 2)
+        in_zt[col[~served]] = True
+        in_zt[rows.long()] = False                      # the loss rows take the first n_sel places
+        other = torch.nonzero(in_zt).flatten()
+        zrow = torch.full((R,), -1, dtype=torch.int64, device=dev)
+        zrow[rows.long()] = torch.arange(n_sel, device=dev)
+        zrow[other] = n_sel + torch.arange(other.numel(), device=dev)
+        zc = zrow.index_select(0, col)
+        zcol = torch.where(zc >= 0, zc, torch.full_like(zc, NO_ROW)).to(torch.int32).contiguous()
+        assert bool((served | (zc >= 0)).all()), "an entry the kernel gathers has no table row"
+        row_p = torch.full((R,), NO_ROW, dtype=torch.int32, device=dev)
+        row_w = torch.zeros(R, dtype=torch.float32, device=dev)
+        row_p[row_e[loss_e]] = pc[loss_e].to(torch.int32)
+        row_w[row_e[loss_e]] = side.val[loss_e]
+        tile_zt = zrow[block_of < 0]
+        cache = (rows, rows._version, dict(zcol=zcol, zrow=zrow.to(torch.int32).contiguous(), zt_rows=torch.cat([rows.long(), other]).contiguous(),
+                                           row_p=row_p, row_w=row_w, tile_zt=tile_zt.contiguous()))
+        g._two_hop_blk = cache
+    return cache[2]
 
 
-def spmm_two_hop_dz(g, Xc, prev, rows, pos, link, cfg=DEFAULT, profile_kind=None):
-    """(A_hat^T dZ, db) with dZ = (A_hat^T Xc) . ELU'/dropout'(prev) never stored as a whole (fitgnn_spmm_two_hop_dz_f32).  Xc: the
-    compact operand [len(rows) + ZERO_ROWS, H]; pos = _compact_positions(g, rows); link: the producing layer's forward epilogue."""
+def spmm_two_hop_blocks(g, Xc, prev, rows, pos, link, cfg=DEFAULT, profile_kind=None):
+    """(A_hat^T dZ, db) with dZ = (A_hat^T Xc) . ELU'/dropout'(prev) made in the whole-subgraph kernel's LDS windows instead of being
+    written and re-read (fitgnn_two_hop_rows_f32 for the side table, fitgnn_spmm_two_hop_blocks_f32; the rows outside the blocks
+    through the tile kernel over the table).  Xc: the compact operand [len(rows) + ZERO_ROWS, H]; pos = _compact_positions(g, rows)."""
     L = _lib.lib()
     side = g.t
     Xc, prev = _f32c(Xc), _f32c(prev)
     _lib.require_cuda(Xc, prev, rows, pos, link.mask)
     H, dev = Xc.shape[1], Xc.device
     n_sel = int(rows.numel())
-    zcol, zt_rows = _two_hop_index(g, rows, pos)
-    n_zt = int(zt_rows.numel())
-    Y = torch.empty((g.n, H), dtype=torch.float32, device=dev)
-    ZT = torch.empty((max(n_zt, 1), H), dtype=torch.float32, device=dev)
-    n_seg, n_ranges = int(g.seg.numel()) - 1, int(g.range_seg.numel()) - 1
-    part = torch.empty((n_ranges, H), dtype=torch.float32, device=dev) if link.want_db else None
+    ix = _two_hop_block_index(g, rows, pos)
+    n_zt = int(ix["zt_rows"].numel())
     seed_v, epi_v = _seed_arg(link.seed, link.epi)
     st = _lib.stream_ptr(dev)
     ev = None
     if cfg.profile is not None:
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         ev[0].record()
-    _lib.check(L.fitgnn_spmm_two_hop_dz_f32(_lib.dptr(side.rowptr), _lib.dptr(side.col), _lib.dptr(side.val), int(side.col.numel()), _lib.dptr(zcol),
-                                            _lib.dptr(pos), _lib.dptr(Xc), Xc.stride(0), n_sel, _lib.dptr(zt_rows), n_zt, _lib.dptr(prev),
-                                            _lib.dptr(Y), Y.stride(0), g.n, H, _lib.dptr(g.seg), n_seg, _lib.dptr(g.range_seg), n_ranges, epi_v,
-                                            float(link.p), seed_v, _lib.dptr(link.mask), _lib.dptr(ZT), ZT.stride(0), _lib.dptr(part), st),
-               "fitgnn_spmm_two_hop_dz_f32")
+    ZT = torch.empty((max(n_zt, 1), H), dtype=torch.float32, device=dev)
+    _lib.check(L.fitgnn_two_hop_rows_f32(_lib.dptr(side.rowptr), _lib.dptr(ix["zcol"]), _lib.dptr(side.val), _lib.dptr(Xc), Xc.stride(0), n_sel,
+                                         _lib.dptr(ix["zt_rows"]), n_zt, _lib.dptr(prev), H, epi_v, float(link.p), seed_v, _lib.dptr(link.mask),
+                                         _lib.dptr(ZT), ZT.stride(0), st), "fitgnn_two_hop_rows_f32")
+    Y = torch.empty((g.n, H), dtype=torch.float32, device=dev)
+    quiet = cfg if cfg.profile is None else cfg.replace(profile=None)
+    if side.small_tiles.shape[0]:
+        spmm_raw(side.rowptr, side.col, side.val, side.small_tiles, ZT, g.n, window_rows=g.window_rows, out=Y, cfg=quiet, xrow=ix["zrow"])
+    n_blocks = int(side.blocks.shape[0])
+    part = torch.zeros((n_blocks, H), dtype=torch.float32, device=dev) if link.want_db else None
+    _lib.check(L.fitgnn_spmm_two_hop_blocks_f32(_lib.dptr(side.rowptr), _lib.dptr(side.col), _lib.dptr(side.val), _lib.dptr(ZT), ZT.stride(0),
+                                                _lib.dptr(Y), Y.stride(0), g.n, H, _lib.dptr(side.blocks), n_blocks, _lib.dptr(side.long_rows),
+                                                _lib.dptr(ix["zrow"]), _lib.dptr(ix["zcol"]), _lib.dptr(prev), _lib.dptr(Xc), Xc.stride(0), n_sel,
+                                                _lib.dptr(ix["row_p"]), _lib.dptr(ix["row_w"]), epi_v, float(link.p), seed_v, _lib.dptr(link.mask),
+                                                _lib.dptr(part), st), "fitgnn_spmm_two_hop_blocks_f32")
     db = None
     if link.want_db:
-        db = torch.empty(H, dtype=torch.float32, device=dev)
-        _lib.check(L.fitgnn_colsum_partials_f32(_lib.dptr(part), n_ranges, H, _lib.dptr(db), st), "fitgnn_colsum_partials_f32")
+        if ix["tile_zt"].numel():
+            part = torch.cat([part, ZT.index_select(0, ix["tile_zt"]).sum(0, keepdim=True)])
+        db = _fold_partials(part, dev, st)
     if ev is not None:
         ev[1].record()
         cfg.profile.append((ev[0], ev[1], profile_kind or "two_hop"))
     return Y, db
+
+
+def _fold_partials(part, dev, st):
+    """Column sums of a [n x H] matrix of partial rows in a fixed order (fitgnn_colsum_partials_f32; many rows are folded in runs first)."""
+    L = _lib.lib()
+    n_part, H = int(part.shape[0]), int(part.shape[1])
+    if n_part > 8192:
+        G = 1024
+        per = n_part // G
+        head = part[: G * per].view(G, per, H).sum(1)
+        part = torch.cat([head, part[G * per:]]) if n_part > G * per else head
+        n_part = int(part.shape[0])
+    db = torch.empty(H, dtype=torch.float32, device=dev)
+    _lib.check(L.fitgnn_colsum_partials_f32(_lib.dptr(part.contiguous()), n_part, H, _lib.dptr(db), st), "fitgnn_colsum_partials_f32")
+    return db
 
 
 def spmm_graph_dz(g, X, prev, epilogue, p=0.0, seed=0, mask=None, want_db=True, transposed=True, xrow=None, cfg=DEFAULT, profile_kind=None,
@@ -1210,7 +1267,7 @@ class FusedGCNLastLayerRows(torch.autograd.Function):
             link = ctx.link_in
             if Xprev is not None and two_hop_supported(g, link, dAH, Xprev, cfg):
                 # ... and the producing layer's own backward SpMM over that dZ in the same pass: what travels back is A_hat^T dZ
-                dX, db_prev = spmm_two_hop_dz(g, dAH, Xprev, rows, _compact_positions(g, rows), link, cfg=cfg)
+                dX, db_prev = spmm_two_hop_blocks(g, dAH, Xprev, rows, _compact_positions(g, rows), link, cfg=cfg)
                 link.fused, link.db, link.aggregated = True, db_prev, True
             elif Xprev is not None:
                 # the producing layer's ELU' / dropout' applied as the rows are stored: what travels back on this edge is its dZ

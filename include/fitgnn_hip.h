@@ -170,28 +170,36 @@ int fitgnn_spmm_rows_compact_dz_f32(const int32_t *rowptr, const int32_t *xcol, 
                                     int32_t zero_from, float *Y, int64_t ldy, int32_t n_rows, int32_t H, const float *prev,
                                     uint32_t epilogue, float p_drop, uint64_t seed, const uint8_t *mask, float *col_part, void *stream);
 
-/* Two backward products in one pass (csrc/spmm.hip: spmm_two_hop_kernel), for the layer right below a last GCN layer that was
- * evaluated on the loss rows (network.py:29-33: h = dropout(ELU(conv(x))) feeding the last GCNConv; run.py:193-204 keeps out[mask]):
+/* Two backward products in one pass on the whole-subgraph kernel (csrc/spmm.hip: spmm_block_kernel<.., TWO>), for the layer right
+ * below a last GCN layer that was evaluated on the loss rows (network.py:29-33: h = dropout(ELU(conv(x))) feeding the last GCNConv;
+ * run.py:193-204 keeps out[mask]):
  *     dZ = (A^T Xc) (.) ELU' / dropout' (prev)         fitgnn_spmm_rows_compact_dz_f32's product, NOT stored as a whole
- *     Y  = A^T dZ                                      fitgnn_spmm_csr_f32's plain product over it
- * rowptr / col / val: the CSR of A^T; Xc: the compact operand ([zero_from + zero rows] x H; rows >= zero_from are zero); xrow
- * [n_rows]: compact position of every row (loss row number i -> i, any other row -> some position >= zero_from); prev: the layer's
- * forward output [n_rows x H] (contiguous); epilogue / p_drop / seed / mask: the FORWARD's ELU / dropout flags (no FITGNN_EPI_BIAS).
- * seg_ptr / range_seg as for fitgnn_spmm_csr_stream_f32 (segments whose first row is their hub).
- * ZT: workspace [n_zt x H] (row stride ldz): a first launch fills it with dZ of the rows zt_rows[0 .. n_zt) (int64) -- the
- * zero_from loss rows in compact order, then every row that another row has an entry for, other than the hub of the row's own
- * segment (which takes dZ of its segment's rows as they stream by).  zcol [nnz]: per entry the ZT row of its column -- a value
- * < zero_from is also the column's operand row in Xc -- or 0x7fffffff where none is needed (the row's own entry, a hub's entry
- * inside its segment whose column is not a loss row).  col_part (may be NULL): [n_ranges x H], one partial row of column sums of dZ
- * per range, every element written.
- * Every entry of A^T enters both products in CSR order: Y has the bits of the two separate launches; what is saved is writing and
- * re-reading dZ for the rows outside ZT (all but the loss rows and the rows seen from outside their star).
- * H, ldx, ldy, ldz multiples of 4; Xc, Y, prev, ZT 16-byte aligned. */
-int fitgnn_spmm_two_hop_dz_f32(const int32_t *rowptr, const int32_t *col, const float *val, int64_t nnz, const int32_t *zcol,
-                               const int32_t *xrow, const float *Xc, int64_t ldx, int32_t zero_from, const int64_t *zt_rows, int32_t n_zt,
-                               const float *prev, float *Y, int64_t ldy, int32_t n_rows, int32_t H, const int32_t *seg_ptr, int32_t n_seg,
-                               const int32_t *range_seg, int32_t n_ranges, uint32_t epilogue, float p_drop, uint64_t seed,
-                               const uint8_t *mask, float *ZT, int64_t ldz, float *col_part, void *stream);
+ *     Y  = A^T dZ                                      fitgnn_spmm_csr_blocks_f32's plain product over it, for the listed blocks
+ * rowptr / col / val: the CSR of A^T; Xc: the compact operand ([zero_from + zero rows] x H; rows >= zero_from are zero); prev: the
+ * layer's forward output [n_rows x H] (contiguous); epilogue / p_drop / seed / mask: the FORWARD's ELU / dropout flags (no
+ * FITGNN_EPI_BIAS).  A row's dZ enters the product from the LDS window its piece is staged in; what the kernel cannot serve from
+ * LDS it reads from the side table ZT [n_zt x H], filled beforehand by
+ *   fitgnn_two_hop_rows_f32: ZT[i] = dZ[zt_rows[i]]  (zt_rows int64; the first zero_from of them are the loss rows in compact order;
+ *                            zcol [nnz]: table row of every entry's column, 0x7fffffff if it has none -- a value < zero_from is
+ *                            also the column's operand row in Xc).
+ * zrow [n_rows]: table row of row r, or -1 for a "simple" row, whose dZ is made while it is staged: at most one of its columns is a
+ * loss row, row_p[r] its compact position (0x7fffffff: none) and row_w[r] the entry's value.  The caller's index must put into ZT:
+ * the loss rows, the blocks' carried long rows (the first 4 of a block's long_rows), every row with two or more loss columns, and
+ * the column of every entry (r, c) that is not served from LDS -- served are: r and c in the same 16-row piece of the same block, c
+ * a carried long row of r's block, r a carried long row and c in its block (ops._two_hop_block_index builds exactly this).  Rows
+ * outside the listed blocks are not touched: run them through fitgnn_spmm_csr_f32 with X = ZT, xrow = zrow.
+ * col_part (may be NULL): [n_blocks x H], ZEROED by the caller, one partial row of column sums of dZ per block.
+ * Same bits as fitgnn_spmm_rows_compact_dz_f32 followed by fitgnn_spmm_csr_blocks_f32.  H, ldx, ldy, ldz multiples of 4; 16-byte
+ * aligned Xc, Y, prev, ZT. */
+int fitgnn_two_hop_rows_f32(const int32_t *rowptr, const int32_t *zcol, const float *val, const float *Xc, int64_t ldx, int32_t zero_from,
+                            const int64_t *zt_rows, int32_t n_zt, const float *prev, int32_t H, uint32_t epilogue, float p_drop,
+                            uint64_t seed, const uint8_t *mask, float *ZT, int64_t ldz, void *stream);
+int fitgnn_spmm_two_hop_blocks_f32(const int32_t *rowptr, const int32_t *col, const float *val, const float *ZT, int64_t ldz, float *Y,
+                                   int64_t ldy, int32_t n_rows, int32_t H, const fitgnn_block_t *blocks, int32_t n_blocks,
+                                   const int32_t *long_rows, const int32_t *zrow, const int32_t *zcol, const float *prev, const float *Xc,
+                                   int64_t ldx, int32_t zero_from, const int32_t *row_p, const float *row_w, uint32_t epilogue,
+                                   float p_drop, uint64_t seed, const uint8_t *mask, float *col_part, void *stream);
+
 
 /* LDS window sizes of the SpMM kernel (rows of the dense operand staged per workgroup): the default used
  * when window_rows == 0, and the largest accepted value.  Tiles should be built with win_rows <= the

@@ -125,6 +125,14 @@ def test_round3_entry_points_check_their_arguments_without_a_gpu():
     # compact-operand row streaming
     assert L.fitgnn_spmm_rows_compact_parts(1) == 1 and L.fitgnn_spmm_rows_compact_parts(64 * 8192 + 1) <= 8192
     assert L.fitgnn_spmm_rows_compact_dz_f32(None, None, None, 0, None, 512, 0, None, 512, 4, 512, None, 0, 0.0, 0, None, None, None) == -1
+    # the two-hop backward: nothing to do / null arrays / a bias flag among the forward's epilogue flags
+    assert L.fitgnn_two_hop_rows_f32(None, None, None, None, 512, 0, None, 0, None, 512, 0, 0.0, 0, None, None, 512, None) == 0
+    assert L.fitgnn_two_hop_rows_f32(None, None, None, None, 512, 0, None, 3, None, 512, 0, 0.0, 0, None, None, 512, None) == -1
+    z = [None] * 3
+    assert L.fitgnn_spmm_two_hop_blocks_f32(*z, None, 512, None, 512, 0, 512, None, 0, None, None, None, None, None, 512, 0, None, None, 0, 0.0, 0,
+                                            None, None, None) == 0
+    assert L.fitgnn_spmm_two_hop_blocks_f32(*z, None, 512, None, 512, 9, 512, None, 2, None, None, None, None, None, 512, 0, None, None, 0, 0.0, 0,
+                                            None, None, None) == -1
     assert L.fitgnn_spmm_rows_compact_f32(None, None, None, 0, None, 512, -1, None, 512, 4, 512, None) == -1   # zero_from < 0
     # segment streaming: xrow and xcol come together
     assert L.fitgnn_spmm_csr_stream_f32(None, None, None, 0, None, 512, None, 512, 0, 512, None, 0, None, 0, None, None, None, 0, 0.0, 0,

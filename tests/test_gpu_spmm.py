@@ -395,21 +395,18 @@ def test_row_streaming_kernel_for_a_compact_operand(mods, H, sizes):
                                                 ([100, 7, 17, 300, 3, 3, 64, 33, 2, 1000, 5, 5, 40], 2, "random"), ([3, 2], 1, "random"),
                                                 ([1], 1, "random")])
 def test_two_hop_backward_gives_the_two_launches_bits(mods, H, sizes, centres, loss):
-    """fitgnn_spmm_two_hop_dz_f32: G = A^T ((A^T dAH) . ELU'/dropout'(prev)) in one pass, dZ never stored, == the compact dZ launch
-    followed by the plain transposed SpMM, bit for bit (every entry enters both products in CSR order); column sums of dZ to fp32
-    summation order.  Loss rows = the centres of the stars (the production case: leaves reference themselves and loss rows only,
-    apart from the few leaf -- leaf edges star_blocks adds, which take the recomputing path) and a random third of the rows (most
-    columns are then neither the row nor a loss row: the recomputing path everywhere); segments that start at a non-loss row;
-    centres with several hundred entries; hashed dropout and an injected mask; ELU alone.  The side table holds the loss rows and
-    the rows seen from outside their star only."""
+    """The two-hop backward (fitgnn_two_hop_rows_f32 + fitgnn_spmm_two_hop_blocks_f32, the rows outside the blocks on the tile kernel
+    over the side table): G = A^T ((A^T dAH) . ELU'/dropout'(prev)) without dZ being stored as a whole == the compact dZ launch followed
+    by the plain transposed SpMM, bit for bit (every entry enters both products in CSR order); column sums of dZ to fp32 summation
+    order.  Blocks of every size (with block_limit 64 the larger ones and all small ones on tiles).  Loss rows = the centres of the
+    stars (the production case: a leaf's columns are itself and loss rows, apart from the leaf -- leaf edges star_blocks adds) and a
+    random third of the rows (rows with several loss columns, long rows that are not loss rows); centres with several hundred
+    entries; hashed dropout and an injected mask; ELU alone."""
     _lib, csr, ops, orc, gorc = mods
     from fitgnn_amd._lib import EPI_DROPOUT, EPI_ELU
 
     ei, n = star_blocks(sizes, centres, seed=H + len(sizes))
     ptr = np.concatenate([[0], np.cumsum(sizes)])
-    g = csr.CSRGraph(ei.cuda(), n, mode="gcn", ptr=ptr)
-    # segments: every block's first centre starts one (the other centres of a block are rows of its segment, as in a cluster with several own nodes)
-    g.seg, g.range_seg = csr.stream_ranges(ptr, n, "cuda", want=7, min_rows=1)
     torch.manual_seed(H + n)
     if loss == "centres":
         rows = torch.cat([torch.arange(min(centres, max(s - 1, 1))) + o for s, o in zip(sizes, ptr[:-1])]).cuda().sort().values
@@ -417,39 +414,52 @@ def test_two_hop_backward_gives_the_two_launches_bits(mods, H, sizes, centres, l
         rows = torch.randperm(n).cuda()[: max(n // 3, 1)].sort().values
     k = int(rows.numel())
     Xc = torch.cat([torch.randn(k, H).cuda(), torch.zeros(ops.ZERO_ROWS, H).cuda()])
-    pos = ops._compact_positions(g, rows)
     prev = torch.randn(n, H).cuda() * (torch.rand(n, H).cuda() > 0.3)
-    cfg = ops.OpConfig(profile=[])
-    for flags, p, mask in ((EPI_ELU | EPI_DROPOUT, 0.5, None), (EPI_ELU | EPI_DROPOUT, 0.5, (torch.rand(n, H).cuda() > 0.5).to(torch.uint8)),
-                           (EPI_ELU, 0.0, None)):
-        link = ops.EpilogueLink()
-        link.record(bool(flags & EPI_DROPOUT), p, 77, mask, True, g=g)
-        assert ops.two_hop_supported(g, link, Xc, prev, cfg)
-        G, db = ops.spmm_two_hop_dz(g, Xc, prev, rows, pos, link, cfg=cfg)
-        dZ, want_db = ops.spmm_graph_dz(g, Xc, prev, flags, p=p, seed=77, mask=mask, want_db=True, xrow=pos, zero_from=k)
-        want = ops.spmm_graph(g, dZ, transposed=True)
-        assert torch.equal(G, want)
-        assert rel_err(db.cpu(), want_db.cpu()) < 1e-5 or float(want_db.abs().max()) == 0.0
-    assert cfg.profile[-1][2] == "two_hop"
-    zcol, zt_rows = ops._two_hop_index(g, rows, pos)
-    assert torch.equal(zt_rows[:k], rows.long()) and int(zt_rows.numel()) <= n
-    if loss == "centres" and centres == 1 and len(sizes) > 3:   # pure stars (no leaf -- leaf edges): nothing but the loss rows in the table
-        ei0, _ = star_blocks(sizes, 1, seed=1, extra=0.0)
-        g0 = csr.CSRGraph(ei0.cuda(), n, mode="gcn", ptr=ptr)
-        g0.seg, g0.range_seg = g.seg, g.range_seg
-        zcol0, zt0 = ops._two_hop_index(g0, rows, ops._compact_positions(g0, rows))
-        assert torch.equal(zt0, rows.long()), "leaves referenced by their own centre alone need no table row"
-        assert int((zcol0 == ops.NO_ROW).sum()) == 2 * (n - k)   # every leaf's own entry and its centre's entry for it
-    # another graph's link, an unsegmented batch: not taken
+    ran = 0
+    for limit in (4096, 64):
+        g = csr.CSRGraph(ei.cuda(), n, mode="gcn", ptr=ptr, block_limit=limit)
+        if g.t.blocks is None:
+            continue
+        ran += 1
+        cfg = ops.OpConfig(profile=[])
+        pos = ops._compact_positions(g, rows)
+        for flags, p, mask in ((EPI_ELU | EPI_DROPOUT, 0.5, None), (EPI_ELU | EPI_DROPOUT, 0.5, (torch.rand(n, H).cuda() > 0.5).to(torch.uint8)),
+                               (EPI_ELU, 0.0, None)):
+            link = ops.EpilogueLink()
+            link.record(bool(flags & EPI_DROPOUT), p, 77, mask, True, g=g)
+            assert ops.two_hop_supported(g, link, Xc, prev, cfg)
+            G, db = ops.spmm_two_hop_blocks(g, Xc, prev, rows, pos, link, cfg=cfg)
+            dZ, want_db = ops.spmm_graph_dz(g, Xc, prev, flags, p=p, seed=77, mask=mask, want_db=True, xrow=pos, zero_from=k)
+            want = ops.spmm_graph(g, dZ, transposed=True)
+            assert torch.equal(G, want)
+            assert rel_err(db.cpu(), want_db.cpu()) < 1e-5 or float(want_db.abs().max()) == 0.0
+        assert cfg.profile[-1][2] == "two_hop"
+        ix = ops._two_hop_block_index(g, rows, pos)
+        assert torch.equal(ix["zt_rows"][:k], rows.long()) and int(ix["zt_rows"].numel()) <= n
+        # another graph's link: not taken
+        assert not ops.two_hop_supported(csr.CSRGraph(ei.cuda(), n, mode="gcn", ptr=ptr, block_limit=limit), link, Xc, prev, cfg)
+    assert ran >= 1 or max(sizes) <= 16
+    if loss == "centres" and centres == 1 and len(sizes) > 3:   # pure stars (no leaf -- leaf edges): the table holds the loss rows and the
+        ei0, _ = star_blocks(sizes, 1, seed=1, extra=0.0)       # rows outside the blocks, every other row is made in the window
+        g0 = csr.CSRGraph(ei0.cuda(), n, mode="gcn", ptr=ptr, block_limit=4096)
+        ix = ops._two_hop_block_index(g0, rows, ops._compact_positions(g0, rows))
+        in_blocks = sum(s_ for s_ in sizes if s_ > 16)
+        assert int(ix["zt_rows"].numel()) == k + (n - in_blocks) - sum(1 for s_ in sizes if s_ <= 16)
+        assert int((ix["zrow"] < 0).sum()) == in_blocks - sum(1 for s_ in sizes if s_ > 16)
+    # a batch that is not split into blocks: not taken
     g2 = csr.CSRGraph(ei.cuda(), n, mode="gcn", ptr=ptr)
-    assert not ops.two_hop_supported(g2, link, Xc, prev, cfg)
-    # argument errors of the C entry point, before any GPU work
+    link = ops.EpilogueLink()
+    link.record(True, 0.5, 77, None, True, g=g2)
+    assert g2.t.blocks is not None or not ops.two_hop_supported(g2, link, Xc, prev, ops.DEFAULT)
+    # argument errors of the C entry points, before any GPU work
     L = _lib.lib()
     z = [None] * 3
-    assert L.fitgnn_spmm_two_hop_dz_f32(*z, 0, None, None, None, 512, 0, None, 0, None, None, 512, 0, 512, None, 0, None, 0, 0, 0.0, 0, None, None,
-                                        512, None, None) == 0      # nothing to do
-    assert L.fitgnn_spmm_two_hop_dz_f32(*z, 0, None, None, None, 512, 0, None, 0, None, None, 512, 5, 510, None, 1, None, 1, 0, 0.0, 0, None, None,
-                                        512, None, None) == -1     # null arrays / H % 4
+    assert L.fitgnn_two_hop_rows_f32(None, None, None, None, 512, 0, None, 0, None, 512, 0, 0.0, 0, None, None, 512, None) == 0
+    assert L.fitgnn_two_hop_rows_f32(None, None, None, None, 512, 0, None, 3, None, 512, 0, 0.0, 0, None, None, 512, None) == -1
+    assert L.fitgnn_spmm_two_hop_blocks_f32(*z, None, 512, None, 512, 0, 512, None, 0, None, None, None, None, None, 512, 0, None, None, 0, 0.0, 0, None,
+                                            None, None) == 0
+    assert L.fitgnn_spmm_two_hop_blocks_f32(*z, None, 512, None, 512, 9, 512, None, 2, None, None, None, None, None, 512, 0, None, None, 0, 0.0, 0, None,
+                                            None, None) == -1
 
 
 @pytest.mark.parametrize("H,C,with_dWl", [(512, 3, True), (512, 47, False), (64, 7, True)])
