@@ -9,7 +9,7 @@ import json
 import os
 import sys
 
-KEEP = ("spmm_tile_kernel", "spmm_block_kernel", "spmm_rows_compact_kernel", "spmm_stream_kernel", "spmm_gather_kernel", "gemm_f32_kernel", "gemm_nt_kernel",
+KEEP = ("two_hop_rows_kernel", "spmm_tile_kernel", "spmm_block_kernel", "spmm_rows_compact_kernel", "spmm_stream_kernel", "spmm_gather_kernel", "gemm_f32_kernel", "gemm_nt_kernel",
         "gemm_atb_kernel", "epilogue_bwd_kernel", "segment_sum_kernel", "head_rows_kernel")
 
 
