@@ -9,7 +9,8 @@ use_community_detection, subgraph-batch DP" on synthetic data of that shape (SUR
 classes (main.py:243), coarsened by the HIP contraction step (variation_neighborhoods, r=0.5), one 1-hop "extra node"
 subgraph per cluster (82.5 k subgraphs, 8.2 M union rows), all loader batches merged into ONE device-resident
 block-diagonal CSR.  A step = one GD training epoch of run.py:177-215: forward over every subgraph (2-layer GCN,
-hidden 512), one NLL loss, backward, Adam step (4 SpMM launches; edges aggregated = 4 * nnz').  The other configs
+hidden 512), one NLL loss, backward, Adam step (4 SpMM products over all nnz' entries: edges aggregated = 4 * nnz'; the two
+backward products run as ONE two-hop launch).  The other configs
 (--workload S-pubmed | S-physics | S-cora) are parity-test cases, selectable for A/B work.
 
 N>1 = data parallel, STRONG scaling: the ONE union is sharded by whole subgraphs (data.shard_clusters: LPT over
@@ -18,8 +19,8 @@ under torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE in the environment) 
 the parent then spawns N fresh children itself BEFORE it touches torch or the GPU and relays rank 0's line.
 
 Prints ONE JSON line (rank 0): the metric (dense products in the reference's fp32 arithmetic: csrc/gemm_f32.hip), `roofline` for
-the SpMM kernel over ALL FOUR launches of the step (HIP events around each launch inside the timed region; per-launch entries
-with their own compulsory bytes), `ms_per_step_bf16x3` (the same step with the dense products as a 3 x bf16 split: secondary),
+the SpMM kernel over ALL FOUR products of the step (HIP events around each launch inside the timed region; per-launch entries
+with the number of products they carry and their own compulsory bytes), `ms_per_step_bf16x3` (the same step with the dense products as a 3 x bf16 split: secondary),
 at N>1 `allreduce_ms` and the ranks' nnz', and at N=1 `cpu_baseline` (the torch-CPU oracle of the same step + the C oracle of the
 contraction, on this host).
 """
