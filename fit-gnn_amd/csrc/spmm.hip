@@ -393,7 +393,7 @@ constexpr int kBlkMeta = 128;  // CSR entries of a piece staged in LDS (threads 
 // there on the kernel is the plain product.  The column sums of dZ (every row of a block passes through a window once) leave as
 // in the backward form.
 template <bool XROW, bool BWD, bool NOEPI = false, bool TWO = false>
-__global__ __launch_bounds__(kThreads, BWD ? 4 : TWO ? 5 : XROW ? 6 : 7) void spmm_block_kernel(
+__global__ __launch_bounds__(kThreads, BWD ? 4 : TWO ? 6 : XROW ? 7 : 7) void spmm_block_kernel(
     const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col, const float *__restrict__ val,
     const float *__restrict__ X, int64_t ldx, float *__restrict__ Y, int64_t ldy, int32_t H,
     const fitgnn_block_t *__restrict__ blocks, int32_t n_blocks, const int32_t *__restrict__ long_rows, int32_t n_slabs,
@@ -436,7 +436,7 @@ __global__ __launch_bounds__(kThreads, BWD ? 4 : TWO ? 5 : XROW ? 6 : 7) void sp
     auto src = [&](int r) -> int64_t { return XROW ? (int64_t)xrow[r] : (int64_t)r; };  // operand row of pattern row / column r
     // operand row of CSR entry e (pattern column c): with the table, xcol[e] = xrow[col[e]] is listed per entry (the caller
     // builds it once per batch), so a gathered entry costs one dependent load, not two
-    auto ecol = [&](int e, int c) -> int { return (XROW && xcol) ? xcol[e] : (XROW ? xrow[c] : c); };
+    auto ecol = [&](int e, int c) -> int { return (TWO || (XROW && xcol)) ? xcol[e] : (XROW ? xrow[c] : c); };
     const int n_long = min(blk.n_long, kBlkLong);
     const float keep_scale = (epi & FITGNN_EPI_DROPOUT) ? 1.0f / (1.0f - p_drop) : 1.0f;
     const uint32_t thresh = fitgnn::dropout_threshold(p_drop);
@@ -450,7 +450,7 @@ __global__ __launch_bounds__(kThreads, BWD ? 4 : TWO ? 5 : XROW ? 6 : 7) void sp
 #pragma unroll
     for (int i = 0; i < 4; ++i) bv[i] = ((epi & FITGNN_EPI_BIAS) && live) ? bias[col0 + i] : 0.f;
 
-    const bool has_zero = XROW && zero_from >= 0;
+    const bool has_zero = XROW && !TWO && zero_from >= 0;   // (the two-hop form's table has no zero rows)
     auto is_zero_row = [&](int64_t opr) { return has_zero && opr >= (int64_t)zero_from; };
     // ---- piece prefetch (registers): window rows wave, wave + 4, ...; row pointers; the piece's CSR slice ----
     T pv[4];
@@ -507,7 +507,7 @@ __global__ __launch_bounds__(kThreads, BWD ? 4 : TWO ? 5 : XROW ? 6 : 7) void sp
         if ((int)threadIdx.x < kBlkMeta) {
             const int e = min(E0 + (int)threadIdx.x, blk.nnz_end - 1);
             p_c = col[e];
-            p_cx = (XROW && xcol) ? xcol[e] : p_c;
+            p_cx = (TWO || (XROW && xcol)) ? xcol[e] : p_c;
             p_v = val[e];
         }
         p_E0 = E0;
@@ -565,19 +565,20 @@ __global__ __launch_bounds__(kThreads, BWD ? 4 : TWO ? 5 : XROW ? 6 : 7) void sp
             }
             const unsigned long long in = __ballot(lc[q] < bound) >> pos[q];
             const int n_in = in == 0 ? 0 : (int)__builtin_popcountll(in);
-            for (int k = pos[q]; k < pos[q] + n_in; k += 8) {
+            constexpr int kLongBatch = (TWO || (XROW && !BWD)) ? 4 : 8;
+            for (int k = pos[q]; k < pos[q] + n_in; k += kLongBatch) {
                 const int last = pos[q] + n_in - 1;
-                T x[8];
-                float w[8];
+                T x[kLongBatch];
+                float w[kLongBatch];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
+                for (int u = 0; u < kLongBatch; ++u) {
                     const int kk = min(k + u, last);
                     const int64_t c = (XROW && xcol) ? (int64_t)__builtin_amdgcn_readlane(lcx[q], kk) : src(__builtin_amdgcn_readlane(lc[q], kk));
                     w[u] = k + u <= last ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lv[q]), kk)) : 0.f;
                     x[u] = is_zero_row(c) ? P::zero() : *reinterpret_cast<const T *>(Xs + c * ldx);   // wave-uniform
                 }
 #pragma unroll
-                for (int u = 0; u < 8; ++u) P::fma(acc_long[q], w[u], x[u]);
+                for (int u = 0; u < kLongBatch; ++u) P::fma(acc_long[q], w[u], x[u]);
             }
             pos[q] += n_in;
             cur[q] += n_in;
@@ -624,7 +625,7 @@ __global__ __launch_bounds__(kThreads, BWD ? 4 : TWO ? 5 : XROW ? 6 : 7) void sp
         if ((int)threadIdx.x < kBlkMeta) {   // entry -> LDS row (window slot, pinned row) or -(operand row + 1): resolved once, by the thread that stages it
             int sl = p_c - r0;
             if ((unsigned)sl >= (unsigned)rows) {
-                const int opr = (XROW && !xcol) ? (int)xrow[p_c] : p_cx;   // a gathered entry: its operand row
+                const int opr = (XROW && !TWO && !xcol) ? (int)xrow[p_c] : p_cx;   // a gathered entry: its operand row
                 sl = is_zero_row(opr) ? kZeroSlot : -(opr + 1);
 #pragma unroll
                 for (int i = 0; i < kBlkLong; ++i)
@@ -681,25 +682,33 @@ __global__ __launch_bounds__(kThreads, BWD ? 4 : TWO ? 5 : XROW ? 6 : 7) void sp
                         }
                     }
                 }
-                for (int k = 0; k < cnt; k += 4) {
-                    const int k1 = min(k + 1, cnt - 1), k2 = min(k + 2, cnt - 1), k3 = min(k + 3, cnt - 1);
-                    const int c0 = __builtin_amdgcn_readlane(my_c, k), c1 = __builtin_amdgcn_readlane(my_c, k1);
-                    const int c2 = __builtin_amdgcn_readlane(my_c, k2), c3 = __builtin_amdgcn_readlane(my_c, k3);
-                    const float w0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_v), k));
-                    const float w1 = k + 1 < cnt ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_v), k1)) : 0.f;
-                    const float w2 = k + 2 < cnt ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_v), k2)) : 0.f;
-                    const float w3 = k + 3 < cnt ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_v), k3)) : 0.f;
-                    T x0, x1, x2, x3;
-                    if ((c0 | c1 | c2 | c3) >= 0) {  // wave-uniform: four LDS reads in flight
-                        x0 = s_win[c0 * 64 + lane]; x1 = s_win[c1 * 64 + lane];
-                        x2 = s_win[c2 * 64 + lane]; x3 = s_win[c3 * 64 + lane];
-                    } else {
-                        if (c0 >= 0) x0 = s_win[c0 * 64 + lane]; else x0 = *reinterpret_cast<const T *>(Xs + (int64_t)(-(c0 + 1)) * ldx);
-                        if (c1 >= 0) x1 = s_win[c1 * 64 + lane]; else x1 = *reinterpret_cast<const T *>(Xs + (int64_t)(-(c1 + 1)) * ldx);
-                        if (c2 >= 0) x2 = s_win[c2 * 64 + lane]; else x2 = *reinterpret_cast<const T *>(Xs + (int64_t)(-(c2 + 1)) * ldx);
-                        if (c3 >= 0) x3 = s_win[c3 * 64 + lane]; else x3 = *reinterpret_cast<const T *>(Xs + (int64_t)(-(c3 + 1)) * ldx);
+                // kRowBatch window rows in flight per step (a last group is padded with its last entry at weight 0); the two-hop form
+                // takes two: a leaf's row is its own entry and its centre's, and the registers buy a workgroup per CU
+                constexpr int kRowBatch = (TWO || (XROW && !BWD)) ? 2 : 4;
+                for (int k = 0; k < cnt; k += kRowBatch) {
+                    int cq[kRowBatch];
+                    float wq[kRowBatch];
+                    T xq[kRowBatch];
+                    int all = 0;
+#pragma unroll
+                    for (int u = 0; u < kRowBatch; ++u) {
+                        const int ku = min(k + u, cnt - 1);
+                        cq[u] = __builtin_amdgcn_readlane(my_c, ku);
+                        wq[u] = (u == 0 || k + u < cnt) ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_v), ku)) : 0.f;
+                        all |= cq[u];
                     }
-                    P::fma(acc, w0, x0); P::fma(acc, w1, x1); P::fma(acc, w2, x2); P::fma(acc, w3, x3);
+                    if (all >= 0) {  // wave-uniform: every read from LDS
+#pragma unroll
+                        for (int u = 0; u < kRowBatch; ++u) xq[u] = s_win[cq[u] * 64 + lane];
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < kRowBatch; ++u) {
+                            if (cq[u] >= 0) xq[u] = s_win[cq[u] * 64 + lane];
+                            else xq[u] = *reinterpret_cast<const T *>(Xs + (int64_t)(-(cq[u] + 1)) * ldx);
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < kRowBatch; ++u) P::fma(acc, wq[u], xq[u]);
                 }
             }
             if (live) finish_row<4, BWD, NOEPI>(acc, row, col0, H, Y, ldy, bv, rowepi, cs, o_prev);
@@ -722,18 +731,20 @@ __global__ __launch_bounds__(kThreads, BWD ? 4 : TWO ? 5 : XROW ? 6 : 7) void sp
                 // entries are sorted by column: those of this piece are the lanes >= pos with col < r1
                 const unsigned long long in = __ballot(lc[q] < r1) >> pos[q];
                 const int n_in = in == 0 ? 0 : (int)__builtin_popcountll(in);
-                for (int k = pos[q]; k < pos[q] + n_in; k += 4) {
+                constexpr int kPieceBatch = (TWO || (XROW && !BWD)) ? 2 : 4;
+                for (int k = pos[q]; k < pos[q] + n_in; k += kPieceBatch) {
                     const int last = pos[q] + n_in - 1;
-                    const int k1 = min(k + 1, last), k2 = min(k + 2, last), k3 = min(k + 3, last);
-                    const int c0 = __builtin_amdgcn_readlane(lc[q], k) - r0, c1 = __builtin_amdgcn_readlane(lc[q], k1) - r0;
-                    const int c2 = __builtin_amdgcn_readlane(lc[q], k2) - r0, c3 = __builtin_amdgcn_readlane(lc[q], k3) - r0;
-                    const float w0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lv[q]), k));
-                    const float w1 = k + 1 <= last ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lv[q]), k1)) : 0.f;
-                    const float w2 = k + 2 <= last ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lv[q]), k2)) : 0.f;
-                    const float w3 = k + 3 <= last ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lv[q]), k3)) : 0.f;
-                    const T x0 = s_win[c0 * 64 + lane], x1 = s_win[c1 * 64 + lane];
-                    const T x2 = s_win[c2 * 64 + lane], x3 = s_win[c3 * 64 + lane];
-                    P::fma(acc_long[q], w0, x0); P::fma(acc_long[q], w1, x1); P::fma(acc_long[q], w2, x2); P::fma(acc_long[q], w3, x3);
+                    float wq[kPieceBatch];
+                    T xq[kPieceBatch];
+#pragma unroll
+                    for (int u = 0; u < kPieceBatch; ++u) {
+                        const int ku = min(k + u, last);
+                        const int cu = __builtin_amdgcn_readlane(lc[q], ku) - r0;
+                        wq[u] = (u == 0 || k + u <= last) ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lv[q]), ku)) : 0.f;
+                        xq[u] = s_win[cu * 64 + lane];
+                    }
+#pragma unroll
+                    for (int u = 0; u < kPieceBatch; ++u) P::fma(acc_long[q], wq[u], xq[u]);
                 }
                 pos[q] += n_in;
                 cur[q] += n_in;

@@ -36,6 +36,10 @@ kinds = {
     "compact operand + derivative in the store": lambda: ops.spmm_graph_dz(g, comp, prev, _lib.EPI_ELU | _lib.EPI_DROPOUT, p=0.5, seed=7, xrow=pos,
                                                                            zero_from=int(rows.numel())),
 }
+link = ops.EpilogueLink()
+link.record(True, 0.5, 7, None, True, g=g)
+if g.t.blocks is not None:
+    kinds["two-hop backward (dZ made in the window)"] = lambda: ops.spmm_two_hop_blocks(g, comp, prev, rows, pos, link)
 names = ["start-up (record -> first barrier)", "publish + barrier (waits for the prefetch)", "short rows", "long rows", "end-of-piece barrier", "tail (long rows out)"]
 for kind, fn in kinds.items():
     fn(); torch.cuda.synchronize()
