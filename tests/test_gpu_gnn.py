@@ -475,6 +475,73 @@ def test_head_on_selected_rows(mods, H, C, n_rows):
     assert rel(y0.index_select(0, rows), (ref - bl).index_select(0, rows)) < 2e-6
 
 
+@pytest.mark.parametrize("layers,dedup", [(2, False), (3, False), (2, True)])
+def test_two_hop_backward_in_the_model(mods, layers, dedup):
+    """embed_and_head(loss_rows=..., compact_logits=True) on a batch that runs on the whole-subgraph kernel: with
+    OpConfig.two_hop_backward the layer below the last one (a plain fused GCN layer, or layer 0 on a de-duplicated table) receives
+    A_hat^T dZ from the last layer's backward and skips its own SpMM -- same logits, same loss, the same weight gradients BIT FOR BIT as
+    with the two separate launches (bias gradient of that layer: fp32 summation order), dropout on (the same injected masks)."""
+    from fitgnn_amd import csr, ops
+
+    network, fnn, gorc = mods
+    rng = np.random.default_rng(4)
+    sizes = [60, 130, 18, 40, 300, 25, 90]
+    src, dst, off = [], [], 0
+    for s_ in sizes:   # stars with two centres and a few leaf -- leaf edges
+        for h in range(2):
+            leaves = np.arange(2, s_)
+            src += [off + h] * len(leaves) + (off + leaves).tolist()
+            dst += (off + leaves).tolist() + [off + h] * len(leaves)
+        a, b = rng.integers(2, s_, size=s_ // 4), rng.integers(2, s_, size=s_ // 4)
+        k = a != b
+        src += (off + a[k]).tolist() + (off + b[k]).tolist()
+        dst += (off + b[k]).tolist() + (off + a[k]).tolist()
+        off += s_
+    n = off
+    ei = torch.tensor(np.unique(np.array([src, dst]), axis=1), dtype=torch.long).cuda()
+    ptr = np.concatenate([[0], np.cumsum(sizes)])
+    g = csr.CSRGraph(ei, n, mode="gcn", ptr=ptr, block_limit=4096)
+    assert g.t.blocks is not None
+    csr.register(ei, g)
+    rows = torch.cat([torch.arange(2) + o for o in ptr[:-1]]).cuda()
+    args = argparse.Namespace(num_layers1=layers, layer_name="GCNConv", num_features=24, hidden=64, num_classes=5)
+    torch.manual_seed(3)
+    m = network.Classify_node(args).cuda()
+    m.train()
+    m.dropout_p = 0.5
+    y = torch.randint(0, 5, (n,)).cuda()
+    if dedup:
+        n_table = n // 3
+        index = torch.randint(0, n_table, (n,)).cuda()
+        x, x_index = torch.randn(n_table, 24).cuda(), ops.RowIndex(index, n_table)
+    else:
+        x, x_index = torch.randn(n, 24).cuda(), None
+    res = []
+    for two in (True, False):
+        cfg = ops.OpConfig(two_hop_backward=two, profile=[])
+        m.set_op_config(cfg)
+        m.zero_grad()
+        torch.manual_seed(11)
+        m._inject_masks = [(torch.rand(n, 64, device="cuda") > 0.5).to(torch.uint8) for _ in range(layers)]
+        z = m.embed_and_head(x, ei, x_index, loss_rows=rows, compact_logits=True)
+        assert z.shape == (rows.numel(), 5)
+        loss = torch.nn.functional.nll_loss(torch.log_softmax(z, 1), y.index_select(0, rows), reduction="sum")
+        loss.backward()
+        kinds = [k for _, _, k in cfg.profile]
+        assert ("two_hop" in kinds) == two, kinds
+        res.append((z.detach().clone(), float(loss.detach()), {k: p.grad.clone() for k, p in m.named_parameters()}))
+    m._inject_masks = None
+    m.set_op_config(ops.DEFAULT)
+    (z1, l1, g1), (z0, l0, g0) = res
+    assert torch.equal(z1, z0) and l1 == l0
+    below = "conv.%d.bias" % (layers - 2)
+    for k in g0:
+        if k == below:
+            assert rel(g1[k], g0[k]) < 1e-5, k
+        else:
+            assert torch.equal(g1[k], g0[k]), k
+
+
 def test_loss_rows_hint_changes_nothing_the_loss_sees(mods):
     """embed_and_head(loss_rows=...) in its three forms -- last layer aggregate-first with the dense part on the loss rows
     (default), transform-first with the head and a compact dZ on the loss rows, transform-first with only the head's weight
