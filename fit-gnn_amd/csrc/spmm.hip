@@ -415,6 +415,7 @@ __global__ __launch_bounds__(kThreads, BWD ? 4 : TWO ? 6 : XROW ? 7 : 7) void sp
     __shared__ int32_t s_col[kBlkMeta];
     __shared__ float s_val[kBlkMeta];
     __shared__ int32_t s_long[kBlkLong];
+    __shared__ int32_t s_hub_pos;   // TWO: compact position of the block's first long row if it is a loss row (its operand row sits in the zero slot)
     // block -> (record position, slab) as in the tile kernel: position p runs on XCD p % 8 with both of its slabs; the host
     // gives every XCD a contiguous range of the batch (records with row_begin == row_end pad the short ranges)
     const int bid = blockIdx.x;
@@ -459,9 +460,12 @@ __global__ __launch_bounds__(kThreads, BWD ? 4 : TWO ? 6 : XROW ? 7 : 7) void sp
     float p_v = 0.f;
     int xr_next = 0;  // XROW: lane j < 4 holds the table row of window row wave + 4 j of the NEXT piece to prefetch
     int xp_next = 0, xw_next = 0;   // TWO: ... and the compact operand row / weight of a simple row's one loss column
-    int xr_pub = 0, xw_pub = 0, xp_pub = 0;   // TWO: the same for the piece whose rows are in pv (published at the top of the piece loop)
-    T hv = P::zero();               // TWO: the compact operand row of the prefetched simple rows' loss column -- ONE per wave and piece, that of
-    int hv_pos = 0x7fffffff;        //      the first such row (the leaves of a star share their centre); a row with another one loads it late
+    // TWO: the same for the piece whose rows are in pv (published at the top of the piece loop), held as scalars; the compact
+    // operand row a simple row needs is its block's first long row's (the leaves of a star and their centre): kept in the LDS slot the
+    // compact forms use for their row of zeros; a row with another loss column loads that row late
+    int sr_pub[4] = {0, 0, 0, 0}, pp_pub[4] = {0, 0, 0, 0};
+    float w_pub[4] = {0.f, 0.f, 0.f, 0.f};
+    int hub_pos = 0x7fffffff;
     auto fetch_indices = [&](int r0, int r1) {
         if (XROW) {
             const int r = r0 + wave + lane * kWaves;
@@ -474,7 +478,7 @@ __global__ __launch_bounds__(kThreads, BWD ? 4 : TWO ? 6 : XROW ? 7 : 7) void sp
     };
     auto prefetch = [&](int r0, int r1, int E0) {
         const int xr = xr_next;
-        if (TWO) { xr_pub = xr; xw_pub = xw_next; xp_pub = xp_next; hv_pos = 0x7fffffff; }
+
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int r = r0 + wave + j * kWaves;
@@ -487,10 +491,9 @@ __global__ __launch_bounds__(kThreads, BWD ? 4 : TWO ? 6 : XROW ? 7 : 7) void sp
                 const int pp = __builtin_amdgcn_readlane(xp_next, j);
                 const T a = *reinterpret_cast<const T *>(rowp);
                 pv[j] = r < r1 ? a : P::zero();
-                if (r < r1 && sr < 0 && pp < xc_zero_from && hv_pos == 0x7fffffff) {   // wave-uniform
-                    hv_pos = pp;
-                    hv = *reinterpret_cast<const T *>(Xc2 + (int64_t)pp * ldxc + colc2);
-                }
+                sr_pub[j] = (int)sr;
+                pp_pub[j] = pp;
+                w_pub[j] = __int_as_float(__builtin_amdgcn_readlane(xw_next, j));
             } else if (r < r1 && !is_zero_row(sr)) {
                 pv[j] = *reinterpret_cast<const T *>(Xs + sr * ldx);   // wave-uniform
             }
@@ -515,7 +518,8 @@ __global__ __launch_bounds__(kThreads, BWD ? 4 : TWO ? 6 : XROW ? 7 : 7) void sp
     // ---- the block's long rows: ids to LDS, their operand rows pinned, this wave's two accumulators and entry cursors ----
     fetch_indices(blk.row_begin, min(blk.row_begin + kBlkRows, blk.row_end));   // (table row ids of the first piece)
     if ((int)threadIdx.x < kBlkLong) s_long[threadIdx.x] = (int)threadIdx.x < n_long ? long_rows[blk.long_off + threadIdx.x] : -1;
-    if (XROW && (int)threadIdx.x < 64) s_win[kZeroSlot * 64 + threadIdx.x] = P::zero();
+    if (XROW && !TWO && (int)threadIdx.x < 64) s_win[kZeroSlot * 64 + threadIdx.x] = P::zero();
+    if (TWO && threadIdx.x == 0) s_hub_pos = 0x7fffffff;
     int my_long[kBlkLW], cur[kBlkLW], end[kBlkLW], pos[kBlkLW], lc[kBlkLW], lcx[kBlkLW];
     float lv[kBlkLW];
     T acc_long[kBlkLW];
@@ -542,9 +546,14 @@ __global__ __launch_bounds__(kThreads, BWD ? 4 : TWO ? 6 : XROW ? 7 : 7) void sp
             end[q] = __builtin_amdgcn_readfirstlane(rowptr[my_long[q] + 1]);
             const int64_t lr_src = src(my_long[q]);
             s_win[(kBlkRows + slot) * 64 + lane] = is_zero_row(lr_src) ? P::zero() : *reinterpret_cast<const T *>(Xs + lr_src * ldx);
+            if (TWO && slot == 0 && lr_src < (int64_t)xc_zero_from) {   // wave 0: the centre is a loss row, its table row number is its compact position
+                s_win[kZeroSlot * 64 + lane] = *reinterpret_cast<const T *>(Xc2 + lr_src * ldxc + colc2);
+                if (lane == 0) s_hub_pos = (int)lr_src;
+            }
         }
     }
     __syncthreads();
+    if (TWO) hub_pos = __builtin_amdgcn_readfirstlane(s_hub_pos);
     int lid[kBlkLong];  // the long-row ids, wave-uniform
 #pragma unroll
     for (int i = 0; i < kBlkLong; ++i) lid[i] = __builtin_amdgcn_readfirstlane(s_long[i]);
@@ -604,13 +613,13 @@ __global__ __launch_bounds__(kThreads, BWD ? 4 : TWO ? 6 : XROW ? 7 : 7) void sp
             if (r < rows) {
                 T v = pv[j];
                 if (TWO) {
-                    if (__builtin_amdgcn_readlane(xr_pub, j) < 0) {   // a simple row: pv is its `prev` slice
+                    if (sr_pub[j] < 0) {   // a simple row: pv is its `prev` slice
                         T u = P::zero();
-                        const int pp = __builtin_amdgcn_readlane(xp_pub, j);
+                        const int pp = pp_pub[j];
                         T h = P::zero();
-                        if (pp == hv_pos) h = hv;
+                        if (pp == hub_pos) h = s_win[kZeroSlot * 64 + lane];
                         else if (pp < xc_zero_from) h = *reinterpret_cast<const T *>(Xc2 + (int64_t)pp * ldxc + colc2);
-                        P::fma(u, __int_as_float(__builtin_amdgcn_readlane(xw_pub, j)), h);
+                        P::fma(u, w_pub[j], h);
                         v = epilogue_value<4, true, false>(u, r0 + r, col0, H, bv, rowepi, cs, pv[j]);
                     } else {
 #pragma unroll

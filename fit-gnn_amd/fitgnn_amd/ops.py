@@ -745,7 +745,8 @@ def spmm_two_hop_blocks(g, Xc, prev, rows, pos, link, cfg=DEFAULT, profile_kind=
     if side.small_tiles.shape[0]:
         spmm_raw(side.rowptr, side.col, side.val, side.small_tiles, ZT, g.n, window_rows=g.window_rows, out=Y, cfg=quiet, xrow=ix["zrow"])
     n_blocks = int(side.blocks.shape[0])
-    part = torch.zeros((n_blocks, H), dtype=torch.float32, device=dev) if link.want_db else None
+    # one partial row of column sums per block + one for the rows outside the blocks (their dZ sits in the table)
+    part = torch.zeros((n_blocks + 1, H), dtype=torch.float32, device=dev) if link.want_db else None
     _lib.check(L.fitgnn_spmm_two_hop_blocks_f32(_lib.dptr(side.rowptr), _lib.dptr(side.col), _lib.dptr(side.val), _lib.dptr(ZT), ZT.stride(0),
                                                 _lib.dptr(Y), Y.stride(0), g.n, H, _lib.dptr(side.blocks), n_blocks, _lib.dptr(side.long_rows),
                                                 _lib.dptr(ix["zrow"]), _lib.dptr(ix["zcol"]), _lib.dptr(prev), _lib.dptr(Xc), Xc.stride(0), n_sel,
@@ -754,7 +755,7 @@ def spmm_two_hop_blocks(g, Xc, prev, rows, pos, link, cfg=DEFAULT, profile_kind=
     db = None
     if link.want_db:
         if ix["tile_zt"].numel():
-            part = torch.cat([part, ZT.index_select(0, ix["tile_zt"]).sum(0, keepdim=True)])
+            torch.sum(ZT.index_select(0, ix["tile_zt"]), 0, out=part[n_blocks])
         db = _fold_partials(part, dev, st)
     if ev is not None:
         ev[1].record()
