@@ -116,6 +116,32 @@ def spawn_ranks(n):
     return rc
 
 
+def pmc_traffic(launches, workload):
+    """`traffic`: HBM bytes per SpMM product from the COMMITTED rocprofv3 --pmc passes of this command (profiles/r03_pmc_bench_kernels.json,
+    tools/profile_round.sh: FETCH_SIZE / WRITE_SIZE in passes of their own, (2 FETCH_SIZE + WRITE_SIZE) * 1024 per the guide's gfx950
+    correction) -- counters cannot be read inside the timed run.  Only for the default workload and launch list the passes were taken
+    on; null otherwise."""
+    kernels = {"table": ["spmm_block_kernel<true, false, false, false>"], "tile": ["spmm_block_kernel<false, false, true, false>"],
+               "two_hop": ["spmm_block_kernel<true, false, true, true>", "two_hop_rows_kernel"]}
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_pmc_bench_kernels.json")
+    try:
+        if workload != "S-products" or not launches:
+            raise KeyError(workload)
+        with open(path) as fh:
+            pmc = json.load(fh)
+        total, products = 0.0, 0
+        for l in launches:
+            b = sum(pmc[k]["hbm_bytes_per_launch"] for k in kernels[l["kind"]])
+            l["pmc_hbm_bytes"] = b
+            total += b
+            products += l.get("products", 1)
+        return {"traffic": total / products,
+                "traffic_note": "mean HBM bytes per SpMM product over the step's launches, from profiles/r03_pmc_bench_kernels.json (rocprofv3 --pmc "
+                                "passes of this command on another run; per launch: launches[].pmc_hbm_bytes)"}
+    except (OSError, KeyError, ValueError):
+        return {"traffic": None}
+
+
 def cpu_model():
     try:
         with open("/proc/cpuinfo") as f:
@@ -450,7 +476,7 @@ def main():
                                 "the small ones; H=%d, f32)" if batch.graph.f.blocks is not None else
                                 "spmm_tile_kernel (CSR SpMM, LDS row windows, H=%d, f32)") % H, "bound": "hbm", "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": None,   # PMC bytes cannot be read inside the run: profiles/ holds the rocprofv3 --pmc passes of this command
+                     **pmc_traffic(launches, args.workload),
                      "covers": covers,
                      "algorithmic_bytes_per_launch": bytes_spmm, "spmm_ms_per_step": sum_ms if launches else None,
                      "launches": launches,
