@@ -50,7 +50,7 @@ def _model(name, seed=2, dropout=0.5):
     return network.Classify_node(args).cuda()
 
 
-def _fast_path(model, batch, scale, masks=None):
+def _fast_path(model, batch, scale, masks=None, **cfg_kw):
     """Forward + fused loss + backward EXACTLY as GDTrainer.step issues them (train.py:189): the de-duplicated layer-0 table, then
     embed_and_head(..., loss_rows=batch.train_idx, compact_logits=True) under the default OpConfig -> ops.FusedGCNLastLayerRows
     (aggregate-first last layer, the head on the loss rows, compact dZ, the backward SpMM with layer 0's ELU' / dropout' in its
@@ -63,7 +63,7 @@ def _fast_path(model, batch, scale, masks=None):
     from fitgnn_amd import ops
     from fitgnn_amd.ops import SoftmaxNLL
 
-    cfg = ops.OpConfig(profile=[])            # the default switches (what GDTrainer runs under) + the launch log
+    cfg = ops.OpConfig(profile=[], **cfg_kw)  # the default switches (what GDTrainer runs under) + the launch log
     model.set_op_config(cfg)
     if masks is None:
         model.eval()
@@ -84,7 +84,7 @@ def _fast_path(model, batch, scale, masks=None):
     assert any(k in ("table", "gather") for k in kinds), kinds   # layer 0 on the de-duplicated table
     model._inject_masks = None
     model.set_op_config(ops.DEFAULT)
-    return z.detach(), float(loss), {k: p.grad.detach().clone() for k, p in model.named_parameters()}, kinds
+    return z.detach(), float(loss.detach()), {k: p.grad.detach().clone() for k, p in model.named_parameters()}, kinds
 
 
 def test_partition_properties(cfg):
@@ -122,6 +122,16 @@ def test_sampled_loader_slices_match_the_oracle_and_the_full_union(cfg):
     if name == "S-products":   # the union whose stars go to the whole-subgraph kernel: all four products of the step ran, the two
         # backward ones in the two-hop launch
         assert full.graph.f.blocks is not None and kinds_full.count("tile") == 1 and kinds_full.count("two_hop") == 1, kinds_full
+        # ... and the two-hop pass gives the two separate launches' gradients at full size (8.2 M rows, a 5-GB side table): bit for bit,
+        # layer 0's bias gradient to fp32 summation order
+        z2, loss2, g2, kinds2 = _fast_path(model, full, scale, two_hop_backward=False)
+        assert kinds2.count("tile") == 2 and "compact_dz" in kinds2 and "two_hop" not in kinds2, kinds2
+        assert torch.equal(z2, z_full) and loss2 == loss_full
+        for k in g_full:
+            if k == "conv.0.bias":
+                assert float((g2[k] - g_full[k]).abs().max()) <= 1e-5 * float(g_full[k].abs().max()) + 1e-12, k
+            else:
+                assert torch.equal(g2[k], g_full[k]), k
     full_idx = full.train_idx
     n_batches = (n_c + 127) // 128
     picks = sorted({0, n_batches // 3, (2 * n_batches) // 3, n_batches - 1})
