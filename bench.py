@@ -119,8 +119,8 @@ def spawn_ranks(n):
 def pmc_traffic(launches, workload):
     """`traffic`: HBM bytes per SpMM product from the COMMITTED rocprofv3 --pmc passes of this command (profiles/r03_pmc_bench_kernels.json,
     tools/profile_round.sh: FETCH_SIZE / WRITE_SIZE in passes of their own, (2 FETCH_SIZE + WRITE_SIZE) * 1024 per the guide's gfx950
-    correction) -- counters cannot be read inside the timed run.  Only for the default workload and launch list the passes were taken
-    on; null otherwise."""
+    correction) -- counters cannot be read inside the timed run.  Only for the default workload on ONE GPU and the launch list the
+    passes were taken on; null otherwise (a rank's shard moves 1/N of these bytes)."""
     kernels = {"table": ["spmm_block_kernel<true, false, false, false>"], "tile": ["spmm_block_kernel<false, false, true, false>"],
                "two_hop": ["spmm_block_kernel<true, false, true, true>", "two_hop_rows_kernel"]}
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_pmc_bench_kernels.json")
@@ -476,7 +476,7 @@ def main():
                                 "the small ones; H=%d, f32)" if batch.graph.f.blocks is not None else
                                 "spmm_tile_kernel (CSR SpMM, LDS row windows, H=%d, f32)") % H, "bound": "hbm", "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     **pmc_traffic(launches, args.workload),
+                     **pmc_traffic(launches, args.workload if world == 1 else None),
                      "covers": covers,
                      "algorithmic_bytes_per_launch": bytes_spmm, "spmm_ms_per_step": sum_ms if launches else None,
                      "launches": launches,
