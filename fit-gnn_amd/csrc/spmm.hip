@@ -617,8 +617,10 @@ __global__ __launch_bounds__(kThreads, BWD ? 4 : TWO ? 6 : XROW ? 7 : 7) void sp
                         T u = P::zero();
                         const int pp = pp_pub[j];
                         T h = P::zero();
-                        if (pp == hub_pos) h = s_win[kZeroSlot * 64 + lane];
-                        else if (pp < xc_zero_from) h = *reinterpret_cast<const T *>(Xc2 + (int64_t)pp * ldxc + colc2);
+                        if (pp < xc_zero_from) {   // (a row without a loss column: h stays 0 -- the slot below may never have been written)
+                            if (pp == hub_pos) h = s_win[kZeroSlot * 64 + lane];
+                            else h = *reinterpret_cast<const T *>(Xc2 + (int64_t)pp * ldxc + colc2);
+                        }
                         P::fma(u, w_pub[j], h);
                         v = epilogue_value<4, true, false>(u, r0 + r, col0, H, bv, rowepi, cs, pv[j]);
                     } else {
