@@ -491,3 +491,77 @@ def test_stream_ranges_cover_whole_segments():
     assert rs.tolist() == [0, 2]
     with pytest.raises(ValueError):
         stream_ranges(np.array([0, 3]), 10, "cpu")
+
+
+def test_two_hop_index_covers_every_entry_the_kernel_cannot_serve_from_lds():
+    """ops._two_hop_block_index (the side-table index of fitgnn_spmm_two_hop_blocks_f32) on the CPU, against a literal restatement of
+    which entries the whole-subgraph kernel serves from LDS -- row and column in the same 16-row piece of the same block, the column a
+    carried long row of the row's block (the first four of the block's long rows), or the row itself one: every other entry's
+    column has a table row, as have the loss rows, the carried long rows, the rows outside the blocks and the rows with two or more
+    loss columns; every remaining ("simple") row has at most one loss column and row_p / row_w name it."""
+    import types
+    import torch
+    from fitgnn_amd import csr, ops
+
+    rng = np.random.default_rng(5)
+    sizes = [40, 7, 120, 16, 17, 300, 3, 64]
+    src, dst, off = [], [], 0
+    for s_ in sizes:   # stars with three centres (rows 0..2 of a block) and some leaf -- leaf edges
+        for h in range(min(3, s_ - 1)):
+            leaves = np.arange(3, s_) if s_ > 3 else np.arange(1, s_)
+            src += [off + h] * len(leaves) + (off + leaves).tolist()
+            dst += (off + leaves).tolist() + [off + h] * len(leaves)
+        if s_ > 8:
+            a, b = rng.integers(0, s_, size=s_), rng.integers(0, s_, size=s_)
+            k = a != b
+            src += (off + a[k]).tolist() + (off + b[k]).tolist()
+            dst += (off + b[k]).tolist() + (off + a[k]).tolist()
+        off += s_
+    n = off
+    e = np.unique(np.array([src + list(range(n)), dst + list(range(n))]), axis=1)   # with self loops, (row, col) sorted
+    rowptr = np.zeros(n + 1, dtype=np.int64)
+    np.add.at(rowptr, e[0] + 1, 1)
+    rowptr = np.cumsum(rowptr)
+    col = e[1]
+    ptr = np.concatenate([[0], np.cumsum(sizes)])
+    small, blocks, long_rows = csr.split_blocks(ptr, torch.from_numpy(rowptr.astype(np.int32)), 16, 4096)
+    assert len(blocks) and len(long_rows)
+    side = types.SimpleNamespace(rowptr=torch.from_numpy(rowptr.astype(np.int32)), col=torch.from_numpy(col.astype(np.int32)),
+                                 val=torch.from_numpy(rng.random(len(col)).astype(np.float32)), blocks=torch.from_numpy(blocks),
+                                 long_rows=torch.from_numpy(long_rows if len(long_rows) else np.zeros(1, np.int32)))
+    g = types.SimpleNamespace(t=side, n=n)
+    rows = torch.from_numpy(np.sort(rng.choice(n, size=n // 5, replace=False)).astype(np.int64))
+    n_sel = int(rows.numel())
+    pos = n_sel + torch.arange(n, dtype=torch.int32) % ops.ZERO_ROWS
+    pos[rows] = torch.arange(n_sel, dtype=torch.int32)
+    ix = ops._two_hop_block_index(g, rows, pos)
+    zrow, zcol, zt_rows = ix["zrow"].numpy(), ix["zcol"].numpy(), ix["zt_rows"].numpy()
+    assert np.array_equal(zt_rows[:n_sel], rows.numpy()) and len(set(zt_rows.tolist())) == len(zt_rows)
+    assert np.array_equal(zrow[zt_rows], np.arange(len(zt_rows))) and int((zrow >= 0).sum()) == len(zt_rows)
+    # the kernel's rule, literally
+    block_of, piece_of, carried = np.full(n, -1), np.zeros(n, dtype=np.int64), np.zeros(n, dtype=bool)
+    for b, rec in enumerate(blocks):
+        r0, r1, _, _, loff, nl = rec[:6]
+        block_of[r0:r1] = b
+        piece_of[r0:r1] = (np.arange(r0, r1) - r0) // 16
+        carried[long_rows[loff:loff + min(nl, 4)]] = True
+    is_loss = np.zeros(n, dtype=bool); is_loss[rows.numpy()] = True
+    for r in range(n):
+        cols = col[rowptr[r]:rowptr[r + 1]]
+        loss_cols = [c for c in cols if is_loss[c]]
+        for j, c in enumerate(cols):
+            served = block_of[r] >= 0 and block_of[r] == block_of[c] and (piece_of[r] == piece_of[c] or carried[c] or carried[r])
+            zc = zcol[rowptr[r] + j]
+            assert zc == (zrow[c] if zrow[c] >= 0 else ops.NO_ROW)
+            assert served or zc != ops.NO_ROW, (r, c)
+            assert not is_loss[c] or zc == pos[c]   # a loss column's table row is its compact position (its operand row)
+        if block_of[r] < 0 or carried[r] or is_loss[r] or len(loss_cols) >= 2:
+            assert zrow[r] >= 0, r
+        if zrow[r] < 0:   # a simple row
+            assert len(loss_cols) <= 1
+            if loss_cols:
+                j = list(cols).index(loss_cols[0])
+                assert ix["row_p"][r] == pos[loss_cols[0]] and float(ix["row_w"][r]) == float(side.val[rowptr[r] + j])
+            else:
+                assert int(ix["row_p"][r]) == ops.NO_ROW and float(ix["row_w"][r]) == 0.0
+    assert np.array_equal(np.sort(ix["tile_zt"].numpy()), np.sort(zrow[block_of < 0]))
