@@ -1225,7 +1225,8 @@ class FusedGCNLastLayerRows(torch.autograd.Function):
         if drop:
             epi |= EPI_DROPOUT
         epilogue_fwd_rows_(outc, rows, b, epi, p=p if drop else 0.0, seed=seed, mask=mask if drop else None)
-        if _exact(cfg, outc, Wl):
+        if _exact(cfg, outc, Wl) and Wl.shape[0] >= 16:
+            # (a head of a few classes stays on head_rows_kernel: a 128-column MFMA tile for 3 columns is slower than its LDS-resident weights)
             # the head on the kept rows as one more exact-fp32 product: [n, H] @ [C, H]^T on the fp32 MFMA (a 256 x 128 tile of which C
             # columns are stored: 0.2 ms at S-products against 0.68 ms for head_rows_kernel's LDS-resident weights), bias added after;
             # the [R, C] form is the same values scattered into zeros
