@@ -225,6 +225,10 @@ struct Plan {
     int wm, wn;          // wave grid of the tile
     int tiles_i, tiles_j, nchunks;
     long chunk_k;
+    // the last, mostly empty round of a long grid as a launch of its own (k-minor a only): rows [main_rows, I) split eight ways over k
+    long main_rows;      // 0: one launch
+    int rem_tiles_i, rem_chunks;
+    long rem_chunk_k;
 };
 
 Plan make_plan(long I, int J, long K, bool akm, bool bkm) {
@@ -261,6 +265,22 @@ Plan make_plan(long I, int J, long K, bool akm, bool bkm) {
         const long per = (K + p.nchunks - 1) / p.nchunks;
         p.chunk_k = (per + kBK - 1) / kBK * kBK;   // (a last chunk may come out empty: it stores zeros)
     }
+    // The tail of a long grid: 1 290 tiles (165 000 rows x 512 columns) are 5.04 rounds of 256 workgroups, and the sixth round keeps 10
+    // CUs busy for a whole tile's time.  With the row-major operand on the a side the rows of that last round can be a launch of
+    // their own, split eight ways over k (80 workgroups of an eighth of a tile each, their 2-MB partials summed in a fixed order):
+    // 5 + 1/8 rounds instead of 6.  Not for a grid of less than one full round (its partials would be the whole output).
+    p.main_rows = 0; p.rem_tiles_i = 0; p.rem_chunks = 1; p.rem_chunk_k = K;
+    const long T = (long)p.tiles_i * p.tiles_j;
+    const long full = T / 256, rem = T % 256;
+    if (!akm && p.nchunks == 1 && full >= 1 && rem > 0 && rem <= 96 && K >= 8 * 2 * kBK && !getenv("FITGNN_GEMM_CHUNKS") && !getenv("FITGNN_GEMM_NO_TAIL")) {
+        const long main_tiles_i = full * 256 / p.tiles_j;
+        if (main_tiles_i >= 1 && main_tiles_i < p.tiles_i) {
+            p.main_rows = main_tiles_i * TI;
+            p.rem_tiles_i = (int)(p.tiles_i - main_tiles_i);
+            p.rem_chunks = 8;
+            p.rem_chunk_k = ((K + 7) / 8 + kBK - 1) / kBK * kBK;
+        }
+    }
     return p;
 }
 
@@ -291,6 +311,7 @@ int launch_shape(const Plan &p, const float *a, long lda, const float *b, long l
 extern "C" size_t fitgnn_gemm_exact_workspace_bytes(int64_t I, int32_t J, int64_t K, int32_t a_kmajor, int32_t b_kmajor) {
     if (I <= 0 || J <= 0 || K <= 0) return 0;
     const Plan p = make_plan((long)I, J, (long)K, a_kmajor != 0, b_kmajor != 0);
+    if (p.main_rows > 0) return (size_t)p.rem_chunks * (size_t)(I - p.main_rows) * (size_t)J * sizeof(float);
     return p.nchunks > 1 ? (size_t)p.nchunks * (size_t)I * (size_t)J * sizeof(float) : 0;
 }
 
@@ -307,6 +328,27 @@ extern "C" int fitgnn_gemm_exact_f32(const float *a, int64_t lda, int32_t a_kmaj
     if (a_kmajor && !b_kmajor) return FITGNN_E_BADARG;   // no caller: (k-major, k-minor) is the transpose of (k-minor, k-major)
     const Plan p = make_plan((long)I, J, (long)K, a_kmajor != 0, b_kmajor != 0);
     hipStream_t s = (hipStream_t)stream;
+    if (p.main_rows > 0) {   // (k-minor a) the full rounds, then the rows of the last round split over k
+        if (!workspace || ((uintptr_t)workspace % 16) != 0) return FITGNN_E_BADARG;
+        Plan pm = p, pr = p;
+        pm.tiles_i = (int)(p.main_rows / (64 * p.wm));
+        pr.tiles_i = p.rem_tiles_i; pr.nchunks = p.rem_chunks; pr.chunk_k = p.rem_chunk_k;
+        const long rem_rows = (long)I - p.main_rows;
+        const float *a_rem = a + p.main_rows * (long)lda;
+        int rc;
+        if (b_kmajor) {
+            rc = launch_shape<false, true>(pm, a, (long)lda, b, (long)ldb, p.main_rows, J, (long)K, c, (long)ldc, s);
+            if (!rc) rc = launch_shape<false, true>(pr, a_rem, (long)lda, b, (long)ldb, rem_rows, J, (long)K, (float *)workspace, (long)J, s);
+        } else {
+            rc = launch_shape<false, false>(pm, a, (long)lda, b, (long)ldb, p.main_rows, J, (long)K, c, (long)ldc, s);
+            if (!rc) rc = launch_shape<false, false>(pr, a_rem, (long)lda, b, (long)ldb, rem_rows, J, (long)K, (float *)workspace, (long)J, s);
+        }
+        if (rc) return rc;
+        const long IJ = rem_rows * J;
+        hipLaunchKernelGGL(sum_chunks_kernel, dim3((unsigned)((IJ + 255) / 256)), dim3(256), 0, s, (const float *)workspace, pr.nchunks, IJ,
+                           c + p.main_rows * (long)ldc, J, (long)ldc);
+        return (int)hipGetLastError();
+    }
     float *dst = c;
     long ldd = (long)ldc;
     if (p.nchunks > 1) {

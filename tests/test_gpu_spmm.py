@@ -619,8 +619,9 @@ def test_weight_gradient_gemm_is_the_split_policys_path(mods):
 # down), rows around the 256 / 64-row tiles, k around the 32-wide stage and the chunking of the split-k form, strided operands.
 EXACT_SHAPES = {
     "nt": [(90549, 512, 512), (20000, 512, 100), (4097, 260, 96), (1024, 512, 32), (257, 64, 64), (5, 4, 36), (19717, 500, 512),
-           (300, 128, 500), (1, 4, 4)],
-    "nn": [(90549, 512, 512), (4097, 96, 260), (257, 64, 64), (19717, 512, 500), (5, 36, 4), (1000, 100, 512)],
+           (300, 128, 500), (1, 4, 4), (33068, 512, 512), (34493, 512, 1024)],   # the last two: a last round of 4 / 14 tiles, launched split over k
+    "nn": [(90549, 512, 512), (4097, 96, 260), (257, 64, 64), (19717, 512, 500), (5, 36, 4), (1000, 100, 512), (33068, 512, 512),
+           (165000, 512, 512)],
     "tn": [(90549, 512, 512), (19717, 512, 500), (165000, 48, 512), (40000, 512, 100), (4097, 260, 36), (1000, 64, 128), (256, 512, 4),
            (33, 8, 4), (31, 8, 8), (2048, 4, 4), (1, 4, 4), (2047, 64, 512)],
 }
