@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """GPU-box tool: the greedy selection (helper waves racing the selecting wave) 40 times per graph against the C oracle: the result
-must not depend on the helpers' timing (120 runs, 0 mismatches on 2026-10-04)."""
+must not depend on the helpers' timing (120 runs, 0 mismatches: profiles/r03_stress_greedy.log)."""
 import os, sys
 ROOT = "/root/repo"
 for p in (ROOT, os.path.join(ROOT, "fit-gnn_amd"), os.path.join(ROOT, "tests")):
