@@ -385,7 +385,7 @@ constexpr int kBlkMeta = 128;  // CSR entries of a piece staged in LDS (threads 
 
 // XROW: operand row r of the pattern lives at X[xrow[r]] (a de-duplicated operand table, as in the tile kernel): the window
 // rows' table indices are fetched one piece ahead of the rows themselves, so the prefetch never waits on an index.
-// TWO (with XROW, NOEPI): the two-hop backward, fitgnn_spmm_two_hop_dz_f32.  The operand of the product is dZ of the layer below,
+// TWO (with XROW, NOEPI): the two-hop backward, fitgnn_spmm_two_hop_blocks_f32.  The operand of the product is dZ of the layer below,
 // which is not stored: X is the side table ZT (dZ of the rows that have to be readable from anywhere), xrow[r] >= 0 names row r's
 // place in it and xcol[e] that of entry e's column; a row with xrow[r] < 0 is a "simple" one -- at most one of its columns is a loss
 // row -- and its dZ is made as the row is staged into the window: the prefetch brings its `prev` slice and the compact operand row
