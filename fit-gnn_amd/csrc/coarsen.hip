@@ -367,7 +367,7 @@ enum SpecAnswer { kSpecNothing = 0, kSpecCost = 1, kSpecList = 2 };
 struct SpecNone {
     __device__ __forceinline__ void publish_head(int) const {}
     __device__ __forceinline__ int lookup(int, int, double &, int32_t &, int32_t &, unsigned long long &) const { return kSpecNothing; }
-    __device__ __forceinline__ void publish_top(int, int32_t, int32_t, int32_t) const {}
+    __device__ __forceinline__ void publish_top(int, int32_t, int32_t, int32_t, bool) const {}
     __device__ __forceinline__ int lookup_top(int, int, double &, int32_t &, int32_t &) const { return kSpecNothing; }
 };
 struct SpecRing {
@@ -394,8 +394,12 @@ struct SpecRing {
     }
     // the queue's new held-out minimum: its members and stored list are final until it is popped (only the set being processed
     // is ever changed), so a helper may prune and cost it now
-    __device__ __forceinline__ void publish_top(int seq, int32_t cand, int32_t off, int32_t len) const {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // this wave's writes to the set's members / list table first
+    // fresh: the set was pruned in THIS iteration -- its compacted members and list-table entry may still be on their way to memory, so
+    // the wave waits for them (a workgroup release is s_waitcnt vmcnt(0): a memory round trip).  A set that comes out of the queue was
+    // written at least one pop earlier, and the loads that just fetched it from the queue have been waited for since (the counter
+    // retires in order): no wait -- and the request for its members, issued just before, stays in flight.
+    __device__ __forceinline__ void publish_top(int seq, int32_t cand, int32_t off, int32_t len, bool fresh) const {
+        if (fresh) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         if ((threadIdx.x & 63) == 0) { sh->job_cand = cand; sh->job_off = off; sh->job_len = len; sh->job_seq = seq; }
     }
     // (a queue set has its own stored list: a helper's list of a superset of it is of no use)
@@ -622,7 +626,7 @@ __device__ inline void greedy_component(const CostGraph &g, CostLds &lds, Heap h
             if (has_top) {
                 top = heap.extract_min();
                 tm = lane < top.len ? mem[top.off + lane] : -1;
-                spec.publish_top(++top_job, top.cand, top.off, top.len);
+                spec.publish_top(++top_job, top.cand, top.off, top.len, false);
             }
         }
         int32_t *S = mem + off;
@@ -725,11 +729,11 @@ __device__ inline void greedy_component(const CostGraph &g, CostLds &lds, Heap h
                 ++seq;
                 if (!has_top) {
                     top = x; tm = xm; has_top = true;
-                    spec.publish_top(++top_job, cand, off, m);
+                    spec.publish_top(++top_job, cand, off, m, true);
                 } else if (item_less(x, top)) {
                     heap.push(top);
                     top = x; tm = xm;
-                    spec.publish_top(++top_job, cand, off, m);
+                    spec.publish_top(++top_job, cand, off, m, true);
                 } else {
                     heap.push(x);
                 }
