@@ -114,7 +114,11 @@ def test_round3_entry_points_check_their_arguments_without_a_gpu():
     work, size queries are host-only."""
     L = _lib.lib()
     # exact fp32 GEMM: k split only where it shortens the launch, in multiples of 8 chunks
-    assert L.fitgnn_gemm_exact_workspace_bytes(165000, 512, 512, 0, 0) == 0                        # 1 290 tiles: no split
+    # 1 290 tiles of 256 x 256 = 5 full rounds of 256 workgroups + 10 tiles: no k split of the grid, but the last round's rows
+    # (165 000 - 5 * 128 * 256 = 1 160) are a launch of their own, split eight ways over k (gemm_f32.hip: make_plan)
+    assert L.fitgnn_gemm_exact_workspace_bytes(165000, 512, 512, 0, 0) == 8 * (165000 - 163840) * 512 * 4
+    assert L.fitgnn_gemm_exact_workspace_bytes(5 * 128 * 256, 512, 512, 0, 0) == 0                 # whole rounds only: one launch
+    assert L.fitgnn_gemm_exact_workspace_bytes(165000, 512, 512, 1, 1) != 8 * 1160 * 512 * 4       # the tail launch needs a k-minor a
     assert L.fitgnn_gemm_exact_workspace_bytes(512, 512, 165000, 1, 1) == 64 * 512 * 512 * 4       # 4 tiles: 64 chunks
     wb = L.fitgnn_gemm_exact_workspace_bytes(34493, 512, 8448, 0, 0)                               # 270 tiles of a long k: split
     assert wb > 0 and (wb // (34493 * 512 * 4)) % 8 == 0
