@@ -21,6 +21,7 @@ MAX_K = 16
 SIGNATURES = {
     "fitgnn_abi_version": (ctypes.c_int, []),
     "fitgnn_error_string": (ctypes.c_char_p, [ctypes.c_int]),
+    "fitgnn_stream_copy_f32": (ctypes.c_int, [ptr, ptr, c_i64, ptr]),
     "fitgnn_spmm_default_window_rows": (ctypes.c_int, []),
     "fitgnn_spmm_max_window_rows": (ctypes.c_int, [c_i32]),
     "fitgnn_gcn_norm_csr_f32": (ctypes.c_int, [ptr, ptr, ptr, ptr, ptr, c_i32, ptr]),

@@ -115,13 +115,15 @@ def broadcast_parameters(model, process_group=None, flat=None):
 
 class GDTrainer:
     def __init__(self, model, batch, lr=0.01, weight_decay=5e-4, reduction="mean", process_group=None, dedup=True,
-                 task="node_cls", prune_unused_rows=False, op_config=None):
+                 task="node_cls", prune_unused_rows=False, op_config=None, global_train_count=None):
         """task 'node_cls': NLLLoss on log-probabilities (run.py:341); 'node_reg': L1Loss on the [n, 1] outputs (run.py:518).
         op_config (ops.OpConfig): the switches this trainer's kernels run under (set on the model; default: the model's own).
         prune_unused_rows: evaluate the last layer only on the rows that can reach the loss (the clusters' own nodes: the
         reference computes and then discards the extra nodes' outputs, run.py:193-204).  Same loss and gradients; the
         last layer's GEMMs and both of its SpMMs shrink to the own-node rows.  Off by default: bench.py's metric counts
-        every non-zero of A_hat in all four SpMMs."""
+        every non-zero of A_hat in all four SpMMs.
+        global_train_count: the number of train rows of the WHOLE job when it is known up front (bench.py --shard: one rank of an
+        N-rank job stepped alone); default: this batch's count, summed over the process group."""
         self.model, self.batch, self.task = model, batch, task
         if op_config is not None:
             model.set_op_config(op_config)
@@ -156,7 +158,7 @@ class GDTrainer:
         count = torch.tensor([float(batch.train_idx.numel())], device=self.flat.buf.device)
         if self.dist:
             torch.distributed.all_reduce(count, group=self.pg)
-        self.global_count = float(count.item())
+        self.global_count = float(count.item()) if global_train_count is None else float(global_train_count)
         # Data parallel: the gradients of everything above the first layer are complete when the first layer's backward
         # starts -- all-reduce that part of the flat buffer asynchronously (RCCL's own stream) under the first layer's
         # backward kernels, the first layer's part afterwards.  xGMI is point-to-point: two latency-bound ~1 MB calls, no

@@ -72,12 +72,14 @@ def assemble(name, ei_d, assign_d, n_clusters, layout="star", clusters=None):
     return sub, data.cluster_nnz(sub)
 
 
-def shard_before_assembly(name, ei_d, assign_d, n_clusters, world):
+def shard_before_assembly(name, ei_d, assign_d, n_clusters, world, return_weights=False):
     """owner[c] = rank of cluster c (whole subgraphs, LPT), decided BEFORE any subgraph exists from
     data.cluster_weights_torch -- computed by every rank from the graph and the partition it already holds, so every rank gets
     the same answer and then assembles its own clusters only."""
     N = SHAPES[name][0]
-    return data.shard_clusters(None, data.cluster_weights_torch(ei_d, N, assign_d, n_clusters, extra_node=True), world)
+    w = data.cluster_weights_torch(ei_d, N, assign_d, n_clusters, extra_node=True)
+    owner = data.shard_clusters(None, w, world)
+    return (owner, w) if return_weights else owner
 
 
 def batch_from_subgraphs(name, sub, device, X=None, y=None):

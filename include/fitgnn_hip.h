@@ -32,6 +32,12 @@ int fitgnn_abi_version(void);
 /* Human-readable text for a return code of this library (host pointer, static storage). */
 const char *fitgnn_error_string(int code);
 
+/* Measurement aid (bench.py's `roofline.copy_ceiling_GBps`): dst[0..n) = src[0..n), n % 4 == 0, both 16-byte aligned -- a
+ * read-once / write-once stream in the shape the SpMM kernels move their rows (one workgroup per 16-KiB chunk, 16-byte
+ * non-temporal accesses, eight loads in flight per lane: the fastest row of tools/microbench/copy_probe.hip).  2 * 4 * n bytes
+ * over its duration is what an HBM-bound stream reaches on the device at hand. */
+int fitgnn_stream_copy_f32(const float *src, float *dst, int64_t n, void *stream);
+
 /* =====================================================================================
  * Train half: GCN-family message passing on block-diagonal subgraph batches
  * replaces: torch_geometric.nn.GCNConv & friends as called from network.py:31,60,90,126,161,197

@@ -18,4 +18,4 @@ done
 python3 $R/tools/summarize_pmc.py $OUT > $OUT/pmc_summary.json
 for d in $OUT/pmc_*/; do rm -rf "$d"; done   # per-dispatch CSVs are large; the summary travels back
 rm -f $OUT/stats/run_kernel_trace.csv
-echo "summary done"
+cp $OUT/pmc_summary.json $OUT/pmc_bench_kernels.json; echo "summary done"
