@@ -36,7 +36,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy ceiling is ~6300
 
 # default (timed steps, warm-up steps) per workload; shapes: fitgnn_amd/workloads.py
-DEFAULT_STEPS = {"S-products": (30, 5), "S-pubmed": (200, 20), "S-cora": (200, 20), "S-physics": (100, 10)}
+DEFAULT_STEPS = {"S-products": (30, 5), "S-pubmed": (200, 20), "S-cora": (200, 20), "S-physics": (100, 10), "S-qm9": (5, 1)}
 
 
 def parse_args():
@@ -45,6 +45,11 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=None, help="timed steps (default per workload: S-products 30)")
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--workload", default="S-products", choices=sorted(DEFAULT_STEPS))
+    ap.add_argument("--layer", default="GCNConv", choices=["GCNConv", "GATConv", "APPNP"],
+                    help="the message-passing operator of the step (north_star: GCN / GAT / APPNP).  GCNConv = the headline; GATConv = "
+                         "network.py's Classify_node with --layer_name GATConv (2 layers, heads 1); APPNP = the SGGC baseline's model "
+                         "(Baselines/SGGC/APPNP/networks.py: 2-layer MLP, then K = 10 propagation steps on the class-wide signal).  "
+                         "Secondary lines: same metric (SpMM products x nnz' per step), per-kernel rooflines for the operator's own kernels")
     ap.add_argument("--hidden", type=int, default=512)
     ap.add_argument("--dropout", type=float, default=0.5, help="F.dropout's p (network.py:33: the default 0.5); 0 makes the step "
                     "deterministic across shardings (the dropout hash is keyed on a rank's own row numbers)")
@@ -208,6 +213,13 @@ def main():
 
     from fitgnn_amd import data, network, ops, train, workloads
 
+    if args.workload == "S-qm9":
+        out = bench_qm9(args, device, world, rank, backend)
+        if rank == 0:
+            print(json.dumps(out), flush=True)
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        return
     N, E, F, C, r = workloads.SHAPES[args.workload]
     H = args.hidden
     info = dict(nodes=N, undirected_edges=E, features=F, classes=C)
@@ -302,9 +314,10 @@ def main():
     del sub
 
     def make_trainer(precision, loss_rows_only=True, prune=None):
-        margs = argparse.Namespace(num_layers1=2, layer_name="GCNConv", num_features=F, hidden=H, num_classes=C, dropout=args.dropout)
+        margs = argparse.Namespace(num_layers1=2, layer_name="GCNConv" if args.layer == "APPNP" else args.layer, num_features=F, hidden=H,
+                                   num_classes=C, dropout=args.dropout, K=10, alpha=0.1)
         torch.manual_seed(2)  # weight seed; identical on every rank
-        model = network.Classify_node(margs).to(device)
+        model = (network.APPNPNet(margs) if args.layer == "APPNP" else network.Classify_node(margs)).to(device)
         sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
         # loss_rows_only=False: the last layer transform-first with every dense operation over all union rows (the shape of the
         # reference's step); True (default): aggregate-first, the dense part on the rows that reach the loss -- see DESIGN §0
@@ -315,7 +328,8 @@ def main():
         kw = {}
         if emu is not None:   # one rank of the N-rank job: the job's train count (every node is a train node), the dist path forced
             kw = dict(process_group=torch.distributed.group.WORLD, global_train_count=float(N))
-        tr = train.GDTrainer(model, batch, lr=0.01, weight_decay=5e-4, dedup=not args.no_dedup,
+        # GATConv has no de-duplicated first layer (its attention scores are per union row): the materialised rows
+        tr = train.GDTrainer(model, batch, lr=0.01, weight_decay=5e-4, dedup=(not args.no_dedup) and args.layer != "GATConv",
                              prune_unused_rows=prune if prune is not None else args.prune_unused_rows, op_config=cfg, **kw)
         return tr, sd
 
@@ -369,7 +383,9 @@ def main():
     torch.cuda.synchronize()
     gemm_events, trainer.cfg.profile_gemm = trainer.cfg.profile_gemm, None
 
-    edges_per_step = 4.0 * batch.nnz
+    edges_per_step = 4.0 * batch.nnz   # GCN / GAT: two layers x (aggregation forward + its adjoint backward)
+    if args.layer == "APPNP":
+        edges_per_step = 2.0 * 10 * batch.nnz   # K = 10 propagation steps forward + 10 backward, on the class-wide signal
     if trainer.sub is not None:   # two full SpMMs (layer 0) + the own-node rows of A_hat twice (layer 1 forward / backward)
         edges_per_step = 2.0 * batch.nnz + 2.0 * int(trainer.sub.f.col.numel())
     edges = torch.tensor([edges_per_step], device=device, dtype=torch.float64)
@@ -386,7 +402,7 @@ def main():
             e2 = 2.0 * batch.nnz + 2.0 * int(tr2.sub.f.col.numel())
         return dict(ms_per_step=dt2 / k2 * 1e3, value=e2 * k2 / dt2, steps=k2, loss=float(loss2), edges_per_step=e2)
 
-    secondary = emu is None
+    secondary = emu is None and args.layer == "GCNConv"
     # secondary: the same step with the dense products as a 3 x bf16 split (narrower than the reference's fp32: never the headline)
     bf16x3 = retime("high") if (secondary and not args.no_bf16x3 and args.gemm_precision == "exact") else None
     # the same step with the last layer transform-first and every dense operation over all union rows
@@ -424,7 +440,38 @@ def main():
     n_launch = len(step_events[0]) if step_events else 0
     full_steps = [ev for ev in step_events if len(ev) == n_launch]
     kinds = [e[2] for e in full_steps[0]] if full_steps else []
-    if full_steps and trainer.sub is None and sum(products.get(k, 1) for k in kinds) == 4:
+    op_kernel = None
+    if args.layer != "GCNConv" and step_events:
+        # GAT / APPNP: every kernel of the operator, grouped by kind (ops._timed), with the compulsory bytes of ONE launch of that kind
+        # (scores 4H R; aggregation = the §8(d) SpMM bytes; SDDMM reads both dense operands once and writes one value per
+        # entry; the edge passes move 4-byte values per entry; APPNP's step is a C-wide SpMM with its teleport operand)
+        Cw = C
+        kind_bytes = {"gat_scores": 4 * H * R + 8 * R, "gat_edge_softmax": 8 * nnz + 4 * (R + 1) + 8 * R,
+                      "gat_aggregate": bytes_spmm, "gat_aggregate_t": bytes_spmm, "gat_epilogue_bwd": 3 * 4 * H * R,
+                      "gat_sddmm": 2 * 4 * H * R + 8 * nnz + 4 * (R + 1), "gat_softmax_bwd": 16 * nnz + 4 * (R + 1) + 12 * R,
+                      "gat_transpose_edges": 28 * nnz + 4 * (R + 1) + 4 * R, "gat_rank1": 2 * 4 * H * R + 8 * R,
+                      "appnp_step": 3 * 4 * Cw * R + 8 * nnz + 4 * (R + 1), "appnp_step_t": 4 * 4 * Cw * R + 8 * nnz + 4 * (R + 1)}
+        per_kind = {}
+        for ev in step_events:
+            for a, b, kind in ev:
+                per_kind.setdefault(kind, []).append(a.elapsed_time(b))
+        n_steps_ev = max(len(step_events), 1)
+        for kind, durs in per_kind.items():
+            ms = float(np.mean(durs))
+            kb = kind_bytes.get(kind, bytes_spmm)
+            launches.append({"launch": kind, "kind": kind, "avg_us": ms * 1e3, "launches_per_step": len(durs) / n_steps_ev,
+                             "us_per_step": float(np.sum(durs)) / n_steps_ev * 1e3, "launches_timed": len(durs),
+                             "algorithmic_bytes": kb, "frac": kb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS})
+        launches.sort(key=lambda l: -l["us_per_step"])
+        sum_ms = sum(l["us_per_step"] for l in launches) * 1e-3
+        achieved = sum(l["algorithmic_bytes"] * l["launches_per_step"] for l in launches) / (sum_ms * 1e-3) / 1e9
+        best = max(launches, key=lambda l: l["frac"])
+        covers = ("every kernel of the %s operator in the step, step-weighted (sum of their compulsory bytes / sum of their launch times); "
+                  "launches[0] is the dominant one" % args.layer)
+        op_kernel = {"GATConv": "gat.hip (scores, edge softmax, SDDMM, softmax backward) + spmm_tile_kernel (aggregation, its adjoint) + "
+                                "epilogue_bwd_kernel, H=%d, f32" % H,
+                     "APPNP": "spmm_narrow_kernel (class-wide CSR SpMM with the teleport term in its store), %d columns, f32" % C}[args.layer]
+    elif full_steps and trainer.sub is None and sum(products.get(k, 1) for k in kinds) == 4:
         pos_name = 0
         for pos, kind in enumerate(kinds):
             n_prod = products.get(kind, 1)
@@ -479,7 +526,7 @@ def main():
     del src, dst
 
     run_cfg = dict(workload=args.workload, hidden=H, classes=C, gemm_precision=args.gemm_precision, two_hop=not args.no_two_hop,
-                   dropout=args.dropout, dedup=not args.no_dedup)
+                   dropout=args.dropout, dedup=not args.no_dedup, layer=args.layer)
     precision_text = {
         "exact": ("f32 everywhere: SpMM, epilogues, loss, Adam in f32; every dense product of the step in the reference's arithmetic -- fp32 "
                   "operands, exact fp32 products, fp32 accumulation on v_mfma_f32_32x32x2_f32 (hand-written csrc/gemm_f32.hip; measured "
@@ -509,7 +556,11 @@ def main():
         "value_pruned": None if pruned is None else pruned["value"],
         "edges_per_step_pruned": None if pruned is None else pruned["edges_per_step"],
         "config": {"workload": f"{args.workload}: variation_neighborhoods r={r}, extra-node subgraphs, ONE block-diagonal union "
-                               f"sharded over the ranks by whole subgraphs, 2-layer GCN hidden {H}, GD step + Adam",
+                               f"sharded over the ranks by whole subgraphs, " +
+                               {"GCNConv": f"2-layer GCN hidden {H}", "GATConv": f"2-layer GAT (heads 1) hidden {H}, network.py --layer_name GATConv",
+                                "APPNP": f"APPNP (Baselines/SGGC/APPNP/networks.py): MLP {F}-{H}-{C} on the de-duplicated table, K = 10, alpha = 0.1"}[args.layer] +
+                               ", GD step + Adam",
+                   "layer": args.layer,
                    "last_layer": ("aggregate-first: A_hat h over every row and edge, then x W^T / bias / ELU / dropout / head and the backward's "
                                   "weight-side products on the rows that reach the loss (every cluster's own nodes: "
                                   f"{n_loss} of {batch.n_rows} union rows); all four SpMMs of the step run over all "
@@ -521,16 +572,16 @@ def main():
                    else "materialised union rows",
                    "rank0_union_rows": R, "rank0_nnz_prime": batch.nnz,
                    **info},
-        "roofline": {"kernel": ("spmm_block_kernel + spmm_tile_kernel (CSR SpMM: whole-subgraph kernel over the stars, LDS row windows over "
+        "roofline": {"kernel": op_kernel or (("spmm_block_kernel + spmm_tile_kernel (CSR SpMM: whole-subgraph kernel over the stars, LDS row windows over "
                                 "the small ones; H=%d, f32)" if batch.graph.f.blocks is not None else
-                                "spmm_tile_kernel (CSR SpMM, LDS row windows, H=%d, f32)") % H, "bound": "hbm", "achieved": achieved,
+                                "spmm_tile_kernel (CSR SpMM, LDS row windows, H=%d, f32)") % H), "bound": "hbm", "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     **pmc_traffic(launches if (world == 1 and emu is None) else None, run_cfg),
+                     **pmc_traffic(launches if (world == 1 and emu is None and args.layer == "GCNConv") else None, run_cfg),
                      "covers": covers,
                      "algorithmic_bytes_per_launch": bytes_spmm, "spmm_ms_per_step": sum_ms if launches else None,
                      "launches": launches,
                      "best_launch": None if best is None else {"launch": best["launch"], "frac": best["frac"], "avg_us": best["avg_us"]},
-                     "spmm_edges_per_s": (4 * nnz / (sum_ms * 1e-3)) if launches else None,
+                     "spmm_edges_per_s": (edges_per_step / (sum_ms * 1e-3)) if launches else None,
                      "copy_ceiling_GBps": copy_gbs, "frac_of_copy_ceiling": achieved / copy_gbs},
         "run_config": run_cfg,
         "gemm_kernels": gemm_summary, "gemm_ms_per_step": gemm_ms_per_step,
@@ -543,7 +594,7 @@ def main():
         out["scaling"] = "strong (one rank of %d stepped alone: `value` is THIS shard's edges/s, not a job's)" % emu[1]
         out["config"]["parallelism"] = "rank %d of dp%d, alone on one GPU (RCCL group of one)" % (info["emulated"]["rank"], emu[1])
     if rank == 0 and world == 1 and emu is None and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(batch, sd0, 2)
+        out["cpu_baseline"] = cpu_baseline(batch, sd0, 2, layer=args.layer)
         out["cpu_baseline"]["cpu_model"] = cpu_model()
         out["cpu_baseline"]["host_cores"] = os.cpu_count()
         # the contraction step of the same graph on the host: the C restatement (one core), next to the HIP time above
@@ -561,7 +612,150 @@ def main():
         torch.distributed.destroy_process_group()
 
 
-def cpu_baseline(batch, sd, num_layers, budget_s=20.0):
+def bench_qm9(args, device, world, rank, backend):
+    """BASELINE.json configs[4] (QM9 graph regression, network.py:189-204 `Regress_graph_gs`, run.py:288-304 `graph_train_Gs`) on the
+    QM9-shaped stand-in of SURVEY §8d: 130 831 molecules coarsened, pooled and assembled in ONE pass each, the training half (65 415
+    graphs, utils.py:33) in loader batches of 128 (run.py:513).  A bench "step" = one training EPOCH = 512 batch steps (forward, L1 loss,
+    backward, Adam; gradients never cleared inside the epoch, run.py:291), each replayed from a hipGraph captured once.
+    value = 4 SpMM products x nnz' of every batch / epoch time."""
+    import numpy as np
+    import torch
+    from fitgnn_amd import graph_data, network, ops, train
+
+    n_graphs, H = 130_831, args.hidden
+    t0 = time.time()
+    mol = graph_data.synthetic_molecules(n_graphs, seed=0)
+    t1 = time.time()
+    gset = graph_data.GraphSet(mol, ratio=0.5, extra_node=True, device=device)
+    torch.cuda.synchronize()
+    t2 = time.time()
+    graphs = list(range(n_graphs // 2))
+    margs = argparse.Namespace(num_layers1=2, layer_name="GCNConv", num_features=11, hidden=H, num_classes=1, dropout=args.dropout)
+    torch.manual_seed(2)
+    model = network.Regress_graph_gs(margs).to(device)
+    cfg = ops.OpConfig(gemm_precision=args.gemm_precision)
+    model.set_op_config(cfg)
+    tr = train.GraphTrainer(model, gset, graphs, kind="gs", batch_size=128, lr=0.001, capture=(world == 1))
+    torch.cuda.synchronize()
+    t3 = time.time()
+    rows = sum(int(b["x"].shape[0]) for b in tr.batches if b is not None)
+    nnz = sum(int(b["edge_index"].shape[1]) + int(b["x"].shape[0]) for b in tr.batches if b is not None)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        loss = tr.step()
+    barrier()
+    t_start = time.perf_counter()
+    for _ in range(args.steps):
+        loss = tr.step()
+    barrier()
+    dt = torch.tensor([time.perf_counter() - t_start], device=device, dtype=torch.float64)
+    tot = torch.tensor([float(nnz), float(rows)], device=device, dtype=torch.float64)
+    if world > 1:
+        torch.distributed.all_reduce(dt, op=torch.distributed.ReduceOp.MAX)
+        torch.distributed.all_reduce(tot)
+    dt = float(dt.item())
+    nnz_total, rows_total = float(tot[0]), float(tot[1])
+    n_batches = len(tr.batches)
+    # the SpMM launches of one EAGER epoch's first batches (HIP events cannot be read back from inside a replayed hipGraph): their mean
+    # duration against the §8(d) bytes of a batch -- these batches are ~10^4 rows: the launches are latency-, not bandwidth-bound
+    launches, achieved = [], float("nan")
+    if world == 1:
+        import types
+        ev_cfg = cfg.replace(profile=[])
+        model.set_op_config(ev_cfg)
+        model.train()
+        k_ev = min(16, n_batches)
+        for b in tr.batches[:k_ev]:
+            out_b = model(b, b["graph_of_masked"])
+            out_b.sum().backward()
+        torch.cuda.synchronize()
+        model.set_op_config(cfg)
+        tr.flat.zero()
+        per_kind = {}
+        for a, b_, kind in ev_cfg.profile:
+            per_kind.setdefault(kind, []).append(a.elapsed_time(b_))
+        r_b, nnz_b = rows / n_batches, nnz / n_batches
+        bytes_spmm = 8 * H * r_b + 8 * nnz_b + 4 * (r_b + 1)
+        for kind, durs in per_kind.items():
+            ms = float(np.mean(durs))
+            launches.append({"kind": kind, "avg_us": ms * 1e3, "launches_per_batch_step": len(durs) / k_ev, "algorithmic_bytes": bytes_spmm,
+                             "frac": bytes_spmm / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS})
+        sum_ms = sum(l["avg_us"] * l["launches_per_batch_step"] for l in launches) * 1e-3
+        achieved = sum(l["algorithmic_bytes"] * l["launches_per_batch_step"] for l in launches) / max(sum_ms * 1e-3, 1e-12) / 1e9
+    out = {
+        "metric": "edges aggregated/sec (GCN fwd+bwd) on coarsened subgraphs",
+        "value": 4.0 * nnz_total * args.steps / dt, "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic",
+        "graphs_per_s": len(graphs) * args.steps / dt, "batch_steps_per_epoch": n_batches, "us_per_batch_step": dt / args.steps / n_batches * 1e6,
+        "config": {"workload": "S-qm9: 130 831 molecules (~18 nodes), variation_neighborhoods r=0.5 per molecule in one batched contraction, "
+                               f"extra-node cluster subgraphs; Regress_graph_gs (2-layer GCN hidden {H}, mean pool of the masked rows, lt1), "
+                               "a step = one training epoch over the 65 415 training graphs in batches of 128 (forward, L1 loss, backward, "
+                               "Adam per batch; gradients accumulate inside the epoch as in run.py:291), every batch step replayed from a hipGraph",
+                   "parallelism": f"dp{world}", "backend": backend, "graphs": n_graphs, "training_graphs": len(graphs),
+                   "union_rows_per_epoch": int(rows_total), "nnz_prime_per_epoch": int(nnz_total), "dropout_p": args.dropout,
+                   "captured": bool(tr.capture), "t_molecules_s": round(t1 - t0, 2), "t_coarsen_pool_assemble_s": round(t2 - t1, 2),
+                   "t_batches_and_capture_s": round(t3 - t2, 2)},
+        "roofline": {"kernel": "spmm_tile_kernel (CSR SpMM, LDS row windows, H=%d, f32) on 128-molecule batches" % H, "bound": "hbm",
+                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "covers": "the SpMM launches of the first 16 batch steps run eagerly after the timed region (a batch is ~10^4 rows: "
+                               "the launches are latency-bound, and the epoch is bound by its launches per batch step)",
+                     "launches": launches},
+        "loss": float(loss),
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline_qm9(gset, mol, model, tr)
+        out["cpu_baseline"]["cpu_model"] = cpu_model()
+        out["cpu_baseline"]["host_cores"] = os.cpu_count()
+    return out
+
+
+def cpu_baseline_qm9(gset, mol, model, tr, budget_s=15.0):
+    """The oracle's literal restatement of network.py:189-204 (a conv stack per cluster subgraph) + L1 loss + backward, on the first
+    loader batches of 128 molecules, as many as fit the budget."""
+    import numpy as np
+    import torch
+    from oracle import gnn_oracle as gorc
+
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    e_all = gset.gs_edge_index
+    done, t_used, nnz_s = 0, 0.0, 0
+    for bi in range(len(tr.batches)):
+        g0 = bi * 128
+        r_lo, r_hi = int(gset.gs_ptr[g0]), int(gset.gs_ptr[g0 + 128])
+        keep = (e_all[0] >= r_lo) & (e_all[0] < r_hi)
+        e = e_all[:, keep].cpu()
+        set_gs = []
+        for g in range(g0, g0 + 128):
+            subs = []
+            for c in range(int(gset.cluster_ptr[g]), int(gset.cluster_ptr[g + 1])):
+                r0, r1 = int(gset.sub_ptr[c]), int(gset.sub_ptr[c + 1])
+                k = (e[0] >= r0) & (e[0] < r1)
+                subs.append(dict(x=gset.gs_x[r0:r1].cpu(), edge_index=e[:, k] - r0, mask=gset.gs_mask[r0:r1].cpu()))
+            set_gs.append(subs)
+        bt = torch.repeat_interleave(torch.arange(128), torch.from_numpy(np.diff(mol["node_ptr"][g0:g0 + 129])))
+        tgt = torch.from_numpy(mol["y"][g0:g0 + 128]).long()[:, 0].view(-1, 1).float()
+        t0 = time.time()
+        params = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        ref = gorc.regress_graph_gs_forward(params, set_gs, bt)
+        torch.nn.functional.l1_loss(ref, tgt).backward()
+        if bi > 0:   # the first batch warms the thread pools up
+            t_used += time.time() - t0
+            nnz_s += int(e.shape[1]) + (r_hi - r_lo)
+            done += 1
+        if t_used > budget_s or done >= 32:
+            break
+    return dict(value=4 * nnz_s / max(t_used, 1e-9), unit="edges/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"loader batches 1..{done} of {len(tr.batches)} (128 molecules each; literal per-subgraph loops of network.py:189-204), "
+                       f"nnz' = {nnz_s}, 1 fwd+bwd each, {t_used:.2f} s")
+
+
+def cpu_baseline(batch, sd, num_layers, budget_s=20.0, layer="GCNConv"):
     """The torch-CPU oracle of the same step (fwd + loss + bwd), timed on this host.  Sample = loader batches of the reference
     (run.py:336: 128 subgraphs each) drawn EVENLY SPACED over the loader's order -- the assembly lists large subgraphs first, so the
     first batches alone would be the densest ones -- as many as fit the time budget; the sample's rows and nnz' are reported."""
@@ -586,7 +780,12 @@ def cpu_baseline(batch, sd, num_layers, budget_s=20.0):
     def run(sample):
         x, e, y, tm, _ = sample
         t0 = time.time()
-        gorc.classify_node_fwd_bwd(sd, x, e, y, num_layers=num_layers, train_mask=tm)
+        if layer == "GATConv":
+            gorc.classify_node_gat_fwd_bwd(sd, x, e, y, num_layers=num_layers, train_mask=tm)
+        elif layer == "APPNP":
+            gorc.appnp_net_fwd_bwd(sd, x, e, y, K=10, alpha=0.1, train_mask=tm)
+        else:
+            gorc.classify_node_fwd_bwd(sd, x, e, y, num_layers=num_layers, train_mask=tm)
         return time.time() - t0, int(e.shape[1]) + int(x.shape[0])
 
     run(gather(min(2, len(spans))))  # warm-up (thread pools, allocator)
@@ -597,7 +796,8 @@ def cpu_baseline(batch, sd, num_layers, budget_s=20.0):
         k = min(len(spans), 256, max(k + 1, int(k * (budget_s / 2) / max(dt, 1e-3))))
         smp = gather(k)
         dt, nnz_s = run(smp)
-    return dict(value=4 * nnz_s / dt, unit="edges/s", cores=torch.get_num_threads(), kind="port",
+    per_step = 20 if layer == "APPNP" else 4   # SpMM products of one step (APPNP: K = 10 forward + 10 backward)
+    return dict(value=per_step * nnz_s / dt, unit="edges/s", cores=torch.get_num_threads(), kind="port",
                 sample=f"{smp[4]} of {len(spans)} loader batches (128 subgraphs each), evenly spaced over the loader's order: "
                        f"{int(smp[0].shape[0])} rows, nnz' = {nnz_s} ({nnz_s / max(batch.nnz, 1):.4f} of the union's), 1 fwd+bwd step, {dt:.2f} s")
 

@@ -205,6 +205,44 @@ class Regress_node(_Base):
         return self.embed_and_head(x, edge_index, x_index)
 
 
+class APPNPNet(nn.Module):
+    """The APPNP model north_star names beside GCN / GAT: Baselines/SGGC/APPNP/networks.py:7-27 (`Net`), same attributes
+    (`lin1`, `lin2`, `prop1`) and forward: dropout -> lin1 -> ReLU -> dropout -> lin2 -> APPNP(K, alpha) -> log_softmax.
+    args: num_features, hidden, num_classes, K (default 10), alpha (default 0.1) (networks.py:9-11).
+    x_index (ops.RowIndex, optional): x is a de-duplicated feature table and union row r is table row x_index.index[r] -- the MLP
+    is per node, so it runs on the table and its class-wide output is gathered to the union rows before the propagation (in
+    training mode the copies of a node then share its dropout draw)."""
+
+    def __init__(self, args):
+        super().__init__()
+        self.lin1 = fnn.Linear(args.num_features, args.hidden)
+        self.lin2 = fnn.Linear(args.hidden, args.num_classes)
+        self.prop1 = fnn.APPNP(int(getattr(args, "K", 10)), float(getattr(args, "alpha", 0.1)))
+        self.dropout_p = float(getattr(args, "dropout", 0.5))
+        self.op_config = ops.DEFAULT
+
+    def set_op_config(self, cfg):
+        self.op_config = cfg
+        for m in self.modules():
+            if isinstance(m, fnn._OpConfigured):
+                m.op_config = cfg
+        return self
+
+    def reset_parameters(self):
+        self.lin1.reset_parameters()
+        self.lin2.reset_parameters()
+
+    def forward(self, x, edge_index, x_index=None):
+        x = F.dropout(x.float(), p=self.dropout_p, training=self.training)
+        x = F.relu(self.lin1(x))
+        x = F.dropout(x, p=self.dropout_p, training=self.training)
+        x = self.lin2(x)
+        if x_index is not None:
+            x = x.index_select(0, x_index.index.long())
+        x = self.prop1(x, edge_index)
+        return F.log_softmax(x, dim=1)
+
+
 class Classify_graph_gc(_Base):
     def forward(self, gc):
         x = self.embed(gc.x, gc.edge_index)

@@ -180,7 +180,7 @@ class APPNP(_OpConfigured, nn.Module):
         g = csr_for(edge_index, x.shape[0], "gcn")
         z0 = x.float()
         if z0.is_cuda and z0.shape[1] <= 64:   # class-wide signal: the narrow kernel, teleport term in its epilogue
-            return ops.APPNPPropagate.apply(z0, g, int(self.K), float(self.alpha))
+            return ops.APPNPPropagate.apply(z0, g, int(self.K), float(self.alpha), self.op_config)
         z = z0
         for _ in range(self.K):
             z = ops.SpMM.apply(z, None, g, self.op_config) * (1.0 - self.alpha) + self.alpha * z0

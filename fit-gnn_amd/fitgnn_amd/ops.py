@@ -189,6 +189,27 @@ def _atb_ok(t):
             and t.shape[1] % 4 == 0 and t.shape[1] >= 4 and t.data_ptr() % 16 == 0)
 
 
+class _timed:
+    """`with _timed(cfg, kind):` -- when cfg.profile is a list, a HIP-event pair around the launches inside (recorded on torch's
+    current stream = the one handed to the C ABI) is appended to it as (start, end, kind)."""
+    __slots__ = ("cfg", "kind", "ev")
+
+    def __init__(self, cfg, kind):
+        self.cfg, self.kind, self.ev = cfg, kind, None
+
+    def __enter__(self):
+        if self.cfg is not None and self.cfg.profile is not None:
+            self.ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            self.ev[0].record()
+        return self
+
+    def __exit__(self, *exc):
+        if self.ev is not None:
+            self.ev[1].record()
+            self.cfg.profile.append((self.ev[0], self.ev[1], self.kind))
+        return False
+
+
 def _gemm_events(cfg, name, flops):
     """cfg.profile_gemm: list of (start event, end event, kernel name, bf16 flops) per hand-written GEMM launch."""
     if cfg.profile_gemm is None:
@@ -1349,17 +1370,20 @@ class GATAggregate(torch.autograd.Function):
         a_src = torch.empty(n, dtype=torch.float32, device=dev)
         a_dst = torch.empty(n, dtype=torch.float32, device=dev)
         att_src, att_dst = _f32c(att_src.reshape(-1)), _f32c(att_dst.reshape(-1))
-        _lib.check(L.fitgnn_gat_scores_f32(_lib.dptr(h), C, n, C, _lib.dptr(att_src), _lib.dptr(att_dst), _lib.dptr(a_src),
-                                           _lib.dptr(a_dst), st), "gat_scores")
+        with _timed(cfg, "gat_scores"):
+            _lib.check(L.fitgnn_gat_scores_f32(_lib.dptr(h), C, n, C, _lib.dptr(att_src), _lib.dptr(att_dst), _lib.dptr(a_src),
+                                               _lib.dptr(a_dst), st), "gat_scores")
         alpha = torch.empty(g.nnz, dtype=torch.float32, device=dev)
-        _lib.check(L.fitgnn_gat_edge_softmax_f32(_lib.dptr(g.f.rowptr), _lib.dptr(g.f.col), _lib.dptr(a_src), _lib.dptr(a_dst),
-                                                 float(slope), n, _lib.dptr(alpha), st), "gat_edge_softmax")
+        with _timed(cfg, "gat_edge_softmax"):
+            _lib.check(L.fitgnn_gat_edge_softmax_f32(_lib.dptr(g.f.rowptr), _lib.dptr(g.f.col), _lib.dptr(a_src), _lib.dptr(a_dst),
+                                                     float(slope), n, _lib.dptr(alpha), st), "gat_edge_softmax")
         epi = EPI_BIAS if bias is not None else 0
         drop = bool(act) and bool(training) and p > 0.0
         if act:
             epi |= EPI_ELU | (EPI_DROPOUT if drop else 0)
         out = spmm_raw(g.f.rowptr, g.f.col, alpha, g.f.tiles, h, n, bias=bias, epilogue=epi, p=p if drop else 0.0, seed=seed,
-                       mask=mask if drop else None, window_rows=g.window_rows, lcol=g.f.lcol, win_cols=g.f.win_cols, cfg=cfg)
+                       mask=mask if drop else None, window_rows=g.window_rows, lcol=g.f.lcol, win_cols=g.f.win_cols, cfg=cfg,
+                       profile_kind="gat_aggregate")
         ctx.save_for_backward(h, att_src, att_dst, a_src, a_dst, alpha, out if act else None, mask if drop else None)
         ctx.g, ctx.slope, ctx.has_bias, ctx.cfg = g, slope, bias is not None, cfg
         ctx.act, ctx.drop, ctx.p, ctx.seed = bool(act), drop, p, seed
@@ -1371,28 +1395,34 @@ class GATAggregate(torch.autograd.Function):
         g, L = ctx.g, _lib.lib()
         dOut = _f32c(dOut)
         db_fused = None
+        cfg = ctx.cfg
         if ctx.act:   # through ELU / dropout first: dOut becomes the gradient of the pre-activation, db its column sums
-            dOut, db_fused = epilogue_bwd_raw(dOut, out, EPI_ELU | (EPI_DROPOUT if ctx.drop else 0), p=ctx.p if ctx.drop else 0.0,
-                                              seed=ctx.seed, mask=mask, want_db=ctx.has_bias)
+            with _timed(cfg, "gat_epilogue_bwd"):
+                dOut, db_fused = epilogue_bwd_raw(dOut, out, EPI_ELU | (EPI_DROPOUT if ctx.drop else 0), p=ctx.p if ctx.drop else 0.0,
+                                                  seed=ctx.seed, mask=mask, want_db=ctx.has_bias)
         n, C = h.shape
         dev = h.device
         st = _lib.stream_ptr(dev)
         dalpha = torch.empty_like(alpha)
-        _lib.check(L.fitgnn_sddmm_csr_f32(_lib.dptr(g.f.rowptr), _lib.dptr(g.f.col), _lib.dptr(dOut), C, _lib.dptr(h), C, n, C,
-                                          _lib.dptr(dalpha), st), "sddmm")
+        with _timed(cfg, "gat_sddmm"):
+            _lib.check(L.fitgnn_sddmm_csr_f32(_lib.dptr(g.f.rowptr), _lib.dptr(g.f.col), _lib.dptr(dOut), C, _lib.dptr(h), C, n, C,
+                                              _lib.dptr(dalpha), st), "sddmm")
         ds = torch.empty_like(alpha)
         da_dst = torch.empty(n, dtype=torch.float32, device=dev)
-        _lib.check(L.fitgnn_gat_softmax_bwd_f32(_lib.dptr(g.f.rowptr), _lib.dptr(g.f.col), _lib.dptr(a_src), _lib.dptr(a_dst),
-                                                _lib.dptr(alpha), _lib.dptr(dalpha), float(ctx.slope), n, _lib.dptr(ds),
-                                                _lib.dptr(da_dst), st), "gat_softmax_bwd")
-        ds_t = ds[g._perm_t].contiguous()
-        da_src = torch.empty(n, dtype=torch.float32, device=dev)
-        _lib.check(L.fitgnn_csr_row_sum_f32(_lib.dptr(g.t.rowptr), _lib.dptr(ds_t), n, _lib.dptr(da_src), st), "csr_row_sum")
-        # dh = A_alpha^T dOut + da_src (x) att_src + da_dst (x) att_dst
-        alpha_t = alpha[g._perm_t].contiguous()
+        with _timed(cfg, "gat_softmax_bwd"):
+            _lib.check(L.fitgnn_gat_softmax_bwd_f32(_lib.dptr(g.f.rowptr), _lib.dptr(g.f.col), _lib.dptr(a_src), _lib.dptr(a_dst),
+                                                    _lib.dptr(alpha), _lib.dptr(dalpha), float(ctx.slope), n, _lib.dptr(ds),
+                                                    _lib.dptr(da_dst), st), "gat_softmax_bwd")
+        with _timed(cfg, "gat_transpose_edges"):
+            ds_t = ds[g._perm_t].contiguous()
+            da_src = torch.empty(n, dtype=torch.float32, device=dev)
+            _lib.check(L.fitgnn_csr_row_sum_f32(_lib.dptr(g.t.rowptr), _lib.dptr(ds_t), n, _lib.dptr(da_src), st), "csr_row_sum")
+            # dh = A_alpha^T dOut + da_src (x) att_src + da_dst (x) att_dst
+            alpha_t = alpha[g._perm_t].contiguous()
         dh = spmm_raw(g.t.rowptr, g.t.col, alpha_t, g.t.tiles, dOut, n, window_rows=g.window_rows, lcol=g.t.lcol,
-                      win_cols=g.t.win_cols, cfg=ctx.cfg)
-        dh.addcmul_(da_src.unsqueeze(1), att_src.unsqueeze(0)).addcmul_(da_dst.unsqueeze(1), att_dst.unsqueeze(0))
+                      win_cols=g.t.win_cols, cfg=ctx.cfg, profile_kind="gat_aggregate_t")
+        with _timed(cfg, "gat_rank1"):
+            dh.addcmul_(da_src.unsqueeze(1), att_src.unsqueeze(0)).addcmul_(da_dst.unsqueeze(1), att_dst.unsqueeze(0))
         # d(att) = h^T da: both vectors in ONE tall-skinny product through the split-K path (two rocBLAS gemv calls on
         # [R x C]^T took 1.5 ms each on the S-pubmed union)
         datt = mm_at_b(torch.stack([da_src, da_dst], dim=1), h, ctx.cfg) if (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]) else None
@@ -1411,7 +1441,7 @@ class APPNPPropagate(torch.autograd.Function):
     accumulates d z0 = alpha * sum_k dz_{k+1} + dz_0 in the same launches."""
 
     @staticmethod
-    def forward(ctx, z0, g, K, alpha):
+    def forward(ctx, z0, g, K, alpha, cfg=None):
         L = _lib.lib()
         z0 = _f32c(z0)
         n, H = z0.shape
@@ -1420,10 +1450,11 @@ class APPNPPropagate(torch.autograd.Function):
         z = z0
         for _ in range(K):
             nxt = torch.empty_like(z0)
-            _lib.check(L.fitgnn_spmm_narrow_f32(_lib.dptr(f.rowptr), _lib.dptr(f.col), _lib.dptr(f.val), _lib.dptr(z), _lib.dptr(nxt),
-                                                n, H, 1.0 - alpha, _lib.dptr(z0), float(alpha), None, 0.0, st), "spmm_narrow")
+            with _timed(cfg, "appnp_step"):
+                _lib.check(L.fitgnn_spmm_narrow_f32(_lib.dptr(f.rowptr), _lib.dptr(f.col), _lib.dptr(f.val), _lib.dptr(z), _lib.dptr(nxt),
+                                                    n, H, 1.0 - alpha, _lib.dptr(z0), float(alpha), None, 0.0, st), "spmm_narrow")
             z = nxt
-        ctx.g, ctx.K, ctx.alpha = g, K, alpha
+        ctx.g, ctx.K, ctx.alpha, ctx.cfg = g, K, alpha, cfg
         return z
 
     @staticmethod
@@ -1436,10 +1467,11 @@ class APPNPPropagate(torch.autograd.Function):
         acc = torch.zeros_like(dz)
         for _ in range(ctx.K):   # dz_k = (1 - alpha) A^T dz_{k+1};  acc += alpha * dz_{k+1}
             nxt = torch.empty_like(dz)
-            _lib.check(L.fitgnn_spmm_narrow_f32(_lib.dptr(t.rowptr), _lib.dptr(t.col), _lib.dptr(t.val), _lib.dptr(dz), _lib.dptr(nxt),
-                                                n, H, 1.0 - ctx.alpha, None, 0.0, _lib.dptr(acc), float(ctx.alpha), st), "spmm_narrow")
+            with _timed(ctx.cfg, "appnp_step_t"):
+                _lib.check(L.fitgnn_spmm_narrow_f32(_lib.dptr(t.rowptr), _lib.dptr(t.col), _lib.dptr(t.val), _lib.dptr(dz), _lib.dptr(nxt),
+                                                    n, H, 1.0 - ctx.alpha, None, 0.0, _lib.dptr(acc), float(ctx.alpha), st), "spmm_narrow")
             dz = nxt
-        return acc + dz, None, None, None
+        return acc + dz, None, None, None, None
 
 
 _HEAD_MAX = None

@@ -90,6 +90,35 @@ def appnp(x, edge_index, K, alpha):
     return z
 
 
+def classify_node_gat_fwd_bwd(sd, x, edge_index, y, num_layers=2, train_mask=None, dtype=torch.float32):
+    """network.py:29-35 with GATConv layers (--layer_name GATConv) in eval mode: forward, NLL loss, gradients."""
+    params = {k: v.detach().clone().to(dtype).requires_grad_(True) for k, v in sd.items()}
+    h = x.to(dtype)
+    for i in range(num_layers):
+        h = F.elu(gat_conv(h, edge_index, params[f"conv.{i}.lin.weight"], params[f"conv.{i}.att_src"], params[f"conv.{i}.att_dst"],
+                           params.get(f"conv.{i}.bias")))
+    out = F.log_softmax(h @ params["lt1.weight"].t() + params["lt1.bias"], dim=1)
+    sel = out if train_mask is None else out[train_mask]
+    tgt = y if train_mask is None else y[train_mask]
+    loss = F.nll_loss(sel, tgt.long())
+    loss.backward()
+    return out.detach(), loss.detach(), {k: v.grad for k, v in params.items()}
+
+
+def appnp_net_fwd_bwd(sd, x, edge_index, y, K=10, alpha=0.1, train_mask=None, dtype=torch.float32):
+    """Baselines/SGGC/APPNP/networks.py:17-27 in eval mode (dropout is the identity): lin1 -> ReLU -> lin2 -> APPNP -> log_softmax,
+    NLL loss, gradients of lin1 / lin2.  sd keys: lin1.weight, lin1.bias, lin2.weight, lin2.bias."""
+    params = {k: v.detach().clone().to(dtype).requires_grad_(True) for k, v in sd.items()}
+    h = F.relu(x.to(dtype) @ params["lin1.weight"].t() + params["lin1.bias"])
+    z = h @ params["lin2.weight"].t() + params["lin2.bias"]
+    out = F.log_softmax(appnp(z, edge_index, K, alpha), dim=1)
+    sel = out if train_mask is None else out[train_mask]
+    tgt = y if train_mask is None else y[train_mask]
+    loss = F.nll_loss(sel, tgt.long())
+    loss.backward()
+    return out.detach(), loss.detach(), {k: v.grad for k, v in params.items()}
+
+
 def classify_node_forward(sd, x, edge_index, num_layers, masks=None, p=0.5):
     """network.py:29-35 with GCNConv layers; `masks` (list of {0,1} tensors) injects dropout patterns
     (training mode); None = eval mode."""

@@ -89,6 +89,38 @@ def test_sage_gin_appnp(mods):
         assert rel(zg.grad.cpu(), zc.grad) < 1e-4, width
 
 
+@pytest.mark.parametrize("dedup", [False, True])
+def test_appnp_net_follows_the_sggc_model(mods, dedup):
+    """network.APPNPNet (Baselines/SGGC/APPNP/networks.py:7-27) in eval mode vs the oracle: log-probabilities, loss, gradients;
+    on a de-duplicated feature table (the MLP on the table, its output gathered to the union rows) it equals the materialised rows."""
+    from fitgnn_amd import ops
+
+    network, fnn, gorc = mods
+    ei, n = graph(n=400, m=1500, seed=4)
+    torch.manual_seed(2)
+    n_table = 150
+    table = torch.randn(n_table, 36)
+    index = torch.randint(0, n_table, (n,))
+    x = table[index]
+    y = torch.randint(0, 7, (n,))
+    tm = torch.rand(n) < 0.4
+    args = argparse.Namespace(num_features=36, hidden=64, num_classes=7, K=10, alpha=0.1)
+    model = network.APPNPNet(args).cuda().eval()
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    assert sorted(sd) == ["lin1.bias", "lin1.weight", "lin2.bias", "lin2.weight"]
+    if dedup:
+        out = model(table.cuda(), ei.cuda(), x_index=ops.RowIndex(index.cuda(), n_table))
+    else:
+        out = model(x.cuda(), ei.cuda())
+    loss = torch.nn.functional.nll_loss(out[tm.cuda()], y.cuda()[tm.cuda()])
+    loss.backward()
+    o_ref, l_ref, g_ref = gorc.appnp_net_fwd_bwd(sd, x, ei, y, K=10, alpha=0.1, train_mask=tm)
+    assert rel(out.detach().cpu(), o_ref) < 1e-4
+    assert float(loss) == pytest.approx(float(l_ref), rel=1e-5)
+    for k, p in model.named_parameters():
+        assert rel(p.grad.cpu(), g_ref[k]) < 1e-3, k
+
+
 @pytest.mark.parametrize("train", [False, True])
 def test_classify_node_logits_loss_grads(mods, train):
     network, fnn, gorc = mods
