@@ -313,6 +313,9 @@ def main():
     info["t_batch_csr_s"] = round(time.time() - t5, 2)
     del sub
 
+    if args.layer == "GATConv":
+        batch.register_mode("gat")   # the attention layers' CSR over the same star runs as the GCN one
+
     def make_trainer(precision, loss_rows_only=True, prune=None):
         margs = argparse.Namespace(num_layers1=2, layer_name="GCNConv" if args.layer == "APPNP" else args.layer, num_features=F, hidden=H,
                                    num_classes=C, dropout=args.dropout, K=10, alpha=0.1)
@@ -328,8 +331,7 @@ def main():
         kw = {}
         if emu is not None:   # one rank of the N-rank job: the job's train count (every node is a train node), the dist path forced
             kw = dict(process_group=torch.distributed.group.WORLD, global_train_count=float(N))
-        # GATConv has no de-duplicated first layer (its attention scores are per union row): the materialised rows
-        tr = train.GDTrainer(model, batch, lr=0.01, weight_decay=5e-4, dedup=(not args.no_dedup) and args.layer != "GATConv",
+        tr = train.GDTrainer(model, batch, lr=0.01, weight_decay=5e-4, dedup=not args.no_dedup,
                              prune_unused_rows=prune if prune is not None else args.prune_unused_rows, op_config=cfg, **kw)
         return tr, sd
 

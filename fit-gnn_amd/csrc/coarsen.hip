@@ -400,6 +400,10 @@ struct SpecRing {
     // retires in order): no wait -- and the request for its members, issued just before, stays in flight.
     __device__ __forceinline__ void publish_top(int seq, int32_t cand, int32_t off, int32_t len, bool fresh) const {
         if (fresh) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        // not fresh: no wait is needed (above), but the COMPILER must still keep the set's earlier global stores ahead of the LDS stores
+        // that publish it: a release at wavefront scope emits no instruction and pins that order (the hardware side rests on global_*
+        // accesses retiring in order on vmcnt -- tests/test_abi_cpu.py checks that the kernel's ISA holds no flat_ access)
+        else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         if ((threadIdx.x & 63) == 0) { sh->job_cand = cand; sh->job_off = off; sh->job_len = len; sh->job_seq = seq; }
     }
     // (a queue set has its own stored list: a helper's list of a superset of it is of no use)

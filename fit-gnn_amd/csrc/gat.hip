@@ -269,6 +269,109 @@ extern "C" int fitgnn_spmm_narrow_f32(const int32_t *rowptr, const int32_t *col,
     return (int)hipGetLastError();
 }
 
+// The same product for a signal whose rows are PADDED to whole float4s (ld = 4 * h4 floats, pad columns zero): the layout APPNP's K
+// steps run in.  A wave packs G = 64 / h4 consecutive rows: lane = (row slot, float4 column), so an operand row is one contiguous
+// 16 * h4-byte access of h4 lanes and a wave instruction gathers G rows; the first kLongFrom entries of every row are taken in CSR
+// order by the row's own lanes (a leaf of a star has 2-4), the rest of a long row (a centre) is split over all G slots and folded
+// across them -- fixed order: the result does not depend on the launch geometry.  No LDS; consecutive rows of a subgraph sit in one
+// wave, so the gathers of a block-diagonal batch hit L1 / L2.
+constexpr int kLongFrom = 8;
+
+__global__ __launch_bounds__(256) void spmm_narrow_packed_kernel(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                                                 const float *__restrict__ val, const float4 *__restrict__ X,
+                                                                 float4 *__restrict__ Y, int32_t n, int32_t h4, float beta,
+                                                                 const float4 *__restrict__ Z0, float gamma, float4 *__restrict__ ACC,
+                                                                 float delta, int32_t groups_per_wave) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (int)((blockIdx.x * (unsigned)blockDim.x + threadIdx.x) >> 6);
+    const int G = 64 / h4;
+    const int slot = lane / h4, q = lane - slot * h4;
+    const bool lane_on = slot < G;
+    const long n_groups = ((long)n + G - 1) / G;
+    const long g_begin = (long)wave * groups_per_wave;
+    long g_end = g_begin + groups_per_wave;
+    if (g_end > n_groups) g_end = n_groups;
+    for (long g = g_begin; g < g_end; ++g) {
+        const long r = g * G + slot;
+        const bool on = lane_on && r < n;
+        int e = 0, len = 0;
+        if (on) {
+            e = rowptr[r];
+            len = rowptr[r + 1] - e;
+        }
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int head = len < kLongFrom ? len : kLongFrom;
+        int most = head;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) most = max(most, __shfl_xor(most, off, 64));
+        for (int k = 0; k < most; ++k) {
+            if (k < head) {
+                const int c = col[e + k];
+                const float v = val[e + k];
+                const float4 x = X[(long)c * h4 + q];
+                acc.x = fmaf(v, x.x, acc.x); acc.y = fmaf(v, x.y, acc.y); acc.z = fmaf(v, x.z, acc.z); acc.w = fmaf(v, x.w, acc.w);
+            }
+        }
+        // long rows of the group, one after the other (wave-uniform): every slot takes every G-th remaining entry
+        unsigned long long longs = __ballot(on && q == 0 && len > kLongFrom);
+        while (longs) {
+            const int src = __ffsll((long long)longs) - 1;   // lane (slot s0, q = 0)
+            longs &= longs - 1;
+            const int e0 = __shfl(e, src, 64) + kLongFrom;
+            const int e1 = __shfl(e, src, 64) + __shfl(len, src, 64);
+            float4 part = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (lane_on) {
+                for (int k = e0 + slot; k < e1; k += G) {
+                    const int c = col[k];
+                    const float v = val[k];
+                    const float4 x = X[(long)c * h4 + q];
+                    part.x = fmaf(v, x.x, part.x); part.y = fmaf(v, x.y, part.y); part.z = fmaf(v, x.z, part.z); part.w = fmaf(v, x.w, part.w);
+                }
+            }
+            float4 tot = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int s2 = 0; s2 < G; ++s2) {   // fold the slots in slot order
+                const int from = s2 * h4 + q;
+                tot.x += __shfl(part.x, from, 64); tot.y += __shfl(part.y, from, 64);
+                tot.z += __shfl(part.z, from, 64); tot.w += __shfl(part.w, from, 64);
+            }
+            if (lane_on && slot == src / h4) { acc.x += tot.x; acc.y += tot.y; acc.z += tot.z; acc.w += tot.w; }
+        }
+        if (on) {
+            const long o = r * h4 + q;
+            float4 y = make_float4(beta * acc.x, beta * acc.y, beta * acc.z, beta * acc.w);
+            if (Z0) {
+                const float4 z = Z0[o];
+                y.x = fmaf(gamma, z.x, y.x); y.y = fmaf(gamma, z.y, y.y); y.z = fmaf(gamma, z.z, y.z); y.w = fmaf(gamma, z.w, y.w);
+            }
+            Y[o] = y;
+            if (ACC) {
+                const float4 x = X[o];
+                float4 a = ACC[o];
+                a.x = fmaf(delta, x.x, a.x); a.y = fmaf(delta, x.y, a.y); a.z = fmaf(delta, x.z, a.z); a.w = fmaf(delta, x.w, a.w);
+                ACC[o] = a;
+            }
+        }
+    }
+}
+
+extern "C" int fitgnn_spmm_narrow_padded_f32(const int32_t *rowptr, const int32_t *col, const float *val, const float *X, float *Y,
+                                             int32_t n_rows, int32_t h4, float beta, const float *Z0, float gamma, float *ACC,
+                                             float delta, void *stream) {
+    if (n_rows < 0 || h4 < 1 || h4 > 16) return FITGNN_E_BADARG;
+    if (n_rows == 0) return 0;
+    if (!rowptr || !col || !val || !X || !Y) return FITGNN_E_BADARG;
+    if ((((uintptr_t)X | (uintptr_t)Y | (uintptr_t)Z0 | (uintptr_t)ACC) % 16) != 0) return FITGNN_E_ALIGN;
+    const int G = 64 / h4;
+    const long n_groups = ((long)n_rows + G - 1) / G;
+    // ~16 k waves (8 per SIMD and a few rounds), each a contiguous run of groups
+    long waves = n_groups < 16384 ? n_groups : 16384;
+    const int per = (int)((n_groups + waves - 1) / waves);
+    waves = (n_groups + per - 1) / per;
+    hipLaunchKernelGGL(spmm_narrow_packed_kernel, dim3((unsigned)((waves * 64 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rowptr,
+                       col, val, (const float4 *)X, (float4 *)Y, n_rows, h4, beta, (const float4 *)Z0, gamma, (float4 *)ACC, delta, per);
+    return (int)hipGetLastError();
+}
+
 extern "C" int fitgnn_csr_row_sum_f32(const int32_t *rowptr, const float *v, int32_t n, float *y, void *stream) {
     if (n < 0) return FITGNN_E_BADARG;
     if (n == 0) return 0;

@@ -34,9 +34,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int kBK = 32;     // k per stage
 constexpr int kPitch = 36;  // dwords per row of a k-minor LDS image
 
-template <int WM, int WN, bool AKM, bool BKM>
+// A workgroup of WM x WN waves, each wave MI x NJ MFMA blocks of 32 x 32: tile (32 MI WM) x (32 NJ WN).
+template <int WM, int WN, int MI, int NJ, bool AKM, bool BKM>
 struct Geo {
-    static constexpr int TI = 64 * WM, TJ = 128 * WN, THREADS = 64 * WM * WN;
+    static constexpr int TI = 32 * MI * WM, TJ = 32 * NJ * WN, THREADS = 64 * WM * WN;
     static constexpr int A_DW = AKM ? kBK * TI : TI * kPitch;
     static constexpr int B_DW = BKM ? kBK * TJ : TJ * kPitch;
     static constexpr int STAGE_DW = A_DW + B_DW;
@@ -104,11 +105,11 @@ __device__ __forceinline__ void frag(float (&f)[4], const float *lds, int o, int
 
 // nchunks > 1: split over k.  Workgroup (chunk, tile) reduces k in [chunk * chunk_k, +chunk_k) and stores its tile into
 // partial[chunk] (an [I x J] matrix each); sum_chunks_kernel adds them in a fixed order.
-template <int WM, int WN, bool AKM, bool BKM>
-__global__ __launch_bounds__(64 * WM * WN, 1) void gemm_f32_kernel(const float *__restrict__ A, long lda, const float *__restrict__ B, long ldb,
+template <int WM, int WN, int MI, int NJ, bool AKM, bool BKM>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(const float *__restrict__ A, long lda, const float *__restrict__ B, long ldb,
                                                                    long I, int J, long K, float *__restrict__ C, long ldc, int tiles_i,
                                                                    int tiles_j, int nchunks, long chunk_k) {
-    using G = Geo<WM, WN, AKM, BKM>;
+    using G = Geo<WM, WN, MI, NJ, AKM, BKM>;
     extern __shared__ __attribute__((aligned(16))) float lds_f[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = wave / WN, wn = wave % WN;
@@ -133,11 +134,11 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void gemm_f32_kernel(const float *
     const long k_end = nchunks > 1 ? (k_begin + chunk_k < K ? k_begin + chunk_k : K) : K;
     const int nstage = k_end > k_begin ? (int)((k_end - k_begin + kBK - 1) / kBK) : 0;
 
-    f32x16 acc[2][4];
+    f32x16 acc[MI][NJ];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -160,17 +161,17 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void gemm_f32_kernel(const float *
         }
 #pragma unroll
         for (int kk = 0; kk < kBK / 8; ++kk) {
-            float fa[2][4], fb[4][4];
+            float fa[MI][4], fb[NJ][4];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) frag<AKM, G::TI>(fa[i], sa, wm * 64 + i * 32, kk, lane);
+            for (int i = 0; i < MI; ++i) frag<AKM, G::TI>(fa[i], sa, wm * (32 * MI) + i * 32, kk, lane);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) frag<BKM, G::TJ>(fb[j], sb, wn * 128 + j * 32, kk, lane);
+            for (int j = 0; j < NJ; ++j) frag<BKM, G::TJ>(fb[j], sb, wn * (32 * NJ) + j * 32, kk, lane);
 #pragma unroll
             for (int st = 0; st < 4; ++st)
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < MI; ++i)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
+                    for (int j = 0; j < NJ; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][st], fb[j][st], acc[i][j], 0, 0, 0);
         }
         if (more) {
@@ -185,11 +186,11 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void gemm_f32_kernel(const float *
     float *out = nchunks > 1 ? C + (long)chunk * I * J : C;
     const long ldo = nchunks > 1 ? (long)J : ldc;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < MI; ++i) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const long col = j0 + wn * 128 + j * 32 + (lane & 31);
-            const long row0 = i0 + wm * 64 + i * 32 + 4 * (lane >> 5);
+        for (int j = 0; j < NJ; ++j) {
+            const long col = j0 + wn * (32 * NJ) + j * 32 + (lane & 31);
+            const long row0 = i0 + wm * (32 * MI) + i * 32 + 4 * (lane >> 5);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const long row = row0 + (r & 3) + 8 * (r >> 2);
@@ -221,8 +222,16 @@ __global__ __launch_bounds__(256) void sum_chunks_kernel(const float *__restrict
     out[(q / J) * ldc + (q % J)] = acc;
 }
 
+// Tile shapes.  256 x 256 (8 waves of 64 x 128) is the full-grid shape: one workgroup per CU (147 KB of LDS), 64 flop per operand
+// byte.  Its grid is too coarse for the short operands of the configurations (S-pubmed's 19 717-row table: 154 tiles on 256 CUs; a
+// 128-molecule QM9 batch: 38), so smaller tiles take over there: 128 x 128 (4 waves of 64 x 64, 74 KB: two workgroups per CU) and
+// 64 x 128 (4 waves of 32 x 64, 55 KB).  64 x 512 serves the head's weight gradient (<= 64 padded class rows), 256 x 128 a narrow J.
+enum Shape { S256 = 0, S256x128, S64x512, S128, S64x128, S128x64 };
+struct ShapeDim { int ti, tj, per_cu; };
+constexpr ShapeDim kShape[] = {{256, 256, 1}, {256, 128, 1}, {64, 512, 1}, {128, 128, 2}, {64, 128, 2}, {128, 64, 2}};
+
 struct Plan {
-    int wm, wn;          // wave grid of the tile
+    int shape;           // Shape
     int tiles_i, tiles_j, nchunks;
     long chunk_k;
     // the last, mostly empty round of a long grid as a launch of its own (k-minor a only): rows [main_rows, I) split eight ways over k
@@ -233,28 +242,59 @@ struct Plan {
 
 Plan make_plan(long I, int J, long K, bool akm, bool bkm) {
     Plan p;
-    // tile shapes: 256 x 256 by default; a short I (the head's weight gradient: 64 padded class rows) takes 64 x 512, a narrow J
-    // (layer 0's weight gradient on a 100-column table) 256 x 128
-    if (I <= 64 && akm && bkm) { p.wm = 1; p.wn = 4; }
-    else if (J <= 128) { p.wm = 4; p.wn = 1; }
-    else { p.wm = 4; p.wn = 2; }
-    const int TI = 64 * p.wm, TJ = 128 * p.wn;
+    const bool tn = akm && bkm;
+    auto tiles_of = [&](int sh) { return ((I + kShape[sh].ti - 1) / kShape[sh].ti) * ((J + kShape[sh].tj - 1) / kShape[sh].tj); };
+    if (tn) {
+        // split-k forms (the weight gradients): a few output tiles times many k chunks.  A short I (the head's <= 64 padded class rows)
+        // takes 64 x 512; otherwise 128 x 128 tiles give the chunking four times the grid for the same partial traffic -- measured
+        // faster up to k ~ 20 000 (42 vs 60 us at k = 4 861, 102 vs 121 at 19 717) and for a narrow J (204 vs 214 us on the 100-column
+        // table at k = 165 000), slower beyond (744 vs 674 us at 512 x 512 x 165 000: 256 x 256 reads each operand row half as often)
+        if (I <= 64) p.shape = S64x512;
+        else if (J <= 128 || K < 65536) p.shape = S128;
+        else p.shape = S256;
+    } else if (J <= 64) {
+        p.shape = S128x64;   // the head on the loss rows (47 classes): a 128-column tile multiplied mostly padding
+    } else if (getenv("FITGNN_GEMM_NO_SMALL_TILES")) {
+        p.shape = J <= 128 ? S256x128 : S256;
+    } else {
+        // One CU works through ceil(tiles / 256) tiles of TI x TJ outputs each, whatever shares the CU meanwhile; the smaller shapes
+        // lose a little per flop (operands re-read more often; 128 x 128 does not fill its third round evenly) and win whenever the
+        // 256 x 256 grid is coarse: 19 717 rows (154 tiles) 146 -> 111 us, 4 861 rows (38 tiles) 136 -> 45 us, a rank's 20 625 loss rows
+        // 135 -> 120 us; from ~90 000 rows on 256 x 256 is the fastest again (414 vs 423 / 440 us)  [tools/gemm_shape_probe.py]
+        const int cand[3] = {J <= 128 ? S256x128 : S256, S128, S64x128};
+        const double eff[3] = {1.0, K <= 256 ? 1.0 : 0.85, 0.94};   // short k: two workgroups per CU hide each other's stores
+        double best_cost = 0;
+        for (int q = 0; q < 3; ++q) {
+            const int sh = cand[q];
+            const long t = tiles_of(sh);
+            double rounds = (double)((t + 255) / 256);
+            if (q == 0 && !akm && t / 256 >= 1 && t % 256 > 0 && t % 256 <= 96 && K >= 8 * 2 * kBK) rounds = (double)(t / 256) + 0.15;   // tail launch
+            const double cost = rounds * kShape[sh].ti * kShape[sh].tj / eff[q];
+            if (q == 0 || cost < best_cost) { best_cost = cost; p.shape = sh; }
+        }
+    }
+    if (const char *force = getenv("FITGNN_GEMM_SHAPE")) {   // experiments
+        const int f = atoi(force);
+        if (f >= 0 && f <= S128x64 && !(f == S64x512 && !tn)) p.shape = f;
+    }
+    const int TI = kShape[p.shape].ti, TJ = kShape[p.shape].tj;
+    const double slots = 256.0 * kShape[p.shape].per_cu;
     p.tiles_i = (int)((I + TI - 1) / TI);
     p.tiles_j = (J + TJ - 1) / TJ;
     p.nchunks = 1;
     p.chunk_k = K;
-    // Split over k where that shortens the launch.  One workgroup per CU (LDS), 256 CUs: a launch takes ceil(workgroups / 256)
-    // rounds of one tile's time each, so 270 full-k tiles (S-physics' layer 0: 34 493 rows) take two rounds with the second one
-    // 5 % full, and 66 tiles leave 190 CUs idle.  c chunks make the tiles c times shorter at the price of c + 1 passes over an
-    // [I x J] partial matrix; the model below -- fp32 MFMA at ~0.45 TFLOP/s per CU as measured, partials at 3 TB/s -- picks c.
+    // Split over k where that shortens the launch.  A launch takes ceil(workgroups / slots) rounds of one tile's time each, so 270
+    // full-k tiles (S-physics' layer 0: 34 493 rows) take two rounds with the second one 5 % full, and 66 tiles leave 190 CUs idle.
+    // c chunks make the tiles c times shorter at the price of c + 1 passes over an [I x J] partial matrix; the model below -- fp32
+    // MFMA at ~0.45 TFLOP/s per CU as measured, partials at 3 TB/s -- picks c.
     const double ntile = (double)p.tiles_i * p.tiles_j;
-    const double t_tile = 2.0 * TI * TJ * (double)K / 0.45e12;
+    const double t_tile = 2.0 * TI * TJ * (double)K / (0.45e12 / kShape[p.shape].per_cu);
     const long most = K / (4 * kBK);   // at least four stages per chunk
     // chunk counts are multiples of 8: a tile's chunks sit on consecutive block ids = one per XCD (block -> (chunk, tile) below), so
     // any other count leaves XCDs idle (measured: 2 chunks of the 34 493 x 8 448 product took 10.0 ms against 4.6 unsplit, 8: 2.8)
-    double best = ceil(ntile / 256.0) * t_tile;
+    double best = ceil(ntile / slots) * t_tile;
     for (long c = 8; c <= most && c <= 256; c += 8) {
-        const double t = ceil(ntile * (double)c / 256.0) * t_tile / (double)c + (double)(c + 1) * (double)I * (double)J * 4.0 / 3.0e12 + 4e-6;
+        const double t = ceil(ntile * (double)c / slots) * t_tile / (double)c + (double)(c + 1) * (double)I * (double)J * 4.0 / 3.0e12 + 4e-6;
         if (t < 0.92 * best) { best = t; p.nchunks = (int)c; }
     }
     if (const char *force = getenv("FITGNN_GEMM_CHUNKS")) {   // experiments: a fixed chunk count (clamped to what K allows)
@@ -272,7 +312,8 @@ Plan make_plan(long I, int J, long K, bool akm, bool bkm) {
     p.main_rows = 0; p.rem_tiles_i = 0; p.rem_chunks = 1; p.rem_chunk_k = K;
     const long T = (long)p.tiles_i * p.tiles_j;
     const long full = T / 256, rem = T % 256;
-    if (!akm && p.nchunks == 1 && full >= 1 && rem > 0 && rem <= 96 && K >= 8 * 2 * kBK && !getenv("FITGNN_GEMM_CHUNKS") && !getenv("FITGNN_GEMM_NO_TAIL")) {
+    if (!akm && kShape[p.shape].per_cu == 1 && p.nchunks == 1 && full >= 1 && rem > 0 && rem <= 96 && K >= 8 * 2 * kBK &&
+        !getenv("FITGNN_GEMM_CHUNKS") && !getenv("FITGNN_GEMM_NO_TAIL")) {
         const long main_tiles_i = full * 256 / p.tiles_j;
         if (main_tiles_i >= 1 && main_tiles_i < p.tiles_i) {
             p.main_rows = main_tiles_i * TI;
@@ -284,26 +325,31 @@ Plan make_plan(long I, int J, long K, bool akm, bool bkm) {
     return p;
 }
 
-template <int WM, int WN, bool AKM, bool BKM>
+template <int WM, int WN, int MI, int NJ, bool AKM, bool BKM>
 int launch(const Plan &p, const float *a, long lda, const float *b, long ldb, long I, int J, long K, float *c, long ldc, hipStream_t s) {
-    using G = Geo<WM, WN, AKM, BKM>;
+    using G = Geo<WM, WN, MI, NJ, AKM, BKM>;
     static std::atomic<uint64_t> lds_done{0};
-    if (const int rc = fitgnn_lds_limit_once((const void *)gemm_f32_kernel<WM, WN, AKM, BKM>, G::LDS_BYTES, lds_done)) return rc;
+    if (const int rc = fitgnn_lds_limit_once((const void *)gemm_f32_kernel<WM, WN, MI, NJ, AKM, BKM>, G::LDS_BYTES, lds_done)) return rc;
     unsigned grid;
     if (p.nchunks > 1) grid = (unsigned)(p.tiles_i * p.tiles_j * ((p.nchunks + 7) / 8 * 8));   // chunk = xcd + 8 * (slot / tiles)
     else grid = (unsigned)((p.tiles_i + 7) / 8 * 8 * p.tiles_j);
-    hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, AKM, BKM>), dim3(grid), dim3(G::THREADS), G::LDS_BYTES, s, a, lda, b, ldb, I, J, K, c, ldc,
-                       p.tiles_i, p.tiles_j, p.nchunks, p.chunk_k);
+    hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, MI, NJ, AKM, BKM>), dim3(grid), dim3(G::THREADS), G::LDS_BYTES, s, a, lda, b, ldb, I, J, K, c,
+                       ldc, p.tiles_i, p.tiles_j, p.nchunks, p.chunk_k);
     return (int)hipGetLastError();
 }
 
 template <bool AKM, bool BKM>
 int launch_shape(const Plan &p, const float *a, long lda, const float *b, long ldb, long I, int J, long K, float *c, long ldc, hipStream_t s) {
     if constexpr (AKM && BKM) {   // make_plan picks the 64 x 512 tile for this pair only (its k-minor LDS image would not fit)
-        if (p.wm == 1) return launch<1, 4, AKM, BKM>(p, a, lda, b, ldb, I, J, K, c, ldc, s);
+        if (p.shape == S64x512) return launch<1, 4, 2, 4, AKM, BKM>(p, a, lda, b, ldb, I, J, K, c, ldc, s);
     }
-    if (p.wn == 1) return launch<4, 1, AKM, BKM>(p, a, lda, b, ldb, I, J, K, c, ldc, s);
-    return launch<4, 2, AKM, BKM>(p, a, lda, b, ldb, I, J, K, c, ldc, s);
+    switch (p.shape) {
+        case S256x128: return launch<4, 1, 2, 4, AKM, BKM>(p, a, lda, b, ldb, I, J, K, c, ldc, s);
+        case S128: return launch<2, 2, 2, 2, AKM, BKM>(p, a, lda, b, ldb, I, J, K, c, ldc, s);
+        case S64x128: return launch<2, 2, 1, 2, AKM, BKM>(p, a, lda, b, ldb, I, J, K, c, ldc, s);
+        case S128x64: return launch<4, 1, 1, 2, AKM, BKM>(p, a, lda, b, ldb, I, J, K, c, ldc, s);
+        default: return launch<4, 2, 2, 4, AKM, BKM>(p, a, lda, b, ldb, I, J, K, c, ldc, s);
+    }
 }
 
 }  // namespace
@@ -331,7 +377,7 @@ extern "C" int fitgnn_gemm_exact_f32(const float *a, int64_t lda, int32_t a_kmaj
     if (p.main_rows > 0) {   // (k-minor a) the full rounds, then the rows of the last round split over k
         if (!workspace || ((uintptr_t)workspace % 16) != 0) return FITGNN_E_BADARG;
         Plan pm = p, pr = p;
-        pm.tiles_i = (int)(p.main_rows / (64 * p.wm));
+        pm.tiles_i = (int)(p.main_rows / kShape[p.shape].ti);
         pr.tiles_i = p.rem_tiles_i; pr.nchunks = p.rem_chunks; pr.chunk_k = p.rem_chunk_k;
         const long rem_rows = (long)I - p.main_rows;
         const float *a_rem = a + p.main_rows * (long)lda;

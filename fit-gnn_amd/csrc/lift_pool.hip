@@ -406,6 +406,99 @@ extern "C" int fitgnn_pool_rows_f32(const int32_t *assign, const double *cval, i
     return (int)hipGetLastError();
 }
 
+// ---- graph-level pooling on sorted segments (global_mean_pool / global_max_pool of network.py:93,131,164,202) ----------------------
+// out[s][c] = max over the segment's member rows of X[member][c], arg[s][c] = the member row that holds it (the first one on a tie;
+// an empty segment gives -inf / -1).  One wave per (segment, 256-column slab), 16-byte row accesses, members broadcast from registers.
+__global__ __launch_bounds__(256) void segment_max_kernel(const int32_t *__restrict__ off, const int32_t *__restrict__ members, int32_t n_seg,
+                                                          const float *__restrict__ X, int64_t ldx, int32_t F, float *__restrict__ out,
+                                                          int32_t *__restrict__ arg, int32_t n_slabs) {
+    const int slab = blockIdx.x % n_slabs;
+    const int sgm = (blockIdx.x / n_slabs) * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (sgm >= n_seg) return;
+    const int f0 = (slab * 64 + lane) * 4;
+    if (f0 >= F) return;
+    const int m0 = off[sgm], m1 = off[sgm + 1];
+    float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    int who[4] = {-1, -1, -1, -1};
+    for (int m = m0; m < m1; ++m) {
+        const int node = members ? members[m] : m;
+        const float *src = X + (int64_t)node * ldx + f0;
+        float v[4];
+        if (f0 + 4 <= F) { const float4 q = *reinterpret_cast<const float4 *>(src); v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w; }
+        else { for (int i = 0; i < 4; ++i) v[i] = f0 + i < F ? src[i] : -INFINITY; }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (v[i] > best[i] || who[i] < 0) { best[i] = v[i]; who[i] = node; }
+    }
+    for (int i = 0; i < 4 && f0 + i < F; ++i) {
+        out[(int64_t)sgm * F + f0 + i] = best[i];
+        arg[(int64_t)sgm * F + f0 + i] = who[i];
+    }
+}
+
+// dst[r] = scale[seg] * src[seg] for seg = seg_of_row[r] >= 0, a row of zeros otherwise: the backward of a mean / sum pool over row
+// subsets (every row of dst is written: no separate zero fill)
+__global__ __launch_bounds__(256) void segment_expand_kernel(const float *__restrict__ src, const int32_t *__restrict__ seg_of_row,
+                                                             const float *__restrict__ scale, int64_t n_rows, int32_t F4,
+                                                             float4 *__restrict__ dst) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n_rows * F4) return;
+    const int64_t r = t / F4;
+    const int c = (int)(t - r * F4);
+    const int sgm = seg_of_row[r];
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (sgm >= 0) {
+        v = reinterpret_cast<const float4 *>(src)[(int64_t)sgm * F4 + c];
+        if (scale) { const float w = scale[sgm]; v.x *= w; v.y *= w; v.z *= w; v.w *= w; }
+    }
+    dst[t] = v;
+}
+
+// dst[arg[s][c]][c] += g[s][c] (dst zeroed by the caller; every (row, column) is the maximum of at most one segment when the segments
+// are disjoint, so plain read-modify-write stores do not collide)
+__global__ __launch_bounds__(256) void segment_max_bwd_kernel(const float *__restrict__ g, const int32_t *__restrict__ arg, int64_t n,
+                                                              int32_t F, float *__restrict__ dst, int64_t ldd) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n) return;
+    const int a = arg[t];
+    if (a >= 0) dst[(int64_t)a * ldd + (t % F)] = g[t];
+}
+
+extern "C" int fitgnn_segment_max_f32(const int32_t *seg_off, const int32_t *members, int32_t n_seg, const float *X, int64_t ldx,
+                                      int32_t F, float *out, int32_t *arg, void *stream) {
+    if (n_seg < 0 || F < 0 || ldx < F) return FITGNN_E_BADARG;
+    if (n_seg == 0 || F == 0) return 0;
+    if (!seg_off || !X || !out || !arg) return FITGNN_E_BADARG;
+    if ((ldx % 4) != 0 || ((uintptr_t)X % 16) != 0) return FITGNN_E_ALIGN;
+    const int n_slabs = (F + 255) / 256;
+    hipLaunchKernelGGL(segment_max_kernel, dim3((unsigned)((n_seg + 3) / 4) * n_slabs), dim3(256), 0, (hipStream_t)stream, seg_off, members,
+                       n_seg, X, ldx, F, out, arg, n_slabs);
+    return (int)hipGetLastError();
+}
+
+extern "C" int fitgnn_segment_max_bwd_f32(const float *g, const int32_t *arg, int32_t n_seg, int32_t F, float *dst, int64_t ldd,
+                                          void *stream) {
+    if (n_seg < 0 || F < 0 || ldd < F) return FITGNN_E_BADARG;
+    if (n_seg == 0 || F == 0) return 0;
+    if (!g || !arg || !dst) return FITGNN_E_BADARG;
+    const int64_t n = (int64_t)n_seg * F;
+    hipLaunchKernelGGL(segment_max_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g, arg, n, F, dst, ldd);
+    return (int)hipGetLastError();
+}
+
+extern "C" int fitgnn_segment_expand_f32(const float *src, const int32_t *seg_of_row, const float *scale, int64_t n_rows, int32_t F,
+                                         float *dst, void *stream) {
+    if (n_rows < 0 || F < 0 || (F % 4) != 0) return FITGNN_E_BADARG;
+    if (n_rows == 0 || F == 0) return 0;
+    if (!src || !seg_of_row || !dst) return FITGNN_E_BADARG;
+    if ((((uintptr_t)src | (uintptr_t)dst) % 16) != 0) return FITGNN_E_ALIGN;
+    const int64_t n = n_rows * (F / 4);
+    hipLaunchKernelGGL(segment_expand_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, seg_of_row, scale, n_rows,
+                       F / 4, (float4 *)dst);
+    return (int)hipGetLastError();
+}
+
 extern "C" int fitgnn_segment_sum_f32(const int32_t *seg_off, const int32_t *members, int32_t n_seg, const float *X,
                                       int64_t ldx, int32_t F, float *out, int64_t ldo, void *stream) {
     if (n_seg < 0 || F < 0 || ldx < F || ldo < F) return FITGNN_E_BADARG;

@@ -622,7 +622,8 @@ __global__ __launch_bounds__(kThreads, BWD ? 4 : TWO ? 6 : XROW ? 7 : 7) void sp
                             else h = *reinterpret_cast<const T *>(Xc2 + (int64_t)pp * ldxc + colc2);
                         }
                         P::fma(u, w_pub[j], h);
-                        v = epilogue_value<4, true, false>(u, r0 + r, col0, H, bv, rowepi, cs, pv[j]);
+                        // (the clamped column: a lane beyond H must not index an injected mask past its row; its value is never stored)
+                        v = epilogue_value<4, true, false>(u, r0 + r, colc2, H, bv, rowepi, cs, pv[j]);
                     } else {
 #pragma unroll
                         for (int q = 0; q < 4; ++q) cs[q] += P::get(v, q);
@@ -1176,7 +1177,7 @@ __global__ __launch_bounds__(kThreads) void two_hop_rows_kernel(
     }
     float none[4] = {0.f, 0.f, 0.f, 0.f};
     const float bv[4] = {0.f, 0.f, 0.f, 0.f};
-    const T z = epilogue_value<4, true, false>(u, row, col0, H, bv, rowepi, none, o);
+    const T z = epilogue_value<4, true, false>(u, row, colc, H, bv, rowepi, none, o);   // (clamped column: see the two-hop kernel)
     if (live) *reinterpret_cast<T *>(ZT + (int64_t)i * ldz + col0) = z;
 }
 

@@ -51,6 +51,9 @@ SIGNATURES = {
     "fitgnn_spmm_two_hop_blocks_f32": (ctypes.c_int, [ptr, ptr, ptr, ptr, c_i64, ptr, c_i64, c_i32, c_i32, ptr, c_i32, ptr, ptr, ptr, ptr, ptr, c_i64,
                                                       c_i32, ptr, ptr, c_u32, c_f32, c_u64, ptr, ptr, ptr]),
     "fitgnn_segment_sum_f32": (ctypes.c_int, [ptr, ptr, c_i32, ptr, c_i64, c_i32, ptr, c_i64, ptr]),
+    "fitgnn_segment_max_f32": (ctypes.c_int, [ptr, ptr, c_i32, ptr, c_i64, c_i32, ptr, ptr, ptr]),
+    "fitgnn_segment_max_bwd_f32": (ctypes.c_int, [ptr, ptr, c_i32, c_i32, ptr, c_i64, ptr]),
+    "fitgnn_segment_expand_f32": (ctypes.c_int, [ptr, ptr, ptr, c_i64, c_i32, ptr, ptr]),
     "fitgnn_plan_tiles_host": (ctypes.c_int, [ptr, ptr, c_i32, c_i32, ptr, c_i32, c_i32, c_i32, ptr, ptr, ptr, ptr, ptr]),
     "fitgnn_epilogue_bwd_workspace_bytes": (c_size, [c_i32, c_i32]),
     "fitgnn_epilogue_bwd_f32": (ctypes.c_int, [ptr, ptr, ptr, c_i32, c_i32, c_u32, c_f32, c_u64, ptr, ptr, ptr, c_size, ptr]),
@@ -92,6 +95,7 @@ SIGNATURES = {
     "fitgnn_colsum_narrow_workspace_bytes": (c_size, [c_i32, c_i32]),
     "fitgnn_colsum_narrow_f32": (ctypes.c_int, [ptr, c_i64, c_i32, c_i32, ptr, ptr, c_size, ptr]),
     "fitgnn_spmm_narrow_f32": (ctypes.c_int, [ptr, ptr, ptr, ptr, ptr, c_i32, c_i32, c_f32, ptr, c_f32, ptr, c_f32, ptr]),
+    "fitgnn_spmm_narrow_padded_f32": (ctypes.c_int, [ptr, ptr, ptr, ptr, ptr, c_i32, c_i32, c_f32, ptr, c_f32, ptr, c_f32, ptr]),
     "fitgnn_csr_row_sum_f32": (ctypes.c_int, [ptr, ptr, c_i32, ptr, ptr]),
     "fitgnn_closed_neighbourhoods": (ctypes.c_int, [ptr, ptr, c_i32, ptr, ptr, ptr]),
     "fitgnn_variation_costs_f64": (ctypes.c_int, [ptr, ptr, ptr, ptr, ptr, c_i32, c_i64, ptr, ptr, ptr, c_i32, ptr, ptr]),

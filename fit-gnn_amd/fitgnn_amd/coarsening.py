@@ -145,10 +145,12 @@ def lanczos_smallest(L, K, device="cuda", tol=1e-5, m=None, max_restarts=300, se
         _lib.check(Lh.fitgnn_lanczos_reduce_f64(_lib.dptr(part), parts, ncol + 1, _lib.dptr(h_out), st), "lanczos_reduce")
 
     def rotate(src, Smat, dst):
-        """dst[c] = sum_j Smat[j, c] src[j] (Smat: host array [m, nk], nk <= 16)."""
-        Sd = torch.from_numpy(np.ascontiguousarray(Smat, dtype=np.float64)).to(dev)
-        _lib.check(Lh.fitgnn_lanczos_rotate_f64(_lib.dptr(src), N, int(Smat.shape[0]), _lib.dptr(Sd), int(Smat.shape[1]), _lib.dptr(dst), N, N, st),
-                   "lanczos_rotate")
+        """dst[c] = sum_j Smat[j, c] src[j] (Smat: host array [m, nk]); the kernel rotates at most 16 columns per launch: groups."""
+        for c0 in range(0, int(Smat.shape[1]), 16):
+            blk = Smat[:, c0:c0 + 16]
+            Sd = torch.from_numpy(np.ascontiguousarray(blk, dtype=np.float64)).to(dev)
+            _lib.check(Lh.fitgnn_lanczos_rotate_f64(_lib.dptr(src), N, int(blk.shape[0]), _lib.dptr(Sd), int(blk.shape[1]), _lib.dptr(dst[c0:]), N, N,
+                                                    st), "lanczos_rotate")
 
     j0 = 0
     for _ in range(max_restarts):
@@ -170,7 +172,7 @@ def lanczos_smallest(L, K, device="cuda", tol=1e-5, m=None, max_restarts=300, se
         resid = np.abs(Hh[m, m - 1] * S[m - 1, idx])
         if float(resid.max()) <= tol * float(np.abs(theta).max()):
             break
-        keep = order[:min(K + 5, m - 2, 16)]
+        keep = order[:min(K + 5, m - 2)]
         nk = int(keep.size)
         rotate(V, S[:, keep], V2)                 # V2[:nk] = the kept Ritz vectors
         V2[nk].copy_(V[m])

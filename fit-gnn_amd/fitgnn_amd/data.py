@@ -331,6 +331,14 @@ class SubgraphBatch:
             _csr.register(self.edge_index, self.graph, "gcn")  # model(x, edge_index) finds it by identity
         self.nnz = int(self.edge_index.shape[1]) + self.n_rows           # nnz' = directed edges + self loops
 
+    def register_mode(self, mode):
+        """Pre-build (and register for `model(x, edge_index)` to find) this union's CSR in another layer's mode -- 'gat', 'sum', 'mean' --
+        with the SAME row runs as the GCN one (the stars of a star-by-star layout), instead of letting the layer detect the diagonal
+        blocks on its first call."""
+        g = CSRGraph(self.edge_index, self.n_rows, mode=mode, ptr=self.seg_ptr)
+        _csr.register(self.edge_index, g, mode)
+        return g
+
     def slice_batches(self, batch_size=128):
         """(row_begin, row_end) of the reference's loader batches (run.py:336: 128 subgraphs each)."""
         c = len(self.ptr) - 1

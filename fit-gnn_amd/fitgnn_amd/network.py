@@ -65,6 +65,9 @@ class _Base(nn.Module):
     def _first_layer_dedup(self, x_table, edge_index, x_index, link_out=None):
         """Layer 0 on a de-duplicated feature table (x_index: ops.RowIndex mapping union rows to table rows)."""
         conv = self.conv[0]
+        if isinstance(conv, fnn.GATConv) and x_table.is_cuda and link_out is None:
+            mask = self._inject_masks[0] if self._inject_masks is not None else None
+            return conv.forward_elu_dropout(x_table, edge_index, p=self.dropout_p, training=self.training, mask=mask, x_index=x_index)
         if not (isinstance(conv, fnn.GCNConv) and x_table.is_cuda):
             return None
         mask = self._inject_masks[0] if self._inject_masks is not None else None
@@ -283,11 +286,17 @@ def _take(x, mask):
     return x.index_select(0, mask) if mask.dtype == torch.int64 else x[mask]
 
 
+def _pool_rows(pool, x, mask, batch_tensor, size):
+    """pool(x[mask]) per graph (network.py:129-131, :200-202); a precomputed row index (GraphSet batches) is folded into the pool."""
+    if mask.dtype == torch.int64 and x.is_cuda:
+        return pool(x, batch_tensor.to(torch.int64), size, rows=mask)
+    return pool(_take(x, mask), batch_tensor.to(torch.int64), size)
+
+
 class Classify_graph_gs(_Base):
     def forward(self, set_gs, batch_tensor):
         x, ei, mask, size = _gs_inputs(set_gs, batch_tensor)
-        x = _take(self.embed(x, ei), mask)
-        x = self.head(fnn.global_max_pool(x, batch_tensor.to(torch.int64), size))
+        x = self.head(_pool_rows(fnn.global_max_pool, self.embed(x, ei), mask, batch_tensor, size))
         return F.softmax(x, dim=0 if x.dim() == 1 else 1)
 
 
@@ -296,5 +305,4 @@ class Regress_graph_gs(_Base):
 
     def forward(self, set_gs, batch_tensor):
         x, ei, mask, size = _gs_inputs(set_gs, batch_tensor)
-        x = _take(self.embed(x, ei), mask)
-        return self.head(fnn.global_mean_pool(x, batch_tensor.to(torch.int64), size))
+        return self.head(_pool_rows(fnn.global_mean_pool, self.embed(x, ei), mask, batch_tensor, size))

@@ -156,14 +156,17 @@ class GATConv(_OpConfigured, nn.Module):
         return ops.GATAggregate.apply(h, self.att_src.view(-1), self.att_dst.view(-1), self.bias, g, self.negative_slope,
                                       False, 0.0, False, 0, None, cfg)
 
-    def forward_elu_dropout(self, x, edge_index, p=0.5, training=False, mask=None):
-        """conv -> F.elu -> F.dropout (network.py:31-33) with the activation in the aggregation kernel's epilogue."""
-        g = csr_for(edge_index, x.shape[0], "gat")
+    def forward_elu_dropout(self, x, edge_index, p=0.5, training=False, mask=None, x_index=None):
+        """conv -> F.elu -> F.dropout (network.py:31-33) with the activation in the aggregation kernel's epilogue.
+        x_index (ops.RowIndex, optional): x is a de-duplicated feature table and node r of the graph is a copy of table row
+        x_index.index[r]: the Linear and the score dots run on the table (ops.GATAggregate, ridx)."""
+        n = x.shape[0] if x_index is None else int(x_index.index.numel())
+        g = csr_for(edge_index, n, "gat")
         cfg = self.op_config
         h = ops.Linear.apply(x.float(), self.lin.weight, cfg)
         seed = ops.next_seed(cfg) if (training and p > 0 and mask is None) else 0
         return ops.GATAggregate.apply(h, self.att_src.view(-1), self.att_dst.view(-1), self.bias, g, self.negative_slope,
-                                      True, float(p), bool(training), seed, mask, cfg)
+                                      True, float(p), bool(training), seed, mask, cfg, x_index)
 
 
 class APPNP(_OpConfigured, nn.Module):
@@ -187,16 +190,30 @@ class APPNP(_OpConfigured, nn.Module):
         return z
 
 
-def global_mean_pool(x, batch, size=None):
-    """torch_geometric.nn.global_mean_pool (network.py:164,202)."""
+def global_mean_pool(x, batch, size=None, rows=None):
+    """torch_geometric.nn.global_mean_pool (network.py:164,202).  rows (int64 index, optional, an extension): pool x[rows], batch[i]
+    being the graph of rows[i] -- the *_gs models' x[mask] without the gathered copy.  On the GPU with a sorted `batch` (PyG's batch
+    vectors are): one gather-and-sum launch per pool (ops.SegmentMeanPool); otherwise the scatter form."""
     size = int(batch.max().item()) + 1 if size is None else size
+    if ops.pool_supported(x):
+        pi = ops.pool_index(batch, size, rows, x.shape[0])
+        if pi.sorted:
+            return ops.SegmentMeanPool.apply(x, pi)
+    if rows is not None:
+        x = x.index_select(0, rows)
     out = torch.zeros((size, x.shape[1]), dtype=x.dtype, device=x.device).index_add_(0, batch, x)
     cnt = torch.zeros(size, dtype=x.dtype, device=x.device).index_add_(0, batch, torch.ones_like(batch, dtype=x.dtype))
     return out / cnt.clamp(min=1).unsqueeze(1)
 
 
-def global_max_pool(x, batch, size=None):
-    """torch_geometric.nn.global_max_pool (network.py:93,131)."""
+def global_max_pool(x, batch, size=None, rows=None):
+    """torch_geometric.nn.global_max_pool (network.py:93,131); `rows` as in global_mean_pool."""
     size = int(batch.max().item()) + 1 if size is None else size
+    if ops.pool_supported(x):
+        pi = ops.pool_index(batch, size, rows, x.shape[0])
+        if pi.sorted:
+            return ops.SegmentMaxPool.apply(x, pi)
+    if rows is not None:
+        x = x.index_select(0, rows)
     out = torch.full((size, x.shape[1]), float("-inf"), dtype=x.dtype, device=x.device)
     return out.scatter_reduce(0, batch.unsqueeze(1).expand_as(x), x, reduce="amax", include_self=True)

@@ -557,6 +557,13 @@ def spmm_graph(g, X, transposed=False, **kw):
     side = g.t if transposed else g.f
     epi = kw.pop("epilogue", 0) | (_lib.SPMM_GATHER if g.gather else 0)
     Xc = _f32c(X)
+    val = kw.pop("val", None)   # per-call CSR values in the side's entry order (GATConv: the attention weights) instead of side.val
+    if val is not None:
+        split = (side.blocks is not None and Xc.shape[1] % 4 == 0 and Xc.data_ptr() % 16 == 0 and kw.get("cfg", DEFAULT).split_large_blocks)
+        if not split:
+            return spmm_raw(side.rowptr, side.col, val, side.tiles, Xc, g.n, epilogue=epi, window_rows=g.window_rows, lcol=side.lcol,
+                            win_cols=side.win_cols, **kw)
+        return _spmm_split(g, side, val, Xc, epi & ~_lib.SPMM_GATHER, kw)
     if (kw.get("xrow") is not None and kw.get("zero_from", -1) >= 0 and kw.get("cfg", DEFAULT).compact_rows_kernel and Xc.shape[1] % 4 == 0
             and (epi & ~_lib.SPMM_GATHER) == 0 and kw.get("bias") is None and kw.get("out") is None):
         return _spmm_rows_compact(g, side, Xc, kw["xrow"], kw["zero_from"], kw.get("cfg", DEFAULT), kw.get("profile_kind"))
@@ -571,6 +578,11 @@ def spmm_graph(g, X, transposed=False, **kw):
     if not split:
         return spmm_raw(side.rowptr, side.col, side.val, side.tiles, Xc, g.n, epilogue=epi, window_rows=g.window_rows,
                         lcol=side.lcol, win_cols=side.win_cols, **kw)
+    return _spmm_split(g, side, side.val, Xc, epi, kw)
+
+
+def _spmm_split(g, side, val, Xc, epi, kw):
+    """The two launches of a batch with large diagonal blocks: tiles over the small blocks, the whole-subgraph kernel over the rest."""
     out = kw.pop("out", None)
     xrow = kw.pop("xrow", None)
     cfg = kw.pop("cfg", DEFAULT)
@@ -583,12 +595,12 @@ def spmm_graph(g, X, transposed=False, **kw):
         ev[0].record()
     quiet = cfg if cfg.profile is None else cfg.replace(profile=None)
     if side.small_tiles.shape[0]:
-        spmm_raw(side.rowptr, side.col, side.val, side.small_tiles, Xc, g.n, epilogue=epi, window_rows=g.window_rows, out=Y, cfg=quiet,
+        spmm_raw(side.rowptr, side.col, val, side.small_tiles, Xc, g.n, epilogue=epi, window_rows=g.window_rows, out=Y, cfg=quiet,
                  xrow=xrow, zero_from=zero_from, **kw)
     xcol = None
     if xrow is not None:   # the table row of every CSR entry, listed once per (pattern side, index): see fitgnn_spmm_csr_blocks_f32
         xcol = _entry_rows(side, xrow)
-    spmm_blocks_raw(side.rowptr, side.col, side.val, side.blocks, side.long_rows, Xc, Y, epilogue=epi, cfg=quiet, xrow=xrow, xcol=xcol,
+    spmm_blocks_raw(side.rowptr, side.col, val, side.blocks, side.long_rows, Xc, Y, epilogue=epi, cfg=quiet, xrow=xrow, xcol=xcol,
                     zero_from=zero_from, **kw)
     if ev is not None:
         ev[1].record()
@@ -970,6 +982,95 @@ def segment_sum(seg_off, members, X, n_seg):
     _lib.check(_lib.lib().fitgnn_segment_sum_f32(_lib.dptr(seg_off), _lib.dptr(members), n_seg, _lib.dptr(X), F_, F_, _lib.dptr(out),
                                                  F_, _lib.stream_ptr(X.device)), "fitgnn_segment_sum_f32")
     return out
+
+
+class PoolIndex:
+    """Sorted-segment view of a PyG `batch` vector for the graph-level pools (fitgnn_segment_sum / _max / _expand_f32): segment s =
+    the rows of graph s.  rows (int64, optional): the pooled rows are x[rows] (the *_gs models' x[mask], network.py:129,200) and
+    batch[i] is the graph of rows[i] -- the gather is folded into the pool."""
+
+    def __init__(self, batch, size, rows=None, n_rows=None):
+        dev = batch.device
+        b = batch.to(torch.int64)
+        self.n_seg = int(size)
+        self.sorted = bool(b.numel() == 0 or bool((b[1:] >= b[:-1]).all()))
+        cnt = torch.bincount(b, minlength=self.n_seg)
+        off = torch.zeros(self.n_seg + 1, dtype=torch.int64, device=dev)
+        off[1:] = torch.cumsum(cnt, 0)
+        self.seg_off = off.to(torch.int32).contiguous()
+        self.n_rows = int(n_rows if n_rows is not None else (b.numel() if rows is None else 0))
+        if rows is None:
+            self.members = torch.arange(b.numel(), dtype=torch.int32, device=dev)
+            self.seg_of_row = b.to(torch.int32).contiguous()
+        else:
+            self.members = rows.to(torch.int32).contiguous()
+            sr = torch.full((self.n_rows,), -1, dtype=torch.int32, device=dev)
+            sr[rows.long()] = b.to(torch.int32)
+            self.seg_of_row = sr
+        self.inv_cnt = (1.0 / cnt.clamp(min=1).to(torch.float32)).contiguous()
+
+
+def pool_index(batch, size, rows=None, n_rows=None):
+    """PoolIndex of (batch, rows), cached on the batch tensor (a trainer passes the same static tensors every step; building it
+    synchronises with the host once, before any capture)."""
+    cache = getattr(batch, "_fitgnn_pool", None)
+    key = (batch._version, int(size), None if rows is None else (rows.data_ptr(), rows._version), n_rows)
+    if cache is None or cache[0] != key:
+        cache = (key, PoolIndex(batch, size, rows, n_rows), rows)   # (the entry holds `rows`: its address cannot be recycled meanwhile)
+        batch._fitgnn_pool = cache
+    return cache[1]
+
+
+class SegmentMeanPool(torch.autograd.Function):
+    """global_mean_pool over sorted segments: one gather-and-sum launch (fitgnn_segment_sum_f32) + the per-graph 1 / count; backward:
+    one launch writing every row of dx (fitgnn_segment_expand_f32)."""
+
+    @staticmethod
+    def forward(ctx, x, pi):
+        x = _f32c(x)
+        ctx.pi, ctx.shape = pi, x.shape
+        return segment_sum(pi.seg_off, pi.members, x, pi.n_seg) * pi.inv_cnt.unsqueeze(1)
+
+    @staticmethod
+    def backward(ctx, g):
+        pi = ctx.pi
+        n, F_ = ctx.shape
+        g = _f32c(g)
+        dx = torch.empty((n, F_), dtype=torch.float32, device=g.device)
+        _lib.check(_lib.lib().fitgnn_segment_expand_f32(_lib.dptr(g), _lib.dptr(pi.seg_of_row), _lib.dptr(pi.inv_cnt), n, F_, _lib.dptr(dx),
+                                                        _lib.stream_ptr(g.device)), "fitgnn_segment_expand_f32")
+        return dx, None
+
+
+class SegmentMaxPool(torch.autograd.Function):
+    """global_max_pool over sorted segments (fitgnn_segment_max_f32) with the arg-max rows kept for the backward scatter (the first row
+    on a tie takes the whole gradient; torch's scatter_reduce splits it evenly among tied rows)."""
+
+    @staticmethod
+    def forward(ctx, x, pi):
+        x = _f32c(x)
+        n, F_ = x.shape
+        out = torch.empty((pi.n_seg, F_), dtype=torch.float32, device=x.device)
+        arg = torch.empty((pi.n_seg, F_), dtype=torch.int32, device=x.device)
+        _lib.check(_lib.lib().fitgnn_segment_max_f32(_lib.dptr(pi.seg_off), _lib.dptr(pi.members), pi.n_seg, _lib.dptr(x), x.stride(0), F_,
+                                                     _lib.dptr(out), _lib.dptr(arg), _lib.stream_ptr(x.device)), "fitgnn_segment_max_f32")
+        ctx.save_for_backward(arg)
+        ctx.shape = x.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (arg,) = ctx.saved_tensors
+        n, F_ = ctx.shape
+        g = _f32c(g)
+        dx = torch.zeros((n, F_), dtype=torch.float32, device=g.device)
+        _lib.check(_lib.lib().fitgnn_segment_max_bwd_f32(_lib.dptr(g), _lib.dptr(arg), int(arg.shape[0]), F_, _lib.dptr(dx), F_,
+                                                         _lib.stream_ptr(g.device)), "fitgnn_segment_max_bwd_f32")
+        return dx, None
+
+
+def pool_supported(x):
+    return x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and x.shape[1] % 4 == 0 and x.shape[0] > 0
 
 
 class RowIndex:
@@ -1360,19 +1461,25 @@ class GATAggregate(torch.autograd.Function):
     (CSRGraph(mode='gat')); attention weights replace its values."""
 
     @staticmethod
-    def forward(ctx, h, att_src, att_dst, bias, g, slope, act, p, training, seed, mask, cfg):
-        """act=True fuses F.elu and F.dropout(p) (network.py:32-33) into the aggregation's epilogue, as for GCNConv."""
+    def forward(ctx, h, att_src, att_dst, bias, g, slope, act, p, training, seed, mask, cfg, ridx=None):
+        """act=True fuses F.elu and F.dropout(p) (network.py:32-33) into the aggregation's epilogue, as for GCNConv.
+        ridx (RowIndex, optional): h is a de-duplicated TABLE [N0, C] and row r of the graph is a copy of table row ridx.index[r] (the
+        first layer of a union batch: h = x W^T and the score dots run on the N0 original nodes; the aggregation, the SDDMM and the
+        softmax read the table through the row indirection; the backward sums each node's copies before the weight-side products)."""
         L = _lib.lib()
         h = _f32c(h)
-        n, C = h.shape
+        nh, C = h.shape
+        n = g.n
         dev = h.device
         st = _lib.stream_ptr(dev)
-        a_src = torch.empty(n, dtype=torch.float32, device=dev)
-        a_dst = torch.empty(n, dtype=torch.float32, device=dev)
+        a_src = torch.empty(nh, dtype=torch.float32, device=dev)
+        a_dst = torch.empty(nh, dtype=torch.float32, device=dev)
         att_src, att_dst = _f32c(att_src.reshape(-1)), _f32c(att_dst.reshape(-1))
         with _timed(cfg, "gat_scores"):
-            _lib.check(L.fitgnn_gat_scores_f32(_lib.dptr(h), C, n, C, _lib.dptr(att_src), _lib.dptr(att_dst), _lib.dptr(a_src),
+            _lib.check(L.fitgnn_gat_scores_f32(_lib.dptr(h), C, nh, C, _lib.dptr(att_src), _lib.dptr(att_dst), _lib.dptr(a_src),
                                                _lib.dptr(a_dst), st), "gat_scores")
+            if ridx is not None:   # per union row
+                a_src, a_dst = a_src.index_select(0, ridx.index.long()), a_dst.index_select(0, ridx.index.long())
         alpha = torch.empty(g.nnz, dtype=torch.float32, device=dev)
         with _timed(cfg, "gat_edge_softmax"):
             _lib.check(L.fitgnn_gat_edge_softmax_f32(_lib.dptr(g.f.rowptr), _lib.dptr(g.f.col), _lib.dptr(a_src), _lib.dptr(a_dst),
@@ -1381,11 +1488,11 @@ class GATAggregate(torch.autograd.Function):
         drop = bool(act) and bool(training) and p > 0.0
         if act:
             epi |= EPI_ELU | (EPI_DROPOUT if drop else 0)
-        out = spmm_raw(g.f.rowptr, g.f.col, alpha, g.f.tiles, h, n, bias=bias, epilogue=epi, p=p if drop else 0.0, seed=seed,
-                       mask=mask if drop else None, window_rows=g.window_rows, lcol=g.f.lcol, win_cols=g.f.win_cols, cfg=cfg,
-                       profile_kind="gat_aggregate")
+        # (a union whose runs go to the whole-subgraph kernel takes it here too: the attention weights are the launch's CSR values)
+        out = spmm_graph(g, h, val=alpha, bias=bias, epilogue=epi, p=p if drop else 0.0, seed=seed, mask=mask if drop else None, cfg=cfg,
+                         profile_kind="gat_aggregate", xrow=None if ridx is None else ridx.index)
         ctx.save_for_backward(h, att_src, att_dst, a_src, a_dst, alpha, out if act else None, mask if drop else None)
-        ctx.g, ctx.slope, ctx.has_bias, ctx.cfg = g, slope, bias is not None, cfg
+        ctx.g, ctx.slope, ctx.has_bias, ctx.cfg, ctx.ridx = g, slope, bias is not None, cfg, ridx
         ctx.act, ctx.drop, ctx.p, ctx.seed = bool(act), drop, p, seed
         return out
 
@@ -1400,12 +1507,16 @@ class GATAggregate(torch.autograd.Function):
             with _timed(cfg, "gat_epilogue_bwd"):
                 dOut, db_fused = epilogue_bwd_raw(dOut, out, EPI_ELU | (EPI_DROPOUT if ctx.drop else 0), p=ctx.p if ctx.drop else 0.0,
                                                   seed=ctx.seed, mask=mask, want_db=ctx.has_bias)
-        n, C = h.shape
+        C = h.shape[1]
+        n = g.n
+        ridx = ctx.ridx
         dev = h.device
         st = _lib.stream_ptr(dev)
         dalpha = torch.empty_like(alpha)
+        # (with a table operand the entries' columns are its rows: index[col], listed once per graph and index)
+        ecol = g.f.col if ridx is None else _entry_rows(g.f, ridx.index)
         with _timed(cfg, "gat_sddmm"):
-            _lib.check(L.fitgnn_sddmm_csr_f32(_lib.dptr(g.f.rowptr), _lib.dptr(g.f.col), _lib.dptr(dOut), C, _lib.dptr(h), C, n, C,
+            _lib.check(L.fitgnn_sddmm_csr_f32(_lib.dptr(g.f.rowptr), _lib.dptr(ecol), _lib.dptr(dOut), C, _lib.dptr(h), C, n, C,
                                               _lib.dptr(dalpha), st), "sddmm")
         ds = torch.empty_like(alpha)
         da_dst = torch.empty(n, dtype=torch.float32, device=dev)
@@ -1419,59 +1530,79 @@ class GATAggregate(torch.autograd.Function):
             _lib.check(L.fitgnn_csr_row_sum_f32(_lib.dptr(g.t.rowptr), _lib.dptr(ds_t), n, _lib.dptr(da_src), st), "csr_row_sum")
             # dh = A_alpha^T dOut + da_src (x) att_src + da_dst (x) att_dst
             alpha_t = alpha[g._perm_t].contiguous()
-        dh = spmm_raw(g.t.rowptr, g.t.col, alpha_t, g.t.tiles, dOut, n, window_rows=g.window_rows, lcol=g.t.lcol,
-                      win_cols=g.t.win_cols, cfg=ctx.cfg, profile_kind="gat_aggregate_t")
+        dh = spmm_graph(g, dOut, transposed=True, val=alpha_t, cfg=ctx.cfg, profile_kind="gat_aggregate_t")
         with _timed(cfg, "gat_rank1"):
-            dh.addcmul_(da_src.unsqueeze(1), att_src.unsqueeze(0)).addcmul_(da_dst.unsqueeze(1), att_dst.unsqueeze(0))
+            da = torch.stack([da_src, da_dst], dim=1)                              # [rows, 2]
+            if ridx is not None:   # every node's copies summed: the table's gradient and its two score gradients
+                dh = segment_sum(ridx.seg_off, ridx.members, dh, ridx.n_table)
+                da = torch.zeros((ridx.n_table, 2), dtype=torch.float32, device=dev).index_add_(0, ridx.index.long(), da)
+            # dh += da_src (x) att_src + da_dst (x) att_dst: one rank-2 pass over dh
+            dh.addmm_(da, torch.stack([att_src, att_dst], dim=0))
         # d(att) = h^T da: both vectors in ONE tall-skinny product through the split-K path (two rocBLAS gemv calls on
         # [R x C]^T took 1.5 ms each on the S-pubmed union)
-        datt = mm_at_b(torch.stack([da_src, da_dst], dim=1), h, ctx.cfg) if (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]) else None
+        datt = mm_at_b(da, h, ctx.cfg) if (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]) else None
         datt_src = datt[0] if ctx.needs_input_grad[1] else None
         datt_dst = datt[1] if ctx.needs_input_grad[2] else None
         if ctx.act:
             db = db_fused if ctx.has_bias else None
         else:
             db = dOut.sum(0) if ctx.has_bias and ctx.needs_input_grad[3] else None
-        return dh, datt_src, datt_dst, db, None, None, None, None, None, None, None, None
+        return dh, datt_src, datt_dst, db, None, None, None, None, None, None, None, None, None
 
 
 class APPNPPropagate(torch.autograd.Function):
     """z_K of  z_{k+1} = (1 - alpha) A_hat z_k + alpha z0,  z_0 = z0  (APPNP's K propagation steps) on a class-wide signal,
     one narrow-SpMM launch per step with the teleport term in its epilogue; the backward pass propagates with A_hat^T and
-    accumulates d z0 = alpha * sum_k dz_{k+1} + dz_0 in the same launches."""
+    accumulates d z0 = alpha * sum_k dz_{k+1} + dz_0 in the same launches.  The K steps run on a copy of the signal whose rows are
+    padded to whole float4s (fitgnn_spmm_narrow_padded_f32: a wave packs 64 / h4 rows, operand rows are contiguous 16-byte accesses)."""
+
+    @staticmethod
+    def _padded(z, h4):
+        n, H = z.shape
+        if H == 4 * h4:
+            return z
+        zp = torch.zeros((n, 4 * h4), dtype=torch.float32, device=z.device)
+        zp[:, :H] = z
+        return zp
 
     @staticmethod
     def forward(ctx, z0, g, K, alpha, cfg=None):
         L = _lib.lib()
         z0 = _f32c(z0)
         n, H = z0.shape
+        h4 = (H + 3) // 4
         st = _lib.stream_ptr(z0.device)
         f = g.f
-        z = z0
+        z0p = APPNPPropagate._padded(z0, h4)
+        z = z0p
         for _ in range(K):
-            nxt = torch.empty_like(z0)
+            nxt = torch.empty_like(z0p)
             with _timed(cfg, "appnp_step"):
-                _lib.check(L.fitgnn_spmm_narrow_f32(_lib.dptr(f.rowptr), _lib.dptr(f.col), _lib.dptr(f.val), _lib.dptr(z), _lib.dptr(nxt),
-                                                    n, H, 1.0 - alpha, _lib.dptr(z0), float(alpha), None, 0.0, st), "spmm_narrow")
+                _lib.check(L.fitgnn_spmm_narrow_padded_f32(_lib.dptr(f.rowptr), _lib.dptr(f.col), _lib.dptr(f.val), _lib.dptr(z), _lib.dptr(nxt),
+                                                           n, h4, 1.0 - alpha, _lib.dptr(z0p), float(alpha), None, 0.0, st), "spmm_narrow_padded")
             z = nxt
-        ctx.g, ctx.K, ctx.alpha, ctx.cfg = g, K, alpha, cfg
-        return z
+        ctx.g, ctx.K, ctx.alpha, ctx.cfg, ctx.H = g, K, alpha, cfg, H
+        return z if H == 4 * h4 else z[:, :H].contiguous()
 
     @staticmethod
     def backward(ctx, dz):
         L = _lib.lib()
         dz = _f32c(dz)
         n, H = dz.shape
+        h4 = (H + 3) // 4
         st = _lib.stream_ptr(dz.device)
         t = ctx.g.t
+        dz = APPNPPropagate._padded(dz, h4)
         acc = torch.zeros_like(dz)
         for _ in range(ctx.K):   # dz_k = (1 - alpha) A^T dz_{k+1};  acc += alpha * dz_{k+1}
             nxt = torch.empty_like(dz)
             with _timed(ctx.cfg, "appnp_step_t"):
-                _lib.check(L.fitgnn_spmm_narrow_f32(_lib.dptr(t.rowptr), _lib.dptr(t.col), _lib.dptr(t.val), _lib.dptr(dz), _lib.dptr(nxt),
-                                                    n, H, 1.0 - ctx.alpha, None, 0.0, _lib.dptr(acc), float(ctx.alpha), st), "spmm_narrow")
+                _lib.check(L.fitgnn_spmm_narrow_padded_f32(_lib.dptr(t.rowptr), _lib.dptr(t.col), _lib.dptr(t.val), _lib.dptr(dz), _lib.dptr(nxt),
+                                                           n, h4, 1.0 - ctx.alpha, None, 0.0, _lib.dptr(acc), float(ctx.alpha), st),
+                           "spmm_narrow_padded")
             dz = nxt
-        return acc + dz, None, None, None, None
+        out = acc + dz
+        return (out if H == 4 * h4 else out[:, :H].contiguous()), None, None, None, None
 
 
 _HEAD_MAX = None

@@ -113,6 +113,15 @@ def broadcast_parameters(model, process_group=None, flat=None):
             dist.broadcast(b.data, src, group=process_group)
 
 
+def _make_adam(model, flat, lr, weight_decay):
+    """Adam(lr, weight_decay) (run.py:344) for a trainer: on the GPU ONE kernel over the flat parameter buffer (FlatAdam: same
+    arithmetic as torch.optim.Adam, step counter on the device: safe to capture in a hipGraph; torch's multi-tensor Adam takes 39 us
+    per step on these six tensors, this 6); on the CPU (host-side logic tests) torch's optimiser itself."""
+    if next(model.parameters()).is_cuda:
+        return FlatAdam(flat, lr=lr, weight_decay=weight_decay)
+    return torch.optim.Adam(model.parameters(), lr=lr, weight_decay=weight_decay)
+
+
 class GDTrainer:
     def __init__(self, model, batch, lr=0.01, weight_decay=5e-4, reduction="mean", process_group=None, dedup=True,
                  task="node_cls", prune_unused_rows=False, op_config=None, global_train_count=None):
@@ -272,7 +281,11 @@ class _CapturedSteps:
         saved_m = {k: v.detach().clone() for k, v in self.model.state_dict().items()}
         # Adam's moment / step tensors must EXIST before capture (a lazily initialised state would be allocated and
         # zeroed inside the first captured step, i.e. reset on every replay): warm up, then restore them in place
-        saved_o = {p: {k: (v.clone() if torch.is_tensor(v) else v) for k, v in st.items()} for p, st in self.opt.state.items()}
+        flat_opt = isinstance(self.opt, FlatAdam)   # its state (m, v, the device-resident step counter) exists from construction
+        if flat_opt:
+            saved_o = (self.opt.m.clone(), self.opt.v.clone(), self.opt.step_count.clone())
+        else:
+            saved_o = {p: {k: (v.clone() if torch.is_tensor(v) else v) for k, v in st.items()} for p, st in self.opt.state.items()}
         # the captured kernels read their dropout seeds through the bank's device pointers: the model runs under a copy of
         # its config that carries the bank while the steps are built (replays re-run no Python)
         prev = self.model.op_config
@@ -287,10 +300,13 @@ class _CapturedSteps:
             torch.cuda.current_stream(dev).wait_stream(side)
             torch.cuda.synchronize(dev)
             self.model.load_state_dict(saved_m)
-            for p, st in self.opt.state.items():
-                for k, v in st.items():
-                    if torch.is_tensor(v):
-                        v.copy_(saved_o[p][k]) if p in saved_o and k in saved_o[p] else v.zero_()
+            if flat_opt:
+                self.opt.m.copy_(saved_o[0]); self.opt.v.copy_(saved_o[1]); self.opt.step_count.copy_(saved_o[2])
+            else:
+                for p, st in self.opt.state.items():
+                    for k, v in st.items():
+                        if torch.is_tensor(v):
+                            v.copy_(saved_o[p][k]) if p in saved_o and k in saved_o[p] else v.zero_()
             self.flat.zero()
             pool = torch.cuda.graph_pool_handle()
             self._graphs = []
@@ -327,10 +343,8 @@ class MBTrainer(_CapturedSteps):
 
         self.model, self.reduction = model, reduction
         self.capture, self._graphs = bool(capture), None
-        fused = next(model.parameters()).is_cuda
-        self.opt = torch.optim.Adam(model.parameters(), lr=lr, weight_decay=weight_decay, fused=fused,
-                                    capturable=bool(capture) and fused)
         self.flat = FlatGrads(model.parameters())
+        self.opt = _make_adam(model, self.flat, lr, weight_decay)
         ei = batch.edge_index
         order = torch.argsort(ei[0], stable=True)
         src_sorted = ei[0][order].contiguous()
@@ -407,13 +421,11 @@ class GraphTrainer(_CapturedSteps):
         self.truncate = truncate_targets
         self.accumulate = bool(accumulate)
         self.capture, self._graphs = bool(capture), None
-        fused = next(model.parameters()).is_cuda
         if share is not None:   # evaluation-only views of the same model: one optimiser / gradient buffer (run.py:718-719)
             self.opt, self.flat = share.opt, share.flat
         else:
-            self.opt = torch.optim.Adam(model.parameters(), lr=lr, weight_decay=weight_decay, fused=fused,
-                                        capturable=bool(capture) and fused)
             self.flat = FlatGrads(model.parameters())
+            self.opt = _make_adam(model, self.flat, lr, weight_decay)
         self._rebuild = None
         if batches is None and reshuffle:
             self.capture = False
@@ -558,8 +570,14 @@ def _cat_pieces(pieces, kind, types):
     if kind == "gs":
         b["mask_idx"] = torch.nonzero(mask).flatten()      # precomputed: x[mask] would synchronise with the host
         b["graph_of_masked"] = graph[mask]
+        if x.is_cuda:   # the pool's segment index, built now (it synchronises once; a captured step must not)
+            from . import ops
+            ops.pool_index(b["graph_of_masked"], n_graphs, b["mask_idx"], int(x.shape[0]))
     else:
         b["gc"] = types.SimpleNamespace(x=x, edge_index=e, batch=graph, num_graphs=n_graphs)
+        if x.is_cuda:
+            from . import ops
+            ops.pool_index(graph, n_graphs, None, int(x.shape[0]))
     return b
 
 

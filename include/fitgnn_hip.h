@@ -257,6 +257,20 @@ int fitgnn_spmm_csr_f32(const int32_t *rowptr, const int32_t *col, const float *
 int fitgnn_segment_sum_f32(const int32_t *seg_off, const int32_t *members, int32_t n_seg, const float *X, int64_t ldx,
                            int32_t F, float *out, int64_t ldo, void *stream);
 
+/* Graph-level pooling over SORTED segments (torch_geometric.nn.global_mean_pool / global_max_pool as called from network.py:93,131,
+ * 164,202; a batch's rows are grouped by graph).  members (int32, may be NULL = the identity) lists the pooled rows -- the row mask
+ * x[mask] of the *_gs models (network.py:129,200) is folded into the pool: no gathered copy.
+ *   mean / sum: fitgnn_segment_sum_f32 above (+ a per-graph scale);
+ *   max: out[s][c] = max_m X[members[m]][c], arg[s][c] = that row (first on a tie; -inf / -1 for an empty segment);
+ *   backward of mean / sum: fitgnn_segment_expand_f32 writes EVERY row of dst [n_rows x F]: scale[seg] * src[seg] for seg =
+ *     seg_of_row[r] >= 0 and zeros otherwise (F % 4 == 0);
+ *   backward of max: fitgnn_segment_max_bwd_f32 stores g[s][c] at dst[arg[s][c]][c] (dst zeroed by the caller; segments disjoint). */
+int fitgnn_segment_max_f32(const int32_t *seg_off, const int32_t *members, int32_t n_seg, const float *X, int64_t ldx, int32_t F,
+                           float *out, int32_t *arg, void *stream);
+int fitgnn_segment_max_bwd_f32(const float *g, const int32_t *arg, int32_t n_seg, int32_t F, float *dst, int64_t ldd, void *stream);
+int fitgnn_segment_expand_f32(const float *src, const int32_t *seg_of_row, const float *scale, int64_t n_rows, int32_t F, float *dst,
+                              void *stream);
+
 /* out[W] = sum over b < B of part[b][W] in a fixed order (W % 4 == 0, 16-byte aligned): combines the partial products
  * of the split-K weight-gradient GEMM dH^T @ X (the library has no deterministic split-K for K = number of rows). */
 int fitgnn_sum_leading_f32(const float *part, int32_t B, int64_t W, float *out, void *stream);
@@ -426,6 +440,12 @@ int fitgnn_csr_row_sum_f32(const int32_t *rowptr, const float *v, int32_t n, flo
 int fitgnn_spmm_narrow_f32(const int32_t *rowptr, const int32_t *col, const float *val, const float *X, float *Y,
                            int32_t n_rows, int32_t H, float beta, const float *Z0, float gamma, float *ACC, float delta,
                            void *stream);
+/* The same product on a signal whose rows are padded to whole float4s: X, Y, Z0, ACC are [n_rows x 4 * h4] (1 <= h4 <= 16, pad
+ * columns zero, 16-byte aligned) -- the layout APPNP's K steps run in (ops.APPNPPropagate): a wave packs 64 / h4 consecutive rows,
+ * an operand row is one contiguous access, long rows (a star's centre) are split over the wave.  Fixed summation order. */
+int fitgnn_spmm_narrow_padded_f32(const int32_t *rowptr, const int32_t *col, const float *val, const float *X, float *Y,
+                                  int32_t n_rows, int32_t h4, float beta, const float *Z0, float gamma, float *ACC, float delta,
+                                  void *stream);
 
 /* =====================================================================================
  * Coarsen half: one contraction level of variation_neighborhoods

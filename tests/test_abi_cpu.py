@@ -119,7 +119,8 @@ def test_round3_entry_points_check_their_arguments_without_a_gpu():
     assert L.fitgnn_gemm_exact_workspace_bytes(165000, 512, 512, 0, 0) == 8 * (165000 - 163840) * 512 * 4
     assert L.fitgnn_gemm_exact_workspace_bytes(5 * 128 * 256, 512, 512, 0, 0) == 0                 # whole rounds only: one launch
     assert L.fitgnn_gemm_exact_workspace_bytes(165000, 512, 512, 1, 1) != 8 * 1160 * 512 * 4       # the tail launch needs a k-minor a
-    assert L.fitgnn_gemm_exact_workspace_bytes(512, 512, 165000, 1, 1) == 64 * 512 * 512 * 4       # 4 tiles: 64 chunks
+    wb = L.fitgnn_gemm_exact_workspace_bytes(512, 512, 165000, 1, 1)                               # a few tiles of a long k: split,
+    assert wb >= 16 * 512 * 512 * 4 and wb % (8 * 512 * 512 * 4) == 0                              # in multiples of 8 chunks
     wb = L.fitgnn_gemm_exact_workspace_bytes(34493, 512, 8448, 0, 0)                               # 270 tiles of a long k: split
     assert wb > 0 and (wb // (34493 * 512 * 4)) % 8 == 0
     assert L.fitgnn_gemm_exact_workspace_bytes(0, 8, 8, 0, 0) == 0

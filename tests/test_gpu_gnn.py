@@ -151,6 +151,44 @@ def test_classify_node_logits_loss_grads(mods, train):
         assert rel(p.grad.cpu(), g_ref[k]) < 1e-3, k
 
 
+@pytest.mark.parametrize("F_", [512, 36])
+@pytest.mark.parametrize("with_rows", [False, True])
+def test_segment_pools_equal_the_scatter_pools(mods, F_, with_rows):
+    """global_mean_pool / global_max_pool on the segment kernels (fitgnn_segment_sum / _max / _expand_f32; sorted batch vector, the
+    x[mask] gather of the *_gs models folded in) against the scatter forms: values and input gradients; empty graphs included."""
+    network, fnn, gorc = mods
+    torch.manual_seed(7)
+    n, G = 700, 40
+    sizes = torch.randint(0, 30, (G,))
+    sizes[3] = 0
+    sizes[-1] = 0
+    batch_all = torch.repeat_interleave(torch.arange(G), sizes)
+    n = int(batch_all.numel())
+    x = torch.randn(n, F_)
+    if with_rows:
+        keep = torch.rand(n) < 0.6
+        rows = torch.nonzero(keep).flatten()
+        batch = batch_all[rows]
+    else:
+        rows, batch = None, batch_all
+    w = torch.randn(G, F_)
+    for pool, ref_pool in ((fnn.global_mean_pool, "mean"), (fnn.global_max_pool, "max")):
+        xg = x.cuda().requires_grad_(True)
+        out = pool(xg, batch.cuda(), G, rows=None if rows is None else rows.cuda())
+        xr = x.clone().requires_grad_(True)
+        sel = xr if rows is None else xr[rows]
+        if ref_pool == "mean":
+            ref = torch.zeros(G, F_).index_add_(0, batch, sel) / torch.bincount(batch, minlength=G).clamp(min=1).unsqueeze(1)
+        else:
+            ref = torch.full((G, F_), float("-inf")).scatter_reduce(0, batch.unsqueeze(1).expand_as(sel), sel, reduce="amax", include_self=True)
+        finite = torch.isfinite(ref)
+        assert torch.equal(torch.isfinite(out.detach().cpu()), finite)
+        assert rel(torch.where(finite, out.detach().cpu(), torch.zeros(())), torch.where(finite, ref.detach(), torch.zeros(()))) < 1e-6
+        (out * torch.where(finite, w, torch.zeros(())).cuda()).nan_to_num(0.0, 0.0, 0.0).sum().backward()
+        (torch.where(finite, ref, torch.zeros(())) * w).sum().backward()
+        assert rel(xg.grad.cpu(), xr.grad) < 1e-6
+
+
 def test_graph_level_models(mods):
     network, fnn, gorc = mods
     from types import SimpleNamespace
@@ -225,8 +263,10 @@ def test_classify_node_with_gat_layers(mods):
     assert rel(out, ref) < 1e-4
 
 
-def test_dedup_first_layer_equals_materialised_rows(mods):
-    """Layer 0 on the de-duplicated table + SpMM row indirection == layer 0 on the gathered union rows."""
+@pytest.mark.parametrize("layer_name", ["GCNConv", "GATConv"])
+def test_dedup_first_layer_equals_materialised_rows(mods, layer_name):
+    """Layer 0 on the de-duplicated table + SpMM row indirection == layer 0 on the gathered union rows (GCN; GAT: the Linear and the
+    score dots on the table, aggregation / SDDMM / softmax through the indirection, the copies' gradients summed per node)."""
     network, fnn, gorc = mods
     from fitgnn_amd import ops
 
@@ -236,7 +276,7 @@ def test_dedup_first_layer_equals_materialised_rows(mods):
     idx = torch.randint(0, N0, (n,))
     idx[:N0] = torch.arange(N0)
     Xt = torch.rand(N0, 40)
-    args = argparse.Namespace(num_layers1=2, layer_name="GCNConv", num_features=40, hidden=128, num_classes=5)
+    args = argparse.Namespace(num_layers1=2, layer_name=layer_name, num_features=40, hidden=128, num_classes=5)
     model = network.Classify_node(args).cuda().train()
     masks = [(torch.rand(n, 128) > 0.5).to(torch.uint8).cuda() for _ in range(2)]
     model._inject_masks = masks

@@ -619,11 +619,12 @@ def test_weight_gradient_gemm_is_the_split_policys_path(mods):
 # down), rows around the 256 / 64-row tiles, k around the 32-wide stage and the chunking of the split-k form, strided operands.
 EXACT_SHAPES = {
     "nt": [(90549, 512, 512), (20000, 512, 100), (4097, 260, 96), (1024, 512, 32), (257, 64, 64), (5, 4, 36), (19717, 500, 512),
-           (300, 128, 500), (1, 4, 4), (33068, 512, 512), (34493, 512, 1024)],   # the last two: a last round of 4 / 14 tiles, launched split over k
+           (300, 128, 500), (1, 4, 4), (33068, 512, 512), (34493, 512, 1024),   # the last two: a last round of 4 / 14 tiles, launched split over k
+           (4861, 512, 512), (20625, 512, 512), (70000, 512, 512)],   # a 128-molecule QM9 batch (64 x 128 tiles), a rank's loss rows (128 x 128), 1.07 rounds
     "nn": [(90549, 512, 512), (4097, 96, 260), (257, 64, 64), (19717, 512, 500), (5, 36, 4), (1000, 100, 512), (33068, 512, 512),
-           (165000, 512, 512)],
+           (165000, 512, 512), (4861, 512, 512), (20625, 512, 512)],
     "tn": [(90549, 512, 512), (19717, 512, 500), (165000, 48, 512), (40000, 512, 100), (4097, 260, 36), (1000, 64, 128), (256, 512, 4),
-           (33, 8, 4), (31, 8, 8), (2048, 4, 4), (1, 4, 4), (2047, 64, 512)],
+           (33, 8, 4), (31, 8, 8), (2048, 4, 4), (1, 4, 4), (2047, 64, 512), (4861, 512, 512)],
 }
 
 
@@ -664,6 +665,30 @@ def test_exact_fp32_gemm_matches_f64(mods, form, dims):
     assert float((ops.gemm_exact(va, vb, form) - want).abs().max() / want.abs().max()) < 3e-6
     # exact zeros survive
     assert float(ops.gemm_exact(torch.zeros_like(a), b, form).abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("form,dims", [("nt", (4861, 512, 512)), ("nn", (19717, 512, 512)), ("nt", (3000, 260, 100)), ("nn", (700, 96, 132))])
+def test_exact_fp32_gemm_tile_shapes_give_the_same_bits(mods, form, dims, monkeypatch):
+    """Without a k split every output element is ONE MFMA chain over k in ascending order whatever tile it sits in: the 256 x 256,
+    128 x 128 and 64 x 128 tile shapes (csrc/gemm_f32.hip: make_plan takes the smaller ones for grids under a round) give
+    bit-identical products."""
+    _lib, csr, ops, orc, gorc = mods
+    g = torch.Generator().manual_seed(sum(dims))
+    if form == "nt":
+        I, J, K = dims
+        a, b = torch.randn(I, K, generator=g).cuda(), torch.randn(J, K, generator=g).cuda()
+    else:
+        I, K, J = dims
+        a, b = torch.randn(I, K, generator=g).cuda(), torch.randn(K, J, generator=g).cuda()
+    outs = []
+    for shape in ("0", "3", "4"):   # S256, S128, S64x128
+        monkeypatch.setenv("FITGNN_GEMM_SHAPE", shape)
+        monkeypatch.setenv("FITGNN_GEMM_NO_TAIL", "1")
+        outs.append(ops.gemm_exact(a, b, form))
+    monkeypatch.delenv("FITGNN_GEMM_SHAPE")
+    monkeypatch.delenv("FITGNN_GEMM_NO_TAIL")
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    assert torch.equal(outs[0], ops.gemm_exact(a, b, form))   # (none of these shapes has a k split or a tail launch in its default plan)
 
 
 def test_exact_fp32_gemm_is_the_default_policy_and_differentiates(mods):
