@@ -80,19 +80,22 @@ __global__ __launch_bounds__(256) void gat_edge_softmax_kernel(const int32_t *__
 }
 
 // d_alpha[e] = dOut[row] . h[col[e]]        (SDDMM; one wave per row keeps dOut[row] in registers)
+// sel (may be NULL): the launch covers the rows sel[0 .. n) only and dOut is COMPACT (row i of dOut belongs to row sel[i]); entries of
+// other rows are not written (the caller zeroes dalpha)
 template <int MAXV>  // MAXV float4 per lane: C <= 256 * MAXV
 __global__ __launch_bounds__(256) void gat_sddmm_kernel(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
                                                         const float *__restrict__ dOut, int64_t ldo,
                                                         const float *__restrict__ h, int64_t ldh, int32_t n, int32_t C,
-                                                        float *__restrict__ dalpha) {
-    const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+                                                        float *__restrict__ dalpha, const int64_t *__restrict__ sel) {
+    const int wi = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
-    if (row >= n) return;
+    if (wi >= n) return;
+    const int row = sel ? (int)sel[wi] : wi;
     float4 g[MAXV];
 #pragma unroll
     for (int v = 0; v < MAXV; ++v) {
         const int c = (v * 64 + lane) * 4;
-        g[v] = c < C ? *reinterpret_cast<const float4 *>(dOut + (int64_t)row * ldo + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        g[v] = c < C ? *reinterpret_cast<const float4 *>(dOut + (int64_t)wi * ldo + c) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     const int e0 = rowptr[row], e1 = rowptr[row + 1];
     // the row's column ids sit on the lanes; four edges per step: their operand rows are all in flight before the first
@@ -131,15 +134,16 @@ __global__ __launch_bounds__(256) void gat_sddmm_kernel(const int32_t *__restric
 __global__ __launch_bounds__(256) void gat_sddmm_scalar_kernel(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
                                                                const float *__restrict__ dOut, int64_t ldo,
                                                                const float *__restrict__ h, int64_t ldh, int32_t n, int32_t C,
-                                                               float *__restrict__ dalpha) {
-    const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+                                                               float *__restrict__ dalpha, const int64_t *__restrict__ sel) {
+    const int wi = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
-    if (row >= n) return;
+    if (wi >= n) return;
+    const int row = sel ? (int)sel[wi] : wi;
     const int e0 = rowptr[row], e1 = rowptr[row + 1];
     for (int e = e0; e < e1; ++e) {
         const float *hr = h + (int64_t)col[e] * ldh;
         float s = 0.f;
-        for (int c = lane; c < C; c += 64) s += dOut[(int64_t)row * ldo + c] * hr[c];
+        for (int c = lane; c < C; c += 64) s += dOut[(int64_t)wi * ldo + c] * hr[c];
         s = wave_sum(s);
         if (lane == 0) dalpha[e] = s;
     }
@@ -151,10 +155,11 @@ __global__ __launch_bounds__(256) void gat_softmax_bwd_kernel(const int32_t *__r
                                                               const float *__restrict__ a_src, const float *__restrict__ a_dst,
                                                               const float *__restrict__ alpha, const float *__restrict__ dalpha,
                                                               float slope, int32_t n, float *__restrict__ ds,
-                                                              float *__restrict__ da_dst) {
-    const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+                                                              float *__restrict__ da_dst, const int64_t *__restrict__ sel) {
+    const int wi = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
-    if (row >= n) return;
+    if (wi >= n) return;
+    const int row = sel ? (int)sel[wi] : wi;   // (sel: only these rows' entries and da_dst are written: the caller zeroes ds / da_dst)
     const int e0 = rowptr[row], e1 = rowptr[row + 1];
     float dot = 0.f;
     for (int e = e0 + lane; e < e1; e += 64) dot += alpha[e] * dalpha[e];
@@ -207,22 +212,34 @@ extern "C" int fitgnn_gat_edge_softmax_f32(const int32_t *rowptr, const int32_t 
     return (int)hipGetLastError();
 }
 
+static int sddmm_launch(const int32_t *rowptr, const int32_t *col, const float *dOut, int64_t ldo, const float *h, int64_t ldh, int32_t n,
+                        int32_t C, float *dalpha, const int64_t *sel, hipStream_t s) {
+    const bool vec = (C % 4 == 0) && (ldo % 4 == 0) && (ldh % 4 == 0) && ((((uintptr_t)dOut | (uintptr_t)h) % 16) == 0);
+    if (vec && C <= 256)
+        hipLaunchKernelGGL(gat_sddmm_kernel<1>, wave_grid(n), dim3(256), 0, s, rowptr, col, dOut, ldo, h, ldh, n, C, dalpha, sel);
+    else if (vec && C <= 512)
+        hipLaunchKernelGGL(gat_sddmm_kernel<2>, wave_grid(n), dim3(256), 0, s, rowptr, col, dOut, ldo, h, ldh, n, C, dalpha, sel);
+    else if (vec && C <= 1024)
+        hipLaunchKernelGGL(gat_sddmm_kernel<4>, wave_grid(n), dim3(256), 0, s, rowptr, col, dOut, ldo, h, ldh, n, C, dalpha, sel);
+    else
+        hipLaunchKernelGGL(gat_sddmm_scalar_kernel, wave_grid(n), dim3(256), 0, s, rowptr, col, dOut, ldo, h, ldh, n, C, dalpha, sel);
+    return (int)hipGetLastError();
+}
+
 extern "C" int fitgnn_sddmm_csr_f32(const int32_t *rowptr, const int32_t *col, const float *dOut, int64_t ldo, const float *h,
                                     int64_t ldh, int32_t n, int32_t C, float *dalpha, void *stream) {
     if (n < 0 || C < 0 || ldo < C || ldh < C) return FITGNN_E_BADARG;
     if (n == 0) return 0;
     if (!rowptr || !dOut || !h) return FITGNN_E_BADARG;
-    hipStream_t s = (hipStream_t)stream;
-    const bool vec = (C % 4 == 0) && (ldo % 4 == 0) && (ldh % 4 == 0) && ((((uintptr_t)dOut | (uintptr_t)h) % 16) == 0);
-    if (vec && C <= 256)
-        hipLaunchKernelGGL(gat_sddmm_kernel<1>, wave_grid(n), dim3(256), 0, s, rowptr, col, dOut, ldo, h, ldh, n, C, dalpha);
-    else if (vec && C <= 512)
-        hipLaunchKernelGGL(gat_sddmm_kernel<2>, wave_grid(n), dim3(256), 0, s, rowptr, col, dOut, ldo, h, ldh, n, C, dalpha);
-    else if (vec && C <= 1024)
-        hipLaunchKernelGGL(gat_sddmm_kernel<4>, wave_grid(n), dim3(256), 0, s, rowptr, col, dOut, ldo, h, ldh, n, C, dalpha);
-    else
-        hipLaunchKernelGGL(gat_sddmm_scalar_kernel, wave_grid(n), dim3(256), 0, s, rowptr, col, dOut, ldo, h, ldh, n, C, dalpha);
-    return (int)hipGetLastError();
+    return sddmm_launch(rowptr, col, dOut, ldo, h, ldh, n, C, dalpha, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int fitgnn_sddmm_csr_rows_f32(const int32_t *rowptr, const int32_t *col, const float *dOut_c, int64_t ldo, const float *h,
+                                         int64_t ldh, const int64_t *sel, int32_t n_sel, int32_t C, float *dalpha, void *stream) {
+    if (n_sel < 0 || C < 0 || ldo < C || ldh < C) return FITGNN_E_BADARG;
+    if (n_sel == 0) return 0;
+    if (!rowptr || !dOut_c || !h || !sel || !dalpha) return FITGNN_E_BADARG;
+    return sddmm_launch(rowptr, col, dOut_c, ldo, h, ldh, n_sel, C, dalpha, sel, (hipStream_t)stream);
 }
 
 extern "C" int fitgnn_gat_softmax_bwd_f32(const int32_t *rowptr, const int32_t *col, const float *a_src, const float *a_dst,
@@ -232,7 +249,18 @@ extern "C" int fitgnn_gat_softmax_bwd_f32(const int32_t *rowptr, const int32_t *
     if (n == 0) return 0;
     if (!rowptr || !a_src || !a_dst || !da_dst) return FITGNN_E_BADARG;
     hipLaunchKernelGGL(gat_softmax_bwd_kernel, wave_grid(n), dim3(256), 0, (hipStream_t)stream, rowptr, col, a_src, a_dst, alpha,
-                       dalpha, negative_slope, n, ds, da_dst);
+                       dalpha, negative_slope, n, ds, da_dst, (const int64_t *)nullptr);
+    return (int)hipGetLastError();
+}
+
+extern "C" int fitgnn_gat_softmax_bwd_rows_f32(const int32_t *rowptr, const int32_t *col, const float *a_src, const float *a_dst,
+                                               const float *alpha, const float *dalpha, float negative_slope, const int64_t *sel,
+                                               int32_t n_sel, float *ds, float *da_dst, void *stream) {
+    if (n_sel < 0) return FITGNN_E_BADARG;
+    if (n_sel == 0) return 0;
+    if (!rowptr || !a_src || !a_dst || !da_dst || !sel) return FITGNN_E_BADARG;
+    hipLaunchKernelGGL(gat_softmax_bwd_kernel, wave_grid(n_sel), dim3(256), 0, (hipStream_t)stream, rowptr, col, a_src, a_dst, alpha,
+                       dalpha, negative_slope, n_sel, ds, da_dst, sel);
     return (int)hipGetLastError();
 }
 

@@ -272,6 +272,9 @@ Plan make_plan(long I, int J, long K, bool akm, bool bkm) {
             const double cost = rounds * kShape[sh].ti * kShape[sh].tj / eff[q];
             if (q == 0 || cost < best_cost) { best_cost = cost; p.shape = sh; }
         }
+        // a long k on a grid of a round or two is split over k below: 128 x 128 tiles give the chunking four times the workgroups
+        // for the same partial traffic (S-physics' layer 0, 34 493 x 512 x 8 448: 2.57 ms against 2.67-2.82 with 256 x 256 tiles)
+        if (K >= 4096 && tiles_of(S256) <= 512 && J > 128) p.shape = S128;
     }
     if (const char *force = getenv("FITGNN_GEMM_SHAPE")) {   // experiments
         const int f = atoi(force);

@@ -123,3 +123,81 @@ extern "C" int fitgnn_plan_tiles_host(const int32_t *rowptr, const int32_t *col,
     *n_win = P.nw;
     return 0;
 }
+
+// ---- contiguous-window tiles and whole-subgraph block records from the diagonal-block boundaries (host; once per static batch) ----
+namespace {
+// consecutive blocks packed into tiles of at most max_rows rows (window == the tile's own rows); a block beyond max_rows is cut into
+// max_rows-row pieces.  Appends (row_begin, row_end, win_begin, win_rows) records; returns false when `cap` records do not suffice.
+bool pack_tiles(const int64_t *ptr, int64_t b0, int64_t b1, int64_t max_rows, int32_t *out, int64_t cap, int64_t &n) {
+    int64_t b = b0;
+    while (b < b1) {
+        const int64_t start = ptr[b], size = ptr[b + 1] - start;
+        if (size > max_rows) {
+            for (int64_t s = start; s < start + size; s += max_rows) {
+                const int64_t e = std::min(s + max_rows, start + size);
+                if (n >= cap) return false;
+                int32_t *t = out + 4 * n++;
+                t[0] = (int32_t)s; t[1] = (int32_t)e; t[2] = (int32_t)s; t[3] = (int32_t)(e - s);
+            }
+            ++b;
+            continue;
+        }
+        int64_t e = b + 1;   // furthest block end within start + max_rows
+        while (e < b1 && ptr[e + 1] - start <= max_rows) ++e;
+        if (n >= cap) return false;
+        int32_t *t = out + 4 * n++;
+        t[0] = (int32_t)start; t[1] = (int32_t)ptr[e]; t[2] = (int32_t)start; t[3] = (int32_t)(ptr[e] - start);
+        b = e;
+    }
+    return true;
+}
+}  // namespace
+
+extern "C" int fitgnn_make_tiles_host(const int64_t *ptr, int64_t n_blocks, int32_t max_rows, int32_t *tiles4, int64_t capacity,
+                                      int64_t *n_tiles) {
+    if (n_blocks < 0 || max_rows < 1 || capacity < 0 || !n_tiles) return FITGNN_E_BADARG;
+    *n_tiles = 0;
+    if (n_blocks == 0) return 0;
+    if (!ptr || !tiles4) return FITGNN_E_BADARG;
+    int64_t n = 0;
+    if (!pack_tiles(ptr, 0, n_blocks, max_rows, tiles4, capacity, n)) return FITGNN_E_WORKSPACE;
+    *n_tiles = n;
+    return 0;
+}
+
+extern "C" int fitgnn_split_blocks_host(const int64_t *ptr, int64_t n_blocks, const int32_t *rowptr, int32_t cap, int64_t limit,
+                                        int32_t long_row, int32_t *tiles4, int64_t tiles_capacity, int64_t *n_tiles, int32_t *blocks8,
+                                        int64_t *n_large, int32_t *long_rows, int64_t long_capacity, int64_t *n_long) {
+    if (n_blocks < 0 || cap < 1 || !n_tiles || !n_large || !n_long) return FITGNN_E_BADARG;
+    *n_tiles = *n_large = *n_long = 0;
+    if (n_blocks == 0) return 0;
+    if (!ptr || !rowptr || !tiles4 || !blocks8 || !long_rows) return FITGNN_E_BADARG;
+    int64_t nt = 0, nl = 0, nlong = 0;
+    int64_t b = 0;
+    while (b < n_blocks) {
+        const int64_t size = ptr[b + 1] - ptr[b];
+        const bool large = size > cap && size <= limit;
+        if (!large) {   // a maximal run of other blocks -> tiles (never packed across a whole-subgraph block)
+            int64_t e = b;
+            while (e < n_blocks && !((ptr[e + 1] - ptr[e]) > cap && (ptr[e + 1] - ptr[e]) <= limit)) ++e;
+            if (!pack_tiles(ptr, b, e, cap, tiles4, tiles_capacity, nt)) return FITGNN_E_WORKSPACE;
+            b = e;
+            continue;
+        }
+        const int64_t r0 = ptr[b], r1 = ptr[b + 1];
+        int32_t *rec = blocks8 + 8 * nl++;
+        rec[0] = (int32_t)r0; rec[1] = (int32_t)r1; rec[2] = rowptr[r0]; rec[3] = rowptr[r1];
+        rec[4] = (int32_t)nlong; rec[6] = rec[7] = 0;
+        int32_t cnt = 0;
+        for (int64_t r = r0; r < r1; ++r)
+            if (rowptr[r + 1] - rowptr[r] > long_row) {
+                if (nlong >= long_capacity) return FITGNN_E_WORKSPACE;
+                long_rows[nlong++] = (int32_t)r;
+                ++cnt;
+            }
+        rec[5] = cnt;
+        ++b;
+    }
+    *n_tiles = nt; *n_large = nl; *n_long = nlong;
+    return 0;
+}

@@ -54,6 +54,8 @@ SIGNATURES = {
     "fitgnn_segment_max_f32": (ctypes.c_int, [ptr, ptr, c_i32, ptr, c_i64, c_i32, ptr, ptr, ptr]),
     "fitgnn_segment_max_bwd_f32": (ctypes.c_int, [ptr, ptr, c_i32, c_i32, ptr, c_i64, ptr]),
     "fitgnn_segment_expand_f32": (ctypes.c_int, [ptr, ptr, ptr, c_i64, c_i32, ptr, ptr]),
+    "fitgnn_make_tiles_host": (ctypes.c_int, [ptr, c_i64, c_i32, ptr, c_i64, ptr]),
+    "fitgnn_split_blocks_host": (ctypes.c_int, [ptr, c_i64, ptr, c_i32, c_i64, c_i32, ptr, c_i64, ptr, ptr, ptr, ptr, c_i64, ptr]),
     "fitgnn_plan_tiles_host": (ctypes.c_int, [ptr, ptr, c_i32, c_i32, ptr, c_i32, c_i32, c_i32, ptr, ptr, ptr, ptr, ptr]),
     "fitgnn_epilogue_bwd_workspace_bytes": (c_size, [c_i32, c_i32]),
     "fitgnn_epilogue_bwd_f32": (ctypes.c_int, [ptr, ptr, ptr, c_i32, c_i32, c_u32, c_f32, c_u64, ptr, ptr, ptr, c_size, ptr]),
@@ -72,6 +74,8 @@ SIGNATURES = {
     "fitgnn_gat_scores_f32": (ctypes.c_int, [ptr, c_i64, c_i32, c_i32, ptr, ptr, ptr, ptr, ptr]),
     "fitgnn_gat_edge_softmax_f32": (ctypes.c_int, [ptr, ptr, ptr, ptr, c_f32, c_i32, ptr, ptr]),
     "fitgnn_sddmm_csr_f32": (ctypes.c_int, [ptr, ptr, ptr, c_i64, ptr, c_i64, c_i32, c_i32, ptr, ptr]),
+    "fitgnn_sddmm_csr_rows_f32": (ctypes.c_int, [ptr, ptr, ptr, c_i64, ptr, c_i64, ptr, c_i32, c_i32, ptr, ptr]),
+    "fitgnn_gat_softmax_bwd_rows_f32": (ctypes.c_int, [ptr, ptr, ptr, ptr, ptr, ptr, c_f32, ptr, c_i32, ptr, ptr, ptr]),
     "fitgnn_gat_softmax_bwd_f32": (ctypes.c_int, [ptr, ptr, ptr, ptr, ptr, ptr, c_f32, c_i32, ptr, ptr, ptr]),
     "fitgnn_softmax_nll_workspace_bytes": (c_size, [c_i32]),
     "fitgnn_softmax_nll_f32": (ctypes.c_int, [ptr, c_i64, c_i32, c_i32, ptr, ptr, c_i32, c_f32, ptr, ptr, ptr, c_size, ptr]),

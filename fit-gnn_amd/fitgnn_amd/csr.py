@@ -88,7 +88,26 @@ def make_tiles(ptr, max_rows, whole=True):
     """Pack consecutive diagonal blocks into row tiles of at most `max_rows` rows (window == the tile's
     own row range, so every column of a block-diagonal batch is a window hit).  Blocks larger than
     `max_rows` are cut into `max_rows`-row pieces whose window is the piece itself (off-window columns
-    are fetched from global memory by the kernel)."""
+    are fetched from global memory by the kernel).  Runs in the library's host code (fitgnn_make_tiles_host: the S-products
+    union has 165 000 stars and 515 000 tiles -- 0.1 s as a Python loop); make_tiles_py is the same packing in Python."""
+    ptr = np.ascontiguousarray(ptr, dtype=np.int64)
+    nb = len(ptr) - 1
+    n = int(ptr[-1]) if nb >= 0 and len(ptr) else 0
+    cap = nb + n // max(int(max_rows), 1) + 2
+    buf = np.zeros((cap, 4), dtype=np.int32)
+    nt = ctypes.c_int64(0)
+    vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+    _lib.check(_lib.lib().fitgnn_make_tiles_host(vp(ptr), nb, int(max_rows), vp(buf), cap, ctypes.byref(nt)), "fitgnn_make_tiles_host")
+    out = np.zeros(nt.value, dtype=TILE_DTYPE)
+    if nt.value:
+        arr = buf[: nt.value]
+        out["row_begin"], out["row_end"], out["win_begin"], out["win_rows"] = arr[:, 0], arr[:, 1], arr[:, 2], arr[:, 3]
+    assert (not whole) or n == 0 or (out["row_begin"][0] == 0 and out["row_end"][-1] == n)
+    return out
+
+
+def make_tiles_py(ptr, max_rows, whole=True):
+    """make_tiles as a Python loop (the reference the host code is tested against)."""
     ptr = np.asarray(ptr, dtype=np.int64)
     n = int(ptr[-1])
     tiles = []
@@ -143,7 +162,39 @@ def split_blocks(ptr, rowptr, cap, limit=None):
     never across a whole-subgraph block; a block beyond `limit` is cut into cap-row tiles as before).  limit bounds the
     longest-running workgroup: by default rows / 2048 (a 256-CU chip then holds >= 8 such blocks per CU), at least 4 pieces.
     ptr: block row offsets (numpy); rowptr: device/host int tensor.
-    Returns (tiles TILE_DTYPE array, blocks int32 [NB, 8], long_rows int32 [NL]) as numpy."""
+    Returns (tiles TILE_DTYPE array, blocks int32 [NB, 8], long_rows int32 [NL]) as numpy.
+    Runs in the library's host code (fitgnn_split_blocks_host); split_blocks_py is the same in NumPy / Python."""
+    ptr = np.ascontiguousarray(ptr, dtype=np.int64)
+    rp = np.ascontiguousarray(rowptr.detach().cpu().numpy() if torch.is_tensor(rowptr) else rowptr, dtype=np.int32)
+    nb = len(ptr) - 1
+    n = int(ptr[-1])
+    if limit is None:
+        limit = max(4 * cap, n // 2048)
+    t_cap = nb + n // max(int(cap), 1) + 2
+    tiles4 = np.zeros((t_cap, 4), dtype=np.int32)
+    blocks = np.zeros((max(nb, 1), BLOCK_INTS), dtype=np.int32)
+    longs = np.zeros(max(n, 1), dtype=np.int32)
+    nt, nl, nlong = ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int64(0)
+    vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+    _lib.check(_lib.lib().fitgnn_split_blocks_host(vp(ptr), nb, vp(rp), int(cap), int(limit), LONG_ROW, vp(tiles4), t_cap, ctypes.byref(nt),
+                                                   vp(blocks), ctypes.byref(nl), vp(longs), len(longs), ctypes.byref(nlong)),
+               "fitgnn_split_blocks_host")
+    small = np.zeros(nt.value, dtype=TILE_DTYPE)
+    if nt.value:
+        arr = tiles4[: nt.value]
+        small["row_begin"], small["row_end"], small["win_begin"], small["win_rows"] = arr[:, 0], arr[:, 1], arr[:, 2], arr[:, 3]
+    blocks = blocks[: nl.value].copy()
+    long_rows = longs[: nlong.value].copy()
+    if nl.value:
+        # row order, an equal share of the rows per XCD (position p runs on XCD p % 8): the stars of one subgraph run on one
+        # XCD at about the same time, so what they still gather from each other (leaf -- leaf edges across stars: 12 % of the
+        # entries of S-products) has a chance of being in that XCD's L2
+        blocks = arrange_tiles_for_xcds(blocks, work=(blocks[:, 1] - blocks[:, 0]).astype(np.int64))
+    return small, blocks, long_rows
+
+
+def split_blocks_py(ptr, rowptr, cap, limit=None):
+    """split_blocks in NumPy / Python (the reference the host code is tested against)."""
     ptr = np.asarray(ptr, dtype=np.int64)
     rp = rowptr.detach().cpu().numpy().astype(np.int64)
     size = np.diff(ptr)
@@ -162,7 +213,7 @@ def split_blocks(ptr, rowptr, cap, limit=None):
         e = b
         while e < nb and not is_large[e]:
             e += 1
-        tiles.append(make_tiles(ptr[b:e + 1], cap, whole=False) if e > b else None)
+        tiles.append(make_tiles_py(ptr[b:e + 1], cap, whole=False) if e > b else None)
         b = e
     small = np.concatenate([t for t in tiles if t is not None and len(t)]) if any(t is not None and len(t) for t in tiles) else np.zeros(0, dtype=TILE_DTYPE)
     blocks = np.zeros((len(large), BLOCK_INTS), dtype=np.int32)

@@ -77,11 +77,11 @@ class _Base(nn.Module):
         return ops.FusedGCNLayerDedup.apply(x_table.float(), conv.lin.weight, conv.bias, g, x_index, float(self.dropout_p),
                                             bool(self.training), seed, mask, link_out, cfg)
 
-    def embed(self, x, edge_index, x_index=None, first=0, link=None):
-        """conv -> ELU -> dropout, num_layers times (network.py:29-33).  link: the EpilogueLink recorded by the layer that
-        produced x (consecutive fused GCN layers are linked: see ops.EpilogueLink; the stack is strictly sequential)."""
+    def embed(self, x, edge_index, x_index=None, first=0, link=None, last=None):
+        """conv -> ELU -> dropout, layers first .. last - 1 (default: all; network.py:29-33).  link: the EpilogueLink recorded by the
+        layer that produced x (consecutive fused GCN layers are linked: see ops.EpilogueLink; the stack is strictly sequential)."""
         x = x.float()
-        for i in range(first, self.num_layers):
+        for i in range(first, self.num_layers if last is None else last):
             conv = self.conv[i]
             if isinstance(conv, fnn.GCNConv) and x.is_cuda:
                 mask = self._inject_masks[i] if self._inject_masks is not None else None
@@ -132,6 +132,19 @@ class _Base(nn.Module):
         else:
             link = None
         if not fused_tail:
+            cfg = self.op_config
+            if (L > 0 and x.is_cuda and isinstance(last, fnn.GATConv) and loss_rows is not None and cfg.last_layer_on_loss_rows
+                    and loss_rows.numel() > 0 and last.lin.weight.shape[0] % 4 == 0 and last.lin.weight.shape[1] % 4 == 0
+                    and ops.head_rows_supported(x.new_empty((1, last.lin.weight.shape[0])), self.lt1.weight)
+                    and (first == L - 1 or isinstance(self.conv[L - 2], (fnn.GATConv, fnn.GCNConv)))):
+                # the last attention layer aggregate-first: its dense part on the loss rows only (ops.FusedGATLastLayerRows)
+                x = self.embed(x, edge_index, first=first, link=link, last=L - 1)
+                mask = self._inject_masks[L - 1] if self._inject_masks is not None else None
+                g = fnn.csr_for(edge_index, x.shape[0], "gat")
+                seed = ops.next_seed(cfg) if (self.training and self.dropout_p > 0 and mask is None) else 0
+                return ops.FusedGATLastLayerRows.apply(x, last.lin.weight, last.att_src.view(-1), last.att_dst.view(-1), last.bias,
+                                                       self.lt1.weight, self.lt1.bias, g, last.negative_slope, float(self.dropout_p),
+                                                       bool(self.training), seed, mask, loss_rows, cfg, bool(compact_logits))
             return self.head(self.embed(x, edge_index, first=first, link=link))
         x = x.float()
         for i in range(first, L - 1):

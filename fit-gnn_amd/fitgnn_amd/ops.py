@@ -559,6 +559,9 @@ def spmm_graph(g, X, transposed=False, **kw):
     Xc = _f32c(X)
     val = kw.pop("val", None)   # per-call CSR values in the side's entry order (GATConv: the attention weights) instead of side.val
     if val is not None:
+        if (kw.get("xrow") is not None and kw.get("zero_from", -1) >= 0 and kw.get("cfg", DEFAULT).compact_rows_kernel and Xc.shape[1] % 4 == 0
+                and epi == 0 and kw.get("bias") is None and kw.get("out") is None):
+            return _spmm_rows_compact(g, side, Xc, kw["xrow"], kw["zero_from"], kw.get("cfg", DEFAULT), kw.get("profile_kind"), val=val)
         split = (side.blocks is not None and Xc.shape[1] % 4 == 0 and Xc.data_ptr() % 16 == 0 and kw.get("cfg", DEFAULT).split_large_blocks)
         if not split:
             return spmm_raw(side.rowptr, side.col, val, side.tiles, Xc, g.n, epilogue=epi, window_rows=g.window_rows, lcol=side.lcol,
@@ -645,11 +648,12 @@ def _spmm_stream(g, side, Xc, xrow, cfg, kind, bias=None, epilogue=0, p=0.0, see
     return Y if dz is None else (Y, db)
 
 
-def _spmm_rows_compact(g, side, Xc, xrow, zero_from, cfg, kind, dz=None):
+def _spmm_rows_compact(g, side, Xc, xrow, zero_from, cfg, kind, dz=None, val=None):
     """A @ X for a compact operand through the row-streaming kernel.  dz = (prev, epilogue, p, seed, mask, want_db): with the
-    previous layer's derivative in the store -> (dZ, db)."""
+    previous layer's derivative in the store -> (dZ, db).  val: per-call CSR values (side's entry order) instead of side.val."""
     L = _lib.lib()
-    _lib.require_cuda(Xc, xrow)
+    _lib.require_cuda(Xc, xrow, val)
+    val = side.val if val is None else val
     H, dev = Xc.shape[1], Xc.device
     xcol = _entry_rows(side, xrow)
     Y = torch.empty((g.n, H), dtype=torch.float32, device=dev)
@@ -660,14 +664,14 @@ def _spmm_rows_compact(g, side, Xc, xrow, zero_from, cfg, kind, dz=None):
         ev[0].record()
     db = None
     if dz is None:
-        _lib.check(L.fitgnn_spmm_rows_compact_f32(_lib.dptr(side.rowptr), _lib.dptr(xcol), _lib.dptr(side.val), int(side.col.numel()), _lib.dptr(Xc),
+        _lib.check(L.fitgnn_spmm_rows_compact_f32(_lib.dptr(side.rowptr), _lib.dptr(xcol), _lib.dptr(val), int(side.col.numel()), _lib.dptr(Xc),
                                                   Xc.stride(0), int(zero_from), _lib.dptr(Y), Y.stride(0), g.n, H, st), "fitgnn_spmm_rows_compact_f32")
     else:
         prev, epilogue, p, seed, mask, want_db = dz
         seed_v, epi_v = _seed_arg(seed, epilogue & ~_lib.SPMM_GATHER)
         n_part = int(L.fitgnn_spmm_rows_compact_parts(g.n))
         part = torch.empty((n_part, H), dtype=torch.float32, device=dev) if want_db else None
-        _lib.check(L.fitgnn_spmm_rows_compact_dz_f32(_lib.dptr(side.rowptr), _lib.dptr(xcol), _lib.dptr(side.val), int(side.col.numel()),
+        _lib.check(L.fitgnn_spmm_rows_compact_dz_f32(_lib.dptr(side.rowptr), _lib.dptr(xcol), _lib.dptr(val), int(side.col.numel()),
                                                      _lib.dptr(Xc), Xc.stride(0), int(zero_from), _lib.dptr(Y), Y.stride(0), g.n, H, _lib.dptr(prev),
                                                      epi_v, float(p), seed_v, _lib.dptr(mask), _lib.dptr(part), st),
                    "fitgnn_spmm_rows_compact_dz_f32")
@@ -1548,6 +1552,111 @@ class GATAggregate(torch.autograd.Function):
         else:
             db = dOut.sum(0) if ctx.has_bias and ctx.needs_input_grad[3] else None
         return dh, datt_src, datt_dst, db, None, None, None, None, None, None, None, None, None
+
+
+class FusedGATLastLayerRows(torch.autograd.Function):
+    """The last GATConv layer + ELU + dropout + head when only `rows` of the result reach the loss (run.py:193-204 keeps out[mask]),
+    evaluated aggregate-first like FusedGCNLastLayerRows: the attention scores need no transformed features,
+        a_src = h . att_src = x . (W^T att_src),   a_dst likewise                (two dots per row on x, fitgnn_gat_scores_f32)
+        out_i = sum_j alpha_ij (x_j W^T) + b = (sum_j alpha_ij x_j) W^T + b      (GATConv, heads = 1: network.py:13-17)
+    so the aggregation runs on x over every row and edge, and the dense part -- x W^T, bias, ELU, dropout, the head and, in the
+    backward, both weight-side products -- on the loss rows alone (the generic path runs three [R x K x H] products; with --extra_node
+    unions 2 % of the rows reach the loss).  The backward's edge passes (SDDMM, softmax / LeakyReLU backward) touch the loss rows'
+    entries only (fitgnn_sddmm_csr_rows_f32, fitgnn_gat_softmax_bwd_rows_f32) and the adjoint aggregation reads the compact gradient
+    through the row-streaming kernel.  g: CSRGraph(mode='gat')."""
+
+    @staticmethod
+    def forward(ctx, X, W, att_src, att_dst, b, Wl, bl, g, slope, p, training, seed, mask, rows, cfg, compact_out=False):
+        L = _lib.lib()
+        X = _f32c(X)
+        R, K = X.shape
+        dev, st = X.device, _lib.stream_ptr(X.device)
+        rows = rows if rows.dtype == torch.int64 else rows.long()
+        att2 = torch.stack([_f32c(att_src.reshape(-1)), _f32c(att_dst.reshape(-1))], dim=0)     # [2, H]
+        u = torch.mm(att2, W).contiguous()                                                        # [2, K]: W^T att
+        a_src = torch.empty(R, dtype=torch.float32, device=dev)
+        a_dst = torch.empty(R, dtype=torch.float32, device=dev)
+        with _timed(cfg, "gat_scores"):
+            _lib.check(L.fitgnn_gat_scores_f32(_lib.dptr(X), X.stride(0), R, K, _lib.dptr(u[0]), _lib.dptr(u[1]), _lib.dptr(a_src), _lib.dptr(a_dst),
+                                               st), "gat_scores")
+        alpha = torch.empty(g.nnz, dtype=torch.float32, device=dev)
+        with _timed(cfg, "gat_edge_softmax"):
+            _lib.check(L.fitgnn_gat_edge_softmax_f32(_lib.dptr(g.f.rowptr), _lib.dptr(g.f.col), _lib.dptr(a_src), _lib.dptr(a_dst), float(slope), R,
+                                                     _lib.dptr(alpha), st), "gat_edge_softmax")
+        AX = spmm_graph(g, X, val=alpha, cfg=cfg, profile_kind="gat_aggregate")                   # [R, K]: every row, every edge
+        AXc = AX.index_select(0, rows)
+        del AX
+        outc = mm_xwt(AXc, W, cfg)
+        if not outc.is_contiguous():
+            outc = outc.contiguous()
+        epi = EPI_ELU | (EPI_BIAS if b is not None else 0)
+        drop = bool(training) and p > 0.0
+        if drop:
+            epi |= EPI_DROPOUT
+        epilogue_fwd_rows_(outc, rows, b, epi, p=p if drop else 0.0, seed=seed, mask=mask if drop else None)
+        if _exact(cfg, outc, Wl) and Wl.shape[0] >= 16:
+            y = gemm_exact(outc, Wl, "nt", cfg)
+            if bl is not None:
+                y = y + bl
+            if not compact_out:
+                y = torch.zeros((R, y.shape[1]), dtype=torch.float32, device=dev).index_copy_(0, rows, y)
+        elif compact_out:
+            y = head_rows(outc, _arange_rows(g, rows.numel(), dev), Wl, bl, n_total=rows.numel())
+        else:
+            y = head_rows(outc, rows, Wl, bl, n_total=R)
+        ctx.save_for_backward(X, W, att2, Wl, AXc, outc, rows, mask if drop else None, alpha, a_src, a_dst, u)
+        ctx.g, ctx.slope, ctx.p, ctx.drop, ctx.seed, ctx.has_bias, ctx.has_bl, ctx.cfg, ctx.compact_out = (
+            g, slope, p, drop, seed, b is not None, bl is not None, cfg, bool(compact_out))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        X, W, att2, Wl, AXc, outc, rows, mask, alpha, a_src, a_dst, u = ctx.saved_tensors
+        g, cfg, L = ctx.g, ctx.cfg, _lib.lib()
+        dev, st = X.device, _lib.stream_ptr(X.device)
+        R, K = X.shape
+        H, C = outc.shape[1], Wl.shape[0]
+        n = int(rows.numel())
+        dy_c = _f32c(dy) if ctx.compact_out else _f32c(dy).index_select(0, rows)
+        epi = EPI_ELU | (EPI_DROPOUT if ctx.drop else 0)
+        inside = ctx.needs_input_grad[5] and bool(L.fitgnn_epilogue_bwd_head_supported(H, C, 1))
+        dZc, db, dWl = epilogue_bwd_head_rows_raw(dy_c, Wl, outc, rows, epi, p=ctx.p if ctx.drop else 0.0, seed=ctx.seed, mask=mask,
+                                                  want_db=ctx.has_bias, want_dWl=inside, inputs_compact=True, zero_rows=0)
+        if ctx.needs_input_grad[5] and not inside:
+            dWl = head_weight_grad_rows(dy_c, outc, cfg)
+        dbl = colsum_narrow(dy_c) if ctx.has_bl and ctx.needs_input_grad[6] else None
+        dW = mm_at_b(dZc, AXc, cfg)                                                               # [H, K]
+        dAX = torch.empty((n + ZERO_ROWS, K), dtype=torch.float32, device=dev)
+        dAX[n:].zero_()
+        dAX[:n] = mm_by_transposed(dZc, W, cfg)                                                   # dZ W on the loss rows
+        # the aggregation's backward, on the loss rows' entries: d(alpha), then the softmax / LeakyReLU backward
+        dalpha = torch.zeros_like(alpha)
+        with _timed(cfg, "gat_sddmm"):
+            _lib.check(L.fitgnn_sddmm_csr_rows_f32(_lib.dptr(g.f.rowptr), _lib.dptr(g.f.col), _lib.dptr(dAX), K, _lib.dptr(X), X.stride(0),
+                                                   _lib.dptr(rows), n, K, _lib.dptr(dalpha), st), "sddmm_rows")
+        ds = torch.zeros_like(alpha)
+        da_dst = torch.zeros(R, dtype=torch.float32, device=dev)
+        with _timed(cfg, "gat_softmax_bwd"):
+            _lib.check(L.fitgnn_gat_softmax_bwd_rows_f32(_lib.dptr(g.f.rowptr), _lib.dptr(g.f.col), _lib.dptr(a_src), _lib.dptr(a_dst), _lib.dptr(alpha),
+                                                         _lib.dptr(dalpha), float(ctx.slope), _lib.dptr(rows), n, _lib.dptr(ds), _lib.dptr(da_dst),
+                                                         st), "gat_softmax_bwd_rows")
+        with _timed(cfg, "gat_transpose_edges"):
+            ds_t = ds[g._perm_t].contiguous()
+            da_src = torch.empty(R, dtype=torch.float32, device=dev)
+            _lib.check(L.fitgnn_csr_row_sum_f32(_lib.dptr(g.t.rowptr), _lib.dptr(ds_t), R, _lib.dptr(da_src), st), "csr_row_sum")
+            alpha_t = alpha[g._perm_t].contiguous()
+        da = torch.stack([da_src, da_dst], dim=1)                                                 # [R, 2]
+        du = mm_at_b(da, X, cfg)                                                                  # [2, K] = da^T x
+        dX = None
+        if ctx.needs_input_grad[0]:
+            dX = spmm_graph(g, dAX, transposed=True, val=alpha_t, cfg=cfg, xrow=_compact_positions(g, rows), zero_from=n,
+                            profile_kind="gat_aggregate_t")
+            with _timed(cfg, "gat_rank1"):
+                dX.addmm_(da, u)                                                                  # + da_src (x) W^T att_src + da_dst (x) W^T att_dst
+        # u = att2 W: the scores' parameter gradients
+        dW = dW + torch.mm(att2.t(), du)
+        datt2 = torch.mm(du, W.t())                                                               # [2, H]
+        return (dX, dW, datt2[0], datt2[1], (db if ctx.has_bias else None), dWl, dbl, None, None, None, None, None, None, None, None, None)
 
 
 class APPNPPropagate(torch.autograd.Function):

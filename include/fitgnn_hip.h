@@ -74,6 +74,20 @@ int fitgnn_plan_tiles_host(const int32_t *rowptr, const int32_t *col, int32_t n_
                            const int64_t *block_ptr, int32_t n_blocks, int32_t max_rows, int32_t max_window,
                            fitgnn_tile_t *tiles, int32_t *n_tiles, int32_t *win_cols, int32_t *n_win, int32_t *lcol);
 
+/* HOST functions (host pointers, no GPU work) for batches whose windows are the tiles' own rows (every column of a block-diagonal
+ * batch is then a window hit): ptr[0..n_blocks] = row offsets of the diagonal blocks (the subgraphs of utils.py:248, or the stars of
+ * a star-by-star layout).
+ *   fitgnn_make_tiles_host   consecutive blocks packed into tiles of <= max_rows rows, a larger block cut into max_rows-row pieces;
+ *                            tiles4: (row_begin, row_end, win_begin, win_rows) records, capacity >= n_blocks + rows / max_rows.
+ *   fitgnn_split_blocks_host blocks of cap < rows <= limit become fitgnn_block_t records for fitgnn_spmm_csr_blocks_f32 (blocks8, in
+ *                            input order, with their long rows -- more than long_row non-zeros -- listed ascending in long_rows);
+ *                            the maximal runs of the other blocks are packed into tiles as above (never across a block record).
+ * Both return FITGNN_E_WORKSPACE when an output capacity is too small. */
+int fitgnn_make_tiles_host(const int64_t *ptr, int64_t n_blocks, int32_t max_rows, int32_t *tiles4, int64_t capacity, int64_t *n_tiles);
+int fitgnn_split_blocks_host(const int64_t *ptr, int64_t n_blocks, const int32_t *rowptr, int32_t cap, int64_t limit, int32_t long_row,
+                             int32_t *tiles4, int64_t tiles_capacity, int64_t *n_tiles, int32_t *blocks8, int64_t *n_large,
+                             int32_t *long_rows, int64_t long_capacity, int64_t *n_long);
+
 /* A run of consecutive rows LARGER than the SpMM window -- a diagonal block (one subgraph of a block-diagonal batch) or a
  * mostly self-contained segment of one (a star: a centre row and the rows that reference it) -- handled whole by one
  * workgroup per column slab (fitgnn_spmm_csr_blocks_f32): every operand row inside the run is read once; columns outside it
@@ -431,6 +445,14 @@ int fitgnn_sddmm_csr_f32(const int32_t *rowptr, const int32_t *col, const float 
 int fitgnn_gat_softmax_bwd_f32(const int32_t *rowptr, const int32_t *col, const float *a_src, const float *a_dst,
                                const float *alpha, const float *dalpha, float negative_slope, int32_t n, float *ds,
                                float *da_dst, void *stream);
+/* The same two passes over the rows sel[0 .. n_sel) only (int64 row ids), for a gradient that is zero outside them (the last GAT layer
+ * of a step whose loss keeps out[mask], run.py:193-204): dOut_c is COMPACT (row i belongs to row sel[i]); only the entries of those rows
+ * are written to dalpha / ds and only their da_dst -- the caller zeroes the three arrays. */
+int fitgnn_sddmm_csr_rows_f32(const int32_t *rowptr, const int32_t *col, const float *dOut_c, int64_t ldo, const float *h, int64_t ldh,
+                              const int64_t *sel, int32_t n_sel, int32_t C, float *dalpha, void *stream);
+int fitgnn_gat_softmax_bwd_rows_f32(const int32_t *rowptr, const int32_t *col, const float *a_src, const float *a_dst,
+                                    const float *alpha, const float *dalpha, float negative_slope, const int64_t *sel, int32_t n_sel,
+                                    float *ds, float *da_dst, void *stream);
 int fitgnn_csr_row_sum_f32(const int32_t *rowptr, const float *v, int32_t n, float *y, void *stream);
 
 /* Propagation on narrow signals (APPNP, Baselines/SGGC/APPNP/networks.py:11,23: z <- (1-alpha) A_hat z + alpha z0 on

@@ -668,6 +668,51 @@ def test_loss_rows_hint_changes_nothing_the_loss_sees(mods):
         assert rel(a, b) < 1e-6
 
 
+@pytest.mark.parametrize("dedup", [False, True])
+@pytest.mark.parametrize("classes", [5, 47])
+def test_gat_last_layer_on_the_loss_rows_changes_nothing_the_loss_sees(mods, dedup, classes):
+    """Classify_node with GATConv layers: embed_and_head(loss_rows=...) evaluates the last attention layer aggregate-first with its
+    dense part on the loss rows (ops.FusedGATLastLayerRows: scores from x . (W^T att), sum_j alpha_ij x_j, then W / bias / ELU /
+    dropout / head on the kept rows; backward edge passes on those rows' entries only) -- the same logits on those rows, loss and
+    gradients of every parameter as the plain full evaluation, dropout off and on (injected masks), compact logits included."""
+    from fitgnn_amd import ops
+
+    network, fnn, gorc = mods
+    batch, _ = _subgraph_batches(seed=12)
+    args = argparse.Namespace(num_layers1=2, layer_name="GATConv", num_features=24, hidden=64, num_classes=classes)
+    torch.manual_seed(6)
+    m = network.Classify_node(args).cuda().train()
+    idx = batch.train_idx
+    y = (batch.y % classes).index_select(0, idx)
+    torch.manual_seed(7)
+    masks = [(torch.rand(batch.n_rows, 64, device="cuda") > 0.5).to(torch.uint8) for _ in range(2)]
+
+    def run(cfg, hint, compact=False):
+        m.set_op_config(cfg)
+        m.zero_grad()
+        if dedup:
+            z = m.embed_and_head(batch.x_table, batch.edge_index, batch.row_index, loss_rows=hint, compact_logits=compact)
+        else:
+            z = m.embed_and_head(batch.x, batch.edge_index, loss_rows=hint, compact_logits=compact)
+        zl = z if (compact and z.shape[0] == idx.numel()) else z.index_select(0, idx)
+        loss = torch.nn.functional.nll_loss(torch.log_softmax(zl, 1), y, reduction="sum")
+        loss.backward()
+        return zl.detach(), float(loss), {k: p.grad.clone() for k, p in m.named_parameters()}
+
+    for p_drop in (0.0, 0.5):
+        m.dropout_p = p_drop
+        m._inject_masks = masks if p_drop > 0 else None
+        z0, l0, g0 = run(ops.OpConfig(last_layer_on_loss_rows=False), None)
+        for compact in (False, True):
+            z1, l1, g1 = run(ops.OpConfig(), idx, compact)
+            assert rel(z1, z0) < 1e-4, (p_drop, compact)
+            assert l1 == pytest.approx(l0, rel=1e-5), (p_drop, compact)
+            for k in g0:
+                assert rel(g1[k], g0[k]) < 5e-4, (k, p_drop, compact)
+    m._inject_masks = None
+    m.set_op_config(ops.DEFAULT)
+
+
 def test_forward_epilogue_on_compact_rows_is_the_spmm_epilogue(mods):
     """fitgnn_epilogue_fwd_rows_f32 on gathered rows == the SpMM kernel's store epilogue on the same rows, bit for bit, with the
     seed-hashed dropout pattern of the ORIGINAL rows."""

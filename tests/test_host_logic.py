@@ -565,3 +565,27 @@ def test_two_hop_index_covers_every_entry_the_kernel_cannot_serve_from_lds():
             else:
                 assert int(ix["row_p"][r]) == ops.NO_ROW and float(ix["row_w"][r]) == 0.0
     assert np.array_equal(np.sort(ix["tile_zt"].numpy()), np.sort(zrow[block_of < 0]))
+
+
+def test_host_tile_packing_and_block_split_equal_their_python_reference():
+    """fitgnn_make_tiles_host / fitgnn_split_blocks_host (the library's host code: 165 000 stars -> 515 000 tiles in milliseconds)
+    against the Python loops they replace, on random block structures: the same tiles, block records and long-row lists."""
+    from fitgnn_amd import csr
+
+    rng = np.random.default_rng(11)
+    for trial in range(40):
+        nb = int(rng.integers(0, 60))
+        sizes = rng.choice([1, 2, 3, 5, 9, 15, 16, 17, 30, 64, 200, 1000], size=nb)
+        ptr = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+        cap = int(rng.choice([4, 16, 64]))
+        a, b = csr.make_tiles(ptr, cap), csr.make_tiles_py(ptr, cap)
+        assert a.dtype == b.dtype and np.array_equal(a, b), (trial, "tiles")
+        n = int(ptr[-1])
+        deg = rng.integers(1, 40, size=n)
+        rowptr = np.concatenate([[0], np.cumsum(deg)]).astype(np.int32)
+        limit = int(rng.choice([4 * cap, 100, 5000]))
+        s1, b1, l1 = csr.split_blocks(ptr, torch.from_numpy(rowptr), cap, limit)
+        s2, b2, l2 = csr.split_blocks_py(ptr, torch.from_numpy(rowptr), cap, limit)
+        assert np.array_equal(s1, s2), (trial, "small tiles")
+        assert np.array_equal(b1, b2), (trial, "blocks")
+        assert np.array_equal(l1, l2), (trial, "long rows")

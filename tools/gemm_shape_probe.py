@@ -18,7 +18,7 @@ def bench(fn, reps=10):
     return e0.elapsed_time(e1) / reps * 1e3
 
 
-shapes = [("nt", 4861, 512, 512), ("nn", 4861, 512, 512), ("tn", 512, 512, 4861), ("nt", 19717, 512, 512), ("nn", 19717, 512, 512),
+shapes = [("nt", 34493, 512, 8448), ("tn", 512, 8448, 34493), ("nt", 4861, 512, 512), ("nn", 4861, 512, 512), ("tn", 512, 512, 4861), ("nt", 19717, 512, 512), ("nn", 19717, 512, 512),
           ("tn", 512, 512, 19717), ("nt", 20625, 512, 512), ("nt", 34493, 512, 512), ("nt", 90549, 512, 512), ("nt", 165000, 512, 128),
           ("tn", 512, 128, 165000), ("tn", 512, 512, 165000), ("tn", 512, 512, 20625), ("nt", 165000, 512, 512), ("nt", 19717, 512, 512 - 12), ("nt", 82500, 48, 512)]
 names = {"0": "256x256", "3": "128x128", "4": "64x128"}
@@ -34,6 +34,11 @@ for form, I, J, K in shapes:
         os.environ["FITGNN_GEMM_SHAPE"] = sh
         us = bench(lambda: ops.gemm_exact(a, b, form))
         line.append(f"{names[sh]} {us:8.1f} us {flops / us / 1e6:6.1f} TF")
+        if K >= 4096 and form != "tn":   # a long k: the same shape without the k split
+            os.environ["FITGNN_GEMM_CHUNKS"] = "1"
+            us = bench(lambda: ops.gemm_exact(a, b, form))
+            line.append(f"{names[sh]} unsplit {us:8.1f} us {flops / us / 1e6:6.1f} TF")
+            os.environ.pop("FITGNN_GEMM_CHUNKS", None)
     os.environ.pop("FITGNN_GEMM_SHAPE", None)
     lib = (lambda: a @ b.t()) if form == "nt" else (lambda: a @ b) if form == "nn" else (lambda: a.t() @ b)
     us = bench(lib)
