@@ -306,7 +306,14 @@ def main():
         info.update(union_rows=sum(info["shard_union_rows"]), nnz_prime=sum(info["shard_nnz_prime"]))
     else:
         info.update(union_rows=int(mine_sizes[0]), nnz_prime=int(mine_sizes[1]))
-    info["t_assemble_s"] = round(t5 - t4, 2)
+    info["t_assemble_s"] = round(t5 - t4, 2)   # the first call in the process: includes the one-time loading of the sort / scan kernels it uses
+    if world == 1 and emu is None and args.layer == "GCNConv":   # the same assembly once more: what it takes once those are resident
+        t_w = time.time()
+        sub_w, _ = workloads.assemble(args.workload, ei_d, assign_d, n_clusters, clusters=mine)
+        torch.cuda.synchronize()
+        info["t_assemble_warm_s"] = round(time.time() - t_w, 3)
+        del sub_w
+        t5 = time.time()
     del ei_d
     batch = workloads.batch_from_subgraphs(args.workload, sub, device)
     torch.cuda.synchronize()

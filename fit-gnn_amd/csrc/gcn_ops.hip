@@ -485,6 +485,34 @@ __global__ __launch_bounds__(256) void head_rows_kernel(const float *__restrict_
 
 }  // namespace
 
+// loss[0] = scale * sum_i |out[i] - tgt[i]|, grad[i] = scale * sign(out[i] - tgt[i])  (L1Loss, run.py:518,716 on the graph-level /
+// node-regression outputs: a few hundred values): ONE workgroup, a fixed-order tree -- instead of sub, abs, mean and their backward
+__global__ __launch_bounds__(256) void l1_loss_kernel(const float *__restrict__ out, const float *__restrict__ tgt, int32_t n, float scale,
+                                                      float *__restrict__ loss, float *__restrict__ grad) {
+    __shared__ float part[256];
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const float d = out[i] - tgt[i];
+        acc += fabsf(d);
+        grad[i] = d > 0.f ? scale : (d < 0.f ? -scale : 0.f);
+    }
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    for (int w = 128; w >= 1; w >>= 1) {
+        if ((int)threadIdx.x < w) part[threadIdx.x] += part[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) loss[0] = scale * part[0];
+}
+
+extern "C" int fitgnn_l1_loss_f32(const float *out, const float *tgt, int32_t n, float scale, float *loss, float *grad, void *stream) {
+    if (n < 0) return FITGNN_E_BADARG;
+    if (!loss) return FITGNN_E_BADARG;
+    if (n > 0 && (!out || !tgt || !grad)) return FITGNN_E_BADARG;
+    hipLaunchKernelGGL(l1_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, out, tgt, n, scale, loss, grad);
+    return (int)hipGetLastError();
+}
+
 extern "C" size_t fitgnn_softmax_nll_workspace_bytes(int32_t n) { return (size_t)((n > 0 ? n : 0) + 255) / 256 * sizeof(float) + 16; }
 
 extern "C" int fitgnn_softmax_nll_f32(const float *z, int64_t ldz, int32_t n_rows, int32_t C, const int64_t *idx,

@@ -77,6 +77,7 @@ SIGNATURES = {
     "fitgnn_sddmm_csr_rows_f32": (ctypes.c_int, [ptr, ptr, ptr, c_i64, ptr, c_i64, ptr, c_i32, c_i32, ptr, ptr]),
     "fitgnn_gat_softmax_bwd_rows_f32": (ctypes.c_int, [ptr, ptr, ptr, ptr, ptr, ptr, c_f32, ptr, c_i32, ptr, ptr, ptr]),
     "fitgnn_gat_softmax_bwd_f32": (ctypes.c_int, [ptr, ptr, ptr, ptr, ptr, ptr, c_f32, c_i32, ptr, ptr, ptr]),
+    "fitgnn_l1_loss_f32": (ctypes.c_int, [ptr, ptr, c_i32, c_f32, ptr, ptr, ptr]),
     "fitgnn_softmax_nll_workspace_bytes": (c_size, [c_i32]),
     "fitgnn_softmax_nll_f32": (ctypes.c_int, [ptr, c_i64, c_i32, c_i32, ptr, ptr, c_i32, c_f32, ptr, ptr, ptr, c_size, ptr]),
     "fitgnn_adam_step_f32": (ctypes.c_int, [ptr, ptr, ptr, ptr, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, ptr, ptr]),
@@ -101,6 +102,8 @@ SIGNATURES = {
     "fitgnn_spmm_narrow_f32": (ctypes.c_int, [ptr, ptr, ptr, ptr, ptr, c_i32, c_i32, c_f32, ptr, c_f32, ptr, c_f32, ptr]),
     "fitgnn_spmm_narrow_padded_f32": (ctypes.c_int, [ptr, ptr, ptr, ptr, ptr, c_i32, c_i32, c_f32, ptr, c_f32, ptr, c_f32, ptr]),
     "fitgnn_csr_row_sum_f32": (ctypes.c_int, [ptr, ptr, c_i32, ptr, ptr]),
+    "fitgnn_induced_edges_count": (ctypes.c_int, [ptr, ptr, ptr, ptr, ptr, ptr, c_i64, ptr, ptr]),
+    "fitgnn_induced_edges_fill": (ctypes.c_int, [ptr, ptr, ptr, ptr, ptr, ptr, ptr, c_i64, ptr, ptr, ptr, ptr]),
     "fitgnn_closed_neighbourhoods": (ctypes.c_int, [ptr, ptr, c_i32, ptr, ptr, ptr]),
     "fitgnn_variation_costs_f64": (ctypes.c_int, [ptr, ptr, ptr, ptr, ptr, c_i32, c_i64, ptr, ptr, ptr, c_i32, ptr, ptr]),
     "fitgnn_variation_costs_batch_f64": (ctypes.c_int, [ptr, ptr, ptr, ptr, ptr, c_i32, c_i64, ptr, ptr, ptr, ptr, c_i32, ptr, ptr]),

@@ -43,17 +43,19 @@ def arrange_tiles_for_xcds(tiles8, n_xcd=8, work=None):
     return out
 
 
-def tiles_to_device(tiles, rowptr):
+def tiles_to_device(tiles, rowptr, rowptr_host=None):
     """Host tile table (TILE_DTYPE) -> device int32 [T, 8] fitgnn_tile_t array with nnz_begin/nnz_end filled
-    from the (device) row pointers."""
+    from the row pointers (rowptr_host: their host copy when the caller already holds one -- the table is then finished on the
+    host and copied once)."""
     dev = rowptr.device
-    t4 = torch.from_numpy(np.ascontiguousarray(tiles).view(np.int32).reshape(-1, 4)).to(dev)
-    out = torch.zeros((t4.shape[0], TILE_INTS), dtype=torch.int32, device=dev)
+    t4 = np.ascontiguousarray(tiles).view(np.int32).reshape(-1, 4)
+    rp = rowptr_host if rowptr_host is not None else rowptr.detach().cpu().numpy()
+    out = np.zeros((t4.shape[0], TILE_INTS), dtype=np.int32)
     out[:, :4] = t4
     if t4.shape[0]:
-        out[:, 4] = rowptr[t4[:, 0].long()]
-        out[:, 5] = rowptr[t4[:, 1].long()]
-    return torch.from_numpy(arrange_tiles_for_xcds(out.cpu().numpy())).to(dev)
+        out[:, 4] = rp[t4[:, 0]]
+        out[:, 5] = rp[t4[:, 1]]
+    return torch.from_numpy(arrange_tiles_for_xcds(out)).to(dev)
 
 
 def block_boundaries(rowptr, col, n_rows):
@@ -165,7 +167,7 @@ def split_blocks(ptr, rowptr, cap, limit=None):
     Returns (tiles TILE_DTYPE array, blocks int32 [NB, 8], long_rows int32 [NL]) as numpy.
     Runs in the library's host code (fitgnn_split_blocks_host); split_blocks_py is the same in NumPy / Python."""
     ptr = np.ascontiguousarray(ptr, dtype=np.int64)
-    rp = np.ascontiguousarray(rowptr.detach().cpu().numpy() if torch.is_tensor(rowptr) else rowptr, dtype=np.int32)
+    rp = np.ascontiguousarray(rowptr.detach().cpu().numpy() if torch.is_tensor(rowptr) else rowptr, dtype=np.int32)   # (no copy for a host int32 array)
     nb = len(ptr) - 1
     n = int(ptr[-1])
     if limit is None:
@@ -378,10 +380,11 @@ class CSRGraph:
             tiles = make_tiles(ptr_np, cap)
             has_large = bool(len(ptr_np) > 1 and np.max(np.diff(ptr_np)) > cap)
             for side in (f, t):  # same diagonal blocks, each side its own CSR offsets
-                side.tiles = tiles_to_device(tiles, side.rowptr)
+                rp_host = np.ascontiguousarray(side.rowptr.detach().cpu().numpy(), dtype=np.int32)   # one copy per side for all tables below
+                side.tiles = tiles_to_device(tiles, side.rowptr, rp_host)
                 side.n_tiles = int(tiles.shape[0])
                 if has_large and self.split_large and not self.gather and self.nnz > 0:
-                    small, blocks, long_rows = split_blocks(ptr_np, side.rowptr, cap, self.block_limit)
+                    small, blocks, long_rows = split_blocks(ptr_np, rp_host, cap, self.block_limit)
                     # the whole-subgraph kernel saves re-reads from HBM: it pays when a good part of the batch sits in such runs
                     # and the operand is beyond the Infinity Cache (a launch on the 90 k-row PubMed union lasts 80 us: a second
                     # launch and a few long-running workgroups cost more than the re-reads, which stay on-die there)
@@ -389,7 +392,7 @@ class CSRGraph:
                     if self.block_limit is None and (in_blocks * 5 < self.n * 3 or self.n < self.split_min_rows):
                         continue   # measured: S-products (stars of ~50 rows) 8.27 -> 7.50 ms with the fused epilogue; S-physics
                                    # (stars of ~14 rows, 40 % of the rows in such runs) 399 -> 441 us: tiles stay the default there
-                    side.small_tiles = tiles_to_device(small, side.rowptr) if len(small) else torch.zeros((0, TILE_INTS), dtype=torch.int32, device=dev)
+                    side.small_tiles = tiles_to_device(small, side.rowptr, rp_host) if len(small) else torch.zeros((0, TILE_INTS), dtype=torch.int32, device=dev)
                     side.blocks = torch.from_numpy(blocks).to(dev)
                     side.long_rows = torch.from_numpy(long_rows if len(long_rows) else np.zeros(1, dtype=np.int32)).to(dev)
                     if self.seg is None:   # the segment-streaming kernel's view of the same runs (both sides share it)

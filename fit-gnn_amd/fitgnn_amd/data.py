@@ -197,9 +197,31 @@ def assemble_subgraphs_torch(edge_index, num_nodes, assign, n_clusters, extra_no
     s_dst = dst[order]
     adj_ptr = torch.zeros(N + 1, dtype=torch.int64, device=dev)
     adj_ptr[1:] = torch.cumsum(torch.bincount(src, minlength=N), 0)
+    R = int(key.numel())
+    if dev.type == "cuda":
+        # the induced edges by the library's kernels (csrc/assemble.hip): every member row walks its node's adjacency list once and
+        # looks the neighbours up inside its own cluster's member run -- no (row, neighbour) temporaries, a 7-step search in L1
+        from . import _lib
+        L, st = _lib.lib(), _lib.stream_ptr(dev)
+        key_node = (key % N).contiguous()
+        s_dst, adj_ptr = s_dst.contiguous(), adj_ptr.contiguous()
+        mem_n, mem_c, ptr_c = mem_n.contiguous(), mem_c.contiguous(), ptr.contiguous()
+        cnt = torch.empty(R, dtype=torch.int32, device=dev)
+        _lib.check(L.fitgnn_induced_edges_count(_lib.dptr(adj_ptr), _lib.dptr(s_dst), _lib.dptr(mem_n), _lib.dptr(mem_c), _lib.dptr(ptr_c),
+                                                _lib.dptr(key_node), R, _lib.dptr(cnt), st), "fitgnn_induced_edges_count")
+        off = torch.zeros(R + 1, dtype=torch.int64, device=dev)
+        off[1:] = torch.cumsum(cnt, 0)
+        n_e = int(off[-1])
+        e = torch.empty((2, n_e), dtype=torch.int64, device=dev)
+        _lib.check(L.fitgnn_induced_edges_fill(_lib.dptr(adj_ptr), _lib.dptr(s_dst), _lib.dptr(mem_n), _lib.dptr(mem_c), _lib.dptr(ptr_c),
+                                               _lib.dptr(key_node), _lib.dptr(None if inv is None else inv.contiguous()), R, _lib.dptr(off),
+                                               _lib.dptr(e[0]), _lib.dptr(e[1]), st), "fitgnn_induced_edges_fill")
+        out = dict(ptr=ptr, node_id=mem_n, core=core, edge_index=e)
+        if seg_start is not None:
+            out["seg_start"] = seg_start
+        return out
     deg = adj_ptr[mem_n + 1] - adj_ptr[mem_n]
     es, ed = [], []
-    R = int(key.numel())
     for r0 in range(0, R, chunk_rows):
         r1 = min(R, r0 + chunk_rows)
         d = deg[r0:r1]

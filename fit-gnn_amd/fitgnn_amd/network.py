@@ -136,6 +136,7 @@ class _Base(nn.Module):
             if (L > 0 and x.is_cuda and isinstance(last, fnn.GATConv) and loss_rows is not None and cfg.last_layer_on_loss_rows
                     and loss_rows.numel() > 0 and last.lin.weight.shape[0] % 4 == 0 and last.lin.weight.shape[1] % 4 == 0
                     and ops.head_rows_supported(x.new_empty((1, last.lin.weight.shape[0])), self.lt1.weight)
+                    and ops.head_fusable(self.lt1.in_features, self.lt1.out_features)
                     and (first == L - 1 or isinstance(self.conv[L - 2], (fnn.GATConv, fnn.GCNConv)))):
                 # the last attention layer aggregate-first: its dense part on the loss rows only (ops.FusedGATLastLayerRows)
                 x = self.embed(x, edge_index, first=first, link=link, last=L - 1)

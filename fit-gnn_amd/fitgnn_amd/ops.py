@@ -460,6 +460,29 @@ class SoftmaxNLL(torch.autograd.Function):
         return dz * g, None, None, None
 
 
+class L1Loss(torch.autograd.Function):
+    """scale * sum |out - tgt| (torch.nn.L1Loss of run.py:518,716 on a regression head's few hundred outputs) with its gradient
+    from the same launch (fitgnn_l1_loss_f32) instead of sub / abs / mean and their three backward kernels.  Returns a 0-dim loss."""
+
+    @staticmethod
+    def forward(ctx, out, tgt, scale):
+        _lib.require_cuda(out, tgt)
+        o, t = _f32c(out).reshape(-1), _f32c(tgt).reshape(-1)
+        assert o.numel() == t.numel()
+        loss = torch.empty(1, dtype=torch.float32, device=o.device)
+        grad = torch.empty_like(o)
+        _lib.check(_lib.lib().fitgnn_l1_loss_f32(_lib.dptr(o), _lib.dptr(t), int(o.numel()), float(scale), _lib.dptr(loss), _lib.dptr(grad),
+                                                 _lib.stream_ptr(o.device)), "fitgnn_l1_loss_f32")
+        ctx.save_for_backward(grad)
+        ctx.shape = out.shape
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return (grad * g).view(ctx.shape), None, None
+
+
 def _f32c(t):
     if t.dtype != torch.float32:
         t = t.float()

@@ -448,13 +448,33 @@ class GraphTrainer(_CapturedSteps):
                 self.batches.append(_cat_pieces(pieces, kind, types))
         if self.world > 1:
             self.capture = False   # the per-step collective is issued eagerly
+        if self.task == "graph_reg":   # static per batch: formed now, not inside a (captured) step
+            for b in self.batches:
+                if b is not None and "_tgt" not in b:
+                    b["_tgt"] = self._target(b["y"])
 
-    def _loss(self, out, y, reduction="mean"):
+    def _target(self, y):
+        """The regression target of a batch as the reference forms it: y.type(torch.long) (run.py:260,:294: truncation), property
+        column `prop` of a multi-property dataset, as a float column."""
         if self.truncate:
             y = y.long()
+        return (y[:, self.prop].view(-1, 1) if self.multi_prop else y).float().contiguous()
+
+    def _loss(self, out, y, reduction="mean", b=None):
         if self.task == "graph_reg":
-            tgt = (y[:, self.prop].view(-1, 1) if self.multi_prop else y).to(out.dtype)
-            return F.l1_loss(out, tgt, reduction=reduction)
+            # the target is static per batch: formed once (a captured step would otherwise replay its cast / gather / copy kernels)
+            if b is None:
+                tgt = self._target(y)
+            else:
+                if "_tgt" not in b:
+                    b["_tgt"] = self._target(y)
+                tgt = b["_tgt"]
+            if out.is_cuda and out.dtype == torch.float32 and tgt.shape == out.shape:
+                from .ops import L1Loss
+                return L1Loss.apply(out, tgt, (1.0 / max(out.numel(), 1)) if reduction == "mean" else 1.0)
+            return F.l1_loss(out, tgt.to(out.dtype), reduction=reduction)
+        if self.truncate:
+            y = y.long()
         # graph_cls: CrossEntropyLoss on the model's SOFTMAX output (run.py:583 on network.py:94,133: a double softmax, kept)
         return F.cross_entropy(out, y.long().flatten(), reduction=reduction)
 
@@ -468,7 +488,7 @@ class GraphTrainer(_CapturedSteps):
             buf.mul_(1.0 / self.world)
         loss = torch.zeros((), device=buf.device)
         if b is not None:
-            loss = self._loss(self._forward(b), b["y"], reduction="sum") / float(self.global_sizes[k])
+            loss = self._loss(self._forward(b), b["y"], reduction="sum", b=b) / float(self.global_sizes[k])
             loss.backward()
         torch.distributed.all_reduce(buf, group=self.pg)
         self.opt.step()
@@ -485,7 +505,7 @@ class GraphTrainer(_CapturedSteps):
     def _one(self, b):
         if not self.accumulate:
             self.flat.zero()
-        loss = self._loss(self._forward(b), b["y"])
+        loss = self._loss(self._forward(b), b["y"], b=b)
         loss.backward()
         self.opt.step()
         return loss.detach()
@@ -525,7 +545,7 @@ class GraphTrainer(_CapturedSteps):
         self.model.eval()
         total, labels = torch.zeros((), device=self.flat.buf.device), []
         for b in self.batches:
-            total += self._loss(self._forward(b), b["y"])
+            total += self._loss(self._forward(b), b["y"], b=b)
             y = b["y"].long() if self.truncate else b["y"]
             labels.append(y[:, self.prop] if self.multi_prop else y.flatten())
         if self.task == "graph_reg" and self.kind == "gs":

@@ -363,6 +363,10 @@ int fitgnn_colsum_partials_f32(const float *partial, int32_t n_chunks, int32_t H
  * network.py:35, followed by NLLLoss, run.py:341; scale = 1/n for reduction='mean', 1/global count under data
  * parallelism), and dz [n_rows x ldz] = its gradient w.r.t. the logits z (zero on rows that are not selected).
  * One pass over the selected rows instead of log_softmax + gather + nll_loss and their three backward kernels. */
+/* loss[0] = scale * sum_i |out[i] - tgt[i]| and grad[i] = scale * sign(out[i] - tgt[i]) over n contiguous values: L1Loss of the
+ * regression tasks (run.py:518,716; scale = 1/n for reduction='mean') with its gradient, one launch (a fixed-order sum). */
+int fitgnn_l1_loss_f32(const float *out, const float *tgt, int32_t n, float scale, float *loss, float *grad, void *stream);
+
 size_t fitgnn_softmax_nll_workspace_bytes(int32_t n);
 int fitgnn_softmax_nll_f32(const float *z, int64_t ldz, int32_t n_rows, int32_t C, const int64_t *idx,
                            const int64_t *labels, int32_t n, float scale, float *loss, float *dz, void *work,
@@ -549,6 +553,21 @@ size_t fitgnn_lift_adjacency_workspace_bytes(int32_t N, int64_t nnz, int32_t n);
 int fitgnn_lift_adjacency(int32_t N, const int32_t *rowptr, const int32_t *col, const double *w,
                           const int32_t *assign, const double *cval, int32_t n, int32_t *rowptr_c, int32_t *col_c,
                           double *w_c, int32_t *nnz_c, void *work, size_t work_bytes, void *stream);
+
+/* Subgraph assembly (utils.py:185-267 `subgraph`, :235-239 --extra_node): the induced edges of ALL cluster subgraphs.
+ * The caller holds the membership list (one row per (cluster, member node)): key_node int64 [R] = the member nodes in KEY order
+ * (clusters ascending, nodes ascending inside a cluster), cl_ptr int64 [n_clusters + 1] = the clusters' row ranges in that order;
+ * the LAYOUT the union is emitted in may be any permutation of it (star by star): row_node / row_cluster int64 [R] = node and
+ * cluster of layout row r, inv int64 [R] (may be NULL = identity) = layout row of key position p.  adj_ptr int64 [N + 1] / adj int64
+ * [2E]: the graph's adjacency lists (CSR by source node, neighbours ascending).
+ *   _count: cnt[r] = number of neighbours of row r's node that are members of its cluster;
+ *   _fill : behind off = exclusive scan of cnt (int64 [R + 1]): e_src / e_dst [off[R]] = the subgraphs' directed edges as layout
+ *           rows, ordered by (row, neighbour): one wavefront per row, a binary search inside the row's own cluster per neighbour. */
+int fitgnn_induced_edges_count(const int64_t *adj_ptr, const int64_t *adj, const int64_t *row_node, const int64_t *row_cluster,
+                               const int64_t *cl_ptr, const int64_t *key_node, int64_t n_rows, int32_t *cnt, void *stream);
+int fitgnn_induced_edges_fill(const int64_t *adj_ptr, const int64_t *adj, const int64_t *row_node, const int64_t *row_cluster,
+                              const int64_t *cl_ptr, const int64_t *key_node, const int64_t *inv, int64_t n_rows, const int64_t *off,
+                              int64_t *e_src, int64_t *e_dst, void *stream);
 
 /* Feature pooling Xc = C . X (utils.py:161,393,738,827): f64 accumulation over each cluster's members in
  * ascending node order, rounded once to f32 (utils.py:738 torch.FloatTensor).  X f32[N x F] (ldx), Xc

@@ -679,13 +679,14 @@ def test_gat_last_layer_on_the_loss_rows_changes_nothing_the_loss_sees(mods, ded
 
     network, fnn, gorc = mods
     batch, _ = _subgraph_batches(seed=12)
-    args = argparse.Namespace(num_layers1=2, layer_name="GATConv", num_features=24, hidden=64, num_classes=classes)
+    hidden = 64 if classes <= 16 else 256   # (the fused head backward takes a head as wide as the last 256-column slab has lanes)
+    args = argparse.Namespace(num_layers1=2, layer_name="GATConv", num_features=24, hidden=hidden, num_classes=classes)
     torch.manual_seed(6)
     m = network.Classify_node(args).cuda().train()
     idx = batch.train_idx
     y = (batch.y % classes).index_select(0, idx)
     torch.manual_seed(7)
-    masks = [(torch.rand(batch.n_rows, 64, device="cuda") > 0.5).to(torch.uint8) for _ in range(2)]
+    masks = [(torch.rand(batch.n_rows, hidden, device="cuda") > 0.5).to(torch.uint8) for _ in range(2)]
 
     def run(cfg, hint, compact=False):
         m.set_op_config(cfg)
@@ -694,6 +695,8 @@ def test_gat_last_layer_on_the_loss_rows_changes_nothing_the_loss_sees(mods, ded
             z = m.embed_and_head(batch.x_table, batch.edge_index, batch.row_index, loss_rows=hint, compact_logits=compact)
         else:
             z = m.embed_and_head(batch.x, batch.edge_index, loss_rows=hint, compact_logits=compact)
+        if hint is not None and cfg.last_layer_on_loss_rows:   # the aggregate-first node ran, not a silent fall-back
+            assert "FusedGATLastLayerRows" in type(z.grad_fn).__name__, type(z.grad_fn).__name__
         zl = z if (compact and z.shape[0] == idx.numel()) else z.index_select(0, idx)
         loss = torch.nn.functional.nll_loss(torch.log_softmax(zl, 1), y, reduction="sum")
         loss.backward()

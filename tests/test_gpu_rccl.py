@@ -109,3 +109,26 @@ def test_bench_shard_mode_steps_one_rank_of_a_job_and_its_shares_add_up(tmp_path
     # heaviest/N names the rank with the largest weight
     w = a["config"]["emulated"]["rank_weights"]
     assert max(w) <= 1.02 * min(w)
+
+
+@pytest.mark.parametrize("layer", ["GATConv", "APPNP"])
+def test_bench_lines_of_the_other_operators(tmp_path, layer):
+    """`bench.py --layer GATConv | APPNP` (north_star names GCN / GAT / APPNP): the same line shape as the headline -- the metric, a
+    step-weighted roofline over the operator's own kernels with per-kind entries, the CPU oracle of the same step beside it."""
+    bench = os.path.join(ROOT, "bench.py")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    res = subprocess.run([sys.executable, bench, "--layer", layer, "--workload", "S-cora", "--steps", "8", "--warmup", "2"], env=env, cwd=tmp_path,
+                         check=True, timeout=600, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+    line = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["metric"].startswith("edges aggregated/sec") and line["value"] > 0 and line["config"]["layer"] == layer
+    kinds = {l["kind"] for l in line["roofline"]["launches"]}
+    if layer == "GATConv":
+        assert {"gat_scores", "gat_edge_softmax", "gat_aggregate", "gat_sddmm", "gat_softmax_bwd", "gat_aggregate_t"} <= kinds
+    else:
+        assert kinds == {"appnp_step", "appnp_step_t"}
+        assert all(abs(l["launches_per_step"] - 10) < 1e-9 for l in line["roofline"]["launches"])
+    assert 0 < line["roofline"]["frac"] < 1.5 and line["roofline"]["bound"] == "hbm"
+    assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["value"] > 0
+    assert np.isfinite(line["loss"])
