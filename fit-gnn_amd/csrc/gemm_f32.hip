@@ -105,7 +105,7 @@ __device__ __forceinline__ void frag(float (&f)[4], const float *lds, int o, int
 
 // nchunks > 1: split over k.  Workgroup (chunk, tile) reduces k in [chunk * chunk_k, +chunk_k) and stores its tile into
 // partial[chunk] (an [I x J] matrix each); sum_chunks_kernel adds them in a fixed order.
-template <int WM, int WN, int MI, int NJ, bool AKM, bool BKM>
+template <int WM, int WN, int MI, int NJ, bool AKM, bool BKM, bool PIPE = false>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(const float *__restrict__ A, long lda, const float *__restrict__ B, long ldb,
                                                                    long I, int J, long K, float *__restrict__ C, long ldc, int tiles_i,
                                                                    int tiles_j, int nchunks, long chunk_k) {
@@ -150,7 +150,54 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(const float *__r
         store_slab<BKM, G::TJ, G::NB, G::THREADS>(rb, lds_f + G::A_DW);
     }
     __syncthreads();
-    for (int s = 0; s < nstage; ++s) {
+    // Two forms of the stage loop.  PIPE (opt-in, FITGNN_GEMM_PIPE=1 on the 128 x 128 / 64 x 128 shapes): software-pipelined across the
+    // barrier -- the fragments of a stage's LAST k-octet are read before the barrier and multiplied after it, while the first octet's
+    // fragments of the NEXT stage are on their way from LDS.  Built because rocprofv3 --pmc puts the MFMA pipe at 80 % of the SIMD
+    // cycles (2.31 GHz) on the 34 493 x 512 x 8 448 product (tools/pmc_gemm.sh); measured: no gain on any shape of
+    // tools/gemm_shape_probe.py (+-1 %), and the 256 x 256 form with a k-major b spills -- the plain loop stays the default.
+    auto read_frags = [&](float (&fa)[MI][4], float (&fb)[NJ][4], const float *sa, const float *sb, int kk) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) frag<AKM, G::TI>(fa[i], sa, wm * (32 * MI) + i * 32, kk, lane);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) frag<BKM, G::TJ>(fb[j], sb, wn * (32 * NJ) + j * 32, kk, lane);
+    };
+    auto multiply = [&](const float (&fa)[MI][4], const float (&fb)[NJ][4]) {
+#pragma unroll
+        for (int st = 0; st < 4; ++st)
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][st], fb[j][st], acc[i][j], 0, 0, 0);
+    };
+    constexpr int NKK = kBK / 8;
+    if (!PIPE) {   // the plain loop (default)
+        for (int s = 0; s < nstage; ++s) {
+            const float *sa = lds_f + (s & 1) * G::STAGE_DW;
+            const float *sb = sa + G::A_DW;
+            const bool more = s + 1 < nstage;
+            if (more) {
+                const long k0 = k_begin + (long)(s + 1) * kBK;
+                load_slab<AKM, G::TI, G::NA, G::THREADS>(ra, A, lda, i0, I, k0, k_end);
+                load_slab<BKM, G::TJ, G::NB, G::THREADS>(rb, B, ldb, j0, (long)J, k0, k_end);
+            }
+#pragma unroll
+            for (int kk = 0; kk < NKK; ++kk) {
+                float fa[MI][4], fb[NJ][4];
+                read_frags(fa, fb, sa, sb, kk);
+                multiply(fa, fb);
+            }
+            if (more) {
+                float *na = lds_f + ((s + 1) & 1) * G::STAGE_DW;
+                store_slab<AKM, G::TI, G::NA, G::THREADS>(ra, na);
+                store_slab<BKM, G::TJ, G::NB, G::THREADS>(rb, na + G::A_DW);
+            }
+            __syncthreads();
+        }
+    }
+    float f0a[MI][4], f0b[NJ][4];   // the first octet of the stage about to be multiplied
+    if (PIPE && nstage > 0) read_frags(f0a, f0b, lds_f, lds_f + G::A_DW, 0);
+    for (int s = 0; PIPE && s < nstage; ++s) {
         const float *sa = lds_f + (s & 1) * G::STAGE_DW;
         const float *sb = sa + G::A_DW;
         const bool more = s + 1 < nstage;   // workgroup-uniform
@@ -159,27 +206,27 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(const float *__r
             load_slab<AKM, G::TI, G::NA, G::THREADS>(ra, A, lda, i0, I, k0, k_end);
             load_slab<BKM, G::TJ, G::NB, G::THREADS>(rb, B, ldb, j0, (long)J, k0, k_end);
         }
+        multiply(f0a, f0b);
 #pragma unroll
-        for (int kk = 0; kk < kBK / 8; ++kk) {
+        for (int kk = 1; kk < NKK - 1; ++kk) {
             float fa[MI][4], fb[NJ][4];
-#pragma unroll
-            for (int i = 0; i < MI; ++i) frag<AKM, G::TI>(fa[i], sa, wm * (32 * MI) + i * 32, kk, lane);
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) frag<BKM, G::TJ>(fb[j], sb, wn * (32 * NJ) + j * 32, kk, lane);
-#pragma unroll
-            for (int st = 0; st < 4; ++st)
-#pragma unroll
-                for (int i = 0; i < MI; ++i)
-#pragma unroll
-                    for (int j = 0; j < NJ; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][st], fb[j][st], acc[i][j], 0, 0, 0);
+            read_frags(fa, fb, sa, sb, kk);
+            multiply(fa, fb);
         }
+        float fla[MI][4], flb[NJ][4];
+        read_frags(fla, flb, sa, sb, NKK - 1);
         if (more) {
             float *na = lds_f + ((s + 1) & 1) * G::STAGE_DW;
             store_slab<AKM, G::TI, G::NA, G::THREADS>(ra, na);
             store_slab<BKM, G::TJ, G::NB, G::THREADS>(rb, na + G::A_DW);
         }
         __syncthreads();
+        if (more) {
+            const float *na = lds_f + ((s + 1) & 1) * G::STAGE_DW;
+            read_frags(f0a, f0b, na, na + G::A_DW, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);   // keep the last octet's products BEHIND the barrier and the reads just issued
+        multiply(fla, flb);
     }
 
     // C/D layout of the 32 x 32 MFMA: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
@@ -226,9 +273,9 @@ __global__ __launch_bounds__(256) void sum_chunks_kernel(const float *__restrict
 // byte.  Its grid is too coarse for the short operands of the configurations (S-pubmed's 19 717-row table: 154 tiles on 256 CUs; a
 // 128-molecule QM9 batch: 38), so smaller tiles take over there: 128 x 128 (4 waves of 64 x 64, 74 KB: two workgroups per CU) and
 // 64 x 128 (4 waves of 32 x 64, 55 KB).  64 x 512 serves the head's weight gradient (<= 64 padded class rows), 256 x 128 a narrow J.
-enum Shape { S256 = 0, S256x128, S64x512, S128, S64x128, S128x64 };
+enum Shape { S256 = 0, S256x128, S64x512, S128, S64x128, S128x64, S64x64 };
 struct ShapeDim { int ti, tj, per_cu; };
-constexpr ShapeDim kShape[] = {{256, 256, 1}, {256, 128, 1}, {64, 512, 1}, {128, 128, 2}, {64, 128, 2}, {128, 64, 2}};
+constexpr ShapeDim kShape[] = {{256, 256, 1}, {256, 128, 1}, {64, 512, 1}, {128, 128, 2}, {64, 128, 2}, {128, 64, 2}, {64, 64, 4}};
 
 struct Plan {
     int shape;           // Shape
@@ -261,10 +308,11 @@ Plan make_plan(long I, int J, long K, bool akm, bool bkm) {
         // lose a little per flop (operands re-read more often; 128 x 128 does not fill its third round evenly) and win whenever the
         // 256 x 256 grid is coarse: 19 717 rows (154 tiles) 146 -> 111 us, 4 861 rows (38 tiles) 136 -> 45 us, a rank's 20 625 loss rows
         // 135 -> 120 us; from ~90 000 rows on 256 x 256 is the fastest again (414 vs 423 / 440 us)  [tools/gemm_shape_probe.py]
-        const int cand[3] = {J <= 128 ? S256x128 : S256, S128, S64x128};
-        const double eff[3] = {1.0, K <= 256 ? 1.0 : 0.85, 0.94};   // short k: two workgroups per CU hide each other's stores
+        // (64 x 64: a 128-molecule QM9 batch, 4 861 rows = 304 tiles of 64 x 128, still leaves every fifth CU with two tiles)
+        const int cand[4] = {J <= 128 ? S256x128 : S256, S128, S64x128, S64x64};
+        const double eff[4] = {1.0, K <= 256 ? 1.0 : 0.85, 0.94, 0.85};   // short k: two workgroups per CU hide each other's stores
         double best_cost = 0;
-        for (int q = 0; q < 3; ++q) {
+        for (int q = 0; q < 4; ++q) {
             const int sh = cand[q];
             const long t = tiles_of(sh);
             double rounds = (double)((t + 255) / 256);
@@ -278,7 +326,7 @@ Plan make_plan(long I, int J, long K, bool akm, bool bkm) {
     }
     if (const char *force = getenv("FITGNN_GEMM_SHAPE")) {   // experiments
         const int f = atoi(force);
-        if (f >= 0 && f <= S128x64 && !(f == S64x512 && !tn)) p.shape = f;
+        if (f >= 0 && f <= S64x64 && !(f == S64x512 && !tn)) p.shape = f;
     }
     const int TI = kShape[p.shape].ti, TJ = kShape[p.shape].tj;
     const double slots = 256.0 * kShape[p.shape].per_cu;
@@ -328,16 +376,16 @@ Plan make_plan(long I, int J, long K, bool akm, bool bkm) {
     return p;
 }
 
-template <int WM, int WN, int MI, int NJ, bool AKM, bool BKM>
+template <int WM, int WN, int MI, int NJ, bool AKM, bool BKM, bool PIPE = false>
 int launch(const Plan &p, const float *a, long lda, const float *b, long ldb, long I, int J, long K, float *c, long ldc, hipStream_t s) {
     using G = Geo<WM, WN, MI, NJ, AKM, BKM>;
     static std::atomic<uint64_t> lds_done{0};
-    if (const int rc = fitgnn_lds_limit_once((const void *)gemm_f32_kernel<WM, WN, MI, NJ, AKM, BKM>, G::LDS_BYTES, lds_done)) return rc;
+    if (const int rc = fitgnn_lds_limit_once((const void *)gemm_f32_kernel<WM, WN, MI, NJ, AKM, BKM, PIPE>, G::LDS_BYTES, lds_done)) return rc;
     unsigned grid;
     if (p.nchunks > 1) grid = (unsigned)(p.tiles_i * p.tiles_j * ((p.nchunks + 7) / 8 * 8));   // chunk = xcd + 8 * (slot / tiles)
     else grid = (unsigned)((p.tiles_i + 7) / 8 * 8 * p.tiles_j);
-    hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, MI, NJ, AKM, BKM>), dim3(grid), dim3(G::THREADS), G::LDS_BYTES, s, a, lda, b, ldb, I, J, K, c,
-                       ldc, p.tiles_i, p.tiles_j, p.nchunks, p.chunk_k);
+    hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, MI, NJ, AKM, BKM, PIPE>), dim3(grid), dim3(G::THREADS), G::LDS_BYTES, s, a, lda, b, ldb, I, J, K,
+                       c, ldc, p.tiles_i, p.tiles_j, p.nchunks, p.chunk_k);
     return (int)hipGetLastError();
 }
 
@@ -348,9 +396,14 @@ int launch_shape(const Plan &p, const float *a, long lda, const float *b, long l
     }
     switch (p.shape) {
         case S256x128: return launch<4, 1, 2, 4, AKM, BKM>(p, a, lda, b, ldb, I, J, K, c, ldc, s);
-        case S128: return launch<2, 2, 2, 2, AKM, BKM>(p, a, lda, b, ldb, I, J, K, c, ldc, s);
-        case S64x128: return launch<2, 2, 1, 2, AKM, BKM>(p, a, lda, b, ldb, I, J, K, c, ldc, s);
+        case S128:
+            if (getenv("FITGNN_GEMM_PIPE")) return launch<2, 2, 2, 2, AKM, BKM, true>(p, a, lda, b, ldb, I, J, K, c, ldc, s);
+            return launch<2, 2, 2, 2, AKM, BKM>(p, a, lda, b, ldb, I, J, K, c, ldc, s);
+        case S64x128:
+            if (getenv("FITGNN_GEMM_PIPE")) return launch<2, 2, 1, 2, AKM, BKM, true>(p, a, lda, b, ldb, I, J, K, c, ldc, s);
+            return launch<2, 2, 1, 2, AKM, BKM>(p, a, lda, b, ldb, I, J, K, c, ldc, s);
         case S128x64: return launch<4, 1, 1, 2, AKM, BKM>(p, a, lda, b, ldb, I, J, K, c, ldc, s);
+        case S64x64: return launch<2, 2, 1, 1, AKM, BKM>(p, a, lda, b, ldb, I, J, K, c, ldc, s);
         default: return launch<4, 2, 2, 4, AKM, BKM>(p, a, lda, b, ldb, I, J, K, c, ldc, s);
     }
 }

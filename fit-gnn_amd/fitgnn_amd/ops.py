@@ -102,7 +102,7 @@ def _exact(cfg, a, b):
     return cfg.gemm_precision == "exact" and _rows_16b(a) and _rows_16b(b)
 
 
-def gemm_exact(a, b, form, cfg=DEFAULT):
+def gemm_exact(a, b, form, cfg=DEFAULT, out=None):
     """One product of a Linear in exact fp32 on the fp32 MFMA (fitgnn_gemm_exact_f32, csrc/gemm_f32.hip):
         form "nt": a [I, K] @ b [J, K]^T   (forward x W^T)
              "nn": a [I, K] @ b [K, J]     (grad_x = dH W: W is read as it lies, no transposed copy)
@@ -119,11 +119,14 @@ def gemm_exact(a, b, form, cfg=DEFAULT):
         assert b.shape[0] == K
     else:
         raise ValueError(form)
-    out = torch.empty((I, J), dtype=torch.float32, device=a.device)
+    if out is None:
+        out = torch.empty((I, J), dtype=torch.float32, device=a.device)
+    else:   # the caller's [I, J] buffer (rows may be strided: e.g. the head of a taller matrix)
+        assert out.shape == (I, J) and out.dtype == torch.float32 and out.stride(1) == 1 and out.is_cuda
     wb = int(L.fitgnn_gemm_exact_workspace_bytes(I, J, K, akm, bkm))
     ws = torch.empty(wb // 4, dtype=torch.float32, device=a.device) if wb else None
     ev = _gemm_events(cfg, "gemm_f32_kernel[%s]" % form, 2.0 * I * J * K)
-    rc = L.fitgnn_gemm_exact_f32(_lib.dptr(a), a.stride(0), akm, _lib.dptr(b), b.stride(0), bkm, I, J, K, _lib.dptr(out), J,
+    rc = L.fitgnn_gemm_exact_f32(_lib.dptr(a), a.stride(0), akm, _lib.dptr(b), b.stride(0), bkm, I, J, K, _lib.dptr(out), out.stride(0),
                                  _lib.dptr(ws), _lib.stream_ptr(a.device))
     _gemm_done(cfg, ev)
     _lib.check(rc, "fitgnn_gemm_exact_f32")
@@ -170,12 +173,15 @@ def _wt_operand(a, W, cfg):
     return W.t().contiguous()
 
 
-def mm_by_transposed(a, W, cfg=DEFAULT):
+def mm_by_transposed(a, W, cfg=DEFAULT, out=None):
     """a @ W for a square-ish weight W [out, in]: the library's kernel for a row-major right operand (NN) takes 201 us on
     the S-pubmed union, the one for a transposed right operand (the forward's x @ W^T form) 160 us -- materialise W^T
-    (1 MB) and use the latter.  Bit-identical result."""
+    (1 MB) and use the latter.  Bit-identical result.  out: write the product there (the exact kernel stores into it directly)."""
     if _exact(cfg, a, W):
-        return gemm_exact(a, W, "nn", cfg)
+        return gemm_exact(a, W, "nn", cfg, out=out)
+    if out is not None:
+        out.copy_(mm_by_transposed(a, W, cfg))
+        return out
     if a.is_cuda and W.dim() == 2 and W.shape[0] >= 64 and W.shape[1] >= 64:
         Wt = _wt_operand(a, W, cfg)
         if _nt_ok(a, Wt, cfg):
@@ -1414,7 +1420,7 @@ class FusedGCNLastLayerRows(torch.autograd.Function):
             n, K = AHc.shape
             dAH = torch.empty((n + ZERO_ROWS, K), dtype=torch.float32, device=dZc.device)
             dAH[n:].zero_()
-            dAH[:n] = mm_by_transposed(dZc, W, cfg)                      # dZ @ W on the loss rows
+            mm_by_transposed(dZc, W, cfg, out=dAH[:n])                   # dZ @ W on the loss rows, stored in place
             link = ctx.link_in
             if Xprev is not None and two_hop_supported(g, link, dAH, Xprev, cfg):
                 # ... and the producing layer's own backward SpMM over that dZ in the same pass: what travels back is A_hat^T dZ
@@ -1651,7 +1657,7 @@ class FusedGATLastLayerRows(torch.autograd.Function):
         dW = mm_at_b(dZc, AXc, cfg)                                                               # [H, K]
         dAX = torch.empty((n + ZERO_ROWS, K), dtype=torch.float32, device=dev)
         dAX[n:].zero_()
-        dAX[:n] = mm_by_transposed(dZc, W, cfg)                                                   # dZ W on the loss rows
+        mm_by_transposed(dZc, W, cfg, out=dAX[:n])                                                # dZ W on the loss rows
         # the aggregation's backward, on the loss rows' entries: d(alpha), then the softmax / LeakyReLU backward
         dalpha = torch.zeros_like(alpha)
         with _timed(cfg, "gat_sddmm"):

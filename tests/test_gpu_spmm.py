@@ -681,13 +681,13 @@ def test_exact_fp32_gemm_tile_shapes_give_the_same_bits(mods, form, dims, monkey
         I, K, J = dims
         a, b = torch.randn(I, K, generator=g).cuda(), torch.randn(K, J, generator=g).cuda()
     outs = []
-    for shape in ("0", "3", "4"):   # S256, S128, S64x128
+    for shape in ("0", "3", "4", "6"):   # S256, S128, S64x128, S64x64
         monkeypatch.setenv("FITGNN_GEMM_SHAPE", shape)
         monkeypatch.setenv("FITGNN_GEMM_NO_TAIL", "1")
         outs.append(ops.gemm_exact(a, b, form))
     monkeypatch.delenv("FITGNN_GEMM_SHAPE")
     monkeypatch.delenv("FITGNN_GEMM_NO_TAIL")
-    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    assert all(torch.equal(outs[0], o) for o in outs[1:])
     assert torch.equal(outs[0], ops.gemm_exact(a, b, form))   # (none of these shapes has a k split or a tail launch in its default plan)
 
 

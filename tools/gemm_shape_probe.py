@@ -21,7 +21,7 @@ def bench(fn, reps=10):
 shapes = [("nt", 34493, 512, 8448), ("tn", 512, 8448, 34493), ("nt", 4861, 512, 512), ("nn", 4861, 512, 512), ("tn", 512, 512, 4861), ("nt", 19717, 512, 512), ("nn", 19717, 512, 512),
           ("tn", 512, 512, 19717), ("nt", 20625, 512, 512), ("nt", 34493, 512, 512), ("nt", 90549, 512, 512), ("nt", 165000, 512, 128),
           ("tn", 512, 128, 165000), ("tn", 512, 512, 165000), ("tn", 512, 512, 20625), ("nt", 165000, 512, 512), ("nt", 19717, 512, 512 - 12), ("nt", 82500, 48, 512)]
-names = {"0": "256x256", "3": "128x128", "4": "64x128"}
+names = {"0": "256x256", "3": "128x128", "4": "64x128", "6": "64x64"}
 for form, I, J, K in shapes:
     if form == "nt": a, b = torch.randn(I, K, device="cuda"), torch.randn(J, K, device="cuda")
     elif form == "nn": a, b = torch.randn(I, K, device="cuda"), torch.randn(K, J, device="cuda")
@@ -30,7 +30,11 @@ for form, I, J, K in shapes:
     os.environ.pop("FITGNN_GEMM_SHAPE", None)
     us = bench(lambda: ops.gemm_exact(a, b, form))
     line = [f"default {us:8.1f} us {flops / us / 1e6:6.1f} TF"]
-    for sh in ("0", "3", "4"):
+    os.environ["FITGNN_GEMM_PIPE"] = "1"   # the 128 x 128 / 64 x 128 shapes with the software-pipelined stage loop
+    us = bench(lambda: ops.gemm_exact(a, b, form))
+    os.environ.pop("FITGNN_GEMM_PIPE", None)
+    line.append(f"default, pipelined loop {us:8.1f} us {flops / us / 1e6:6.1f} TF")
+    for sh in ("0", "3", "4", "6"):
         os.environ["FITGNN_GEMM_SHAPE"] = sh
         us = bench(lambda: ops.gemm_exact(a, b, form))
         line.append(f"{names[sh]} {us:8.1f} us {flops / us / 1e6:6.1f} TF")
