@@ -306,12 +306,15 @@ def main():
         info.update(union_rows=sum(info["shard_union_rows"]), nnz_prime=sum(info["shard_nnz_prime"]))
     else:
         info.update(union_rows=int(mine_sizes[0]), nnz_prime=int(mine_sizes[1]))
-    info["t_assemble_s"] = round(t5 - t4, 2)   # the first call in the process: includes the one-time loading of the sort / scan kernels it uses
-    if world == 1 and emu is None and args.layer == "GCNConv":   # the same assembly once more: what it takes once those are resident
+    # t_assemble_first_call_s: this process's FIRST assembly -- it includes the one-time paging-in of the library sort / unique / scan
+    # kernels' code objects (0.2-0.8 s, box dependent); t_assemble_s: the same assembly once more = what the algorithm takes
+    info["t_assemble_first_call_s"] = round(t5 - t4, 3)
+    info["t_assemble_s"] = info["t_assemble_first_call_s"]
+    if world == 1 and emu is None and args.layer == "GCNConv":
         t_w = time.time()
         sub_w, _ = workloads.assemble(args.workload, ei_d, assign_d, n_clusters, clusters=mine)
         torch.cuda.synchronize()
-        info["t_assemble_warm_s"] = round(time.time() - t_w, 3)
+        info["t_assemble_s"] = round(time.time() - t_w, 3)
         del sub_w
         t5 = time.time()
     del ei_d

@@ -1583,6 +1583,34 @@ class GATAggregate(torch.autograd.Function):
         return dh, datt_src, datt_dst, db, None, None, None, None, None, None, None, None, None
 
 
+def _gat_rank2_csr(g, rows, pos):
+    """The transposed pattern of g with TWO extra entries per row, for the adjoint aggregation of FusedGATLastLayerRows with the
+    scores' rank-2 term in the same launch: dX[r] = sum_e alpha_e dAX[.] + da_src[r] u_src + da_dst[r] u_dst -- the two vectors u ride
+    as operand rows n, n + 1 of the compact operand (zero rows from n + 2 on) and the two extra entries of row r carry da_src[r],
+    da_dst[r].  Static per (graph, loss rows): (rowptr_aug int32 [R + 1], xcol_aug int32 [nnz + 2 R], main int64 [nnz] = where the
+    pattern's own entries sit, ext int64 [R] = where row r's first extra entry sits); cached on the graph."""
+    cache = getattr(g, "_gat_rank2", None)
+    if not _same_index(cache, rows):
+        side, dev, R, n = g.t, rows.device, g.n, int(rows.numel())
+        rp = side.rowptr.long()
+        ar = torch.arange(R + 1, device=dev)
+        rp_aug = rp + 2 * ar
+        cnt = (rp[1:] - rp[:-1])
+        row_e = torch.repeat_interleave(ar[:-1], cnt)
+        main = torch.arange(int(rp[-1]), device=dev) + 2 * row_e                     # entry e of row r moves behind 2 r extras
+        ext = rp_aug[1:] - 2                                                          # the last two slots of every row
+        # operand rows: loss rows 0..n-1, then u_src, u_dst (n, n + 1), then the zero rows: a non-loss row r reads n + 2 + r % ZERO_ROWS
+        posz = pos.long()
+        posz = torch.where(posz >= n, posz + 2, posz)
+        xcol_aug = torch.empty(int(rp_aug[-1]), dtype=torch.int32, device=dev)
+        xcol_aug[main] = posz.index_select(0, side.col.long()).to(torch.int32)
+        xcol_aug[ext] = n
+        xcol_aug[ext + 1] = n + 1
+        cache = (rows, rows._version, (rp_aug.to(torch.int32).contiguous(), xcol_aug, main, ext))
+        g._gat_rank2 = cache
+    return cache[2]
+
+
 class FusedGATLastLayerRows(torch.autograd.Function):
     """The last GATConv layer + ELU + dropout + head when only `rows` of the result reach the loss (run.py:193-204 keeps out[mask]),
     evaluated aggregate-first like FusedGCNLastLayerRows: the attention scores need no transformed features,
@@ -1655,8 +1683,14 @@ class FusedGATLastLayerRows(torch.autograd.Function):
             dWl = head_weight_grad_rows(dy_c, outc, cfg)
         dbl = colsum_narrow(dy_c) if ctx.has_bl and ctx.needs_input_grad[6] else None
         dW = mm_at_b(dZc, AXc, cfg)                                                               # [H, K]
-        dAX = torch.empty((n + ZERO_ROWS, K), dtype=torch.float32, device=dev)
-        dAX[n:].zero_()
+        # the compact gradient of the aggregation's output: rows 0..n-1 = dZ W on the loss rows; with the rank-2 term folded into the
+        # adjoint aggregation (below) rows n, n + 1 carry u = W^T att, and the zero rows follow
+        fold = bool(ctx.needs_input_grad[0]) and cfg.compact_rows_kernel and K % 4 == 0
+        lead = n + 2 if fold else n
+        dAX = torch.empty((lead + ZERO_ROWS, K), dtype=torch.float32, device=dev)
+        dAX[lead:].zero_()
+        if fold:
+            dAX[n:n + 2] = u
         mm_by_transposed(dZc, W, cfg, out=dAX[:n])                                                # dZ W on the loss rows
         # the aggregation's backward, on the loss rows' entries: d(alpha), then the softmax / LeakyReLU backward
         dalpha = torch.zeros_like(alpha)
@@ -1677,7 +1711,22 @@ class FusedGATLastLayerRows(torch.autograd.Function):
         da = torch.stack([da_src, da_dst], dim=1)                                                 # [R, 2]
         du = mm_at_b(da, X, cfg)                                                                  # [2, K] = da^T x
         dX = None
-        if ctx.needs_input_grad[0]:
+        if fold:
+            # the adjoint aggregation AND the scores' rank-2 term  + da_src (x) W^T att_src + da_dst (x) W^T att_dst  in one launch of
+            # the row-streaming kernel: u's two rows ride in the compact operand, da in two extra entries per row (_gat_rank2_csr)
+            rp_aug, xcol_aug, main, ext = _gat_rank2_csr(g, rows, _compact_positions(g, rows))
+            op = dAX
+            with _timed(cfg, "gat_rank1"):
+                val_aug = torch.empty(int(xcol_aug.numel()), dtype=torch.float32, device=dev)
+                val_aug[main] = alpha_t
+                val_aug[ext] = da_src
+                val_aug[ext + 1] = da_dst
+            dX = torch.empty((R, K), dtype=torch.float32, device=dev)
+            with _timed(cfg, "gat_aggregate_t"):
+                _lib.check(L.fitgnn_spmm_rows_compact_f32(_lib.dptr(rp_aug), _lib.dptr(xcol_aug), _lib.dptr(val_aug), int(xcol_aug.numel()),
+                                                          _lib.dptr(op), op.stride(0), n + 2, _lib.dptr(dX), dX.stride(0), R, K, st),
+                           "fitgnn_spmm_rows_compact_f32")
+        elif ctx.needs_input_grad[0]:
             dX = spmm_graph(g, dAX, transposed=True, val=alpha_t, cfg=cfg, xrow=_compact_positions(g, rows), zero_from=n,
                             profile_kind="gat_aggregate_t")
             with _timed(cfg, "gat_rank1"):

@@ -29,7 +29,7 @@ def timed(owner, name):
 
 
 def main():
-    wl = sys.argv[1] if len(sys.argv) > 1 else "S-products"
+    wl = sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].startswith("-") else "S-products"
     dev = torch.device("cuda")
     w0 = workloads.coarsen_workload(wl, dev)
     ei_d = torch.from_numpy(w0["ei"]).to(dev)
@@ -40,6 +40,15 @@ def main():
                          (csr.CSRGraph, ["finalize", "__init__"]), (ops.RowIndex, ["__init__"]), (data.SubgraphBatch, ["__init__"])):
         for n in names:
             timed(owner, n)
+    if "--prewarm" in sys.argv:   # the same torch / library kernels on a small graph first: is the first call's cost code loading or allocation?
+        w1 = workloads.coarsen_workload("S-pubmed", dev)
+        e1, a1 = torch.from_numpy(w1["ei"]).to(dev), torch.from_numpy(w1["assign"]).to(dev)
+        torch.cuda.synchronize(); t0 = time.time()
+        s1, _ = workloads.assemble("S-pubmed", e1, a1, w1["n_clusters"])
+        b1 = workloads.batch_from_subgraphs("S-pubmed", s1, dev)
+        torch.cuda.synchronize()
+        print(f"prewarm on S-pubmed: {time.time() - t0:.3f} s")
+        del s1, b1
     for rnd in range(2):
         TIMES.clear()
         torch.cuda.synchronize(); t0 = time.time()
