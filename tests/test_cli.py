@@ -114,6 +114,21 @@ def test_cli_end_to_end_on_synthetic_cora(tmp_path, monkeypatch):
 
 
 @pytest.mark.gpu
+def test_cli_trains_attention_layers_on_the_subgraph_union(tmp_path, monkeypatch):
+    """`--layer_name GATConv` through the kept command line (network.py:13-17): Gs training in GD mode runs the first attention
+    layer on the de-duplicated table and the last one aggregate-first on the loss rows (ops.FusedGATLastLayerRows); inference on the
+    subgraphs with the saved weights; the state_dict carries PyG's GATConv keys."""
+    monkeypatch.chdir(tmp_path)
+    common = ["--dataset", "synthetic-cora", "--runs", "1", "--hidden", "64", "--seed", "0", "--normalize_features", "--layer_name", "GATConv"]
+    _, acc, _ = cli.main(common + ["--output_dir", "g", "--train_fitgnn", "--exp_setup", "Gs_train_2_Gs_infer", "--coarsening_ratio", "0.5",
+                                   "--epochs1", "40", "--epochs2", "60", "--extra_node"])
+    assert acc[0] > 0.4, acc   # 7 classes, homophilous synthetic labels
+    sd = torch.load("save/node_cls/g/model.pt")
+    assert sorted(sd) == ["conv.0.att_dst", "conv.0.att_src", "conv.0.bias", "conv.0.lin.weight", "conv.1.att_dst", "conv.1.att_src",
+                          "conv.1.bias", "conv.1.lin.weight", "lt1.bias", "lt1.weight"]
+
+
+@pytest.mark.gpu
 def test_cli_graph_regression_on_synthetic_qm9(tmp_path, monkeypatch):
     """main.py on the QM9-shaped stand-in (BASELINE.json config 5's plumbing): batched coarsening of every molecule,
     Gs / Gc training loops, results row with the reference's columns; the model must beat predicting zero."""
