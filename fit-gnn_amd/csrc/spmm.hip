@@ -20,6 +20,8 @@
 
 #include <algorithm>
 
+#include <cstdlib>
+
 #include "common.h"
 #include "fitgnn_hip.h"
 
@@ -1511,11 +1513,14 @@ extern "C" int fitgnn_spmm_csr_blocks_dz_f32(const int32_t *rowptr, const int32_
 
 namespace {
 // ranges of consecutive rows, one per (wave, slab): enough waves to fill 256 CUs x 32 waves several times over on a large batch,
-// at least 64 rows each
+// at least 32 rows each (64 left the 90 549-row S-pubmed union with 11 waves per CU: 122 -> 93 us for its compact-operand launch; 16
+// and 8 are no faster)
 inline void rows_plan(int32_t n_rows, int32_t *rows_per_range, int32_t *n_ranges) {
     const int want = 8192;
     int per = (n_rows + want - 1) / want;
-    if (per < 64) per = 64;
+    int least = 32;
+    if (const char *e = getenv("FITGNN_ROWS_MIN")) least = atoi(e) > 0 ? atoi(e) : 32;   // experiments
+    if (per < least) per = least;
     *rows_per_range = per;
     *n_ranges = (n_rows + per - 1) / per;
 }
