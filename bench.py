@@ -157,6 +157,14 @@ def pmc_traffic(launches, run_cfg):
         return {"traffic": None}
 
 
+def _pruned_edges(tr, batch):
+    """Edges aggregated by one pruned step: with the forward aggregation of the last layer on the loss rows alone (GDTrainer.prune_forward)
+    layer 0's forward and both backward products still run over every entry (the backward's operand is zero outside the loss rows, every
+    entry is multiplied); the older row-subset path runs both of layer 1's products on the own rows' entries."""
+    sub_nnz = float(tr.sub.f.col.numel())
+    return (3.0 * batch.nnz + sub_nnz) if getattr(tr, "prune_forward", False) else (2.0 * batch.nnz + 2.0 * sub_nnz)
+
+
 def cpu_model():
     try:
         with open("/proc/cpuinfo") as f:
@@ -398,8 +406,8 @@ def main():
     edges_per_step = 4.0 * batch.nnz   # GCN / GAT: two layers x (aggregation forward + its adjoint backward)
     if args.layer == "APPNP":
         edges_per_step = 2.0 * 10 * batch.nnz   # K = 10 propagation steps forward + 10 backward, on the class-wide signal
-    if trainer.sub is not None:   # two full SpMMs (layer 0) + the own-node rows of A_hat twice (layer 1 forward / backward)
-        edges_per_step = 2.0 * batch.nnz + 2.0 * int(trainer.sub.f.col.numel())
+    if trainer.sub is not None:   # layer 0 forward, both backward products over every entry + the loss rows' entries of A_hat (layer 1 forward)
+        edges_per_step = _pruned_edges(trainer, batch)
     edges = torch.tensor([edges_per_step], device=device, dtype=torch.float64)
     if world > 1:
         torch.distributed.all_reduce(edges)
@@ -411,7 +419,7 @@ def main():
         dt2, loss2 = timed(tr2, k2, max(2, min(args.warmup, 10)))
         e2 = edges_per_step_total
         if tr2.sub is not None:   # the pruned step aggregates fewer edges: its own count
-            e2 = 2.0 * batch.nnz + 2.0 * int(tr2.sub.f.col.numel())
+            e2 = _pruned_edges(tr2, batch)
         return dict(ms_per_step=dt2 / k2 * 1e3, value=e2 * k2 / dt2, steps=k2, loss=float(loss2), edges_per_step=e2)
 
     secondary = emu is None and args.layer == "GCNConv"

@@ -100,7 +100,7 @@ class _Base(nn.Module):
                 link = None
         return x
 
-    def embed_and_head(self, x, edge_index, x_index=None, out_rows=None, loss_rows=None, compact_logits=False):
+    def embed_and_head(self, x, edge_index, x_index=None, out_rows=None, loss_rows=None, compact_logits=False, forward_rows_only=False):
         """embed() followed by lt1; on the GPU the last GCN layer and the head form one autograd node.
         x_index (ops.RowIndex, optional): x is a de-duplicated table and union row r is table row x_index.index[r].
         out_rows (csr.RowSubset, optional): return the head's output on those rows only.  The last layer is then
@@ -111,7 +111,10 @@ class _Base(nn.Module):
         gradients are then reduced over those rows alone, and the head itself is evaluated on those rows alone (the result is
         zero on the others; the GCN layers still compute every row).
         compact_logits (with loss_rows): the caller accepts the result as [len(loss_rows), C] (the logits of those rows, in their
-        order) when the last layer runs on the loss rows -- check the returned shape: other paths return all rows."""
+        order) when the last layer runs on the loss rows -- check the returned shape: other paths return all rows.
+        forward_rows_only (with loss_rows, sorted ascending): the last layer's forward aggregation runs on the loss rows alone
+        (A_hat[rows, :] h: the rows nobody reads are not computed at all -- the pruned step); ignored where the aggregate-first
+        last layer does not apply."""
         L = self.num_layers
         if out_rows is not None:
             return self._embed_and_head_rows(x, edge_index, x_index, out_rows)
@@ -167,9 +170,17 @@ class _Base(nn.Module):
                 and last.lin.weight.shape[0] % 4 == 0 and ops.head_rows_supported(x.new_empty((1, last.lin.weight.shape[0])), self.lt1.weight)):
             # aggregate first, then the dense part on the loss rows only; the previous layer's epilogue backward rides on the
             # backward SpMM's store (link)
+            fwd_sub = None
+            if forward_rows_only:   # A_hat[rows, :] and its tiles, built once per (graph, loss rows)
+                cache = getattr(g, "_rows_fwd", None)
+                if not ops._same_index(cache, loss_rows):
+                    from .csr import RowSubset
+                    cache = (loss_rows, loss_rows._version, RowSubset(g, loss_rows))
+                    g._rows_fwd = cache
+                fwd_sub = cache[2]
             return ops.FusedGCNLastLayerRows.apply(x, last.lin.weight, last.bias, self.lt1.weight, self.lt1.bias, g,
                                                    float(self.dropout_p), bool(self.training), seed, mask, loss_rows, cfg, link,
-                                                   bool(compact_logits))
+                                                   bool(compact_logits), fwd_sub)
         return ops.FusedGCNLayerHead.apply(x, last.lin.weight, last.bias, self.lt1.weight, self.lt1.bias, g,
                                            float(self.dropout_p), bool(self.training), seed, mask, link, cfg, loss_rows)
 

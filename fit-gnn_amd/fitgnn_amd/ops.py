@@ -1363,15 +1363,22 @@ class FusedGCNLastLayerRows(torch.autograd.Function):
     (every edge aggregated, as in layer_backward's compact path)."""
 
     @staticmethod
-    def forward(ctx, X, W, b, Wl, bl, g, p, training, seed, mask, rows, cfg, link_in=None, compact_out=False):
+    def forward(ctx, X, W, b, Wl, bl, g, p, training, seed, mask, rows, cfg, link_in=None, compact_out=False, fwd_sub=None):
         """compact_out: return the logits of the kept rows only, [len(rows), C] in the order of `rows`, instead of an [R, C] matrix
-        that is zero elsewhere (the caller's loss then runs on them directly: no [R, C] logits, no [R, C] gradient)."""
+        that is zero elsewhere (the caller's loss then runs on them directly: no [R, C] logits, no [R, C] gradient).
+        fwd_sub (csr.RowSubset over `rows`, optional): the forward aggregation itself on the kept rows only, A_hat[rows, :] X -- the
+        pruned step (GDTrainer(prune_unused_rows=True)): rows nobody reads are neither aggregated nor stored; the backward is the
+        same (its operand is zero outside `rows` either way)."""
         X = _f32c(X)
         rows = rows if rows.dtype == torch.int64 else rows.long()
         ctx.link_in, ctx.compact_out = link_in, bool(compact_out)
-        AH = spmm_graph(g, X, cfg=cfg)                                   # [R, K]
-        AHc = AH.index_select(0, rows)                                   # [n, K]
-        del AH
+        if fwd_sub is not None:
+            f = fwd_sub.f
+            AHc = spmm_raw(f.rowptr, f.col, f.val, f.tiles, X, fwd_sub.m, window_rows=fwd_sub.window_rows, cfg=cfg, profile_kind="rows_fwd")
+        else:
+            AH = spmm_graph(g, X, cfg=cfg)                               # [R, K]
+            AHc = AH.index_select(0, rows)                               # [n, K]
+            del AH
         outc = mm_xwt(AHc, W, cfg)                                       # [n, H]
         if not outc.is_contiguous():
             outc = outc.contiguous()
@@ -1433,7 +1440,7 @@ class FusedGCNLastLayerRows(torch.autograd.Function):
                 link.fused, link.db = True, db_prev
             else:
                 dX = spmm_graph(g, dAH, transposed=True, cfg=cfg, xrow=_compact_positions(g, rows), profile_kind="compact", zero_from=n)
-        return dX, dW, (db if ctx.has_bias else None), dWl, dbl, None, None, None, None, None, None, None, None, None
+        return dX, dW, (db if ctx.has_bias else None), dWl, dbl, None, None, None, None, None, None, None, None, None, None
 
 
 class FusedGCNLayerDedup(torch.autograd.Function):

@@ -127,10 +127,11 @@ class GDTrainer:
                  task="node_cls", prune_unused_rows=False, op_config=None, global_train_count=None):
         """task 'node_cls': NLLLoss on log-probabilities (run.py:341); 'node_reg': L1Loss on the [n, 1] outputs (run.py:518).
         op_config (ops.OpConfig): the switches this trainer's kernels run under (set on the model; default: the model's own).
-        prune_unused_rows: evaluate the last layer only on the rows that can reach the loss (the clusters' own nodes: the
-        reference computes and then discards the extra nodes' outputs, run.py:193-204).  Same loss and gradients; the
-        last layer's GEMMs and both of its SpMMs shrink to the own-node rows.  Off by default: bench.py's metric counts
-        every non-zero of A_hat in all four SpMMs.
+        prune_unused_rows: evaluate the last layer only on the rows that reach the loss (train nodes are own nodes of their
+        cluster; the reference computes and then discards every other output, run.py:193-204).  Same loss and gradients; with a GCN
+        last layer the step is the default one with the forward aggregation A_hat[loss rows, :] h instead of A_hat h over every
+        row (ops.FusedGCNLastLayerRows, fwd_sub); other layers: the row-subset path over the own rows.  Off by default: bench.py's
+        metric counts every non-zero of A_hat in all four SpMMs.
         global_train_count: the number of train rows of the WHOLE job when it is known up front (bench.py --shard: one rank of an
         N-rank job stepped alone); default: this batch's count, summed over the process group."""
         self.model, self.batch, self.task = model, batch, task
@@ -156,14 +157,24 @@ class GDTrainer:
         self.fused_loss = (task == "node_cls" and isinstance(model, _net.Classify_node) and next(model.parameters()).is_cuda)
         self._y_train = batch.y.index_select(0, batch.train_idx) if self.fused_loss else None
         self._train_arange = None
+        self.prune_forward = False
         if prune_unused_rows and self.fused_loss and batch.graph is not None:
+            from . import nn as _fnn
             from .csr import RowSubset
-            core_rows = torch.nonzero(batch.core).flatten()
-            self.sub = RowSubset(batch.graph, core_rows)
-            pos = torch.full((batch.n_rows,), -1, dtype=torch.int64, device=core_rows.device)
-            pos[core_rows] = torch.arange(core_rows.numel(), device=core_rows.device)
-            self._train_pos = pos[batch.train_idx]          # train rows are own nodes (utils.py:695-698)
-            assert self._train_pos.numel() == 0 or int(self._train_pos.min()) >= 0
+            last = model.conv[-1] if len(model.conv) else None
+            if isinstance(last, _fnn.GCNConv) and self.cfg.last_layer_on_loss_rows:
+                # the aggregate-first last layer with its forward aggregation on the loss rows alone (ops.FusedGCNLastLayerRows,
+                # fwd_sub): everything else of the step -- compact backward, two-hop pass -- is the full step's
+                self.prune_forward = True
+                self.sub = RowSubset(batch.graph, batch.train_idx)   # (also the trainer's record of what is aggregated: bench.py counts its entries)
+                batch.graph._rows_fwd = (batch.train_idx, batch.train_idx._version, self.sub)   # what embed_and_head looks up
+            elif isinstance(last, _fnn.GCNConv):
+                core_rows = torch.nonzero(batch.core).flatten()
+                self.sub = RowSubset(batch.graph, core_rows)
+                pos = torch.full((batch.n_rows,), -1, dtype=torch.int64, device=core_rows.device)
+                pos[core_rows] = torch.arange(core_rows.numel(), device=core_rows.device)
+                self._train_pos = pos[batch.train_idx]          # train rows are own nodes (utils.py:695-698)
+                assert self._train_pos.numel() == 0 or int(self._train_pos.min()) >= 0
         count = torch.tensor([float(batch.train_idx.numel())], device=self.flat.buf.device)
         if self.dist:
             torch.distributed.all_reduce(count, group=self.pg)
@@ -232,13 +243,14 @@ class GDTrainer:
         scale = 1.0 / self.global_count if self.reduction == "mean" else 1.0
         if self.fused_loss:   # logits -> loss and d(loss)/d(logits) in one kernel (same arithmetic as log_softmax + NLLLoss)
             from .ops import SoftmaxNLL
-            if self.sub is not None:
+            if self.sub is not None and not self.prune_forward:
                 z = (m.embed_and_head(b.x_table, b.edge_index, b.row_index, out_rows=self.sub) if self.dedup
                      else m.embed_and_head(b.x, b.edge_index, out_rows=self.sub))
                 loss = SoftmaxNLL.apply(z, self._train_pos, self._y_train, scale)
             else:
-                z = (m.embed_and_head(b.x_table, b.edge_index, b.row_index, loss_rows=b.train_idx, compact_logits=True) if self.dedup
-                     else m.embed_and_head(b.x, b.edge_index, loss_rows=b.train_idx, compact_logits=True))
+                z = (m.embed_and_head(b.x_table, b.edge_index, b.row_index, loss_rows=b.train_idx, compact_logits=True,
+                                      forward_rows_only=self.prune_forward) if self.dedup
+                     else m.embed_and_head(b.x, b.edge_index, loss_rows=b.train_idx, compact_logits=True, forward_rows_only=self.prune_forward))
                 if z.shape[0] == b.train_idx.numel() and z.shape[0] != b.n_rows:   # the logits of the train rows only, in their order
                     if self._train_arange is None:
                         self._train_arange = torch.arange(z.shape[0], dtype=torch.int64, device=z.device)

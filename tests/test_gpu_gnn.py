@@ -494,7 +494,7 @@ def test_flat_adam_equals_torch_adam(mods):
 
 
 def test_pruned_last_layer_equals_full_evaluation(mods):
-    """GDTrainer(prune_unused_rows=True) -- last layer as (A_hat[own rows] h) W^T on the clusters' own nodes only -- gives
+    """GDTrainer(prune_unused_rows=True) -- last layer as (A_hat[loss rows] h) W^T: rows nobody reads are not aggregated -- gives
     the same loss and, after three epochs, the same weights as the full evaluation (dropout off); RowSubset's two
     patterns are adjoint."""
     from fitgnn_amd import ops, train
@@ -509,7 +509,8 @@ def test_pruned_last_layer_equals_full_evaluation(mods):
     m2.load_state_dict(m1.state_dict())
     t1 = train.GDTrainer(m1, batch, lr=0.01, weight_decay=5e-4)
     t2 = train.GDTrainer(m2, batch, lr=0.01, weight_decay=5e-4, prune_unused_rows=True)
-    assert t2.sub is not None and t2.sub.m == int(batch.core.sum())
+    # the pruned step = the aggregate-first last layer with its forward aggregation on the loss rows alone (A_hat[train rows, :] h)
+    assert t2.prune_forward and t2.sub is not None and t2.sub.m == int(batch.train_idx.numel())
     for epoch in range(3):
         a, b = float(t1.step()), float(t2.step())
         assert a == pytest.approx(b, rel=2e-5), (epoch, a, b)
