@@ -150,11 +150,13 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(const float *__r
         store_slab<BKM, G::TJ, G::NB, G::THREADS>(rb, lds_f + G::A_DW);
     }
     __syncthreads();
-    // Two forms of the stage loop.  PIPE (opt-in, FITGNN_GEMM_PIPE=1 on the 128 x 128 / 64 x 128 shapes): software-pipelined across the
-    // barrier -- the fragments of a stage's LAST k-octet are read before the barrier and multiplied after it, while the first octet's
-    // fragments of the NEXT stage are on their way from LDS.  Built because rocprofv3 --pmc puts the MFMA pipe at 80 % of the SIMD
-    // cycles (2.31 GHz) on the 34 493 x 512 x 8 448 product (tools/pmc_gemm.sh); measured: no gain on any shape of
-    // tools/gemm_shape_probe.py (+-1 %), and the 256 x 256 form with a k-major b spills -- the plain loop stays the default.
+    // The stage loop: the next stage's operand slabs are requested before a stage is multiplied and stored to the other LDS buffer
+    // after it.  Two deeper forms were built on rocprofv3's "MFMA pipe busy 80 % of the SIMD cycles at 2.31 GHz" (tools/pmc_gemm.sh)
+    // and measured out (tools/gemm_shape_probe.py, profiles/r04_gemm_shape_probe_*.log): (a) PIPE (opt-in, FITGNN_GEMM_DEEP=1 on the
+    // small tile shapes) requests the next-but-ONE stage as well (two register sets used alternately: a small tile's stage is 1-2 us of
+    // products per workgroup, about a global load's round trip): 0-10 % SLOWER on every shape (238 -> 253 us on the 165 000 x 512 x 128
+    // table product, 113 -> 125 on 19 717 x 512 x 512); (b) a loop pipelined across its barrier (the last k-octet's fragments read
+    // before it, multiplied after it under the next stage's first LDS reads): +-1 % -- removed.
     auto read_frags = [&](float (&fa)[MI][4], float (&fb)[NJ][4], const float *sa, const float *sb, int kk) {
 #pragma unroll
         for (int i = 0; i < MI; ++i) frag<AKM, G::TI>(fa[i], sa, wm * (32 * MI) + i * 32, kk, lane);
@@ -171,22 +173,25 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(const float *__r
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][st], fb[j][st], acc[i][j], 0, 0, 0);
     };
     constexpr int NKK = kBK / 8;
-    if (!PIPE) {   // the plain loop (default)
+    auto products = [&](int s) {
+        const float *sa = lds_f + (s & 1) * G::STAGE_DW;
+        const float *sb = sa + G::A_DW;
+#pragma unroll
+        for (int kk = 0; kk < NKK; ++kk) {
+            float fa[MI][4], fb[NJ][4];
+            read_frags(fa, fb, sa, sb, kk);
+            multiply(fa, fb);
+        }
+    };
+    if (!PIPE) {
         for (int s = 0; s < nstage; ++s) {
-            const float *sa = lds_f + (s & 1) * G::STAGE_DW;
-            const float *sb = sa + G::A_DW;
-            const bool more = s + 1 < nstage;
+            const bool more = s + 1 < nstage;   // workgroup-uniform
             if (more) {
                 const long k0 = k_begin + (long)(s + 1) * kBK;
                 load_slab<AKM, G::TI, G::NA, G::THREADS>(ra, A, lda, i0, I, k0, k_end);
                 load_slab<BKM, G::TJ, G::NB, G::THREADS>(rb, B, ldb, j0, (long)J, k0, k_end);
             }
-#pragma unroll
-            for (int kk = 0; kk < NKK; ++kk) {
-                float fa[MI][4], fb[NJ][4];
-                read_frags(fa, fb, sa, sb, kk);
-                multiply(fa, fb);
-            }
+            products(s);
             if (more) {
                 float *na = lds_f + ((s + 1) & 1) * G::STAGE_DW;
                 store_slab<AKM, G::TI, G::NA, G::THREADS>(ra, na);
@@ -194,39 +199,31 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(const float *__r
             }
             __syncthreads();
         }
-    }
-    float f0a[MI][4], f0b[NJ][4];   // the first octet of the stage about to be multiplied
-    if (PIPE && nstage > 0) read_frags(f0a, f0b, lds_f, lds_f + G::A_DW, 0);
-    for (int s = 0; PIPE && s < nstage; ++s) {
-        const float *sa = lds_f + (s & 1) * G::STAGE_DW;
-        const float *sb = sa + G::A_DW;
-        const bool more = s + 1 < nstage;   // workgroup-uniform
-        if (more) {
-            const long k0 = k_begin + (long)(s + 1) * kBK;
-            load_slab<AKM, G::TI, G::NA, G::THREADS>(ra, A, lda, i0, I, k0, k_end);
-            load_slab<BKM, G::TJ, G::NB, G::THREADS>(rb, B, ldb, j0, (long)J, k0, k_end);
+    } else {
+        float4 ra2[G::NA], rb2[G::NB];
+        if (nstage > 1) {   // stage 1 on its way while stage 0 is multiplied
+            load_slab<AKM, G::TI, G::NA, G::THREADS>(ra, A, lda, i0, I, k_begin + kBK, k_end);
+            load_slab<BKM, G::TJ, G::NB, G::THREADS>(rb, B, ldb, j0, (long)J, k_begin + kBK, k_end);
         }
-        multiply(f0a, f0b);
-#pragma unroll
-        for (int kk = 1; kk < NKK - 1; ++kk) {
-            float fa[MI][4], fb[NJ][4];
-            read_frags(fa, fb, sa, sb, kk);
-            multiply(fa, fb);
+        // one stage: `cur` holds stage s + 1 (requested a stage ago), `nxt` receives stage s + 2
+        auto body = [&](int s, float4 (&cur_a)[G::NA], float4 (&cur_b)[G::NB], float4 (&nxt_a)[G::NA], float4 (&nxt_b)[G::NB]) {
+            if (s + 2 < nstage) {
+                const long k0 = k_begin + (long)(s + 2) * kBK;
+                load_slab<AKM, G::TI, G::NA, G::THREADS>(nxt_a, A, lda, i0, I, k0, k_end);
+                load_slab<BKM, G::TJ, G::NB, G::THREADS>(nxt_b, B, ldb, j0, (long)J, k0, k_end);
+            }
+            products(s);
+            if (s + 1 < nstage) {
+                float *na = lds_f + ((s + 1) & 1) * G::STAGE_DW;
+                store_slab<AKM, G::TI, G::NA, G::THREADS>(cur_a, na);
+                store_slab<BKM, G::TJ, G::NB, G::THREADS>(cur_b, na + G::A_DW);
+            }
+            __syncthreads();
+        };
+        for (int s = 0; s < nstage; s += 2) {
+            body(s, ra, rb, ra2, rb2);
+            if (s + 1 < nstage) body(s + 1, ra2, rb2, ra, rb);
         }
-        float fla[MI][4], flb[NJ][4];
-        read_frags(fla, flb, sa, sb, NKK - 1);
-        if (more) {
-            float *na = lds_f + ((s + 1) & 1) * G::STAGE_DW;
-            store_slab<AKM, G::TI, G::NA, G::THREADS>(ra, na);
-            store_slab<BKM, G::TJ, G::NB, G::THREADS>(rb, na + G::A_DW);
-        }
-        __syncthreads();
-        if (more) {
-            const float *na = lds_f + ((s + 1) & 1) * G::STAGE_DW;
-            read_frags(f0a, f0b, na, na + G::A_DW, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);   // keep the last octet's products BEHIND the barrier and the reads just issued
-        multiply(fla, flb);
     }
 
     // C/D layout of the 32 x 32 MFMA: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
@@ -397,13 +394,17 @@ int launch_shape(const Plan &p, const float *a, long lda, const float *b, long l
     switch (p.shape) {
         case S256x128: return launch<4, 1, 2, 4, AKM, BKM>(p, a, lda, b, ldb, I, J, K, c, ldc, s);
         case S128:
-            if (getenv("FITGNN_GEMM_PIPE")) return launch<2, 2, 2, 2, AKM, BKM, true>(p, a, lda, b, ldb, I, J, K, c, ldc, s);
-            return launch<2, 2, 2, 2, AKM, BKM>(p, a, lda, b, ldb, I, J, K, c, ldc, s);
+            if (getenv("FITGNN_GEMM_DEEP")) return launch<2, 2, 2, 2, AKM, BKM, true>(p, a, lda, b, ldb, I, J, K, c, ldc, s);
+            return launch<2, 2, 2, 2, AKM, BKM, false>(p, a, lda, b, ldb, I, J, K, c, ldc, s);
         case S64x128:
-            if (getenv("FITGNN_GEMM_PIPE")) return launch<2, 2, 1, 2, AKM, BKM, true>(p, a, lda, b, ldb, I, J, K, c, ldc, s);
-            return launch<2, 2, 1, 2, AKM, BKM>(p, a, lda, b, ldb, I, J, K, c, ldc, s);
-        case S128x64: return launch<4, 1, 1, 2, AKM, BKM>(p, a, lda, b, ldb, I, J, K, c, ldc, s);
-        case S64x64: return launch<2, 2, 1, 1, AKM, BKM>(p, a, lda, b, ldb, I, J, K, c, ldc, s);
+            if (getenv("FITGNN_GEMM_DEEP")) return launch<2, 2, 1, 2, AKM, BKM, true>(p, a, lda, b, ldb, I, J, K, c, ldc, s);
+            return launch<2, 2, 1, 2, AKM, BKM, false>(p, a, lda, b, ldb, I, J, K, c, ldc, s);
+        case S128x64:
+            if (getenv("FITGNN_GEMM_DEEP")) return launch<4, 1, 1, 2, AKM, BKM, true>(p, a, lda, b, ldb, I, J, K, c, ldc, s);
+            return launch<4, 1, 1, 2, AKM, BKM, false>(p, a, lda, b, ldb, I, J, K, c, ldc, s);
+        case S64x64:
+            if (getenv("FITGNN_GEMM_DEEP")) return launch<2, 2, 1, 1, AKM, BKM, true>(p, a, lda, b, ldb, I, J, K, c, ldc, s);
+            return launch<2, 2, 1, 1, AKM, BKM, false>(p, a, lda, b, ldb, I, J, K, c, ldc, s);
         default: return launch<4, 2, 2, 4, AKM, BKM>(p, a, lda, b, ldb, I, J, K, c, ldc, s);
     }
 }

@@ -30,10 +30,10 @@ for form, I, J, K in shapes:
     os.environ.pop("FITGNN_GEMM_SHAPE", None)
     us = bench(lambda: ops.gemm_exact(a, b, form))
     line = [f"default {us:8.1f} us {flops / us / 1e6:6.1f} TF"]
-    os.environ["FITGNN_GEMM_PIPE"] = "1"   # the 128 x 128 / 64 x 128 shapes with the software-pipelined stage loop
+    os.environ["FITGNN_GEMM_DEEP"] = "1"   # the small shapes with a two-stage look-ahead (measured slower: opt-in)
     us = bench(lambda: ops.gemm_exact(a, b, form))
-    os.environ.pop("FITGNN_GEMM_PIPE", None)
-    line.append(f"default, pipelined loop {us:8.1f} us {flops / us / 1e6:6.1f} TF")
+    os.environ.pop("FITGNN_GEMM_DEEP", None)
+    line.append(f"default, two-stage look-ahead {us:8.1f} us {flops / us / 1e6:6.1f} TF")
     for sh in ("0", "3", "4", "6"):
         os.environ["FITGNN_GEMM_SHAPE"] = sh
         us = bench(lambda: ops.gemm_exact(a, b, form))
