@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- edges aggregated/sec (GCN fwd+bwd) on coarsened subgraphs (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload S-products]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload S-products] [--layer GCNConv] [--shard K/N]
 
 Workload (config.workload), default S-products = BASELINE.json configs[3], the north_star target: "ogbn-products
 use_community_detection, subgraph-batch DP" on synthetic data of that shape: one community graph of
@@ -11,7 +11,11 @@ subgraph per cluster (82.5 k subgraphs, 8.2 M union rows), all loader batches me
 block-diagonal CSR.  A step = one GD training epoch of run.py:177-215: forward over every subgraph (2-layer GCN,
 hidden 512), one NLL loss, backward, Adam step (4 SpMM products over all nnz' entries: edges aggregated = 4 * nnz'; the two
 backward products run as ONE two-hop launch).  The other configs
-(--workload S-pubmed | S-physics | S-cora) are parity-test cases, selectable for A/B work.
+(--workload S-pubmed | S-physics | S-cora) are parity-test cases, selectable for A/B work; --workload S-qm9 is BASELINE.json
+configs[4] (graph regression over 130 831 molecules: a step = one training epoch of 512 captured batch steps, bench_qm9 below);
+--layer GATConv | APPNP times the same step with the other operators north_star names (per-kind rooflines of their own kernels).
+--shard K/N steps ONE rank of an N-rank job alone on this GPU, the gradient all-reduce over RCCL in a group of one: the scaling
+evidence a single MI355X can give (tools/shard_curve.py).
 
 N>1 = data parallel, STRONG scaling: the ONE union is sharded by whole subgraphs (data.shard_clusters: LPT over
 nnz'), every rank steps on its shard, one flat RCCL gradient all-reduce per step (train.GDTrainer).  Launch either
@@ -20,9 +24,11 @@ the parent then spawns N fresh children itself BEFORE it touches torch or the GP
 
 Prints ONE JSON line (rank 0): the metric (dense products in the reference's fp32 arithmetic: csrc/gemm_f32.hip), `roofline` for
 the SpMM kernel over ALL FOUR products of the step (HIP events around each launch inside the timed region; per-launch entries
-with the number of products they carry and their own compulsory bytes), `ms_per_step_bf16x3` (the same step with the dense products as a 3 x bf16 split: secondary),
-at N>1 `allreduce_ms` and the ranks' nnz', and at N=1 `cpu_baseline` (the torch-CPU oracle of the same step + the C oracle of the
-contraction, on this host).
+with the number of products they carry and their own compulsory bytes; `traffic` = HBM bytes per product from the committed PMC
+passes; `copy_ceiling_GBps` = the library's own stream-copy kernel in this process), `ms_per_step_bf16x3` (the same step with the
+dense products as a 3 x bf16 split: secondary), `ms_per_step_pruned` / `value_pruned` (the last layer's forward aggregation on the loss
+rows alone: fewer edges, its own count: secondary), at N>1 `allreduce_ms` and the ranks' nnz', and at N=1 `cpu_baseline` (the torch-CPU
+oracle of the same step on an evenly spaced sample of loader batches + the C oracle of the contraction, on this host).
 """
 import argparse
 import json

@@ -223,6 +223,13 @@ def test_device_eigensolver_feeds_the_contraction(mods):
     Cc = sp.csc_matrix(C)
     assert np.all(np.diff(Cc.indptr) == 1) and Cc.shape[0] == int(np.ceil(0.5 * g.N))
     assert np.allclose(np.asarray(Cc.power(2).sum(1)).ravel(), 1.0)
+    # more than 16 eigenpairs: the rotation kernel takes 16 columns per launch, the solver rotates in groups (K > 16
+    # used to fail in the final rotation, after the whole solve)
+    lk20, Uk20 = co.lanczos_smallest(Gr.L, 20)
+    ref20 = np.sort(np.linalg.eigvalsh(Gr.L.toarray()))[:20]
+    assert lk20.shape == (20,) and Uk20.shape == (g.N, 20)
+    assert np.abs(lk20 - ref20).max() < 1e-4 * offset
+    assert np.abs(Gr.L @ Uk20 - Uk20 * lk20).max() < 1e-3 * offset and np.abs(Uk20.T @ Uk20 - np.eye(20)).max() < 1e-8
 
 
 def test_pipeline_batched_components_equal_per_component_loop(mods):
