@@ -74,6 +74,9 @@ def parse_args():
                     help="A/B: layer 0 on the de-duplicated table through the LDS-window SpMM (row indirection) instead of the "
                          "direct-gather variant")
     ap.add_argument("--stream-kernel", action="store_true", help="A/B: the segment-streaming kernel (one wave per run of segments, no LDS) instead of the whole-subgraph kernel")
+    ap.add_argument("--round3-graph-step", action="store_true",
+                    help="A/B (S-qm9): the batch step as round 3 had it -- first layer transform-first (its two SpMMs per step), pool / scale / "
+                         "library product / bias add for the head, `grad += new` per tensor, loss.backward() from a ones fill")
     ap.add_argument("--no-two-hop", action="store_true", help="A/B: the two backward SpMM products as two launches (dZ written and re-read)")
     ap.add_argument("--no-compact-rows", action="store_true", help="A/B: the compact backward operand through the tile / whole-subgraph kernels")
     ap.add_argument("--gemm-precision", default="exact", choices=["exact", "high", "highest"],
@@ -659,9 +662,11 @@ def bench_qm9(args, device, world, rank, backend):
     margs = argparse.Namespace(num_layers1=2, layer_name="GCNConv", num_features=11, hidden=H, num_classes=1, dropout=args.dropout)
     torch.manual_seed(2)
     model = network.Regress_graph_gs(margs).to(device)
-    cfg = ops.OpConfig(gemm_precision=args.gemm_precision)
+    lean = not args.round3_graph_step
+    cfg = ops.OpConfig(gemm_precision=args.gemm_precision, narrow_input_first=lean, fused_pool_head=lean)
     model.set_op_config(cfg)
-    tr = train.GraphTrainer(model, gset, graphs, kind="gs", batch_size=128, lr=0.001, capture=(world == 1))
+    tr = train.GraphTrainer(model, gset, graphs, kind="gs", batch_size=128, lr=0.001, capture=(world == 1), lean_step=lean)
+    cfg_step = model.op_config   # (the trainer's copy: + its gradient sink)
     torch.cuda.synchronize()
     t3 = time.time()
     rows = sum(int(b["x"].shape[0]) for b in tr.batches if b is not None)
@@ -692,7 +697,7 @@ def bench_qm9(args, device, world, rank, backend):
     launches, achieved = [], float("nan")
     if world == 1:
         import types
-        ev_cfg = cfg.replace(profile=[])
+        ev_cfg = cfg.replace(profile=[])   # (no gradient sink: these passes run outside the trainer)
         model.set_op_config(ev_cfg)
         model.train()
         k_ev = min(16, n_batches)
@@ -700,7 +705,7 @@ def bench_qm9(args, device, world, rank, backend):
             out_b = model(b, b["graph_of_masked"])
             out_b.sum().backward()
         torch.cuda.synchronize()
-        model.set_op_config(cfg)
+        model.set_op_config(cfg_step)
         tr.flat.zero()
         per_kind = {}
         for a, b_, kind in ev_cfg.profile:
@@ -713,16 +718,23 @@ def bench_qm9(args, device, world, rank, backend):
                              "frac": bytes_spmm / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS})
         sum_ms = sum(l["avg_us"] * l["launches_per_batch_step"] for l in launches) * 1e-3
         achieved = sum(l["algorithmic_bytes"] * l["launches_per_batch_step"] for l in launches) / max(sum_ms * 1e-3, 1e-12) / 1e9
+    # SpMM products a batch step really runs: 4 transform-first; 2 with the first layer on the aggregated input (A_hat x of the 11 atom
+    # features is formed once per batch, outside the timed region, and that layer's backward needs no aggregation: x takes no gradient)
+    products = round(sum(l["launches_per_batch_step"] for l in launches)) if launches else (2 if lean else 4)
     out = {
         "metric": "edges aggregated/sec (GCN fwd+bwd) on coarsened subgraphs",
-        "value": 4.0 * nnz_total * args.steps / dt, "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "value": float(products) * nnz_total * args.steps / dt, "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic",
+        "spmm_products_per_batch_step": products,
+        "value_at_the_reference_product_count": 4.0 * nnz_total * args.steps / dt,
         "graphs_per_s": len(graphs) * args.steps / dt, "batch_steps_per_epoch": n_batches, "us_per_batch_step": dt / args.steps / n_batches * 1e6,
         "config": {"workload": "S-qm9: 130 831 molecules (~18 nodes), variation_neighborhoods r=0.5 per molecule in one batched contraction, "
                                f"extra-node cluster subgraphs; Regress_graph_gs (2-layer GCN hidden {H}, mean pool of the masked rows, lt1), "
                                "a step = one training epoch over the 65 415 training graphs in batches of 128 (forward, L1 loss, backward, "
-                               "Adam per batch; gradients accumulate inside the epoch as in run.py:291), every batch step replayed from a hipGraph",
+                               "Adam per batch; gradients accumulate inside the epoch as in run.py:291), every batch step replayed from a hipGraph"
+                               + ("; first layer aggregate-first on A_hat x (formed once per batch), pool + head in one launch each way, weight "
+                                  "gradients written where the optimiser kernel reads them" if lean else "; round 3's batch step (A/B)"),
                    "parallelism": f"dp{world}", "backend": backend, "graphs": n_graphs, "training_graphs": len(graphs),
                    "union_rows_per_epoch": int(rows_total), "nnz_prime_per_epoch": int(nnz_total), "dropout_p": args.dropout,
                    "captured": bool(tr.capture), "t_molecules_s": round(t1 - t0, 2), "t_coarsen_pool_assemble_s": round(t2 - t1, 2),

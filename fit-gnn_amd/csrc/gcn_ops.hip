@@ -229,9 +229,11 @@ __global__ __launch_bounds__(256) void epilogue_bwd_kernel(const float *__restri
 // n_chunks / 64 partials (a thread's loads are a serial chain of L2 round trips: keep it short), then a fixed
 // binary tree over the 64 phases in LDS.
 constexpr int kColsumPhases = 64, kColsumCols = 16;
+// db2 / split (optional): columns >= split go to db2[h - split] (two destinations for one reduction: fitgnn_narrow_atb_f32's dW | db)
 __global__ __launch_bounds__(kColsumPhases * kColsumCols) void colsum_partials_kernel(const float *__restrict__ partial,
                                                                                       int32_t n_chunks, int32_t H,
-                                                                                      float *__restrict__ db) {
+                                                                                      float *__restrict__ db, float *__restrict__ db2 = nullptr,
+                                                                                      int32_t split = 0) {
     __shared__ float red[kColsumPhases][kColsumCols];
     const int cl = threadIdx.x % kColsumCols, ph = threadIdx.x / kColsumCols;
     const int h = blockIdx.x * kColsumCols + cl;
@@ -246,7 +248,10 @@ __global__ __launch_bounds__(kColsumPhases * kColsumCols) void colsum_partials_k
         if (ph < w) red[ph][cl] = red[ph][cl] + red[ph + w][cl];
         __syncthreads();
     }
-    if (ph == 0 && h < H) db[h] = red[0][cl];
+    if (ph == 0 && h < H) {
+        if (db2 && h >= split) db2[h - split] = red[0][cl];
+        else db[h] = red[0][cl];
+    }
 }
 
 // out[w] = sum_b part[b][w], partials combined in a fixed tree: four interleaved running sums, then (s0+s1)+(s2+s3)
@@ -332,6 +337,51 @@ __global__ __launch_bounds__(256) void adam_flat_kernel(float4 *__restrict__ p, 
 }
 __global__ void adam_step_advance_kernel(float *step) { *step += 1.0f; }
 
+// The same update for a step whose backward wrote its weight gradients into a buffer of their own (g_new, laid out like the accumulated
+// buffer g_acc: ops.GradSink) instead of adding them to g_acc tensor by tensor: the gradient used is g_acc + g_new and it is stored
+// back to g_acc (run.py:254-304 never clears the gradients inside an epoch, so they accumulate over the batch steps), g_new is cleared -- the six to
+// eight `grad += new` launches of a step fold into this one.  The LAST workgroup to finish (a ticket counter next to the step
+// count: state[1], left at zero) advances the step count and, when given, the dropout seeds of the next captured step (every
+// workgroup has read the count by the time it takes its ticket): no separate one-thread launches.
+__global__ __launch_bounds__(256) void adam_flat_acc_kernel(float4 *__restrict__ p, float4 *__restrict__ g_acc, float4 *__restrict__ g_new,
+                                                            float4 *__restrict__ m, float4 *__restrict__ v, int64_t n4, float lr, float b1,
+                                                            float b2, float eps, float wd, float *__restrict__ state,
+                                                            unsigned long long *__restrict__ seeds, int32_t n_seeds,
+                                                            unsigned long long seed_stride) {
+    const float t = state[0] + 1.0f;
+    const float bc1 = 1.0f - powf(b1, t), bc2s = sqrtf(1.0f - powf(b2, t));
+    const float step_size = lr / bc1;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n4) {
+        float4 pp = p[i], gg = g_acc[i], mm = m[i], vv = v[i];
+        if (g_new) {
+            const float4 gn = g_new[i];
+            gg.x += gn.x; gg.y += gn.y; gg.z += gn.z; gg.w += gn.w;
+            g_acc[i] = gg;
+            g_new[i] = make_float4(0.f, 0.f, 0.f, 0.f);   // consumed: a step whose backward writes only some slices adds nothing stale
+        }
+        float *pa = &pp.x, *ga = &gg.x, *ma = &mm.x, *va = &vv.x;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float gk = ga[k] + wd * pa[k];
+            ma[k] = b1 * ma[k] + (1.0f - b1) * gk;
+            va[k] = b2 * va[k] + (1.0f - b2) * gk * gk;
+            pa[k] -= step_size * ma[k] / (sqrtf(va[k]) / bc2s + eps);
+        }
+        p[i] = pp; m[i] = mm; v[i] = vv;
+    }
+    __syncthreads();   // every thread of the workgroup has read state[0]
+    if (threadIdx.x == 0) {
+        unsigned *ticket = reinterpret_cast<unsigned *>(state + 1);
+        __threadfence();
+        if (atomicAdd(ticket, 1u) == gridDim.x - 1) {
+            state[0] = t;
+            *ticket = 0u;
+            for (int q = 0; q < n_seeds; ++q) seeds[q] += seed_stride;
+        }
+    }
+}
+
 // NLLLoss(log_softmax(z)[idx], labels) (network.py:35 + run.py:341) and its gradient in one pass over the selected rows:
 //   part[block] = sum over the block's rows of (logsumexp(z_r) - z_r[label]) * scale,  dz[r] = (softmax(z_r) - onehot) * scale
 // dz is zero elsewhere (cleared by the launcher).  One thread per selected row; fixed-order block and grid reductions.
@@ -410,6 +460,174 @@ __global__ __launch_bounds__(256) void epilogue_fwd_rows_kernel(float *__restric
             x[e] = y;
         }
         *reinterpret_cast<float4 *>(z + i * ldz + col0) = make_float4(x[0], x[1], x[2], x[3]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// a layer's dense part on a FEW input columns: out = dropout(ELU(a W^T + b)),  a [n x K], K <= 32
+// ------------------------------------------------------------------------------------------------
+// GCNConv on an input with fewer columns than the layer is wide (QM9: 11 atom features -> hidden 512, network.py:189-204)
+// is evaluated aggregate-first, (A_hat x) W^T: A_hat x has K columns, and since neither the graph nor the input features
+// change between steps it is formed ONCE per batch (ops.FusedGCNLayerAggregatedInput) -- what is left of the layer per step is
+// this pass: a K-term dot product per output element and the SpMM kernels' store epilogue (spmm.hip finish_row: same flags,
+// same arithmetic, the dropout hash / mask entry of (row, column)).  A [n x K] @ [K x H] product with K = 11 is a pass over the
+// OUTPUT, not a GEMM: W^T sits in LDS as [K][H] for the block's lifetime, a block takes kNarrowKRows rows of `a` at a time,
+// a thread owns four consecutive output columns of one row (ds_read_b128 of W^T, the row's value a broadcast) and adds the
+// K products in ascending k.
+constexpr int kNarrowKMax = 32;
+constexpr int kNarrowKRows = 16;
+__global__ __launch_bounds__(256) void dense_narrow_k_kernel(const float *__restrict__ a, int64_t lda, const float *__restrict__ W,
+                                                             int64_t ldw, int32_t n, int32_t K, int32_t H,
+                                                             const float *__restrict__ bias, uint32_t epi, float p_drop,
+                                                             uint64_t seed_arg, const uint8_t *__restrict__ mask,
+                                                             float *__restrict__ out, int64_t ldo, int32_t rows_per_block) {
+    extern __shared__ __attribute__((aligned(16))) float nk_lds[];
+    float *s_w = nk_lds;                    // [K][H]: W^T
+    float *s_a = nk_lds + (size_t)K * H;    // [kNarrowKRows][K]
+    const uint64_t seed = fitgnn::resolve_seed(seed_arg, epi);
+    const float keep_scale = (epi & FITGNN_EPI_DROPOUT) ? 1.0f / (1.0f - p_drop) : 1.0f;
+    const uint32_t thresh = fitgnn::dropout_threshold(p_drop);
+    const int H4 = H >> 2;
+    // W^T into LDS: the global reads walk W as it lies (coalesced, eight in flight per thread); the transposing stores collide on
+    // banks (stride H), which costs cycles, not memory round trips
+    {
+        const int total = K * H;
+        for (int i0 = threadIdx.x; i0 < total; i0 += 256 * 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + u * 256;
+                const int j = i / K, k = i - j * K;
+                v[u] = i < total ? W[(int64_t)j * ldw + k] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + u * 256;
+                const int j = i / K, k = i - j * K;
+                if (i < total) s_w[k * H + j] = v[u];
+            }
+        }
+    }
+    const int rb = blockIdx.x * rows_per_block;
+    const int re = min(n, rb + rows_per_block);
+    for (int r0 = rb; r0 < re; r0 += kNarrowKRows) {
+        const int rows = min(kNarrowKRows, re - r0);
+        __syncthreads();   // W^T staged (first pass) / the previous chunk's rows consumed
+        for (int i = threadIdx.x; i < rows * K; i += 256) {
+            const int r = i / K, k = i - r * K;
+            s_a[i] = a[(int64_t)(r0 + r) * lda + k];
+        }
+        __syncthreads();
+        for (int it = threadIdx.x; it < rows * H4; it += 256) {
+            const int r = it / H4;
+            const int col0 = (it - r * H4) * 4;
+            float x[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int k = 0; k < K; ++k) {
+                const float av = s_a[r * K + k];
+                const float4 w = *reinterpret_cast<const float4 *>(s_w + k * H + col0);
+                x[0] = fmaf(av, w.x, x[0]); x[1] = fmaf(av, w.y, x[1]); x[2] = fmaf(av, w.z, x[2]); x[3] = fmaf(av, w.w, x[3]);
+            }
+            const int64_t orow = r0 + r;
+            const uint64_t idx0 = (uint64_t)orow * (uint64_t)H + (uint64_t)col0;
+            uint64_t bits = 0;
+            if ((epi & FITGNN_EPI_DROPOUT) && !mask) bits = fitgnn::dropout_bits(seed, idx0 >> 2);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float y = x[e] + ((epi & FITGNN_EPI_BIAS) ? bias[col0 + e] : 0.f);
+                if (epi & FITGNN_EPI_ELU) y = y > 0.f ? y : __expf(y) - 1.0f;
+                if (epi & FITGNN_EPI_DROPOUT) {
+                    const bool keep = mask ? (mask[idx0 + e] != 0) : fitgnn::dropout_keep(bits, (int)((idx0 + e) & 3), thresh);
+                    y = keep ? y * keep_scale : 0.f;
+                }
+                x[e] = y;
+            }
+            *reinterpret_cast<float4 *>(out + orow * ldo + col0) = make_float4(x[0], x[1], x[2], x[3]);
+        }
+    }
+}
+
+// ... and its backward: dW[j][k] = sum_r dZ[r][j] a[r][k]  ([H x K]) and db[j] = sum_r dZ[r][j] in ONE pass over the incoming
+// gradient.  With `prev` (the layer's output o = dropout(ELU(z))) the input is the gradient w.r.t. o and dZ is formed in registers
+// (epilogue_bwd_kernel's arithmetic, the forward's flags / seed / mask) -- it is never written: the layer's input needs no
+// gradient.  A block takes a range of rows; a thread owns four columns j of every PH-th row of the range (PH = 256 / (H / 4) row
+// phases) and keeps its 4 x K + 4 sums in registers; the rows' a values come from LDS as broadcasts.  Per (block, phase) one
+// partial row [H x K | H], reduced in a fixed order by colsum_partials_kernel.
+constexpr int kNarrowAtbRows = 16;   // rows per block
+template <int KT>
+__global__ __launch_bounds__(256) void narrow_atb_kernel(const float *__restrict__ dZ, int64_t ldz, const float *__restrict__ prev,
+                                                         uint32_t epi, float p_drop, uint64_t seed_arg, const uint8_t *__restrict__ mask,
+                                                         const float *__restrict__ a, int64_t lda, int32_t n, int32_t K, int32_t H,
+                                                         float *__restrict__ partial) {
+    __shared__ float s_a[kNarrowAtbRows * KT];
+    const uint64_t seed = fitgnn::resolve_seed(seed_arg, epi);
+    const float keep_scale = (epi & FITGNN_EPI_DROPOUT) ? 1.0f / (1.0f - p_drop) : 1.0f;
+    const float unscale = (epi & FITGNN_EPI_DROPOUT) ? 1.0f - p_drop : 1.0f;
+    const uint32_t thresh = fitgnn::dropout_threshold(p_drop);
+    const int H4 = H >> 2, PH = 256 / H4;
+    const int cg = threadIdx.x % H4, ph = threadIdx.x / H4;
+    const int r0 = blockIdx.x * kNarrowAtbRows;
+    const int rows = min(kNarrowAtbRows, n - r0);
+    for (int i = threadIdx.x; i < kNarrowAtbRows * KT; i += 256) {
+        const int r = i / KT, k = i - r * KT;
+        s_a[i] = (r < rows && k < K) ? a[(int64_t)(r0 + r) * lda + k] : 0.f;
+    }
+    __syncthreads();
+    float acc[4][KT], bsum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int k = 0; k < KT; ++k) acc[e][k] = 0.f;
+    constexpr int U = 4;   // rows in flight per thread: every load of a group is issued before the first use
+    for (int rg = ph; rg < rows; rg += PH * U) {
+        float4 dv[U], ov[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t row = r0 + min(rg + u * PH, rows - 1);   // clamped: loaded again, never used
+            dv[u] = *reinterpret_cast<const float4 *>(dZ + row * ldz + 4 * cg);
+            ov[u] = prev ? *reinterpret_cast<const float4 *>(prev + row * (int64_t)H + 4 * cg) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int r = rg + u * PH;
+            if (r >= rows) break;
+            const int64_t row = r0 + r;
+            float d[4] = {dv[u].x, dv[u].y, dv[u].z, dv[u].w};
+            if (prev) {
+                const float o[4] = {ov[u].x, ov[u].y, ov[u].z, ov[u].w};
+                const uint64_t idx0 = (uint64_t)row * (uint64_t)H + (uint64_t)(4 * cg);
+                uint64_t bits = 0;
+                if ((epi & FITGNN_EPI_DROPOUT) && !mask) bits = fitgnn::dropout_bits(seed, idx0 >> 2);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float g = d[e];
+                    if (epi & FITGNN_EPI_DROPOUT) {
+                        const bool keep = mask ? (mask[idx0 + e] != 0) : fitgnn::dropout_keep(bits, (int)((idx0 + e) & 3), thresh);
+                        g = keep ? g * keep_scale : 0.f;
+                    }
+                    if (epi & FITGNN_EPI_ELU) {
+                        const float ev = o[e] * unscale;
+                        g = ev > 0.f ? g : g * (ev + 1.0f);
+                    }
+                    d[e] = g;
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bsum[e] += d[e];
+#pragma unroll
+            for (int k = 0; k < KT; ++k) {
+                const float av = s_a[r * KT + k];
+                acc[0][k] = fmaf(d[0], av, acc[0][k]); acc[1][k] = fmaf(d[1], av, acc[1][k]);
+                acc[2][k] = fmaf(d[2], av, acc[2][k]); acc[3][k] = fmaf(d[3], av, acc[3][k]);
+            }
+        }
+    }
+    float *dst = partial + ((int64_t)blockIdx.x * PH + ph) * ((int64_t)H * K + H);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+#pragma unroll
+        for (int k = 0; k < KT; ++k)
+            if (k < K) dst[(int64_t)(4 * cg + e) * K + k] = acc[e][k];
+        dst[(int64_t)H * K + 4 * cg + e] = bsum[e];
     }
 }
 
@@ -542,6 +760,22 @@ extern "C" int fitgnn_adam_step_f32(float *param, const float *grad, float *exp_
     hipLaunchKernelGGL(adam_flat_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, (float4 *)param, (const float4 *)grad,
                        (float4 *)exp_avg, (float4 *)exp_avg_sq, n4, lr, beta1, beta2, eps, weight_decay, step);
     hipLaunchKernelGGL(adam_step_advance_kernel, dim3(1), dim3(1), 0, s, step);
+    return (int)hipGetLastError();
+}
+
+extern "C" int fitgnn_adam_step_acc_f32(float *param, float *grad_acc, float *grad_new, float *exp_avg, float *exp_avg_sq, int64_t n,
+                                        float lr, float beta1, float beta2, float eps, float weight_decay, float *state, uint64_t *seeds,
+                                        int32_t n_seeds, uint64_t seed_stride, void *stream) {
+    if (n < 0 || (n % 4) != 0 || n_seeds < 0) return FITGNN_E_BADARG;
+    if (n == 0) return 0;
+    if (!param || !grad_acc || !exp_avg || !exp_avg_sq || !state || (n_seeds > 0 && !seeds)) return FITGNN_E_BADARG;
+    if ((((uintptr_t)param | (uintptr_t)grad_acc | (uintptr_t)grad_new | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) % 16) != 0 ||
+        ((uintptr_t)state % 4) != 0)
+        return FITGNN_E_ALIGN;
+    const int64_t n4 = n / 4;
+    hipLaunchKernelGGL(adam_flat_acc_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (float4 *)param,
+                       (float4 *)grad_acc, (float4 *)grad_new, (float4 *)exp_avg, (float4 *)exp_avg_sq, n4, lr, beta1, beta2, eps,
+                       weight_decay, state, (unsigned long long *)seeds, n_seeds, (unsigned long long)seed_stride);
     return (int)hipGetLastError();
 }
 
@@ -718,6 +952,61 @@ extern "C" int fitgnn_epilogue_fwd_rows_f32(float *z, int64_t ldz, const int64_t
     const int blocks = (int)std::min<int64_t>((total + 255) / 256, 256 * 16);
     hipLaunchKernelGGL(epilogue_fwd_rows_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, z, ldz, rows, n, H, bias, epilogue, p_drop,
                        seed, mask);
+    return (int)hipGetLastError();
+}
+
+extern "C" size_t fitgnn_dense_narrow_k_lds_bytes(int32_t K, int32_t H) {
+    if (K < 1 || K > kNarrowKMax || H < 4 || (H % 4) != 0) return 0;
+    const size_t b = ((size_t)K * (size_t)H + (size_t)kNarrowKRows * (size_t)K) * sizeof(float);
+    return b <= 64 * 1024 ? b : 0;
+}
+
+extern "C" int fitgnn_dense_narrow_k_f32(const float *a, int64_t lda, const float *W, int64_t ldw, int32_t n, int32_t K, int32_t H,
+                                         const float *bias, uint32_t epilogue, float p_drop, uint64_t seed, const uint8_t *mask,
+                                         float *out, int64_t ldo, void *stream) {
+    if (n < 0 || lda < K || ldw < K || ldo < H || (ldo % 4) != 0) return FITGNN_E_BADARG;
+    const size_t lds = fitgnn_dense_narrow_k_lds_bytes(K, H);
+    if (lds == 0) return FITGNN_E_BADARG;
+    if (n == 0) return 0;
+    if (!a || !W || !out) return FITGNN_E_BADARG;
+    if ((epilogue & FITGNN_EPI_BIAS) && !bias) return FITGNN_E_BADARG;
+    if ((epilogue & FITGNN_EPI_DROPOUT) && !(p_drop >= 0.f && p_drop < 1.f)) return FITGNN_E_BADARG;
+    if (((uintptr_t)out % 16) != 0) return FITGNN_E_ALIGN;
+    // one range of rows per block, about a block per CU: W^T is staged once per block
+    int rows_per_block = std::max((n + 255) / 256, 8);
+    const int blocks = (n + rows_per_block - 1) / rows_per_block;
+    hipLaunchKernelGGL(dense_narrow_k_kernel, dim3(blocks), dim3(256), lds, (hipStream_t)stream, a, lda, W, ldw, n, K, H, bias, epilogue,
+                       p_drop, seed, mask, out, ldo, rows_per_block);
+    return (int)hipGetLastError();
+}
+
+// H / 4 must divide 256 (a block's threads = whole row phases): hidden widths 16 ... 1024 in powers of two
+extern "C" size_t fitgnn_narrow_atb_workspace_bytes(int32_t n, int32_t K, int32_t H) {
+    if (n <= 0 || K < 1 || K > kNarrowKMax || H < 4 || (H % 4) != 0 || (H / 4) > 256 || (256 % (H / 4)) != 0) return 0;
+    const size_t blocks = ((size_t)n + kNarrowAtbRows - 1) / kNarrowAtbRows;
+    return blocks * (size_t)(256 / (H / 4)) * ((size_t)H * (size_t)K + (size_t)H) * sizeof(float);
+}
+
+extern "C" int fitgnn_narrow_atb_f32(const float *d, int64_t ldd, const float *prev, uint32_t epilogue, float p_drop, uint64_t seed,
+                                     const uint8_t *mask, const float *a, int64_t lda, int32_t n, int32_t K, int32_t H, float *dW, float *db,
+                                     void *work, size_t work_bytes, void *stream) {
+    if (n <= 0 || ldd < H || (ldd % 4) != 0 || lda < K) return FITGNN_E_BADARG;
+    const size_t need = fitgnn_narrow_atb_workspace_bytes(n, K, H);
+    if (need == 0) return FITGNN_E_BADARG;
+    if (!d || !a || !dW || !db) return FITGNN_E_BADARG;
+    if ((epilogue & FITGNN_EPI_DROPOUT) && !(p_drop >= 0.f && p_drop < 1.f)) return FITGNN_E_BADARG;
+    if (!work || work_bytes < need) return FITGNN_E_WORKSPACE;
+    if ((((uintptr_t)d | (uintptr_t)prev) % 16) != 0) return FITGNN_E_ALIGN;
+    hipStream_t s = (hipStream_t)stream;
+    const int blocks = (n + kNarrowAtbRows - 1) / kNarrowAtbRows;
+    const int parts = blocks * (256 / (H / 4));
+    const int width = H * K + H;
+    float *partial = (float *)work;
+    if (K <= 8) hipLaunchKernelGGL(narrow_atb_kernel<8>, dim3(blocks), dim3(256), 0, s, d, ldd, prev, epilogue, p_drop, seed, mask, a, lda, n, K, H, partial);
+    else if (K <= 16) hipLaunchKernelGGL(narrow_atb_kernel<16>, dim3(blocks), dim3(256), 0, s, d, ldd, prev, epilogue, p_drop, seed, mask, a, lda, n, K, H, partial);
+    else hipLaunchKernelGGL(narrow_atb_kernel<32>, dim3(blocks), dim3(256), 0, s, d, ldd, prev, epilogue, p_drop, seed, mask, a, lda, n, K, H, partial);
+    hipLaunchKernelGGL(colsum_partials_kernel, dim3((width + kColsumCols - 1) / kColsumCols), dim3(kColsumPhases * kColsumCols), 0, s, partial,
+                       parts, width, dW, db, H * K);
     return (int)hipGetLastError();
 }
 

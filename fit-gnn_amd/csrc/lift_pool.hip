@@ -455,6 +455,107 @@ __global__ __launch_bounds__(256) void segment_expand_kernel(const float *__rest
     dst[t] = v;
 }
 
+// Mean pool over row subsets + a narrow head in ONE launch (Regress_graph_gs / _gc: lt1(global_mean_pool(x[mask])), network.py:164-166,
+// :200-204 -- on a 128-graph batch four launches of a few microseconds each: gather-and-sum, 1 / count, a [128 x 512] @ [512 x 1]
+// library product, the bias).  One workgroup per graph: its 256 threads are PH = 256 / (F / 4) row phases x F / 4 column groups; a
+// phase sums every PH-th member row (four rows in flight), the phases are added in ascending order through LDS, phase 0 scales by
+// 1 / count, stores the pooled row (the backward's operand) and reduces the C dot products with the head's rows by a fixed tree.
+constexpr int kPoolHeadMaxC = 8;
+__global__ __launch_bounds__(256) void pool_head_kernel(const int32_t *__restrict__ off, const int32_t *__restrict__ members,
+                                                        const float *__restrict__ X, int64_t ldx, int32_t F,
+                                                        const float *__restrict__ inv_cnt, const float *__restrict__ W,
+                                                        const float *__restrict__ b, int32_t C, float *__restrict__ pooled,
+                                                        float *__restrict__ y) {
+    __shared__ float4 s_red[256];
+    __shared__ float s_dot[256];
+    const int sgm = blockIdx.x;
+    const int F4 = F >> 2, PH = 256 / F4;
+    const int cg = threadIdx.x % F4, ph = threadIdx.x / F4;
+    const int m0 = off[sgm], m1 = off[sgm + 1];
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int base = m0 + ph; base < m1; base += 4 * PH) {
+        int node[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) node[u] = members[min(base + u * PH, m1 - 1)];
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4 *>(X + (int64_t)node[u] * ldx + 4 * cg);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (base + u * PH < m1) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+    }
+    s_red[threadIdx.x] = acc;
+    __syncthreads();
+    float4 tot = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ph == 0) {
+        for (int q = 0; q < PH; ++q) {
+            const float4 t = s_red[q * F4 + cg];
+            tot.x += t.x; tot.y += t.y; tot.z += t.z; tot.w += t.w;
+        }
+        const float w = inv_cnt[sgm];
+        tot.x *= w; tot.y *= w; tot.z *= w; tot.w *= w;
+        *reinterpret_cast<float4 *>(pooled + (int64_t)sgm * F + 4 * cg) = tot;
+    }
+    for (int c = 0; c < C; ++c) {
+        __syncthreads();
+        if (ph == 0) {
+            const float4 wv = *reinterpret_cast<const float4 *>(W + (int64_t)c * F + 4 * cg);
+            s_dot[cg] = fmaf(tot.w, wv.w, fmaf(tot.z, wv.z, fmaf(tot.y, wv.y, tot.x * wv.x)));
+        }
+        __syncthreads();
+        for (int w2 = F4 >> 1; w2 >= 1; w2 >>= 1) {
+            if ((int)threadIdx.x < w2) s_dot[threadIdx.x] += s_dot[threadIdx.x + w2];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) y[(int64_t)sgm * C + c] = s_dot[0] + (b ? b[c] : 0.f);
+    }
+}
+
+// ... and its backward in one launch: blocks [0, nb_dx) write every row of dx (dx[r] = (1 / count) sum_c dy[s][c] W[c] for a pooled row
+// of graph s, zeros for the others); the blocks after them form dW[c][f] = sum_s dy[s][c] pooled[s][f] and db[c] = sum_s dy[s][c]
+// (ascending s: reproducible).
+__global__ __launch_bounds__(256) void pool_head_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ W, int32_t C,
+                                                            const float *__restrict__ pooled, const int32_t *__restrict__ seg_of_row,
+                                                            const float *__restrict__ inv_cnt, int64_t n_rows, int32_t n_seg, int32_t F,
+                                                            int32_t nb_dx, float4 *__restrict__ dx, float *__restrict__ dW,
+                                                            float *__restrict__ db) {
+    const int F4 = F >> 2;
+    if ((int)blockIdx.x < nb_dx) {
+        const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+        if (t >= n_rows * F4) return;
+        const int64_t r = t / F4;
+        const int c4 = (int)(t - r * F4);
+        const int sgm = seg_of_row[r];
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (sgm >= 0) {
+            for (int c = 0; c < C; ++c) {
+                const float d = dy[(int64_t)sgm * C + c];
+                const float4 wv = *reinterpret_cast<const float4 *>(W + (int64_t)c * F + 4 * c4);
+                v.x = fmaf(d, wv.x, v.x); v.y = fmaf(d, wv.y, v.y); v.z = fmaf(d, wv.z, v.z); v.w = fmaf(d, wv.w, v.w);
+            }
+            const float w = inv_cnt[sgm];
+            v.x *= w; v.y *= w; v.z *= w; v.w *= w;
+        }
+        dx[t] = v;
+        return;
+    }
+    const int q = ((int)blockIdx.x - nb_dx) * 256 + threadIdx.x;
+    if (q < C * F) {
+        if (!dW) return;
+        const int c = q / F, f = q - c * F;
+        float acc = 0.f;
+#pragma unroll 8
+        for (int sg = 0; sg < n_seg; ++sg) acc = fmaf(dy[(int64_t)sg * C + c], pooled[(int64_t)sg * F + f], acc);
+        dW[q] = acc;
+    } else if (q < C * F + C) {
+        if (!db) return;
+        const int c = q - C * F;
+        float acc = 0.f;
+        for (int sg = 0; sg < n_seg; ++sg) acc += dy[(int64_t)sg * C + c];
+        db[c] = acc;
+    }
+}
+
 // dst[arg[s][c]][c] += g[s][c] (dst zeroed by the caller; every (row, column) is the maximum of at most one segment when the segments
 // are disjoint, so plain read-modify-write stores do not collide)
 __global__ __launch_bounds__(256) void segment_max_bwd_kernel(const float *__restrict__ g, const int32_t *__restrict__ arg, int64_t n,
@@ -496,6 +597,37 @@ extern "C" int fitgnn_segment_expand_f32(const float *src, const int32_t *seg_of
     const int64_t n = n_rows * (F / 4);
     hipLaunchKernelGGL(segment_expand_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, seg_of_row, scale, n_rows,
                        F / 4, (float4 *)dst);
+    return (int)hipGetLastError();
+}
+
+extern "C" int fitgnn_pool_head_supported(int32_t F, int32_t C) {
+    return (F >= 4 && (F % 4) == 0 && (F / 4) <= 256 && (256 % (F / 4)) == 0 && C >= 1 && C <= kPoolHeadMaxC) ? 1 : 0;
+}
+
+extern "C" int fitgnn_pool_head_f32(const int32_t *seg_off, const int32_t *members, int32_t n_seg, const float *X, int64_t ldx, int32_t F,
+                                    const float *inv_cnt, const float *W, const float *b, int32_t C, float *pooled, float *y,
+                                    void *stream) {
+    if (n_seg < 0 || !fitgnn_pool_head_supported(F, C) || ldx < F || (ldx % 4) != 0) return FITGNN_E_BADARG;
+    if (n_seg == 0) return 0;
+    if (!seg_off || !members || !X || !inv_cnt || !W || !pooled || !y) return FITGNN_E_BADARG;
+    if ((((uintptr_t)X | (uintptr_t)W | (uintptr_t)pooled) % 16) != 0) return FITGNN_E_ALIGN;
+    hipLaunchKernelGGL(pool_head_kernel, dim3((unsigned)n_seg), dim3(256), 0, (hipStream_t)stream, seg_off, members, X, ldx, F, inv_cnt, W, b,
+                       C, pooled, y);
+    return (int)hipGetLastError();
+}
+
+extern "C" int fitgnn_pool_head_bwd_f32(const float *dy, const float *W, int32_t C, const float *pooled, const int32_t *seg_of_row,
+                                        const float *inv_cnt, int64_t n_rows, int32_t n_seg, int32_t F, float *dx, float *dW, float *db,
+                                        void *stream) {
+    if (n_rows < 0 || n_seg < 0 || !fitgnn_pool_head_supported(F, C)) return FITGNN_E_BADARG;
+    if (n_rows == 0 && n_seg == 0) return 0;
+    if (!dy || !W || !pooled || !seg_of_row || !inv_cnt || (n_rows > 0 && !dx)) return FITGNN_E_BADARG;
+    if ((((uintptr_t)W | (uintptr_t)dx) % 16) != 0) return FITGNN_E_ALIGN;
+    const int64_t n = n_rows * (F / 4);
+    const int nb_dx = (int)((n + 255) / 256);
+    const int nb_w = (dW || db) ? (C * F + C + 255) / 256 : 0;
+    hipLaunchKernelGGL(pool_head_bwd_kernel, dim3((unsigned)(nb_dx + nb_w)), dim3(256), 0, (hipStream_t)stream, dy, W, C, pooled, seg_of_row,
+                       inv_cnt, n_rows, n_seg, F, nb_dx, (float4 *)dx, dW, db);
     return (int)hipGetLastError();
 }
 

@@ -97,6 +97,15 @@ SIGNATURES = {
     "fitgnn_head_rows_lds_bytes": (c_size, [c_i32, c_i32]),
     "fitgnn_head_rows_f32": (ctypes.c_int, [ptr, c_i64, ptr, c_i32, ptr, ptr, c_i32, c_i32, ptr, c_i64, c_i32, ptr]),
     "fitgnn_epilogue_fwd_rows_f32": (ctypes.c_int, [ptr, c_i64, ptr, c_i32, c_i32, ptr, c_u32, c_f32, c_u64, ptr, ptr]),
+    "fitgnn_dense_narrow_k_lds_bytes": (c_size, [c_i32, c_i32]),
+    "fitgnn_dense_narrow_k_f32": (ctypes.c_int, [ptr, c_i64, ptr, c_i64, c_i32, c_i32, c_i32, ptr, c_u32, c_f32, c_u64, ptr, ptr, c_i64, ptr]),
+    "fitgnn_narrow_atb_workspace_bytes": (c_size, [c_i32, c_i32, c_i32]),
+    "fitgnn_narrow_atb_f32": (ctypes.c_int, [ptr, c_i64, ptr, c_u32, c_f32, c_u64, ptr, ptr, c_i64, c_i32, c_i32, c_i32, ptr, ptr, ptr, c_size,
+                                             ptr]),
+    "fitgnn_adam_step_acc_f32": (ctypes.c_int, [ptr, ptr, ptr, ptr, ptr, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, ptr, ptr, c_i32, c_u64, ptr]),
+    "fitgnn_pool_head_supported": (ctypes.c_int, [c_i32, c_i32]),
+    "fitgnn_pool_head_f32": (ctypes.c_int, [ptr, ptr, c_i32, ptr, c_i64, c_i32, ptr, ptr, ptr, c_i32, ptr, ptr, ptr]),
+    "fitgnn_pool_head_bwd_f32": (ctypes.c_int, [ptr, ptr, c_i32, ptr, ptr, ptr, c_i64, c_i32, c_i32, ptr, ptr, ptr, ptr]),
     "fitgnn_colsum_narrow_workspace_bytes": (c_size, [c_i32, c_i32]),
     "fitgnn_colsum_narrow_f32": (ctypes.c_int, [ptr, c_i64, c_i32, c_i32, ptr, ptr, c_size, ptr]),
     "fitgnn_spmm_narrow_f32": (ctypes.c_int, [ptr, ptr, ptr, ptr, ptr, c_i32, c_i32, c_f32, ptr, c_f32, ptr, c_f32, ptr]),

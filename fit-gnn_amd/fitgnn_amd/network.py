@@ -77,6 +77,14 @@ class _Base(nn.Module):
         return ops.FusedGCNLayerDedup.apply(x_table.float(), conv.lin.weight, conv.bias, g, x_index, float(self.dropout_p),
                                             bool(self.training), seed, mask, link_out, cfg)
 
+    def prepare_static(self, x, edge_index):
+        """Form ahead of time what the first layer keeps per (graph, input) -- A_hat x of a narrow static input
+        (ops.aggregated_input) -- e.g. before the steps over a set of static batches are captured in hipGraphs."""
+        conv = self.conv[0] if self.num_layers > 0 else None
+        if (isinstance(conv, fnn.GCNConv) and torch.is_tensor(x) and x.is_cuda and x.dtype == torch.float32
+                and ops.narrow_input_supported(x, conv.lin.weight, self.op_config)):
+            ops.aggregated_input(conv.graph(edge_index, x.shape[0]), x, self.op_config)
+
     def embed(self, x, edge_index, x_index=None, first=0, link=None, last=None):
         """conv -> ELU -> dropout, layers first .. last - 1 (default: all; network.py:29-33).  link: the EpilogueLink recorded by the
         layer that produced x (consecutive fused GCN layers are linked: see ops.EpilogueLink; the stack is strictly sequential)."""
@@ -86,8 +94,16 @@ class _Base(nn.Module):
             if isinstance(conv, fnn.GCNConv) and x.is_cuda:
                 mask = self._inject_masks[i] if self._inject_masks is not None else None
                 nxt = ops.EpilogueLink() if i + 1 < self.num_layers else None   # the last output goes to lt1: plain gradient
-                x = conv.forward_elu_dropout(x, edge_index, p=self.dropout_p, training=self.training, mask=mask, link_in=link,
-                                             link_out=nxt)
+                if i == 0 and link is None and ops.narrow_input_supported(x, conv.lin.weight, self.op_config):
+                    # a narrow static input (QM9's 11 atom features): aggregate first, A_hat x formed once per (graph, input)
+                    cfg = self.op_config
+                    ax = ops.aggregated_input(conv.graph(edge_index, x.shape[0]), x, cfg)
+                    seed = ops.next_seed(cfg) if (self.training and self.dropout_p > 0 and mask is None) else 0
+                    x = ops.FusedGCNLayerAggregatedInput.apply(ax, conv.lin.weight, conv.bias, float(self.dropout_p), bool(self.training),
+                                                               seed, mask, nxt, cfg)
+                else:
+                    x = conv.forward_elu_dropout(x, edge_index, p=self.dropout_p, training=self.training, mask=mask, link_in=link,
+                                                 link_out=nxt)
                 link = nxt
             elif isinstance(conv, fnn.GATConv) and x.is_cuda:
                 mask = self._inject_masks[i] if self._inject_masks is not None else None
@@ -277,12 +293,25 @@ class Classify_graph_gc(_Base):
         return F.softmax(self.head(fnn.global_max_pool(x, gc.batch, getattr(gc, "num_graphs", None))), dim=1)
 
 
+def _mean_pool_head(model, x, batch, size, rows=None):
+    """lt1(global_mean_pool(x[rows])): one launch each way on the GPU (ops.MeanPoolHead) when the batch vector is sorted and the
+    shapes allow it, else the pool followed by the head."""
+    if (model.op_config.fused_pool_head and size is not None and ops.pool_head_supported(x, model.lt1.weight)
+            and batch.dtype == torch.int64):
+        pi = ops.pool_index(batch, size, rows, x.shape[0])
+        if pi.sorted:
+            return ops.MeanPoolHead.apply(x, pi, model.lt1.weight, model.lt1.bias, model.op_config)
+    if rows is not None:
+        return model.head(fnn.global_mean_pool(x, batch, size, rows=rows))
+    return model.head(fnn.global_mean_pool(x, batch, size))
+
+
 class Regress_graph_gc(_Base):
     out_dim_from_classes = False
 
     def forward(self, gc):
         x = self.embed(gc.x, gc.edge_index)
-        return self.head(fnn.global_mean_pool(x, gc.batch, getattr(gc, "num_graphs", None)))
+        return _mean_pool_head(self, x, gc.batch.to(torch.int64), getattr(gc, "num_graphs", None))
 
 
 def _merge_subgraphs(set_gs, device):
@@ -330,4 +359,7 @@ class Regress_graph_gs(_Base):
 
     def forward(self, set_gs, batch_tensor):
         x, ei, mask, size = _gs_inputs(set_gs, batch_tensor)
-        return self.head(_pool_rows(fnn.global_mean_pool, self.embed(x, ei), mask, batch_tensor, size))
+        h = self.embed(x, ei)
+        if mask.dtype == torch.int64 and h.is_cuda:   # a precomputed row index (GraphSet batches): pool and head in one launch
+            return _mean_pool_head(self, h, batch_tensor.to(torch.int64), size, rows=mask)
+        return self.head(_pool_rows(fnn.global_mean_pool, h, mask, batch_tensor, size))

@@ -56,6 +56,17 @@ class OpConfig:
                      windows and never written as a whole) instead of dZ followed by its own plain SpMM: most of the 8 H R bytes of
                      writing and re-reading dZ are not moved (same bits for the gradient rows; the bias gradient's partial sums are
                      grouped differently).  Needs a batch that runs on the whole-subgraph kernel (split_large_blocks).
+    narrow_input_first  a first GCN layer whose input has at most 32 columns and needs no gradient (QM9: 11 atom features into hidden
+                     512) runs aggregate-first, (A_hat x) W^T, with A_hat x formed ONCE per (graph, input) and kept on the graph: per
+                     step the layer is one pass over its output (fitgnn_dense_narrow_k_f32) and its backward one pass over the incoming
+                     gradient (fitgnn_narrow_atb_f32: no SpMM, no dZ) -- FusedGCNLayerAggregatedInput.
+    fused_pool_head  lt1(global_mean_pool(x[rows])) of the graph-level regression models as one launch each way (MeanPoolHead) instead
+                     of pool, scale, library product and bias add (A/B switch).
+    grad_sink        None, or an object with `.view(data_ptr)` -> the slice of a "fresh gradients" buffer that belongs to the parameter stored at
+                     that address (train.FlatGrads with fresh=True).  Backward nodes that know it write a weight / bias gradient THERE
+                     (the product's own output buffer) and return None for it, so autograd issues no `grad += new` launch per tensor; the
+                     optimiser kernel folds the buffer into the accumulated gradients (fitgnn_adam_step_acc_f32).  A parameter must
+                     feed ONE such node per backward (a second write would replace the first, not add to it).
     pad_table_min_k  static feature tables at least this wide whose width is not a multiple of 32 run layer 0's
                      products on a copy zero-padded once (real feature widths: 100, 500, 1 433, 8 415).
     profile / profile_gemm / profile_fused   None, or a list that collects HIP-event pairs around the SpMM / hand-written
@@ -63,11 +74,13 @@ class OpConfig:
     seed_bank        None, or a SeedBank supplying device-resident dropout seeds (steps captured in a hipGraph)."""
     __slots__ = ("gemm_precision", "atb_kernel", "nt_kernel", "nt_presplit", "fuse_dx_epilogue", "fold_backward",
                  "dedup_gather", "pad_table_min_k", "split_large_blocks", "compact_head_backward", "last_layer_on_loss_rows",
-                 "compact_rows_kernel", "stream_kernel", "two_hop_backward", "profile", "profile_gemm", "profile_fused", "seed_bank")
+                 "compact_rows_kernel", "stream_kernel", "two_hop_backward", "narrow_input_first", "fused_pool_head", "grad_sink", "profile", "profile_gemm",
+                 "profile_fused", "seed_bank")
 
     def __init__(self, gemm_precision="exact", atb_kernel=True, nt_kernel=True, nt_presplit=True, fuse_dx_epilogue=True,
                  fold_backward=False, dedup_gather=True, pad_table_min_k=0, split_large_blocks=True, compact_head_backward=True,
-                 last_layer_on_loss_rows=True, compact_rows_kernel=True, stream_kernel=False, two_hop_backward=True, profile=None, profile_gemm=None, profile_fused=None, seed_bank=None):
+                 last_layer_on_loss_rows=True, compact_rows_kernel=True, stream_kernel=False, two_hop_backward=True, narrow_input_first=True, fused_pool_head=True, grad_sink=None,
+                 profile=None, profile_gemm=None, profile_fused=None, seed_bank=None):
         if gemm_precision not in ("exact", "high", "highest"):
             raise ValueError(f"gemm_precision {gemm_precision!r}: 'exact', 'high' or 'highest'")
         self.gemm_precision, self.atb_kernel, self.nt_kernel, self.nt_presplit = gemm_precision, atb_kernel, nt_kernel, nt_presplit
@@ -75,6 +88,7 @@ class OpConfig:
         self.pad_table_min_k, self.split_large_blocks = pad_table_min_k, split_large_blocks
         self.compact_head_backward, self.last_layer_on_loss_rows = compact_head_backward, last_layer_on_loss_rows
         self.compact_rows_kernel, self.stream_kernel, self.two_hop_backward = compact_rows_kernel, stream_kernel, two_hop_backward
+        self.narrow_input_first, self.fused_pool_head, self.grad_sink = narrow_input_first, fused_pool_head, grad_sink
         self.profile, self.profile_gemm, self.profile_fused, self.seed_bank = profile, profile_gemm, profile_fused, seed_bank
 
     def replace(self, **kw):
@@ -85,6 +99,13 @@ class OpConfig:
 
 
 DEFAULT = OpConfig()   # what ops run under when their caller names no config; never modified by this package
+
+
+def _sink(cfg, t):
+    """The fresh-gradient slice of parameter tensor `t` (or of the parameter stored at address `t`) under cfg.grad_sink, else None."""
+    if cfg.grad_sink is None or t is None:
+        return None
+    return cfg.grad_sink.view(t if isinstance(t, int) else t.data_ptr())
 
 
 def mm(a, b):
@@ -353,13 +374,18 @@ def head_weight_grad_rows(dy_c, out_c, cfg=DEFAULT):
     return mm_at_b(dy_c, out_c, cfg)
 
 
-def mm_at_b(a, b, cfg=DEFAULT):
+def mm_at_b(a, b, cfg=DEFAULT, out=None):
     """a^T @ b for tall operands a [R, M], b [R, N] (the weight-gradient product dH^T @ X, reduction over all R
     rows): the hand-written split-K kernel where it applies.  Otherwise the library: hipBLASLt serves this huge-K /
     small-MN shape poorly as one GEMM (541 us for R = 90k, M = N = 512); as a batched GEMM over ~1400-row slices plus
     a sum of the partial products it takes 394 us -- split-K by hand.  The partials are summed in a fixed order:
     reproducible."""
     R = a.shape[0]
+    if out is not None:   # the caller's buffer (a gradient sink): the exact kernel stores there, other paths are copied
+        if _exact(cfg, a, b):
+            return gemm_exact(a, b, "tn", cfg, out=out)
+        out.copy_(mm_at_b(a, b, cfg))
+        return out
     if _exact(cfg, a, b):
         return gemm_exact(a, b, "tn", cfg)
     if (cfg.gemm_precision == "high" and cfg.atb_kernel and R >= 256 and min(a.shape[1], b.shape[1]) >= 64 and _atb_ok(a)
@@ -466,6 +492,20 @@ class SoftmaxNLL(torch.autograd.Function):
         return dz * g, None, None, None
 
 
+def l1_loss_raw(out, tgt, scale, loss_out=None):
+    """(loss, grad): loss = scale * sum |out - tgt| as a one-element tensor (loss_out when given: the kernel writes it there) and
+    grad = d loss / d out, from ONE launch (fitgnn_l1_loss_f32).  A trainer that owns the step calls out.backward(grad) instead of
+    loss.backward(): the same gradient without autograd's ones-fill and the multiplication by it."""
+    _lib.require_cuda(out, tgt)
+    o, t = _f32c(out).reshape(-1), _f32c(tgt).reshape(-1)
+    assert o.numel() == t.numel()
+    loss = loss_out if loss_out is not None else torch.empty(1, dtype=torch.float32, device=o.device)
+    grad = torch.empty_like(o)
+    _lib.check(_lib.lib().fitgnn_l1_loss_f32(_lib.dptr(o), _lib.dptr(t), int(o.numel()), float(scale), _lib.dptr(loss), _lib.dptr(grad),
+                                             _lib.stream_ptr(o.device)), "fitgnn_l1_loss_f32")
+    return loss, grad.view(out.shape)
+
+
 class L1Loss(torch.autograd.Function):
     """scale * sum |out - tgt| (torch.nn.L1Loss of run.py:518,716 on a regression head's few hundred outputs) with its gradient
     from the same launch (fitgnn_l1_loss_f32) instead of sub / abs / mean and their three backward kernels.  Returns a 0-dim loss."""
@@ -520,15 +560,15 @@ def spmm_raw(rowptr, col, val, tiles, X, n_rows, bias=None, epilogue=0, p=0.0, s
     return Y
 
 
-def epilogue_bwd_raw(dOut, out, epilogue, p=0.0, seed=0, mask=None, want_db=True):
-    """dZ (and db = column sums of dZ) for out = dropout(ELU(z)) through fitgnn_epilogue_bwd_f32."""
+def epilogue_bwd_raw(dOut, out, epilogue, p=0.0, seed=0, mask=None, want_db=True, db_out=None):
+    """dZ (and db = column sums of dZ) for out = dropout(ELU(z)) through fitgnn_epilogue_bwd_f32.  db_out: write db there."""
     _lib.require_cuda(dOut, out, mask)
     L = _lib.lib()
     dOut, out = _f32c(dOut), _f32c(out)
     n, H = dOut.shape
     seed, epilogue = _seed_arg(seed, epilogue)
     dZ = torch.empty_like(dOut)
-    db = torch.empty(H, dtype=torch.float32, device=dOut.device) if want_db else None
+    db = (db_out if db_out is not None else torch.empty(H, dtype=torch.float32, device=dOut.device)) if want_db else None
     wb = int(L.fitgnn_epilogue_bwd_workspace_bytes(n, H)) if want_db else 0
     work = torch.empty(max(wb, 4), dtype=torch.uint8, device=dOut.device)
     rc = L.fitgnn_epilogue_bwd_f32(_lib.dptr(dOut), _lib.dptr(out), _lib.dptr(dZ), n, H, epilogue, float(p),
@@ -1102,6 +1142,52 @@ class SegmentMaxPool(torch.autograd.Function):
         return dx, None
 
 
+def pool_head_supported(x, Wl):
+    return (x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and x.shape[0] > 0 and Wl.dim() == 2 and Wl.shape[1] == x.shape[1]
+            and bool(_lib.lib().fitgnn_pool_head_supported(int(x.shape[1]), int(Wl.shape[0]))))
+
+
+class MeanPoolHead(torch.autograd.Function):
+    """lt1(global_mean_pool(x[rows])) (Regress_graph_gs / _gc, network.py:164-166, :200-204) as one launch forward
+    (fitgnn_pool_head_f32: gather-and-sum, 1 / count, the head's few dot products, its bias) and one backward
+    (fitgnn_pool_head_bwd_f32: every row of dx, the head's weight and bias gradients) -- on a 128-graph batch the separate pool,
+    scale, [128 x 512] @ [512 x 1] library product and bias add are four launches forward and seven backward."""
+
+    @staticmethod
+    def forward(ctx, x, pi, Wl, bl, cfg):
+        L = _lib.lib()
+        x, W = _f32c(x), _f32c(Wl)
+        n, F_ = x.shape
+        C = int(W.shape[0])
+        pooled = torch.empty((pi.n_seg, F_), dtype=torch.float32, device=x.device)
+        y = torch.empty((pi.n_seg, C), dtype=torch.float32, device=x.device)
+        _lib.check(L.fitgnn_pool_head_f32(_lib.dptr(pi.seg_off), _lib.dptr(pi.members), pi.n_seg, _lib.dptr(x), x.stride(0), F_,
+                                          _lib.dptr(pi.inv_cnt), _lib.dptr(W), _lib.dptr(bl), C, _lib.dptr(pooled), _lib.dptr(y),
+                                          _lib.stream_ptr(x.device)), "fitgnn_pool_head_f32")
+        ctx.save_for_backward(pooled, W)
+        ctx.pi, ctx.shape, ctx.cfg = pi, (n, F_), cfg
+        ctx.W_ptr, ctx.b_ptr = Wl.data_ptr(), (bl.data_ptr() if bl is not None else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        pooled, W = ctx.saved_tensors
+        L = _lib.lib()
+        pi, (n, F_), cfg = ctx.pi, ctx.shape, ctx.cfg
+        C = int(W.shape[0])
+        dy = _f32c(dy)
+        dev = dy.device
+        dx = torch.empty((n, F_), dtype=torch.float32, device=dev) if ctx.needs_input_grad[0] else None
+        sW = _sink(cfg, ctx.W_ptr) if ctx.needs_input_grad[2] else None
+        sb = _sink(cfg, ctx.b_ptr) if (ctx.b_ptr is not None and ctx.needs_input_grad[3]) else None
+        dW = (sW if sW is not None else torch.empty((C, F_), dtype=torch.float32, device=dev)) if ctx.needs_input_grad[2] else None
+        db = (sb if sb is not None else torch.empty(C, dtype=torch.float32, device=dev)) if (ctx.b_ptr is not None and ctx.needs_input_grad[3]) else None
+        _lib.check(L.fitgnn_pool_head_bwd_f32(_lib.dptr(dy), _lib.dptr(W), C, _lib.dptr(pooled), _lib.dptr(pi.seg_of_row), _lib.dptr(pi.inv_cnt),
+                                              n if dx is not None else 0, pi.n_seg, F_, _lib.dptr(dx), _lib.dptr(dW), _lib.dptr(db),
+                                              _lib.stream_ptr(dev)), "fitgnn_pool_head_bwd_f32")
+        return dx, None, (None if sW is not None else dW), (None if sb is not None else db), None
+
+
 def pool_supported(x):
     return x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and x.shape[1] % 4 == 0 and x.shape[0] > 0
 
@@ -1121,7 +1207,7 @@ class RowIndex:
         self.seg_off = off.to(torch.int32).contiguous()
 
 
-def layer_backward(g, out, epi, p, seed, mask, want_db, dOut=None, dy=None, Wl=None, want_dWl=False, cfg=DEFAULT, loss_rows=None):
+def layer_backward(g, out, epi, p, seed, mask, want_db, dOut=None, dy=None, Wl=None, want_dWl=False, cfg=DEFAULT, loss_rows=None, db_out=None):
     """(dH, db, dWl) of one fused layer: dZ = epilogue'(dOut or dy @ Wl), db = colsum dZ, dH = A^T dZ.
     Epilogue-backward kernel + SpMM; with cfg.fold_backward one kernel (dZ stays in LDS) when the graph / shape allow it --
     measured on the S-pubmed union no faster than the two kernels (254 vs 223 us per hidden layer, 262 vs 263 us with the
@@ -1175,7 +1261,7 @@ def layer_backward(g, out, epi, p, seed, mask, want_db, dOut=None, dy=None, Wl=N
             else:
                 dWl = mm_at_b(_f32c(dy), out, cfg)
     else:
-        dZ, db = epilogue_bwd_raw(dOut, out, epi, p=p, seed=seed, mask=mask, want_db=want_db)
+        dZ, db = epilogue_bwd_raw(dOut, out, epi, p=p, seed=seed, mask=mask, want_db=want_db, db_out=db_out)   # (db is db_out when given)
         dWl = None
     return spmm_graph(g, dZ, transposed=True, cfg=cfg), db, dWl
 
@@ -1249,15 +1335,17 @@ def _dx_through_link(cfg, link, dH, W, X):
     return mm_by_transposed(dH, W, cfg)
 
 
-def _producer_backward(cfg, link, g, out, epi, p, seed, mask, has_bias, dOut):
-    """(dH, db) of a fused layer: through the link when its consumer already applied the epilogue's derivative."""
+def _producer_backward(cfg, link, g, out, epi, p, seed, mask, has_bias, dOut, db_out=None):
+    """(dH, db) of a fused layer: through the link when its consumer already applied the epilogue's derivative.  db_out: a buffer the
+    bias gradient may be written to (it is then the returned db itself -- check identity)."""
     if link is not None and link.fused:
         db, aggregated = link.db, link.aggregated
         link.fused, link.db, link.aggregated = False, None, False
         if aggregated:   # the consumer's backward already ran this layer's SpMM over dZ (two-hop)
             return _f32c(dOut), db
         return spmm_graph(g, _f32c(dOut), transposed=True, cfg=cfg), db
-    dH, db, _ = layer_backward(g, out, epi, p, seed, mask, has_bias, dOut=dOut, cfg=cfg)
+    plain = not (cfg.fold_backward and getattr(g, "fold_ok", False))
+    dH, db, _ = layer_backward(g, out, epi, p, seed, mask, has_bias, dOut=dOut, cfg=cfg, db_out=db_out if plain else None)
     return dH, db
 
 
@@ -1277,6 +1365,7 @@ class FusedGCNLayer(torch.autograd.Function):
         ctx.save_for_backward(X, W, out, mask if drop else None)
         ctx.g, ctx.p, ctx.drop, ctx.seed, ctx.has_bias, ctx.cfg = g, p, drop, seed, b is not None, cfg
         ctx.link_in, ctx.link_out = link_in, link_out
+        ctx.b_ptr = b.data_ptr() if b is not None else None
         if link_out is not None:
             link_out.record(drop, p, seed, mask, b is not None, g=g)
         return out
@@ -1287,10 +1376,100 @@ class FusedGCNLayer(torch.autograd.Function):
         g = ctx.g
         epi = EPI_ELU | (EPI_DROPOUT if ctx.drop else 0)
         cfg = ctx.cfg
-        dH, db = _producer_backward(cfg, ctx.link_out, g, out, epi, ctx.p if ctx.drop else 0.0, ctx.seed, mask, ctx.has_bias, dOut)
-        dW = mm_at_b(dH, X, cfg) if ctx.needs_input_grad[1] else None
+        sb = _sink(cfg, ctx.b_ptr) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        dH, db = _producer_backward(cfg, ctx.link_out, g, out, epi, ctx.p if ctx.drop else 0.0, ctx.seed, mask, ctx.has_bias, dOut, db_out=sb)
+        if sb is not None and db is sb:
+            db = None   # written to the gradient sink
+        dW = None
+        if ctx.needs_input_grad[1]:
+            sW = _sink(cfg, W)
+            if sW is not None:
+                mm_at_b(dH, X, cfg, out=sW)
+            else:
+                dW = mm_at_b(dH, X, cfg)
         dX = _dx_through_link(cfg, ctx.link_in, dH, W, X) if ctx.needs_input_grad[0] else None
         return dX, dW, (db if ctx.has_bias else None), None, None, None, None, None, None, None, None
+
+
+def narrow_input_supported(x, W, cfg=DEFAULT):
+    """A first GCN layer can run on the aggregated input: a device input of at most 32 columns that needs no gradient, narrower than
+    the layer, shapes the two narrow kernels take."""
+    if not (cfg.narrow_input_first and x.is_cuda and x.dim() == 2 and not x.requires_grad and x.shape[0] > 0):
+        return False
+    K, H = int(x.shape[1]), int(W.shape[0])
+    L = _lib.lib()
+    return K < H and bool(L.fitgnn_dense_narrow_k_lds_bytes(K, H)) and bool(L.fitgnn_narrow_atb_workspace_bytes(int(x.shape[0]), K, H))
+
+
+def aggregated_input(g, x, cfg=DEFAULT):
+    """A_hat x for a static input x, formed once per (graph, input tensor) and kept on the graph.  The entry HOLDS x (its storage
+    cannot be recycled for another tensor while the entry lives) and its version counter (an in-place edit re-forms the product)."""
+    cache = getattr(g, "_agg_input", None)
+    if cache is None or cache[0] is not x or cache[1] != x._version:
+        with torch.no_grad():
+            ax = spmm_graph(g, _f32c(x), cfg=cfg.replace(profile=None) if cfg.profile is not None else cfg)
+        cache = (x, x._version, ax)
+        g._agg_input = cache
+    return cache[2]
+
+
+class FusedGCNLayerAggregatedInput(torch.autograd.Function):
+    """out = dropout(ELU((A_hat x) W^T + b)) for a first layer on a narrow static input (network.py:189-204 on QM9: GCNConv(11, 512)
+    + F.elu + F.dropout): AX = A_hat x is an argument (ops.aggregated_input), the forward is one pass over the output, the backward
+    one pass over the incoming gradient producing dW and db -- the input needs no gradient, so neither dZ nor A_hat^T dZ exist.
+    Same values as FusedGCNLayer up to the order of the additions (A (x W^T) = (A x) W^T)."""
+
+    @staticmethod
+    def forward(ctx, AX, W, b, p, training, seed, mask, link_out, cfg):
+        L = _lib.lib()
+        n, K = AX.shape
+        H = int(W.shape[0])
+        Wc = _f32c(W)
+        epi = EPI_ELU | (EPI_BIAS if b is not None else 0)
+        drop = bool(training) and p > 0.0
+        if drop:
+            epi |= EPI_DROPOUT
+        out = torch.empty((n, H), dtype=torch.float32, device=AX.device)
+        seed_v, epi_v = _seed_arg(seed, epi)
+        m = mask if drop else None
+        rc = L.fitgnn_dense_narrow_k_f32(_lib.dptr(AX), AX.stride(0), _lib.dptr(Wc), Wc.stride(0), n, K, H, _lib.dptr(b), epi_v,
+                                         float(p if drop else 0.0), seed_v, _lib.dptr(m), _lib.dptr(out), out.stride(0),
+                                         _lib.stream_ptr(AX.device))
+        _lib.check(rc, "fitgnn_dense_narrow_k_f32")
+        ctx.save_for_backward(AX, out, m)
+        ctx.p, ctx.drop, ctx.seed, ctx.has_bias, ctx.cfg, ctx.link_out, ctx.H = p, drop, seed, b is not None, cfg, link_out, H
+        ctx.W_ptr, ctx.b_ptr = W.data_ptr(), (b.data_ptr() if b is not None else None)
+        if link_out is not None:   # g=None: the consumer may hand back dZ, never A_hat^T dZ (this layer has no backward SpMM)
+            link_out.record(drop, p, seed, mask, b is not None, g=None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dOut):
+        AX, out, mask = ctx.saved_tensors
+        L = _lib.lib()
+        n, K = AX.shape
+        H = ctx.H
+        dOut = _f32c(dOut)
+        link = ctx.link_out
+        prev, epi = out, EPI_ELU | (EPI_DROPOUT if ctx.drop else 0)
+        if link is not None and link.fused:   # the consumer already applied this layer's ELU' / dropout': dOut is dZ
+            link.fused, link.db, link.aggregated = False, None, False
+            prev, epi = None, 0
+        seed_v, epi_v = _seed_arg(ctx.seed, epi)
+        cfg = ctx.cfg
+        sW = _sink(cfg, ctx.W_ptr) if ctx.needs_input_grad[1] else None
+        sb = _sink(cfg, ctx.b_ptr) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        dW = sW if sW is not None else torch.empty((H, K), dtype=torch.float32, device=dOut.device)
+        db = sb if sb is not None else torch.empty(H, dtype=torch.float32, device=dOut.device)
+        wb = int(L.fitgnn_narrow_atb_workspace_bytes(n, K, H))
+        work = torch.empty(wb // 4, dtype=torch.float32, device=dOut.device)
+        rc = L.fitgnn_narrow_atb_f32(_lib.dptr(dOut), dOut.stride(0), _lib.dptr(prev), epi_v, float(ctx.p if ctx.drop else 0.0), seed_v,
+                                     _lib.dptr(mask), _lib.dptr(AX), AX.stride(0), n, K, H, _lib.dptr(dW), _lib.dptr(db), _lib.dptr(work), wb,
+                                     _lib.stream_ptr(dOut.device))
+        _lib.check(rc, "fitgnn_narrow_atb_f32")
+        dW = dW if (ctx.needs_input_grad[1] and sW is None) else None
+        db = db if (ctx.has_bias and ctx.needs_input_grad[2] and sb is None) else None
+        return None, dW, db, None, None, None, None, None, None
 
 
 class FusedGCNLayerHead(torch.autograd.Function):

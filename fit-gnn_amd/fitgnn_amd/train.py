@@ -32,9 +32,28 @@ class FlatGrads:
         self.grads, self.tail = self.buf[:n], self.buf[n:]
         for p, off in zip(self.params, self.offsets):
             p.grad = self.buf[off:off + p.numel()].view_as(p)
+        self.fresh, self._fresh_views = None, None
 
     def zero(self):
         self.buf.zero_()
+
+    def enable_fresh(self):
+        """A second buffer of the same layout for the gradients of ONE backward pass (ops.OpConfig.grad_sink): backward nodes that
+        know it store a weight gradient straight into its slice -- no `grad += new` launch per tensor -- and the optimiser kernel
+        adds the buffer to the accumulated gradients and clears it (FlatAdam.step -> fitgnn_adam_step_acc_f32)."""
+        if self.fresh is None:
+            self.fresh = torch.zeros(self.n, dtype=torch.float32, device=self.buf.device)
+        return self
+
+    def view(self, data_ptr):
+        """The fresh-gradient slice (shaped like the parameter) of the parameter stored at `data_ptr`, or None."""
+        if self.fresh is None:
+            return None
+        m = self._fresh_views
+        if m is None or data_ptr not in m:   # (parameters are re-pointed once, by FlatAdam: map them as they are now)
+            m = {p.data_ptr(): self.fresh[off:off + p.numel()].view_as(p) for p, off in zip(self.params, self.offsets)}
+            self._fresh_views = m
+        return m.get(data_ptr)
 
 
 class FlatAdam:
@@ -53,12 +72,28 @@ class FlatAdam:
             view.copy_(p.data)
             p.data = view
         self.m, self.v = torch.zeros_like(self.P), torch.zeros_like(self.P)
-        self.step_count = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.step_count = torch.zeros(2, dtype=torch.float32, device=dev)   # [step count, fitgnn_adam_step_acc_f32's ticket word]
+        self.seed_bank = None   # an ops.SeedBank this optimiser's kernel advances after every step (captured step sequences)
 
     def step(self):
         from . import _lib
 
         b = self.flat.grads
+        if self.flat.fresh is not None or self.seed_bank is not None:
+            # one launch: gradients of this backward (the fresh buffer) folded into the accumulated ones and cleared, the update, the
+            # step count, the next step's dropout seeds
+            sb = self.seed_bank
+            fresh = self.flat.fresh
+            _lib.check(_lib.lib().fitgnn_adam_step_acc_f32(_lib.dptr(self.P), _lib.dptr(b), _lib.dptr(fresh), _lib.dptr(self.m),
+                                                           _lib.dptr(self.v), int(b.numel()), self.lr, self.betas[0], self.betas[1],
+                                                           self.eps, self.wd, _lib.dptr(self.step_count),
+                                                           _lib.dptr(sb.seeds) if sb is not None else None,
+                                                           int(sb.seeds.numel()) if sb is not None else 0,
+                                                           (sb.GOLD & 0xFFFFFFFFFFFFFFFF) if sb is not None else 0,
+                                                           _lib.stream_ptr(b.device)), "fitgnn_adam_step_acc_f32")
+            if sb is not None:
+                sb.cursor = 0
+            return
         _lib.check(_lib.lib().fitgnn_adam_step_f32(_lib.dptr(self.P), _lib.dptr(b), _lib.dptr(self.m), _lib.dptr(self.v), int(b.numel()),
                                                    self.lr, self.betas[0], self.betas[1], self.eps, self.wd, _lib.dptr(self.step_count),
                                                    _lib.stream_ptr(b.device)), "fitgnn_adam_step_f32")
@@ -71,7 +106,7 @@ class FlatAdam:
 
     def state_dict(self):
         st = {}
-        if float(self.step_count) > 0:
+        if float(self.step_count[0]) > 0:
             for i, (m, v) in enumerate(zip(self._views(self.m), self._views(self.v))):
                 st[i] = {"step": self.step_count[0].clone(), "exp_avg": m.clone(), "exp_avg_sq": v.clone()}
         group = dict(lr=self.lr, betas=self.betas, eps=self.eps, weight_decay=self.wd, amsgrad=False, maximize=False,
@@ -86,7 +121,7 @@ class FlatAdam:
             if i in sd["state"]:
                 e = sd["state"][i]
                 m.copy_(e["exp_avg"]); v.copy_(e["exp_avg_sq"])
-                self.step_count.fill_(float(e["step"]))
+                self.step_count[0] = float(e["step"])
 
 
 def broadcast_parameters(model, process_group=None, flat=None):
@@ -111,6 +146,14 @@ def broadcast_parameters(model, process_group=None, flat=None):
                     p.data.copy_(c)
         for b in model.buffers():
             dist.broadcast(b.data, src, group=process_group)
+
+
+def _drop_stale_sink(model):
+    """A model that an earlier trainer left writing its weight gradients to THAT trainer's fresh buffer (OpConfig.grad_sink) must
+    not keep doing so under a new gradient buffer."""
+    cfg = getattr(model, "op_config", None)
+    if cfg is not None and getattr(cfg, "grad_sink", None) is not None and hasattr(model, "set_op_config"):
+        model.set_op_config(cfg.replace(grad_sink=None))
 
 
 def _make_adam(model, flat, lr, weight_decay):
@@ -143,6 +186,7 @@ class GDTrainer:
         # first layer on the de-duplicated feature table when the batch carries one (same arithmetic, fewer FLOPs)
         self.dedup = dedup and getattr(batch, "row_index", None) is not None
         self.flat = FlatGrads(model.parameters())
+        _drop_stale_sink(model)
         if next(model.parameters()).is_cuda:   # one kernel over the flat buffers (same arithmetic as torch.optim.Adam)
             self.opt = FlatAdam(self.flat, lr=lr, weight_decay=weight_decay)
         else:                                  # host-side logic tests (gloo): the reference's optimiser itself
@@ -302,12 +346,24 @@ class _CapturedSteps:
         # its config that carries the bank while the steps are built (replays re-run no Python)
         prev = self.model.op_config
         self.model.set_op_config(prev.replace(seed_bank=self._bank))
+        # the optimiser kernel moves the seeds on after every step (one launch less per step) when it is the flat one
+        adam_advances = flat_opt and getattr(self, "lean", True)
+        if adam_advances:
+            self.opt.seed_bank = self._bank
+        # what a step keeps per batch (A_hat x of a narrow first layer, ops.aggregated_input) is formed NOW: made lazily inside a
+        # step it would be captured with it and replayed every epoch
+        prepare = getattr(self.model, "prepare_static", None)
+        if prepare is not None:
+            for b in self._steps():
+                if b is not None:
+                    prepare(*self._static_inputs(b))
         try:
             side = torch.cuda.Stream(device=dev)
             side.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(side):
                 for b in self._steps()[:2]:
-                    self._bank.advance()
+                    if not adam_advances:
+                        self._bank.advance()
                     self._one(b)
             torch.cuda.current_stream(dev).wait_stream(side)
             torch.cuda.synchronize(dev)
@@ -325,8 +381,13 @@ class _CapturedSteps:
             for k, b in enumerate(self._steps()):
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, pool=pool):
-                    self._bank.advance()
-                    self._losses[k:k + 1].copy_(self._one(b).view(1))
+                    if not adam_advances:
+                        self._bank.advance()
+                    self._bank.cursor = 0
+                    slot = self._losses[k:k + 1]
+                    r = self._one(b, loss_out=slot)   # (a loss kernel that can write the slot itself saves the copy)
+                    if r.data_ptr() != slot.data_ptr():
+                        slot.copy_(r.view(1))
                 self._graphs.append(g)
             # capturing does not execute: the weights are untouched, but the gradient buffer was only zeroed eagerly
             self.flat.zero()
@@ -356,6 +417,7 @@ class MBTrainer(_CapturedSteps):
         self.model, self.reduction = model, reduction
         self.capture, self._graphs = bool(capture), None
         self.flat = FlatGrads(model.parameters())
+        _drop_stale_sink(model)
         self.opt = _make_adam(model, self.flat, lr, weight_decay)
         ei = batch.edge_index
         order = torch.argsort(ei[0], stable=True)
@@ -378,7 +440,10 @@ class MBTrainer(_CapturedSteps):
     def _steps(self):
         return self.parts
 
-    def _one(self, part):
+    def _static_inputs(self, part):
+        return part[0], part[1]
+
+    def _one(self, part, loss_out=None):
         x, e, y, idx = part
         loss = F.nll_loss(self.model(x, e).index_select(0, idx), y, reduction=self.reduction)
         loss.backward()           # accumulates into the flat buffer: no zero_grad between batches (run.py:222)
@@ -409,7 +474,7 @@ class GraphTrainer(_CapturedSteps):
 
     def __init__(self, model, gset, graphs, kind="gs", batch_size=128, lr=0.01, weight_decay=5e-4, task="graph_reg",
                  multi_prop=True, prop=0, truncate_targets=True, capture=False, share=None, rank=None, world=None,
-                 process_group=None, batches=None, global_sizes=None, accumulate=True, reshuffle=False):
+                 process_group=None, batches=None, global_sizes=None, accumulate=True, reshuffle=False, lean_step=True):
         """capture=True: every batch step (forward, loss, backward, Adam) is captured once in a hipGraph and replayed
         -- the steps are launch-bound (small batches, ~40 kernels each).  Dropout seeds then live on the device
         (ops.SeedBank) and are advanced by a kernel inside each captured step.
@@ -421,7 +486,9 @@ class GraphTrainer(_CapturedSteps):
         accumulate=False: clear the gradients before every batch (the baselines' loops, run.py:988-991, :1058-1060).
         reshuffle=True: re-draw the graph order before every epoch, as the reference's DataLoader(shuffle=True) does
         (run.py:710); every batch's CSR is then rebuilt per epoch and the steps run eagerly (≈ 3 ms of set-up per batch: the
-        default draws the order once and replays captured steps)."""
+        default draws the order once and replays captured steps).
+        lean_step=False (A/B): the step as round 3 had it -- autograd's own `grad += new` per tensor, loss.backward() from a ones
+        fill, the seeds and the step count advanced by launches of their own."""
         import types
 
         dist_on = torch.distributed.is_available() and torch.distributed.is_initialized()
@@ -431,6 +498,7 @@ class GraphTrainer(_CapturedSteps):
 
         self.model, self.kind, self.task, self.multi_prop, self.prop = model, kind, task, multi_prop, prop
         self.truncate = truncate_targets
+        self.lean = bool(lean_step)
         self.accumulate = bool(accumulate)
         self.capture, self._graphs = bool(capture), None
         if share is not None:   # evaluation-only views of the same model: one optimiser / gradient buffer (run.py:718-719)
@@ -460,6 +528,14 @@ class GraphTrainer(_CapturedSteps):
                 self.batches.append(_cat_pieces(pieces, kind, types))
         if self.world > 1:
             self.capture = False   # the per-step collective is issued eagerly
+        if share is None:
+            if self.lean and self.world == 1 and isinstance(self.opt, FlatAdam) and hasattr(model, "set_op_config"):
+                # weight gradients straight into a buffer the optimiser kernel folds in (no `grad += new` launch per tensor); not
+                # under data parallelism, whose all-reduce runs over the accumulated buffer between backward and step
+                self.flat.enable_fresh()
+                model.set_op_config(model.op_config.replace(grad_sink=self.flat))
+            else:
+                _drop_stale_sink(model)
         if self.task == "graph_reg":   # static per batch: formed now, not inside a (captured) step
             for b in self.batches:
                 if b is not None and "_tgt" not in b:
@@ -514,10 +590,26 @@ class GraphTrainer(_CapturedSteps):
     def _steps(self):
         return self.batches
 
-    def _one(self, b):
+    def _static_inputs(self, b):
+        if self.kind == "gs":
+            return b["x"], b["edge_index"]
+        return b["gc"].x, b["gc"].edge_index
+
+    def _one(self, b, loss_out=None):
+        """One batch step.  loss_out (a one-element device tensor, optional): where the loss may be written directly."""
         if not self.accumulate:
             self.flat.zero()
-        loss = self._loss(self._forward(b), b["y"], b=b)
+        out = self._forward(b)
+        tgt = b.get("_tgt") if self.task == "graph_reg" else None
+        if self.lean and tgt is not None and out.is_cuda and out.dtype == torch.float32 and tgt.shape == out.shape and out.requires_grad:
+            # L1 loss and its gradient from one launch, handed to autograd as the output's gradient: loss.backward() would fill a
+            # one, multiply the stored gradient by it and copy the loss to its slot
+            from .ops import l1_loss_raw
+            loss, grad = l1_loss_raw(out, tgt, 1.0 / max(out.numel(), 1), loss_out)
+            out.backward(grad)
+            self.opt.step()
+            return loss.view(())
+        loss = self._loss(out, b["y"], b=b)
         loss.backward()
         self.opt.step()
         return loss.detach()

@@ -285,6 +285,19 @@ int fitgnn_segment_max_bwd_f32(const float *g, const int32_t *arg, int32_t n_seg
 int fitgnn_segment_expand_f32(const float *src, const int32_t *seg_of_row, const float *scale, int64_t n_rows, int32_t F, float *dst,
                               void *stream);
 
+/* lt1(global_mean_pool(x[rows])) in one launch (Regress_graph_gs / _gc, network.py:164-166, :200-204): graph s pools the rows
+ * members[seg_off[s] .. seg_off[s+1]) of X (row stride ldx, F columns), scaled by inv_cnt[s]; pooled [n_seg x F] (contiguous) keeps
+ * the pooled rows for the backward, y [n_seg x C] = pooled W^T + b (W [C x F] contiguous, b may be NULL).  One workgroup per graph,
+ * fixed summation order.  fitgnn_pool_head_supported(F, C): F % 4 == 0, F / 4 divides 256, C <= 8.
+ * Backward: dx [n_rows x F] (contiguous; EVERY row written: dx[r] = inv_cnt[s] sum_c dy[s][c] W[c] for seg_of_row[r] = s >= 0, zeros
+ * otherwise), dW [C x F] = dy^T pooled and db [C] = column sums of dy (either may be NULL), sums over ascending s. */
+int fitgnn_pool_head_supported(int32_t F, int32_t C);
+int fitgnn_pool_head_f32(const int32_t *seg_off, const int32_t *members, int32_t n_seg, const float *X, int64_t ldx, int32_t F,
+                         const float *inv_cnt, const float *W, const float *b, int32_t C, float *pooled, float *y, void *stream);
+int fitgnn_pool_head_bwd_f32(const float *dy, const float *W, int32_t C, const float *pooled, const int32_t *seg_of_row,
+                             const float *inv_cnt, int64_t n_rows, int32_t n_seg, int32_t F, float *dx, float *dW, float *db,
+                             void *stream);
+
 /* out[W] = sum over b < B of part[b][W] in a fixed order (W % 4 == 0, 16-byte aligned): combines the partial products
  * of the split-K weight-gradient GEMM dH^T @ X (the library has no deterministic split-K for K = number of rows). */
 int fitgnn_sum_leading_f32(const float *part, int32_t B, int64_t W, float *out, void *stream);
@@ -378,6 +391,17 @@ int fitgnn_softmax_nll_f32(const float *z, int64_t ldz, int32_t n_rows, int32_t 
 int fitgnn_adam_step_f32(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, float lr,
                          float beta1, float beta2, float eps, float weight_decay, float *step, void *stream);
 
+/* The same update for a step whose backward wrote its weight gradients into a buffer of their own, grad_new (laid out like grad_acc;
+ * NULL: none), instead of adding them to grad_acc tensor by tensor: the gradient used is grad_acc + grad_new, stored back to grad_acc,
+ * and grad_new is cleared
+ * (run.py:254-304 never clears the gradients inside an epoch: they accumulate over the batch steps).  state: float[2] -- the step
+ * count, then a word the kernel uses as a ticket counter and leaves at zero (zero-initialise both).  The last workgroup to finish
+ * advances the count and adds seed_stride (mod 2^64) to each of the n_seeds device-resident dropout seeds (seeds may be NULL with
+ * n_seeds == 0): ONE launch per optimiser step of a captured step sequence. */
+int fitgnn_adam_step_acc_f32(float *param, float *grad_acc, float *grad_new, float *exp_avg, float *exp_avg_sq, int64_t n, float lr,
+                             float beta1, float beta2, float eps, float weight_decay, float *state, uint64_t *seeds, int32_t n_seeds,
+                             uint64_t seed_stride, void *stream);
+
 /* Backward of the fused epilogue  out = dropout(ELU(z)):  given dOut and the forward OUTPUT `out`
  *   dZ = keep ? dOut * 1/(1-p) * (o > 0 ? 1 : o + 1) : 0,   o = out*(1-p) (pre-dropout ELU value)
  * and the bias gradient db[h] = sum_rows dZ[row][h] (deterministic two-pass reduction through `work`).
@@ -419,6 +443,28 @@ int fitgnn_epilogue_bwd_head_rows_f32(const float *dy, const float *Wl, int32_t 
  * same arithmetic) for a layer whose dense part is evaluated on selected rows only.  H % 4 == 0, z 16-byte aligned. */
 int fitgnn_epilogue_fwd_rows_f32(float *z, int64_t ldz, const int64_t *rows, int32_t n, int32_t H, const float *bias,
                                  uint32_t epilogue, float p_drop, uint64_t seed, const uint8_t *mask, void *stream);
+
+/* A layer's dense part on a FEW input columns: out = dropout(ELU(a W^T + bias)), a [n x K] (row stride lda), W [H x K] (row
+ * stride ldw: torch's Linear weight), 1 <= K <= 32, H % 4 == 0, out 16-byte aligned with ldo % 4 == 0; flags, dropout hash and
+ * mask indexing as fitgnn_spmm_csr_f32's store epilogue (element (row, column) of an [n x H] matrix).  Serves GCNConv on an input
+ * narrower than the layer (network.py:189-204 on QM9's 11 atom features) evaluated aggregate-first, (A_hat x) W^T, with a = A_hat x
+ * formed once per batch: per step the layer is this one pass over its output.  The K products of an element are added in
+ * ascending k.  fitgnn_dense_narrow_k_lds_bytes: the kernel's LDS need, 0 when (K, H) is not supported (W^T must fit 64 KiB). */
+size_t fitgnn_dense_narrow_k_lds_bytes(int32_t K, int32_t H);
+int fitgnn_dense_narrow_k_f32(const float *a, int64_t lda, const float *W, int64_t ldw, int32_t n, int32_t K, int32_t H,
+                              const float *bias, uint32_t epilogue, float p_drop, uint64_t seed, const uint8_t *mask, float *out,
+                              int64_t ldo, void *stream);
+
+/* ... and that layer's backward in one pass over the incoming gradient d [n x H] (row stride ldd, 16-byte aligned):
+ * dW [H x K] (contiguous) = dZ^T a and db [H] = column sums of dZ, a [n x K] as above.  prev == NULL: d is dZ itself.
+ * prev != NULL ([n x H] contiguous, the layer's output o = dropout(ELU(z))): d is the gradient w.r.t. o and
+ * dZ = fitgnn_epilogue_bwd_f32's arithmetic with the forward's flags (FITGNN_EPI_ELU / _DROPOUT), seed and mask, formed in registers
+ * (the layer's input needs no gradient, so dZ is never written).  Per-block partial sums reduced in a fixed order (reproducible).
+ * H / 4 must divide 256.  Workspace: fitgnn_narrow_atb_workspace_bytes(n, K, H) (0 = shape not supported). */
+size_t fitgnn_narrow_atb_workspace_bytes(int32_t n, int32_t K, int32_t H);
+int fitgnn_narrow_atb_f32(const float *d, int64_t ldd, const float *prev, uint32_t epilogue, float p_drop, uint64_t seed,
+                          const uint8_t *mask, const float *a, int64_t lda, int32_t n, int32_t K, int32_t H, float *dW, float *db,
+                          void *work, size_t work_bytes, void *stream);
 
 /* Backward SpMM with the epilogue backward folded in: dH = A^T dZ with dZ (above) formed while the operand rows are
  * staged, never written to memory; db / dWl reduced over tiles in a fixed order.  (rowptr, col, val, tiles) describe

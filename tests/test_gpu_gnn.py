@@ -490,7 +490,7 @@ def test_flat_adam_equals_torch_adam(mods):
     ref2 = torch.optim.Adam(qs, lr=0.01, weight_decay=5e-4)
     ref2.load_state_dict(sd)          # torch accepts it
     opt.load_state_dict(ref.state_dict())
-    assert float(opt.step_count) == 5.0 and rel(opt._views(opt.m)[2], ref.state[qs[2]]["exp_avg"]) < 1e-6
+    assert float(opt.step_count[0]) == 5.0 and rel(opt._views(opt.m)[2], ref.state[qs[2]]["exp_avg"]) < 1e-6
 
 
 def test_pruned_last_layer_equals_full_evaluation(mods):
@@ -957,3 +957,138 @@ def test_row_index_caches_follow_the_index_tensor_not_its_address(mods):
         assert rel(a, b) < 2e-4
     for a, b in zip(g_first, grads(first, False)):
         assert rel(a, b) < 2e-4
+
+
+@pytest.mark.parametrize("K,H,n,layers", [(11, 512, 1237, 2), (3, 64, 77, 2), (32, 128, 333, 1), (1, 16, 5, 2), (17, 256, 2050, 3)])
+@pytest.mark.parametrize("mode", ["eval", "masks", "hashed"])
+def test_narrow_first_layer_runs_aggregate_first_with_the_same_values(mods, K, H, n, layers, mode):
+    """ops.FusedGCNLayerAggregatedInput (A_hat x formed once, fitgnn_dense_narrow_k_f32 / fitgnn_narrow_atb_f32) against the
+    transform-first layer (OpConfig(narrow_input_first=False)) and against the oracle: logits, loss, every gradient."""
+    network, fnn, gorc = mods
+    from fitgnn_amd import ops
+
+    ei, _ = graph(n=n, m=3 * n, seed=K + n)
+    args = argparse.Namespace(num_layers1=layers, layer_name="GCNConv", num_features=K, hidden=H, num_classes=5)
+    torch.manual_seed(K * 7 + H)
+    model = network.Classify_node(args).cuda()
+    with torch.no_grad():
+        for c in model.conv:
+            c.bias.normal_(std=0.1)
+    x = torch.rand(n, K) - 0.3
+    y = torch.randint(0, 5, (n,))
+    tm = torch.rand(n) < 0.4
+    tm[0] = True
+    masks = None
+    if mode == "eval":
+        model.eval()
+    else:
+        model.train()
+        if mode == "masks":
+            masks = [(torch.rand(n, H) > 0.5).to(torch.uint8) for _ in range(layers)]
+            model._inject_masks = [m.cuda() for m in masks]
+    xg, eig = x.cuda(), ei.cuda()
+    res = {}
+    for narrow in (True, False):
+        model.set_op_config(ops.DEFAULT.replace(narrow_input_first=narrow))
+        model.zero_grad()
+        torch.manual_seed(99)   # the hashed dropout draws its per-layer seeds from torch's generator
+        # embed() is the graph-level models' path; the node-level head follows it here
+        out = torch.nn.functional.log_softmax(model.head(model.embed(xg, eig)), dim=1)
+        loss = torch.nn.functional.nll_loss(out[tm.cuda()], y.cuda()[tm.cuda()])
+        loss.backward()
+        res[narrow] = (out.detach().cpu(), float(loss), {k: p.grad.detach().cpu().clone() for k, p in model.named_parameters()})
+    g = model.conv[0].graph(eig, n)
+    assert getattr(g, "_agg_input", None) is not None and g._agg_input[0] is xg, "the aggregate-first node did not run"
+    assert g._agg_input[2].shape == (n, K)
+    a, b = res[True], res[False]
+    assert rel(a[0], b[0]) < 2e-5
+    assert abs(a[1] - b[1]) < 2e-5 * abs(b[1])
+    for k in b[2]:
+        assert rel(a[2][k], b[2][k]) < 2e-4, k
+    if mode != "hashed":
+        sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+        o_ref, l_ref, g_ref = gorc.classify_node_fwd_bwd(sd, x, ei, y, num_layers=layers, train_mask=tm, masks=masks)
+        assert rel(a[0], o_ref) < 1e-4
+        for k in g_ref:
+            assert rel(a[2][k], g_ref[k]) < 1e-3, k
+    # an in-place edit of the input re-forms A_hat x
+    before = g._agg_input[2].clone()
+    xg.mul_(2.0)
+    model.set_op_config(ops.DEFAULT)
+    model.embed(xg, eig)
+    assert rel(g._agg_input[2].cpu(), (2.0 * before).cpu()) < 1e-6
+
+
+@pytest.mark.parametrize("F_,C,with_rows", [(512, 1, True), (64, 3, False), (256, 8, True), (16, 2, True), (1024, 1, False)])
+def test_mean_pool_head_equals_pool_then_head(mods, F_, C, with_rows):
+    """ops.MeanPoolHead (fitgnn_pool_head_f32 / _bwd_f32: lt1(global_mean_pool(x[rows])) in one launch each way) against the pool
+    followed by the head in fp64: outputs, the input gradient on every row, the head's weight and bias gradients; empty graphs."""
+    from fitgnn_amd import ops
+
+    torch.manual_seed(F_ + C)
+    G = 37
+    sizes = torch.randint(0, 40, (G,))
+    sizes[5] = 0
+    sizes[-1] = 0
+    batch_all = torch.repeat_interleave(torch.arange(G), sizes)
+    n = int(batch_all.numel())
+    x = torch.randn(n, F_)
+    if with_rows:
+        rows = torch.nonzero(torch.rand(n) < 0.6).flatten()
+        batch = batch_all[rows]
+    else:
+        rows, batch = None, batch_all
+    W, b = torch.randn(C, F_) / F_ ** 0.5, torch.randn(C)
+    gy = torch.randn(G, C)
+    xg = x.cuda().requires_grad_(True)
+    Wg, bg = W.cuda().requires_grad_(True), b.cuda().requires_grad_(True)
+    assert ops.pool_head_supported(xg, Wg)
+    pi = ops.pool_index(batch.cuda(), G, None if rows is None else rows.cuda(), n)
+    y = ops.MeanPoolHead.apply(xg, pi, Wg, bg, ops.DEFAULT)
+    y.backward(gy.cuda())
+    xr, Wr, br = x.double().requires_grad_(True), W.double().requires_grad_(True), b.double().requires_grad_(True)
+    sel = xr if rows is None else xr[rows]
+    pooled = torch.zeros(G, F_, dtype=torch.float64).index_add_(0, batch, sel) / torch.bincount(batch, minlength=G).clamp(min=1).unsqueeze(1)
+    ref = pooled @ Wr.t() + br
+    ref.backward(gy.double())
+    assert rel(y.detach().cpu().double(), ref.detach()) < 1e-5
+    assert rel(xg.grad.cpu().double(), xr.grad) < 1e-5
+    assert rel(Wg.grad.cpu().double(), Wr.grad) < 1e-5
+    assert rel(bg.grad.cpu().double(), br.grad) < 1e-5
+    # twice to the same bits
+    xg2 = x.cuda().requires_grad_(True)
+    y2 = ops.MeanPoolHead.apply(xg2, pi, Wg.detach(), bg.detach(), ops.DEFAULT)
+    assert torch.equal(y2.detach(), y.detach())
+
+
+def test_adam_folds_a_fresh_gradient_buffer_and_advances_its_state(mods):
+    """FlatGrads.enable_fresh + FlatAdam.step (fitgnn_adam_step_acc_f32): gradients written to the fresh buffer (ops.OpConfig.grad_sink)
+    give the weights, moments and accumulated gradients of the same gradients added tensor by tensor (bit for bit); the buffer is
+    cleared; the step count and the seed bank move on once per step."""
+    from fitgnn_amd import ops, train
+
+    torch.manual_seed(0)
+    shapes = [(64, 24), (64,), (64, 64), (64,), (1, 64), (1,)]
+    ps = [torch.nn.Parameter(torch.randn(s, device="cuda")) for s in shapes]
+    qs = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    f1, f2 = train.FlatGrads(ps).enable_fresh(), train.FlatGrads(qs)
+    o1, o2 = train.FlatAdam(f1, lr=0.01, weight_decay=5e-4), train.FlatAdam(f2, lr=0.01, weight_decay=5e-4)
+    bank = ops.SeedBank(3, torch.device("cuda"))
+    expect = bank.seeds.clone()
+    o1.seed_bank = bank
+    for it in range(4):
+        for k, (p, q) in enumerate(zip(ps, qs)):
+            g = torch.randn_like(q)
+            if k % 2 == 0 or it == 2:
+                f1.view(p.data_ptr()).copy_(g)     # a backward node that knows the sink
+            else:
+                p.grad.add_(g)                      # autograd's own accumulation
+            q.grad.add_(g)                          # (never cleared between steps: run.py:254-304)
+        o1.step(); o2.step()
+        assert torch.equal(o1.P, o2.P) and torch.equal(o1.m, o2.m) and torch.equal(o1.v, o2.v), it
+        assert torch.equal(f1.grads, f2.grads)
+        assert float(f1.fresh.abs().max()) == 0.0
+        assert float(o1.step_count[0]) == it + 1 and float(o1.step_count[1]) == 0.0
+        expect.add_(ops.SeedBank.GOLD)   # (wraps modulo 2^64, as SeedBank.advance)
+        assert torch.equal(bank.seeds, expect)
+    assert f1.view(12345) is None
