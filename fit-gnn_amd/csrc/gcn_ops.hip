@@ -229,11 +229,12 @@ __global__ __launch_bounds__(256) void epilogue_bwd_kernel(const float *__restri
 // n_chunks / 64 partials (a thread's loads are a serial chain of L2 round trips: keep it short), then a fixed
 // binary tree over the 64 phases in LDS.
 constexpr int kColsumPhases = 64, kColsumCols = 16;
-// db2 / split (optional): columns >= split go to db2[h - split] (two destinations for one reduction: fitgnn_narrow_atb_f32's dW | db)
+// db2 / split (optional): columns >= split go to db2[h - split] (two destinations for one reduction: fitgnn_narrow_atb_f32's dW | db);
+// tr_rows / tr_cols (optional): the first tr_rows x tr_cols columns are a row-major matrix that is stored transposed
 __global__ __launch_bounds__(kColsumPhases * kColsumCols) void colsum_partials_kernel(const float *__restrict__ partial,
                                                                                       int32_t n_chunks, int32_t H,
                                                                                       float *__restrict__ db, float *__restrict__ db2 = nullptr,
-                                                                                      int32_t split = 0) {
+                                                                                      int32_t split = 0, int32_t tr_rows = 0, int32_t tr_cols = 0) {
     __shared__ float red[kColsumPhases][kColsumCols];
     const int cl = threadIdx.x % kColsumCols, ph = threadIdx.x / kColsumCols;
     const int h = blockIdx.x * kColsumCols + cl;
@@ -250,6 +251,7 @@ __global__ __launch_bounds__(kColsumPhases * kColsumCols) void colsum_partials_k
     }
     if (ph == 0 && h < H) {
         if (db2 && h >= split) db2[h - split] = red[0][cl];
+        else if (tr_rows > 0 && h < tr_rows * tr_cols) db[(h % tr_cols) * tr_rows + h / tr_cols] = red[0][cl];   // [tr_rows x tr_cols] -> its transpose
         else db[h] = red[0][cl];
     }
 }
@@ -351,8 +353,12 @@ __global__ __launch_bounds__(256) void adam_flat_acc_kernel(float4 *__restrict__
     const float t = state[0] + 1.0f;
     const float bc1 = 1.0f - powf(b1, t), bc2s = sqrtf(1.0f - powf(b2, t));
     const float step_size = lr / bc1;
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n4) {
+    // four float4 per thread: a quarter of the workgroups, i.e. of the tickets taken below (the atomics of ~260 workgroups were most
+    // of the launch on a 270 k-float model)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int64_t i = ((int64_t)blockIdx.x * 4 + u) * 256 + threadIdx.x;
+        if (i >= n4) continue;
         float4 pp = p[i], gg = g_acc[i], mm = m[i], vv = v[i];
         if (g_new) {
             const float4 gn = g_new[i];
@@ -518,6 +524,52 @@ __global__ __launch_bounds__(256) void dense_narrow_k_kernel(const float *__rest
             s_a[i] = a[(int64_t)(r0 + r) * lda + k];
         }
         __syncthreads();
+        // a thread owns ONE column group and takes the chunk's rows four at a time (PH = 256 / H4 row phases when H4 divides 256,
+        // else a plain item loop): W^T's float4 of a k is read once per four rows and the four dot products advance together --
+        // taken one (row, column group) at a time, every k was an LDS round trip with nothing else in flight
+        if (256 % H4 == 0) {
+            const int PH = 256 / H4, cg = threadIdx.x % H4, ph = threadIdx.x / H4;
+            const int col0 = 4 * cg;
+            for (int rg = ph; rg < rows; rg += 4 * PH) {
+                float x[4][4];
+                int rr[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    rr[u] = min(rg + u * PH, rows - 1);   // clamped: computed again, not stored
+                    x[u][0] = x[u][1] = x[u][2] = x[u][3] = 0.f;
+                }
+#pragma unroll 4
+                for (int k = 0; k < K; ++k) {
+                    const float4 w = *reinterpret_cast<const float4 *>(s_w + k * H + col0);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const float av = s_a[rr[u] * K + k];
+                        x[u][0] = fmaf(av, w.x, x[u][0]); x[u][1] = fmaf(av, w.y, x[u][1]);
+                        x[u][2] = fmaf(av, w.z, x[u][2]); x[u][3] = fmaf(av, w.w, x[u][3]);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (rg + u * PH >= rows) break;
+                    const int64_t orow = r0 + rr[u];
+                    const uint64_t idx0 = (uint64_t)orow * (uint64_t)H + (uint64_t)col0;
+                    uint64_t bits = 0;
+                    if ((epi & FITGNN_EPI_DROPOUT) && !mask) bits = fitgnn::dropout_bits(seed, idx0 >> 2);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float y = x[u][e] + ((epi & FITGNN_EPI_BIAS) ? bias[col0 + e] : 0.f);
+                        if (epi & FITGNN_EPI_ELU) y = y > 0.f ? y : __expf(y) - 1.0f;
+                        if (epi & FITGNN_EPI_DROPOUT) {
+                            const bool keep = mask ? (mask[idx0 + e] != 0) : fitgnn::dropout_keep(bits, (int)((idx0 + e) & 3), thresh);
+                            y = keep ? y * keep_scale : 0.f;
+                        }
+                        x[u][e] = y;
+                    }
+                    *reinterpret_cast<float4 *>(out + orow * ldo + col0) = make_float4(x[u][0], x[u][1], x[u][2], x[u][3]);
+                }
+            }
+            continue;
+        }
         for (int it = threadIdx.x; it < rows * H4; it += 256) {
             const int r = it / H4;
             const int col0 = (it - r * H4) * 4;
@@ -559,6 +611,7 @@ __global__ __launch_bounds__(256) void narrow_atb_kernel(const float *__restrict
                                                          const float *__restrict__ a, int64_t lda, int32_t n, int32_t K, int32_t H,
                                                          float *__restrict__ partial) {
     __shared__ float s_a[kNarrowAtbRows * KT];
+    __shared__ float4 s_red[256];
     const uint64_t seed = fitgnn::resolve_seed(seed_arg, epi);
     const float keep_scale = (epi & FITGNN_EPI_DROPOUT) ? 1.0f / (1.0f - p_drop) : 1.0f;
     const float unscale = (epi & FITGNN_EPI_DROPOUT) ? 1.0f - p_drop : 1.0f;
@@ -577,7 +630,7 @@ __global__ __launch_bounds__(256) void narrow_atb_kernel(const float *__restrict
     for (int e = 0; e < 4; ++e)
 #pragma unroll
         for (int k = 0; k < KT; ++k) acc[e][k] = 0.f;
-    constexpr int U = 4;   // rows in flight per thread: every load of a group is issued before the first use
+    constexpr int U = KT <= 16 ? 8 : 4;   // rows in flight per thread: every load of a group is issued before the first use
     for (int rg = ph; rg < rows; rg += PH * U) {
         float4 dv[U], ov[U];
 #pragma unroll
@@ -621,13 +674,26 @@ __global__ __launch_bounds__(256) void narrow_atb_kernel(const float *__restrict
             }
         }
     }
-    float *dst = partial + ((int64_t)blockIdx.x * PH + ph) * ((int64_t)H * K + H);
+    // the row phases of the block are added in ascending order through LDS, one k at a time, and the block's partial row is stored
+    // k-major, [K][H] then the H bias sums: float4 stores, coalesced over the column groups (stored [H][K] every lane wrote 4-byte
+    // pieces 44 bytes apart); the final reduction transposes
+    float *dst = partial + (int64_t)blockIdx.x * ((int64_t)H * K + H);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-#pragma unroll
-        for (int k = 0; k < KT; ++k)
-            if (k < K) dst[(int64_t)(4 * cg + e) * K + k] = acc[e][k];
-        dst[(int64_t)H * K + 4 * cg + e] = bsum[e];
+    for (int k = 0; k <= KT; ++k) {
+        if (k < KT && k >= K) continue;
+        const float4 mine = k < KT ? make_float4(acc[0][k < KT ? k : 0], acc[1][k < KT ? k : 0], acc[2][k < KT ? k : 0], acc[3][k < KT ? k : 0])
+                                   : make_float4(bsum[0], bsum[1], bsum[2], bsum[3]);
+        __syncthreads();
+        s_red[threadIdx.x] = mine;
+        __syncthreads();
+        if (ph == 0) {
+            float4 t = s_red[cg];
+            for (int q = 1; q < PH; ++q) {
+                const float4 o = s_red[q * H4 + cg];
+                t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w;
+            }
+            *reinterpret_cast<float4 *>(dst + (int64_t)(k < KT ? k : K) * H + 4 * cg) = t;
+        }
     }
 }
 
@@ -773,7 +839,7 @@ extern "C" int fitgnn_adam_step_acc_f32(float *param, float *grad_acc, float *gr
         ((uintptr_t)state % 4) != 0)
         return FITGNN_E_ALIGN;
     const int64_t n4 = n / 4;
-    hipLaunchKernelGGL(adam_flat_acc_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (float4 *)param,
+    hipLaunchKernelGGL(adam_flat_acc_kernel, dim3((unsigned)((n4 + 1023) / 1024)), dim3(256), 0, (hipStream_t)stream, (float4 *)param,
                        (float4 *)grad_acc, (float4 *)grad_new, (float4 *)exp_avg, (float4 *)exp_avg_sq, n4, lr, beta1, beta2, eps,
                        weight_decay, state, (unsigned long long *)seeds, n_seeds, (unsigned long long)seed_stride);
     return (int)hipGetLastError();
@@ -972,8 +1038,8 @@ extern "C" int fitgnn_dense_narrow_k_f32(const float *a, int64_t lda, const floa
     if ((epilogue & FITGNN_EPI_BIAS) && !bias) return FITGNN_E_BADARG;
     if ((epilogue & FITGNN_EPI_DROPOUT) && !(p_drop >= 0.f && p_drop < 1.f)) return FITGNN_E_BADARG;
     if (((uintptr_t)out % 16) != 0) return FITGNN_E_ALIGN;
-    // one range of rows per block, about a block per CU: W^T is staged once per block
-    int rows_per_block = std::max((n + 255) / 256, 8);
+    // one range of rows per block: W^T is staged once per block
+    int rows_per_block = std::max((n + 511) / 512, 8);   // two workgroups per CU: one's LDS round trips under the other's
     const int blocks = (n + rows_per_block - 1) / rows_per_block;
     hipLaunchKernelGGL(dense_narrow_k_kernel, dim3(blocks), dim3(256), lds, (hipStream_t)stream, a, lda, W, ldw, n, K, H, bias, epilogue,
                        p_drop, seed, mask, out, ldo, rows_per_block);
@@ -984,7 +1050,7 @@ extern "C" int fitgnn_dense_narrow_k_f32(const float *a, int64_t lda, const floa
 extern "C" size_t fitgnn_narrow_atb_workspace_bytes(int32_t n, int32_t K, int32_t H) {
     if (n <= 0 || K < 1 || K > kNarrowKMax || H < 4 || (H % 4) != 0 || (H / 4) > 256 || (256 % (H / 4)) != 0) return 0;
     const size_t blocks = ((size_t)n + kNarrowAtbRows - 1) / kNarrowAtbRows;
-    return blocks * (size_t)(256 / (H / 4)) * ((size_t)H * (size_t)K + (size_t)H) * sizeof(float);
+    return blocks * ((size_t)H * (size_t)K + (size_t)H) * sizeof(float);
 }
 
 extern "C" int fitgnn_narrow_atb_f32(const float *d, int64_t ldd, const float *prev, uint32_t epilogue, float p_drop, uint64_t seed,
@@ -999,14 +1065,14 @@ extern "C" int fitgnn_narrow_atb_f32(const float *d, int64_t ldd, const float *p
     if ((((uintptr_t)d | (uintptr_t)prev) % 16) != 0) return FITGNN_E_ALIGN;
     hipStream_t s = (hipStream_t)stream;
     const int blocks = (n + kNarrowAtbRows - 1) / kNarrowAtbRows;
-    const int parts = blocks * (256 / (H / 4));
+    const int parts = blocks;
     const int width = H * K + H;
     float *partial = (float *)work;
     if (K <= 8) hipLaunchKernelGGL(narrow_atb_kernel<8>, dim3(blocks), dim3(256), 0, s, d, ldd, prev, epilogue, p_drop, seed, mask, a, lda, n, K, H, partial);
     else if (K <= 16) hipLaunchKernelGGL(narrow_atb_kernel<16>, dim3(blocks), dim3(256), 0, s, d, ldd, prev, epilogue, p_drop, seed, mask, a, lda, n, K, H, partial);
     else hipLaunchKernelGGL(narrow_atb_kernel<32>, dim3(blocks), dim3(256), 0, s, d, ldd, prev, epilogue, p_drop, seed, mask, a, lda, n, K, H, partial);
     hipLaunchKernelGGL(colsum_partials_kernel, dim3((width + kColsumCols - 1) / kColsumCols), dim3(kColsumPhases * kColsumCols), 0, s, partial,
-                       parts, width, dW, db, H * K);
+                       parts, width, dW, db, H * K, K, H);
     return (int)hipGetLastError();
 }
 

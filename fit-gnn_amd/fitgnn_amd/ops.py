@@ -1324,7 +1324,8 @@ def _dx_through_link(cfg, link, dH, W, X):
     """dX = dH @ W for the consumer of a linked layer (tensor to return as the input gradient): with cfg.fuse_dx_epilogue
     the GEMM's epilogue applies the producing layer's ELU'/dropout' (csrc/gemm_nt.hip, EPI) instead of writing dOut and
     running the epilogue-backward kernel over it."""
-    if link is not None and cfg.fuse_dx_epilogue and W.shape[1] % 4 == 0 and X.is_contiguous() and X.dtype == torch.float32:
+    if (link is not None and cfg.fuse_dx_epilogue and cfg.gemm_precision == "high" and W.shape[1] % 4 == 0 and X.is_contiguous()
+            and X.dtype == torch.float32):   # (only the 3 x bf16 kernel carries the epilogue: no W^T operand is formed otherwise)
         dH = _f32c(dH)
         Wt = _wt_operand(dH, W, cfg)
         if _nt_ok(dH, Wt, cfg):

@@ -327,7 +327,8 @@ class _CapturedSteps:
     _steps() (the batches) and _one(batch) (one eager step returning the detached loss)."""
 
     def _build_graphs(self):
-        """Capture one hipGraph per batch (shared memory pool: the graphs replay one after another, in order)."""
+        """Capture the steps in hipGraphs of `steps_per_graph` (8) consecutive batches each (shared memory pool: the graphs replay one
+        after another, in order)."""
         from . import ops
 
         dev = self.flat.buf.device
@@ -378,16 +379,19 @@ class _CapturedSteps:
             self.flat.zero()
             pool = torch.cuda.graph_pool_handle()
             self._graphs = []
-            for k, b in enumerate(self._steps()):
+            steps = self._steps()
+            per = max(int(getattr(self, "steps_per_graph", 8)), 1)   # consecutive steps share a hipGraph: a replay costs ~9 us of its own
+            for k0 in range(0, len(steps), per):
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, pool=pool):
-                    if not adam_advances:
-                        self._bank.advance()
-                    self._bank.cursor = 0
-                    slot = self._losses[k:k + 1]
-                    r = self._one(b, loss_out=slot)   # (a loss kernel that can write the slot itself saves the copy)
-                    if r.data_ptr() != slot.data_ptr():
-                        slot.copy_(r.view(1))
+                    for k in range(k0, min(k0 + per, len(steps))):
+                        if not adam_advances:
+                            self._bank.advance()
+                        self._bank.cursor = 0
+                        slot = self._losses[k:k + 1]
+                        r = self._one(steps[k], loss_out=slot)   # (a loss kernel that can write the slot itself saves the copy)
+                        if r.data_ptr() != slot.data_ptr():
+                            slot.copy_(r.view(1))
                 self._graphs.append(g)
             # capturing does not execute: the weights are untouched, but the gradient buffer was only zeroed eagerly
             self.flat.zero()
