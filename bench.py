@@ -74,6 +74,11 @@ def parse_args():
                     help="A/B: layer 0 on the de-duplicated table through the LDS-window SpMM (row indirection) instead of the "
                          "direct-gather variant")
     ap.add_argument("--stream-kernel", action="store_true", help="A/B: the segment-streaming kernel (one wave per run of segments, no LDS) instead of the whole-subgraph kernel")
+    ap.add_argument("--reshuffle", default="off", choices=["off", "replay", "eager"],
+                    help="S-qm9: re-draw the graph order before every epoch as the reference's DataLoader(shuffle=True) does (run.py:710). "
+                         "replay: batches assembled on the device into fixed-capacity buffers, ONE captured step replayed for every batch "
+                         "(graph_data.PaddedBatchPlan); eager: every batch's CSR rebuilt on the host, steps run eagerly; off (default): the "
+                         "order is drawn once and each batch's captured step replayed")
     ap.add_argument("--round3-graph-step", action="store_true",
                     help="A/B (S-qm9): the batch step as round 3 had it -- first layer transform-first (its two SpMMs per step), pool / scale / "
                          "library product / bias add for the head, `grad += new` per tensor, loss.backward() from a ones fill")
@@ -665,7 +670,8 @@ def bench_qm9(args, device, world, rank, backend):
     lean = not args.round3_graph_step
     cfg = ops.OpConfig(gemm_precision=args.gemm_precision, narrow_input_first=lean, fused_pool_head=lean)
     model.set_op_config(cfg)
-    tr = train.GraphTrainer(model, gset, graphs, kind="gs", batch_size=128, lr=0.001, capture=(world == 1), lean_step=lean)
+    tr = train.GraphTrainer(model, gset, graphs, kind="gs", batch_size=128, lr=0.001, capture=(world == 1 and args.reshuffle != "eager"),
+                            lean_step=lean, reshuffle=args.reshuffle != "off")
     cfg_step = model.op_config   # (the trainer's copy: + its gradient sink)
     torch.cuda.synchronize()
     t3 = time.time()
@@ -737,7 +743,10 @@ def bench_qm9(args, device, world, rank, backend):
                                   "gradients written where the optimiser kernel reads them" if lean else "; round 3's batch step (A/B)"),
                    "parallelism": f"dp{world}", "backend": backend, "graphs": n_graphs, "training_graphs": len(graphs),
                    "union_rows_per_epoch": int(rows_total), "nnz_prime_per_epoch": int(nnz_total), "dropout_p": args.dropout,
-                   "captured": bool(tr.capture), "t_molecules_s": round(t1 - t0, 2), "t_coarsen_pool_assemble_s": round(t2 - t1, 2),
+                   "captured": bool(tr.capture or tr._plan is not None), "reshuffle": args.reshuffle,
+                   "padded_batch": (None if tr._plan is None else {"R_cap": tr._plan.R_cap, "E_cap": tr._plan.E_cap, "T_cap": tr._plan.T_cap,
+                                                                   "mean_rows": rows / max(len(tr.batches), 1)}),
+                   "t_molecules_s": round(t1 - t0, 2), "t_coarsen_pool_assemble_s": round(t2 - t1, 2),
                    "t_batches_and_capture_s": round(t3 - t2, 2)},
         "roofline": {"kernel": "spmm_tile_kernel (CSR SpMM, LDS row windows, H=%d, f32) on 128-molecule batches" % H, "bound": "hbm",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,

@@ -113,6 +113,9 @@ SIGNATURES = {
     "fitgnn_csr_row_sum_f32": (ctypes.c_int, [ptr, ptr, c_i32, ptr, ptr]),
     "fitgnn_induced_edges_count": (ctypes.c_int, [ptr, ptr, ptr, ptr, ptr, ptr, c_i64, ptr, ptr]),
     "fitgnn_induced_edges_fill": (ctypes.c_int, [ptr, ptr, ptr, ptr, ptr, ptr, ptr, c_i64, ptr, ptr, ptr, ptr]),
+    "fitgnn_batch_offsets": (ctypes.c_int, [ptr, ptr, c_i32, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr]),
+    "fitgnn_batch_gather": (ctypes.c_int, [c_i32, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, c_i32, ptr, c_i32, c_i32,
+                                           c_i32, c_i32, c_i32, c_i32, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, c_i32, ptr, ptr]),
     "fitgnn_closed_neighbourhoods": (ctypes.c_int, [ptr, ptr, c_i32, ptr, ptr, ptr]),
     "fitgnn_variation_costs_f64": (ctypes.c_int, [ptr, ptr, ptr, ptr, ptr, c_i32, c_i64, ptr, ptr, ptr, c_i32, ptr, ptr]),
     "fitgnn_variation_costs_batch_f64": (ctypes.c_int, [ptr, ptr, ptr, ptr, ptr, c_i32, c_i64, ptr, ptr, ptr, ptr, c_i32, ptr, ptr]),

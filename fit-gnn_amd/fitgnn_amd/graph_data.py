@@ -202,3 +202,143 @@ class GraphSet:
         if dev.type == "cuda" and r1 > r0:
             register(e, CSRGraph(e, r1 - r0, mode="gcn", ptr=blocks), "gcn")
         return dict(x=x, edge_index=e, graph=graph, mask=mask, y=self.y[g0:g1], n_graphs=g1 - g0)
+
+
+class PaddedBatchPlan:
+    """Batches of ANY graphs of a GraphSet's subgraph view ('gs') assembled on the device into buffers of fixed capacity, so that one
+    captured hipGraph serves every batch of every epoch of a reshuffling loader (run.py:710 DataLoader(shuffle=True);
+    train.GraphTrainer(reshuffle=True, capture=True)).
+
+    Built once per (set, batch size): the whole dataset's normalised CSR (rows, entries and row tiles of a graph contiguous and
+    cut at graph boundaries), its pooled-row lists, the first layer's aggregated input A_hat x of EVERY row (ops.aggregated_input's
+    product, formed once for the dataset: A_hat is block diagonal per graph, so a batch's A_hat x is a gather of rows), the truncated
+    targets.  `assemble()` issues fitgnn_batch_offsets + fitgnn_batch_gather for the batch perm[step B .. + B) (step: a device
+    counter the first kernel advances); `batch` is the static batch dict those launches fill, shaped like GraphSet.batch_ids':
+    x / edge_index are stand-ins whose cached CSR graph, aggregated input and pool index are the plan's buffers.
+    Capacities: mean + `sigmas` standard deviations of a batch's totals (rows, entries, tiles, pooled rows): GEMMs and SpMMs of the
+    step run over R_cap rows, the surplus rows being empty; `fits(ids)` tells the host -- which knows every graph's sizes -- whether a
+    batch fits (a batch that does not is run the eager way)."""
+
+    def __init__(self, gset, batch_size, target_fn, model_features=None, sigmas=6.0):
+        from . import _lib, ops
+
+        dev = gset.x.device
+        B = int(batch_size)
+        assert dev.type == "cuda" and 1 <= B <= 1024
+        G = gset.n_graphs
+        self.gset, self.B, self.dev = gset, B, dev
+        whole = gset.batch(0, G, "gs")                       # the dataset as ONE block-diagonal batch: its CSR, normalised
+        self._whole = whole                                  # (the CSR cache is keyed on this edge tensor: keep it alive)
+        g_all = ops_csr_for(whole["edge_index"], int(gset.gs_ptr[-1]))
+        f, t = g_all.f, g_all.t
+        if not (torch.equal(f.rowptr, t.rowptr) and torch.equal(f.col, t.col) and torch.equal(f.val, t.val)):
+            raise ValueError("the subgraph union's normalised adjacency is not symmetric: its transpose cannot share the batch's CSR")
+        R = int(gset.gs_ptr[-1])
+        rp_host = f.rowptr.cpu().numpy().astype(np.int64)
+        g_row = np.asarray(gset.gs_ptr, dtype=np.int64)
+        g_nnz = rp_host[g_row]
+        # row tiles: the usual packing of the cluster subgraphs' blocks, cut at every graph boundary (a tile's window is its own rows,
+        # and graph boundaries are block boundaries: both halves of a cut tile are valid tiles)
+        from .csr import make_tiles, TILE_INTS
+        base = make_tiles(np.asarray(gset.sub_ptr, dtype=np.int64), g_all.window_rows)
+        starts = np.union1d(base["row_begin"].astype(np.int64), g_row[:-1])
+        starts = starts[starts < R]
+        ends = np.append(starts[1:], R)
+        tiles = np.zeros((len(starts), TILE_INTS), dtype=np.int32)
+        tiles[:, 0], tiles[:, 1], tiles[:, 2], tiles[:, 3] = starts, ends, starts, ends - starts
+        tiles[:, 4], tiles[:, 5] = rp_host[starts], rp_host[ends]
+        g_tile = np.searchsorted(starts, g_row, side="left")
+        pooled = gset.gs_mask.to(torch.uint8).contiguous()
+        mem = torch.nonzero(gset.gs_mask).flatten().to(torch.int32).contiguous()          # ascending: grouped by graph
+        g_mem = np.searchsorted(mem.cpu().numpy().astype(np.int64), g_row, side="left")
+        self.sizes = np.stack([np.diff(g_row), np.diff(g_nnz), np.diff(g_tile), np.diff(g_mem)], 1).astype(np.int64)   # [G, 4]
+        mean, std = self.sizes.mean(0), self.sizes.std(0)
+        cap = np.ceil(B * mean + sigmas * np.sqrt(B) * std + 1).astype(np.int64)
+        cap = np.minimum(cap, np.sort(self.sizes, 0)[::-1][:B].sum(0))                   # never beyond the true worst case
+        self.R_cap = int((cap[0] + 63) // 64 * 64)
+        self.E_cap = int(cap[1] + 64)
+        self.T_cap = int(cap[2] + self.R_cap // 16 + 2)      # + the tiles that cover the rows past a batch's total
+        self.M_cap = int(cap[3] + 64)
+        self.caps = np.array([self.R_cap, self.E_cap, int(cap[2]), self.M_cap], dtype=np.int64)
+        i32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(dev)  # noqa: E731
+        self.g_row, self.g_nnz, self.g_tile, self.g_mem = i32(g_row), i32(g_nnz), i32(g_tile), i32(g_mem)
+        self.rowptr, self.col, self.val = f.rowptr, f.col, f.val
+        self.tiles, self.mem, self.pooled = torch.from_numpy(tiles).to(dev), mem, pooled
+        x = gset.gs_x
+        self.K = int(x.shape[1])
+        self.ax = ops.aggregated_input(g_all, x).contiguous()                             # [R, K]
+        self.tgt = target_fn(gset.y).contiguous()                                         # [G, 1]
+        self.n_tgt = int(self.tgt.shape[1])
+        # ---- the batch's buffers ----
+        z = lambda n, dt: torch.zeros(n, dtype=dt, device=dev)                            # noqa: E731
+        self.b_rowptr, self.b_col, self.b_val = z(self.R_cap + 1, torch.int32), z(self.E_cap, torch.int32), z(self.E_cap, torch.float32)
+        self.b_tiles = torch.zeros((self.T_cap, TILE_INTS), dtype=torch.int32, device=dev)
+        self.b_members, self.b_seg_off = z(self.M_cap, torch.int32), z(B + 1, torch.int32)
+        self.b_seg_of_row, self.b_inv_cnt = z(self.R_cap, torch.int32), z(B, torch.float32)
+        self.b_ax = torch.zeros((self.R_cap, self.K), dtype=torch.float32, device=dev)
+        self.b_tgt = torch.zeros((B, self.n_tgt), dtype=torch.float32, device=dev)
+        self.off, self.gid = z(4 * (B + 1), torch.int32), z(B, torch.int32)
+        self.step_idx = z(1, torch.int32)
+        self.loss_slot, self.loss_sum = z(1, torch.float32), z(1, torch.float32)
+        self.perm = None                                     # int64 [>= steps x B]: set_epoch()
+        self.batch = self._static_batch(g_all)
+        self._L, self._lib = _lib.lib(), _lib
+
+    def _static_batch(self, g_all):
+        """The batch dict the model is stepped on: stand-in x / edge_index / index tensors whose cached objects are the plan's buffers."""
+        from . import ops
+        from .csr import CSRGraph, _Side, register
+
+        dev, B = self.dev, self.B
+        side = _Side(self.b_rowptr, self.b_col)
+        side.val, side.tiles, side.n_tiles = self.b_val, self.b_tiles, self.T_cap
+        g = object.__new__(CSRGraph)
+        g.device, g.n, g.mode, g.nnz = dev, self.R_cap, "gcn", self.E_cap
+        g.planned, g.gather, g.split_large, g.block_limit = False, False, False, None
+        g.fold_ok, g.f, g.t = False, side, side               # symmetric normalised adjacency: the transpose is the matrix itself
+        g.dinv, g.seg, g.range_seg, g.window_rows, g.ptr = None, None, None, g_all.window_rows, None
+        x = torch.zeros((self.R_cap, self.K), dtype=torch.float32, device=dev)            # never read: the first layer runs on b_ax
+        e = torch.zeros((2, 1), dtype=torch.int64, device=dev)
+        register(e, g, "gcn")
+        g._agg_input = (x, x._version, self.b_ax)
+        rows = torch.zeros(self.M_cap, dtype=torch.int64, device=dev)                     # stand-ins for mask_idx / graph_of_masked
+        batch = torch.zeros(self.M_cap, dtype=torch.int64, device=dev)
+        pi = object.__new__(ops.PoolIndex)
+        pi.n_seg, pi.sorted, pi.seg_off, pi.members = B, True, self.b_seg_off, self.b_members
+        pi.n_rows, pi.seg_of_row, pi.inv_cnt = self.R_cap, self.b_seg_of_row, self.b_inv_cnt
+        batch._fitgnn_pool = ((batch._version, B, (rows.data_ptr(), rows._version), self.R_cap), pi, rows)
+        self.graph = g
+        return dict(x=x, edge_index=e, mask=None, mask_idx=rows, graph_of_masked=batch, y=self.b_tgt, _tgt=self.b_tgt, n_graphs=B)
+
+    def fits(self, ids):
+        """ids [n, B] (host): which of the n batches fit the capacities."""
+        tot = self.sizes[np.asarray(ids, dtype=np.int64)].sum(1)                           # [n, 4]
+        return (tot <= self.caps[None, :]).all(1)
+
+    def set_epoch(self, ids_flat):
+        """Upload the epoch's graph order (host int64 array, whole batches) and rewind the step counter and the loss sum."""
+        t = torch.from_numpy(np.ascontiguousarray(ids_flat, dtype=np.int64))
+        if self.perm is None or self.perm.numel() < t.numel():
+            self.perm = torch.zeros(max(t.numel(), 1), dtype=torch.int64, device=self.dev)
+        self.perm[: t.numel()].copy_(t)
+        self.step_idx.zero_(); self.loss_sum.zero_(); self.loss_slot.zero_()
+
+    def assemble(self):
+        """The two launches that fill the static batch with perm[step B .. + B) (capturable)."""
+        L, lb = self._L, self._lib
+        st = lb.stream_ptr(self.dev)
+        d = lb.dptr
+        lb.check(L.fitgnn_batch_offsets(d(self.perm), d(self.step_idx), self.B, d(self.g_row), d(self.g_nnz), d(self.g_tile), d(self.g_mem),
+                                        d(self.off), d(self.gid), d(self.loss_slot), d(self.loss_sum), st), "fitgnn_batch_offsets")
+        lb.check(L.fitgnn_batch_gather(self.B, d(self.off), d(self.gid), d(self.g_row), d(self.g_nnz), d(self.g_tile), d(self.g_mem),
+                                       d(self.rowptr), d(self.col), d(self.val), d(self.tiles), d(self.mem), d(self.pooled), d(self.ax),
+                                       self.ax.stride(0), d(self.tgt), self.n_tgt, self.K, self.R_cap, self.E_cap, self.T_cap, self.M_cap,
+                                       d(self.b_rowptr), d(self.b_col), d(self.b_val), d(self.b_tiles), d(self.b_members), d(self.b_seg_off),
+                                       d(self.b_seg_of_row), d(self.b_inv_cnt), d(self.b_ax), self.b_ax.stride(0), d(self.b_tgt), st),
+                 "fitgnn_batch_gather")
+
+
+def ops_csr_for(edge_index, n):
+    from .csr import csr_for
+
+    return csr_for(edge_index, n, "gcn")

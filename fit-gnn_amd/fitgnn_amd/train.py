@@ -510,10 +510,13 @@ class GraphTrainer(_CapturedSteps):
         else:
             self.flat = FlatGrads(model.parameters())
             self.opt = _make_adam(model, self.flat, lr, weight_decay)
-        self._rebuild = None
+        self._rebuild, self._plan, self._shuffled_graph = None, None, None
         if batches is None and reshuffle:
+            want_capture = self.capture
             self.capture = False
             self._rebuild = (gset, [int(g) for g in graphs], kind, batch_size, types)
+            if want_capture:
+                self._plan = self._make_plan(gset, kind, batch_size, lean_step, share)
         if batches is not None:   # pre-built (entries may be None: this rank holds no graph of that batch)
             self.batches = list(batches)
             self.global_sizes = list(global_sizes) if global_sizes is not None else [int(b["y"].shape[0]) for b in self.batches]
@@ -618,6 +621,99 @@ class GraphTrainer(_CapturedSteps):
         self.opt.step()
         return loss.detach()
 
+    def _make_plan(self, gset, kind, batch_size, lean_step, share):
+        """reshuffle=True with capture=True: batches assembled on the device into fixed-capacity buffers (graph_data.PaddedBatchPlan)
+        and ONE captured step replayed for every full batch of every epoch.  Needs what makes the step independent of the batch's
+        contents: the subgraph view, a first GCN layer on the aggregated narrow input (its A_hat x is gathered like everything else),
+        the L1 regression step whose loss kernel writes a device slot, a single rank.  Otherwise None: the eager rebuild."""
+        from . import nn as fnn
+        from . import ops
+        from .graph_data import PaddedBatchPlan
+
+        model = self.model
+        ok = (kind == "gs" and lean_step and share is None and self.world == 1 and self.task == "graph_reg" and isinstance(self.opt, FlatAdam)
+              and gset is not None and gset.x.is_cuda and getattr(model, "num_layers", 0) > 0 and isinstance(model.conv[0], fnn.GCNConv))
+        if not ok:
+            return None
+        probe = torch.zeros((1, gset.gs_x.shape[1]), dtype=torch.float32, device=gset.x.device)
+        if not ops.narrow_input_supported(probe, model.conv[0].lin.weight, model.op_config):
+            return None
+        return PaddedBatchPlan(gset, batch_size, self._target)
+
+    def _build_shuffled_graph(self):
+        """Capture [assemble the batch at the device counter, forward, L1 loss, backward, Adam] once (PaddedBatchPlan.batch is static)."""
+        from . import ops
+
+        plan, dev = self._plan, self.flat.buf.device
+        bank = ops.SeedBank(max(len(self.model.conv), 1), dev)
+        saved_m = {k: v.detach().clone() for k, v in self.model.state_dict().items()}
+        saved_o = (self.opt.m.clone(), self.opt.v.clone(), self.opt.step_count.clone())
+        prev = self.model.op_config
+        self.model.set_op_config(prev.replace(seed_bank=bank))
+        self.opt.seed_bank = bank
+        try:
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                for _ in range(2):   # warm-up (library workspaces, autograd buffers) on the epoch's first batch
+                    plan.step_idx.zero_()
+                    plan.assemble()
+                    bank.cursor = 0
+                    self._one(plan.batch, loss_out=plan.loss_slot)
+            torch.cuda.current_stream(dev).wait_stream(side)
+            torch.cuda.synchronize(dev)
+            self.model.load_state_dict(saved_m)
+            self.opt.m.copy_(saved_o[0]); self.opt.v.copy_(saved_o[1]); self.opt.step_count.copy_(saved_o[2])
+            self.flat.zero()
+            plan.step_idx.zero_(); plan.loss_sum.zero_(); plan.loss_slot.zero_()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                plan.assemble()
+                bank.cursor = 0
+                self._one(plan.batch, loss_out=plan.loss_slot)
+            self._shuffled_graph, self._bank = g, bank
+            plan.step_idx.zero_(); plan.loss_sum.zero_(); plan.loss_slot.zero_()   # (capturing does not execute)
+        finally:
+            self.model.set_op_config(prev)
+
+    def _step_shuffled(self):
+        """One epoch over freshly shuffled batches: full batches that fit the plan's capacities replay the captured step, the others
+        (and a last, shorter batch) run the eager way."""
+        import numpy as np
+
+        plan = self._plan
+        gset, graphs, kind, batch_size, types = self._rebuild
+        perm = torch.randperm(len(graphs)).tolist()   # torch's generator, as the DataLoader's sampler
+        ids = np.asarray([graphs[i] for i in perm], dtype=np.int64)
+        B = plan.B
+        n_full = len(ids) // B
+        full = ids[: n_full * B].reshape(n_full, B)
+        fits = plan.fits(full) if n_full else np.zeros(0, dtype=bool)
+        plan.set_epoch(full.reshape(-1))
+        if self._shuffled_graph is None and n_full:
+            self._build_shuffled_graph()
+        self.flat.zero()
+        total = torch.zeros((), device=self.flat.buf.device)
+
+        def eager(id_list):
+            b = _cat_pieces([gset.batch_ids(id_list, kind)], kind, types)
+            b["_tgt"] = self._target(b["y"])
+            return self._one(b)
+
+        for k in range(n_full):
+            if fits[k]:
+                self._shuffled_graph.replay()
+            else:
+                plan.step_idx.add_(1)
+                total += eager(full[k].tolist())
+        n_batches = n_full
+        if len(ids) > n_full * B:
+            total += eager(ids[n_full * B:].tolist())
+            n_batches += 1
+        self.global_sizes = [B] * n_full + ([len(ids) - n_full * B] if n_batches > n_full else [])
+        total = total + plan.loss_sum[0] + plan.loss_slot[0]   # (the last replayed step's loss is still in its slot)
+        return total / max(n_batches, 1)
+
     def _reshuffle(self):
         gset, graphs, kind, batch_size, types = self._rebuild
         perm = torch.randperm(len(graphs)).tolist()   # torch's generator, as the DataLoader's sampler; same on every rank
@@ -631,6 +727,8 @@ class GraphTrainer(_CapturedSteps):
 
     def step(self):
         self.model.train()
+        if self._plan is not None:
+            return self._step_shuffled()
         if self._rebuild is not None:
             self._reshuffle()
         if self.capture and self.flat.buf.is_cuda:

@@ -615,6 +615,30 @@ int fitgnn_induced_edges_fill(const int64_t *adj_ptr, const int64_t *adj, const 
                               const int64_t *cl_ptr, const int64_t *key_node, const int64_t *inv, int64_t n_rows, const int64_t *off,
                               int64_t *e_src, int64_t *e_dst, void *stream);
 
+/* A training batch of a graph-level dataset assembled on the device (run.py:710: shuffle=True loaders -- every epoch's batches hold
+ * other graphs).  The dataset keeps, per graph g, contiguous ranges of union rows g_row_ptr[g .. g+1], CSR entries g_nnz_ptr (=
+ * rowptr[g_row_ptr[g]]), row tiles g_tile_ptr (no tile spans two graphs) and pooled rows g_mem_ptr (mem: global row ids of the rows
+ * that are pooled, grouped by graph; pooled: the same as one byte per row); the batch of graphs perm[step B .. step B + B), step =
+ * *step_idx, is those pieces re-based behind four exclusive scans.
+ * fitgnn_batch_offsets (one workgroup): off [4 x (B + 1)] int32 -- rows, entries, tiles, pooled rows; off[k][B] = the batch's totals --
+ * and gid [B] = the batch's graphs; *step_idx is advanced; loss_slot / loss_sum (both or neither): *loss_sum += *loss_slot, then the
+ * slot is cleared (the previous step's loss joins the epoch's sum inside the next step's first launch).  B <= 1024.
+ * fitgnn_batch_gather: fills the batch's fixed-capacity buffers: CSR b_rowptr [R_cap + 1] / b_col / b_val [E_cap], b_tiles [T_cap],
+ * the pool's b_members [M_cap] / b_seg_off [B + 1] / b_seg_of_row [R_cap] (graph of a pooled row, else -1) / b_inv_cnt [B], the first
+ * layer's aggregated input b_ax [R_cap x K] (row stride ld_ax) gathered from ax (row stride ld_ax_g), the targets b_tgt [B x n_tgt].
+ * Rows past the batch's total hold no entries and zeros in b_ax and are covered by tiles of their own (16 rows each: T_cap must
+ * leave room for them); entries / pooled rows past the totals are zeros.  The caller guarantees that the totals fit the capacities
+ * (it knows every graph's sizes). */
+int fitgnn_batch_offsets(const int64_t *perm, int32_t *step_idx, int32_t B, const int32_t *g_row_ptr, const int32_t *g_nnz_ptr,
+                         const int32_t *g_tile_ptr, const int32_t *g_mem_ptr, int32_t *off, int32_t *gid, float *loss_slot, float *loss_sum,
+                         void *stream);
+int fitgnn_batch_gather(int32_t B, const int32_t *off, const int32_t *gid, const int32_t *g_row_ptr, const int32_t *g_nnz_ptr,
+                        const int32_t *g_tile_ptr, const int32_t *g_mem_ptr, const int32_t *rowptr, const int32_t *col, const float *val,
+                        const fitgnn_tile_t *tiles, const int32_t *mem, const uint8_t *pooled, const float *ax, int32_t ld_ax_g,
+                        const float *tgt, int32_t n_tgt, int32_t K, int32_t R_cap, int32_t E_cap, int32_t T_cap, int32_t M_cap,
+                        int32_t *b_rowptr, int32_t *b_col, float *b_val, fitgnn_tile_t *b_tiles, int32_t *b_members, int32_t *b_seg_off,
+                        int32_t *b_seg_of_row, float *b_inv_cnt, float *b_ax, int32_t ld_ax, float *b_tgt, void *stream);
+
 /* Feature pooling Xc = C . X (utils.py:161,393,738,827): f64 accumulation over each cluster's members in
  * ascending node order, rounded once to f32 (utils.py:738 torch.FloatTensor).  X f32[N x F] (ldx), Xc
  * f32[n x F] (ldxc).  Xc64 (f64[n x F], leading dimension F) may be NULL. */

@@ -1092,3 +1092,92 @@ def test_adam_folds_a_fresh_gradient_buffer_and_advances_its_state(mods):
         expect.add_(ops.SeedBank.GOLD)   # (wraps modulo 2^64, as SeedBank.advance)
         assert torch.equal(bank.seeds, expect)
     assert f1.view(12345) is None
+
+
+def test_padded_batch_plan_assembles_the_batch_of_any_graphs(mods):
+    """graph_data.PaddedBatchPlan (fitgnn_batch_offsets / fitgnn_batch_gather): the batch of 16 arbitrary graphs assembled on the device
+    from the dataset's global arrays == the batch GraphSet.batch_ids builds on the host (normalised CSR, pooled rows, first layer's
+    aggregated input, targets: bit for bit), its tiles partition the padded row range, two consecutive steps walk the permutation."""
+    from fitgnn_amd import graph_data, ops
+    from fitgnn_amd.csr import csr_for
+
+    mol = graph_data.synthetic_molecules(96, seed=9)
+    gset = graph_data.GraphSet(mol, ratio=0.5, extra_node=True, device="cuda")
+    B = 16
+    plan = graph_data.PaddedBatchPlan(gset, B, lambda y: y[:, 2:3].long().float())
+    rng = np.random.default_rng(1)
+    ids = rng.permutation(96)[:2 * B]
+    assert plan.fits(ids.reshape(2, B)).all()
+    plan.set_epoch(ids)
+    for step in range(2):
+        plan.assemble()
+        torch.cuda.synchronize()
+        assert int(plan.step_idx) == step + 1
+        want = gset.batch_ids(ids[step * B:(step + 1) * B].tolist(), "gs")
+        g = csr_for(want["edge_index"], int(want["x"].shape[0]), "gcn")
+        n, nnz = g.n, g.nnz
+        assert n <= plan.R_cap and nnz <= plan.E_cap
+        assert torch.equal(plan.b_rowptr[:n + 1], g.f.rowptr) and bool((plan.b_rowptr[n:] == nnz).all())
+        assert torch.equal(plan.b_col[:nnz], g.f.col) and torch.equal(plan.b_val[:nnz], g.f.val)
+        assert torch.equal(g.f.val, g.t.val) and torch.equal(g.f.col, g.t.col)          # (what lets the batch's transpose be itself)
+        mask_idx = torch.nonzero(want["mask"]).flatten()
+        m = int(mask_idx.numel())
+        assert torch.equal(plan.b_members[:m].long(), mask_idx)
+        graph_of = want["graph"][want["mask"]]
+        assert torch.equal(plan.b_seg_of_row[:n][mask_idx].long(), graph_of) and int((plan.b_seg_of_row[:n] >= 0).sum()) == m
+        assert bool((plan.b_seg_of_row[n:] == -1).all())
+        cnt = torch.bincount(graph_of, minlength=B)
+        assert torch.equal(plan.b_seg_off.long(), torch.cat([torch.zeros(1, dtype=torch.int64, device="cuda"), torch.cumsum(cnt, 0)]))
+        assert torch.equal(plan.b_inv_cnt, 1.0 / cnt.clamp(min=1).float())
+        ax = ops.spmm_graph(g, want["x"].float())
+        assert torch.equal(plan.b_ax[:n], ax) and float(plan.b_ax[n:].abs().max() if n < plan.R_cap else 0.0) == 0.0
+        assert torch.equal(plan.b_tgt, want["y"][:, 2:3].long().float())
+        t = plan.b_tiles.cpu().numpy()
+        live = t[t[:, 1] > t[:, 0]]
+        order = np.argsort(live[:, 0])
+        live = live[order]
+        assert live[0, 0] == 0 and live[-1, 1] == plan.R_cap and np.array_equal(live[1:, 0], live[:-1, 1])      # a partition of the rows
+        assert np.all(live[:, 1] - live[:, 0] <= 16) and np.array_equal(live[:, 2], live[:, 0]) and np.array_equal(live[:, 3], live[:, 1] - live[:, 0])
+        rp = plan.b_rowptr.cpu().numpy()
+        assert np.array_equal(live[:, 4], rp[live[:, 0]]) and np.array_equal(live[:, 5], rp[live[:, 1]])
+        # a product over the static batch == the product over the host-built one; the rows past the batch are written (zeros)
+        X = torch.randn(plan.R_cap, 64, device="cuda")
+        Y = ops.spmm_graph(plan.graph, X)
+        assert torch.equal(Y[:n], ops.spmm_graph(g, X[:n].contiguous())) and float(Y[n:].abs().max() if n < plan.R_cap else 0.0) == 0.0
+
+
+@pytest.mark.parametrize("force_eager_every", [0, 2])
+def test_shuffled_epochs_replay_one_captured_step(mods, force_eager_every):
+    """GraphTrainer(reshuffle=True, capture=True): the batches of every epoch assembled on the device and stepped by ONE captured
+    hipGraph == the eager rebuild of the same shuffled batches (same torch seed per epoch, dropout off): epoch losses and final weights;
+    a last, shorter batch and batches declared not to fit take the eager way in between."""
+    from fitgnn_amd import graph_data, train
+
+    network, fnn, gorc = mods
+    mol = graph_data.synthetic_molecules(110, seed=6)   # 110 = 6 x 16 + 14: a short last batch
+    gset = graph_data.GraphSet(mol, ratio=0.5, extra_node=True, device="cuda")
+    args = argparse.Namespace(num_layers1=2, layer_name="GCNConv", num_features=11, hidden=64, num_classes=1)
+    torch.manual_seed(3)
+    m1, m2 = network.Regress_graph_gs(args).cuda(), network.Regress_graph_gs(args).cuda()
+    m2.load_state_dict(m1.state_dict())
+    m1.dropout_p = m2.dropout_p = 0.0
+    t1 = train.GraphTrainer(m1, gset, list(range(110)), kind="gs", batch_size=16, prop=1, reshuffle=True)
+    t2 = train.GraphTrainer(m2, gset, list(range(110)), kind="gs", batch_size=16, prop=1, reshuffle=True, capture=True)
+    assert t1._plan is None and t2._plan is not None
+    if force_eager_every:
+        t2._plan.fits = lambda ids: np.arange(len(ids)) % force_eager_every == 0
+    for epoch in range(3):
+        torch.manual_seed(100 + epoch)
+        a = float(t1.step())
+        torch.manual_seed(100 + epoch)
+        b = float(t2.step())
+        assert a == pytest.approx(b, rel=2e-5), (epoch, a, b)
+    for (k, v), (_, w) in zip(m1.state_dict().items(), m2.state_dict().items()):
+        assert rel(w, v) < 2e-4, k
+    # dropout on: the replayed step draws fresh patterns (the optimiser kernel moves the seeds on)
+    m2.dropout_p = 0.5
+    torch.manual_seed(7)
+    l1 = float(t2.step())
+    torch.manual_seed(7)
+    l2 = float(t2.step())
+    assert l1 != l2
