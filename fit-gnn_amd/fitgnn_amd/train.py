@@ -666,12 +666,17 @@ class GraphTrainer(_CapturedSteps):
             self.opt.m.copy_(saved_o[0]); self.opt.v.copy_(saved_o[1]); self.opt.step_count.copy_(saved_o[2])
             self.flat.zero()
             plan.step_idx.zero_(); plan.loss_sum.zero_(); plan.loss_slot.zero_()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                plan.assemble()
-                bank.cursor = 0
-                self._one(plan.batch, loss_out=plan.loss_slot)
-            self._shuffled_graph, self._bank = g, bank
+            pool = torch.cuda.graph_pool_handle()
+            graphs = []
+            for reps in (1, max(int(getattr(self, "steps_per_graph", 8)), 1)):   # one step, and a run of steps (a replay costs ~10 us of its own)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, pool=pool):
+                    for _ in range(reps):
+                        plan.assemble()
+                        bank.cursor = 0
+                        self._one(plan.batch, loss_out=plan.loss_slot)
+                graphs.append((reps, g))
+            self._shuffled_graph, self._bank = graphs, bank
             plan.step_idx.zero_(); plan.loss_sum.zero_(); plan.loss_slot.zero_()   # (capturing does not execute)
         finally:
             self.model.set_op_config(prev)
@@ -700,12 +705,19 @@ class GraphTrainer(_CapturedSteps):
             b["_tgt"] = self._target(b["y"])
             return self._one(b)
 
-        for k in range(n_full):
-            if fits[k]:
-                self._shuffled_graph.replay()
+        (_, g_one), (per, g_run) = self._shuffled_graph if n_full else ((1, None), (1, None))
+        k = 0
+        while k < n_full:
+            if per > 1 and k + per <= n_full and bool(fits[k:k + per].all()):
+                g_run.replay()
+                k += per
+            elif fits[k]:
+                g_one.replay()
+                k += 1
             else:
                 plan.step_idx.add_(1)
                 total += eager(full[k].tolist())
+                k += 1
         n_batches = n_full
         if len(ids) > n_full * B:
             total += eager(ids[n_full * B:].tolist())

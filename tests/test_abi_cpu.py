@@ -154,3 +154,33 @@ def test_round3_entry_points_check_their_arguments_without_a_gpu():
     assert L.fitgnn_lanczos_reduce_f64(None, 4, 200, None, None) == -1
     assert L.fitgnn_lanczos_rotate_f64(None, 10, 60, None, 17, None, 10, 10, None) == -1            # more than 16 rotated columns
     assert L.fitgnn_lanczos_finish_f64(None, 4, 0, None, 10, None, None, None, None, 1, None) == -1  # ldv < n
+
+
+def test_round4_graph_step_entry_points_check_their_arguments_without_a_gpu():
+    """The narrow first layer, the pool + head pair, the accumulating Adam and the device batch assembly: shape support queries are
+    host-only, argument errors are reported before any launch."""
+    L = _lib.lib()
+    lds = L.fitgnn_dense_narrow_k_lds_bytes
+    assert lds(11, 512) == (11 * 512 + 16 * 11) * 4 and lds(32, 128) > 0
+    assert lds(33, 512) == 0 and lds(0, 512) == 0 and lds(11, 510) == 0 and lds(32, 1024) == 0   # K > 32, H % 4, W^T beyond 64 KiB
+    assert L.fitgnn_dense_narrow_k_f32(None, 11, None, 11, 5, 11, 512, None, 0, 0.0, 0, None, None, 512, None) == -1       # NULL operands
+    assert L.fitgnn_dense_narrow_k_f32(None, 11, None, 11, 0, 11, 512, None, 0, 0.0, 0, None, None, 512, None) == 0        # nothing to do
+    assert L.fitgnn_dense_narrow_k_f32(None, 11, None, 11, 5, 40, 512, None, 0, 0.0, 0, None, None, 512, None) == -1       # K not supported
+    wb = L.fitgnn_narrow_atb_workspace_bytes
+    assert wb(4861, 11, 512) == ((4861 + 15) // 16) * (512 * 11 + 512) * 4
+    assert wb(100, 11, 96) == 0 and wb(100, 33, 512) == 0 and wb(0, 11, 512) == 0                 # H / 4 must divide 256; K <= 32
+    assert L.fitgnn_narrow_atb_f32(None, 512, None, 0, 0.0, 0, None, None, 11, 100, 11, 512, None, None, None, 0, None) == -1
+    S = L.fitgnn_pool_head_supported
+    assert S(512, 1) and S(64, 8) and S(1024, 3) and not S(96, 1) and not S(512, 9) and not S(510, 1) and not S(2048, 1)
+    assert L.fitgnn_pool_head_f32(None, None, 0, None, 512, 512, None, None, None, 1, None, None, None) == 0
+    assert L.fitgnn_pool_head_f32(None, None, 4, None, 512, 512, None, None, None, 1, None, None, None) == -1
+    assert L.fitgnn_pool_head_bwd_f32(None, None, 1, None, None, None, 10, 4, 512, None, None, None, None) == -1
+    assert L.fitgnn_adam_step_acc_f32(None, None, None, None, None, 6, 0.01, 0.9, 0.999, 1e-8, 0.0, None, None, 0, 0, None) == -1   # n % 4
+    assert L.fitgnn_adam_step_acc_f32(None, None, None, None, None, 0, 0.01, 0.9, 0.999, 1e-8, 0.0, None, None, 0, 0, None) == 0
+    assert L.fitgnn_adam_step_acc_f32(None, None, None, None, None, 8, 0.01, 0.9, 0.999, 1e-8, 0.0, None, None, 0, 0, None) == -1   # NULL buffers
+    assert L.fitgnn_batch_offsets(None, None, 2000, None, None, None, None, None, None, None, None, None) == -1                    # B > 1024
+    assert L.fitgnn_batch_offsets(None, None, 128, None, None, None, None, None, None, None, None, None) == -1
+    n13 = [None] * 13
+    n9 = [None] * 9
+    assert L.fitgnn_batch_gather(128, *n13, 11, None, 1, 11, 64, 64, 64, 64, *n9, 11, None, None) == -1                            # NULL arrays
+    assert L.fitgnn_batch_gather(128, *n13, 8, None, 1, 11, 64, 64, 64, 64, *n9, 11, None, None) == -1                             # ld_ax_g < K

@@ -1164,6 +1164,7 @@ def test_shuffled_epochs_replay_one_captured_step(mods, force_eager_every):
     t1 = train.GraphTrainer(m1, gset, list(range(110)), kind="gs", batch_size=16, prop=1, reshuffle=True)
     t2 = train.GraphTrainer(m2, gset, list(range(110)), kind="gs", batch_size=16, prop=1, reshuffle=True, capture=True)
     assert t1._plan is None and t2._plan is not None
+    t2.steps_per_graph = 4   # six full batches per epoch: one captured run of four steps, then two single steps
     if force_eager_every:
         t2._plan.fits = lambda ids: np.arange(len(ids)) % force_eager_every == 0
     for epoch in range(3):
