@@ -205,7 +205,7 @@ class GraphSet:
 
 
 class PaddedBatchPlan:
-    """Batches of ANY graphs of a GraphSet's subgraph view ('gs') assembled on the device into buffers of fixed capacity, so that one
+    """Batches of ANY graphs of a GraphSet's subgraph view ('gs') or coarse view ('gc') assembled on the device into buffers of fixed capacity, so that one
     captured hipGraph serves every batch of every epoch of a reshuffling loader (run.py:710 DataLoader(shuffle=True);
     train.GraphTrainer(reshuffle=True, capture=True)).
 
@@ -219,28 +219,34 @@ class PaddedBatchPlan:
     step run over R_cap rows, the surplus rows being empty; `fits(ids)` tells the host -- which knows every graph's sizes -- whether a
     batch fits (a batch that does not is run the eager way)."""
 
-    def __init__(self, gset, batch_size, target_fn, model_features=None, sigmas=6.0):
+    def __init__(self, gset, batch_size, target_fn, kind="gs", sigmas=6.0):
+        """kind 'gs': the subgraph union (pooled rows = the reference's row mask); 'gc': the coarse graphs (every row pooled)."""
         from . import _lib, ops
 
         dev = gset.x.device
         B = int(batch_size)
-        assert dev.type == "cuda" and 1 <= B <= 1024
+        assert dev.type == "cuda" and 1 <= B <= 1024 and kind in ("gs", "gc")
         G = gset.n_graphs
-        self.gset, self.B, self.dev = gset, B, dev
-        whole = gset.batch(0, G, "gs")                       # the dataset as ONE block-diagonal batch: its CSR, normalised
+        self.gset, self.B, self.dev, self.kind = gset, B, dev, kind
+        if kind == "gs":
+            g_row, blocks, x, pooled_mask = np.asarray(gset.gs_ptr, dtype=np.int64), np.asarray(gset.sub_ptr, dtype=np.int64), gset.gs_x, gset.gs_mask
+        else:
+            g_row = np.asarray(gset.cluster_ptr, dtype=np.int64)
+            blocks, x = g_row, gset.gc_x
+            pooled_mask = torch.ones(int(g_row[-1]), dtype=torch.bool, device=dev)
+        R = int(g_row[-1])
+        whole = gset.batch(0, G, kind)                       # the dataset as ONE block-diagonal batch: its CSR, normalised
         self._whole = whole                                  # (the CSR cache is keyed on this edge tensor: keep it alive)
-        g_all = ops_csr_for(whole["edge_index"], int(gset.gs_ptr[-1]))
+        g_all = ops_csr_for(whole["edge_index"], R)
         f, t = g_all.f, g_all.t
         if not (torch.equal(f.rowptr, t.rowptr) and torch.equal(f.col, t.col) and torch.equal(f.val, t.val)):
-            raise ValueError("the subgraph union's normalised adjacency is not symmetric: its transpose cannot share the batch's CSR")
-        R = int(gset.gs_ptr[-1])
+            raise ValueError("the union's normalised adjacency is not symmetric: its transpose cannot share the batch's CSR")
         rp_host = f.rowptr.cpu().numpy().astype(np.int64)
-        g_row = np.asarray(gset.gs_ptr, dtype=np.int64)
         g_nnz = rp_host[g_row]
-        # row tiles: the usual packing of the cluster subgraphs' blocks, cut at every graph boundary (a tile's window is its own rows,
-        # and graph boundaries are block boundaries: both halves of a cut tile are valid tiles)
+        # row tiles: the usual packing of the diagonal blocks (cluster subgraphs / coarse graphs), cut at every graph boundary (a
+        # tile's window is its own rows, and graph boundaries are block boundaries: both halves of a cut tile are valid tiles)
         from .csr import make_tiles, TILE_INTS
-        base = make_tiles(np.asarray(gset.sub_ptr, dtype=np.int64), g_all.window_rows)
+        base = make_tiles(blocks, g_all.window_rows)
         starts = np.union1d(base["row_begin"].astype(np.int64), g_row[:-1])
         starts = starts[starts < R]
         ends = np.append(starts[1:], R)
@@ -248,8 +254,8 @@ class PaddedBatchPlan:
         tiles[:, 0], tiles[:, 1], tiles[:, 2], tiles[:, 3] = starts, ends, starts, ends - starts
         tiles[:, 4], tiles[:, 5] = rp_host[starts], rp_host[ends]
         g_tile = np.searchsorted(starts, g_row, side="left")
-        pooled = gset.gs_mask.to(torch.uint8).contiguous()
-        mem = torch.nonzero(gset.gs_mask).flatten().to(torch.int32).contiguous()          # ascending: grouped by graph
+        pooled = pooled_mask.to(torch.uint8).contiguous()
+        mem = torch.nonzero(pooled_mask).flatten().to(torch.int32).contiguous()           # ascending: grouped by graph
         g_mem = np.searchsorted(mem.cpu().numpy().astype(np.int64), g_row, side="left")
         self.sizes = np.stack([np.diff(g_row), np.diff(g_nnz), np.diff(g_tile), np.diff(g_mem)], 1).astype(np.int64)   # [G, 4]
         mean, std = self.sizes.mean(0), self.sizes.std(0)
@@ -264,7 +270,6 @@ class PaddedBatchPlan:
         self.g_row, self.g_nnz, self.g_tile, self.g_mem = i32(g_row), i32(g_nnz), i32(g_tile), i32(g_mem)
         self.rowptr, self.col, self.val = f.rowptr, f.col, f.val
         self.tiles, self.mem, self.pooled = torch.from_numpy(tiles).to(dev), mem, pooled
-        x = gset.gs_x
         self.K = int(x.shape[1])
         self.ax = ops.aggregated_input(g_all, x).contiguous()                             # [R, K]
         self.tgt = target_fn(gset.y).contiguous()                                         # [G, 1]
@@ -301,14 +306,20 @@ class PaddedBatchPlan:
         e = torch.zeros((2, 1), dtype=torch.int64, device=dev)
         register(e, g, "gcn")
         g._agg_input = (x, x._version, self.b_ax)
-        rows = torch.zeros(self.M_cap, dtype=torch.int64, device=dev)                     # stand-ins for mask_idx / graph_of_masked
-        batch = torch.zeros(self.M_cap, dtype=torch.int64, device=dev)
         pi = object.__new__(ops.PoolIndex)
         pi.n_seg, pi.sorted, pi.seg_off, pi.members = B, True, self.b_seg_off, self.b_members
         pi.n_rows, pi.seg_of_row, pi.inv_cnt = self.R_cap, self.b_seg_of_row, self.b_inv_cnt
-        batch._fitgnn_pool = ((batch._version, B, (rows.data_ptr(), rows._version), self.R_cap), pi, rows)
         self.graph = g
-        return dict(x=x, edge_index=e, mask=None, mask_idx=rows, graph_of_masked=batch, y=self.b_tgt, _tgt=self.b_tgt, n_graphs=B)
+        if self.kind == "gs":
+            rows = torch.zeros(self.M_cap, dtype=torch.int64, device=dev)                 # stand-ins for mask_idx / graph_of_masked
+            batch = torch.zeros(self.M_cap, dtype=torch.int64, device=dev)
+            batch._fitgnn_pool = ((batch._version, B, (rows.data_ptr(), rows._version), self.R_cap), pi, rows)
+            return dict(x=x, edge_index=e, mask=None, mask_idx=rows, graph_of_masked=batch, y=self.b_tgt, n_graphs=B)
+        import types
+        batch = torch.zeros(self.R_cap, dtype=torch.int64, device=dev)                    # stand-in for the PyG batch vector
+        batch._fitgnn_pool = ((batch._version, B, None, self.R_cap), pi, None)
+        return dict(x=x, edge_index=e, mask=None, y=self.b_tgt, n_graphs=B,
+                    gc=types.SimpleNamespace(x=x, edge_index=e, batch=batch, num_graphs=B))
 
     def fits(self, ids):
         """ids [n, B] (host): which of the n batches fit the capacities."""

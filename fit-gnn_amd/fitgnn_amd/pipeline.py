@@ -466,7 +466,8 @@ def graph_regression(args, path, mol, device="cuda", log=print):
     T = {}
     for m in ("gc", "gs"):   # one optimiser per model across all phases (run.py:718-719)
         model = model_gc if m == "gc" else model_gs
-        T[(m, "train")] = GraphTrainer(model, gset, split["train"], kind=m, **kw)
+        # the training loaders reshuffle every epoch (run.py:710 shuffle=True) where that replays one captured step ("auto")
+        T[(m, "train")] = GraphTrainer(model, gset, split["train"], kind=m, reshuffle="auto", **kw)
         for s in ("val", "test"):
             T[(m, s)] = GraphTrainer(model, gset, split[s], kind=m, share=T[(m, "train")], **kw)
     ckpt = os.path.join(path, "model.pt")

@@ -489,8 +489,11 @@ class GraphTrainer(_CapturedSteps):
         batches (+ global_sizes): pre-built batch dicts (tests / custom pipelines) instead of gset + graphs.
         accumulate=False: clear the gradients before every batch (the baselines' loops, run.py:988-991, :1058-1060).
         reshuffle=True: re-draw the graph order before every epoch, as the reference's DataLoader(shuffle=True) does
-        (run.py:710); every batch's CSR is then rebuilt per epoch and the steps run eagerly (≈ 3 ms of set-up per batch: the
-        default draws the order once and replays captured steps).
+        (run.py:710).  With capture=True the batches are assembled on the device into fixed-capacity buffers and ONE captured step
+        is replayed for every full batch (graph_data.PaddedBatchPlan; S-qm9: 0.13 s per epoch); without it -- or where the plan
+        does not apply: a first layer that is not a GCNConv on a narrow input, data parallelism -- every batch's CSR is rebuilt on
+        the host and the steps run eagerly (≈ 3 ms per batch).  reshuffle="auto": reshuffle only where the plan applies, else
+        the order is drawn once and each batch's captured step replayed (the default, reshuffle=False).
         lean_step=False (A/B): the step as round 3 had it -- autograd's own `grad += new` per tensor, loss.backward() from a ones
         fill, the seeds and the step count advanced by launches of their own."""
         import types
@@ -513,10 +516,11 @@ class GraphTrainer(_CapturedSteps):
         self._rebuild, self._plan, self._shuffled_graph = None, None, None
         if batches is None and reshuffle:
             want_capture = self.capture
-            self.capture = False
-            self._rebuild = (gset, [int(g) for g in graphs], kind, batch_size, types)
             if want_capture:
                 self._plan = self._make_plan(gset, kind, batch_size, lean_step, share)
+            if reshuffle != "auto" or self._plan is not None:   # "auto": reshuffle only where it replays a captured step
+                self.capture = False
+                self._rebuild = (gset, [int(g) for g in graphs], kind, batch_size, types)
         if batches is not None:   # pre-built (entries may be None: this rank holds no graph of that batch)
             self.batches = list(batches)
             self.global_sizes = list(global_sizes) if global_sizes is not None else [int(b["y"].shape[0]) for b in self.batches]
@@ -631,14 +635,20 @@ class GraphTrainer(_CapturedSteps):
         from .graph_data import PaddedBatchPlan
 
         model = self.model
-        ok = (kind == "gs" and lean_step and share is None and self.world == 1 and self.task == "graph_reg" and isinstance(self.opt, FlatAdam)
-              and gset is not None and gset.x.is_cuda and getattr(model, "num_layers", 0) > 0 and isinstance(model.conv[0], fnn.GCNConv))
+        ok = (kind in ("gs", "gc") and lean_step and share is None and self.world == 1 and self.task in ("graph_reg", "graph_cls")
+              and isinstance(self.opt, FlatAdam) and gset is not None and gset.x.is_cuda and getattr(model, "num_layers", 0) > 0
+              and isinstance(model.conv[0], fnn.GCNConv) and 1 <= int(batch_size) <= 1024)
         if not ok:
             return None
-        probe = torch.zeros((1, gset.gs_x.shape[1]), dtype=torch.float32, device=gset.x.device)
+        x_all = gset.gs_x if kind == "gs" else gset.gc_x
+        probe = torch.zeros((1, x_all.shape[1]), dtype=torch.float32, device=gset.x.device)
         if not ops.narrow_input_supported(probe, model.conv[0].lin.weight, model.op_config):
             return None
-        return PaddedBatchPlan(gset, batch_size, self._target)
+        target_fn = self._target if self.task == "graph_reg" else (lambda y: y.float())
+        try:
+            return PaddedBatchPlan(gset, batch_size, target_fn, kind=kind)
+        except ValueError:   # (a union whose normalised adjacency is not symmetric)
+            return None
 
     def _build_shuffled_graph(self):
         """Capture [assemble the batch at the device counter, forward, L1 loss, backward, Adam] once (PaddedBatchPlan.batch is static)."""
@@ -659,7 +669,7 @@ class GraphTrainer(_CapturedSteps):
                     plan.step_idx.zero_()
                     plan.assemble()
                     bank.cursor = 0
-                    self._one(plan.batch, loss_out=plan.loss_slot)
+                    self._one(self._plan_batch(), loss_out=plan.loss_slot)
             torch.cuda.current_stream(dev).wait_stream(side)
             torch.cuda.synchronize(dev)
             self.model.load_state_dict(saved_m)
@@ -674,12 +684,20 @@ class GraphTrainer(_CapturedSteps):
                     for _ in range(reps):
                         plan.assemble()
                         bank.cursor = 0
-                        self._one(plan.batch, loss_out=plan.loss_slot)
+                        r = self._one(self._plan_batch(), loss_out=plan.loss_slot)
+                        if r.data_ptr() != plan.loss_slot.data_ptr():   # (a loss that is not written to the slot by its own kernel)
+                            plan.loss_slot.copy_(r.detach().view(1))
                 graphs.append((reps, g))
             self._shuffled_graph, self._bank = graphs, bank
             plan.step_idx.zero_(); plan.loss_sum.zero_(); plan.loss_slot.zero_()   # (capturing does not execute)
         finally:
             self.model.set_op_config(prev)
+
+    def _plan_batch(self):
+        b = self._plan.batch
+        if self.task == "graph_reg" and "_tgt" not in b:
+            b["_tgt"] = b["y"]   # (the plan's targets are already in the form the regression loss takes)
+        return b
 
     def _step_shuffled(self):
         """One epoch over freshly shuffled batches: full batches that fit the plan's capacities replay the captured step, the others
@@ -702,7 +720,8 @@ class GraphTrainer(_CapturedSteps):
 
         def eager(id_list):
             b = _cat_pieces([gset.batch_ids(id_list, kind)], kind, types)
-            b["_tgt"] = self._target(b["y"])
+            if self.task == "graph_reg":
+                b["_tgt"] = self._target(b["y"])
             return self._one(b)
 
         (_, g_one), (per, g_run) = self._shuffled_graph if n_full else ((1, None), (1, None))

@@ -1146,24 +1146,34 @@ def test_padded_batch_plan_assembles_the_batch_of_any_graphs(mods):
         assert torch.equal(Y[:n], ops.spmm_graph(g, X[:n].contiguous())) and float(Y[n:].abs().max() if n < plan.R_cap else 0.0) == 0.0
 
 
-@pytest.mark.parametrize("force_eager_every", [0, 2])
-def test_shuffled_epochs_replay_one_captured_step(mods, force_eager_every):
+@pytest.mark.parametrize("kind,task,force_eager_every", [("gs", "graph_reg", 0), ("gs", "graph_reg", 2), ("gc", "graph_reg", 0), ("gs", "graph_cls", 0),
+                                                        ("gc", "graph_cls", 3)])
+def test_shuffled_epochs_replay_one_captured_step(mods, kind, task, force_eager_every):
     """GraphTrainer(reshuffle=True, capture=True): the batches of every epoch assembled on the device and stepped by ONE captured
     hipGraph == the eager rebuild of the same shuffled batches (same torch seed per epoch, dropout off): epoch losses and final weights;
-    a last, shorter batch and batches declared not to fit take the eager way in between."""
+    a last, shorter batch and batches declared not to fit take the eager way in between.  Subgraph and coarse views, regression (L1)
+    and classification (max pool, softmax, cross-entropy)."""
     from fitgnn_amd import graph_data, train
 
     network, fnn, gorc = mods
-    mol = graph_data.synthetic_molecules(110, seed=6)   # 110 = 6 x 16 + 14: a short last batch
+    if task == "graph_reg":
+        mol = graph_data.synthetic_molecules(110, seed=6)   # 110 = 6 x 16 + 14: a short last batch
+        args = argparse.Namespace(num_layers1=2, layer_name="GCNConv", num_features=11, hidden=64, num_classes=1)
+        cls = network.Regress_graph_gs if kind == "gs" else network.Regress_graph_gc
+        kw = dict(prop=1)
+    else:
+        mol = graph_data.synthetic_graph_classes(110, seed=6)
+        args = argparse.Namespace(num_layers1=2, layer_name="GCNConv", num_features=3, hidden=64, num_classes=2)
+        cls = network.Classify_graph_gs if kind == "gs" else network.Classify_graph_gc
+        kw = dict(task="graph_cls", multi_prop=False)
     gset = graph_data.GraphSet(mol, ratio=0.5, extra_node=True, device="cuda")
-    args = argparse.Namespace(num_layers1=2, layer_name="GCNConv", num_features=11, hidden=64, num_classes=1)
     torch.manual_seed(3)
-    m1, m2 = network.Regress_graph_gs(args).cuda(), network.Regress_graph_gs(args).cuda()
+    m1, m2 = cls(args).cuda(), cls(args).cuda()
     m2.load_state_dict(m1.state_dict())
     m1.dropout_p = m2.dropout_p = 0.0
-    t1 = train.GraphTrainer(m1, gset, list(range(110)), kind="gs", batch_size=16, prop=1, reshuffle=True)
-    t2 = train.GraphTrainer(m2, gset, list(range(110)), kind="gs", batch_size=16, prop=1, reshuffle=True, capture=True)
-    assert t1._plan is None and t2._plan is not None
+    t1 = train.GraphTrainer(m1, gset, list(range(110)), kind=kind, batch_size=16, reshuffle=True, **kw)
+    t2 = train.GraphTrainer(m2, gset, list(range(110)), kind=kind, batch_size=16, reshuffle=True, capture=True, **kw)
+    assert t1._plan is None and t2._plan is not None and t2._plan.kind == kind
     t2.steps_per_graph = 4   # six full batches per epoch: one captured run of four steps, then two single steps
     if force_eager_every:
         t2._plan.fits = lambda ids: np.arange(len(ids)) % force_eager_every == 0
@@ -1182,3 +1192,11 @@ def test_shuffled_epochs_replay_one_captured_step(mods, force_eager_every):
     torch.manual_seed(7)
     l2 = float(t2.step())
     assert l1 != l2
+    # "auto" on a model the plan does not take (attention layers): the order is drawn once, the captured per-batch steps stay
+    if kind == "gs" and task == "graph_reg" and not force_eager_every:
+        gargs = argparse.Namespace(num_layers1=2, layer_name="GATConv", num_features=11, hidden=64, num_classes=1)
+        t4 = train.GraphTrainer(network.Regress_graph_gs(gargs).cuda(), gset, list(range(64)), kind="gs", batch_size=16, prop=1, reshuffle="auto",
+                                capture=True)
+        assert t4._plan is None and t4._rebuild is None and t4.capture
+        t5 = train.GraphTrainer(m1, gset, list(range(64)), kind="gs", batch_size=16, prop=1, reshuffle="auto", capture=True)
+        assert t5._plan is not None and t5._rebuild is not None
