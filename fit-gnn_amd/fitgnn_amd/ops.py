@@ -426,14 +426,16 @@ class Linear(torch.autograd.Function):
         return dx, dW, None
 
 
-def colsum_narrow(x):
-    """Column sums of a tall [rows, C <= 64] matrix (the head's bias gradient) through fitgnn_colsum_narrow_f32."""
+def colsum_narrow(x, out=None):
+    """Column sums of a tall [rows, C <= 64] matrix (the head's bias gradient) through fitgnn_colsum_narrow_f32.  out: write them there
+    (a gradient sink; None is returned when it was used)."""
     if not (x.is_cuda and x.dim() == 2 and x.shape[1] <= 64 and x.dtype == torch.float32 and x.stride(1) == 1):
         # torch's dim-0 reduction of a tall narrow matrix is slow (50 us for 90 k x 3): reduce the transposed copy instead
         return x.t().contiguous().sum(1) if (x.dim() == 2 and x.shape[0] > 4 * x.shape[1]) else x.sum(0)
     L = _lib.lib()
     n, C = x.shape
-    out = torch.empty(C, dtype=torch.float32, device=x.device)
+    if out is None:
+        out = torch.empty(C, dtype=torch.float32, device=x.device)
     wb = int(L.fitgnn_colsum_narrow_workspace_bytes(n, C))
     work = torch.empty(max(wb, 4), dtype=torch.uint8, device=x.device)
     _lib.check(L.fitgnn_colsum_narrow_f32(_lib.dptr(x), x.stride(0), n, C, _lib.dptr(out), _lib.dptr(work), wb,
@@ -976,7 +978,7 @@ ZERO_ROWS = 256
 
 
 def epilogue_bwd_head_rows_raw(dy, Wl, out, rows, epilogue, p=0.0, seed=0, mask=None, want_db=True, want_dWl=True, inputs_compact=False,
-                               zero_rows=ZERO_ROWS):
+                               zero_rows=ZERO_ROWS, db_out=None, dWl_out=None):
     """epilogue_bwd_head_raw over the rows `rows` only, compact: dZc [len(rows) + zero_rows, H] whose last rows are zero (the
     operand of every row outside `rows` in a backward SpMM), db, dWl (fitgnn_epilogue_bwd_head_rows_f32).  inputs_compact: dy and
     out hold those rows only (row i = original row rows[i])."""
@@ -990,8 +992,8 @@ def epilogue_bwd_head_rows_raw(dy, Wl, out, rows, epilogue, p=0.0, seed=0, mask=
     dZc = torch.empty((n_sel + zero_rows, H), dtype=torch.float32, device=out.device)
     if zero_rows:
         dZc[n_sel:].zero_()
-    db = torch.empty(H, dtype=torch.float32, device=out.device) if want_db else None
-    dWl = torch.empty((C, H), dtype=torch.float32, device=out.device) if want_dWl else None
+    db = (db_out if db_out is not None else torch.empty(H, dtype=torch.float32, device=out.device)) if want_db else None
+    dWl = (dWl_out if dWl_out is not None else torch.empty((C, H), dtype=torch.float32, device=out.device)) if want_dWl else None
     wb = int(L.fitgnn_epilogue_bwd_head_workspace_bytes(n_sel, H, C))
     work = torch.empty(max(wb, 4), dtype=torch.uint8, device=out.device)
     rc = L.fitgnn_epilogue_bwd_head_rows_f32(_lib.dptr(dy), _lib.dptr(Wl), C, _lib.dptr(out), _lib.dptr(rows), n_sel, 1 if inputs_compact else 0,
@@ -1585,6 +1587,7 @@ class FusedGCNLastLayerRows(torch.autograd.Function):
         keep_x = link_in is not None and cfg.fuse_dx_epilogue and X.shape[1] % 4 == 0
         ctx.save_for_backward(W, Wl, AHc, outc, rows, mask if drop else None, X if keep_x else None)
         ctx.g, ctx.p, ctx.drop, ctx.seed, ctx.has_bias, ctx.has_bl, ctx.cfg = g, p, drop, seed, b is not None, bl is not None, cfg
+        ctx.ptrs = (W.data_ptr(), b.data_ptr() if b is not None else None, Wl.data_ptr(), bl.data_ptr() if bl is not None else None)
         return y
 
     @staticmethod
@@ -1596,12 +1599,32 @@ class FusedGCNLastLayerRows(torch.autograd.Function):
         dy_c = _f32c(dy) if ctx.compact_out else _f32c(dy).index_select(0, rows)   # [n, C]
         epi = EPI_ELU | (EPI_DROPOUT if ctx.drop else 0)
         inside = ctx.needs_input_grad[3] and bool(L.fitgnn_epilogue_bwd_head_supported(H, C, 1))
+        # weight / bias gradients go straight to the trainer's gradient sink where there is one (OpConfig.grad_sink): no `grad += new`
+        pW, pb, pWl, pbl = ctx.ptrs
+        sW = _sink(cfg, pW) if ctx.needs_input_grad[1] else None
+        sb = _sink(cfg, pb) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        sWl = _sink(cfg, pWl) if inside else None
+        sbl = _sink(cfg, pbl) if (ctx.has_bl and ctx.needs_input_grad[4]) else None
         dZc, db, dWl = epilogue_bwd_head_rows_raw(dy_c, Wl, outc, rows, epi, p=ctx.p if ctx.drop else 0.0, seed=ctx.seed, mask=mask,
-                                                  want_db=ctx.has_bias, want_dWl=inside, inputs_compact=True, zero_rows=0)
+                                                  want_db=ctx.has_bias, want_dWl=inside, inputs_compact=True, zero_rows=0, db_out=sb,
+                                                  dWl_out=sWl)
+        if sb is not None:
+            db = None
+        if sWl is not None:
+            dWl = None
         if ctx.needs_input_grad[3] and not inside:
             dWl = head_weight_grad_rows(dy_c, outc, cfg)
-        dbl = colsum_narrow(dy_c) if ctx.has_bl and ctx.needs_input_grad[4] else None
-        dW = mm_at_b(dZc, AHc, cfg) if ctx.needs_input_grad[1] else None  # [H, K]
+        dbl = None
+        if ctx.has_bl and ctx.needs_input_grad[4]:
+            dbl = colsum_narrow(dy_c, out=sbl)
+            if sbl is not None and dbl is sbl:
+                dbl = None
+        dW = None
+        if ctx.needs_input_grad[1]:   # [H, K]
+            if sW is not None:
+                mm_at_b(dZc, AHc, cfg, out=sW)
+            else:
+                dW = mm_at_b(dZc, AHc, cfg)
         dX = None
         if ctx.needs_input_grad[0]:
             n, K = AHc.shape
@@ -1669,8 +1692,15 @@ class FusedGCNLayerDedup(torch.autograd.Function):
             dW = gemm_exact(_f32c(dHt), padded_table(Xt), "tn", cfg)[:, : Xt.shape[1]]
         elif ctx.wide and ctx.needs_input_grad[1]:
             dW = gemm_atb(_f32c(dHt), padded_table(Xt), cfg)[:, : Xt.shape[1]]   # [H, F'] on the padded table, F' - F zero columns dropped
+        elif ctx.needs_input_grad[1]:
+            sW = _sink(cfg, W)
+            if sW is not None:
+                mm_at_b(dHt, Xt, cfg, out=sW)
+                dW = None
+            else:
+                dW = mm_at_b(dHt, Xt, cfg)
         else:
-            dW = mm_at_b(dHt, Xt, cfg) if ctx.needs_input_grad[1] else None
+            dW = None
         dXt = mm(dHt, W) if ctx.needs_input_grad[0] else None
         return dXt, dW, (db if ctx.has_bias else None), None, None, None, None, None, None, None, None
 

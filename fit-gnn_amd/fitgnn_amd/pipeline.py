@@ -370,6 +370,10 @@ def node_classification(args, path, data, co, device="cuda", log=print):
                     best = vloss
                     best_sd = _keep(model, ckpt, rank)
             model.load_state_dict(best_sd)
+            # drop the last epoch's autograd graph: while `loss` lives, the parameters' AccumulateGrad nodes stay bound to the stream
+            # this phase ran on, and a trainer that captures its step on another stream would fork that stream into the capture
+            # (train._accumulate_stream_guard detects it and falls back to eager steps; without the reference it does not arise)
+            loss = out = None
         if args.exp_setup in ("Gs_train_2_Gs_infer", "Gc_train_2_Gs_train"):
             if args.gradient_method == "GD":
                 # the extra nodes' last-layer outputs never reach the loss: evaluate that layer on the own nodes only

@@ -15,6 +15,39 @@ def _pad4(n):
     return (n + 3) // 4 * 4
 
 
+class _accumulate_stream_guard:
+    """Context for the warm-up steps that precede a hipGraph capture: tells whether autograd found a parameter's AccumulateGrad node bound
+    to ANOTHER stream than the backward ran on (`.mismatch`).  Such a node outlived an earlier iteration -- a `loss` tensor of an earlier
+    training phase that is still referenced keeps its graph's nodes alive -- and executes on the stream it was created on, usually the
+    default stream: inside a capture that forks the default stream into the graph without a join, and ending the capture then takes the
+    process down (found through main.py --exp_setup Gc_train_2_Gs_train, whose Gc phase trains the same parameters eagerly first).
+    Autograd reports the condition as a warn-once UserWarning; the guard makes it warn always for its duration and records it, other
+    warnings are passed on.  A trainer that sees `.mismatch` does not capture: it runs its steps eagerly."""
+    KEY = "AccumulateGrad node's stream"
+
+    def __enter__(self):
+        import warnings
+        self.mismatch = False
+        self._prev = torch.is_warn_always_enabled()
+        torch.set_warn_always(True)
+        self._cw = warnings.catch_warnings(record=True)
+        self._log = self._cw.__enter__()
+        warnings.simplefilter("always")
+        return self
+
+    def __exit__(self, *exc):
+        import warnings
+        log = list(self._log)
+        self._cw.__exit__(*exc)
+        torch.set_warn_always(self._prev)
+        for w in log:
+            if self.KEY in str(w.message):
+                self.mismatch = True
+            else:
+                warnings.warn_explicit(w.message, w.category, w.filename, w.lineno)
+        return False
+
+
 class FlatGrads:
     """All parameter gradients as views into one contiguous buffer -> one all-reduce per step.  Every parameter starts
     on a 16-byte boundary (sizes padded to multiples of four floats; the padding stays zero).  `buf` = the `n` gradient
@@ -167,7 +200,7 @@ def _make_adam(model, flat, lr, weight_decay):
 
 class GDTrainer:
     def __init__(self, model, batch, lr=0.01, weight_decay=5e-4, reduction="mean", process_group=None, dedup=True,
-                 task="node_cls", prune_unused_rows=False, op_config=None, global_train_count=None):
+                 task="node_cls", prune_unused_rows=False, op_config=None, global_train_count=None, lean_step=True, capture="auto"):
         """task 'node_cls': NLLLoss on log-probabilities (run.py:341); 'node_reg': L1Loss on the [n, 1] outputs (run.py:518).
         op_config (ops.OpConfig): the switches this trainer's kernels run under (set on the model; default: the model's own).
         prune_unused_rows: evaluate the last layer only on the rows that reach the loss (train nodes are own nodes of their
@@ -176,7 +209,14 @@ class GDTrainer:
         row (ops.FusedGCNLastLayerRows, fwd_sub); other layers: the row-subset path over the own rows.  Off by default: bench.py's
         metric counts every non-zero of A_hat in all four SpMMs.
         global_train_count: the number of train rows of the WHOLE job when it is known up front (bench.py --shard: one rank of an
-        N-rank job stepped alone); default: this batch's count, summed over the process group."""
+        N-rank job stepped alone); default: this batch's count, summed over the process group.
+        lean_step (single rank, GPU): the step's weight gradients go straight to a buffer the optimiser kernel folds in
+        (ops.OpConfig.grad_sink, fitgnn_adam_step_acc_f32: no `grad += new` launch per tensor, step count advanced by the same launch).
+        capture ("auto" | True | False; single rank, GPU, fused loss): the whole step -- forward, loss, backward, Adam -- replayed from a
+        hipGraph captured at the first step (dropout seeds device-resident, moved on by the optimiser kernel).  "auto": when the union is
+        small enough that a second, private copy of the step's intermediates is cheap (rows x 2 KiB <= 1 GiB: the launch-bound regime,
+        where ten host gaps and twenty launch floors are 15 % of a 1.1-ms S-pubmed step); a step run while the config carries profiling
+        hooks (cfg.profile / profile_gemm / profile_fused) runs eagerly."""
         self.model, self.batch, self.task = model, batch, task
         if op_config is not None:
             model.set_op_config(op_config)
@@ -199,6 +239,15 @@ class GDTrainer:
             broadcast_parameters(model, process_group, flat=self.opt if isinstance(self.opt, FlatAdam) else None)
         from . import network as _net
         self.fused_loss = (task == "node_cls" and isinstance(model, _net.Classify_node) and next(model.parameters()).is_cuda)
+        self.lean = bool(lean_step) and not self.dist and isinstance(self.opt, FlatAdam) and hasattr(model, "set_op_config")
+        if self.lean:
+            self.cfg = self.cfg.replace(grad_sink=self.flat.enable_fresh())
+            model.set_op_config(self.cfg)
+        small = int(getattr(batch, "n_rows", 0) or 0) * 2048 <= (1 << 30)
+        from . import nn as _fnn0
+        gcn_only = all(isinstance(c, _fnn0.GCNConv) for c in getattr(model, "conv", [])) and len(getattr(model, "conv", [])) > 0
+        self.capture = (self.lean and self.fused_loss and gcn_only and (capture is True or (capture == "auto" and small)))
+        self._graph, self._graph_loss, self._bank = None, None, None
         self._y_train = batch.y.index_select(0, batch.train_idx) if self.fused_loss else None
         self._train_arange = None
         self.prune_forward = False
@@ -277,8 +326,52 @@ class GDTrainer:
         self.opt.step()
         return self.flat.tail[0].clone() if self.dist else loss.detach()
 
+    def _capture_step(self):
+        """Capture one step in a hipGraph (weights / optimiser state are put back after the warm-up steps)."""
+        from . import ops
+
+        dev = self.flat.buf.device
+        bank = ops.SeedBank(max(len(self.model.conv), 1), dev)
+        saved_m = {k: v.detach().clone() for k, v in self.model.state_dict().items()}
+        saved_o = (self.opt.m.clone(), self.opt.v.clone(), self.opt.step_count.clone())
+        self.model.set_op_config(self.cfg.replace(seed_bank=bank))
+        self.opt.seed_bank = bank
+        try:
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with _accumulate_stream_guard() as guard, torch.cuda.stream(side):
+                for _ in range(2):
+                    bank.cursor = 0
+                    self._step_eager()
+            torch.cuda.current_stream(dev).wait_stream(side)
+            torch.cuda.synchronize(dev)
+            self.model.load_state_dict(saved_m)
+            self.opt.m.copy_(saved_o[0]); self.opt.v.copy_(saved_o[1]); self.opt.step_count.copy_(saved_o[2])
+            if guard.mismatch:   # an older autograd graph keeps the parameters' AccumulateGrad nodes on another stream: no capture
+                self.capture = False
+                self.opt.seed_bank = None
+                return
+            g = torch.cuda.CUDAGraph()
+            self._graph_loss = torch.zeros((), device=dev)
+            with torch.cuda.graph(g):
+                bank.cursor = 0
+                self._graph_loss.copy_(self._step_eager())
+            self._graph, self._bank = g, bank
+        finally:
+            self.model.set_op_config(self.cfg)
+
     def step(self):
         """One GD epoch (run.py:177-215).  Returns the global loss (over every rank's subgraphs) as a 0-dim device tensor."""
+        if self.capture and self.cfg.profile is None and self.cfg.profile_gemm is None and self.cfg.profile_fused is None:
+            if self._graph is None:
+                self._capture_step()
+            if self._graph is not None:
+                self._graph.replay()
+                self.local_loss = self._graph_loss
+                return self._graph_loss   # (the step's static loss buffer: the next replay overwrites it)
+        return self._step_eager()
+
+    def _step_eager(self):
         m, b = self.model, self.batch
         m.train()
         self.flat.zero()  # optimizer.zero_grad(); grads live in the flat buffer
@@ -361,7 +454,7 @@ class _CapturedSteps:
         try:
             side = torch.cuda.Stream(device=dev)
             side.wait_stream(torch.cuda.current_stream(dev))
-            with torch.cuda.stream(side):
+            with _accumulate_stream_guard() as guard, torch.cuda.stream(side):
                 for b in self._steps()[:2]:
                     if not adam_advances:
                         self._bank.advance()
@@ -377,6 +470,11 @@ class _CapturedSteps:
                         if torch.is_tensor(v):
                             v.copy_(saved_o[p][k]) if p in saved_o and k in saved_o[p] else v.zero_()
             self.flat.zero()
+            if guard.mismatch:   # (see _accumulate_stream_guard) the steps run eagerly
+                self.capture = False
+                if adam_advances:
+                    self.opt.seed_bank = None
+                return
             pool = torch.cuda.graph_pool_handle()
             self._graphs = []
             steps = self._steps()
@@ -400,8 +498,11 @@ class _CapturedSteps:
 
 
     def _replay(self):
+        """The epoch's losses from the captured steps, or None when the steps cannot be captured (the caller then runs them eagerly)."""
         if self._graphs is None:
             self._build_graphs()
+            if self._graphs is None:
+                return None
         self.flat.zero()
         for g in self._graphs:
             g.replay()
@@ -458,7 +559,9 @@ class MBTrainer(_CapturedSteps):
         self.model.train()
         denom = self.n_loader_batches if self.reduction == "mean" else max(self.n_train, 1)
         if self.capture and self.flat.buf.is_cuda:
-            return self._replay().sum() / denom
+            losses = self._replay()
+            if losses is not None:
+                return losses.sum() / denom
         self.flat.zero()
         total = torch.zeros((), device=self.flat.buf.device)
         for part in self.parts:
@@ -664,7 +767,7 @@ class GraphTrainer(_CapturedSteps):
         try:
             side = torch.cuda.Stream(device=dev)
             side.wait_stream(torch.cuda.current_stream(dev))
-            with torch.cuda.stream(side):
+            with _accumulate_stream_guard() as guard, torch.cuda.stream(side):
                 for _ in range(2):   # warm-up (library workspaces, autograd buffers) on the epoch's first batch
                     plan.step_idx.zero_()
                     plan.assemble()
@@ -676,6 +779,10 @@ class GraphTrainer(_CapturedSteps):
             self.opt.m.copy_(saved_o[0]); self.opt.v.copy_(saved_o[1]); self.opt.step_count.copy_(saved_o[2])
             self.flat.zero()
             plan.step_idx.zero_(); plan.loss_sum.zero_(); plan.loss_slot.zero_()
+            if guard.mismatch:   # (see _accumulate_stream_guard) every batch of every epoch takes the eager way
+                self._shuffled_graph = "eager"
+                self.opt.seed_bank = None
+                return
             pool = torch.cuda.graph_pool_handle()
             graphs = []
             for reps in (1, max(int(getattr(self, "steps_per_graph", 8)), 1)):   # one step, and a run of steps (a replay costs ~10 us of its own)
@@ -724,7 +831,9 @@ class GraphTrainer(_CapturedSteps):
                 b["_tgt"] = self._target(b["y"])
             return self._one(b)
 
-        (_, g_one), (per, g_run) = self._shuffled_graph if n_full else ((1, None), (1, None))
+        if self._shuffled_graph == "eager":
+            fits = np.zeros(n_full, dtype=bool)
+        (_, g_one), (per, g_run) = self._shuffled_graph if (n_full and self._shuffled_graph != "eager") else ((1, None), (1, None))
         k = 0
         while k < n_full:
             if per > 1 and k + per <= n_full and bool(fits[k:k + per].all()):
@@ -763,7 +872,9 @@ class GraphTrainer(_CapturedSteps):
         if self._rebuild is not None:
             self._reshuffle()
         if self.capture and self.flat.buf.is_cuda:
-            return self._replay().sum() / max(len(self.batches), 1)
+            losses = self._replay()
+            if losses is not None:
+                return losses.sum() / max(len(self.batches), 1)
         self.flat.zero()
         total = torch.zeros((), device=self.flat.buf.device)
         if self.world > 1:

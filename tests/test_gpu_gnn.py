@@ -1200,3 +1200,71 @@ def test_shuffled_epochs_replay_one_captured_step(mods, kind, task, force_eager_
         assert t4._plan is None and t4._rebuild is None and t4.capture
         t5 = train.GraphTrainer(m1, gset, list(range(64)), kind="gs", batch_size=16, prop=1, reshuffle="auto", capture=True)
         assert t5._plan is not None and t5._rebuild is not None
+
+
+@pytest.mark.parametrize("hidden,classes", [(32, 4), (64, 47)])
+def test_gd_step_replayed_from_a_hipgraph_equals_the_eager_step(mods, hidden, classes):
+    """GDTrainer's lean, captured step (weight gradients to the optimiser's fresh buffer, ONE Adam launch, the whole step replayed
+    from a hipGraph) against the plain eager step (lean_step=False, capture=False): losses and weights over four epochs bit for bit
+    (dropout off), the gradients it leaves in p.grad; a step run under profiling hooks takes the eager path and still matches; with
+    dropout on successive replays draw different patterns."""
+    from fitgnn_amd import train
+
+    network, fnn, gorc = mods
+    batch, _ = _subgraph_batches(seed=3)
+    args = argparse.Namespace(num_layers1=2, layer_name="GCNConv", num_features=24, hidden=hidden, num_classes=classes)
+    if classes > 4:
+        batch.y = torch.randint(0, classes, batch.y.shape, device=batch.y.device)
+    torch.manual_seed(5)
+    m1, m2 = network.Classify_node(args).cuda(), network.Classify_node(args).cuda()
+    m2.load_state_dict(m1.state_dict())
+    m1.dropout_p = m2.dropout_p = 0.0
+    t1 = train.GDTrainer(m1, batch, lr=0.01, weight_decay=5e-4, lean_step=False, capture=False)
+    t2 = train.GDTrainer(m2, batch, lr=0.01, weight_decay=5e-4)
+    assert not t1.capture and t1.cfg.grad_sink is None and t2.capture and t2.cfg.grad_sink is t2.flat
+    for epoch in range(4):
+        if epoch == 2:
+            t2.cfg.profile = []        # hooks on: this step runs eagerly (and records its SpMM launches)
+        a, b = float(t1.step()), float(t2.step())
+        if epoch == 2:
+            assert len(t2.cfg.profile) >= 3
+            t2.cfg.profile = None
+        assert a == b, (epoch, a, b)
+        for (k, p), (_, q) in zip(m1.named_parameters(), m2.named_parameters()):
+            assert torch.equal(p.detach(), q.detach()), (epoch, k)
+            assert torch.equal(p.grad, q.grad), (epoch, k)
+    assert t2._graph is not None
+    m2.dropout_p = 0.5
+    t3 = train.GDTrainer(m2, batch, lr=0.0, weight_decay=0.0, capture=True)
+    l1 = float(t3.step())
+    l2 = float(t3.step())
+    assert l1 != l2
+
+
+def test_a_stale_autograd_graph_makes_the_trainers_step_eagerly_instead_of_capturing(mods):
+    """A `loss` of an earlier eager training phase that is still referenced keeps the parameters' AccumulateGrad nodes bound to the stream
+    that phase ran on; capturing a step on another stream would fork that stream into the hipGraph without a join (main.py --exp_setup
+    Gc_train_2_Gs_train did that once: the process died ending the capture).  train._accumulate_stream_guard sees autograd's report of it
+    during the warm-up steps and the trainers fall back to eager steps; once the reference is gone they capture."""
+    from fitgnn_amd import train
+
+    network, fnn, gorc = mods
+    batch, _ = _subgraph_batches(seed=4)
+    args = argparse.Namespace(num_layers1=2, layer_name="GCNConv", num_features=24, hidden=32, num_classes=4)
+    torch.manual_seed(5)
+    model = network.Classify_node(args).cuda()
+    model.dropout_p = 0.0
+    out = model(batch.x, batch.edge_index)
+    stale = torch.nn.functional.nll_loss(out.index_select(0, batch.train_idx), batch.y.index_select(0, batch.train_idx))
+    stale.backward()                       # ... and `stale` stays alive
+    ref = train.GDTrainer(model, batch, lr=0.0, weight_decay=0.0, lean_step=False, capture=False)
+    want = float(ref.step())
+    tr = train.GDTrainer(model, batch, lr=0.0, weight_decay=0.0, capture=True)
+    got = float(tr.step())
+    assert not tr.capture and tr._graph is None and got == want
+    mb = train.MBTrainer(model, batch, batch_size=8, lr=0.0, weight_decay=0.0, capture=True)
+    mb.step()
+    assert not mb.capture and mb._graphs is None
+    del stale, out
+    tr2 = train.GDTrainer(model, batch, lr=0.0, weight_decay=0.0, capture=True)
+    assert float(tr2.step()) == want and tr2.capture and tr2._graph is not None

@@ -59,7 +59,8 @@ def test_step_over_a_one_rank_rccl_group_equals_the_plain_step_bit_for_bit(dropo
         m_plain = network.Classify_node(args).cuda()
         m_dist = network.Classify_node(args).cuda()
         m_dist.load_state_dict(m_plain.state_dict())
-        t_plain = train.GDTrainer(m_plain, batch, lr=0.01, weight_decay=5e-4)
+        # (capture=False: a captured step draws its dropout seeds from a device-resident bank, the distributed step from torch's generator)
+        t_plain = train.GDTrainer(m_plain, batch, lr=0.01, weight_decay=5e-4, capture=False)
         assert not t_plain.dist                     # a one-rank default group alone does not switch the collectives on
         t_dist = train.GDTrainer(m_dist, batch, lr=0.01, weight_decay=5e-4, process_group=dist.group.WORLD)
         assert t_dist.dist and t_dist._split > 0    # two buckets: the late one leaves from the autograd hook
