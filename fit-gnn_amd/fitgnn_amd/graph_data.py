@@ -246,14 +246,7 @@ class PaddedBatchPlan:
         # row tiles: the usual packing of the diagonal blocks (cluster subgraphs / coarse graphs), cut at every graph boundary (a
         # tile's window is its own rows, and graph boundaries are block boundaries: both halves of a cut tile are valid tiles)
         from .csr import make_tiles, TILE_INTS
-        base = make_tiles(blocks, g_all.window_rows)
-        starts = np.union1d(base["row_begin"].astype(np.int64), g_row[:-1])
-        starts = starts[starts < R]
-        ends = np.append(starts[1:], R)
-        tiles = np.zeros((len(starts), TILE_INTS), dtype=np.int32)
-        tiles[:, 0], tiles[:, 1], tiles[:, 2], tiles[:, 3] = starts, ends, starts, ends - starts
-        tiles[:, 4], tiles[:, 5] = rp_host[starts], rp_host[ends]
-        g_tile = np.searchsorted(starts, g_row, side="left")
+        tiles, g_tile = cut_tiles_at_graphs(make_tiles(blocks, g_all.window_rows), g_row, rp_host)
         pooled = pooled_mask.to(torch.uint8).contiguous()
         mem = torch.nonzero(pooled_mask).flatten().to(torch.int32).contiguous()           # ascending: grouped by graph
         g_mem = np.searchsorted(mem.cpu().numpy().astype(np.int64), g_row, side="left")
@@ -347,6 +340,25 @@ class PaddedBatchPlan:
                                        d(self.b_rowptr), d(self.b_col), d(self.b_val), d(self.b_tiles), d(self.b_members), d(self.b_seg_off),
                                        d(self.b_seg_of_row), d(self.b_inv_cnt), d(self.b_ax), self.b_ax.stride(0), d(self.b_tgt), st),
                  "fitgnn_batch_gather")
+
+
+def cut_tiles_at_graphs(base, g_row, rowptr):
+    """Contiguous-window row tiles (csr.make_tiles: a partition of rows 0 .. R into runs of whole diagonal blocks, window == the tile's
+    own rows) cut at every graph boundary g_row[1:-1], so that no tile spans two graphs and a graph's tiles can be moved with its rows.
+    Graph boundaries are block boundaries: both halves of a cut tile are valid tiles.  Returns (tiles int32 [T, 8] in row order with
+    nnz_begin / nnz_end from `rowptr`, g_tile int64 [G + 1]: graph g owns tiles g_tile[g] .. g_tile[g + 1])."""
+    from .csr import TILE_INTS
+
+    g_row = np.asarray(g_row, dtype=np.int64)
+    rowptr = np.asarray(rowptr, dtype=np.int64)
+    R = int(g_row[-1])
+    starts = np.union1d(np.asarray(base["row_begin"], dtype=np.int64), g_row[:-1])
+    starts = starts[starts < R]
+    ends = np.append(starts[1:], R)
+    tiles = np.zeros((len(starts), TILE_INTS), dtype=np.int32)
+    tiles[:, 0], tiles[:, 1], tiles[:, 2], tiles[:, 3] = starts, ends, starts, ends - starts
+    tiles[:, 4], tiles[:, 5] = rowptr[starts], rowptr[ends]
+    return tiles, np.searchsorted(starts, g_row, side="left")
 
 
 def ops_csr_for(edge_index, n):

@@ -589,3 +589,35 @@ def test_host_tile_packing_and_block_split_equal_their_python_reference():
         assert np.array_equal(s1, s2), (trial, "small tiles")
         assert np.array_equal(b1, b2), (trial, "blocks")
         assert np.array_equal(l1, l2), (trial, "long rows")
+
+
+def test_tiles_cut_at_graph_boundaries_partition_every_graph():
+    """graph_data.cut_tiles_at_graphs (the device batch assembly's tile table): the packed tiles of a dataset's diagonal blocks cut at every
+    graph boundary -- a partition of the rows in order, no tile across two graphs, every tile a run of whole blocks of at most `cap`
+    rows (or a piece of a larger block) whose window is its own rows, per-graph tile ranges that cover exactly the graph's rows."""
+    from fitgnn_amd import csr, graph_data
+
+    rng = np.random.default_rng(5)
+    for trial in range(30):
+        n_graphs = int(rng.integers(1, 25))
+        blocks_per_graph = rng.integers(1, 7, size=n_graphs)
+        sizes = rng.choice([1, 2, 3, 5, 9, 15, 16, 17, 40], size=int(blocks_per_graph.sum()))
+        ptr = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+        g_row = ptr[np.concatenate([[0], np.cumsum(blocks_per_graph)])]
+        R = int(ptr[-1])
+        rowptr = np.concatenate([[0], np.cumsum(rng.integers(1, 9, size=R))]).astype(np.int64)
+        cap = int(rng.choice([4, 16]))
+        tiles, g_tile = graph_data.cut_tiles_at_graphs(csr.make_tiles(ptr, cap), g_row, rowptr)
+        assert tiles[0, 0] == 0 and tiles[-1, 1] == R and np.array_equal(tiles[1:, 0], tiles[:-1, 1])
+        assert np.array_equal(tiles[:, 2], tiles[:, 0]) and np.array_equal(tiles[:, 3], tiles[:, 1] - tiles[:, 0])
+        assert np.all(tiles[:, 3] <= cap) and np.all(tiles[:, 3] > 0)
+        assert np.array_equal(tiles[:, 4], rowptr[tiles[:, 0]]) and np.array_equal(tiles[:, 5], rowptr[tiles[:, 1]])
+        block_set = set(ptr.tolist())
+        for a, b in tiles[:, :2]:
+            whole = (int(a) in block_set) and (int(b) in block_set)
+            inside = np.searchsorted(ptr, a, side="right") == np.searchsorted(ptr, b - 1, side="right")
+            assert whole or inside, (trial, a, b)   # a run of whole blocks, or a piece inside one large block
+        assert g_tile[0] == 0 and g_tile[-1] == len(tiles)
+        for g in range(n_graphs):
+            t = tiles[g_tile[g]:g_tile[g + 1]]
+            assert len(t) > 0 and t[0, 0] == g_row[g] and t[-1, 1] == g_row[g + 1]
