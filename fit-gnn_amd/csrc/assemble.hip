@@ -173,6 +173,7 @@ struct BatchGlobal {   // the dataset's arrays (device)
     const fitgnn_tile_t *tiles;
     const int32_t *mem;         // pooled rows (global row ids), grouped by graph
     const uint8_t *pooled;      // per row: 1 = the row is pooled
+    const int32_t *mem_rank;    // per row: its rank among the pooled rows of its graph (pooled rows only)
     const float *ax;            // [rows x K] (row stride ld_ax): the first layer's aggregated input
     const float *tgt;           // [graphs x n_tgt]
 };
@@ -182,11 +183,15 @@ struct BatchOut {      // the batch's fixed-capacity buffers (device)
     fitgnn_tile_t *tiles;
     int32_t *members, *seg_off, *seg_of_row;
     float *inv_cnt, *ax, *tgt;
+    int64_t *members64;         // the pooled rows once more, as the int64 row index the layers take
+    int32_t *cseg;              // graph of compact (pooled) row i, -1 past the batch's pooled rows
+    int32_t *pos;               // per batch row: its compact position, or M_cap + r % zero_rows (a zero row of a compact operand)
 };
 
 __global__ __launch_bounds__(256) void batch_gather_kernel(int32_t B, const int32_t *__restrict__ off, const int32_t *__restrict__ gid,
                                                            BatchGlobal G, BatchOut O, int32_t R_cap, int32_t E_cap, int32_t T_cap,
-                                                           int32_t M_cap, int32_t K, int32_t ld_ax_g, int32_t ld_ax, int32_t n_tgt) {
+                                                           int32_t M_cap, int32_t K, int32_t ld_ax_g, int32_t ld_ax, int32_t n_tgt,
+                                                           int32_t zero_rows) {
     const int32_t idx = (int32_t)(blockIdx.x * 256 + threadIdx.x);
     const int32_t *o_row = off, *o_nnz = off + (B + 1), *o_tile = off + 2 * (B + 1), *o_mem = off + 3 * (B + 1);
     const int32_t n_row = o_row[B], n_nnz = o_nnz[B], n_tile = o_tile[B], n_mem = o_mem[B];
@@ -196,12 +201,15 @@ __global__ __launch_bounds__(256) void batch_gather_kernel(int32_t B, const int3
             const int32_t g = gid[i];
             const int32_t src = G.g_row_ptr[g] + (idx - o_row[i]);
             O.rowptr[idx] = o_nnz[i] + (G.rowptr[src] - G.g_nnz_ptr[g]);
-            O.seg_of_row[idx] = G.pooled[src] ? i : -1;
+            const bool pl = G.pooled[src] != 0;
+            O.seg_of_row[idx] = pl ? i : -1;
+            if (O.pos) O.pos[idx] = pl ? o_mem[i] + G.mem_rank[src] : M_cap + idx % zero_rows;
             for (int k = 0; k < K; ++k) O.ax[(int64_t)idx * ld_ax + k] = G.ax[(int64_t)src * ld_ax_g + k];
         } else {
             O.rowptr[idx] = n_nnz;   // rows past the batch: no entries
             if (idx < R_cap) {
                 O.seg_of_row[idx] = -1;
+                if (O.pos) O.pos[idx] = M_cap + idx % zero_rows;
                 for (int k = 0; k < K; ++k) O.ax[(int64_t)idx * ld_ax + k] = 0.f;
             }
         }
@@ -243,13 +251,16 @@ __global__ __launch_bounds__(256) void batch_gather_kernel(int32_t B, const int3
         O.tiles[idx] = t;
     }
     if (idx < M_cap) {    // pooled rows, grouped by graph
-        int32_t m = 0;
+        int32_t m = 0, sg = -1;
         if (idx < n_mem) {
             const int i = batch_find(o_mem, B, idx);
             const int32_t g = gid[i];
             m = G.mem[G.g_mem_ptr[g] + (idx - o_mem[i])] - G.g_row_ptr[g] + o_row[i];
+            sg = i;
         }
         O.members[idx] = m;
+        if (O.members64) O.members64[idx] = m;
+        if (O.cseg) O.cseg[idx] = sg;
     }
     if (idx <= B) {       // per graph: segment offsets, 1 / count, targets
         O.seg_off[idx] = o_mem[idx];
@@ -280,16 +291,18 @@ extern "C" int fitgnn_batch_gather(int32_t B, const int32_t *off, const int32_t 
                                    int32_t ld_ax_g, const float *tgt, int32_t n_tgt, int32_t K, int32_t R_cap, int32_t E_cap, int32_t T_cap,
                                    int32_t M_cap, int32_t *b_rowptr, int32_t *b_col, float *b_val, fitgnn_tile_t *b_tiles,
                                    int32_t *b_members, int32_t *b_seg_off, int32_t *b_seg_of_row, float *b_inv_cnt, float *b_ax,
-                                   int32_t ld_ax, float *b_tgt, void *stream) {
+                                   int32_t ld_ax, float *b_tgt, const int32_t *mem_rank, int64_t *b_members64, int32_t *b_cseg,
+                                   int32_t *b_pos, int32_t zero_rows, void *stream) {
     if (B < 1 || B > kBatchMaxGraphs || R_cap < 1 || E_cap < 1 || T_cap < 1 || M_cap < 1 || K < 1 || n_tgt < 1 || ld_ax_g < K || ld_ax < K)
         return FITGNN_E_BADARG;
     if (!off || !gid || !g_row_ptr || !g_nnz_ptr || !g_tile_ptr || !g_mem_ptr || !rowptr || !col || !val || !tiles || !mem || !pooled || !ax ||
         !tgt || !b_rowptr || !b_col || !b_val || !b_tiles || !b_members || !b_seg_off || !b_seg_of_row || !b_inv_cnt || !b_ax || !b_tgt)
         return FITGNN_E_BADARG;
-    const BatchGlobal G{g_row_ptr, g_nnz_ptr, g_tile_ptr, g_mem_ptr, rowptr, col, val, tiles, mem, pooled, ax, tgt};
-    const BatchOut O{b_rowptr, b_col, b_val, b_tiles, b_members, b_seg_off, b_seg_of_row, b_inv_cnt, b_ax, b_tgt};
+    if (b_pos && (!mem_rank || zero_rows < 1)) return FITGNN_E_BADARG;
+    const BatchGlobal G{g_row_ptr, g_nnz_ptr, g_tile_ptr, g_mem_ptr, rowptr, col, val, tiles, mem, pooled, mem_rank, ax, tgt};
+    const BatchOut O{b_rowptr, b_col, b_val, b_tiles, b_members, b_seg_off, b_seg_of_row, b_inv_cnt, b_ax, b_tgt, b_members64, b_cseg, b_pos};
     const int64_t items = std::max<int64_t>(std::max<int64_t>((int64_t)R_cap + 1, E_cap), std::max<int64_t>(std::max<int64_t>(T_cap, M_cap), B + 1));
     hipLaunchKernelGGL(batch_gather_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, (hipStream_t)stream, B, off, gid, G, O, R_cap,
-                       E_cap, T_cap, M_cap, K, ld_ax_g, ld_ax, n_tgt);
+                       E_cap, T_cap, M_cap, K, ld_ax_g, ld_ax, n_tgt, zero_rows > 0 ? zero_rows : 1);
     return (int)hipGetLastError();
 }

@@ -1006,6 +1006,14 @@ extern "C" int fitgnn_epilogue_bwd_head_rows_f32(const float *dy, const float *W
                                rows, inputs_compact ? 1 : 0);
 }
 
+extern "C" int fitgnn_epilogue_bwd_rows_f32(const float *dOut, const float *out, const int64_t *rows, int32_t n_sel, int32_t inputs_compact,
+                                            float *dZc, int32_t H, uint32_t epilogue, float p_drop, uint64_t seed, const uint8_t *mask,
+                                            float *db, void *work, size_t work_bytes, void *stream) {
+    if (n_sel > 0 && (!rows || !dOut)) return FITGNN_E_BADARG;
+    return epilogue_bwd_launch(dOut, nullptr, nullptr, 0, out, dZc, n_sel, H, epilogue, p_drop, seed, mask, db, nullptr, work, work_bytes,
+                               stream, rows, inputs_compact ? 1 : 0);
+}
+
 extern "C" int fitgnn_epilogue_fwd_rows_f32(float *z, int64_t ldz, const int64_t *rows, int32_t n, int32_t H, const float *bias,
                                             uint32_t epilogue, float p_drop, uint64_t seed, const uint8_t *mask, void *stream) {
     if (n < 0 || H < 4 || (H % 4) != 0 || ldz < H || (ldz % 4) != 0) return FITGNN_E_BADARG;

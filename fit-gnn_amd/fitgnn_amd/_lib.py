@@ -67,6 +67,7 @@ SIGNATURES = {
                                                    ptr, c_size, ptr]),
     "fitgnn_epilogue_bwd_head_rows_f32": (ctypes.c_int, [ptr, ptr, c_i32, ptr, ptr, c_i32, c_i32, ptr, c_i32, c_u32, c_f32, c_u64, ptr,
                                                         ptr, ptr, ptr, c_size, ptr]),
+    "fitgnn_epilogue_bwd_rows_f32": (ctypes.c_int, [ptr, ptr, ptr, c_i32, c_i32, ptr, c_i32, c_u32, c_f32, c_u64, ptr, ptr, ptr, c_size, ptr]),
     "fitgnn_spmm_epilogue_bwd_supported": (ctypes.c_int, [c_i32, c_i32, c_i32]),
     "fitgnn_spmm_epilogue_bwd_workspace_bytes": (c_size, [c_i32, c_i32, c_i32]),
     "fitgnn_spmm_epilogue_bwd_f32": (ctypes.c_int, [ptr, ptr, ptr, ptr, c_i32, c_i32, ptr, ptr, ptr, c_i32, ptr, ptr, c_i32, c_i32,
@@ -115,7 +116,8 @@ SIGNATURES = {
     "fitgnn_induced_edges_fill": (ctypes.c_int, [ptr, ptr, ptr, ptr, ptr, ptr, ptr, c_i64, ptr, ptr, ptr, ptr]),
     "fitgnn_batch_offsets": (ctypes.c_int, [ptr, ptr, c_i32, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr]),
     "fitgnn_batch_gather": (ctypes.c_int, [c_i32, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, c_i32, ptr, c_i32, c_i32,
-                                           c_i32, c_i32, c_i32, c_i32, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, c_i32, ptr, ptr]),
+                                           c_i32, c_i32, c_i32, c_i32, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, c_i32, ptr, ptr, ptr, ptr, ptr,
+                                           c_i32, ptr]),
     "fitgnn_closed_neighbourhoods": (ctypes.c_int, [ptr, ptr, c_i32, ptr, ptr, ptr]),
     "fitgnn_variation_costs_f64": (ctypes.c_int, [ptr, ptr, ptr, ptr, ptr, c_i32, c_i64, ptr, ptr, ptr, c_i32, ptr, ptr]),
     "fitgnn_variation_costs_batch_f64": (ctypes.c_int, [ptr, ptr, ptr, ptr, ptr, c_i32, c_i64, ptr, ptr, ptr, ptr, c_i32, ptr, ptr]),

@@ -249,7 +249,13 @@ class PaddedBatchPlan:
         tiles, g_tile = cut_tiles_at_graphs(make_tiles(blocks, g_all.window_rows), g_row, rp_host)
         pooled = pooled_mask.to(torch.uint8).contiguous()
         mem = torch.nonzero(pooled_mask).flatten().to(torch.int32).contiguous()           # ascending: grouped by graph
-        g_mem = np.searchsorted(mem.cpu().numpy().astype(np.int64), g_row, side="left")
+        mem_host = mem.cpu().numpy().astype(np.int64)
+        g_mem = np.searchsorted(mem_host, g_row, side="left")
+        # rank of a pooled row among its graph's pooled rows (the compact position of the row inside its graph)
+        rank = np.zeros(R, dtype=np.int32)
+        graph_of_mem = np.searchsorted(g_row, mem_host, side="right") - 1
+        rank[mem_host] = (np.arange(len(mem_host)) - g_mem[graph_of_mem]).astype(np.int32)
+        self.mem_rank = torch.from_numpy(rank).to(dev)
         self.sizes = np.stack([np.diff(g_row), np.diff(g_nnz), np.diff(g_tile), np.diff(g_mem)], 1).astype(np.int64)   # [G, 4]
         mean, std = self.sizes.mean(0), self.sizes.std(0)
         cap = np.ceil(B * mean + sigmas * np.sqrt(B) * std + 1).astype(np.int64)
@@ -272,6 +278,7 @@ class PaddedBatchPlan:
         self.b_rowptr, self.b_col, self.b_val = z(self.R_cap + 1, torch.int32), z(self.E_cap, torch.int32), z(self.E_cap, torch.float32)
         self.b_tiles = torch.zeros((self.T_cap, TILE_INTS), dtype=torch.int32, device=dev)
         self.b_members, self.b_seg_off = z(self.M_cap, torch.int32), z(B + 1, torch.int32)
+        self.b_members64, self.b_cseg, self.b_pos = z(self.M_cap, torch.int64), z(self.M_cap, torch.int32), z(self.R_cap, torch.int32)
         self.b_seg_of_row, self.b_inv_cnt = z(self.R_cap, torch.int32), z(B, torch.float32)
         self.b_ax = torch.zeros((self.R_cap, self.K), dtype=torch.float32, device=dev)
         self.b_tgt = torch.zeros((B, self.n_tgt), dtype=torch.float32, device=dev)
@@ -279,6 +286,7 @@ class PaddedBatchPlan:
         self.step_idx = z(1, torch.int32)
         self.loss_slot, self.loss_sum = z(1, torch.float32), z(1, torch.float32)
         self.perm = None                                     # int64 [>= steps x B]: set_epoch()
+        self._zero_rows = int(ops.ZERO_ROWS)
         self.batch = self._static_batch(g_all)
         self._L, self._lib = _lib.lib(), _lib
 
@@ -304,13 +312,22 @@ class PaddedBatchPlan:
         pi.n_rows, pi.seg_of_row, pi.inv_cnt = self.R_cap, self.b_seg_of_row, self.b_inv_cnt
         self.graph = g
         if self.kind == "gs":
-            rows = torch.zeros(self.M_cap, dtype=torch.int64, device=dev)                 # stand-ins for mask_idx / graph_of_masked
-            batch = torch.zeros(self.M_cap, dtype=torch.int64, device=dev)
-            batch._fitgnn_pool = ((batch._version, B, (rows.data_ptr(), rows._version), self.R_cap), pi, rows)
+            rows = self.b_members64                                                       # mask_idx: the pooled rows (filled per batch)
+            batch = torch.zeros(self.M_cap, dtype=torch.int64, device=dev)                # stand-in for graph_of_masked
+            # the pool over x[rows] ...
+            cache = {(batch._version, B, (rows.data_ptr(), rows._version), self.R_cap): (pi, rows)}
+            # ... and over the compact pooled rows (a last layer evaluated on them only, ops.FusedGCNLayerRows): members = 0 .. M_cap - 1
+            pc = object.__new__(ops.PoolIndex)
+            pc.n_seg, pc.sorted, pc.seg_off = B, True, self.b_seg_off
+            pc.members = torch.arange(self.M_cap, dtype=torch.int32, device=dev)
+            pc.n_rows, pc.seg_of_row, pc.inv_cnt = self.M_cap, self.b_cseg, self.b_inv_cnt
+            cache[(batch._version, B, None, self.M_cap)] = (pc, None)
+            batch._fitgnn_pool = cache
+            g._compact_pos = (rows, rows._version, self.b_pos)                            # ops._compact_positions(g, rows)
             return dict(x=x, edge_index=e, mask=None, mask_idx=rows, graph_of_masked=batch, y=self.b_tgt, n_graphs=B)
         import types
         batch = torch.zeros(self.R_cap, dtype=torch.int64, device=dev)                    # stand-in for the PyG batch vector
-        batch._fitgnn_pool = ((batch._version, B, None, self.R_cap), pi, None)
+        batch._fitgnn_pool = {(batch._version, B, None, self.R_cap): (pi, None)}
         return dict(x=x, edge_index=e, mask=None, y=self.b_tgt, n_graphs=B,
                     gc=types.SimpleNamespace(x=x, edge_index=e, batch=batch, num_graphs=B))
 
@@ -338,7 +355,8 @@ class PaddedBatchPlan:
                                        d(self.rowptr), d(self.col), d(self.val), d(self.tiles), d(self.mem), d(self.pooled), d(self.ax),
                                        self.ax.stride(0), d(self.tgt), self.n_tgt, self.K, self.R_cap, self.E_cap, self.T_cap, self.M_cap,
                                        d(self.b_rowptr), d(self.b_col), d(self.b_val), d(self.b_tiles), d(self.b_members), d(self.b_seg_off),
-                                       d(self.b_seg_of_row), d(self.b_inv_cnt), d(self.b_ax), self.b_ax.stride(0), d(self.b_tgt), st),
+                                       d(self.b_seg_of_row), d(self.b_inv_cnt), d(self.b_ax), self.b_ax.stride(0), d(self.b_tgt), d(self.mem_rank),
+                                       d(self.b_members64), d(self.b_cseg), d(self.b_pos), self._zero_rows, st),
                  "fitgnn_batch_gather")
 
 

@@ -77,17 +77,23 @@ class _Base(nn.Module):
         return ops.FusedGCNLayerDedup.apply(x_table.float(), conv.lin.weight, conv.bias, g, x_index, float(self.dropout_p),
                                             bool(self.training), seed, mask, link_out, cfg)
 
-    def prepare_static(self, x, edge_index):
-        """Form ahead of time what the first layer keeps per (graph, input) -- A_hat x of a narrow static input
-        (ops.aggregated_input) -- e.g. before the steps over a set of static batches are captured in hipGraphs."""
+    def prepare_static(self, x, edge_index, pooled_rows=None):
+        """Form ahead of time what the layers keep per (graph, input) -- A_hat x of a narrow static input (ops.aggregated_input), the
+        compact positions of the pooled rows (ops.FusedGCNLayerRows' backward) -- e.g. before the steps over a
+        set of static batches are captured in hipGraphs: made lazily inside a step they would be captured and replayed with it."""
         conv = self.conv[0] if self.num_layers > 0 else None
         if (isinstance(conv, fnn.GCNConv) and torch.is_tensor(x) and x.is_cuda and x.dtype == torch.float32
                 and ops.narrow_input_supported(x, conv.lin.weight, self.op_config)):
             ops.aggregated_input(conv.graph(edge_index, x.shape[0]), x, self.op_config)
+        last = self.conv[self.num_layers - 1] if self.num_layers > 0 else None
+        if (pooled_rows is not None and torch.is_tensor(x) and x.is_cuda and isinstance(last, fnn.GCNConv) and self.op_config.pooled_rows_last_layer
+                and pooled_rows.dtype == torch.int64 and pooled_rows.numel() > 0):
+            ops._compact_positions(last.graph(edge_index, x.shape[0]), pooled_rows)
 
-    def embed(self, x, edge_index, x_index=None, first=0, link=None, last=None):
+    def embed(self, x, edge_index, x_index=None, first=0, link=None, last=None, return_link=False):
         """conv -> ELU -> dropout, layers first .. last - 1 (default: all; network.py:29-33).  link: the EpilogueLink recorded by the
-        layer that produced x (consecutive fused GCN layers are linked: see ops.EpilogueLink; the stack is strictly sequential)."""
+        layer that produced x (consecutive fused GCN layers are linked: see ops.EpilogueLink; the stack is strictly sequential).
+        return_link: also return the link the last evaluated layer recorded for its ONE consumer (None when it recorded none)."""
         x = x.float()
         for i in range(first, self.num_layers if last is None else last):
             conv = self.conv[i]
@@ -114,7 +120,28 @@ class _Base(nn.Module):
                 x = F.elu(x)
                 x = F.dropout(x, p=self.dropout_p, training=self.training)
                 link = None
-        return x
+        return (x, link) if return_link else x
+
+    def embed_pooled_rows(self, x, edge_index, rows):
+        """embed() for a consumer that reads only `rows` of the result (the *_graph_gs models' pool over x[mask], network.py:129-131,
+        :200-202): the last GCN layer aggregate-first on those rows, output compact [len(rows), hidden] (ops.FusedGCNLayerRows).
+        None where that does not apply (the caller then embeds every row)."""
+        L, cfg = self.num_layers, self.op_config
+        last = self.conv[L - 1] if L > 0 else None
+        if not (cfg.pooled_rows_last_layer and x.is_cuda and isinstance(last, fnn.GCNConv) and rows.dtype == torch.int64 and rows.numel() > 0
+                and last.lin.weight.shape[0] % 4 == 0 and all(isinstance(c, (fnn.GCNConv, fnn.GATConv)) for c in self.conv)):
+            return None
+        if L > 1:
+            h, link = self.embed(x, edge_index, last=L - 1, return_link=True)
+        else:
+            h, link = x.float(), None
+        if h.shape[1] % 4 != 0 and link is not None:
+            link = None
+        mask = self._inject_masks[L - 1] if self._inject_masks is not None else None
+        g = last.graph(edge_index, h.shape[0])
+        seed = ops.next_seed(cfg) if (self.training and self.dropout_p > 0 and mask is None) else 0
+        return ops.FusedGCNLayerRows.apply(h, last.lin.weight, last.bias, g, float(self.dropout_p), bool(self.training), seed, mask, rows, cfg,
+                                           link)
 
     def embed_and_head(self, x, edge_index, x_index=None, out_rows=None, loss_rows=None, compact_logits=False, forward_rows_only=False):
         """embed() followed by lt1; on the GPU the last GCN layer and the head form one autograd node.
@@ -335,6 +362,11 @@ def _gs_inputs(set_gs, batch_tensor):
     return _merge_subgraphs(set_gs, batch_tensor.device) + (None,)
 
 
+def _pooled_rows_ok(set_gs, mask):
+    """The pooled rows come as a precomputed int64 index (GraphSet batches) and the batch does not opt out."""
+    return isinstance(set_gs, dict) and mask is not None and mask.dtype == torch.int64 and not set_gs.get("_no_pooled_rows", False)
+
+
 def _take(x, mask):
     """x[mask] for a bool mask, or index_select for a precomputed index (no host sync: usable under graph capture)."""
     return x.index_select(0, mask) if mask.dtype == torch.int64 else x[mask]
@@ -350,7 +382,11 @@ def _pool_rows(pool, x, mask, batch_tensor, size):
 class Classify_graph_gs(_Base):
     def forward(self, set_gs, batch_tensor):
         x, ei, mask, size = _gs_inputs(set_gs, batch_tensor)
-        x = self.head(_pool_rows(fnn.global_max_pool, self.embed(x, ei), mask, batch_tensor, size))
+        hc = self.embed_pooled_rows(x, ei, mask) if _pooled_rows_ok(set_gs, mask) else None
+        if hc is not None:   # the last layer on the pooled rows only: the pool runs over the compact rows
+            x = self.head(fnn.global_max_pool(hc, batch_tensor.to(torch.int64), size))
+        else:
+            x = self.head(_pool_rows(fnn.global_max_pool, self.embed(x, ei), mask, batch_tensor, size))
         return F.softmax(x, dim=0 if x.dim() == 1 else 1)
 
 
@@ -359,6 +395,9 @@ class Regress_graph_gs(_Base):
 
     def forward(self, set_gs, batch_tensor):
         x, ei, mask, size = _gs_inputs(set_gs, batch_tensor)
+        hc = self.embed_pooled_rows(x, ei, mask) if _pooled_rows_ok(set_gs, mask) else None
+        if hc is not None:   # the last layer on the pooled rows only: pool and head over the compact rows
+            return _mean_pool_head(self, hc, batch_tensor.to(torch.int64), size)
         h = self.embed(x, ei)
         if mask.dtype == torch.int64 and h.is_cuda:   # a precomputed row index (GraphSet batches): pool and head in one launch
             return _mean_pool_head(self, h, batch_tensor.to(torch.int64), size, rows=mask)

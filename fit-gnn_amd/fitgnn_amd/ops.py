@@ -46,6 +46,10 @@ class OpConfig:
     compact_rows_kernel  a backward SpMM whose operand is compact (compact_head_backward / last_layer_on_loss_rows) runs on the
                      row-streaming kernel (fitgnn_spmm_rows_compact[_dz]_f32: no LDS windows, every wave streams a range of rows)
                      instead of the tile / whole-subgraph kernels with a row indirection (A/B switch; dZ bit-identical).
+    rows_kernel_min_rows  ... for a backward product WITH the previous layer's derivative in its store (spmm_graph_dz) only from this
+                     many rows on (32 768): the kernel gives every wave a contiguous range of >= 32 rows, so a 5 000-row batch of small
+                     graphs is 150 ranges -- a few dozen workgroups walking their rows one after the other (38 us on a 128-molecule QM9
+                     batch against 8 us for the tile kernel with the row indirection); it is the kernel for unions of 10^5 rows and more.
     stream_kernel    a batch whose runs go to the whole-subgraph kernel (split_large_blocks) runs on the segment-streaming kernel instead
                      (fitgnn_spmm_csr_stream[_dz]_f32: the same algorithm with one wave per run of segments, no LDS; one launch covers
                      every row; same bits).  Off: measured slower than the whole-subgraph kernel on S-products (7.6-7.9 vs 6.3-6.7 ms
@@ -60,6 +64,8 @@ class OpConfig:
                      512) runs aggregate-first, (A_hat x) W^T, with A_hat x formed ONCE per (graph, input) and kept on the graph: per
                      step the layer is one pass over its output (fitgnn_dense_narrow_k_f32) and its backward one pass over the incoming
                      gradient (fitgnn_narrow_atb_f32: no SpMM, no dZ) -- FusedGCNLayerAggregatedInput.
+    pooled_rows_last_layer  the last GCN layer of the *_graph_gs models aggregate-first on the rows their pool reads (x[mask]), output
+                     compact (FusedGCNLayerRows): its dense products run on about half of the union's rows (A/B switch).
     fused_pool_head  lt1(global_mean_pool(x[rows])) of the graph-level regression models as one launch each way (MeanPoolHead) instead
                      of pool, scale, library product and bias add (A/B switch).
     grad_sink        None, or an object with `.view(data_ptr)` -> the slice of a "fresh gradients" buffer that belongs to the parameter stored at
@@ -74,12 +80,12 @@ class OpConfig:
     seed_bank        None, or a SeedBank supplying device-resident dropout seeds (steps captured in a hipGraph)."""
     __slots__ = ("gemm_precision", "atb_kernel", "nt_kernel", "nt_presplit", "fuse_dx_epilogue", "fold_backward",
                  "dedup_gather", "pad_table_min_k", "split_large_blocks", "compact_head_backward", "last_layer_on_loss_rows",
-                 "compact_rows_kernel", "stream_kernel", "two_hop_backward", "narrow_input_first", "fused_pool_head", "grad_sink", "profile", "profile_gemm",
+                 "compact_rows_kernel", "stream_kernel", "two_hop_backward", "narrow_input_first", "fused_pool_head", "pooled_rows_last_layer", "rows_kernel_min_rows", "grad_sink", "profile", "profile_gemm",
                  "profile_fused", "seed_bank")
 
     def __init__(self, gemm_precision="exact", atb_kernel=True, nt_kernel=True, nt_presplit=True, fuse_dx_epilogue=True,
                  fold_backward=False, dedup_gather=True, pad_table_min_k=0, split_large_blocks=True, compact_head_backward=True,
-                 last_layer_on_loss_rows=True, compact_rows_kernel=True, stream_kernel=False, two_hop_backward=True, narrow_input_first=True, fused_pool_head=True, grad_sink=None,
+                 last_layer_on_loss_rows=True, compact_rows_kernel=True, stream_kernel=False, two_hop_backward=True, narrow_input_first=True, fused_pool_head=True, pooled_rows_last_layer=True, rows_kernel_min_rows=32768, grad_sink=None,
                  profile=None, profile_gemm=None, profile_fused=None, seed_bank=None):
         if gemm_precision not in ("exact", "high", "highest"):
             raise ValueError(f"gemm_precision {gemm_precision!r}: 'exact', 'high' or 'highest'")
@@ -89,6 +95,7 @@ class OpConfig:
         self.compact_head_backward, self.last_layer_on_loss_rows = compact_head_backward, last_layer_on_loss_rows
         self.compact_rows_kernel, self.stream_kernel, self.two_hop_backward = compact_rows_kernel, stream_kernel, two_hop_backward
         self.narrow_input_first, self.fused_pool_head, self.grad_sink = narrow_input_first, fused_pool_head, grad_sink
+        self.pooled_rows_last_layer, self.rows_kernel_min_rows = pooled_rows_last_layer, int(rows_kernel_min_rows)
         self.profile, self.profile_gemm, self.profile_fused, self.seed_bank = profile, profile_gemm, profile_fused, seed_bank
 
     def replace(self, **kw):
@@ -580,6 +587,25 @@ def epilogue_bwd_raw(dOut, out, epilogue, p=0.0, seed=0, mask=None, want_db=True
     return dZ, db
 
 
+def epilogue_bwd_rows_raw(dOutc, outc, rows, epilogue, p=0.0, seed=0, mask=None, want_db=True, db_out=None):
+    """epilogue_bwd_raw on compact matrices: row i of dOutc / outc is ORIGINAL row rows[i] (its mask entry / dropout hash)
+    (fitgnn_epilogue_bwd_rows_f32)."""
+    _lib.require_cuda(dOutc, outc, rows, mask)
+    L = _lib.lib()
+    dOutc, outc = _f32c(dOutc), _f32c(outc)
+    rows = (rows if rows.dtype == torch.int64 else rows.long()).contiguous()
+    n, H = outc.shape
+    seed, epilogue = _seed_arg(seed, epilogue)
+    dZ = torch.empty_like(outc)
+    db = (db_out if db_out is not None else torch.empty(H, dtype=torch.float32, device=outc.device)) if want_db else None
+    wb = int(L.fitgnn_epilogue_bwd_workspace_bytes(n, H)) if want_db else 0
+    work = torch.empty(max(wb, 4), dtype=torch.uint8, device=outc.device)
+    rc = L.fitgnn_epilogue_bwd_rows_f32(_lib.dptr(dOutc), _lib.dptr(outc), _lib.dptr(rows), n, 1, _lib.dptr(dZ), H, epilogue, float(p), seed,
+                                        _lib.dptr(mask), _lib.dptr(db), _lib.dptr(work), wb, _lib.stream_ptr(outc.device))
+    _lib.check(rc, "fitgnn_epilogue_bwd_rows_f32")
+    return dZ, db
+
+
 def spmm_blocks_raw(rowptr, col, val, blocks, long_rows, X, Y, bias=None, epilogue=0, p=0.0, seed=0, mask=None, cfg=DEFAULT, xrow=None,
                     xcol=None, zero_from=-1):
     """The rows of the listed large diagonal blocks of Y = epilogue(A @ X) through fitgnn_spmm_csr_blocks_f32 (one workgroup
@@ -896,7 +922,7 @@ def spmm_graph_dz(g, X, prev, epilogue, p=0.0, seed=0, mask=None, want_db=True, 
     _lib.require_cuda(Xc, prev, mask, xrow)
     L = _lib.lib()
     H = Xc.shape[1]
-    if xrow is not None and zero_from >= 0 and cfg.compact_rows_kernel and H % 4 == 0:
+    if xrow is not None and zero_from >= 0 and cfg.compact_rows_kernel and H % 4 == 0 and g.n >= cfg.rows_kernel_min_rows:
         return _spmm_rows_compact(g, side, Xc, xrow, zero_from, cfg, profile_kind, dz=(prev, epilogue, p, seed, mask, want_db))
     if (side.blocks is not None and cfg.split_large_blocks and cfg.stream_kernel and g.seg is not None and zero_from < 0 and H % 4 == 0
             and Xc.stride(0) % 4 == 0):
@@ -1089,11 +1115,17 @@ def pool_index(batch, size, rows=None, n_rows=None):
     """PoolIndex of (batch, rows), cached on the batch tensor (a trainer passes the same static tensors every step; building it
     synchronises with the host once, before any capture)."""
     cache = getattr(batch, "_fitgnn_pool", None)
-    key = (batch._version, int(size), None if rows is None else (rows.data_ptr(), rows._version), n_rows)
-    if cache is None or cache[0] != key:
-        cache = (key, PoolIndex(batch, size, rows, n_rows), rows)   # (the entry holds `rows`: its address cannot be recycled meanwhile)
+    if cache is None:
+        cache = {}
         batch._fitgnn_pool = cache
-    return cache[1]
+    key = (batch._version, int(size), None if rows is None else (rows.data_ptr(), rows._version), n_rows)
+    hit = cache.get(key)
+    if hit is None:
+        if len(cache) > 8:
+            cache.clear()
+        hit = (PoolIndex(batch, size, rows, n_rows), rows)   # (the entry holds `rows`: its address cannot be recycled meanwhile)
+        cache[key] = hit
+    return hit[0]
 
 
 class SegmentMeanPool(torch.autograd.Function):
@@ -1644,6 +1676,71 @@ class FusedGCNLastLayerRows(torch.autograd.Function):
             else:
                 dX = spmm_graph(g, dAH, transposed=True, cfg=cfg, xrow=_compact_positions(g, rows), profile_kind="compact", zero_from=n)
         return dX, dW, (db if ctx.has_bias else None), dWl, dbl, None, None, None, None, None, None, None, None, None, None
+
+
+class FusedGCNLayerRows(torch.autograd.Function):
+    """A fused GCN layer of which only `rows` are read downstream, evaluated aggregate-first on those rows, output COMPACT:
+        out_c[i] = dropout(ELU((A_hat X)[rows[i]] W^T + b))          [len(rows), H]
+    -- the last conv layer of the *_graph_gs models, whose pool reads x[mask] (network.py:129-131, :200-202: with --extra_node about
+    half of a subgraph union's rows).  (A X) W^T = A (X W^T) (network.py:31 applies the Linear first; same values up to fp32
+    rounding): the layer's product, its epilogue and, in the backward, both weight-side products run over len(rows) rows instead of
+    all of them; dX = A_hat^T dAH reads the compact gradient through a row indirection (every edge aggregated).  FusedGCNLastLayerRows
+    is this node with the output head of the node-level models behind it.  link_in: X is the un-shared output of a fused layer whose
+    ELU' / dropout' is then applied in the backward SpMM's store (what travels back on that edge is its dZ)."""
+
+    @staticmethod
+    def forward(ctx, X, W, b, g, p, training, seed, mask, rows, cfg, link_in=None):
+        X = _f32c(X)
+        rows = rows if rows.dtype == torch.int64 else rows.long()
+        AHc = spmm_graph(g, X, cfg=cfg).index_select(0, rows)          # [n, K]
+        outc = mm_xwt(AHc, W, cfg)
+        if not outc.is_contiguous():
+            outc = outc.contiguous()
+        epi = EPI_ELU | (EPI_BIAS if b is not None else 0)
+        drop = bool(training) and p > 0.0
+        if drop:
+            epi |= EPI_DROPOUT
+        epilogue_fwd_rows_(outc, rows, b, epi, p=p if drop else 0.0, seed=seed, mask=mask if drop else None)
+        keep_x = link_in is not None and cfg.fuse_dx_epilogue and X.shape[1] % 4 == 0
+        ctx.save_for_backward(W, AHc, outc, rows, mask if drop else None, X if keep_x else None)
+        ctx.g, ctx.p, ctx.drop, ctx.seed, ctx.has_bias, ctx.cfg, ctx.link_in = g, p, drop, seed, b is not None, cfg, link_in
+        ctx.ptrs = (W.data_ptr(), b.data_ptr() if b is not None else None)
+        return outc
+
+    @staticmethod
+    def backward(ctx, dOutc):
+        W, AHc, outc, rows, mask, Xprev = ctx.saved_tensors
+        g, cfg = ctx.g, ctx.cfg
+        epi = EPI_ELU | (EPI_DROPOUT if ctx.drop else 0)
+        pW, pb = ctx.ptrs
+        sW = _sink(cfg, pW) if ctx.needs_input_grad[1] else None
+        sb = _sink(cfg, pb) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        dZc, db = epilogue_bwd_rows_raw(dOutc, outc, rows, epi, p=ctx.p if ctx.drop else 0.0, seed=ctx.seed, mask=mask, want_db=ctx.has_bias,
+                                        db_out=sb)
+        if sb is not None:
+            db = None
+        dW = None
+        if ctx.needs_input_grad[1]:
+            if sW is not None:
+                mm_at_b(dZc, AHc, cfg, out=sW)
+            else:
+                dW = mm_at_b(dZc, AHc, cfg)
+        dX = None
+        if ctx.needs_input_grad[0]:
+            n, K = AHc.shape
+            # rows [n, n + ZERO_ROWS) stand for the rows outside the selection: every kernel that takes zero_from treats them as zeros
+            # WITHOUT loading them (staged as zeros / read from a row of zeros in LDS / multiplied from registers), so they are not filled
+            dAH = torch.empty((n + ZERO_ROWS, K), dtype=torch.float32, device=dZc.device)
+            mm_by_transposed(dZc, W, cfg, out=dAH[:n])
+            link = ctx.link_in
+            pos = _compact_positions(g, rows)
+            if Xprev is not None:
+                dX, db_prev = spmm_graph_dz(g, dAH, Xprev, link.epi, p=link.p, seed=link.seed, mask=link.mask, want_db=link.want_db, xrow=pos,
+                                            cfg=cfg, profile_kind="compact_dz", zero_from=n)
+                link.fused, link.db = True, db_prev
+            else:
+                dX = spmm_graph(g, dAH, transposed=True, cfg=cfg, xrow=pos, profile_kind="compact", zero_from=n)
+        return dX, dW, (db if ctx.has_bias else None), None, None, None, None, None, None, None, None
 
 
 class FusedGCNLayerDedup(torch.autograd.Function):

@@ -706,7 +706,7 @@ class GraphTrainer(_CapturedSteps):
 
     def _static_inputs(self, b):
         if self.kind == "gs":
-            return b["x"], b["edge_index"]
+            return b["x"], b["edge_index"], b.get("mask_idx")
         return b["gc"].x, b["gc"].edge_index
 
     def _one(self, b, loss_out=None):
@@ -941,6 +941,7 @@ def _cat_pieces(pieces, kind, types):
         if x.is_cuda:   # the pool's segment index, built now (it synchronises once; a captured step must not)
             from . import ops
             ops.pool_index(b["graph_of_masked"], n_graphs, b["mask_idx"], int(x.shape[0]))
+            ops.pool_index(b["graph_of_masked"], n_graphs, None, int(b["mask_idx"].numel()))   # (the pool over the compact pooled rows)
     else:
         b["gc"] = types.SimpleNamespace(x=x, edge_index=e, batch=graph, num_graphs=n_graphs)
         if x.is_cuda:

@@ -438,6 +438,14 @@ int fitgnn_epilogue_bwd_head_rows_f32(const float *dy, const float *Wl, int32_t 
                                       uint64_t seed, const uint8_t *mask, float *db, float *dWl, void *work, size_t work_bytes,
                                       void *stream);
 
+/* fitgnn_epilogue_bwd_f32 over selected rows, compact: dZc [n_sel x H] row i = dOut row . ELU' / dropout' of ORIGINAL row rows[i] (its
+ * mask entry / dropout hash), db = column sums; inputs_compact != 0: dOut and out hold the selected rows only (row i), else they are the
+ * full matrices read at row rows[i].  Serves a GCN layer evaluated aggregate-first on the rows its consumer reads (the pooled rows of
+ * the *_graph_gs models, network.py:129,200: x[mask]).  Workspace: fitgnn_epilogue_bwd_workspace_bytes(n_sel, H). */
+int fitgnn_epilogue_bwd_rows_f32(const float *dOut, const float *out, const int64_t *rows, int32_t n_sel, int32_t inputs_compact, float *dZc,
+                                 int32_t H, uint32_t epilogue, float p_drop, uint64_t seed, const uint8_t *mask, float *db, void *work,
+                                 size_t work_bytes, void *stream);
+
 /* z[i] <- dropout(ELU(z[i] + bias)) for the n rows of a compact matrix z (row stride ldz), row i standing for ORIGINAL row
  * rows[i] (rows == NULL: i) whose dropout hash / mask entry it takes: the store epilogue of fitgnn_spmm_csr_f32 (same flags,
  * same arithmetic) for a layer whose dense part is evaluated on selected rows only.  H % 4 == 0, z 16-byte aligned. */
@@ -628,7 +636,10 @@ int fitgnn_induced_edges_fill(const int64_t *adj_ptr, const int64_t *adj, const 
  * layer's aggregated input b_ax [R_cap x K] (row stride ld_ax) gathered from ax (row stride ld_ax_g), the targets b_tgt [B x n_tgt].
  * Rows past the batch's total hold no entries and zeros in b_ax and are covered by tiles of their own (16 rows each: T_cap must
  * leave room for them); entries / pooled rows past the totals are zeros.  The caller guarantees that the totals fit the capacities
- * (it knows every graph's sizes). */
+ * (it knows every graph's sizes).  Optional (NULL to skip), for a last layer evaluated on the pooled rows only (compact operands):
+ * b_members64 [M_cap] = b_members as int64, b_cseg [M_cap] = the graph of compact row i (-1 past the batch's pooled rows),
+ * b_pos [R_cap] = a batch row's compact position -- mem_rank[row] = its rank among its graph's pooled rows -- or, for a row that is
+ * not pooled, M_cap + r % zero_rows (a zero row of a compact operand that is never loaded). */
 int fitgnn_batch_offsets(const int64_t *perm, int32_t *step_idx, int32_t B, const int32_t *g_row_ptr, const int32_t *g_nnz_ptr,
                          const int32_t *g_tile_ptr, const int32_t *g_mem_ptr, int32_t *off, int32_t *gid, float *loss_slot, float *loss_sum,
                          void *stream);
@@ -637,7 +648,8 @@ int fitgnn_batch_gather(int32_t B, const int32_t *off, const int32_t *gid, const
                         const fitgnn_tile_t *tiles, const int32_t *mem, const uint8_t *pooled, const float *ax, int32_t ld_ax_g,
                         const float *tgt, int32_t n_tgt, int32_t K, int32_t R_cap, int32_t E_cap, int32_t T_cap, int32_t M_cap,
                         int32_t *b_rowptr, int32_t *b_col, float *b_val, fitgnn_tile_t *b_tiles, int32_t *b_members, int32_t *b_seg_off,
-                        int32_t *b_seg_of_row, float *b_inv_cnt, float *b_ax, int32_t ld_ax, float *b_tgt, void *stream);
+                        int32_t *b_seg_of_row, float *b_inv_cnt, float *b_ax, int32_t ld_ax, float *b_tgt, const int32_t *mem_rank,
+                        int64_t *b_members64, int32_t *b_cseg, int32_t *b_pos, int32_t zero_rows, void *stream);
 
 /* Feature pooling Xc = C . X (utils.py:161,393,738,827): f64 accumulation over each cluster's members in
  * ascending node order, rounded once to f32 (utils.py:738 torch.FloatTensor).  X f32[N x F] (ldx), Xc

@@ -182,5 +182,5 @@ def test_round4_graph_step_entry_points_check_their_arguments_without_a_gpu():
     assert L.fitgnn_batch_offsets(None, None, 128, None, None, None, None, None, None, None, None, None) == -1
     n13 = [None] * 13
     n9 = [None] * 9
-    assert L.fitgnn_batch_gather(128, *n13, 11, None, 1, 11, 64, 64, 64, 64, *n9, 11, None, None) == -1                            # NULL arrays
-    assert L.fitgnn_batch_gather(128, *n13, 8, None, 1, 11, 64, 64, 64, 64, *n9, 11, None, None) == -1                             # ld_ax_g < K
+    assert L.fitgnn_batch_gather(128, *n13, 11, None, 1, 11, 64, 64, 64, 64, *n9, 11, None, None, None, None, None, 0, None) == -1   # NULL arrays
+    assert L.fitgnn_batch_gather(128, *n13, 8, None, 1, 11, 64, 64, 64, 64, *n9, 11, None, None, None, None, None, 0, None) == -1    # ld_ax_g < K

@@ -1126,6 +1126,13 @@ def test_padded_batch_plan_assembles_the_batch_of_any_graphs(mods):
         graph_of = want["graph"][want["mask"]]
         assert torch.equal(plan.b_seg_of_row[:n][mask_idx].long(), graph_of) and int((plan.b_seg_of_row[:n] >= 0).sum()) == m
         assert bool((plan.b_seg_of_row[n:] == -1).all())
+        # the compact view of the pooled rows (a last layer evaluated on them only): int64 row index, graph of a compact row, positions
+        assert torch.equal(plan.b_members64[:m], mask_idx) and bool((plan.b_members64[m:] == 0).all())
+        assert torch.equal(plan.b_cseg[:m].long(), graph_of) and bool((plan.b_cseg[m:] == -1).all())
+        assert torch.equal(plan.b_pos[:n][mask_idx].long(), torch.arange(m, device="cuda"))
+        rest = torch.ones(plan.R_cap, dtype=torch.bool, device="cuda")
+        rest[mask_idx] = False
+        assert bool((plan.b_pos[rest] >= plan.M_cap).all()) and bool((plan.b_pos[rest] < plan.M_cap + ops.ZERO_ROWS).all())
         cnt = torch.bincount(graph_of, minlength=B)
         assert torch.equal(plan.b_seg_off.long(), torch.cat([torch.zeros(1, dtype=torch.int64, device="cuda"), torch.cumsum(cnt, 0)]))
         assert torch.equal(plan.b_inv_cnt, 1.0 / cnt.clamp(min=1).float())
@@ -1268,3 +1275,46 @@ def test_a_stale_autograd_graph_makes_the_trainers_step_eagerly_instead_of_captu
     del stale, out
     tr2 = train.GDTrainer(model, batch, lr=0.0, weight_decay=0.0, capture=True)
     assert float(tr2.step()) == want and tr2.capture and tr2._graph is not None
+
+
+@pytest.mark.parametrize("cls_name,layers", [("Regress_graph_gs", 2), ("Regress_graph_gs", 1), ("Regress_graph_gs", 3), ("Classify_graph_gs", 2)])
+@pytest.mark.parametrize("mode", ["eval", "masks", "hashed"])
+def test_last_layer_on_the_pooled_rows_changes_nothing_the_pool_sees(mods, cls_name, layers, mode):
+    """ops.FusedGCNLayerRows behind the *_graph_gs models (the last GCN layer aggregate-first on x[mask]'s rows, compact output, the
+    pool over the compact rows) against the layer over every row (OpConfig(pooled_rows_last_layer=False)): model output, loss and
+    every gradient; eval, injected dropout masks, hashed dropout."""
+    from fitgnn_amd import graph_data, ops, train
+    import types
+
+    network, fnn, gorc = mods
+    reg = cls_name.startswith("Regress")
+    mol = graph_data.synthetic_molecules(24, seed=8) if reg else graph_data.synthetic_graph_classes(24, seed=8)
+    gset = graph_data.GraphSet(mol, ratio=0.5, extra_node=True, device="cuda")
+    F_in = 11 if reg else 3
+    args = argparse.Namespace(num_layers1=layers, layer_name="GCNConv", num_features=F_in, hidden=64, num_classes=1 if reg else 2)
+    torch.manual_seed(layers + 17)
+    model = getattr(network, cls_name)(args).cuda()
+    with torch.no_grad():
+        for c in model.conv:
+            c.bias.normal_(std=0.1)
+    b = train._cat_pieces([gset.batch(0, 24, "gs")], "gs", types)
+    n = int(b["x"].shape[0])
+    if mode == "eval":
+        model.eval()
+    else:
+        model.train()
+        if mode == "masks":
+            model._inject_masks = [(torch.rand(n, 64, device="cuda") > 0.5).to(torch.uint8) for _ in range(layers)]
+    w = torch.randn(24, 1 if reg else 2, device="cuda")
+    res = {}
+    for flag in (True, False):
+        model.set_op_config(ops.DEFAULT.replace(pooled_rows_last_layer=flag))
+        model.zero_grad()
+        torch.manual_seed(5)
+        out = model(b, b["graph_of_masked"])
+        (out * w).sum().backward()
+        res[flag] = (out.detach().clone(), {k: p.grad.detach().clone() for k, p in model.named_parameters()})
+    assert int(b["mask_idx"].numel()) < n          # (the pooled rows are a proper subset: about half)
+    assert rel(res[True][0], res[False][0]) < 3e-5
+    for k in res[False][1]:
+        assert rel(res[True][1][k], res[False][1][k]) < 3e-4, k

@@ -360,7 +360,7 @@ def test_row_streaming_kernel_for_a_compact_operand(mods, H, sizes):
     Xc = torch.cat([torch.randn(k, H).cuda(), torch.zeros(ops.ZERO_ROWS, H).cuda()])
     pos = ops._compact_positions(g, rows)
     dense = torch.zeros(n, H).cuda(); dense[rows] = Xc[:k]
-    old, new = ops.OpConfig(compact_rows_kernel=False, profile=[]), ops.OpConfig(compact_rows_kernel=True, profile=[])
+    old, new = ops.OpConfig(compact_rows_kernel=False, profile=[]), ops.OpConfig(compact_rows_kernel=True, rows_kernel_min_rows=0, profile=[])
     for transposed in (True, False):
         want = ops.spmm_graph(g, dense, transposed=transposed)
         a = ops.spmm_graph(g, Xc, transposed=transposed, xrow=pos, zero_from=k, cfg=old)
