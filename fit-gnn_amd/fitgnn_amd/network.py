@@ -62,12 +62,14 @@ class _Base(nn.Module):
             m.reset_parameters()
         self.lt1.reset_parameters()
 
-    def _first_layer_dedup(self, x_table, edge_index, x_index, link_out=None):
-        """Layer 0 on a de-duplicated feature table (x_index: ops.RowIndex mapping union rows to table rows)."""
+    def _first_layer_dedup(self, x_table, edge_index, x_index, link_out=None, gat_link=None):
+        """Layer 0 on a de-duplicated feature table (x_index: ops.RowIndex mapping union rows to table rows).
+        gat_link: the link an attention layer records for an aggregate-first attention layer right behind it (FusedGATLastLayerRows)."""
         conv = self.conv[0]
         if isinstance(conv, fnn.GATConv) and x_table.is_cuda and link_out is None:
             mask = self._inject_masks[0] if self._inject_masks is not None else None
-            return conv.forward_elu_dropout(x_table, edge_index, p=self.dropout_p, training=self.training, mask=mask, x_index=x_index)
+            return conv.forward_elu_dropout(x_table, edge_index, p=self.dropout_p, training=self.training, mask=mask, x_index=x_index,
+                                            link_out=gat_link)
         if not (isinstance(conv, fnn.GCNConv) and x_table.is_cuda):
             return None
         mask = self._inject_masks[0] if self._inject_masks is not None else None
@@ -90,10 +92,11 @@ class _Base(nn.Module):
                 and pooled_rows.dtype == torch.int64 and pooled_rows.numel() > 0):
             ops._compact_positions(last.graph(edge_index, x.shape[0]), pooled_rows)
 
-    def embed(self, x, edge_index, x_index=None, first=0, link=None, last=None, return_link=False):
+    def embed(self, x, edge_index, x_index=None, first=0, link=None, last=None, return_link=False, tail_link=None):
         """conv -> ELU -> dropout, layers first .. last - 1 (default: all; network.py:29-33).  link: the EpilogueLink recorded by the
         layer that produced x (consecutive fused GCN layers are linked: see ops.EpilogueLink; the stack is strictly sequential).
-        return_link: also return the link the last evaluated layer recorded for its ONE consumer (None when it recorded none)."""
+        return_link: also return the link the last evaluated layer recorded for its ONE consumer (None when it recorded none).
+        tail_link: the link the LAST evaluated layer records when it is an attention layer (its consumer: FusedGATLastLayerRows)."""
         x = x.float()
         for i in range(first, self.num_layers if last is None else last):
             conv = self.conv[i]
@@ -113,7 +116,9 @@ class _Base(nn.Module):
                 link = nxt
             elif isinstance(conv, fnn.GATConv) and x.is_cuda:
                 mask = self._inject_masks[i] if self._inject_masks is not None else None
-                x = conv.forward_elu_dropout(x, edge_index, p=self.dropout_p, training=self.training, mask=mask)
+                is_tail = i + 1 == (self.num_layers if last is None else last)
+                x = conv.forward_elu_dropout(x, edge_index, p=self.dropout_p, training=self.training, mask=mask,
+                                             link_out=tail_link if is_tail else None)
                 link = None
             else:
                 x = conv(x, edge_index)
@@ -168,8 +173,13 @@ class _Base(nn.Module):
         # the conv stack is strictly sequential (network.py:29-33): consecutive fused GCN layers share an EpilogueLink, so
         # that the backward GEMM dH @ W of layer i+1 applies layer i's ELU'/dropout' in its epilogue
         link = ops.EpilogueLink() if (L > 1 and x.is_cuda and isinstance(self.conv[1], fnn.GCNConv)) else None
+        # an attention layer right below an aggregate-first attention layer hands its ELU' / dropout' to that layer's adjoint aggregation
+        glink = None
+        if (not fused_tail and L > 1 and x.is_cuda and isinstance(last, fnn.GATConv) and isinstance(self.conv[L - 2], fnn.GATConv)
+                and loss_rows is not None and self.op_config.last_layer_on_loss_rows and loss_rows.numel() > 0):
+            glink = ops.EpilogueLink()
         if x_index is not None:
-            h = self._first_layer_dedup(x, edge_index, x_index, link_out=link) if L > 1 else None
+            h = self._first_layer_dedup(x, edge_index, x_index, link_out=link, gat_link=glink if L == 2 else None) if L > 1 else None
             if h is None:
                 x = x.index_select(0, x_index.index.long())  # materialise the union rows
                 link = None
@@ -185,13 +195,14 @@ class _Base(nn.Module):
                     and ops.head_fusable(self.lt1.in_features, self.lt1.out_features)
                     and (first == L - 1 or isinstance(self.conv[L - 2], (fnn.GATConv, fnn.GCNConv)))):
                 # the last attention layer aggregate-first: its dense part on the loss rows only (ops.FusedGATLastLayerRows)
-                x = self.embed(x, edge_index, first=first, link=link, last=L - 1)
+                x = self.embed(x, edge_index, first=first, link=link, last=L - 1, tail_link=glink)
                 mask = self._inject_masks[L - 1] if self._inject_masks is not None else None
                 g = fnn.csr_for(edge_index, x.shape[0], "gat")
                 seed = ops.next_seed(cfg) if (self.training and self.dropout_p > 0 and mask is None) else 0
+                used = glink if (glink is not None and glink.epi != 0) else None   # (recorded by the layer below: it is an attention layer with act)
                 return ops.FusedGATLastLayerRows.apply(x, last.lin.weight, last.att_src.view(-1), last.att_dst.view(-1), last.bias,
                                                        self.lt1.weight, self.lt1.bias, g, last.negative_slope, float(self.dropout_p),
-                                                       bool(self.training), seed, mask, loss_rows, cfg, bool(compact_logits))
+                                                       bool(self.training), seed, mask, loss_rows, cfg, bool(compact_logits), used)
             return self.head(self.embed(x, edge_index, first=first, link=link))
         x = x.float()
         for i in range(first, L - 1):

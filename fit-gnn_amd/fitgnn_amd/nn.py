@@ -156,17 +156,18 @@ class GATConv(_OpConfigured, nn.Module):
         return ops.GATAggregate.apply(h, self.att_src.view(-1), self.att_dst.view(-1), self.bias, g, self.negative_slope,
                                       False, 0.0, False, 0, None, cfg)
 
-    def forward_elu_dropout(self, x, edge_index, p=0.5, training=False, mask=None, x_index=None):
+    def forward_elu_dropout(self, x, edge_index, p=0.5, training=False, mask=None, x_index=None, link_out=None):
         """conv -> F.elu -> F.dropout (network.py:31-33) with the activation in the aggregation kernel's epilogue.
         x_index (ops.RowIndex, optional): x is a de-duplicated feature table and node r of the graph is a copy of table row
-        x_index.index[r]: the Linear and the score dots run on the table (ops.GATAggregate, ridx)."""
+        x_index.index[r]: the Linear and the score dots run on the table (ops.GATAggregate, ridx).
+        link_out (ops.EpilogueLink): the output goes to exactly one consumer that may apply this layer's ELU' / dropout' itself."""
         n = x.shape[0] if x_index is None else int(x_index.index.numel())
         g = csr_for(edge_index, n, "gat")
         cfg = self.op_config
         h = ops.Linear.apply(x.float(), self.lin.weight, cfg)
         seed = ops.next_seed(cfg) if (training and p > 0 and mask is None) else 0
         return ops.GATAggregate.apply(h, self.att_src.view(-1), self.att_dst.view(-1), self.bias, g, self.negative_slope,
-                                      True, float(p), bool(training), seed, mask, cfg, x_index)
+                                      True, float(p), bool(training), seed, mask, cfg, x_index, link_out)
 
 
 class APPNP(_OpConfigured, nn.Module):

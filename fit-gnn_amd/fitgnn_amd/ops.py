@@ -1808,8 +1808,10 @@ class GATAggregate(torch.autograd.Function):
     (CSRGraph(mode='gat')); attention weights replace its values."""
 
     @staticmethod
-    def forward(ctx, h, att_src, att_dst, bias, g, slope, act, p, training, seed, mask, cfg, ridx=None):
+    def forward(ctx, h, att_src, att_dst, bias, g, slope, act, p, training, seed, mask, cfg, ridx=None, link_out=None):
         """act=True fuses F.elu and F.dropout(p) (network.py:32-33) into the aggregation's epilogue, as for GCNConv.
+        link_out (EpilogueLink, with act): the output feeds exactly ONE consumer, which may hand back the gradient of the
+        pre-activation (its backward SpMM applies this layer's ELU' / dropout' in its store) and the bias gradient.
         ridx (RowIndex, optional): h is a de-duplicated TABLE [N0, C] and row r of the graph is a copy of table row ridx.index[r] (the
         first layer of a union batch: h = x W^T and the score dots run on the N0 original nodes; the aggregation, the SDDMM and the
         softmax read the table through the row indirection; the backward sums each node's copies before the weight-side products)."""
@@ -1841,6 +1843,9 @@ class GATAggregate(torch.autograd.Function):
         ctx.save_for_backward(h, att_src, att_dst, a_src, a_dst, alpha, out if act else None, mask if drop else None)
         ctx.g, ctx.slope, ctx.has_bias, ctx.cfg, ctx.ridx = g, slope, bias is not None, cfg, ridx
         ctx.act, ctx.drop, ctx.p, ctx.seed = bool(act), drop, p, seed
+        ctx.link_out = link_out if act else None
+        if ctx.link_out is not None:   # g=None: the consumer may hand back dZ, never an aggregated form of it
+            link_out.record(drop, p, seed, mask, bias is not None, g=None)
         return out
 
     @staticmethod
@@ -1850,7 +1855,11 @@ class GATAggregate(torch.autograd.Function):
         dOut = _f32c(dOut)
         db_fused = None
         cfg = ctx.cfg
-        if ctx.act:   # through ELU / dropout first: dOut becomes the gradient of the pre-activation, db its column sums
+        link = ctx.link_out
+        if ctx.act and link is not None and link.fused:   # the consumer already applied this layer's ELU' / dropout': dOut is dZ
+            db_fused = link.db
+            link.fused, link.db, link.aggregated = False, None, False
+        elif ctx.act:   # through ELU / dropout first: dOut becomes the gradient of the pre-activation, db its column sums
             with _timed(cfg, "gat_epilogue_bwd"):
                 dOut, db_fused = epilogue_bwd_raw(dOut, out, EPI_ELU | (EPI_DROPOUT if ctx.drop else 0), p=ctx.p if ctx.drop else 0.0,
                                                   seed=ctx.seed, mask=mask, want_db=ctx.has_bias)
@@ -1894,7 +1903,7 @@ class GATAggregate(torch.autograd.Function):
             db = db_fused if ctx.has_bias else None
         else:
             db = dOut.sum(0) if ctx.has_bias and ctx.needs_input_grad[3] else None
-        return dh, datt_src, datt_dst, db, None, None, None, None, None, None, None, None, None
+        return dh, datt_src, datt_dst, db, None, None, None, None, None, None, None, None, None, None
 
 
 def _gat_rank2_csr(g, rows, pos):
@@ -1937,7 +1946,7 @@ class FusedGATLastLayerRows(torch.autograd.Function):
     through the row-streaming kernel.  g: CSRGraph(mode='gat')."""
 
     @staticmethod
-    def forward(ctx, X, W, att_src, att_dst, b, Wl, bl, g, slope, p, training, seed, mask, rows, cfg, compact_out=False):
+    def forward(ctx, X, W, att_src, att_dst, b, Wl, bl, g, slope, p, training, seed, mask, rows, cfg, compact_out=False, link_in=None):
         L = _lib.lib()
         X = _f32c(X)
         R, K = X.shape
@@ -1978,6 +1987,7 @@ class FusedGATLastLayerRows(torch.autograd.Function):
         ctx.save_for_backward(X, W, att2, Wl, AXc, outc, rows, mask if drop else None, alpha, a_src, a_dst, u)
         ctx.g, ctx.slope, ctx.p, ctx.drop, ctx.seed, ctx.has_bias, ctx.has_bl, ctx.cfg, ctx.compact_out = (
             g, slope, p, drop, seed, b is not None, bl is not None, cfg, bool(compact_out))
+        ctx.link_in = link_in   # X is the un-shared output of a fused layer: its ELU' / dropout' may go into the adjoint aggregation's store
         return y
 
     @staticmethod
@@ -2036,10 +2046,27 @@ class FusedGATLastLayerRows(torch.autograd.Function):
                 val_aug[ext] = da_src
                 val_aug[ext + 1] = da_dst
             dX = torch.empty((R, K), dtype=torch.float32, device=dev)
+            link = ctx.link_in
             with _timed(cfg, "gat_aggregate_t"):
-                _lib.check(L.fitgnn_spmm_rows_compact_f32(_lib.dptr(rp_aug), _lib.dptr(xcol_aug), _lib.dptr(val_aug), int(xcol_aug.numel()),
-                                                          _lib.dptr(op), op.stride(0), n + 2, _lib.dptr(dX), dX.stride(0), R, K, st),
-                           "fitgnn_spmm_rows_compact_f32")
+                if link is not None and X.is_contiguous():
+                    # ... with the producing layer's ELU' / dropout' applied as the rows are stored (X is that layer's output): what travels
+                    # back is its dZ and its bias gradient -- the 50-GB elementwise pass over [R x K] of its own backward is not run
+                    n_part = int(L.fitgnn_spmm_rows_compact_parts(R))
+                    part = torch.empty((n_part, K), dtype=torch.float32, device=dev) if link.want_db else None
+                    seed_v, epi_v = _seed_arg(link.seed, link.epi)
+                    _lib.check(L.fitgnn_spmm_rows_compact_dz_f32(_lib.dptr(rp_aug), _lib.dptr(xcol_aug), _lib.dptr(val_aug), int(xcol_aug.numel()),
+                                                                 _lib.dptr(op), op.stride(0), n + 2, _lib.dptr(dX), dX.stride(0), R, K, _lib.dptr(X),
+                                                                 epi_v, float(link.p), seed_v, _lib.dptr(link.mask), _lib.dptr(part), st),
+                               "fitgnn_spmm_rows_compact_dz_f32")
+                    db_prev = None
+                    if link.want_db:
+                        db_prev = torch.empty(K, dtype=torch.float32, device=dev)
+                        _lib.check(L.fitgnn_colsum_partials_f32(_lib.dptr(part), n_part, K, _lib.dptr(db_prev), st), "fitgnn_colsum_partials_f32")
+                    link.fused, link.db = True, db_prev
+                else:
+                    _lib.check(L.fitgnn_spmm_rows_compact_f32(_lib.dptr(rp_aug), _lib.dptr(xcol_aug), _lib.dptr(val_aug), int(xcol_aug.numel()),
+                                                              _lib.dptr(op), op.stride(0), n + 2, _lib.dptr(dX), dX.stride(0), R, K, st),
+                               "fitgnn_spmm_rows_compact_f32")
         elif ctx.needs_input_grad[0]:
             dX = spmm_graph(g, dAX, transposed=True, val=alpha_t, cfg=cfg, xrow=_compact_positions(g, rows), zero_from=n,
                             profile_kind="gat_aggregate_t")
@@ -2048,7 +2075,7 @@ class FusedGATLastLayerRows(torch.autograd.Function):
         # u = att2 W: the scores' parameter gradients
         dW = dW + torch.mm(att2.t(), du)
         datt2 = torch.mm(du, W.t())                                                               # [2, H]
-        return (dX, dW, datt2[0], datt2[1], (db if ctx.has_bias else None), dWl, dbl, None, None, None, None, None, None, None, None, None)
+        return (dX, dW, datt2[0], datt2[1], (db if ctx.has_bias else None), dWl, dbl, None, None, None, None, None, None, None, None, None, None)
 
 
 class APPNPPropagate(torch.autograd.Function):
