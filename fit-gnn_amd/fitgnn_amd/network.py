@@ -314,15 +314,19 @@ class APPNPNet(nn.Module):
         self.lin1.reset_parameters()
         self.lin2.reset_parameters()
 
-    def forward(self, x, edge_index, x_index=None):
+    def logits(self, x, edge_index, x_index=None):
+        """forward() without its log_softmax: a trainer whose loss reads a few rows (run.py:193-204 keeps out[mask]) takes the
+        softmax and the NLL on those rows only (ops.SoftmaxNLL) instead of normalising every union row twice."""
         x = F.dropout(x.float(), p=self.dropout_p, training=self.training)
         x = F.relu(self.lin1(x))
         x = F.dropout(x, p=self.dropout_p, training=self.training)
         x = self.lin2(x)
         if x_index is not None:
             x = x.index_select(0, x_index.index.long())
-        x = self.prop1(x, edge_index)
-        return F.log_softmax(x, dim=1)
+        return self.prop1(x, edge_index)
+
+    def forward(self, x, edge_index, x_index=None):
+        return F.log_softmax(self.logits(x, edge_index, x_index), dim=1)
 
 
 class Classify_graph_gc(_Base):

@@ -248,7 +248,9 @@ class GDTrainer:
         gcn_only = all(isinstance(c, _fnn0.GCNConv) for c in getattr(model, "conv", [])) and len(getattr(model, "conv", [])) > 0
         self.capture = (self.lean and self.fused_loss and gcn_only and (capture is True or (capture == "auto" and small)))
         self._graph, self._graph_loss, self._bank = None, None, None
-        self._y_train = batch.y.index_select(0, batch.train_idx) if self.fused_loss else None
+        # (a model with a `logits` method -- network.APPNPNet -- gets the same fused loss on its train rows)
+        self.fused_logits = (task == "node_cls" and not self.fused_loss and hasattr(model, "logits") and next(model.parameters()).is_cuda)
+        self._y_train = batch.y.index_select(0, batch.train_idx) if (self.fused_loss or self.fused_logits) else None
         self._train_arange = None
         self.prune_forward = False
         if prune_unused_rows and self.fused_loss and batch.graph is not None:
@@ -395,6 +397,10 @@ class GDTrainer:
                 else:
                     loss = SoftmaxNLL.apply(z, b.train_idx, self._y_train, scale)
             return self._backward_and_step(loss)
+        if self.fused_logits:
+            from .ops import SoftmaxNLL
+            z = m.logits(b.x_table, b.edge_index, x_index=b.row_index) if self.dedup else m.logits(b.x, b.edge_index)
+            return self._backward_and_step(SoftmaxNLL.apply(z, b.train_idx, self._y_train, scale))
         out = m(b.x_table, b.edge_index, x_index=b.row_index) if self.dedup else m(b.x, b.edge_index)
         sel = out.index_select(0, b.train_idx)
         if self.task == "node_reg":

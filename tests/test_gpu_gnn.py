@@ -1318,3 +1318,24 @@ def test_last_layer_on_the_pooled_rows_changes_nothing_the_pool_sees(mods, cls_n
     assert rel(res[True][0], res[False][0]) < 3e-5
     for k in res[False][1]:
         assert rel(res[True][1][k], res[False][1][k]) < 3e-4, k
+
+
+def test_appnp_trainer_takes_the_loss_on_the_train_rows_only(mods):
+    """GDTrainer on network.APPNPNet: softmax + NLL on the train rows of the model's logits (ops.SoftmaxNLL) == log_softmax over every
+    row followed by NLLLoss on out[mask] (the model's forward): losses and weights over three steps (dropout off)."""
+    from fitgnn_amd import train
+
+    network, fnn, gorc = mods
+    batch, _ = _subgraph_batches(seed=6)
+    args = argparse.Namespace(num_features=24, hidden=32, num_classes=4, K=4, alpha=0.1, dropout=0.0)
+    torch.manual_seed(9)
+    m1, m2 = network.APPNPNet(args).cuda(), network.APPNPNet(args).cuda()
+    m2.load_state_dict(m1.state_dict())
+    t1, t2 = train.GDTrainer(m1, batch, lr=0.01, weight_decay=5e-4), train.GDTrainer(m2, batch, lr=0.01, weight_decay=5e-4)
+    assert t1.fused_logits and t2.fused_logits
+    t2.fused_logits = False
+    for step in range(3):
+        a, b = float(t1.step()), float(t2.step())
+        assert a == pytest.approx(b, rel=1e-5), (step, a, b)
+    for (k, v), (_, w) in zip(m1.state_dict().items(), m2.state_dict().items()):
+        assert rel(v, w) < 1e-4, k
