@@ -485,6 +485,12 @@ def main():
                       "gat_sddmm": 2 * 4 * H * R + 8 * nnz + 4 * (R + 1), "gat_softmax_bwd": 16 * nnz + 4 * (R + 1) + 12 * R,
                       "gat_transpose_edges": 28 * nnz + 4 * (R + 1) + 4 * R, "gat_rank1": 2 * 4 * H * R + 8 * R,
                       "appnp_step": 3 * 4 * Cw * R + 8 * nnz + 4 * (R + 1), "appnp_step_t": 4 * 4 * Cw * R + 8 * nnz + 4 * (R + 1)}
+        plan = next(iter(getattr(batch.graph, "_appnp_plan", {}).values()), None) if args.layer == "APPNP" else None
+        if plan is not None:   # the K steps in LDS for the rows in units (read z0 / write z_K once), the per-step kernel on the others' sub-matrix
+            r_u, r_o, nnz_o = plan.rows_in_units, plan.n_open, plan.nnz_open
+            kind_bytes.update({"appnp_units": 2 * 4 * Cw * r_u + 8 * (nnz - nnz_o) + 4 * (r_u + 1),
+                               "appnp_units_t": 2 * 4 * Cw * r_u + 8 * (nnz - nnz_o) + 4 * (r_u + 1),
+                               "appnp_step": 3 * 4 * Cw * r_o + 8 * nnz_o + 4 * (r_o + 1), "appnp_step_t": 4 * 4 * Cw * r_o + 8 * nnz_o + 4 * (r_o + 1)})
         per_kind = {}
         for ev in step_events:
             for a, b, kind in ev:

@@ -478,6 +478,142 @@ extern "C" int fitgnn_spmm_narrow_padded_f32(const int32_t *rowptr, const int32_
     return (int)hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// APPNP's K propagation steps with the signal resident in LDS (fitgnn_appnp_units_f32).
+//
+// The batches this library serves are block diagonal: a cluster subgraph shares no edge with another (utils.py:248), so
+// z_{k+1} = (1 - alpha) A_hat z_k + alpha z_0 never mixes two subgraphs -- and a subgraph of a few dozen rows x 47 classes is a few
+// kilobytes.  One launch per propagation step (spmm_narrow_packed_kernel) reads and writes the whole signal K times: 20 passes per
+// training step for K = 10.  Here a "unit" -- a run of consecutive rows closed under the pattern (whole subgraphs; at most 768 / h4
+// rows and 2 048 CSR entries; the caller lists them) -- is loaded ONCE by one wavefront, stepped K times between two LDS buffers (its CSR
+// slice staged beside them, columns re-based to the unit), and stored once.  A lane owns the items (row, float4 column) lane,
+// lane + 64, ...: the 12 column groups of a long row (a star's centre) sit on 12 lanes, so a step costs the longest row once, not 12
+// times.  Forward: the teleport operand z_0 stays in the lane's registers.  Backward (BWD; the pattern handed in is the transposed
+// one): g_{k+1} = (1 - alpha) A^T g_k with acc += alpha g_k in registers, result acc + g_K -- APPNPPropagate.backward's recurrence.
+// Rows outside the units (subgraphs larger than a unit) are the caller's: it runs the per-step kernel on their sub-matrix.
+constexpr int kAppnpItems = 12;      // float4 items per lane: a unit holds at most 64 * 12 = 768 (row, float4 column) items,
+constexpr int kAppnpRowsMax = 768;   // i.e. 768 / h4 rows (768 rows of a 3-class signal, 64 of a 47-class one)
+constexpr int kAppnpEntries = 2048;  // CSR entries of a unit staged in LDS (44 KiB per wavefront in all: three units per CU)
+__host__ __device__ inline int appnp_rows(int h4) { return (64 * kAppnpItems) / h4 < kAppnpRowsMax ? (64 * kAppnpItems) / h4 : kAppnpRowsMax; }
+
+template <bool BWD>
+__global__ __launch_bounds__(64) void appnp_units_kernel(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                                         const float *__restrict__ val, const int32_t *__restrict__ units, int32_t n_units,
+                                                         const float4 *__restrict__ X, float4 *__restrict__ Y, int32_t h4, int32_t K,
+                                                         float alpha, int32_t cap_rows, int32_t cap_entries) {
+    // LDS: two signal buffers of cap_rows x h4 float4, row pointers, the CSR slice -- sized by the launch for ITS largest unit
+    extern __shared__ __attribute__((aligned(16))) unsigned char au_lds[];
+    float4 *buf0 = reinterpret_cast<float4 *>(au_lds);
+    float4 *buf1 = buf0 + cap_rows * h4;
+    int32_t *s_rp = reinterpret_cast<int32_t *>(buf1 + cap_rows * h4);
+    int32_t *s_col = s_rp + cap_rows + 4;
+    float *s_val = reinterpret_cast<float *>(s_col + cap_entries);
+    const int u = blockIdx.x;
+    if (u >= n_units) return;
+    const int lane = threadIdx.x;
+    const int r0 = units[2 * u], r1 = units[2 * u + 1];
+    const int n = r1 - r0;
+    const int E0 = rowptr[r0];
+    const int nE = rowptr[r1] - E0;
+    for (int i = lane; i <= n; i += 64) s_rp[i] = rowptr[r0 + i] - E0;
+    for (int e = lane; e < nE; e += 64) {
+        s_col[e] = col[E0 + e] - r0;
+        s_val[e] = val[E0 + e];
+    }
+    const int total = n * h4;
+    const int64_t base = (int64_t)r0 * h4;   // the unit's rows are consecutive: item i is X[base + i]
+    float4 keep[kAppnpItems];
+#pragma unroll
+    for (int j = 0; j < kAppnpItems; ++j) {
+        const int i = lane + 64 * j;
+        float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < total) {
+            x = X[base + i];
+            buf0[i] = x;
+        }
+        keep[j] = BWD ? make_float4(0.f, 0.f, 0.f, 0.f) : x;
+    }
+    __syncthreads();
+    const float beta = 1.0f - alpha;
+    for (int k = 0; k < K; ++k) {
+        const float4 *cur = (k & 1) ? buf1 : buf0;
+        float4 *nxt = (k & 1) ? buf0 : buf1;
+#pragma unroll
+        for (int j = 0; j < kAppnpItems; ++j) {
+            const int i = lane + 64 * j;
+            if (i >= total) break;
+            const int row = i / h4, q = i - row * h4;
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int e1 = s_rp[row + 1];
+            // four entries at a time: their (column, value) reads, then their four operand reads, are issued together -- one at a time an
+            // entry is two dependent LDS round trips, and a star's centre (50-300 entries) made the whole unit wait for its chain (eight
+            // at a time pads the leaves' 3-entry rows to 8 reads: slower at S-products); a last group is padded with its last entry at
+            // weight 0; the additions stay in CSR order
+            for (int e = s_rp[row]; e < e1; e += 4) {
+                int c[4];
+                float v[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int et = min(e + t, e1 - 1);
+                    c[t] = s_col[et];
+                    v[t] = e + t < e1 ? s_val[et] : 0.f;
+                }
+                float4 x[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) x[t] = cur[c[t] * h4 + q];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    acc.x = fmaf(v[t], x[t].x, acc.x); acc.y = fmaf(v[t], x[t].y, acc.y);
+                    acc.z = fmaf(v[t], x[t].z, acc.z); acc.w = fmaf(v[t], x[t].w, acc.w);
+                }
+            }
+            float4 y = make_float4(beta * acc.x, beta * acc.y, beta * acc.z, beta * acc.w);
+            if (BWD) {
+                const float4 x = cur[i];
+                keep[j].x = fmaf(alpha, x.x, keep[j].x); keep[j].y = fmaf(alpha, x.y, keep[j].y);
+                keep[j].z = fmaf(alpha, x.z, keep[j].z); keep[j].w = fmaf(alpha, x.w, keep[j].w);
+            } else {
+                y.x = fmaf(alpha, keep[j].x, y.x); y.y = fmaf(alpha, keep[j].y, y.y);
+                y.z = fmaf(alpha, keep[j].z, y.z); y.w = fmaf(alpha, keep[j].w, y.w);
+            }
+            nxt[i] = y;
+        }
+        __syncthreads();
+    }
+    const float4 *fin = (K & 1) ? buf1 : buf0;
+#pragma unroll
+    for (int j = 0; j < kAppnpItems; ++j) {
+        const int i = lane + 64 * j;
+        if (i >= total) break;
+        float4 y = fin[i];
+        if (BWD) { y.x += keep[j].x; y.y += keep[j].y; y.z += keep[j].z; y.w += keep[j].w; }
+        Y[base + i] = y;
+    }
+}
+
+extern "C" int fitgnn_appnp_unit_rows(int32_t h4) { return (h4 >= 1 && h4 <= 16) ? appnp_rows(h4) : 0; }
+extern "C" int fitgnn_appnp_unit_entries(void) { return kAppnpEntries; }
+
+extern "C" int fitgnn_appnp_units_f32(const int32_t *rowptr, const int32_t *col, const float *val, const int32_t *units, int32_t n_units,
+                                      int32_t max_rows, int32_t max_entries, const float *X, float *Y, int32_t h4, int32_t K, float alpha,
+                                      int32_t backward, void *stream) {
+    if (n_units < 0 || h4 < 1 || h4 > 16 || K < 0) return FITGNN_E_BADARG;
+    if (n_units > 0 && (max_rows < 1 || max_rows > appnp_rows(h4) || max_entries < 1 || max_entries > kAppnpEntries)) return FITGNN_E_BADARG;
+    if (n_units == 0) return 0;
+    if (!rowptr || !col || !val || !units || !X || !Y) return FITGNN_E_BADARG;
+    if ((((uintptr_t)X | (uintptr_t)Y) % 16) != 0) return FITGNN_E_ALIGN;
+    const int cap_rows = (max_rows + 3) / 4 * 4, cap_entries = (max_entries + 3) / 4 * 4;
+    const size_t lds = (size_t)2 * cap_rows * h4 * sizeof(float4) + (size_t)(cap_rows + 4) * sizeof(int32_t) +
+                       (size_t)cap_entries * (sizeof(int32_t) + sizeof(float));   // <= 24 KiB + 3 KiB + 16 KiB
+    if (backward)
+        hipLaunchKernelGGL(appnp_units_kernel<true>, dim3((unsigned)n_units), dim3(64), lds, (hipStream_t)stream, rowptr, col, val, units,
+                           n_units, (const float4 *)X, (float4 *)Y, h4, K, alpha, cap_rows, cap_entries);
+    else
+        hipLaunchKernelGGL(appnp_units_kernel<false>, dim3((unsigned)n_units), dim3(64), lds, (hipStream_t)stream, rowptr, col, val, units,
+                           n_units, (const float4 *)X, (float4 *)Y, h4, K, alpha, cap_rows, cap_entries);
+    return (int)hipGetLastError();
+}
+
 extern "C" int fitgnn_csr_row_sum_f32(const int32_t *rowptr, const float *v, int32_t n, float *y, void *stream) {
     if (n < 0) return FITGNN_E_BADARG;
     if (n == 0) return 0;

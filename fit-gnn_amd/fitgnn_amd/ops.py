@@ -66,6 +66,8 @@ class OpConfig:
                      gradient (fitgnn_narrow_atb_f32: no SpMM, no dZ) -- FusedGCNLayerAggregatedInput.
     pooled_rows_last_layer  the last GCN layer of the *_graph_gs models aggregate-first on the rows their pool reads (x[mask]), output
                      compact (FusedGCNLayerRows): its dense products run on about half of the union's rows (A/B switch).
+    appnp_in_lds     APPNP's K propagation steps for the subgraphs that fit a wavefront's LDS (<= 64 rows) in ONE launch with the signal
+                     resident in LDS (fitgnn_appnp_units_f32), the per-step kernel only on the sub-matrix of the larger subgraphs (A/B).
     fused_pool_head  lt1(global_mean_pool(x[rows])) of the graph-level regression models as one launch each way (MeanPoolHead) instead
                      of pool, scale, library product and bias add (A/B switch).
     grad_sink        None, or an object with `.view(data_ptr)` -> the slice of a "fresh gradients" buffer that belongs to the parameter stored at
@@ -80,12 +82,12 @@ class OpConfig:
     seed_bank        None, or a SeedBank supplying device-resident dropout seeds (steps captured in a hipGraph)."""
     __slots__ = ("gemm_precision", "atb_kernel", "nt_kernel", "nt_presplit", "fuse_dx_epilogue", "fold_backward",
                  "dedup_gather", "pad_table_min_k", "split_large_blocks", "compact_head_backward", "last_layer_on_loss_rows",
-                 "compact_rows_kernel", "stream_kernel", "two_hop_backward", "narrow_input_first", "fused_pool_head", "pooled_rows_last_layer", "rows_kernel_min_rows", "grad_sink", "profile", "profile_gemm",
+                 "compact_rows_kernel", "stream_kernel", "two_hop_backward", "narrow_input_first", "fused_pool_head", "pooled_rows_last_layer", "rows_kernel_min_rows", "appnp_in_lds", "grad_sink", "profile", "profile_gemm",
                  "profile_fused", "seed_bank")
 
     def __init__(self, gemm_precision="exact", atb_kernel=True, nt_kernel=True, nt_presplit=True, fuse_dx_epilogue=True,
                  fold_backward=False, dedup_gather=True, pad_table_min_k=0, split_large_blocks=True, compact_head_backward=True,
-                 last_layer_on_loss_rows=True, compact_rows_kernel=True, stream_kernel=False, two_hop_backward=True, narrow_input_first=True, fused_pool_head=True, pooled_rows_last_layer=True, rows_kernel_min_rows=32768, grad_sink=None,
+                 last_layer_on_loss_rows=True, compact_rows_kernel=True, stream_kernel=False, two_hop_backward=True, narrow_input_first=True, fused_pool_head=True, pooled_rows_last_layer=True, rows_kernel_min_rows=32768, appnp_in_lds=True, grad_sink=None,
                  profile=None, profile_gemm=None, profile_fused=None, seed_bank=None):
         if gemm_precision not in ("exact", "high", "highest"):
             raise ValueError(f"gemm_precision {gemm_precision!r}: 'exact', 'high' or 'highest'")
@@ -96,6 +98,7 @@ class OpConfig:
         self.compact_rows_kernel, self.stream_kernel, self.two_hop_backward = compact_rows_kernel, stream_kernel, two_hop_backward
         self.narrow_input_first, self.fused_pool_head, self.grad_sink = narrow_input_first, fused_pool_head, grad_sink
         self.pooled_rows_last_layer, self.rows_kernel_min_rows = pooled_rows_last_layer, int(rows_kernel_min_rows)
+        self.appnp_in_lds = appnp_in_lds
         self.profile, self.profile_gemm, self.profile_fused, self.seed_bank = profile, profile_gemm, profile_fused, seed_bank
 
     def replace(self, **kw):
@@ -2078,6 +2081,81 @@ class FusedGATLastLayerRows(torch.autograd.Function):
         return (dX, dW, datt2[0], datt2[1], (db if ctx.has_bias else None), dWl, dbl, None, None, None, None, None, None, None, None, None, None)
 
 
+class AppnpPlan:
+    """Which rows of a block-diagonal batch APPNP propagates inside LDS, and the sub-matrix of the others (built once per graph).
+
+    units [n_units, 2] int32: runs of whole diagonal blocks (ops csr.block_boundaries: the pattern's own closed blocks = cluster
+    subgraphs) of at most fitgnn_appnp_unit_rows(h4) rows and fitgnn_appnp_unit_entries() entries each, packed like SpMM tiles;
+    open_rows (int64, ascending): the rows of every other block, with their own CSR in both orientations (rows and columns
+    renumbered 0 .. n_open - 1: those blocks are closed too)."""
+
+    def __init__(self, g, h4):
+        from .csr import block_boundaries, make_tiles
+        import numpy as np
+
+        L = _lib.lib()
+        cap_r, cap_e = int(L.fitgnn_appnp_unit_rows(int(h4))), int(L.fitgnn_appnp_unit_entries())
+        self.cap_rows = cap_r
+        dev = g.f.rowptr.device
+        n = g.n
+        ptr = block_boundaries(g.f.rowptr, g.f.col, n).cpu().numpy().astype(np.int64)
+        rp = g.f.rowptr.cpu().numpy().astype(np.int64)
+        # units: (i) the blocks of at most PACK rows, packed like SpMM tiles (parallelism: one wavefront per unit -- packing a 90 k-row
+        # batch of 9-row subgraphs into 768-row units would leave 118 wavefronts); (ii) every block between PACK and the capacity alone
+        PACK = min(64, cap_r)
+        tiles = make_tiles(ptr, PACK)
+        a, b = tiles["row_begin"].astype(np.int64), tiles["row_end"].astype(np.int64)
+        is_b = np.zeros(n + 1, dtype=bool)
+        is_b[ptr] = True
+        closed = is_b[a] & is_b[b] & (rp[b] - rp[a] <= cap_e) & (b > a)
+        size = np.diff(ptr)
+        mid = (size > PACK) & (size <= cap_r) & (rp[ptr[1:]] - rp[ptr[:-1]] <= cap_e)
+        a = np.concatenate([a[closed], ptr[:-1][mid]])
+        b = np.concatenate([b[closed], ptr[1:][mid]])
+        order = np.argsort(a, kind="stable")
+        a, b = a[order], b[order]
+        closed = np.ones(len(a), dtype=bool)
+        self.units = torch.from_numpy(np.stack([a, b], 1).astype(np.int32)).to(dev).contiguous()
+        self.n_units = int(len(a))
+        self.max_rows = int((b - a).max()) if len(a) else 0
+        self.max_entries = int((rp[b] - rp[a]).max()) if len(a) else 0
+        row_open = np.ones(n, dtype=bool)
+        if self.n_units:
+            cover = np.zeros(n + 1, dtype=np.int64)
+            np.add.at(cover, a[closed], 1)
+            np.add.at(cover, b[closed], -1)
+            row_open = np.cumsum(cover[:-1]) == 0
+        self.n_open = int(row_open.sum())
+        self.rows_in_units = n - self.n_open
+        self.open_rows, self.sub = None, {}
+        if self.n_open:
+            open_t = torch.from_numpy(row_open).to(dev)
+            self.open_rows = torch.nonzero(open_t).flatten()
+            new_id = (torch.cumsum(open_t.to(torch.int64), 0) - 1).to(torch.int32)
+            for name, side in (("f", g.f), ("t", g.t)):
+                cnt = (side.rowptr[1:] - side.rowptr[:-1]).to(torch.int64)
+                cnt_o = cnt[self.open_rows]
+                rowptr = torch.zeros(self.n_open + 1, dtype=torch.int64, device=dev)
+                rowptr[1:] = torch.cumsum(cnt_o, 0)
+                ent = torch.repeat_interleave(open_t, cnt)                    # entries of open rows
+                col = new_id[side.col[ent].long()].contiguous()
+                self.sub[name] = (rowptr.to(torch.int32).contiguous(), col, side.val[ent].contiguous())
+            self.nnz_open = int(self.sub["f"][1].numel())
+        else:
+            self.nnz_open = 0
+
+
+def appnp_plan(g, h4):
+    """The plan for a signal of h4 float4 columns (a unit holds 768 / h4 rows), cached on the graph per h4."""
+    plans = getattr(g, "_appnp_plan", None)
+    if plans is None:
+        plans = {}
+        g._appnp_plan = plans
+    if h4 not in plans:
+        plans[h4] = AppnpPlan(g, h4)
+    return plans[h4]
+
+
 class APPNPPropagate(torch.autograd.Function):
     """z_K of  z_{k+1} = (1 - alpha) A_hat z_k + alpha z0,  z_0 = z0  (APPNP's K propagation steps) on a class-wide signal,
     one narrow-SpMM launch per step with the teleport term in its epilogue; the backward pass propagates with A_hat^T and
@@ -2102,6 +2180,31 @@ class APPNPPropagate(torch.autograd.Function):
         st = _lib.stream_ptr(z0.device)
         f = g.f
         z0p = APPNPPropagate._padded(z0, h4)
+        plan = appnp_plan(g, h4) if (cfg is None or cfg.appnp_in_lds) and K > 0 and h4 <= 16 else None
+        if plan is not None and plan.n_units == 0:
+            plan = None
+        ctx.g, ctx.K, ctx.alpha, ctx.cfg, ctx.H, ctx.plan = g, K, alpha, cfg, H, plan
+        if plan is not None:
+            # the subgraphs that fit a wavefront's LDS: all K steps in one launch; the rows of the larger ones: the per-step kernel on
+            # their own sub-matrix (gathered in, scattered out)
+            out = torch.empty_like(z0p)
+            with _timed(cfg, "appnp_units"):
+                _lib.check(L.fitgnn_appnp_units_f32(_lib.dptr(f.rowptr), _lib.dptr(f.col), _lib.dptr(f.val), _lib.dptr(plan.units), plan.n_units,
+                                                    plan.max_rows, plan.max_entries, _lib.dptr(z0p), _lib.dptr(out), h4, K, float(alpha), 0, st),
+                           "fitgnn_appnp_units_f32")
+            if plan.n_open:
+                rp, cc, vv = plan.sub["f"]
+                zb0 = z0p.index_select(0, plan.open_rows)
+                z = zb0
+                for _ in range(K):
+                    nxt = torch.empty_like(zb0)
+                    with _timed(cfg, "appnp_step"):
+                        _lib.check(L.fitgnn_spmm_narrow_padded_f32(_lib.dptr(rp), _lib.dptr(cc), _lib.dptr(vv), _lib.dptr(z), _lib.dptr(nxt),
+                                                                   plan.n_open, h4, 1.0 - alpha, _lib.dptr(zb0), float(alpha), None, 0.0, st),
+                                   "spmm_narrow_padded")
+                    z = nxt
+                out.index_copy_(0, plan.open_rows, z)
+            return out if H == 4 * h4 else out[:, :H].contiguous()
         z = z0p
         for _ in range(K):
             nxt = torch.empty_like(z0p)
@@ -2109,7 +2212,6 @@ class APPNPPropagate(torch.autograd.Function):
                 _lib.check(L.fitgnn_spmm_narrow_padded_f32(_lib.dptr(f.rowptr), _lib.dptr(f.col), _lib.dptr(f.val), _lib.dptr(z), _lib.dptr(nxt),
                                                            n, h4, 1.0 - alpha, _lib.dptr(z0p), float(alpha), None, 0.0, st), "spmm_narrow_padded")
             z = nxt
-        ctx.g, ctx.K, ctx.alpha, ctx.cfg, ctx.H = g, K, alpha, cfg, H
         return z if H == 4 * h4 else z[:, :H].contiguous()
 
     @staticmethod
@@ -2121,6 +2223,26 @@ class APPNPPropagate(torch.autograd.Function):
         st = _lib.stream_ptr(dz.device)
         t = ctx.g.t
         dz = APPNPPropagate._padded(dz, h4)
+        plan = ctx.plan
+        if plan is not None:
+            out = torch.empty_like(dz)
+            with _timed(ctx.cfg, "appnp_units_t"):
+                _lib.check(L.fitgnn_appnp_units_f32(_lib.dptr(t.rowptr), _lib.dptr(t.col), _lib.dptr(t.val), _lib.dptr(plan.units), plan.n_units,
+                                                    plan.max_rows, plan.max_entries, _lib.dptr(dz), _lib.dptr(out), h4, ctx.K, float(ctx.alpha), 1, st),
+                           "fitgnn_appnp_units_f32")
+            if plan.n_open:
+                rp, cc, vv = plan.sub["t"]
+                gb = dz.index_select(0, plan.open_rows)
+                accb = torch.zeros_like(gb)
+                for _ in range(ctx.K):
+                    nxt = torch.empty_like(gb)
+                    with _timed(ctx.cfg, "appnp_step_t"):
+                        _lib.check(L.fitgnn_spmm_narrow_padded_f32(_lib.dptr(rp), _lib.dptr(cc), _lib.dptr(vv), _lib.dptr(gb), _lib.dptr(nxt),
+                                                                   plan.n_open, h4, 1.0 - ctx.alpha, None, 0.0, _lib.dptr(accb), float(ctx.alpha), st),
+                                   "spmm_narrow_padded")
+                    gb = nxt
+                out.index_copy_(0, plan.open_rows, accb + gb)
+            return (out if H == 4 * h4 else out[:, :H].contiguous()), None, None, None, None
         acc = torch.zeros_like(dz)
         for _ in range(ctx.K):   # dz_k = (1 - alpha) A^T dz_{k+1};  acc += alpha * dz_{k+1}
             nxt = torch.empty_like(dz)

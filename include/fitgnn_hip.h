@@ -527,6 +527,20 @@ int fitgnn_spmm_narrow_padded_f32(const int32_t *rowptr, const int32_t *col, con
                                   int32_t n_rows, int32_t h4, float beta, const float *Z0, float gamma, float *ACC, float delta,
                                   void *stream);
 
+/* APPNP's K propagation steps z_{k+1} = (1 - alpha) A z_k + alpha z_0 (Baselines/SGGC/APPNP/networks.py:11,23) with the signal resident
+ * in LDS, for the "units" of a block-diagonal batch: units [n_units x 2] = (row_begin, row_end) of runs of consecutive rows that are
+ * CLOSED under the pattern (every column of their rows lies inside the run: whole cluster subgraphs), at most
+ * fitgnn_appnp_unit_rows(h4) rows (768 / h4) and fitgnn_appnp_unit_entries() CSR entries each.  X, Y: [rows x 4 h4] padded signals as in fitgnn_spmm_narrow_padded_f32 (only
+ * the units' rows are read / written).  One wavefront per unit loads it once, steps it K times between two LDS buffers and stores it
+ * once -- one launch instead of K passes over the signal.  backward != 0: hand in the TRANSPOSED pattern; computes
+ * alpha sum_{k<K} g_k + g_K with g_0 = X, g_{k+1} = (1 - alpha) A^T g_k (the gradient w.r.t. z_0).  Rows outside the units are the
+ * caller's (the per-step kernel on their sub-matrix).  max_rows / max_entries: the largest unit of this launch (its LDS is sized by them:
+ * a batch of 50-row subgraphs runs five wavefronts per CU, one with a 700-row unit one). */
+int fitgnn_appnp_unit_rows(int32_t h4);
+int fitgnn_appnp_unit_entries(void);
+int fitgnn_appnp_units_f32(const int32_t *rowptr, const int32_t *col, const float *val, const int32_t *units, int32_t n_units, int32_t max_rows,
+                           int32_t max_entries, const float *X, float *Y, int32_t h4, int32_t K, float alpha, int32_t backward, void *stream);
+
 /* =====================================================================================
  * Coarsen half: one contraction level of variation_neighborhoods
  * replaces: graph_coarsening/coarsening_utils.py contract_variation_linear :530-650,

@@ -180,6 +180,11 @@ def test_round4_graph_step_entry_points_check_their_arguments_without_a_gpu():
     assert L.fitgnn_adam_step_acc_f32(None, None, None, None, None, 8, 0.01, 0.9, 0.999, 1e-8, 0.0, None, None, 0, 0, None) == -1   # NULL buffers
     assert L.fitgnn_batch_offsets(None, None, 2000, None, None, None, None, None, None, None, None, None) == -1                    # B > 1024
     assert L.fitgnn_batch_offsets(None, None, 128, None, None, None, None, None, None, None, None, None) == -1
+    assert L.fitgnn_appnp_unit_rows(12) == 64 and L.fitgnn_appnp_unit_rows(1) == 768 and L.fitgnn_appnp_unit_rows(17) == 0
+    assert L.fitgnn_appnp_unit_entries() == 2048
+    assert L.fitgnn_appnp_units_f32(None, None, None, None, 0, 0, 0, None, None, 12, 10, 0.1, 0, None) == 0           # nothing to do
+    assert L.fitgnn_appnp_units_f32(None, None, None, None, 5, 64, 100, None, None, 12, 10, 0.1, 0, None) == -1       # NULL arrays
+    assert L.fitgnn_appnp_units_f32(None, None, None, None, 5, 65, 100, None, None, 12, 10, 0.1, 0, None) == -1       # a unit beyond the capacity
     n13 = [None] * 13
     n9 = [None] * 9
     assert L.fitgnn_batch_gather(128, *n13, 11, None, 1, 11, 64, 64, 64, 64, *n9, 11, None, None, None, None, None, 0, None) == -1   # NULL arrays

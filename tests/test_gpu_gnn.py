@@ -19,6 +19,11 @@ def mods():
     return network, fnn, gorc
 
 
+def _lib_mod():
+    from fitgnn_amd import _lib
+    return _lib
+
+
 def graph(n=300, m=900, seed=0):
     rng = np.random.default_rng(seed)
     a, b = rng.integers(0, n, size=m), rng.integers(0, n, size=m)
@@ -1339,3 +1344,53 @@ def test_appnp_trainer_takes_the_loss_on_the_train_rows_only(mods):
         assert a == pytest.approx(b, rel=1e-5), (step, a, b)
     for (k, v), (_, w) in zip(m1.state_dict().items(), m2.state_dict().items()):
         assert rel(v, w) < 1e-4, k
+
+
+@pytest.mark.parametrize("C", [3, 47, 64])
+@pytest.mark.parametrize("sizes", [[100, 7, 17, 300, 3, 3, 64, 33, 2, 5, 5, 40, 65, 1, 800, 769, 768], [5] * 200, [70, 200], [1500, 1025]])
+def test_appnp_in_lds_equals_the_per_step_propagation(mods, C, sizes):
+    """fitgnn_appnp_units_f32 (the K steps of a subgraph of <= 64 rows between two LDS buffers, one launch) + the per-step kernel on the
+    sub-matrix of the larger subgraphs == the per-step kernel over every row (OpConfig(appnp_in_lds=False)): propagated signal and the
+    gradient w.r.t. z_0; blocks around the unit size, tiny blocks packed into one unit, a batch with no unit at all."""
+    from fitgnn_amd import csr, ops
+
+    rng = np.random.default_rng(C + len(sizes))
+    src, dst, off = [], [], 0
+    for sz in sizes:   # every block: a ring plus chords (connected, symmetric)
+        ring = np.arange(sz)
+        und = {(min(a, b), max(a, b)) for a, b in zip(ring, np.roll(ring, -1)) if a != b}
+        for _ in range(sz // 2):
+            a, b = rng.integers(0, sz, size=2)
+            if a != b:
+                und.add((min(a, b), max(a, b)))
+        if und:
+            u = np.array(sorted(und), dtype=np.int64) + off
+            src += [u[:, 0], u[:, 1]]; dst += [u[:, 1], u[:, 0]]
+        off += sz
+    ei = torch.from_numpy(np.stack([np.concatenate(src), np.concatenate(dst)])).cuda()
+    n = off
+    g = csr.CSRGraph(ei, n, mode="gcn")
+    h4 = (C + 3) // 4
+    plan = ops.appnp_plan(g, h4)
+    assert plan.cap_rows == min(768, 768 // h4)
+    rp = g.f.rowptr.cpu().numpy()
+    bounds = np.concatenate([[0], np.cumsum(sizes)])
+    L = _lib_mod().lib()
+    small = sum(int(sz) for sz, a, b in zip(sizes, bounds[:-1], bounds[1:])
+                if sz <= plan.cap_rows and rp[b] - rp[a] <= L.fitgnn_appnp_unit_entries())
+    assert plan.rows_in_units == small and plan.n_open == n - small
+    assert plan.max_rows <= plan.cap_rows and (plan.n_units == 0 or plan.max_rows >= min(max(sizes), 1))
+    z0 = torch.randn(n, C, device="cuda")
+    w = torch.randn(n, C, device="cuda")
+    res = {}
+    for flag in (True, False):
+        zz = z0.clone().requires_grad_(True)
+        out = ops.APPNPPropagate.apply(zz, g, 10, 0.1, ops.DEFAULT.replace(appnp_in_lds=flag))
+        (out * w).sum().backward()
+        res[flag] = (out.detach(), zz.grad.detach())
+    assert rel(res[True][0], res[False][0]) < 1e-5
+    assert rel(res[True][1], res[False][1]) < 1e-5
+    # K = 1 and a different alpha
+    a = ops.APPNPPropagate.apply(z0, g, 1, 0.3, ops.DEFAULT)
+    b = ops.APPNPPropagate.apply(z0, g, 1, 0.3, ops.DEFAULT.replace(appnp_in_lds=False))
+    assert rel(a, b) < 1e-6
