@@ -614,6 +614,387 @@ extern "C" int fitgnn_appnp_units_f32(const int32_t *rowptr, const int32_t *col,
     return (int)hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The subgraphs too large for a unit (fitgnn_appnp_blocks_f32): one WORKGROUP per closed diagonal block, all K steps in one launch.
+//
+// A block of ~1 600 rows x 47 classes is 300 KB per buffer: not LDS, but a few hundred KB that one workgroup reads and writes K times
+// stay in its XCD's L2 -- so the steps ping-pong between two global scratch signals T1 / T2 (only the block's own rows are touched),
+// separated by workgroup barriers instead of launches (the block is closed: no other workgroup reads or writes its rows).  The
+// block's CSR slice (row pointers, columns, values: read K times) is staged in LDS once, which leaves one global round trip per
+// group of rows (the operand gather) where the per-step kernel has three (row pointer -> column -> operand).  The arithmetic of a
+// row is spmm_narrow_packed_kernel's, entry for entry (a wave packs G = 64 / h4 rows; the first kLongFrom entries by the row's own
+// lanes, the rest of a long row split over the G slots and folded in slot order): the two paths give the same bits.
+// Forward: z_{k+1} = (1 - alpha) A z_k + alpha X, result in Y.  Backward (transposed pattern handed in): g_{k+1} = (1 - alpha) A^T g_k,
+// Y accumulates alpha g_k (read-modify-write by the item's own lane) and ends as that sum + g_K.
+constexpr int kAppnpBlockThreads = 1024;
+constexpr int kAppnpBlockRows = 4096;      // rows of a block: its row pointers in LDS (16 KiB)
+constexpr int kAppnpBlockEntries = 16384;  // CSR entries of a block in LDS (128 KiB); a launch sizes its LDS by ITS largest block
+
+template <bool BWD>
+__global__ __launch_bounds__(kAppnpBlockThreads) void appnp_blocks_kernel(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                                                          const float *__restrict__ val, const int32_t *__restrict__ blocks,
+                                                                          int32_t n_blocks, const float4 *X, float4 *Y, float4 *T1, float4 *T2,
+                                                                          int32_t h4, int32_t K, float alpha, int32_t cap_rows) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char ab_lds[];
+    int32_t *s_rp = reinterpret_cast<int32_t *>(ab_lds);
+    const int b = blockIdx.x;
+    if (b >= n_blocks) return;
+    const int r0 = blocks[2 * b], r1 = blocks[2 * b + 1];
+    const int n = r1 - r0;
+    const int E0 = rowptr[r0];
+    const int nE = rowptr[r1] - E0;
+    int32_t *s_col = s_rp + cap_rows + 4;
+    float *s_val = reinterpret_cast<float *>(s_col + ((nE + 3) & ~3));
+    const int n_threads = blockDim.x;
+    for (int i = threadIdx.x; i <= n; i += n_threads) s_rp[i] = rowptr[r0 + i] - E0;
+    for (int e = threadIdx.x; e < nE; e += n_threads) {
+        s_col[e] = col[E0 + e];
+        s_val[e] = val[E0 + e];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n_waves = n_threads >> 6;
+    const int G = 64 / h4;
+    const int slot = lane / h4, q = lane - slot * h4;
+    const bool lane_on = slot < G;
+    const int n_groups = (n + G - 1) / G;
+    const float beta = 1.0f - alpha;
+    for (int k = 0; k < K; ++k) {
+        const float4 *cur = k == 0 ? X : ((k & 1) ? T1 : T2);
+        float4 *nxt = (k & 1) ? T2 : T1;
+        const bool last = k == K - 1;
+        for (int g = wave; g < n_groups; g += n_waves) {
+            const int lr = g * G + slot;   // row within the block
+            const bool on = lane_on && lr < n;
+            int e = 0, len = 0;
+            if (on) {
+                e = s_rp[lr];
+                len = s_rp[lr + 1] - e;
+            }
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int head = len < kLongFrom ? len : kLongFrom;
+            int most = head;
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) most = max(most, __shfl_xor(most, off, 64));
+            // the head entries: (column, value) of all of them first (LDS), then the operand rows (L2), then the sums in CSR order
+            {
+                int c[kLongFrom];
+                float v[kLongFrom];
+#pragma unroll
+                for (int t = 0; t < kLongFrom; ++t) {
+                    const bool has = t < head;
+                    c[t] = has ? s_col[e + t] : 0;
+                    v[t] = has ? s_val[e + t] : 0.f;
+                }
+                float4 x[kLongFrom];
+#pragma unroll
+                for (int t = 0; t < kLongFrom; ++t)
+                    if (t < most) x[t] = t < head ? cur[(int64_t)c[t] * h4 + q] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int t = 0; t < kLongFrom; ++t)
+                    if (t < head) {
+                        acc.x = fmaf(v[t], x[t].x, acc.x); acc.y = fmaf(v[t], x[t].y, acc.y);
+                        acc.z = fmaf(v[t], x[t].z, acc.z); acc.w = fmaf(v[t], x[t].w, acc.w);
+                    }
+            }
+            unsigned long long longs = __ballot(on && q == 0 && len > kLongFrom);
+            while (longs) {
+                const int src = __ffsll((long long)longs) - 1;
+                longs &= longs - 1;
+                const int e0 = __shfl(e, src, 64) + kLongFrom;
+                const int e1 = __shfl(e, src, 64) + __shfl(len, src, 64);
+                float4 part = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (lane_on) {
+                    for (int kk = e0 + slot; kk < e1; kk += G) {
+                        const int c = s_col[kk];
+                        const float v = s_val[kk];
+                        const float4 x = cur[(int64_t)c * h4 + q];
+                        part.x = fmaf(v, x.x, part.x); part.y = fmaf(v, x.y, part.y); part.z = fmaf(v, x.z, part.z); part.w = fmaf(v, x.w, part.w);
+                    }
+                }
+                float4 tot = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int s2 = 0; s2 < G; ++s2) {
+                    const int from = s2 * h4 + q;
+                    tot.x += __shfl(part.x, from, 64); tot.y += __shfl(part.y, from, 64);
+                    tot.z += __shfl(part.z, from, 64); tot.w += __shfl(part.w, from, 64);
+                }
+                if (lane_on && slot == src / h4) { acc.x += tot.x; acc.y += tot.y; acc.z += tot.z; acc.w += tot.w; }
+            }
+            if (on) {
+                const int64_t o = (int64_t)(r0 + lr) * h4 + q;
+                float4 y = make_float4(beta * acc.x, beta * acc.y, beta * acc.z, beta * acc.w);
+                if (!BWD) {
+                    const float4 z = X[o];
+                    y.x = fmaf(alpha, z.x, y.x); y.y = fmaf(alpha, z.y, y.y); y.z = fmaf(alpha, z.z, y.z); y.w = fmaf(alpha, z.w, y.w);
+                    (last ? Y : nxt)[o] = y;
+                } else {
+                    const float4 x = cur[o];
+                    float4 a = k == 0 ? make_float4(0.f, 0.f, 0.f, 0.f) : Y[o];
+                    a.x = fmaf(alpha, x.x, a.x); a.y = fmaf(alpha, x.y, a.y); a.z = fmaf(alpha, x.z, a.z); a.w = fmaf(alpha, x.w, a.w);
+                    if (last) {
+                        a.x += y.x; a.y += y.y; a.z += y.z; a.w += y.w;
+                    } else {
+                        nxt[o] = y;
+                    }
+                    Y[o] = a;
+                }
+            }
+        }
+        __syncthreads();   // the step's rows (global, this workgroup's own) before the next step gathers them
+    }
+}
+
+extern "C" int fitgnn_appnp_block_rows(void) { return kAppnpBlockRows; }
+extern "C" int fitgnn_appnp_block_entries(void) { return kAppnpBlockEntries; }
+
+extern "C" int fitgnn_appnp_blocks_f32(const int32_t *rowptr, const int32_t *col, const float *val, const int32_t *blocks, int32_t n_blocks,
+                                       int32_t max_rows, int32_t max_entries, const float *X, float *Y, float *T1, float *T2, int32_t h4,
+                                       int32_t K, float alpha, int32_t backward, void *stream) {
+    if (n_blocks < 0 || h4 < 1 || h4 > 16 || K < 1) return FITGNN_E_BADARG;
+    if (n_blocks > 0 && (max_rows < 1 || max_rows > kAppnpBlockRows || max_entries < 0 || max_entries > kAppnpBlockEntries)) return FITGNN_E_BADARG;
+    if (n_blocks == 0) return 0;
+    if (!rowptr || !col || !val || !blocks || !X || !Y || !T1 || !T2) return FITGNN_E_BADARG;
+    if (X == Y || T1 == T2 || X == T1 || X == T2 || Y == T1 || Y == T2) return FITGNN_E_BADARG;
+    if ((((uintptr_t)X | (uintptr_t)Y | (uintptr_t)T1 | (uintptr_t)T2) % 16) != 0) return FITGNN_E_ALIGN;
+    const int cap_rows = (max_rows + 3) / 4 * 4, cap_entries = (max_entries + 3) / 4 * 4 + 4;
+    const size_t lds = (size_t)(cap_rows + 4) * sizeof(int32_t) + (size_t)cap_entries * (sizeof(int32_t) + sizeof(float));
+    const void *fn = backward ? (const void *)appnp_blocks_kernel<true> : (const void *)appnp_blocks_kernel<false>;
+    int threads = kAppnpBlockThreads;
+    if (const char *ev = getenv("FITGNN_APPNP_BLOCK_THREADS")) {   // tuning knob: 64 .. 1024, whole wavefronts
+        const int t = atoi(ev);
+        if (t >= 64 && t <= kAppnpBlockThreads && t % 64 == 0) threads = t;
+    }
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    if (backward)
+        hipLaunchKernelGGL(appnp_blocks_kernel<true>, dim3((unsigned)n_blocks), dim3(threads), lds, (hipStream_t)stream, rowptr, col,
+                           val, blocks, n_blocks, (const float4 *)X, (float4 *)Y, (float4 *)T1, (float4 *)T2, h4, K, alpha, cap_rows);
+    else
+        hipLaunchKernelGGL(appnp_blocks_kernel<false>, dim3((unsigned)n_blocks), dim3(threads), lds, (hipStream_t)stream, rowptr, col,
+                           val, blocks, n_blocks, (const float4 *)X, (float4 *)Y, (float4 *)T1, (float4 *)T2, h4, K, alpha, cap_rows);
+    return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The K steps in LDS for subgraphs of any size that fits, by COLUMN SLICES (fitgnn_appnp_lds_f32).
+//
+// The recurrence never mixes two columns of the signal, so a workgroup need not hold a subgraph's whole [rows x 4 h4] signal: it
+// stages the CSR slice of its range once (columns re-based to the range as 16-bit, values, row pointers) and then, for one slice of
+// w <= `slice` float4 columns after the other, loads the slice of its rows, steps it K times between two LDS buffers and stores it.
+// A 1 600-row subgraph of a 47-class signal is 300 KB whole and 25 KB per buffer as a one-float4 slice; a 50-row star whose
+// wavefront held 24 KB of buffers (one wavefront per SIMD) holds 6 KB at w = 4.  Work of a step: a thread owns the items (row,
+// slice column) tid, tid + T, ... (at most kLdsKeep: the teleport operand z_0, or the backward's running alpha-sum, stays in its
+// registers) and sums a SHORT row's entries in CSR order, four at a time; a row of more than kLdsShort entries (a star's centre) is
+// taken by a whole wavefront -- lane = (entry slot, slice column), 64 / w entries per round, slots folded by xor shuffles in a fixed
+// tree -- so a step costs a centre a few LDS round trips instead of a chain as long as its row.  Long rows are listed at staging
+// (LDS counter: the list's order varies, no result depends on it); their z_0 / alpha-sum lives in LDS beside the buffers.
+constexpr int kLdsKeep = 4;     // items per thread: rows of a range x w <= kLdsKeep x threads
+constexpr int kLdsShort = 16;   // rows of more entries than this are summed by a wavefront
+constexpr int kLdsMaxBytes = 160 * 1024;
+
+struct LdsPlan { int cap_rows, cap_entries, cap_long; size_t bytes; };
+__host__ __device__ inline LdsPlan appnp_lds_plan(int max_rows, int max_entries, int slice) {
+    LdsPlan p;
+    p.cap_rows = (max_rows + 3) / 4 * 4;
+    p.cap_entries = (max_entries + 7) / 8 * 8 + 8;
+    p.cap_long = (max_entries / (kLdsShort + 1) + 8) / 8 * 8;
+    p.bytes = (size_t)2 * p.cap_rows * slice * 16 + (size_t)p.cap_long * slice * 16 + (size_t)p.cap_entries * 4 + (size_t)(p.cap_rows + 4) * 4 +
+              (size_t)p.cap_entries * 2 + (size_t)p.cap_long * 2 + 16;
+    return p;
+}
+
+template <bool BWD>
+__global__ __launch_bounds__(1024) void appnp_lds_kernel(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                                         const float *__restrict__ val, const int32_t *__restrict__ ranges, int32_t n_ranges,
+                                                         const float4 *__restrict__ X, float4 *__restrict__ Y, int32_t h4, int32_t K, float alpha,
+                                                         int32_t max_rows, int32_t max_entries, int32_t slice) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char al_lds[];
+    const LdsPlan P = appnp_lds_plan(max_rows, max_entries, slice);
+    float4 *buf0 = reinterpret_cast<float4 *>(al_lds);
+    float4 *buf1 = buf0 + P.cap_rows * slice;
+    float4 *s_keep = buf1 + P.cap_rows * slice;
+    float *s_val = reinterpret_cast<float *>(s_keep + P.cap_long * slice);
+    int32_t *s_rp = reinterpret_cast<int32_t *>(s_val + P.cap_entries);
+    uint16_t *s_col = reinterpret_cast<uint16_t *>(s_rp + P.cap_rows + 4);
+    uint16_t *s_long = s_col + P.cap_entries;
+    int32_t *s_cnt = reinterpret_cast<int32_t *>(s_long + P.cap_long);
+    const int u = blockIdx.x;
+    if (u >= n_ranges) return;
+    const int tid = threadIdx.x, T = blockDim.x;
+    const int lane = tid & 63, wave = tid >> 6, W = T >> 6;
+    const int r0 = ranges[2 * u], r1 = ranges[2 * u + 1];
+    const int n = r1 - r0;
+    const int E0 = rowptr[r0];
+    const int nE = rowptr[r1] - E0;
+    if (n > max_rows || nE > max_entries || (n << 0) * slice > kLdsKeep * T) return;   // not the list the launch was sized for (uniform)
+    if (tid == 0) *s_cnt = 0;
+    for (int i = tid; i <= n; i += T) s_rp[i] = rowptr[r0 + i] - E0;
+    for (int e = tid; e < nE; e += T) {
+        s_col[e] = (uint16_t)(col[E0 + e] - r0);
+        s_val[e] = val[E0 + e];
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += T)
+        if (s_rp[i + 1] - s_rp[i] > kLdsShort) s_long[atomicAdd(s_cnt, 1)] = (uint16_t)i;
+    __syncthreads();
+    const int n_long = *s_cnt;
+    const float beta = 1.0f - alpha;
+    for (int c0 = 0; c0 < h4;) {
+        // this slice: w = the largest power of two <= min(slice, h4 - c0) columns
+        int lw = 0;
+        while ((2 << lw) <= slice && (2 << lw) <= h4 - c0) ++lw;
+        const int w = 1 << lw;
+        const int total = n << lw;
+        float4 keep[kLdsKeep];
+#pragma unroll
+        for (int j = 0; j < kLdsKeep; ++j) {
+            const int i = tid + j * T;
+            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < total) {
+                x = X[(int64_t)(r0 + (i >> lw)) * h4 + c0 + (i & (w - 1))];
+                buf0[i] = x;
+            }
+            keep[j] = BWD ? make_float4(0.f, 0.f, 0.f, 0.f) : x;
+        }
+        __syncthreads();
+        for (int i = tid; i < (n_long << lw); i += T)   // the long rows' z_0 / alpha-sum
+            s_keep[i] = BWD ? make_float4(0.f, 0.f, 0.f, 0.f) : buf0[((int)s_long[i >> lw] << lw) + (i & (w - 1))];
+        __syncthreads();
+        const int q_l = lane & (w - 1), slot = lane >> lw, S = 64 >> lw;
+        for (int k = 0; k < K; ++k) {
+            const float4 *cur = (k & 1) ? buf1 : buf0;
+            float4 *nxt = (k & 1) ? buf0 : buf1;
+#pragma unroll
+            for (int j = 0; j < kLdsKeep; ++j) {
+                const int i = tid + j * T;
+                if (i < total) {
+                    const int row = i >> lw, q = i & (w - 1);
+                    const int e1 = s_rp[row + 1];
+                    int e = s_rp[row];
+                    if (e1 - e <= kLdsShort) {   // (a longer row is a wavefront's)
+                        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+                        for (; e < e1; e += 4) {   // four entries' (column, value) reads, then their operand reads, issued together; sums in CSR order
+                            int c[4];
+                            float v[4];
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) {
+                                const int et = min(e + t, e1 - 1);
+                                c[t] = s_col[et];
+                                v[t] = e + t < e1 ? s_val[et] : 0.f;
+                            }
+                            float4 x[4];
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) x[t] = cur[(c[t] << lw) + q];
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) {
+                                acc.x = fmaf(v[t], x[t].x, acc.x); acc.y = fmaf(v[t], x[t].y, acc.y);
+                                acc.z = fmaf(v[t], x[t].z, acc.z); acc.w = fmaf(v[t], x[t].w, acc.w);
+                            }
+                        }
+                        float4 y = make_float4(beta * acc.x, beta * acc.y, beta * acc.z, beta * acc.w);
+                        if (BWD) {
+                            const float4 x = cur[i];
+                            keep[j].x = fmaf(alpha, x.x, keep[j].x); keep[j].y = fmaf(alpha, x.y, keep[j].y);
+                            keep[j].z = fmaf(alpha, x.z, keep[j].z); keep[j].w = fmaf(alpha, x.w, keep[j].w);
+                        } else {
+                            y.x = fmaf(alpha, keep[j].x, y.x); y.y = fmaf(alpha, keep[j].y, y.y);
+                            y.z = fmaf(alpha, keep[j].z, y.z); y.w = fmaf(alpha, keep[j].w, y.w);
+                        }
+                        nxt[i] = y;
+                    }
+                }
+            }
+            for (int j = wave; j < n_long; j += W) {   // a long row: entries e0 + slot, e0 + slot + S, ... per lane, two rounds in flight
+                const int row = s_long[j];
+                const int e1 = s_rp[row + 1];
+                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int e = s_rp[row] + slot; e < e1; e += 2 * S) {
+                    const bool two = e + S < e1;
+                    const int ca = s_col[e], cb = s_col[two ? e + S : e];
+                    const float va = s_val[e], vb = two ? s_val[e + S] : 0.f;
+                    const float4 xa = cur[(ca << lw) + q_l], xb = cur[(cb << lw) + q_l];
+                    acc.x = fmaf(va, xa.x, acc.x); acc.y = fmaf(va, xa.y, acc.y); acc.z = fmaf(va, xa.z, acc.z); acc.w = fmaf(va, xa.w, acc.w);
+                    acc.x = fmaf(vb, xb.x, acc.x); acc.y = fmaf(vb, xb.y, acc.y); acc.z = fmaf(vb, xb.z, acc.z); acc.w = fmaf(vb, xb.w, acc.w);
+                }
+                for (int off = 32; off >= w; off >>= 1) {   // fold the slots: a fixed tree
+                    acc.x += __shfl_xor(acc.x, off, 64); acc.y += __shfl_xor(acc.y, off, 64);
+                    acc.z += __shfl_xor(acc.z, off, 64); acc.w += __shfl_xor(acc.w, off, 64);
+                }
+                if (slot == 0) {
+                    const int i = (row << lw) + q_l;
+                    float4 y = make_float4(beta * acc.x, beta * acc.y, beta * acc.z, beta * acc.w);
+                    float4 kp = s_keep[(j << lw) + q_l];
+                    if (BWD) {
+                        const float4 x = cur[i];
+                        kp.x = fmaf(alpha, x.x, kp.x); kp.y = fmaf(alpha, x.y, kp.y); kp.z = fmaf(alpha, x.z, kp.z); kp.w = fmaf(alpha, x.w, kp.w);
+                        s_keep[(j << lw) + q_l] = kp;
+                    } else {
+                        y.x = fmaf(alpha, kp.x, y.x); y.y = fmaf(alpha, kp.y, y.y); y.z = fmaf(alpha, kp.z, y.z); y.w = fmaf(alpha, kp.w, y.w);
+                    }
+                    nxt[i] = y;
+                }
+            }
+            __syncthreads();
+        }
+        float4 *fin = (K & 1) ? buf1 : buf0;
+        if (BWD) {   // the long rows' sums: folded into the final buffer first (the lanes that hold them are not the items' owners)
+            for (int i = tid; i < (n_long << lw); i += T) {
+                const int at = ((int)s_long[i >> lw] << lw) + (i & (w - 1));
+                float4 y = fin[at];
+                const float4 kp = s_keep[i];
+                y.x += kp.x; y.y += kp.y; y.z += kp.z; y.w += kp.w;
+                fin[at] = y;
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int j = 0; j < kLdsKeep; ++j) {
+            const int i = tid + j * T;
+            if (i < total) {
+                float4 y = fin[i];
+                if (BWD) { y.x += keep[j].x; y.y += keep[j].y; y.z += keep[j].z; y.w += keep[j].w; }   // (a long row's keep[j] stayed 0)
+                Y[(int64_t)(r0 + (i >> lw)) * h4 + c0 + (i & (w - 1))] = y;
+            }
+        }
+        __syncthreads();   // the buffers are the next slice's
+        c0 += w;
+    }
+}
+
+extern "C" int64_t fitgnn_appnp_lds_bytes(int32_t max_rows, int32_t max_entries, int32_t slice) {
+    if (max_rows < 1 || max_rows > 65535 || max_entries < 0 || (slice != 1 && slice != 2 && slice != 4)) return -1;
+    return (int64_t)appnp_lds_plan(max_rows, max_entries, slice).bytes;
+}
+extern "C" int fitgnn_appnp_lds_max_bytes(void) { return kLdsMaxBytes; }
+extern "C" int fitgnn_appnp_lds_items_per_thread(void) { return kLdsKeep; }
+
+extern "C" int fitgnn_appnp_lds_f32(const int32_t *rowptr, const int32_t *col, const float *val, const int32_t *ranges, int32_t n_ranges,
+                                    int32_t max_rows, int32_t max_entries, const float *X, float *Y, int32_t h4, int32_t K, float alpha,
+                                    int32_t backward, int32_t threads, int32_t slice, void *stream) {
+    if (n_ranges < 0 || h4 < 1 || h4 > 16 || K < 0) return FITGNN_E_BADARG;
+    if (n_ranges == 0) return 0;
+    if (threads < 64 || threads > 1024 || threads % 64 != 0 || (slice != 1 && slice != 2 && slice != 4)) return FITGNN_E_BADARG;
+    if (max_rows < 1 || max_rows > 65535 || max_entries < 0 || (int64_t)max_rows * slice > (int64_t)kLdsKeep * threads) return FITGNN_E_BADARG;
+    const LdsPlan P = appnp_lds_plan(max_rows, max_entries, slice);
+    if (P.bytes > (size_t)kLdsMaxBytes) return FITGNN_E_BADARG;
+    if (!rowptr || !col || !val || !ranges || !X || !Y) return FITGNN_E_BADARG;
+    if ((((uintptr_t)X | (uintptr_t)Y) % 16) != 0) return FITGNN_E_ALIGN;
+    const void *fn = backward ? (const void *)appnp_lds_kernel<true> : (const void *)appnp_lds_kernel<false>;
+    if (P.bytes > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P.bytes);
+        if (e != hipSuccess) return (int)e;
+    }
+    if (backward)
+        hipLaunchKernelGGL(appnp_lds_kernel<true>, dim3((unsigned)n_ranges), dim3(threads), P.bytes, (hipStream_t)stream, rowptr, col, val, ranges,
+                           n_ranges, (const float4 *)X, (float4 *)Y, h4, K, alpha, max_rows, max_entries, slice);
+    else
+        hipLaunchKernelGGL(appnp_lds_kernel<false>, dim3((unsigned)n_ranges), dim3(threads), P.bytes, (hipStream_t)stream, rowptr, col, val, ranges,
+                           n_ranges, (const float4 *)X, (float4 *)Y, h4, K, alpha, max_rows, max_entries, slice);
+    return (int)hipGetLastError();
+}
+
 extern "C" int fitgnn_csr_row_sum_f32(const int32_t *rowptr, const float *v, int32_t n, float *y, void *stream) {
     if (n < 0) return FITGNN_E_BADARG;
     if (n == 0) return 0;

@@ -113,6 +113,13 @@ SIGNATURES = {
     "fitgnn_spmm_narrow_padded_f32": (ctypes.c_int, [ptr, ptr, ptr, ptr, ptr, c_i32, c_i32, c_f32, ptr, c_f32, ptr, c_f32, ptr]),
     "fitgnn_appnp_unit_rows": (ctypes.c_int, [c_i32]),
     "fitgnn_appnp_unit_entries": (ctypes.c_int, []),
+    "fitgnn_appnp_block_rows": (ctypes.c_int, []),
+    "fitgnn_appnp_block_entries": (ctypes.c_int, []),
+    "fitgnn_appnp_blocks_f32": (ctypes.c_int, [ptr, ptr, ptr, ptr, c_i32, c_i32, c_i32, ptr, ptr, ptr, ptr, c_i32, c_i32, c_f32, c_i32, ptr]),
+    "fitgnn_appnp_lds_bytes": (ctypes.c_int64, [c_i32, c_i32, c_i32]),
+    "fitgnn_appnp_lds_max_bytes": (ctypes.c_int, []),
+    "fitgnn_appnp_lds_items_per_thread": (ctypes.c_int, []),
+    "fitgnn_appnp_lds_f32": (ctypes.c_int, [ptr, ptr, ptr, ptr, c_i32, c_i32, c_i32, ptr, ptr, c_i32, c_i32, c_f32, c_i32, c_i32, c_i32, ptr]),
     "fitgnn_appnp_units_f32": (ctypes.c_int, [ptr, ptr, ptr, ptr, c_i32, c_i32, c_i32, ptr, ptr, c_i32, c_i32, c_f32, c_i32, ptr]),
     "fitgnn_csr_row_sum_f32": (ctypes.c_int, [ptr, ptr, c_i32, ptr, ptr]),
     "fitgnn_induced_edges_count": (ctypes.c_int, [ptr, ptr, ptr, ptr, ptr, ptr, c_i64, ptr, ptr]),

@@ -68,6 +68,11 @@ class OpConfig:
                      compact (FusedGCNLayerRows): its dense products run on about half of the union's rows (A/B switch).
     appnp_in_lds     APPNP's K propagation steps for the subgraphs that fit a wavefront's LDS (<= 64 rows) in ONE launch with the signal
                      resident in LDS (fitgnn_appnp_units_f32), the per-step kernel only on the sub-matrix of the larger subgraphs (A/B).
+    appnp_sliced     with appnp_in_lds: the K steps in LDS a slice of <= 4 float4 columns at a time (fitgnn_appnp_lds_f32): the units at
+                     three times the wavefronts per CU, a long row summed by a whole wavefront, and every larger subgraph that fits LDS
+                     one slice at a time (a 2 000-row subgraph of a 47-class signal does); off = the whole-signal units kernel (A/B).
+    appnp_blocks     with appnp_in_lds: the larger subgraphs (<= 4 096 rows) one workgroup each, all K steps in ONE launch between two
+                     scratch signals that stay in L2, CSR slice in LDS (fitgnn_appnp_blocks_f32); off = the per-step kernel on them (A/B).
     fused_pool_head  lt1(global_mean_pool(x[rows])) of the graph-level regression models as one launch each way (MeanPoolHead) instead
                      of pool, scale, library product and bias add (A/B switch).
     grad_sink        None, or an object with `.view(data_ptr)` -> the slice of a "fresh gradients" buffer that belongs to the parameter stored at
@@ -82,12 +87,12 @@ class OpConfig:
     seed_bank        None, or a SeedBank supplying device-resident dropout seeds (steps captured in a hipGraph)."""
     __slots__ = ("gemm_precision", "atb_kernel", "nt_kernel", "nt_presplit", "fuse_dx_epilogue", "fold_backward",
                  "dedup_gather", "pad_table_min_k", "split_large_blocks", "compact_head_backward", "last_layer_on_loss_rows",
-                 "compact_rows_kernel", "stream_kernel", "two_hop_backward", "narrow_input_first", "fused_pool_head", "pooled_rows_last_layer", "rows_kernel_min_rows", "appnp_in_lds", "grad_sink", "profile", "profile_gemm",
+                 "compact_rows_kernel", "stream_kernel", "two_hop_backward", "narrow_input_first", "fused_pool_head", "pooled_rows_last_layer", "rows_kernel_min_rows", "appnp_in_lds", "appnp_blocks", "appnp_sliced", "grad_sink", "profile", "profile_gemm",
                  "profile_fused", "seed_bank")
 
     def __init__(self, gemm_precision="exact", atb_kernel=True, nt_kernel=True, nt_presplit=True, fuse_dx_epilogue=True,
                  fold_backward=False, dedup_gather=True, pad_table_min_k=0, split_large_blocks=True, compact_head_backward=True,
-                 last_layer_on_loss_rows=True, compact_rows_kernel=True, stream_kernel=False, two_hop_backward=True, narrow_input_first=True, fused_pool_head=True, pooled_rows_last_layer=True, rows_kernel_min_rows=32768, appnp_in_lds=True, grad_sink=None,
+                 last_layer_on_loss_rows=True, compact_rows_kernel=True, stream_kernel=False, two_hop_backward=True, narrow_input_first=True, fused_pool_head=True, pooled_rows_last_layer=True, rows_kernel_min_rows=32768, appnp_in_lds=True, appnp_blocks=True, appnp_sliced=True, grad_sink=None,
                  profile=None, profile_gemm=None, profile_fused=None, seed_bank=None):
         if gemm_precision not in ("exact", "high", "highest"):
             raise ValueError(f"gemm_precision {gemm_precision!r}: 'exact', 'high' or 'highest'")
@@ -98,7 +103,7 @@ class OpConfig:
         self.compact_rows_kernel, self.stream_kernel, self.two_hop_backward = compact_rows_kernel, stream_kernel, two_hop_backward
         self.narrow_input_first, self.fused_pool_head, self.grad_sink = narrow_input_first, fused_pool_head, grad_sink
         self.pooled_rows_last_layer, self.rows_kernel_min_rows = pooled_rows_last_layer, int(rows_kernel_min_rows)
-        self.appnp_in_lds = appnp_in_lds
+        self.appnp_in_lds, self.appnp_blocks, self.appnp_sliced = appnp_in_lds, appnp_blocks, appnp_sliced
         self.profile, self.profile_gemm, self.profile_fused, self.seed_bank = profile, profile_gemm, profile_fused, seed_bank
 
     def replace(self, **kw):
@@ -2084,12 +2089,18 @@ class FusedGATLastLayerRows(torch.autograd.Function):
 class AppnpPlan:
     """Which rows of a block-diagonal batch APPNP propagates inside LDS, and the sub-matrix of the others (built once per graph).
 
+    lds_blocks [n_lds_blocks, 2] int32 (sliced=True): the diagonal blocks beyond a unit whose CSR slice and two one-slice signal buffers
+    fit LDS (fitgnn_appnp_lds_bytes), sixteen wavefronts each, lds_slice float4 columns per pass;
+    blocks [n_blocks, 2] int32: the diagonal blocks beyond that but within fitgnn_appnp_block_rows() / _entries(), one workgroup each
+    (when there are at least MIN_BLOCKS of them);
     units [n_units, 2] int32: runs of whole diagonal blocks (ops csr.block_boundaries: the pattern's own closed blocks = cluster
     subgraphs) of at most fitgnn_appnp_unit_rows(h4) rows and fitgnn_appnp_unit_entries() entries each, packed like SpMM tiles;
     open_rows (int64, ascending): the rows of every other block, with their own CSR in both orientations (rows and columns
     renumbered 0 .. n_open - 1: those blocks are closed too)."""
 
-    def __init__(self, g, h4):
+    MIN_BLOCKS = 128   # fewer subgraphs beyond a unit than this: they stay on the per-step launches
+
+    def __init__(self, g, h4, blocks=True, sliced=True):
         from .csr import block_boundaries, make_tiles
         import numpy as np
 
@@ -2119,14 +2130,63 @@ class AppnpPlan:
         self.n_units = int(len(a))
         self.max_rows = int((b - a).max()) if len(a) else 0
         self.max_entries = int((rp[b] - rp[a]).max()) if len(a) else 0
-        row_open = np.ones(n, dtype=bool)
+        # blocks: the subgraphs beyond a unit, one workgroup each (fitgnn_appnp_blocks_f32: K steps between two global scratch signals
+        # that stay in L2, the block's CSR slice in LDS) -- when there are enough of them to fill the chip; a handful of large
+        # blocks is better served by the per-step launches over all of their rows
+        blk_r, blk_e = int(L.fitgnn_appnp_block_rows()), int(L.fitgnn_appnp_block_entries())
+        ent = rp[ptr[1:]] - rp[ptr[:-1]]
+        cover = np.zeros(n + 1, dtype=np.int64)
+        np.add.at(cover, a, 1)
+        np.add.at(cover, b, -1)
+        in_unit = np.cumsum(cover)[np.minimum(ptr[:-1], n - 1)] > 0   # a block is inside a unit or outside all of them
+        # sliced: the column-sliced LDS kernel (fitgnn_appnp_lds_f32) runs the units (a few wavefronts each) and, sixteen wavefronts
+        # each, every larger subgraph whose CSR slice and two one-slice buffers fit LDS
+        self.sliced = bool(sliced)
+        pow2 = lambda v: 1 << (int(v).bit_length() - 1)   # noqa: E731
+        keep, lds_max = int(L.fitgnn_appnp_lds_items_per_thread()), int(L.fitgnn_appnp_lds_max_bytes())
+        self.unit_slice = pow2(min(4, h4))
+        self.unit_threads = 64
         if self.n_units:
+            self.unit_threads = max(64, -(-self.max_rows * self.unit_slice // (keep * 64)) * 64)
+            if self.unit_threads > 1024 or L.fitgnn_appnp_lds_bytes(self.max_rows, self.max_entries, self.unit_slice) > lds_max:
+                self.unit_slice, self.unit_threads = 1, max(64, -(-self.max_rows // (keep * 64)) * 64)
+        lds_fit = np.zeros(len(size), dtype=bool)
+        self.lds_slice = 1
+        if sliced:
+            cand = ~in_unit & (size > 0) & (size <= keep * 1024)
+            bytes1 = np.array([L.fitgnn_appnp_lds_bytes(int(r), int(e), 1) if c else 0 for r, e, c in zip(size, ent, cand)], dtype=np.int64)
+            lds_fit = cand & (bytes1 <= lds_max)
+            if lds_fit.any():
+                mr, me = int(size[lds_fit].max()), int(ent[lds_fit].max())
+                for sl in (4, 2):   # a wider slice (fewer passes) when two workgroups per CU still fit
+                    if sl <= pow2(h4) and mr * sl <= keep * 1024 and L.fitgnn_appnp_lds_bytes(mr, me, sl) <= lds_max // 2:
+                        self.lds_slice = sl
+                        break
+        la, lb = ptr[:-1][lds_fit], ptr[1:][lds_fit]
+        self.lds_blocks = torch.from_numpy(np.stack([la, lb], 1).astype(np.int32)).to(dev).contiguous() if len(la) else None
+        self.n_lds_blocks = int(len(la))
+        self.lds_max_rows = int((lb - la).max()) if len(la) else 0
+        self.lds_max_entries = int(ent[lds_fit].max()) if len(la) else 0
+        self.rows_in_lds_blocks = int((lb - la).sum())
+        self.nnz_lds_blocks = int(ent[lds_fit].sum())
+        big = ~in_unit & ~lds_fit & (size > 0) & (size <= blk_r) & (ent <= blk_e)
+        if not blocks or int(big.sum()) < self.MIN_BLOCKS:
+            big[:] = False
+        ba, bb = ptr[:-1][big], ptr[1:][big]
+        self.blocks = torch.from_numpy(np.stack([ba, bb], 1).astype(np.int32)).to(dev).contiguous() if len(ba) else None
+        self.n_blocks = int(len(ba))
+        self.block_max_rows = int((bb - ba).max()) if len(ba) else 0
+        self.block_max_entries = int(ent[big].max()) if len(ba) else 0
+        self.rows_in_blocks = int((bb - ba).sum())
+        self.nnz_blocks = int(ent[big].sum())
+        row_open = np.ones(n, dtype=bool)
+        if self.n_units or self.n_blocks or self.n_lds_blocks:
             cover = np.zeros(n + 1, dtype=np.int64)
-            np.add.at(cover, a[closed], 1)
-            np.add.at(cover, b[closed], -1)
+            np.add.at(cover, np.concatenate([a, ba, la]), 1)
+            np.add.at(cover, np.concatenate([b, bb, lb]), -1)
             row_open = np.cumsum(cover[:-1]) == 0
         self.n_open = int(row_open.sum())
-        self.rows_in_units = n - self.n_open
+        self.rows_in_units = n - self.n_open - self.rows_in_blocks - self.rows_in_lds_blocks
         self.open_rows, self.sub = None, {}
         if self.n_open:
             open_t = torch.from_numpy(row_open).to(dev)
@@ -2145,15 +2205,16 @@ class AppnpPlan:
             self.nnz_open = 0
 
 
-def appnp_plan(g, h4):
-    """The plan for a signal of h4 float4 columns (a unit holds 768 / h4 rows), cached on the graph per h4."""
+def appnp_plan(g, h4, blocks=True, sliced=True):
+    """The plan for a signal of h4 float4 columns (a unit holds 768 / h4 rows), cached on the graph per (h4, blocks, sliced)."""
     plans = getattr(g, "_appnp_plan", None)
     if plans is None:
         plans = {}
         g._appnp_plan = plans
-    if h4 not in plans:
-        plans[h4] = AppnpPlan(g, h4)
-    return plans[h4]
+    key = (int(h4), bool(blocks), bool(sliced))
+    if key not in plans:
+        plans[key] = AppnpPlan(g, h4, blocks, sliced)
+    return plans[key]
 
 
 class APPNPPropagate(torch.autograd.Function):
@@ -2172,6 +2233,27 @@ class APPNPPropagate(torch.autograd.Function):
         return zp
 
     @staticmethod
+    def _in_lds(plan, side, x, out, h4, K, alpha, backward, cfg, st, tag):
+        """The launches whose K steps run in LDS: the units (the column-sliced kernel, or the whole-signal one under
+        OpConfig(appnp_sliced=False)) and the larger subgraphs that fit LDS a slice at a time."""
+        L = _lib.lib()
+        if plan.n_units and plan.sliced:
+            with _timed(cfg, "appnp_units" + tag):
+                _lib.check(L.fitgnn_appnp_lds_f32(_lib.dptr(side.rowptr), _lib.dptr(side.col), _lib.dptr(side.val), _lib.dptr(plan.units),
+                                                  plan.n_units, plan.max_rows, plan.max_entries, _lib.dptr(x), _lib.dptr(out), h4, K, float(alpha),
+                                                  backward, plan.unit_threads, plan.unit_slice, st), "fitgnn_appnp_lds_f32")
+        elif plan.n_units:
+            with _timed(cfg, "appnp_units" + tag):
+                _lib.check(L.fitgnn_appnp_units_f32(_lib.dptr(side.rowptr), _lib.dptr(side.col), _lib.dptr(side.val), _lib.dptr(plan.units),
+                                                    plan.n_units, plan.max_rows, plan.max_entries, _lib.dptr(x), _lib.dptr(out), h4, K, float(alpha),
+                                                    backward, st), "fitgnn_appnp_units_f32")
+        if plan.n_lds_blocks:
+            with _timed(cfg, "appnp_lds_blocks" + tag):
+                _lib.check(L.fitgnn_appnp_lds_f32(_lib.dptr(side.rowptr), _lib.dptr(side.col), _lib.dptr(side.val), _lib.dptr(plan.lds_blocks),
+                                                  plan.n_lds_blocks, plan.lds_max_rows, plan.lds_max_entries, _lib.dptr(x), _lib.dptr(out), h4, K,
+                                                  float(alpha), backward, 1024, plan.lds_slice, st), "fitgnn_appnp_lds_f32")
+
+    @staticmethod
     def forward(ctx, z0, g, K, alpha, cfg=None):
         L = _lib.lib()
         z0 = _f32c(z0)
@@ -2180,18 +2262,23 @@ class APPNPPropagate(torch.autograd.Function):
         st = _lib.stream_ptr(z0.device)
         f = g.f
         z0p = APPNPPropagate._padded(z0, h4)
-        plan = appnp_plan(g, h4) if (cfg is None or cfg.appnp_in_lds) and K > 0 and h4 <= 16 else None
-        if plan is not None and plan.n_units == 0:
+        plan = (appnp_plan(g, h4, cfg is None or cfg.appnp_blocks, cfg is None or cfg.appnp_sliced)
+                if (cfg is None or cfg.appnp_in_lds) and K > 0 and h4 <= 16 else None)
+        if plan is not None and plan.n_units == 0 and plan.n_blocks == 0 and plan.n_lds_blocks == 0:
             plan = None
         ctx.g, ctx.K, ctx.alpha, ctx.cfg, ctx.H, ctx.plan = g, K, alpha, cfg, H, plan
         if plan is not None:
-            # the subgraphs that fit a wavefront's LDS: all K steps in one launch; the rows of the larger ones: the per-step kernel on
-            # their own sub-matrix (gathered in, scattered out)
+            # the subgraphs that fit a wavefront's LDS: all K steps in one launch; the larger ones: one workgroup each, all K steps in
+            # one launch between two scratch signals; rows of what is left: the per-step kernel on their own sub-matrix (gathered in,
+            # scattered out)
             out = torch.empty_like(z0p)
-            with _timed(cfg, "appnp_units"):
-                _lib.check(L.fitgnn_appnp_units_f32(_lib.dptr(f.rowptr), _lib.dptr(f.col), _lib.dptr(f.val), _lib.dptr(plan.units), plan.n_units,
-                                                    plan.max_rows, plan.max_entries, _lib.dptr(z0p), _lib.dptr(out), h4, K, float(alpha), 0, st),
-                           "fitgnn_appnp_units_f32")
+            APPNPPropagate._in_lds(plan, f, z0p, out, h4, K, alpha, 0, cfg, st, "")
+            if plan.n_blocks:
+                t1, t2 = torch.empty_like(z0p), torch.empty_like(z0p)
+                with _timed(cfg, "appnp_blocks"):
+                    _lib.check(L.fitgnn_appnp_blocks_f32(_lib.dptr(f.rowptr), _lib.dptr(f.col), _lib.dptr(f.val), _lib.dptr(plan.blocks),
+                                                         plan.n_blocks, plan.block_max_rows, plan.block_max_entries, _lib.dptr(z0p), _lib.dptr(out),
+                                                         _lib.dptr(t1), _lib.dptr(t2), h4, K, float(alpha), 0, st), "fitgnn_appnp_blocks_f32")
             if plan.n_open:
                 rp, cc, vv = plan.sub["f"]
                 zb0 = z0p.index_select(0, plan.open_rows)
@@ -2226,10 +2313,14 @@ class APPNPPropagate(torch.autograd.Function):
         plan = ctx.plan
         if plan is not None:
             out = torch.empty_like(dz)
-            with _timed(ctx.cfg, "appnp_units_t"):
-                _lib.check(L.fitgnn_appnp_units_f32(_lib.dptr(t.rowptr), _lib.dptr(t.col), _lib.dptr(t.val), _lib.dptr(plan.units), plan.n_units,
-                                                    plan.max_rows, plan.max_entries, _lib.dptr(dz), _lib.dptr(out), h4, ctx.K, float(ctx.alpha), 1, st),
-                           "fitgnn_appnp_units_f32")
+            APPNPPropagate._in_lds(plan, t, dz, out, h4, ctx.K, ctx.alpha, 1, ctx.cfg, st, "_t")
+            if plan.n_blocks:
+                t1, t2 = torch.empty_like(dz), torch.empty_like(dz)
+                with _timed(ctx.cfg, "appnp_blocks_t"):
+                    _lib.check(L.fitgnn_appnp_blocks_f32(_lib.dptr(t.rowptr), _lib.dptr(t.col), _lib.dptr(t.val), _lib.dptr(plan.blocks),
+                                                         plan.n_blocks, plan.block_max_rows, plan.block_max_entries, _lib.dptr(dz), _lib.dptr(out),
+                                                         _lib.dptr(t1), _lib.dptr(t2), h4, ctx.K, float(ctx.alpha), 1, st),
+                               "fitgnn_appnp_blocks_f32")
             if plan.n_open:
                 rp, cc, vv = plan.sub["t"]
                 gb = dz.index_select(0, plan.open_rows)

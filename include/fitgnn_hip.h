@@ -541,6 +541,35 @@ int fitgnn_appnp_unit_entries(void);
 int fitgnn_appnp_units_f32(const int32_t *rowptr, const int32_t *col, const float *val, const int32_t *units, int32_t n_units, int32_t max_rows,
                            int32_t max_entries, const float *X, float *Y, int32_t h4, int32_t K, float alpha, int32_t backward, void *stream);
 
+/* The subgraphs beyond a unit: `blocks` [n_blocks][2] = closed diagonal blocks (row ranges) of at most fitgnn_appnp_block_rows() rows and
+ * fitgnn_appnp_block_entries() CSR entries (max_rows / max_entries: the largest of THIS list, which sizes the launch's LDS).  One
+ * workgroup per block runs all K >= 1 steps: the block's CSR slice staged in LDS, the steps ping-pong between the scratch signals T1 / T2
+ * (same shape as X; only the blocks' rows are touched; they stay in L2), separated by workgroup barriers.  Forward: Y = z_K,
+ * z_{k+1} = (1 - alpha) A z_k + alpha X.  backward != 0 (hand in the transposed pattern): Y = g_K + alpha * sum_{k<K} g_k,
+ * g_{k+1} = (1 - alpha) A^T g_k, g_0 = X.  Row arithmetic = fitgnn_spmm_narrow_padded_f32's, bit for bit.  X, Y, T1, T2 distinct,
+ * 16-byte aligned, rows of 4 * h4 floats.  Replaces K calls of APPNP.propagate per direction (Baselines/SGGC/APPNP/networks.py:30-38,
+ * torch_geometric.nn.APPNP) on those rows. */
+int fitgnn_appnp_block_rows(void);
+int fitgnn_appnp_block_entries(void);
+int fitgnn_appnp_blocks_f32(const int32_t *rowptr, const int32_t *col, const float *val, const int32_t *blocks, int32_t n_blocks, int32_t max_rows,
+                            int32_t max_entries, const float *X, float *Y, float *T1, float *T2, int32_t h4, int32_t K, float alpha,
+                            int32_t backward, void *stream);
+
+/* The K steps in LDS by COLUMN SLICES, for closed row ranges (`ranges` [n_ranges][2]) of any size that fits: a workgroup of `threads`
+ * (64 .. 1024) stages its range's CSR slice once (columns re-based, 16 bit), then for one slice of <= `slice` (1, 2 or 4) float4 columns
+ * after the other loads the slice of its rows, steps it K times between two LDS buffers and stores it (the recurrence never mixes
+ * columns).  A thread owns <= fitgnn_appnp_lds_items_per_thread() (row, slice column) items: max_rows * slice <= that * threads; a row of
+ * more than 16 entries is summed by a whole wavefront.  LDS: fitgnn_appnp_lds_bytes(max_rows, max_entries, slice) <=
+ * fitgnn_appnp_lds_max_bytes(); max_rows / max_entries = the largest range of THIS list (a larger one is skipped by its workgroup).
+ * Semantics of X, Y, K, alpha, backward as fitgnn_appnp_units_f32 (same reference lines).  Sums of a short row in CSR order; a long
+ * row's in a fixed tree: results do not depend on the launch. */
+int64_t fitgnn_appnp_lds_bytes(int32_t max_rows, int32_t max_entries, int32_t slice);
+int fitgnn_appnp_lds_max_bytes(void);
+int fitgnn_appnp_lds_items_per_thread(void);
+int fitgnn_appnp_lds_f32(const int32_t *rowptr, const int32_t *col, const float *val, const int32_t *ranges, int32_t n_ranges, int32_t max_rows,
+                         int32_t max_entries, const float *X, float *Y, int32_t h4, int32_t K, float alpha, int32_t backward, int32_t threads,
+                         int32_t slice, void *stream);
+
 /* =====================================================================================
  * Coarsen half: one contraction level of variation_neighborhoods
  * replaces: graph_coarsening/coarsening_utils.py contract_variation_linear :530-650,

@@ -185,6 +185,18 @@ def test_round4_graph_step_entry_points_check_their_arguments_without_a_gpu():
     assert L.fitgnn_appnp_units_f32(None, None, None, None, 0, 0, 0, None, None, 12, 10, 0.1, 0, None) == 0           # nothing to do
     assert L.fitgnn_appnp_units_f32(None, None, None, None, 5, 64, 100, None, None, 12, 10, 0.1, 0, None) == -1       # NULL arrays
     assert L.fitgnn_appnp_units_f32(None, None, None, None, 5, 65, 100, None, None, 12, 10, 0.1, 0, None) == -1       # a unit beyond the capacity
+    assert L.fitgnn_appnp_lds_items_per_thread() == 4 and L.fitgnn_appnp_lds_max_bytes() == 160 * 1024
+    assert 0 < L.fitgnn_appnp_lds_bytes(64, 300, 4) < 16 * 1024 and L.fitgnn_appnp_lds_bytes(2000, 7000, 1) < 160 * 1024 < L.fitgnn_appnp_lds_bytes(2000, 7000, 2)
+    assert L.fitgnn_appnp_lds_bytes(64, 300, 3) == -1 and L.fitgnn_appnp_lds_bytes(70000, 300, 1) == -1
+    assert L.fitgnn_appnp_lds_f32(None, None, None, None, 0, 0, 0, None, None, 12, 10, 0.1, 0, 64, 4, None) == 0            # nothing to do
+    assert L.fitgnn_appnp_lds_f32(None, None, None, None, 5, 64, 100, None, None, 12, 10, 0.1, 0, 64, 4, None) == -1        # NULL arrays
+    assert L.fitgnn_appnp_lds_f32(None, None, None, None, 5, 65, 100, None, None, 12, 10, 0.1, 0, 64, 4, None) == -1        # 65 x 4 items > 4 x 64
+    assert L.fitgnn_appnp_lds_f32(None, None, None, None, 5, 4096, 16000, None, None, 12, 10, 0.1, 0, 1024, 1, None) == -1  # beyond LDS
+    assert L.fitgnn_appnp_block_rows() == 4096 and L.fitgnn_appnp_block_entries() == 16384
+    assert L.fitgnn_appnp_blocks_f32(None, None, None, None, 0, 0, 0, None, None, None, None, 12, 10, 0.1, 0, None) == 0   # nothing to do
+    assert L.fitgnn_appnp_blocks_f32(None, None, None, None, 5, 64, 100, None, None, None, None, 12, 10, 0.1, 0, None) == -1   # NULL arrays
+    assert L.fitgnn_appnp_blocks_f32(None, None, None, None, 5, 4097, 100, None, None, None, None, 12, 10, 0.1, 0, None) == -1   # beyond the capacity
+    assert L.fitgnn_appnp_blocks_f32(None, None, None, None, 5, 64, 100, None, None, None, None, 12, 0, 0.1, 0, None) == -1   # K >= 1
     n13 = [None] * 13
     n9 = [None] * 9
     assert L.fitgnn_batch_gather(128, *n13, 11, None, 1, 11, 64, 64, 64, 64, *n9, 11, None, None, None, None, None, 0, None) == -1   # NULL arrays

@@ -90,6 +90,6 @@ def test_graph_step_kernels_keep_their_accumulators_in_registers(code_objects):
     """Round 4's graph-level step: narrow_atb_kernel<KT> holds 4 x KT + 4 running sums and eight rows' loads per thread, dense_narrow_k_kernel
     four rows' dot products, the batch assembly and the accumulating Adam are pure streams -- none may spill or use scratch."""
     for pat in (r"narrow_atb_kernel", r"dense_narrow_k_kernel", r"pool_head_kernel", r"pool_head_bwd_kernel", r"adam_flat_acc_kernel",
-                r"batch_offsets_kernel", r"batch_gather_kernel", r"appnp_units_kernel"):
+                r"batch_offsets_kernel", r"batch_gather_kernel", r"appnp_units_kernel", r"appnp_blocks_kernel", r"appnp_lds_kernel"):
         for name, m in _kernels(code_objects, pat).items():
             assert m["vgpr_spill"] == 0 and m["scratch"] == 0, (name, m)

@@ -1378,19 +1378,145 @@ def test_appnp_in_lds_equals_the_per_step_propagation(mods, C, sizes):
     L = _lib_mod().lib()
     small = sum(int(sz) for sz, a, b in zip(sizes, bounds[:-1], bounds[1:])
                 if sz <= plan.cap_rows and rp[b] - rp[a] <= L.fitgnn_appnp_unit_entries())
-    assert plan.rows_in_units == small and plan.n_open == n - small
+    # the larger blocks: all of these fit LDS one slice at a time (the column-sliced kernel, sixteen wavefronts each)
+    assert plan.rows_in_units == small and plan.rows_in_lds_blocks == n - small and plan.n_open == 0
+    old = ops.appnp_plan(g, h4, sliced=False)
+    assert old.rows_in_units == small and old.n_open == n - small and old.n_lds_blocks == 0
     assert plan.max_rows <= plan.cap_rows and (plan.n_units == 0 or plan.max_rows >= min(max(sizes), 1))
     z0 = torch.randn(n, C, device="cuda")
     w = torch.randn(n, C, device="cuda")
     res = {}
-    for flag in (True, False):
+    for flag, cfg in (("sliced", ops.DEFAULT), ("whole", ops.DEFAULT.replace(appnp_sliced=False)), (False, ops.DEFAULT.replace(appnp_in_lds=False))):
         zz = z0.clone().requires_grad_(True)
-        out = ops.APPNPPropagate.apply(zz, g, 10, 0.1, ops.DEFAULT.replace(appnp_in_lds=flag))
+        out = ops.APPNPPropagate.apply(zz, g, 10, 0.1, cfg)
         (out * w).sum().backward()
         res[flag] = (out.detach(), zz.grad.detach())
-    assert rel(res[True][0], res[False][0]) < 1e-5
-    assert rel(res[True][1], res[False][1]) < 1e-5
+    for flag in ("sliced", "whole"):
+        assert rel(res[flag][0], res[False][0]) < 1e-5, flag
+        assert rel(res[flag][1], res[False][1]) < 1e-5, flag
     # K = 1 and a different alpha
     a = ops.APPNPPropagate.apply(z0, g, 1, 0.3, ops.DEFAULT)
     b = ops.APPNPPropagate.apply(z0, g, 1, 0.3, ops.DEFAULT.replace(appnp_in_lds=False))
     assert rel(a, b) < 1e-6
+
+
+def _ring_blocks(sizes, rng, hub_every=0):
+    """Block-diagonal symmetric pattern: every block a ring plus chords; hub_every > 0: every hub_every-th node of a block is also tied
+    to the block's first node (a long row, as a star's centre)."""
+    src, dst, off = [], [], 0
+    for sz in sizes:
+        sz = int(sz)
+        ring = np.arange(sz)
+        und = {(min(a, b), max(a, b)) for a, b in zip(ring, np.roll(ring, -1)) if a != b}
+        for _ in range(sz // 2):
+            a, b = rng.integers(0, sz, size=2)
+            if a != b:
+                und.add((min(a, b), max(a, b)))
+        if hub_every:
+            und |= {(0, int(j)) for j in range(hub_every, sz, hub_every)}
+        if und:
+            u = np.array(sorted(und), dtype=np.int64) + off
+            src += [u[:, 0], u[:, 1]]; dst += [u[:, 1], u[:, 0]]
+        off += sz
+    return torch.from_numpy(np.stack([np.concatenate(src), np.concatenate(dst)])).cuda(), off
+
+
+@pytest.mark.parametrize("C,K", [(3, 10), (47, 10), (47, 1), (47, 3), (64, 2)])
+def test_appnp_one_workgroup_per_large_subgraph_equals_the_per_step_propagation(mods, C, K):
+    """fitgnn_appnp_blocks_f32: the subgraphs beyond a unit, one workgroup each, all K steps in one launch between two scratch signals
+    (CSR slice in LDS) == the per-step kernel, BIT FOR BIT on those rows (same row arithmetic), forward and the gradient w.r.t. z_0;
+    odd and even K (which scratch signal the last step reads), long rows (split over the wave's slots), a block beyond the row
+    capacity and small blocks beside them (those stay on the per-step kernel / the units)."""
+    from fitgnn_amd import csr, ops
+
+    L = _lib_mod().lib()
+    h4 = (C + 3) // 4
+    cap = int(L.fitgnn_appnp_unit_rows(h4))
+    rng = np.random.default_rng(100 * C + K)
+    sizes = [int(v) for v in rng.integers(cap + 1, cap + 500, size=ops.AppnpPlan.MIN_BLOCKS + 10)] + [5] * 20 + [int(L.fitgnn_appnp_block_rows()) + 1, 7, cap + 3]
+    ei, n = _ring_blocks(sizes, rng, hub_every=3)
+    g = csr.CSRGraph(ei, n, mode="gcn")
+    plan = ops.appnp_plan(g, h4, sliced=False)
+    big = [sz for sz in sizes if cap < sz <= L.fitgnn_appnp_block_rows()]
+    assert plan.n_blocks == len(big) and plan.rows_in_blocks == sum(big) and plan.block_max_rows == max(big)
+    assert plan.n_open == int(L.fitgnn_appnp_block_rows()) + 1 and plan.rows_in_units == n - plan.n_open - plan.rows_in_blocks
+    assert ops.appnp_plan(g, h4, blocks=False, sliced=False).n_blocks == 0
+    sl = ops.appnp_plan(g, h4)   # the default: these blocks fit LDS a slice at a time, the workgroup-per-block launch has nothing left
+    assert sl.n_lds_blocks == len(big) and sl.n_blocks == 0 and sl.n_open == plan.n_open and sl.lds_slice in (1, 2, 4)
+    in_blocks = torch.zeros(n, dtype=torch.bool, device="cuda")
+    for a, b in plan.blocks.cpu().numpy():
+        in_blocks[a:b] = True
+    z0 = torch.randn(n, C, device="cuda")
+    w = torch.randn(n, C, device="cuda")
+    res = {}
+    whole = ops.DEFAULT.replace(appnp_sliced=False)
+    for name, cfg in (("blocks", whole), ("steps", ops.DEFAULT.replace(appnp_in_lds=False)), ("no_blocks", whole.replace(appnp_blocks=False)),
+                      ("sliced", ops.DEFAULT)):
+        zz = z0.clone().requires_grad_(True)
+        out = ops.APPNPPropagate.apply(zz, g, K, 0.1, cfg)
+        (out * w).sum().backward()
+        res[name] = (out.detach(), zz.grad.detach())
+    for i in (0, 1):
+        assert torch.equal(res["blocks"][i][in_blocks], res["steps"][i][in_blocks]), ("rows in blocks", i)
+        assert torch.equal(res["blocks"][i], res["no_blocks"][i]), ("against the sub-matrix path", i)
+        assert rel(res["blocks"][i], res["steps"][i]) < 1e-5
+        assert rel(res["sliced"][i], res["steps"][i]) < 1e-5
+        assert rel(res["sliced"][i][in_blocks], res["steps"][i][in_blocks]) < 1e-5
+
+
+@pytest.mark.parametrize("C,threads,slice_", [(3, 64, 1), (10, 128, 4), (10, 64, 2), (47, 256, 4), (47, 1024, 1), (47, 512, 2), (50, 192, 4), (64, 1024, 4)])
+def test_appnp_column_sliced_lds_kernel_for_every_launch_shape(mods, C, threads, slice_):
+    """fitgnn_appnp_lds_f32 called directly: every block its own range, workgroups of 1 .. 16 wavefronts, slices of 1 / 2 / 4 float4 columns
+    (h4 = 3 at slice 4 = passes of 2 + 1 columns, h4 = 13 = 4 + 4 + 4 + 1), rows longer than 16 entries (a wavefront's: 1, 2 and many
+    rounds of 64 / w entries) next to short ones, K odd and even == the per-step kernel, forward and the adjoint; and the argument checks."""
+    from fitgnn_amd import csr, ops
+
+    L = _lib_mod().lib()
+    h4 = (C + 3) // 4
+    cap = 4 * threads // slice_
+    while L.fitgnn_appnp_lds_bytes(cap, 5 * cap, slice_) > L.fitgnn_appnp_lds_max_bytes():   # (about four entries per row below)
+        cap = cap * 3 // 4
+    rng = np.random.default_rng(C + threads + slice_)
+    sizes = [int(v) for v in rng.integers(1, cap + 1, size=40)] + [cap, 1, 2, cap]
+    ei, n = _ring_blocks(sizes, rng, hub_every=2)
+    g = csr.CSRGraph(ei, n, mode="gcn")
+    bounds = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    ranges = torch.from_numpy(np.stack([bounds[:-1], bounds[1:]], 1).copy()).cuda()
+    rp = g.f.rowptr.cpu().numpy()
+    max_e = int((rp[bounds[1:]] - rp[bounds[:-1]]).max())
+    assert L.fitgnn_appnp_lds_bytes(cap, max_e, slice_) <= L.fitgnn_appnp_lds_max_bytes()
+    z0 = torch.randn(n, C, device="cuda")
+    w = torch.randn(n, C, device="cuda")
+    pad = lambda t: ops.APPNPPropagate._padded(t.contiguous(), h4)   # noqa: E731
+    st = _lib_mod().stream_ptr(z0.device)
+    dp = _lib_mod().dptr
+    for K in (1, 4, 7):
+        zz = z0.clone().requires_grad_(True)
+        ref = ops.APPNPPropagate.apply(zz, g, K, 0.15, ops.DEFAULT.replace(appnp_in_lds=False))
+        (ref * w).sum().backward()
+        for side, x, want, bwd in ((g.f, pad(z0), ref.detach(), 0), (g.t, pad(w), zz.grad, 1)):
+            y = torch.full_like(x, float("nan"))
+            rc = L.fitgnn_appnp_lds_f32(dp(side.rowptr), dp(side.col), dp(side.val), dp(ranges), len(sizes), cap, max_e, dp(x), dp(y), h4, K, 0.15,
+                                        bwd, threads, slice_, st)
+            assert rc == 0
+            assert rel(y[:, :C], want) < 1e-5, (K, bwd)
+            assert not torch.isnan(y).any() and (C == 4 * h4 or float(y[:, C:].abs().max()) == 0.0)
+    x = pad(z0)
+    y = torch.empty_like(x)
+    args = lambda **kw: [dp(g.f.rowptr), dp(g.f.col), dp(g.f.val), dp(ranges), len(sizes), kw.get("rows", cap), max_e, dp(x), dp(y), h4, 3, 0.1, 0,  # noqa: E731
+                         kw.get("threads", threads), kw.get("slice_", slice_), st]
+    assert L.fitgnn_appnp_lds_f32(*args(rows=4 * threads // slice_ + 1)) == -1          # more items than four per thread
+    assert L.fitgnn_appnp_lds_f32(*args(threads=threads + 1)) == -1   # whole wavefronts
+    assert L.fitgnn_appnp_lds_f32(*args(slice_=3)) == -1
+
+
+def test_appnp_few_large_subgraphs_stay_on_the_per_step_kernel(mods):
+    """Fewer blocks than AppnpPlan.MIN_BLOCKS: no workgroup-per-block launch (it would leave most of the chip idle)."""
+    from fitgnn_amd import csr, ops
+
+    rng = np.random.default_rng(3)
+    ei, n = _ring_blocks([300, 400, 5, 5], rng)
+    g = csr.CSRGraph(ei, n, mode="gcn")
+    plan = ops.appnp_plan(g, 12, sliced=False)
+    assert plan.n_blocks == 0 and plan.blocks is None and plan.n_open == 700
+    assert ops.appnp_plan(g, 12).n_open == 0   # (LDS holds them a slice at a time: no threshold there)
