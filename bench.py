@@ -87,6 +87,9 @@ def parse_args():
     ap.add_argument("--round3-graph-step", action="store_true",
                     help="A/B (S-qm9): the batch step as round 3 had it -- first layer transform-first (its two SpMMs per step), pool / scale / "
                          "library product / bias add for the head, `grad += new` per tensor, loss.backward() from a ones fill")
+    ap.add_argument("--no-appnp-sliced", action="store_true",
+                    help="A/B (--layer APPNP): the whole-signal units kernel (one wavefront per <= 64-row unit, 24 KB of LDS buffers) and no "
+                         "larger subgraph in LDS, instead of the column-sliced kernel (fitgnn_appnp_lds_f32)")
     ap.add_argument("--no-appnp-blocks", action="store_true",
                     help="A/B (--layer APPNP): the subgraphs beyond a wavefront's LDS on the per-step kernel (20 launches per step) instead of "
                          "one workgroup each for all K steps (fitgnn_appnp_blocks_f32)")
@@ -396,7 +399,8 @@ def main():
         cfg = ops.OpConfig(gemm_precision=precision, fold_backward=args.fold, dedup_gather=not args.no_dedup_gather,
                            last_layer_on_loss_rows=loss_rows_only, compact_head_backward=loss_rows_only,
                            stream_kernel=args.stream_kernel, compact_rows_kernel=not args.no_compact_rows,
-                           two_hop_backward=not args.no_two_hop, appnp_blocks=not args.no_appnp_blocks)
+                           two_hop_backward=not args.no_two_hop, appnp_blocks=not args.no_appnp_blocks,
+                           appnp_sliced=not args.no_appnp_sliced)
         kw = {}
         if emu is not None:   # one rank of the N-rank job: the job's train count (every node is a train node), the dist path forced
             kw = dict(process_group=torch.distributed.group.WORLD, global_train_count=float(N))
@@ -527,8 +531,11 @@ def main():
             # (the larger ones one workgroup each: read the signal / write the result once -- the scratch signals between the steps are L2
             # traffic by design; backward also reads and writes its accumulator, which the algorithm does not need: not counted)
             r_u, r_o, nnz_o, r_b, nnz_b = plan.rows_in_units, plan.n_open, plan.nnz_open, plan.rows_in_blocks, plan.nnz_blocks
-            kind_bytes.update({"appnp_units": 2 * 4 * Cw * r_u + 8 * (nnz - nnz_o - nnz_b) + 4 * (r_u + 1),
-                               "appnp_units_t": 2 * 4 * Cw * r_u + 8 * (nnz - nnz_o - nnz_b) + 4 * (r_u + 1),
+            r_l, nnz_l = plan.rows_in_lds_blocks, plan.nnz_lds_blocks
+            kind_bytes.update({"appnp_units": 2 * 4 * Cw * r_u + 8 * (nnz - nnz_o - nnz_b - nnz_l) + 4 * (r_u + 1),
+                               "appnp_units_t": 2 * 4 * Cw * r_u + 8 * (nnz - nnz_o - nnz_b - nnz_l) + 4 * (r_u + 1),
+                               "appnp_lds_blocks": 2 * 4 * Cw * r_l + 8 * nnz_l + 4 * (r_l + 1),
+                               "appnp_lds_blocks_t": 2 * 4 * Cw * r_l + 8 * nnz_l + 4 * (r_l + 1),
                                "appnp_blocks": 2 * 4 * Cw * r_b + 8 * nnz_b + 4 * (r_b + 1),
                                "appnp_blocks_t": 2 * 4 * Cw * r_b + 8 * nnz_b + 4 * (r_b + 1),
                                "appnp_step": 3 * 4 * Cw * r_o + 8 * nnz_o + 4 * (r_o + 1), "appnp_step_t": 4 * 4 * Cw * r_o + 8 * nnz_o + 4 * (r_o + 1)})

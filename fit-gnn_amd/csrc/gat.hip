@@ -809,7 +809,7 @@ template <bool BWD>
 __global__ __launch_bounds__(1024) void appnp_lds_kernel(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
                                                          const float *__restrict__ val, const int32_t *__restrict__ ranges, int32_t n_ranges,
                                                          const float4 *__restrict__ X, float4 *__restrict__ Y, int32_t h4, int32_t K, float alpha,
-                                                         int32_t max_rows, int32_t max_entries, int32_t slice) {
+                                                         int32_t max_rows, int32_t max_entries, int32_t slice, int32_t dbg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char al_lds[];
     const LdsPlan P = appnp_lds_plan(max_rows, max_entries, slice);
     float4 *buf0 = reinterpret_cast<float4 *>(al_lds);
@@ -862,78 +862,135 @@ __global__ __launch_bounds__(1024) void appnp_lds_kernel(const int32_t *__restri
         for (int i = tid; i < (n_long << lw); i += T)   // the long rows' z_0 / alpha-sum
             s_keep[i] = BWD ? make_float4(0.f, 0.f, 0.f, 0.f) : buf0[((int)s_long[i >> lw] << lw) + (i & (w - 1))];
         __syncthreads();
-        const int q_l = lane & (w - 1), slot = lane >> lw, S = 64 >> lw;
+        // a thread's items keep their rows across the K steps, and the CSR does not change: row bounds and the first four entries'
+        // operand positions -- all there is for 98 % of the rows of a coarsened batch -- are read ONCE per slice, so a step is one LDS
+        // round trip for such an item (its four operand reads and their values), two of the thread's items in flight together
+        // (packed: entry offset << 5 | count; operand item indices (< 4 096) two per register -- 1 024 threads leave 128 registers each)
+        uint32_t it_en[kLdsKeep], it_c[kLdsKeep][2];
+#pragma unroll
+        for (int j = 0; j < kLdsKeep; ++j) {
+            const int i = tid + j * T;
+            int e = 0, cnt = 0;   // cnt 0 = not this thread's (beyond the range, or a wavefront's long row)
+            if (i < total) {
+                const int row = i >> lw;
+                e = s_rp[row];
+                const int len = s_rp[row + 1] - e;
+                cnt = len <= kLdsShort ? len : 0;
+            }
+            it_en[j] = ((uint32_t)e << 5) | (uint32_t)cnt;
+            uint32_t c4[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) c4[t] = s_col[e + (t < cnt ? t : 0)];   // (unconditional reads, all in flight: entry 0 exists)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) c4[t] = t < cnt ? (uint32_t)(((int)c4[t] << lw) + (i & (w - 1))) : 0u;
+            it_c[j][0] = c4[0] | (c4[1] << 16);
+            it_c[j][1] = c4[2] | (c4[3] << 16);
+        }
         for (int k = 0; k < K; ++k) {
             const float4 *cur = (k & 1) ? buf1 : buf0;
             float4 *nxt = (k & 1) ? buf0 : buf1;
+            if (!(dbg & 2))
 #pragma unroll
-            for (int j = 0; j < kLdsKeep; ++j) {
-                const int i = tid + j * T;
-                if (i < total) {
-                    const int row = i >> lw, q = i & (w - 1);
-                    const int e1 = s_rp[row + 1];
-                    int e = s_rp[row];
-                    if (e1 - e <= kLdsShort) {   // (a longer row is a wavefront's)
-                        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-                        for (; e < e1; e += 4) {   // four entries' (column, value) reads, then their operand reads, issued together; sums in CSR order
-                            int c[4];
-                            float v[4];
+            for (int jh = 0; jh < kLdsKeep; jh += 2) {   // two items' eight operand reads in flight (all four items': spills at 1 024 threads)
+            if (BWD) {   // the running alpha-sum first (its operand is not live beside the eight gathers below)
 #pragma unroll
-                            for (int t = 0; t < 4; ++t) {
-                                const int et = min(e + t, e1 - 1);
-                                c[t] = s_col[et];
-                                v[t] = e + t < e1 ? s_val[et] : 0.f;
-                            }
-                            float4 x[4];
+                for (int j = jh; j < jh + 2; ++j)
+                    if ((it_en[j] & 31u) > 0) {
+                        const float4 xs = cur[tid + j * T];
+                        keep[j].x = fmaf(alpha, xs.x, keep[j].x); keep[j].y = fmaf(alpha, xs.y, keep[j].y);
+                        keep[j].z = fmaf(alpha, xs.z, keep[j].z); keep[j].w = fmaf(alpha, xs.w, keep[j].w);
+                    }
+            }
+            float4 x[kLdsKeep][4];
+            float it_v[kLdsKeep][4];   // (the values ride the same round trip as the operands: keeping them too spills)
 #pragma unroll
-                            for (int t = 0; t < 4; ++t) x[t] = cur[(c[t] << lw) + q];
+            for (int j = jh; j < jh + 2; ++j)
 #pragma unroll
-                            for (int t = 0; t < 4; ++t) {
-                                acc.x = fmaf(v[t], x[t].x, acc.x); acc.y = fmaf(v[t], x[t].y, acc.y);
-                                acc.z = fmaf(v[t], x[t].z, acc.z); acc.w = fmaf(v[t], x[t].w, acc.w);
-                            }
+                for (int t = 0; t < 4; ++t) {
+                    x[j][t] = cur[(it_c[j][t >> 1] >> (16 * (t & 1))) & 0xffffu];   // (an absent entry reads slot 0 at weight 0)
+                    it_v[j][t] = t < (int)(it_en[j] & 31u) ? s_val[(it_en[j] >> 5) + t] : 0.f;
+                }
+#pragma unroll
+            for (int j = jh; j < jh + 2; ++j) {
+                if ((it_en[j] & 31u) > 0) {
+                    const int i = tid + j * T;
+                    const int q = i & (w - 1);
+                    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        acc.x = fmaf(it_v[j][t], x[j][t].x, acc.x); acc.y = fmaf(it_v[j][t], x[j][t].y, acc.y);
+                        acc.z = fmaf(it_v[j][t], x[j][t].z, acc.z); acc.w = fmaf(it_v[j][t], x[j][t].w, acc.w);
+                    }
+                    const int e1 = (int)(it_en[j] >> 5) + (int)(it_en[j] & 31u);
+                    for (int e = (int)(it_en[j] >> 5) + 4; e < e1; e += 2) {   // entries 5 .. 16 (2 % of the rows), two at a time; sums in CSR order
+                        const int eb = min(e + 1, e1 - 1);
+                        const int ca = s_col[e], cb = s_col[eb];
+                        const float va = s_val[e], vb = e + 1 < e1 ? s_val[eb] : 0.f;
+                        const float4 xa = cur[(ca << lw) + q], xb = cur[(cb << lw) + q];
+                        acc.x = fmaf(va, xa.x, acc.x); acc.y = fmaf(va, xa.y, acc.y); acc.z = fmaf(va, xa.z, acc.z); acc.w = fmaf(va, xa.w, acc.w);
+                        acc.x = fmaf(vb, xb.x, acc.x); acc.y = fmaf(vb, xb.y, acc.y); acc.z = fmaf(vb, xb.z, acc.z); acc.w = fmaf(vb, xb.w, acc.w);
+                    }
+                    float4 y = make_float4(beta * acc.x, beta * acc.y, beta * acc.z, beta * acc.w);
+                    if (!BWD) {
+                        y.x = fmaf(alpha, keep[j].x, y.x); y.y = fmaf(alpha, keep[j].y, y.y);
+                        y.z = fmaf(alpha, keep[j].z, y.z); y.w = fmaf(alpha, keep[j].w, y.w);
+                    }
+                    nxt[i] = y;
+                }
+            }
+            }
+            if (!(dbg & 1)) {
+                // the long rows, 8 / w at a time per wavefront: lane = (group, entry slot 0..7, slice column); a lane sums entries
+                // e0 + slot, e0 + slot + 8, ... in order (four in flight), the eight slots fold by xor shuffles in a fixed tree
+                const int q_l = lane & (w - 1), slot = (lane >> lw) & 7, grp = lane >> (lw + 3);
+                const int rpw = 8 >> lw;
+                for (int jb = 0; jb < n_long; jb += W * rpw) {
+                    const int j = jb + wave * rpw + grp;
+                    const bool on = j < n_long;
+                    int row = 0, e = 0, e1 = 0;
+                    if (on) {
+                        row = s_long[j];
+                        e = s_rp[row] + slot;
+                        e1 = s_rp[row + 1];
+                    }
+                    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+                    for (; e < e1; e += 32) {
+                        int c[4];
+                        float v[4];
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            const bool has = e + 8 * t < e1;
+                            c[t] = s_col[has ? e + 8 * t : e];
+                            v[t] = has ? s_val[e + 8 * t] : 0.f;
                         }
+                        float4 x[4];
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) x[t] = cur[(c[t] << lw) + q_l];
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            acc.x = fmaf(v[t], x[t].x, acc.x); acc.y = fmaf(v[t], x[t].y, acc.y);
+                            acc.z = fmaf(v[t], x[t].z, acc.z); acc.w = fmaf(v[t], x[t].w, acc.w);
+                        }
+                    }
+#pragma unroll
+                    for (int st = 4; st >= 1; st >>= 1) {
+                        const int off = st << lw;
+                        acc.x += __shfl_xor(acc.x, off, 64); acc.y += __shfl_xor(acc.y, off, 64);
+                        acc.z += __shfl_xor(acc.z, off, 64); acc.w += __shfl_xor(acc.w, off, 64);
+                    }
+                    if (on && slot == 0) {
+                        const int i = (row << lw) + q_l;
                         float4 y = make_float4(beta * acc.x, beta * acc.y, beta * acc.z, beta * acc.w);
+                        float4 kp = s_keep[(j << lw) + q_l];
                         if (BWD) {
                             const float4 x = cur[i];
-                            keep[j].x = fmaf(alpha, x.x, keep[j].x); keep[j].y = fmaf(alpha, x.y, keep[j].y);
-                            keep[j].z = fmaf(alpha, x.z, keep[j].z); keep[j].w = fmaf(alpha, x.w, keep[j].w);
+                            kp.x = fmaf(alpha, x.x, kp.x); kp.y = fmaf(alpha, x.y, kp.y); kp.z = fmaf(alpha, x.z, kp.z); kp.w = fmaf(alpha, x.w, kp.w);
+                            s_keep[(j << lw) + q_l] = kp;
                         } else {
-                            y.x = fmaf(alpha, keep[j].x, y.x); y.y = fmaf(alpha, keep[j].y, y.y);
-                            y.z = fmaf(alpha, keep[j].z, y.z); y.w = fmaf(alpha, keep[j].w, y.w);
+                            y.x = fmaf(alpha, kp.x, y.x); y.y = fmaf(alpha, kp.y, y.y); y.z = fmaf(alpha, kp.z, y.z); y.w = fmaf(alpha, kp.w, y.w);
                         }
                         nxt[i] = y;
                     }
-                }
-            }
-            for (int j = wave; j < n_long; j += W) {   // a long row: entries e0 + slot, e0 + slot + S, ... per lane, two rounds in flight
-                const int row = s_long[j];
-                const int e1 = s_rp[row + 1];
-                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-                for (int e = s_rp[row] + slot; e < e1; e += 2 * S) {
-                    const bool two = e + S < e1;
-                    const int ca = s_col[e], cb = s_col[two ? e + S : e];
-                    const float va = s_val[e], vb = two ? s_val[e + S] : 0.f;
-                    const float4 xa = cur[(ca << lw) + q_l], xb = cur[(cb << lw) + q_l];
-                    acc.x = fmaf(va, xa.x, acc.x); acc.y = fmaf(va, xa.y, acc.y); acc.z = fmaf(va, xa.z, acc.z); acc.w = fmaf(va, xa.w, acc.w);
-                    acc.x = fmaf(vb, xb.x, acc.x); acc.y = fmaf(vb, xb.y, acc.y); acc.z = fmaf(vb, xb.z, acc.z); acc.w = fmaf(vb, xb.w, acc.w);
-                }
-                for (int off = 32; off >= w; off >>= 1) {   // fold the slots: a fixed tree
-                    acc.x += __shfl_xor(acc.x, off, 64); acc.y += __shfl_xor(acc.y, off, 64);
-                    acc.z += __shfl_xor(acc.z, off, 64); acc.w += __shfl_xor(acc.w, off, 64);
-                }
-                if (slot == 0) {
-                    const int i = (row << lw) + q_l;
-                    float4 y = make_float4(beta * acc.x, beta * acc.y, beta * acc.z, beta * acc.w);
-                    float4 kp = s_keep[(j << lw) + q_l];
-                    if (BWD) {
-                        const float4 x = cur[i];
-                        kp.x = fmaf(alpha, x.x, kp.x); kp.y = fmaf(alpha, x.y, kp.y); kp.z = fmaf(alpha, x.z, kp.z); kp.w = fmaf(alpha, x.w, kp.w);
-                        s_keep[(j << lw) + q_l] = kp;
-                    } else {
-                        y.x = fmaf(alpha, kp.x, y.x); y.y = fmaf(alpha, kp.y, y.y); y.z = fmaf(alpha, kp.z, y.z); y.w = fmaf(alpha, kp.w, y.w);
-                    }
-                    nxt[i] = y;
                 }
             }
             __syncthreads();
@@ -951,7 +1008,8 @@ __global__ __launch_bounds__(1024) void appnp_lds_kernel(const int32_t *__restri
         }
 #pragma unroll
         for (int j = 0; j < kLdsKeep; ++j) {
-            const int i = tid + j * T;
+            int i = tid + j * T;
+            asm volatile("" : "+v"(i));   // re-derive the store addresses here: held across the K steps they cost eight registers (spills)
             if (i < total) {
                 float4 y = fin[i];
                 if (BWD) { y.x += keep[j].x; y.y += keep[j].y; y.z += keep[j].z; y.w += keep[j].w; }   // (a long row's keep[j] stayed 0)
@@ -982,16 +1040,18 @@ extern "C" int fitgnn_appnp_lds_f32(const int32_t *rowptr, const int32_t *col, c
     if (!rowptr || !col || !val || !ranges || !X || !Y) return FITGNN_E_BADARG;
     if ((((uintptr_t)X | (uintptr_t)Y) % 16) != 0) return FITGNN_E_ALIGN;
     const void *fn = backward ? (const void *)appnp_lds_kernel<true> : (const void *)appnp_lds_kernel<false>;
+    const char *dv = getenv("FITGNN_APPNP_LDS_DEBUG");
+    const int dbg = dv ? atoi(dv) : 0;
     if (P.bytes > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P.bytes);
         if (e != hipSuccess) return (int)e;
     }
     if (backward)
         hipLaunchKernelGGL(appnp_lds_kernel<true>, dim3((unsigned)n_ranges), dim3(threads), P.bytes, (hipStream_t)stream, rowptr, col, val, ranges,
-                           n_ranges, (const float4 *)X, (float4 *)Y, h4, K, alpha, max_rows, max_entries, slice);
+                           n_ranges, (const float4 *)X, (float4 *)Y, h4, K, alpha, max_rows, max_entries, slice, dbg);
     else
         hipLaunchKernelGGL(appnp_lds_kernel<false>, dim3((unsigned)n_ranges), dim3(threads), P.bytes, (hipStream_t)stream, rowptr, col, val, ranges,
-                           n_ranges, (const float4 *)X, (float4 *)Y, h4, K, alpha, max_rows, max_entries, slice);
+                           n_ranges, (const float4 *)X, (float4 *)Y, h4, K, alpha, max_rows, max_entries, slice, dbg);
     return (int)hipGetLastError();
 }
 

@@ -2089,8 +2089,8 @@ class FusedGATLastLayerRows(torch.autograd.Function):
 class AppnpPlan:
     """Which rows of a block-diagonal batch APPNP propagates inside LDS, and the sub-matrix of the others (built once per graph).
 
-    lds_blocks [n_lds_blocks, 2] int32 (sliced=True): the diagonal blocks beyond a unit whose CSR slice and two one-slice signal buffers
-    fit LDS (fitgnn_appnp_lds_bytes), sixteen wavefronts each, lds_slice float4 columns per pass;
+    lds_launches (sliced=True): the diagonal blocks beyond a unit whose CSR slice and two one-slice signal buffers fit LDS
+    (fitgnn_appnp_lds_bytes), one launch per (slice width, workgroup size): each block at the widest slice it fits at, 4 / 8 / 16 wavefronts;
     blocks [n_blocks, 2] int32: the diagonal blocks beyond that but within fitgnn_appnp_block_rows() / _entries(), one workgroup each
     (when there are at least MIN_BLOCKS of them);
     units [n_units, 2] int32: runs of whole diagonal blocks (ops csr.block_boundaries: the pattern's own closed blocks = cluster
@@ -2150,23 +2150,37 @@ class AppnpPlan:
             self.unit_threads = max(64, -(-self.max_rows * self.unit_slice // (keep * 64)) * 64)
             if self.unit_threads > 1024 or L.fitgnn_appnp_lds_bytes(self.max_rows, self.max_entries, self.unit_slice) > lds_max:
                 self.unit_slice, self.unit_threads = 1, max(64, -(-self.max_rows // (keep * 64)) * 64)
+        # every larger subgraph that fits LDS a slice at a time goes to the launch of the WIDEST slice it fits at (fewer passes over its
+        # K steps, wider global accesses); a launch sizes its LDS by its own largest range
         lds_fit = np.zeros(len(size), dtype=bool)
-        self.lds_slice = 1
+        self.lds_launches = []   # (slice, ranges [m, 2] int32, m, max_rows, max_entries, threads)
         if sliced:
             cand = ~in_unit & (size > 0) & (size <= keep * 1024)
-            bytes1 = np.array([L.fitgnn_appnp_lds_bytes(int(r), int(e), 1) if c else 0 for r, e, c in zip(size, ent, cand)], dtype=np.int64)
-            lds_fit = cand & (bytes1 <= lds_max)
-            if lds_fit.any():
-                mr, me = int(size[lds_fit].max()), int(ent[lds_fit].max())
-                for sl in (4, 2):   # a wider slice (fewer passes) when two workgroups per CU still fit
-                    if sl <= pow2(h4) and mr * sl <= keep * 1024 and L.fitgnn_appnp_lds_bytes(mr, me, sl) <= lds_max // 2:
-                        self.lds_slice = sl
-                        break
+            for sl in (4, 2, 1):
+                if sl > pow2(h4):
+                    continue
+                todo = cand & ~lds_fit & (size * sl <= keep * 1024)
+                need = np.array([L.fitgnn_appnp_lds_bytes(int(r), int(e), sl) if c else 0 for r, e, c in zip(size, ent, todo)], dtype=np.int64)
+                fits = todo & (need <= lds_max)
+                # by workgroup size too (a thread owns <= `keep` items): a 100-row block among 1 000-row ones would idle 900 threads and
+                # take the largest block's LDS
+                lo = 0
+                for threads in (256, 512, 1024):
+                    cls = fits & (size * sl > lo) & (size * sl <= keep * threads)
+                    lo = keep * threads
+                    # the launch is sized by (most rows, most entries) of its list -- two different blocks: drop the costliest until
+                    # that fits (they get the next narrower slice)
+                    for b_i in np.argsort(-np.where(cls, need, 0), kind="stable"):
+                        if not cls.any() or L.fitgnn_appnp_lds_bytes(int(size[cls].max()), int(ent[cls].max()), sl) <= lds_max:
+                            break
+                        cls[b_i] = False
+                    if cls.any():
+                        la, lb = ptr[:-1][cls], ptr[1:][cls]
+                        self.lds_launches.append((sl, torch.from_numpy(np.stack([la, lb], 1).astype(np.int32)).to(dev).contiguous(), int(len(la)),
+                                                  int((lb - la).max()), int(ent[cls].max()), threads))
+                        lds_fit |= cls
         la, lb = ptr[:-1][lds_fit], ptr[1:][lds_fit]
-        self.lds_blocks = torch.from_numpy(np.stack([la, lb], 1).astype(np.int32)).to(dev).contiguous() if len(la) else None
         self.n_lds_blocks = int(len(la))
-        self.lds_max_rows = int((lb - la).max()) if len(la) else 0
-        self.lds_max_entries = int(ent[lds_fit].max()) if len(la) else 0
         self.rows_in_lds_blocks = int((lb - la).sum())
         self.nnz_lds_blocks = int(ent[lds_fit].sum())
         big = ~in_unit & ~lds_fit & (size > 0) & (size <= blk_r) & (ent <= blk_e)
@@ -2247,11 +2261,11 @@ class APPNPPropagate(torch.autograd.Function):
                 _lib.check(L.fitgnn_appnp_units_f32(_lib.dptr(side.rowptr), _lib.dptr(side.col), _lib.dptr(side.val), _lib.dptr(plan.units),
                                                     plan.n_units, plan.max_rows, plan.max_entries, _lib.dptr(x), _lib.dptr(out), h4, K, float(alpha),
                                                     backward, st), "fitgnn_appnp_units_f32")
-        if plan.n_lds_blocks:
+        for sl, ranges, m, max_rows, max_entries, threads in plan.lds_launches:
             with _timed(cfg, "appnp_lds_blocks" + tag):
-                _lib.check(L.fitgnn_appnp_lds_f32(_lib.dptr(side.rowptr), _lib.dptr(side.col), _lib.dptr(side.val), _lib.dptr(plan.lds_blocks),
-                                                  plan.n_lds_blocks, plan.lds_max_rows, plan.lds_max_entries, _lib.dptr(x), _lib.dptr(out), h4, K,
-                                                  float(alpha), backward, 1024, plan.lds_slice, st), "fitgnn_appnp_lds_f32")
+                _lib.check(L.fitgnn_appnp_lds_f32(_lib.dptr(side.rowptr), _lib.dptr(side.col), _lib.dptr(side.val), _lib.dptr(ranges), m, max_rows,
+                                                  max_entries, _lib.dptr(x), _lib.dptr(out), h4, K, float(alpha), backward, threads, sl, st),
+                           "fitgnn_appnp_lds_f32")
 
     @staticmethod
     def forward(ctx, z0, g, K, alpha, cfg=None):
