@@ -478,6 +478,37 @@ extern "C" int fitgnn_spmm_narrow_padded_f32(const int32_t *rowptr, const int32_
     return (int)hipGetLastError();
 }
 
+// The padded layout the propagation runs in, made in ONE pass from the model's class-wide output: dst[r] = src[index ? index[r] : r]
+// (H floats, row stride lds) followed by zeros up to 4 h4 floats.  Replaces index_select (the de-duplicated table's rows -> union
+// rows) + zero fill + strided copy: three passes over the [R x 47] signal, 1.9 ms of a 20-ms step at S-products.
+__global__ __launch_bounds__(256) void gather_rows_padded_kernel(const float *__restrict__ src, int64_t lds, int32_t H,
+                                                                 const int32_t *__restrict__ index, int64_t n, float4 *__restrict__ dst,
+                                                                 int32_t h4) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n * h4) return;
+    const int64_t r = t / h4;
+    const int c = 4 * (int)(t - r * h4);
+    const float *row = src + (index ? (int64_t)index[r] : r) * lds + c;
+    float4 v;
+    v.x = c < H ? row[0] : 0.f;
+    v.y = c + 1 < H ? row[1] : 0.f;
+    v.z = c + 2 < H ? row[2] : 0.f;
+    v.w = c + 3 < H ? row[3] : 0.f;
+    dst[t] = v;
+}
+
+extern "C" int fitgnn_gather_rows_padded_f32(const float *src, int64_t lds, int32_t H, const int32_t *index, int64_t n_rows, float *dst,
+                                             int32_t h4, void *stream) {
+    if (n_rows < 0 || H < 1 || h4 < 1 || 4 * h4 < H || lds < H) return FITGNN_E_BADARG;
+    if (n_rows == 0) return 0;
+    if (!src || !dst) return FITGNN_E_BADARG;
+    if (((uintptr_t)dst % 16) != 0) return FITGNN_E_ALIGN;
+    const int64_t total = n_rows * h4;
+    hipLaunchKernelGGL(gather_rows_padded_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, lds, H, index,
+                       n_rows, (float4 *)dst, h4);
+    return (int)hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------------------------------------------------------------
 // APPNP's K propagation steps with the signal resident in LDS (fitgnn_appnp_units_f32).
 //
@@ -791,6 +822,8 @@ extern "C" int fitgnn_appnp_blocks_f32(const int32_t *rowptr, const int32_t *col
 // tree -- so a step costs a centre a few LDS round trips instead of a chain as long as its row.  Long rows are listed at staging
 // (LDS counter: the list's order varies, no result depends on it); their z_0 / alpha-sum lives in LDS beside the buffers.
 constexpr int kLdsKeep = 4;     // items per thread: rows of a range x w <= kLdsKeep x threads
+constexpr int kLdsFly = 2;      // items of a thread whose operand reads are in flight together (2: the step's results, held in
+                                // registers until the barrier, spill at 1 024 threads x 128 registers)
 constexpr int kLdsShort = 16;   // rows of more entries than this are summed by a wavefront
 constexpr int kLdsMaxBytes = 160 * 1024;
 
@@ -800,7 +833,7 @@ __host__ __device__ inline LdsPlan appnp_lds_plan(int max_rows, int max_entries,
     p.cap_rows = (max_rows + 3) / 4 * 4;
     p.cap_entries = (max_entries + 7) / 8 * 8 + 8;
     p.cap_long = (max_entries / (kLdsShort + 1) + 8) / 8 * 8;
-    p.bytes = (size_t)2 * p.cap_rows * slice * 16 + (size_t)p.cap_long * slice * 16 + (size_t)p.cap_entries * 4 + (size_t)(p.cap_rows + 4) * 4 +
+    p.bytes = (size_t)p.cap_rows * slice * 16 + (size_t)2 * p.cap_long * slice * 16 + (size_t)p.cap_entries * 4 + (size_t)(p.cap_rows + 4) * 4 +
               (size_t)p.cap_entries * 2 + (size_t)p.cap_long * 2 + 16;
     return p;
 }
@@ -812,10 +845,10 @@ __global__ __launch_bounds__(1024) void appnp_lds_kernel(const int32_t *__restri
                                                          int32_t max_rows, int32_t max_entries, int32_t slice, int32_t dbg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char al_lds[];
     const LdsPlan P = appnp_lds_plan(max_rows, max_entries, slice);
-    float4 *buf0 = reinterpret_cast<float4 *>(al_lds);
-    float4 *buf1 = buf0 + P.cap_rows * slice;
-    float4 *s_keep = buf1 + P.cap_rows * slice;
-    float *s_val = reinterpret_cast<float *>(s_keep + P.cap_long * slice);
+    float4 *buf = reinterpret_cast<float4 *>(al_lds);          // the slice of the signal: ONE buffer (see the step loop)
+    float4 *s_keep = buf + P.cap_rows * slice;                  // long rows: z_0 / alpha-sum
+    float4 *s_ylong = s_keep + P.cap_long * slice;              // long rows: the step's results until the barrier
+    float *s_val = reinterpret_cast<float *>(s_ylong + P.cap_long * slice);
     int32_t *s_rp = reinterpret_cast<int32_t *>(s_val + P.cap_entries);
     uint16_t *s_col = reinterpret_cast<uint16_t *>(s_rp + P.cap_rows + 4);
     uint16_t *s_long = s_col + P.cap_entries;
@@ -854,13 +887,13 @@ __global__ __launch_bounds__(1024) void appnp_lds_kernel(const int32_t *__restri
             float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
             if (i < total) {
                 x = X[(int64_t)(r0 + (i >> lw)) * h4 + c0 + (i & (w - 1))];
-                buf0[i] = x;
+                buf[i] = x;
             }
             keep[j] = BWD ? make_float4(0.f, 0.f, 0.f, 0.f) : x;
         }
         __syncthreads();
         for (int i = tid; i < (n_long << lw); i += T)   // the long rows' z_0 / alpha-sum
-            s_keep[i] = BWD ? make_float4(0.f, 0.f, 0.f, 0.f) : buf0[((int)s_long[i >> lw] << lw) + (i & (w - 1))];
+            s_keep[i] = BWD ? make_float4(0.f, 0.f, 0.f, 0.f) : buf[((int)s_long[i >> lw] << lw) + (i & (w - 1))];
         __syncthreads();
         // a thread's items keep their rows across the K steps, and the CSR does not change: row bounds and the first four entries'
         // operand positions -- all there is for 98 % of the rows of a coarsened batch -- are read ONCE per slice, so a step is one LDS
@@ -886,15 +919,18 @@ __global__ __launch_bounds__(1024) void appnp_lds_kernel(const int32_t *__restri
             it_c[j][0] = c4[0] | (c4[1] << 16);
             it_c[j][1] = c4[2] | (c4[3] << 16);
         }
+        // ONE signal buffer: a step's results wait in registers (a thread's own items) and in s_ylong (the long rows) until every
+        // wavefront has gathered, then overwrite the buffer -- two barriers per step instead of one (a barrier costs 0.05 us here)
+        // for half the LDS per row, i.e. twice the slice width for a large subgraph: half the passes over its K steps
         for (int k = 0; k < K; ++k) {
-            const float4 *cur = (k & 1) ? buf1 : buf0;
-            float4 *nxt = (k & 1) ? buf0 : buf1;
+            const float4 *cur = buf;
+            float4 yv[kLdsKeep];
             if (!(dbg & 2))
 #pragma unroll
-            for (int jh = 0; jh < kLdsKeep; jh += 2) {   // two items' eight operand reads in flight (all four items': spills at 1 024 threads)
+            for (int jh = 0; jh < kLdsKeep; jh += kLdsFly) {   // kLdsFly items' eight operand reads in flight (all four items': spills at 1 024 threads)
             if (BWD) {   // the running alpha-sum first (its operand is not live beside the eight gathers below)
 #pragma unroll
-                for (int j = jh; j < jh + 2; ++j)
+                for (int j = jh; j < jh + kLdsFly; ++j)
                     if ((it_en[j] & 31u) > 0) {
                         const float4 xs = cur[tid + j * T];
                         keep[j].x = fmaf(alpha, xs.x, keep[j].x); keep[j].y = fmaf(alpha, xs.y, keep[j].y);
@@ -904,14 +940,17 @@ __global__ __launch_bounds__(1024) void appnp_lds_kernel(const int32_t *__restri
             float4 x[kLdsKeep][4];
             float it_v[kLdsKeep][4];   // (the values ride the same round trip as the operands: keeping them too spills)
 #pragma unroll
-            for (int j = jh; j < jh + 2; ++j)
+            for (int j = jh; j < jh + kLdsFly; ++j)   // (the sixteen operand ADDRESSES, hoisted out of the K loop, would undo the packing)
+                asm volatile("" : "+v"(it_c[j][0]), "+v"(it_c[j][1]), "+v"(it_en[j]));
+#pragma unroll
+            for (int j = jh; j < jh + kLdsFly; ++j)
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     x[j][t] = cur[(it_c[j][t >> 1] >> (16 * (t & 1))) & 0xffffu];   // (an absent entry reads slot 0 at weight 0)
                     it_v[j][t] = t < (int)(it_en[j] & 31u) ? s_val[(it_en[j] >> 5) + t] : 0.f;
                 }
 #pragma unroll
-            for (int j = jh; j < jh + 2; ++j) {
+            for (int j = jh; j < jh + kLdsFly; ++j) {
                 if ((it_en[j] & 31u) > 0) {
                     const int i = tid + j * T;
                     const int q = i & (w - 1);
@@ -935,7 +974,7 @@ __global__ __launch_bounds__(1024) void appnp_lds_kernel(const int32_t *__restri
                         y.x = fmaf(alpha, keep[j].x, y.x); y.y = fmaf(alpha, keep[j].y, y.y);
                         y.z = fmaf(alpha, keep[j].z, y.z); y.w = fmaf(alpha, keep[j].w, y.w);
                     }
-                    nxt[i] = y;
+                    yv[j] = y;
                 }
             }
             }
@@ -989,13 +1028,19 @@ __global__ __launch_bounds__(1024) void appnp_lds_kernel(const int32_t *__restri
                         } else {
                             y.x = fmaf(alpha, kp.x, y.x); y.y = fmaf(alpha, kp.y, y.y); y.z = fmaf(alpha, kp.z, y.z); y.w = fmaf(alpha, kp.w, y.w);
                         }
-                        nxt[i] = y;
+                        s_ylong[(j << lw) + q_l] = y;
                     }
                 }
             }
+            __syncthreads();   // every gather of the step done
+#pragma unroll
+            for (int j = 0; j < kLdsKeep; ++j)
+                if ((it_en[j] & 31u) > 0) buf[tid + j * T] = yv[j];
+            if (!(dbg & 1))
+                for (int i = tid; i < (n_long << lw); i += T) buf[((int)s_long[i >> lw] << lw) + (i & (w - 1))] = s_ylong[i];
             __syncthreads();
         }
-        float4 *fin = (K & 1) ? buf1 : buf0;
+        float4 *fin = buf;
         if (BWD) {   // the long rows' sums: folded into the final buffer first (the lanes that hold them are not the items' owners)
             for (int i = tid; i < (n_long << lw); i += T) {
                 const int at = ((int)s_long[i >> lw] << lw) + (i & (w - 1));

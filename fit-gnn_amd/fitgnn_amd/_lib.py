@@ -120,6 +120,7 @@ SIGNATURES = {
     "fitgnn_appnp_lds_max_bytes": (ctypes.c_int, []),
     "fitgnn_appnp_lds_items_per_thread": (ctypes.c_int, []),
     "fitgnn_appnp_lds_f32": (ctypes.c_int, [ptr, ptr, ptr, ptr, c_i32, c_i32, c_i32, ptr, ptr, c_i32, c_i32, c_f32, c_i32, c_i32, c_i32, ptr]),
+    "fitgnn_gather_rows_padded_f32": (ctypes.c_int, [ptr, c_i64, c_i32, ptr, c_i64, ptr, c_i32, ptr]),
     "fitgnn_appnp_units_f32": (ctypes.c_int, [ptr, ptr, ptr, ptr, c_i32, c_i32, c_i32, ptr, ptr, c_i32, c_i32, c_f32, c_i32, ptr]),
     "fitgnn_csr_row_sum_f32": (ctypes.c_int, [ptr, ptr, c_i32, ptr, ptr]),
     "fitgnn_induced_edges_count": (ctypes.c_int, [ptr, ptr, ptr, ptr, ptr, ptr, c_i64, ptr, ptr]),

@@ -321,9 +321,7 @@ class APPNPNet(nn.Module):
         x = F.relu(self.lin1(x))
         x = F.dropout(x, p=self.dropout_p, training=self.training)
         x = self.lin2(x)
-        if x_index is not None:
-            x = x.index_select(0, x_index.index.long())
-        return self.prop1(x, edge_index)
+        return self.prop1(x, edge_index, x_index=x_index)   # (the table's rows are gathered into the propagation's own layout there)
 
     def forward(self, x, edge_index, x_index=None):
         return F.log_softmax(self.logits(x, edge_index, x_index), dim=1)

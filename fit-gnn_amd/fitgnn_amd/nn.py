@@ -72,7 +72,9 @@ class Linear(_OpConfigured, nn.Linear):
     def forward(self, x):
         if x.is_cuda and x.dim() == 2:
             y = ops.Linear.apply(x.float(), self.weight, self.op_config)
-            return y if self.bias is None else y + self.bias
+            if self.bias is None:
+                return y
+            return ops.BiasAdd.apply(y, self.bias) if (self.out_features <= 64 and y.shape[0] > 4096) else y + self.bias
         return super().forward(x)
 
 
@@ -180,11 +182,16 @@ class APPNP(_OpConfigured, nn.Module):
     def reset_parameters(self):
         pass
 
-    def forward(self, x, edge_index):
-        g = csr_for(edge_index, x.shape[0], "gcn")
+    def forward(self, x, edge_index, x_index=None):
+        """x_index (ops.RowIndex, optional, an extension): x is a de-duplicated table and row r of the propagated signal is
+        x[x_index.index[r]] (edge_index numbers the signal's rows)."""
+        n = x.shape[0] if x_index is None else int(x_index.index.numel())
+        g = csr_for(edge_index, n, "gcn")
         z0 = x.float()
         if z0.is_cuda and z0.shape[1] <= 64:   # class-wide signal: the narrow kernel, teleport term in its epilogue
-            return ops.APPNPPropagate.apply(z0, g, int(self.K), float(self.alpha), self.op_config)
+            return ops.APPNPPropagate.apply(z0, g, int(self.K), float(self.alpha), self.op_config, x_index)
+        if x_index is not None:
+            z0 = z0.index_select(0, x_index.index.long())
         z = z0
         for _ in range(self.K):
             z = ops.SpMM.apply(z, None, g, self.op_config) * (1.0 - self.alpha) + self.alpha * z0

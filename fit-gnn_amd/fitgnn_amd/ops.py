@@ -458,6 +458,19 @@ def colsum_narrow(x, out=None):
     return out
 
 
+class BiasAdd(torch.autograd.Function):
+    """y + b for a tall y with a narrow row (a Linear into the classes): the bias gradient through colsum_narrow instead of torch's
+    dim-0 reduction of a [2.4 M x 47] matrix (870 us at S-products against ~100 for one pass over it)."""
+
+    @staticmethod
+    def forward(ctx, y, b):
+        return y + b
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, (colsum_narrow(g if g.stride(1) == 1 else g.contiguous()) if ctx.needs_input_grad[1] else None)
+
+
 class SmallLinear(torch.autograd.Function):
     """y = x W^T + b for a narrow output (lt1: hidden -> classes, network.py:34).  nn.Linear's addmm picks a 340 us
     kernel for [90k x 512] @ [512 x 3]; mm + a broadcast add is 10x faster.  Same arithmetic."""
@@ -480,6 +493,29 @@ class SmallLinear(torch.autograd.Function):
         return dx, dW, db, None
 
 
+def softmax_nll_raw(z, idx, labels, scale):
+    """(loss, dz): loss = scale * sum_t NLL(log_softmax(z[idx[t]]), labels[t]) as a one-element tensor and dz = d loss / d z, from ONE
+    launch (fitgnn_softmax_nll_f32).  z may be a [rows x C] view with a row stride (the padded signal APPNPPropagate returns): it is
+    read in place and dz comes back as the same view of an equally strided buffer.  A trainer that owns the step calls
+    z.backward(dz) instead of loss.backward(): the same gradient without the multiplication by autograd's ones."""
+    _lib.require_cuda(z, idx, labels)
+    L = _lib.lib()
+    if z.dtype != torch.float32 or z.stride(1) != 1 or z.stride(0) < z.shape[1]:
+        z = _f32c(z)
+    n_rows, C = z.shape
+    ldz = int(z.stride(0))
+    n = int(idx.numel())
+    idx, labels = idx.long().contiguous(), labels.long().contiguous()
+    loss = torch.empty(1, dtype=torch.float32, device=z.device)
+    dz = torch.empty((n_rows, ldz), dtype=torch.float32, device=z.device)
+    wb = int(L.fitgnn_softmax_nll_workspace_bytes(n))
+    work = torch.empty(wb, dtype=torch.uint8, device=z.device)
+    _lib.check(L.fitgnn_softmax_nll_f32(_lib.dptr(z), ldz, n_rows, C, _lib.dptr(idx), _lib.dptr(labels), n, float(scale),
+                                        _lib.dptr(loss), _lib.dptr(dz), _lib.dptr(work), wb, _lib.stream_ptr(z.device)),
+               "fitgnn_softmax_nll_f32")
+    return loss, (dz if ldz == C else dz[:, :C])
+
+
 class SoftmaxNLL(torch.autograd.Function):
     """scale * sum_t NLL(log_softmax(z[idx[t]]), labels[t]): Classify_node's log_softmax (network.py:35) + NLLLoss
     (run.py:341) over the train rows, with the gradient w.r.t. the logits produced by the same kernel
@@ -487,19 +523,7 @@ class SoftmaxNLL(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, z, idx, labels, scale):
-        _lib.require_cuda(z, idx, labels)
-        L = _lib.lib()
-        z = _f32c(z)
-        n_rows, C = z.shape
-        n = int(idx.numel())
-        idx, labels = idx.long().contiguous(), labels.long().contiguous()
-        loss = torch.empty(1, dtype=torch.float32, device=z.device)
-        dz = torch.empty_like(z)
-        wb = int(L.fitgnn_softmax_nll_workspace_bytes(n))
-        work = torch.empty(wb, dtype=torch.uint8, device=z.device)
-        _lib.check(L.fitgnn_softmax_nll_f32(_lib.dptr(z), C, n_rows, C, _lib.dptr(idx), _lib.dptr(labels), n, float(scale),
-                                            _lib.dptr(loss), _lib.dptr(dz), _lib.dptr(work), wb, _lib.stream_ptr(z.device)),
-                   "fitgnn_softmax_nll_f32")
+        loss, dz = softmax_nll_raw(z, idx, labels, scale)
         ctx.save_for_backward(dz)
         return loss[0]
 
@@ -2238,13 +2262,34 @@ class APPNPPropagate(torch.autograd.Function):
     padded to whole float4s (fitgnn_spmm_narrow_padded_f32: a wave packs 64 / h4 rows, operand rows are contiguous 16-byte accesses)."""
 
     @staticmethod
-    def _padded(z, h4):
-        n, H = z.shape
-        if H == 4 * h4:
+    def _padded(z, h4, row_index=None):
+        """[rows x 4 h4] contiguous: the rows z[row_index.index[r]] (all of z's rows, in order, without an index) padded with zeros --
+        one pass (fitgnn_gather_rows_padded_f32); z itself when there is nothing to do."""
+        H = z.shape[1]
+        if row_index is None and H == 4 * h4 and z.is_contiguous():
             return z
-        zp = torch.zeros((n, 4 * h4), dtype=torch.float32, device=z.device)
-        zp[:, :H] = z
+        if z.stride(1) != 1:
+            z = z.contiguous()
+        idx = None if row_index is None else row_index.index
+        n = int(z.shape[0] if idx is None else idx.numel())
+        zp = torch.empty((n, 4 * h4), dtype=torch.float32, device=z.device)
+        _lib.check(_lib.lib().fitgnn_gather_rows_padded_f32(_lib.dptr(z), z.stride(0), H, _lib.dptr(idx), n, _lib.dptr(zp), h4,
+                                                            _lib.stream_ptr(z.device)), "fitgnn_gather_rows_padded_f32")
         return zp
+
+    @staticmethod
+    def _padded_grad(dz, h4):
+        """The incoming gradient in the padded layout: as it is when it IS a [rows x H] view of a padded buffer (what SoftmaxNLL hands
+        back for the view forward() returned: the pad columns never mix with the others, their content does not matter), else padded."""
+        n, H = dz.shape
+        if dz.dtype != torch.float32:
+            dz = dz.float()
+        if H == 4 * h4:
+            return _f32c(dz)
+        if (dz.stride(1) == 1 and dz.stride(0) == 4 * h4 and dz.storage_offset() % 4 == 0
+                and dz.untyped_storage().nbytes() >= 4 * (dz.storage_offset() + n * 4 * h4)):
+            return dz.as_strided((n, 4 * h4), (4 * h4, 1))
+        return APPNPPropagate._padded(dz, h4)
 
     @staticmethod
     def _in_lds(plan, side, x, out, h4, K, alpha, backward, cfg, st, tag):
@@ -2268,14 +2313,20 @@ class APPNPPropagate(torch.autograd.Function):
                            "fitgnn_appnp_lds_f32")
 
     @staticmethod
-    def forward(ctx, z0, g, K, alpha, cfg=None):
+    def forward(ctx, z0, g, K, alpha, cfg=None, row_index=None):
+        """row_index (ops.RowIndex, optional): z0 is the class-wide output on a de-duplicated table and the signal's row r is
+        z0[row_index.index[r]] -- gathered into the padded layout in one pass, its adjoint (fitgnn_segment_sum_f32) in backward.
+        The result is the [rows x H] VIEW of the padded signal (no copy out of it)."""
         L = _lib.lib()
-        z0 = _f32c(z0)
-        n, H = z0.shape
+        if z0.dtype != torch.float32:
+            z0 = z0.float()
+        H = int(z0.shape[1])
+        n = int(z0.shape[0] if row_index is None else row_index.index.numel())
         h4 = (H + 3) // 4
         st = _lib.stream_ptr(z0.device)
         f = g.f
-        z0p = APPNPPropagate._padded(z0, h4)
+        z0p = APPNPPropagate._padded(z0, h4, row_index)
+        ctx.row_index = row_index
         plan = (appnp_plan(g, h4, cfg is None or cfg.appnp_blocks, cfg is None or cfg.appnp_sliced)
                 if (cfg is None or cfg.appnp_in_lds) and K > 0 and h4 <= 16 else None)
         if plan is not None and plan.n_units == 0 and plan.n_blocks == 0 and plan.n_lds_blocks == 0:
@@ -2305,7 +2356,7 @@ class APPNPPropagate(torch.autograd.Function):
                                    "spmm_narrow_padded")
                     z = nxt
                 out.index_copy_(0, plan.open_rows, z)
-            return out if H == 4 * h4 else out[:, :H].contiguous()
+            return out if H == 4 * h4 else out[:, :H]
         z = z0p
         for _ in range(K):
             nxt = torch.empty_like(z0p)
@@ -2313,17 +2364,29 @@ class APPNPPropagate(torch.autograd.Function):
                 _lib.check(L.fitgnn_spmm_narrow_padded_f32(_lib.dptr(f.rowptr), _lib.dptr(f.col), _lib.dptr(f.val), _lib.dptr(z), _lib.dptr(nxt),
                                                            n, h4, 1.0 - alpha, _lib.dptr(z0p), float(alpha), None, 0.0, st), "spmm_narrow_padded")
             z = nxt
-        return z if H == 4 * h4 else z[:, :H].contiguous()
+        if z is z0p and z0p is z0:
+            z = z.clone()   # (K = 0: the input itself)
+        return z if H == 4 * h4 else z[:, :H]
+
+    @staticmethod
+    def _grad_out(ctx, res, H, h4):
+        """res [rows x 4 h4] -> the gradient w.r.t. z0: summed back per table row under a row index, else the [rows x H] view."""
+        ri = ctx.row_index
+        if ri is None:
+            return res if H == 4 * h4 else res[:, :H]
+        out = torch.empty((ri.n_table, H), dtype=torch.float32, device=res.device)
+        _lib.check(_lib.lib().fitgnn_segment_sum_f32(_lib.dptr(ri.seg_off), _lib.dptr(ri.members), ri.n_table, _lib.dptr(res), 4 * h4, H,
+                                                     _lib.dptr(out), H, _lib.stream_ptr(res.device)), "fitgnn_segment_sum_f32")
+        return out
 
     @staticmethod
     def backward(ctx, dz):
         L = _lib.lib()
-        dz = _f32c(dz)
         n, H = dz.shape
         h4 = (H + 3) // 4
         st = _lib.stream_ptr(dz.device)
         t = ctx.g.t
-        dz = APPNPPropagate._padded(dz, h4)
+        dz = APPNPPropagate._padded_grad(dz, h4)
         plan = ctx.plan
         if plan is not None:
             out = torch.empty_like(dz)
@@ -2347,7 +2410,7 @@ class APPNPPropagate(torch.autograd.Function):
                                    "spmm_narrow_padded")
                     gb = nxt
                 out.index_copy_(0, plan.open_rows, accb + gb)
-            return (out if H == 4 * h4 else out[:, :H].contiguous()), None, None, None, None
+            return APPNPPropagate._grad_out(ctx, out, H, h4), None, None, None, None, None
         acc = torch.zeros_like(dz)
         for _ in range(ctx.K):   # dz_k = (1 - alpha) A^T dz_{k+1};  acc += alpha * dz_{k+1}
             nxt = torch.empty_like(dz)
@@ -2357,7 +2420,7 @@ class APPNPPropagate(torch.autograd.Function):
                            "spmm_narrow_padded")
             dz = nxt
         out = acc + dz
-        return (out if H == 4 * h4 else out[:, :H].contiguous()), None, None, None, None
+        return APPNPPropagate._grad_out(ctx, out, H, h4), None, None, None, None, None
 
 
 _HEAD_MAX = None

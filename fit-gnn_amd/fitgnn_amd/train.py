@@ -400,6 +400,13 @@ class GDTrainer:
         if self.fused_logits:
             from .ops import SoftmaxNLL
             z = m.logits(b.x_table, b.edge_index, x_index=b.row_index) if self.dedup else m.logits(b.x, b.edge_index)
+            if self.lean and not self.dist:   # the loss's own gradient handed to backward (no ones-fill, no multiplication by it)
+                from .ops import softmax_nll_raw
+                loss, dz = softmax_nll_raw(z, b.train_idx, self._y_train, scale)
+                self.local_loss = loss[0]
+                z.backward(dz)
+                self.opt.step()
+                return loss[0]
             return self._backward_and_step(SoftmaxNLL.apply(z, b.train_idx, self._y_train, scale))
         out = m(b.x_table, b.edge_index, x_index=b.row_index) if self.dedup else m(b.x, b.edge_index)
         sel = out.index_select(0, b.train_idx)

@@ -527,6 +527,13 @@ int fitgnn_spmm_narrow_padded_f32(const int32_t *rowptr, const int32_t *col, con
                                   int32_t n_rows, int32_t h4, float beta, const float *Z0, float gamma, float *ACC, float delta,
                                   void *stream);
 
+/* dst [n_rows x 4 h4] (contiguous, 16-byte aligned) = the rows src[index[r]] (index int32, NULL = the identity; H <= 4 h4 floats each, row
+ * stride lds) padded with zeros: the layout fitgnn_spmm_narrow_padded_f32 / fitgnn_appnp_*_f32 run in, made in one pass from the model's
+ * class-wide output -- x.index_select(0, x_index) of a de-duplicated table (Baselines/SGGC/APPNP/networks.py:21-23 runs lin2's output
+ * through prop1 directly; the indirection is this library's) + zero fill + strided copy. */
+int fitgnn_gather_rows_padded_f32(const float *src, int64_t lds, int32_t H, const int32_t *index, int64_t n_rows, float *dst, int32_t h4,
+                                  void *stream);
+
 /* APPNP's K propagation steps z_{k+1} = (1 - alpha) A z_k + alpha z_0 (Baselines/SGGC/APPNP/networks.py:11,23) with the signal resident
  * in LDS, for the "units" of a block-diagonal batch: units [n_units x 2] = (row_begin, row_end) of runs of consecutive rows that are
  * CLOSED under the pattern (every column of their rows lies inside the run: whole cluster subgraphs), at most

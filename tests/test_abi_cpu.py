@@ -185,8 +185,11 @@ def test_round4_graph_step_entry_points_check_their_arguments_without_a_gpu():
     assert L.fitgnn_appnp_units_f32(None, None, None, None, 0, 0, 0, None, None, 12, 10, 0.1, 0, None) == 0           # nothing to do
     assert L.fitgnn_appnp_units_f32(None, None, None, None, 5, 64, 100, None, None, 12, 10, 0.1, 0, None) == -1       # NULL arrays
     assert L.fitgnn_appnp_units_f32(None, None, None, None, 5, 65, 100, None, None, 12, 10, 0.1, 0, None) == -1       # a unit beyond the capacity
+    assert L.fitgnn_gather_rows_padded_f32(None, 47, 47, None, 0, None, 12, None) == 0            # nothing to do
+    assert L.fitgnn_gather_rows_padded_f32(None, 47, 47, None, 10, None, 12, None) == -1          # NULL arrays
+    assert L.fitgnn_gather_rows_padded_f32(None, 47, 47, None, 10, None, 11, None) == -1          # 4 h4 < H
     assert L.fitgnn_appnp_lds_items_per_thread() == 4 and L.fitgnn_appnp_lds_max_bytes() == 160 * 1024
-    assert 0 < L.fitgnn_appnp_lds_bytes(64, 300, 4) < 16 * 1024 and L.fitgnn_appnp_lds_bytes(2000, 7000, 1) < 160 * 1024 < L.fitgnn_appnp_lds_bytes(2000, 7000, 2)
+    assert 0 < L.fitgnn_appnp_lds_bytes(64, 300, 4) < 16 * 1024 and L.fitgnn_appnp_lds_bytes(2000, 7000, 2) < 160 * 1024 < L.fitgnn_appnp_lds_bytes(2000, 7000, 4)
     assert L.fitgnn_appnp_lds_bytes(64, 300, 3) == -1 and L.fitgnn_appnp_lds_bytes(70000, 300, 1) == -1
     assert L.fitgnn_appnp_lds_f32(None, None, None, None, 0, 0, 0, None, None, 12, 10, 0.1, 0, 64, 4, None) == 0            # nothing to do
     assert L.fitgnn_appnp_lds_f32(None, None, None, None, 5, 64, 100, None, None, 12, 10, 0.1, 0, 64, 4, None) == -1        # NULL arrays

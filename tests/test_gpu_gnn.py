@@ -1512,6 +1512,49 @@ def test_appnp_column_sliced_lds_kernel_for_every_launch_shape(mods, C, threads,
     assert L.fitgnn_appnp_lds_f32(*args(slice_=3)) == -1
 
 
+@pytest.mark.parametrize("C", [3, 47, 48])
+def test_appnp_takes_the_table_rows_and_hands_the_padded_signal_to_the_loss(mods, C):
+    """APPNPPropagate(z_table, ..., row_index): the de-duplicated table's rows gathered straight into the padded layout
+    (fitgnn_gather_rows_padded_f32) and summed back per table row in backward (fitgnn_segment_sum_f32) == index_select + propagate;
+    the result is the [rows x C] view of the padded signal, which softmax_nll_raw reads in place and answers with an equally strided
+    gradient that backward takes as it is == SoftmaxNLL on a contiguous copy (loss, gradient w.r.t. the table)."""
+    from fitgnn_amd import csr, ops
+
+    rng = np.random.default_rng(C)
+    sizes = [int(v) for v in rng.integers(1, 300, size=60)]
+    ei, n = _ring_blocks(sizes, rng, hub_every=5)
+    g = csr.CSRGraph(ei, n, mode="gcn")
+    n_table = 700
+    idx = torch.from_numpy(rng.integers(0, n_table, size=n)).cuda()
+    ri = ops.RowIndex(idx, n_table)
+    zt = torch.randn(n_table, C, device="cuda")
+    w = torch.randn(n, C, device="cuda")
+    a_in = zt.clone().requires_grad_(True)
+    a = ops.APPNPPropagate.apply(a_in, g, 6, 0.1, ops.DEFAULT, ri)
+    assert a.shape == (n, C) and a.stride() == (4 * ((C + 3) // 4), 1)
+    (a * w).sum().backward()
+    b_in = zt.clone().requires_grad_(True)
+    b = ops.APPNPPropagate.apply(b_in.index_select(0, idx), g, 6, 0.1, ops.DEFAULT.replace(appnp_in_lds=False))
+    (b * w).sum().backward()
+    assert rel(a, b) < 1e-5 and rel(a_in.grad, b_in.grad) < 1e-5
+    # the loss on the view
+    train = torch.from_numpy(rng.choice(n, size=n // 3, replace=False)).cuda()
+    y = torch.from_numpy(rng.integers(0, C, size=train.numel())).cuda()
+    c_in = zt.clone().requires_grad_(True)
+    z = ops.APPNPPropagate.apply(c_in, g, 6, 0.1, ops.DEFAULT, ri)
+    loss, dz = ops.softmax_nll_raw(z, train, y, 1.0 / train.numel())
+    assert dz.shape == (n, C) and dz.stride() == z.stride()
+    z.backward(dz)
+    d_in = zt.clone().requires_grad_(True)
+    z2 = ops.APPNPPropagate.apply(d_in, g, 6, 0.1, ops.DEFAULT, ri).contiguous()
+    loss2 = ops.SoftmaxNLL.apply(z2, train, y, 1.0 / train.numel())
+    loss2.backward()
+    assert float(loss[0]) == pytest.approx(float(loss2), rel=1e-6)
+    assert rel(c_in.grad, d_in.grad) < 1e-6
+    want = torch.nn.functional.nll_loss(torch.log_softmax(b.detach().double(), 1)[train], y, reduction="mean")
+    assert float(loss[0]) == pytest.approx(float(want), rel=1e-4)
+
+
 def test_appnp_few_large_subgraphs_stay_on_the_per_step_kernel(mods):
     """Fewer blocks than AppnpPlan.MIN_BLOCKS: no workgroup-per-block launch (it would leave most of the chip idle)."""
     from fitgnn_amd import csr, ops
