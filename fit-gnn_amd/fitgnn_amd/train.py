@@ -246,10 +246,13 @@ class GDTrainer:
         small = int(getattr(batch, "n_rows", 0) or 0) * 2048 <= (1 << 30)
         from . import nn as _fnn0
         gcn_only = all(isinstance(c, _fnn0.GCNConv) for c in getattr(model, "conv", [])) and len(getattr(model, "conv", [])) > 0
-        self.capture = (self.lean and self.fused_loss and gcn_only and (capture is True or (capture == "auto" and small)))
-        self._graph, self._graph_loss, self._bank = None, None, None
         # (a model with a `logits` method -- network.APPNPNet -- gets the same fused loss on its train rows)
         self.fused_logits = (task == "node_cls" and not self.fused_loss and hasattr(model, "logits") and next(model.parameters()).is_cuda)
+        # the whole step replayed from a hipGraph when it is launch-bound (a small union): the GCN models (dropout seeds on the device,
+        # ops.SeedBank) and the `logits` models (APPNPNet: torch's own dropout, whose generator torch's graphs advance per replay)
+        self.capture = (self.lean and ((self.fused_loss and gcn_only) or self.fused_logits)
+                        and (capture is True or (capture == "auto" and small)))
+        self._graph, self._graph_loss, self._bank = None, None, None
         self._y_train = batch.y.index_select(0, batch.train_idx) if (self.fused_loss or self.fused_logits) else None
         self._train_arange = None
         self.prune_forward = False
@@ -333,7 +336,7 @@ class GDTrainer:
         from . import ops
 
         dev = self.flat.buf.device
-        bank = ops.SeedBank(max(len(self.model.conv), 1), dev)
+        bank = ops.SeedBank(max(len(getattr(self.model, "conv", [])), 1), dev)
         saved_m = {k: v.detach().clone() for k, v in self.model.state_dict().items()}
         saved_o = (self.opt.m.clone(), self.opt.v.clone(), self.opt.step_count.clone())
         self.model.set_op_config(self.cfg.replace(seed_bank=bank))
@@ -364,7 +367,8 @@ class GDTrainer:
 
     def step(self):
         """One GD epoch (run.py:177-215).  Returns the global loss (over every rank's subgraphs) as a 0-dim device tensor."""
-        if self.capture and self.cfg.profile is None and self.cfg.profile_gemm is None and self.cfg.profile_fused is None:
+        if (self.capture and (self.fused_loss or self.fused_logits) and self.cfg.profile is None and self.cfg.profile_gemm is None
+                and self.cfg.profile_fused is None):
             if self._graph is None:
                 self._capture_step()
             if self._graph is not None:
@@ -771,7 +775,7 @@ class GraphTrainer(_CapturedSteps):
         from . import ops
 
         plan, dev = self._plan, self.flat.buf.device
-        bank = ops.SeedBank(max(len(self.model.conv), 1), dev)
+        bank = ops.SeedBank(max(len(getattr(self.model, "conv", [])), 1), dev)
         saved_m = {k: v.detach().clone() for k, v in self.model.state_dict().items()}
         saved_o = (self.opt.m.clone(), self.opt.v.clone(), self.opt.step_count.clone())
         prev = self.model.op_config

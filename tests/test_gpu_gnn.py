@@ -121,7 +121,7 @@ def test_appnp_net_follows_the_sggc_model(mods, dedup):
     loss.backward()
     o_ref, l_ref, g_ref = gorc.appnp_net_fwd_bwd(sd, x, ei, y, K=10, alpha=0.1, train_mask=tm)
     assert rel(out.detach().cpu(), o_ref) < 1e-4
-    assert float(loss) == pytest.approx(float(l_ref), rel=1e-5)
+    assert float(loss.detach()) == pytest.approx(float(l_ref), rel=1e-5)
     for k, p in model.named_parameters():
         assert rel(p.grad.cpu(), g_ref[k]) < 1e-3, k
 
@@ -1344,6 +1344,34 @@ def test_appnp_trainer_takes_the_loss_on_the_train_rows_only(mods):
         assert a == pytest.approx(b, rel=1e-5), (step, a, b)
     for (k, v), (_, w) in zip(m1.state_dict().items(), m2.state_dict().items()):
         assert rel(v, w) < 1e-4, k
+
+
+def test_appnp_step_replayed_from_a_hipgraph_equals_the_eager_step(mods):
+    """GDTrainer(capture="auto") on network.APPNPNet (a small union): forward, loss on the padded view, backward and Adam replayed from
+    one hipGraph == the eager step, bit for bit (dropout off: torch's generator is the only difference otherwise), over five steps;
+    with dropout on the replays draw fresh masks (the losses differ from step to step and stay finite)."""
+    from fitgnn_amd import train
+
+    network, fnn, gorc = mods
+    batch, _ = _subgraph_batches(seed=8)
+    args = argparse.Namespace(num_features=24, hidden=32, num_classes=4, K=5, alpha=0.1, dropout=0.0)
+    torch.manual_seed(11)
+    m1, m2 = network.APPNPNet(args).cuda(), network.APPNPNet(args).cuda()
+    m2.load_state_dict(m1.state_dict())
+    t1 = train.GDTrainer(m1, batch, lr=0.01, weight_decay=5e-4, capture="auto")
+    t2 = train.GDTrainer(m2, batch, lr=0.01, weight_decay=5e-4, capture=False)
+    assert t1.capture and not t2.capture
+    for step in range(5):
+        a, b = float(t1.step()), float(t2.step())
+        assert a == b, (step, a, b)
+    assert t1._graph is not None
+    for (k, v), (_, w) in zip(m1.state_dict().items(), m2.state_dict().items()):
+        assert torch.equal(v, w), k
+    args.dropout = 0.5
+    m3 = network.APPNPNet(args).cuda()
+    t3 = train.GDTrainer(m3, batch, lr=0.0, weight_decay=0.0, capture="auto")   # lr 0: the weights stay, only the masks change
+    losses = [float(t3.step()) for _ in range(4)]
+    assert t3._graph is not None and all(np.isfinite(losses)) and len(set(losses)) == 4, losses
 
 
 @pytest.mark.parametrize("C", [3, 47, 64])
