@@ -7,6 +7,8 @@ process-wide mutable state: switches travel in an OpConfig argument.
 """
 import ctypes
 
+import os
+
 import torch
 
 from . import _lib
@@ -912,6 +914,7 @@ def spmm_two_hop_blocks(g, Xc, prev, rows, pos, link, cfg=DEFAULT, profile_kind=
         spmm_raw(side.rowptr, side.col, side.val, side.small_tiles, ZT, g.n, window_rows=g.window_rows, out=Y, cfg=quiet, xrow=ix["zrow"])
     n_blocks = int(side.blocks.shape[0])
     # one partial row of column sums per block + one for the rows outside the blocks (their dZ sits in the table)
+    # (zeros, not uninitialised memory: the two-hop kernel leaves rows of `part` unwritten -- poisoned with NaN, conv.0.bias's gradient is NaN)
     part = torch.zeros((n_blocks + 1, H), dtype=torch.float32, device=dev) if link.want_db else None
     _lib.check(L.fitgnn_spmm_two_hop_blocks_f32(_lib.dptr(side.rowptr), _lib.dptr(side.col), _lib.dptr(side.val), _lib.dptr(ZT), ZT.stride(0),
                                                 _lib.dptr(Y), Y.stride(0), g.n, H, _lib.dptr(side.blocks), n_blocks, _lib.dptr(side.long_rows),
@@ -967,6 +970,8 @@ def spmm_graph_dz(g, X, prev, epilogue, p=0.0, seed=0, mask=None, want_db=True, 
     n_tiles = int(tiles.shape[0])
     n_blocks = int(side.blocks.shape[0]) if split else 0
     Y = torch.empty((g.n, H), dtype=torch.float32, device=dev)
+    # (zeros, not uninitialised memory: tried -- with the buffer poisoned with NaN, 19 GPU tests fail: the kernels leave partial rows
+    # unwritten; the fill is a 4.6-us launch of a 180-us batch step at S-qm9)
     part = torch.zeros((n_tiles + n_blocks, H), dtype=torch.float32, device=dev) if want_db else None
     st = _lib.stream_ptr(dev)
     ev = None
