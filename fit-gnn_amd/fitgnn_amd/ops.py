@@ -2242,7 +2242,7 @@ class AppnpPlan:
                 rowptr[1:] = torch.cumsum(cnt_o, 0)
                 ent = torch.repeat_interleave(open_t, cnt)                    # entries of open rows
                 col = new_id[side.col[ent].long()].contiguous()
-                self.sub[name] = (rowptr.to(torch.int32).contiguous(), col, side.val[ent].contiguous())
+                self.sub[name] = (rowptr.to(torch.int32).contiguous(), col, None if side.val is None else side.val[ent].contiguous())
             self.nnz_open = int(self.sub["f"][1].numel())
         else:
             self.nnz_open = 0

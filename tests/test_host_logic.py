@@ -621,3 +621,50 @@ def test_tiles_cut_at_graph_boundaries_partition_every_graph():
         for g in range(n_graphs):
             t = tiles[g_tile[g]:g_tile[g + 1]]
             assert len(t) > 0 and t[0, 0] == g_row[g] and t[-1, 1] == g_row[g + 1]
+
+
+def test_appnp_plan_sends_every_row_to_exactly_one_launch():
+    """ops.AppnpPlan (host logic over the library's size queries; no GPU): the diagonal blocks of a block-diagonal pattern are split
+    into units (packed to <= 64 rows), LDS launches (one per slice width and workgroup size, each within the kernel's item and LDS
+    limits for ITS largest range), the global-scratch tier (only with enough blocks) and the open rows -- every row exactly once."""
+    import numpy as np
+    import torch
+    from fitgnn_amd import _lib, csr, ops
+
+    L = _lib.lib()
+    sizes = [5] * 40 + [64, 65, 100, 300, 70, 1500, 2500, 1024, 1025, 2048, 4096, 5000, 3, 7] + [900] * 10
+    src, dst, off = [], [], 0
+    for sz in sizes:   # rings
+        r = np.arange(sz)
+        a, b = r, np.roll(r, -1)
+        m = a != b
+        src += [a[m] + off, b[m] + off]; dst += [b[m] + off, a[m] + off]
+        off += sz
+    ei = torch.from_numpy(np.stack([np.concatenate(src), np.concatenate(dst)]))
+    g = csr.CSRGraph(ei, off, mode="gcn")
+    for h4 in (1, 12, 16):
+        plan = ops.AppnpPlan(g, h4)
+        cover = np.zeros(off, dtype=np.int64)
+        for a, b in plan.units.numpy():
+            cover[a:b] += 1
+        assert plan.max_rows <= plan.cap_rows and plan.max_rows * plan.unit_slice <= 4 * plan.unit_threads
+        assert L.fitgnn_appnp_lds_bytes(plan.max_rows, plan.max_entries, plan.unit_slice) <= L.fitgnn_appnp_lds_max_bytes()
+        seen = set()
+        for sl, ranges, m, mr, me, threads in plan.lds_launches:
+            assert (sl, threads) not in seen and sl <= h4 and m == len(ranges)
+            seen.add((sl, threads))
+            assert mr * sl <= 4 * threads and L.fitgnn_appnp_lds_bytes(mr, me, sl) <= L.fitgnn_appnp_lds_max_bytes()
+            rr = ranges.numpy()
+            assert (rr[:, 1] - rr[:, 0]).max() == mr
+            for a, b in rr:
+                cover[a:b] += 1
+        assert plan.n_blocks == 0 and plan.blocks is None   # fewer than MIN_BLOCKS blocks beyond LDS
+        if plan.n_open:
+            cover[plan.open_rows.numpy()] += 1
+        assert (cover == 1).all()
+        assert plan.rows_in_units + plan.rows_in_lds_blocks + plan.n_open == off
+        # open: the block beyond four items per thread x 1 024 threads at a one-float4 slice, and the 4 096-row one, whose CSR slice
+        # (three entries a row) and buffer exceed LDS even at that slice
+        assert plan.n_open == 5000 + 4096
+        old = ops.AppnpPlan(g, h4, sliced=False)
+        assert old.lds_launches == [] and old.rows_in_units == plan.rows_in_units and old.n_open == off - old.rows_in_units
