@@ -970,8 +970,9 @@ def spmm_graph_dz(g, X, prev, epilogue, p=0.0, seed=0, mask=None, want_db=True, 
     n_tiles = int(tiles.shape[0])
     n_blocks = int(side.blocks.shape[0]) if split else 0
     Y = torch.empty((g.n, H), dtype=torch.float32, device=dev)
-    # (zeros, not uninitialised memory: tried -- with the buffer poisoned with NaN, 19 GPU tests fail: the kernels leave partial rows
-    # unwritten; the fill is a 4.6-us launch of a 180-us batch step at S-qm9)
+    # (zeros, not uninitialised memory: the whole-subgraph kernel writes partial rows for some of its segments only -- with the buffer
+    # poisoned with NaN 17 of 24 block rows of a split test graph stay NaN and 19 GPU tests fail; the tile kernel writes every row.
+    # The fill is a 4.6-us launch of a 180-us batch step at S-qm9)
     part = torch.zeros((n_tiles + n_blocks, H), dtype=torch.float32, device=dev) if want_db else None
     st = _lib.stream_ptr(dev)
     ev = None
