@@ -321,6 +321,26 @@ def test_backward_spmm_with_the_previous_layers_epilogue_in_its_store(mods, H, u
         assert none is None and torch.equal(got2, want2)
 
 
+def test_tiles_only_column_sum_partials_need_no_zero_fill(mods, monkeypatch):
+    """spmm_graph_dz on a graph without whole-subgraph blocks hands its kernels an UNINITIALISED partial buffer (one launch less in a
+    launch-bound batch step): with that buffer poisoned with NaN (FITGNN_POISON's switch) db is finite and the zero-filled path's, for
+    H = 64 / 96 / 512 (one slab, a ragged slab, two slabs) -- the tile kernel writes every (tile, column)."""
+    _lib, csr, ops, orc, gorc = mods
+    from fitgnn_amd._lib import EPI_DROPOUT, EPI_ELU
+
+    ei, n = block_graph([5, 3, 9, 2, 7, 30, 4, 17, 1, 64] * 6, seed=5, p=0.4)
+    g = csr.CSRGraph(ei.cuda(), n, mode="gcn")
+    assert g.t.blocks is None
+    for H in (64, 96, 512):
+        torch.manual_seed(H)
+        X, prev = torch.randn(n, H).cuda(), torch.randn(n, H).cuda()
+        monkeypatch.setattr(ops, "_POISON", False)
+        want, want_db = ops.spmm_graph_dz(g, X, prev, EPI_ELU | EPI_DROPOUT, p=0.5, seed=9, want_db=True)
+        monkeypatch.setattr(ops, "_POISON", True)
+        got, got_db = ops.spmm_graph_dz(g, X, prev, EPI_ELU | EPI_DROPOUT, p=0.5, seed=9, want_db=True)
+        assert torch.equal(got, want) and torch.isfinite(got_db).all() and torch.equal(got_db, want_db)
+
+
 def test_backward_epilogue_with_a_window_smaller_than_its_column_sum_scratch(mods):
     """The tile kernel's backward epilogue folds its column sums through LDS (4 waves x 64 lanes x 4 floats = 4 KiB); a window
     of 2 or 3 rows allocates less than that for the window itself: the launcher keeps the allocation at the scratch's
