@@ -397,9 +397,17 @@ class GDTrainer:
                 if z.shape[0] == b.train_idx.numel() and z.shape[0] != b.n_rows:   # the logits of the train rows only, in their order
                     if self._train_arange is None:
                         self._train_arange = torch.arange(z.shape[0], dtype=torch.int64, device=z.device)
-                    loss = SoftmaxNLL.apply(z, self._train_arange, self._y_train, scale)
+                    rows = self._train_arange
                 else:
-                    loss = SoftmaxNLL.apply(z, b.train_idx, self._y_train, scale)
+                    rows = b.train_idx
+                if self.lean and not self.dist:   # the loss's own gradient handed to backward (no ones-fill, no multiplication by it)
+                    from .ops import softmax_nll_raw
+                    loss1, dz = softmax_nll_raw(z, rows, self._y_train, scale)
+                    self.local_loss = loss1[0]
+                    z.backward(dz)
+                    self.opt.step()
+                    return loss1[0]
+                loss = SoftmaxNLL.apply(z, rows, self._y_train, scale)
             return self._backward_and_step(loss)
         if self.fused_logits:
             from .ops import SoftmaxNLL
