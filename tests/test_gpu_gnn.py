@@ -1583,6 +1583,26 @@ def test_appnp_takes_the_table_rows_and_hands_the_padded_signal_to_the_loss(mods
     assert float(loss[0]) == pytest.approx(float(want), rel=1e-4)
 
 
+def test_csr_row_sum_with_eight_lanes_per_row(mods):
+    """fitgnn_csr_row_sum_f32 (GAT's d a_src on the transposed edge order): rows of 0, 1, 7, 8, 9, 16, 17, 300 and 5 000 entries, a
+    row count that is not a multiple of eight == float64 sums (<= 1e-6 relative), and the same bits on a second call."""
+    L = _lib_mod().lib()
+    dp = _lib_mod().dptr
+    rng = np.random.default_rng(4)
+    lens = np.array([0, 1, 7, 8, 9, 16, 17, 300, 0, 5000, 3, 2, 4] + list(rng.integers(0, 40, size=1000)), dtype=np.int64)
+    rowptr = torch.from_numpy(np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)).cuda()
+    v = torch.randn(int(lens.sum()), device="cuda")
+    n = len(lens)
+    y = torch.full((n,), float("nan"), device="cuda")
+    st = _lib_mod().stream_ptr(v.device)
+    assert L.fitgnn_csr_row_sum_f32(dp(rowptr), dp(v), n, dp(y), st) == 0
+    want = torch.zeros(n, dtype=torch.float64, device="cuda").index_add_(0, torch.repeat_interleave(torch.arange(n, device="cuda"), torch.from_numpy(lens).cuda()), v.double())
+    assert not torch.isnan(y).any()
+    assert float((y.double() - want).abs().max()) <= 1e-6 * float(want.abs().max() + 1)
+    y2 = torch.empty_like(y)
+    assert L.fitgnn_csr_row_sum_f32(dp(rowptr), dp(v), n, dp(y2), st) == 0 and torch.equal(y, y2)
+
+
 def test_appnp_few_large_subgraphs_stay_on_the_per_step_kernel(mods):
     """Fewer blocks than AppnpPlan.MIN_BLOCKS: no workgroup-per-block launch (it would leave most of the chip idle)."""
     from fitgnn_amd import csr, ops
