@@ -1941,7 +1941,7 @@ class GATAggregate(torch.autograd.Function):
             da = torch.stack([da_src, da_dst], dim=1)                              # [rows, 2]
             if ridx is not None:   # every node's copies summed: the table's gradient and its two score gradients
                 dh = segment_sum(ridx.seg_off, ridx.members, dh, ridx.n_table)
-                da = torch.zeros((ridx.n_table, 2), dtype=torch.float32, device=dev).index_add_(0, ridx.index.long(), da)
+                da = segment_sum(ridx.seg_off, ridx.members, da, ridx.n_table)   # (fixed order; index_add_'s atomics are not)
             # dh += da_src (x) att_src + da_dst (x) att_dst: one rank-2 pass over dh
             dh.addmm_(da, torch.stack([att_src, att_dst], dim=0))
         # d(att) = h^T da: both vectors in ONE tall-skinny product through the split-K path (two rocBLAS gemv calls on
