@@ -416,9 +416,24 @@ def mm_at_b(a, b, cfg=DEFAULT, out=None):
     part = torch.bmm(a[:main].view(B, Kc, a.shape[1]).transpose(1, 2), b[:main].view(B, Kc, b.shape[1]))
     W = part.shape[1] * part.shape[2]
     if part.is_cuda and W % 4 == 0:
-        out = torch.empty(part.shape[1:], dtype=torch.float32, device=part.device)
-        _lib.check(_lib.lib().fitgnn_sum_leading_f32(_lib.dptr(part), B, W, _lib.dptr(out), _lib.stream_ptr(part.device)),
-                   "fitgnn_sum_leading_f32")
+        L = _lib.lib()
+        st = _lib.stream_ptr(part.device)
+        # many partials of a narrow product (GAT's h^T [da_src da_dst] at S-products: 5 856 partials of 1 024 floats) would be ONE
+        # workgroup walking them all (765 us): fold them in two fixed-order stages -- viewed as [B / G, G x W] the same kernel sums
+        # every G-th partial in G x W / 1 024 workgroups, then the G sums (and the B % G left-over partials)
+        G = 64
+        if B >= 8 * G and W <= 16384:
+            Bg = B // G
+            flat = part.view(B, W)
+            stage = torch.empty((G + B - Bg * G, W), dtype=torch.float32, device=part.device)
+            _lib.check(L.fitgnn_sum_leading_f32(_lib.dptr(flat), Bg, G * W, _lib.dptr(stage), st), "fitgnn_sum_leading_f32")
+            if B > Bg * G:
+                stage[G:].copy_(flat[Bg * G:])
+            part, B = stage, int(stage.shape[0])
+            out = torch.empty((a.shape[1], b.shape[1]), dtype=torch.float32, device=part.device)
+        else:
+            out = torch.empty(part.shape[1:], dtype=torch.float32, device=part.device)
+        _lib.check(L.fitgnn_sum_leading_f32(_lib.dptr(part), B, W, _lib.dptr(out), st), "fitgnn_sum_leading_f32")
     else:
         out = part.sum(0)
     if main < R:

@@ -321,6 +321,21 @@ def test_backward_spmm_with_the_previous_layers_epilogue_in_its_store(mods, H, u
         assert none is None and torch.equal(got2, want2)
 
 
+def test_many_narrow_partials_are_folded_in_two_stages(mods):
+    """mm_at_b on a very tall pair with a two-column operand (GAT's h^T [da_src da_dst]): thousands of batched partial products of a
+    few hundred floats, summed by fitgnn_sum_leading_f32 in two fixed-order stages (one workgroup walking all of them took 765 us
+    at S-products) == the float64 product, the same bits twice, with and without a remainder of partials / rows."""
+    _lib, csr, ops, orc, gorc = mods
+    for R in (1408 * 640, 1408 * 700 + 77, 1408 * 513 + 1407):
+        torch.manual_seed(R % 1000)
+        a, b = torch.randn(R, 64).cuda(), torch.randn(R, 2).cuda()
+        got = ops.mm_at_b(a, b)
+        ref = (a.double().t() @ b.double())
+        assert got.shape == (64, 2)
+        assert float((got.double() - ref).abs().max() / ref.abs().max()) < 1e-5
+        assert torch.equal(got, ops.mm_at_b(a, b))
+
+
 def test_tiles_only_column_sum_partials_need_no_zero_fill(mods, monkeypatch):
     """spmm_graph_dz on a graph without whole-subgraph blocks hands its kernels an UNINITIALISED partial buffer (one launch less in a
     launch-bound batch step): with that buffer poisoned with NaN (FITGNN_POISON's switch) db is finite and the zero-filled path's, for
