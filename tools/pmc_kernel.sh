@@ -10,7 +10,7 @@ cd /tmp && export TMPDIR=/tmp
 i=0
 for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES" "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" "SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA" "GRBM_GUI_ACTIVE SQ_INSTS_BRANCH SQ_INSTS_SENDMSG"; do
   i=$((i+1))
-  rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT/p$i -o run -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-bf16x3 --no-all-rows "$@" > $OUT/p$i.json 2> $OUT/p$i.err || echo "set $i failed"
+  rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT/p$i -o run -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --gpu-warm-seconds 0 --no-bf16x3 --no-all-rows "$@" > $OUT/p$i.json 2> $OUT/p$i.err || echo "set $i failed"
   python3 - "$OUT/p$i" "$kern" <<'PY' >> $OUT/summary.txt
 import csv, glob, sys, collections
 d, kern = sys.argv[1], sys.argv[2]

@@ -8,6 +8,6 @@ OUT=$R/gpurun_out/$tag
 mkdir -p $OUT
 python3 $R/bench.py --layer $layer --workload $wl "$@" > $OUT/bench_${layer}_${wl}.json 2> $OUT/bench_${layer}_${wl}.err
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_${layer}_${wl} -o run -- python3 $R/bench.py --layer $layer --workload $wl --steps 10 --warmup 3 --no-cpu-baseline "$@" > $OUT/rocprof_${layer}_${wl}.json 2> $OUT/rocprof_${layer}_${wl}.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_${layer}_${wl} -o run -- python3 $R/bench.py --layer $layer --workload $wl --steps 10 --warmup 3 --no-cpu-baseline --gpu-warm-seconds 0 "$@" > $OUT/rocprof_${layer}_${wl}.json 2> $OUT/rocprof_${layer}_${wl}.err
 rm -f $OUT/stats_${layer}_${wl}/run_kernel_trace.csv
 echo "$layer $wl done"

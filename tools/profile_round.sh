@@ -8,11 +8,11 @@ R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/$tag
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o run -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-bf16x3 --no-all-rows "$@" > $OUT/bench_under_rocprof.json 2> $OUT/rocprof_stats.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o run -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --gpu-warm-seconds 0 --no-bf16x3 --no-all-rows "$@" > $OUT/bench_under_rocprof.json 2> $OUT/rocprof_stats.err
 echo "stats done"
 for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
   n=$(echo $set | cut -c1-8 | tr ' ' '_')
-  rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT/pmc_$n -o run -- python3 $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-bf16x3 --no-all-rows "$@" > $OUT/pmc_$n.json 2> $OUT/pmc_$n.err
+  rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT/pmc_$n -o run -- python3 $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --gpu-warm-seconds 0 --no-bf16x3 --no-all-rows "$@" > $OUT/pmc_$n.json 2> $OUT/pmc_$n.err
   echo "pmc $n done"
 done
 python3 $R/tools/summarize_pmc.py $OUT > $OUT/pmc_summary.json
